@@ -1,0 +1,418 @@
+"""Synthetic polyMesh + case generators (INPUT DATA for both the HIP path and the oracle).
+
+The reference reads an OpenFOAM case directory (constant/polyMesh + 0/ fields); its
+regression meshes (ConvergentChannel, NACA0012, pitzDaily...) are downloaded at
+test time (reference tests/Allrun:8-18) and are not available here.  These
+generators emit the *same data model* (points / faces / owner / neighbour /
+patch table in OpenFOAM ordering) for hex blocks that are then treated as fully
+unstructured by everything downstream.
+
+Face ordering follows OpenFOAM's polyMesh contract: internal faces first in
+upper-triangular order (by owner, then by neighbour), then boundary faces
+patch by patch; every face normal points from owner to neighbour (or out of
+the domain).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+# boundary-condition type codes shared with the C-ABI (include/dafoam_amd.h)
+BC_FIXED_VALUE = 0
+BC_ZERO_GRADIENT = 1
+BC_INLET_OUTLET = 2
+BC_SYMMETRY = 3
+# nut wall treatment codes
+NUT_CALCULATED = 0
+NUT_LOWRE_WALL = 1  # nut_w = 0 (nutLowReWallFunction, reference DAField.C:1155-1218)
+NUT_SPALDING_WALL = 2  # nutUSpaldingWallFunction (reference DAMisc/nutUSpaldingWallFunctionDF)
+NUT_SYMMETRY = 3
+
+
+@dataclass
+class Patch:
+    name: str
+    type: str  # "patch" | "wall" | "symmetry"
+    start: int
+    size: int
+
+
+@dataclass
+class PolyMesh:
+    points: np.ndarray  # (P,3) float64
+    face_ptr: np.ndarray  # (F+1,) int32 CSR into face_pts
+    face_pts: np.ndarray  # int32 point ids
+    owner: np.ndarray  # (F,) int32
+    neighbour: np.ndarray  # (Fi,) int32
+    patches: List[Patch]
+
+    @property
+    def n_cells(self) -> int:
+        return int(self.owner.max()) + 1 if self.owner.size else 0
+
+    @property
+    def n_faces(self) -> int:
+        return int(self.owner.size)
+
+    @property
+    def n_internal_faces(self) -> int:
+        return int(self.neighbour.size)
+
+    @property
+    def n_points(self) -> int:
+        return int(self.points.shape[0])
+
+
+@dataclass
+class FoamCase:
+    """Everything the reference would read from the case directory for the hot path."""
+
+    mesh: PolyMesh
+    solver_name: str  # "DASimpleFoam" | "DAScalarTransportFoam"
+    nu: float = 1.5e-5
+    # per patch name -> {field: (bc_code, value)}; value scalar or 3-vector
+    bcs: Dict[str, Dict[str, tuple]] = field(default_factory=dict)
+    relax: Dict[str, float] = field(default_factory=lambda: {"U": 0.7, "nuTilda": 0.7, "T": 1.0})
+    y_wall: Optional[np.ndarray] = None  # frozen wall distance (reference DASpalartAllmaras.C:94)
+    states: Optional[np.ndarray] = None  # W in DAIndex "state" ordering
+    # scalar transport extras
+    DT: float = 0.01
+    deltaT: float = 1.0
+    phi: Optional[np.ndarray] = None  # frozen face flux (ScalarTransport)
+    T_old: Optional[np.ndarray] = None
+
+
+def hex_block(
+    nx: int,
+    ny: int,
+    nz: int,
+    lengths=(1.0, 1.0, 1.0),
+    mapping: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+    patch_names=("inlet", "outlet", "bottom", "top", "front", "back"),
+    patch_types=("patch", "patch", "wall", "wall", "symmetry", "symmetry"),
+    grading_y: float = 1.0,
+) -> PolyMesh:
+    """Structured nx*ny*nz hex block emitted as an unstructured polyMesh.
+
+    mapping: optional function on the (P,3) unit-box point array (after scaling)
+    used to bend/skew the block (creates non-orthogonality).
+    grading_y: two-sided geometric clustering towards y=0 and y=Ly (ratio of
+    centre/wall cell size).
+    """
+    Lx, Ly, Lz = lengths
+    xs = np.linspace(0.0, Lx, nx + 1)
+    if grading_y != 1.0:
+        t = np.linspace(-1.0, 1.0, ny + 1)
+        beta = np.log(grading_y)
+        ys = 0.5 * Ly * (1.0 + np.tanh(beta * t) / np.tanh(beta))
+    else:
+        ys = np.linspace(0.0, Ly, ny + 1)
+    zs = np.linspace(0.0, Lz, nz + 1)
+    Z, Y, X = np.meshgrid(zs, ys, xs, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    if mapping is not None:
+        pts = np.ascontiguousarray(mapping(pts))
+
+    def pid(i, j, k):
+        return i + (nx + 1) * (j + (ny + 1) * k)
+
+    def cid(i, j, k):
+        return i + nx * (j + ny * k)
+
+    I, J, K = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    # cell-major order: cell index increasing -> iterate k, j, i
+    order = np.argsort(cid(I, J, K).ravel())
+    I, J, K = I.ravel()[order], J.ravel()[order], K.ravel()[order]
+    c = cid(I, J, K)
+
+    faces = []
+    own = []
+    nei = []
+    # per cell, faces to +x, +y, +z neighbours (ascending neighbour id) -> upper-triangular order
+    # build per-direction then interleave by (owner, neighbour) sort
+    fx_mask = I < nx - 1
+    fy_mask = J < ny - 1
+    fz_mask = K < nz - 1
+
+    def quad_x(i, j, k):  # face at x = i (normal +x)
+        return np.stack([pid(i, j, k), pid(i, j + 1, k), pid(i, j + 1, k + 1), pid(i, j, k + 1)], axis=1)
+
+    def quad_y(i, j, k):  # face at y = j (normal +y)
+        return np.stack([pid(i, j, k), pid(i, j, k + 1), pid(i + 1, j, k + 1), pid(i + 1, j, k)], axis=1)
+
+    def quad_z(i, j, k):  # face at z = k (normal +z)
+        return np.stack([pid(i, j, k), pid(i + 1, j, k), pid(i + 1, j + 1, k), pid(i, j + 1, k)], axis=1)
+
+    fo = np.concatenate([c[fx_mask], c[fy_mask], c[fz_mask]])
+    fn = np.concatenate([c[fx_mask] + 1, c[fy_mask] + nx, c[fz_mask] + nx * ny])
+    fq = np.concatenate(
+        [
+            quad_x(I[fx_mask] + 1, J[fx_mask], K[fx_mask]),
+            quad_y(I[fy_mask], J[fy_mask] + 1, K[fy_mask]),
+            quad_z(I[fz_mask], J[fz_mask], K[fz_mask] + 1),
+        ]
+    )
+    o = np.lexsort((fn, fo))
+    own.append(fo[o])
+    nei.append(fn[o])
+    faces.append(fq[o])
+    n_int = fo.size
+
+    patches: List[Patch] = []
+    start = n_int
+
+    def add_patch(idx, quads, cells):
+        nonlocal start
+        faces.append(quads)
+        own.append(cells)
+        patches.append(Patch(patch_names[idx], patch_types[idx], start, len(cells)))
+        start += len(cells)
+
+    JJ, KK = np.meshgrid(np.arange(ny), np.arange(nz), indexing="ij")
+    JJ, KK = JJ.ravel(), KK.ravel()
+    o = np.argsort(cid(0, JJ, KK))
+    # x- : outward normal -x -> reverse winding of quad_x
+    add_patch(0, quad_x(np.zeros_like(JJ), JJ, KK)[o][:, ::-1], cid(0, JJ, KK)[o])
+    o = np.argsort(cid(nx - 1, JJ, KK))
+    add_patch(1, quad_x(np.full_like(JJ, nx), JJ, KK)[o], cid(nx - 1, JJ, KK)[o])
+    II, KK = np.meshgrid(np.arange(nx), np.arange(nz), indexing="ij")
+    II, KK = II.ravel(), KK.ravel()
+    o = np.argsort(cid(II, 0, KK))
+    add_patch(2, quad_y(II, np.zeros_like(II), KK)[o][:, ::-1], cid(II, 0, KK)[o])
+    o = np.argsort(cid(II, ny - 1, KK))
+    add_patch(3, quad_y(II, np.full_like(II, ny), KK)[o], cid(II, ny - 1, KK)[o])
+    II, JJ = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    II, JJ = II.ravel(), JJ.ravel()
+    o = np.argsort(cid(II, JJ, 0))
+    add_patch(4, quad_z(II, JJ, np.zeros_like(II))[o][:, ::-1], cid(II, JJ, 0)[o])
+    o = np.argsort(cid(II, JJ, nz - 1))
+    add_patch(5, quad_z(II, JJ, np.full_like(II, nz))[o], cid(II, JJ, nz - 1)[o])
+
+    fq = np.concatenate(faces).astype(np.int32)
+    F = fq.shape[0]
+    return PolyMesh(
+        points=pts.astype(np.float64),
+        face_ptr=(4 * np.arange(F + 1)).astype(np.int32),
+        face_pts=np.ascontiguousarray(fq.ravel()),
+        owner=np.concatenate(own).astype(np.int32),
+        neighbour=np.concatenate(nei).astype(np.int32),
+        patches=patches,
+    )
+
+
+def bump_mapping(height: float = 0.1, skew: float = 0.15, Lx: float = 1.0, Ly: float = 1.0):
+    """Convergent-channel-like bump on the bottom wall plus a sinusoidal interior skew
+    (gives non-orthogonal, non-uniform hexes like the reference's ConvergentChannel)."""
+
+    def f(p):
+        q = p.copy()
+        x, y, z = p[:, 0] / Lx, p[:, 1] / Ly, p[:, 2]
+        bump = height * Ly * np.sin(np.pi * x) ** 2
+        q[:, 1] = p[:, 1] + bump * (1.0 - y)
+        q[:, 0] = p[:, 0] + skew * Lx / 8.0 * np.sin(np.pi * y) * np.sin(2 * np.pi * x)
+        q[:, 2] = z * (1.0 + 0.05 * np.sin(np.pi * x) * np.sin(np.pi * y))
+        return q
+
+    return f
+
+
+class _InputGeometry:
+    """Face/cell geometry used ONLY to build consistent synthetic input fields (phi from
+    U, wall distance).  The product's geometry lives in csrc/mesh_geom.cpp; the oracle's
+    in oracle/foam_mesh.py - neither is imported here."""
+
+    def __init__(self, mesh: PolyMesh):
+        F = mesh.n_faces
+        nv = np.diff(mesh.face_ptr)
+        assert np.all(nv == nv[0]), "input generator handles uniform polygons"
+        k = int(nv[0])
+        P = mesh.points[mesh.face_pts.reshape(F, k)]  # (F,k,3)
+        fc = P.mean(axis=1)
+        Pn = np.roll(P, -1, axis=1)
+        n = np.cross(Pn - P, fc[:, None, :] - P)  # (F,k,3)
+        a = np.linalg.norm(n, axis=2)
+        c = P + Pn + fc[:, None, :]
+        self.Sf = 0.5 * n.sum(axis=1)
+        self.Cf = (a[:, :, None] * c).sum(axis=1) / (3.0 * a.sum(axis=1)[:, None])
+        N = mesh.n_cells
+        nIF = mesh.n_internal_faces
+        own, nei = mesh.owner, mesh.neighbour
+        cnt = np.bincount(own, minlength=N) + np.bincount(nei, minlength=N)
+        cE = np.zeros((N, 3))
+        for d in range(3):
+            cE[:, d] = (np.bincount(own, self.Cf[:, d], N) + np.bincount(nei, self.Cf[:nIF, d], N)) / cnt
+        pv_o = np.einsum("ij,ij->i", self.Sf, self.Cf - cE[own])
+        pv_n = np.einsum("ij,ij->i", self.Sf[:nIF], cE[nei] - self.Cf[:nIF])
+        pc_o = 0.75 * self.Cf + 0.25 * cE[own]
+        pc_n = 0.75 * self.Cf[:nIF] + 0.25 * cE[nei]
+        V3 = np.bincount(own, pv_o, N) + np.bincount(nei, pv_n, N)
+        self.C = np.zeros((N, 3))
+        for d in range(3):
+            self.C[:, d] = (np.bincount(own, pv_o * pc_o[:, d], N) + np.bincount(nei, pv_n * pc_n[:, d], N)) / V3
+        self.V = V3 / 3.0
+        so = np.abs(np.einsum("ij,ij->i", self.Sf[:nIF], self.Cf[:nIF] - self.C[own[:nIF]]))
+        sn = np.abs(np.einsum("ij,ij->i", self.Sf[:nIF], self.C[nei] - self.Cf[:nIF]))
+        self.w = sn / (so + sn)
+
+
+def wall_distance(mesh: PolyMesh, cell_centres, face_centres, face_areas) -> np.ndarray:
+    """Frozen wall distance y (reference: yWall from meshWaveFrozen, DASolver.C:4433-4482).
+
+    Input data, not hot path: nearest wall-face centre, distance projected on that face's
+    normal (exact for flat walls), floored at 1e-12.
+    """
+    from scipy.spatial import cKDTree
+
+    idx = []
+    for p in mesh.patches:
+        if p.type == "wall":
+            idx.append(np.arange(p.start, p.start + p.size))
+    if not idx:
+        return np.full(mesh.n_cells, 1.0)
+    idx = np.concatenate(idx)
+    tree = cKDTree(face_centres[idx])
+    _, nn = tree.query(cell_centres)
+    f = idx[nn]
+    n = face_areas[f] / np.linalg.norm(face_areas[f], axis=1)[:, None]
+    d = np.abs(np.einsum("ij,ij->i", cell_centres - face_centres[f], n))
+    return np.maximum(d, 1e-12)
+
+
+def n_states(case: FoamCase) -> int:
+    m = case.mesh
+    if case.solver_name == "DAScalarTransportFoam":
+        return m.n_cells
+    if case.solver_name == "DASimpleFoam":
+        return 5 * m.n_cells + m.n_faces
+    raise ValueError(case.solver_name)
+
+
+def channel_case(
+    nx=7,
+    ny=7,
+    nz=7,
+    lengths=(1.0, 0.2, 0.1),
+    U0=10.0,
+    nu=1.5e-5,
+    nuTilda0=4.5e-5,
+    bump=0.1,
+    skew=0.15,
+    grading_y=1.0,
+    wall_function=False,
+    side_walls=False,
+    seed=0,
+    perturb=0.02,
+) -> FoamCase:
+    """DASimpleFoam + SA channel (7x7x7 = 343 cells mirrors the reference's
+    ConvergentChannel size, tests/runRegTests_DASimpleFoamForward.py:32; U0/nu/nuTilda0
+    are the values of tests/runRegTests_AeroOpt.py:29-48).  The state is a smooth
+    synthetic flow (not a converged primal - the primal solver is upstream of the hot
+    path) with a seeded perturbation so that no term degenerates."""
+    types = ("patch", "patch", "wall", "wall") + (("wall", "wall") if side_walls else ("symmetry", "symmetry"))
+    mesh = hex_block(
+        nx, ny, nz, lengths, bump_mapping(bump, skew, lengths[0], lengths[1]), patch_types=types, grading_y=grading_y
+    )
+    g = _InputGeometry(mesh)
+    wall_nut = NUT_SPALDING_WALL if wall_function else NUT_LOWRE_WALL
+    bcs = {
+        "inlet": {
+            "U": (BC_FIXED_VALUE, (U0, 0.0, 0.0)),
+            "p": (BC_ZERO_GRADIENT, 0.0),
+            "nuTilda": (BC_FIXED_VALUE, nuTilda0),
+            "nut": (NUT_CALCULATED, 0.0),
+        },
+        "outlet": {
+            "U": (BC_INLET_OUTLET, (0.0, 0.0, 0.0)),
+            "p": (BC_FIXED_VALUE, 0.0),
+            "nuTilda": (BC_INLET_OUTLET, nuTilda0),
+            "nut": (NUT_CALCULATED, 0.0),
+        },
+    }
+    for nm, tp in zip(("bottom", "top", "front", "back"), types[2:]):
+        if tp == "wall":
+            bcs[nm] = {
+                "U": (BC_FIXED_VALUE, (0.0, 0.0, 0.0)),
+                "p": (BC_ZERO_GRADIENT, 0.0),
+                "nuTilda": (BC_FIXED_VALUE, 0.0),
+                "nut": (wall_nut, 0.0),
+            }
+        else:
+            bcs[nm] = {
+                "U": (BC_SYMMETRY, (0.0, 0.0, 0.0)),
+                "p": (BC_SYMMETRY, 0.0),
+                "nuTilda": (BC_SYMMETRY, 0.0),
+                "nut": (NUT_SYMMETRY, 0.0),
+            }
+    y = wall_distance(mesh, g.C, g.Cf, g.Sf)
+    case = FoamCase(mesh=mesh, solver_name="DASimpleFoam", nu=nu, bcs=bcs, y_wall=y)
+    # smooth synthetic state: turbulent-like profile in wall distance + perturbation
+    rng = np.random.default_rng(seed)
+    N, F = mesh.n_cells, mesh.n_faces
+    H = lengths[1]
+    eta = np.clip(y / (0.5 * H), 0.0, 1.0)
+    prof = eta ** (1.0 / 7.0)
+    xh = g.C[:, 0] / lengths[0]
+    U = np.zeros((N, 3))
+    U[:, 0] = U0 * prof * (1.0 + 0.3 * np.sin(np.pi * xh) ** 2)
+    U[:, 1] = 0.05 * U0 * prof * np.sin(2 * np.pi * xh + 0.3)
+    U[:, 2] = 0.03 * U0 * prof * (0.3 + np.sin(np.pi * xh) * (g.C[:, 2] / lengths[2] - 0.3))
+    U *= 1.0 + perturb * rng.standard_normal((N, 1))
+    p = 0.5 * U0 * U0 * 0.2 * (1.0 - xh) * (1.0 + perturb * rng.standard_normal(N))
+    nuT = nuTilda0 * (1.0 + 20.0 * eta * (1.0 - 0.5 * eta)) * (1.0 + perturb * rng.standard_normal(N))
+    # face flux: linear interpolate of U dotted with Sf, boundary from BC-like values
+    nIF = mesh.n_internal_faces
+    own, nei = mesh.owner, mesh.neighbour
+    Uf = g.w[:, None] * U[own[:nIF]] + (1 - g.w[:, None]) * U[nei]
+    phi = np.zeros(F)
+    phi[:nIF] = np.einsum("ij,ij->i", Uf, g.Sf[:nIF])
+    for pt in mesh.patches:
+        sl = slice(pt.start, pt.start + pt.size)
+        if pt.name == "inlet":
+            phi[sl] = U0 * g.Sf[sl, 0]
+        elif pt.name == "outlet":
+            phi[sl] = np.einsum("ij,ij->i", U[own[sl]], g.Sf[sl])
+        else:
+            phi[sl] = 0.0
+    phi[:nIF] *= 1.0 + perturb * rng.standard_normal(nIF)
+    case.states = np.concatenate([U.ravel(), p, nuT, phi])
+    return case
+
+
+def scalar_transport_case(nx=18, ny=17, nz=16, lengths=(1.0, 0.5, 0.5), DT=0.01, deltaT=0.05, seed=0) -> FoamCase:
+    """DAScalarTransportFoam box (BASELINE.json configs[0]: 18x17x16 = 4896 cells).
+    phi from uniform U=(1,0,0); T = smooth blob advected 'a few steps' (T_old shifted)."""
+    mesh = hex_block(
+        nx, ny, nz, lengths, bump_mapping(0.05, 0.1, lengths[0], lengths[1]),
+        patch_types=("patch", "patch", "wall", "wall", "wall", "wall"),
+    )
+    g = _InputGeometry(mesh)
+    bcs = {
+        "inlet": {"T": (BC_FIXED_VALUE, 1.0)},
+        "outlet": {"T": (BC_ZERO_GRADIENT, 0.0)},
+    }
+    for nm in ("bottom", "top", "front", "back"):
+        bcs[nm] = {"T": (BC_ZERO_GRADIENT, 0.0)}
+    case = FoamCase(mesh=mesh, solver_name="DAScalarTransportFoam", bcs=bcs, DT=DT, deltaT=deltaT)
+    rng = np.random.default_rng(seed)
+    nIF = mesh.n_internal_faces
+    Uc = np.zeros((mesh.n_cells, 3))
+    Uc[:, 0] = 1.0
+    Uc[:, 1] = 0.2 * np.sin(2 * np.pi * g.C[:, 0] / lengths[0])
+    own, nei = mesh.owner, mesh.neighbour
+    Uf = np.zeros((mesh.n_faces, 3))
+    Uf[:nIF] = g.w[:, None] * Uc[own[:nIF]] + (1 - g.w[:, None]) * Uc[nei]
+    Uf[nIF:] = Uc[own[nIF:]]
+    phi = np.einsum("ij,ij->i", Uf, g.Sf)
+    for pt in mesh.patches:
+        if pt.type == "wall":
+            phi[pt.start : pt.start + pt.size] = 0.0
+    x = g.C / np.array(lengths)
+    T = np.exp(-20 * ((x[:, 0] - 0.4) ** 2 + (x[:, 1] - 0.5) ** 2 + (x[:, 2] - 0.5) ** 2))
+    T_old = np.exp(-20 * ((x[:, 0] - 0.35) ** 2 + (x[:, 1] - 0.5) ** 2 + (x[:, 2] - 0.5) ** 2))
+    T *= 1.0 + 0.01 * rng.standard_normal(T.size)
+    case.phi = phi
+    case.T_old = T_old
+    case.states = T.copy()
+    return case

@@ -1,0 +1,508 @@
+"""ORACLE (test infrastructure only - never imported by the product path).
+
+CPU (numpy) restatement of the reference's residual functions R(W):
+
+  * DAResidualSimpleFoam::calcResiduals      reference src/adjoint/DAResidual/DAResidualSimpleFoam.C:106-237
+  * DASpalartAllmaras::calcResiduals/correctNut  reference src/adjoint/DAModel/DATurbulenceModel/DASpalartAllmaras.C:124-178,215-233,407-488
+  * DATurbulenceModel::divDevRhoReff/nuEff    reference src/adjoint/DAModel/DATurbulenceModel/DATurbulenceModel.C:212-223,378-408
+  * nutUSpaldingWallFunction (calcNut/calcUTau) reference src/adjoint/DAMisc/nutUSpaldingWallFunctionDF/...DF.C:42-150
+  * DAResidualScalarTransportFoam::calcResiduals reference src/adjoint/DAResidual/DAResidualScalarTransportFoam.C:57-84
+  * residual scaling macros                   reference src/include/DAMacroFunctions.H:28-51
+  * DAResidual::masterFunction (W -> fields -> BCs -> intermediates -> R) reference src/adjoint/DAResidual/DAResidual.C:100-171
+  * state/residual vector layout              reference src/adjoint/DAIndex/DAIndex.C:188-397,518-661 ("state" ordering)
+
+The reference writes these with OpenFOAM operators (fvm::div, fvm::laplacian, fvc::grad,
+fvMatrix::A/H/flux/operator&/relax, constrainHbyA, BC classes) whose source is NOT under
+/root/reference (un-vendored OpenFOAM-AD v2506).  Their published algorithms are restated
+here for the canonical scheme set ("Canonical discretisation"):
+    grad: Gauss linear; div(phi,U): bounded Gauss linearUpwindV grad(U);
+    div(phi,nuTilda), div(pc): bounded Gauss upwind; laplacian: Gauss linear corrected;
+    interpolation: linear; snGrad: corrected; div((nuEff*dev2(T(grad(U))))): Gauss linear.
+
+PARITY UNPINNED: no golden vector of the reference can be evaluated in
+this container (meshes not vendored, reference not buildable).  What pins this file instead:
+algebraic identities in tests/ (complex-step == finite differences, dot-product test,
+brute-force Jacobian == coloured Jacobian, manufactured solutions).
+
+All functions are dtype-generic: running them on complex128 states gives exact directional
+derivatives by the complex-step method (the oracle's stand-in for the reference's CoDiPack
+reverse-mode AD, DASolver.C:1364-1441); branches use real parts.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from dafoam_amd.meshgen import (
+    BC_FIXED_VALUE,
+    BC_INLET_OUTLET,
+    BC_SYMMETRY,
+    BC_ZERO_GRADIENT,
+    NUT_CALCULATED,
+    NUT_LOWRE_WALL,
+    NUT_SPALDING_WALL,
+    NUT_SYMMETRY,
+)
+
+VSMALL = 1e-300
+SMALL = 1e-15
+ROOTVSMALL = 1e-150
+
+# Spalart-Allmaras constants, reference DASpalartAllmaras.C:47-80
+SA = dict(sigmaNut=0.66666, kappa=0.41, Cb1=0.1355, Cb2=0.622, Cw2=0.3, Cw3=2.0, Cv1=7.1, Cs=0.3)
+SA["Cw1"] = SA["Cb1"] / SA["kappa"] ** 2 + (1.0 + SA["Cb2"]) / SA["sigmaNut"]
+# nutUSpaldingWallFunction defaults (OpenFOAM nutWallFunction: kappa 0.41, E 9.8; maxIter 10)
+WF = dict(kappa=0.41, E=9.8, maxIter=10, tol=1e-14)
+
+
+# ----------------------------------------------------------------------------- helpers
+def _abs(x):
+    return np.where(np.real(x) >= 0, x, -x)
+
+
+def _max(a, b):
+    return np.where(np.real(a) >= np.real(b), a, b)
+
+
+def _min(a, b):
+    return np.where(np.real(a) <= np.real(b), a, b)
+
+
+def sadd(idx, vals, n):
+    """scatter-add vals (m,) or (m,k) into n rows; complex safe."""
+    vals = np.asarray(vals)
+    if vals.ndim == 1:
+        if np.iscomplexobj(vals):
+            return np.bincount(idx, vals.real, n) + 1j * np.bincount(idx, vals.imag, n)
+        return np.bincount(idx, vals, n)
+    out = np.zeros((n,) + vals.shape[1:], dtype=vals.dtype)
+    flat = vals.reshape(vals.shape[0], -1)
+    o2 = out.reshape(n, -1)
+    for k in range(flat.shape[1]):
+        o2[:, k] = sadd(idx, flat[:, k], n)
+    return out
+
+
+class BCTable:
+    """Per-boundary-face BC codes/values expanded from the case's per-patch table."""
+
+    def __init__(self, case, g, fields):
+        self.code = {}
+        self.val = {}
+        nBF = g.nBF
+        sl = g.patch_slices()
+        for f in fields:
+            vec = f == "U"
+            self.code[f] = np.zeros(nBF, np.int32)
+            self.val[f] = np.zeros((nBF, 3)) if vec else np.zeros(nBF)
+            for p in case.mesh.patches:
+                code, v = case.bcs[p.name][f]
+                self.code[f][sl[p.name]] = code
+                self.val[f][sl[p.name]] = v
+
+
+def bc_scalar(code, val, xc, delta, phib):
+    """value/gradient coefficients of a scalar patch field (OpenFOAM fvPatchField contract):
+    x_b = vic*x_c + vbc ; snGrad_b = gic*x_c + gbc.  fixedValue / zeroGradient / inletOutlet
+    (mixed, valueFraction = 1 - pos0(phi)) / symmetry (scalar: zero gradient)."""
+    dt = xc.dtype
+    one = np.ones_like(xc)
+    f = np.zeros(code.shape)
+    f[code == BC_FIXED_VALUE] = 1.0
+    io = code == BC_INLET_OUTLET
+    f[io] = 1.0 - (np.real(phib[io]) >= 0)
+    vic = (1.0 - f) * one
+    vbc = (f * val).astype(dt)
+    gic = (-f * delta) * one
+    gbc = (f * delta * val).astype(dt)
+    xb = vic * xc + vbc
+    return xb, vic, vbc, gic, gbc
+
+
+def bc_vector(code, val, Xc, delta, phib, n):
+    """Vector patch field coefficients (component-wise).  symmetry follows
+    basicSymmetryFvPatchField/transformFvPatchField: x_b = X_c - n (n.X_c),
+    snGrad = -n (n.X_c) delta, snGradTransformDiag = |n| component-wise."""
+    dt = Xc.dtype
+    f = np.zeros(code.shape)
+    f[code == BC_FIXED_VALUE] = 1.0
+    io = code == BC_INLET_OUTLET
+    f[io] = 1.0 - (np.real(phib[io]) >= 0)
+    f3 = f[:, None]
+    vic = (1.0 - f3) * np.ones_like(Xc)
+    vbc = (f3 * val).astype(dt)
+    gic = (-f3 * delta[:, None]) * np.ones_like(Xc)
+    gbc = (f3 * delta[:, None] * val).astype(dt)
+    sym = code == BC_SYMMETRY
+    if sym.any():
+        ns = n[sym]
+        Xs = Xc[sym]
+        nX = (ns * Xs).sum(1)[:, None]
+        xb = Xs - ns * nX
+        sd = np.abs(ns)
+        vics = 1.0 - sd
+        vic[sym] = vics
+        vbc[sym] = xb - vics * Xs
+        sng = -ns * nX * delta[sym][:, None]
+        gics = -delta[sym][:, None] * sd
+        gic[sym] = gics
+        gbc[sym] = sng - gics * Xs
+    Xb = vic * Xc + vbc
+    return Xb, vic, vbc, gic, gbc
+
+
+def fv1_of(chi):
+    chi3 = chi**3
+    return chi3 / (chi3 + SA["Cv1"] ** 3)
+
+
+def spalding_nut(magUp, magGradU, y, nu):
+    """nutUSpaldingWallFunction calcNut/calcUTau (reference ...DF.C:42-150): Newton solve of
+    Spalding's law for u_tau per wall face; nut_w = max(0, u_tau^2/(|dU/dn|+ROOTVSMALL) - nu).
+    Start value: laminar seed sqrt(nu*|dU/dn|) (the reference's 'exact restart' variant,
+    :117-118) so that nut_w is a pure function of the state."""
+    kappa, E = WF["kappa"], WF["E"]
+    ut = np.sqrt(nu * magGradU)
+    active = np.real(ut) > ROOTVSMALL
+    ut = np.where(active, ut, 1.0)
+    done = ~active
+    for _ in range(WF["maxIter"]):
+        kUu = _min(kappa * magUp / ut, 50.0 + 0 * ut)
+        fkUu = np.exp(kUu) - 1 - kUu * (1 + 0.5 * kUu)
+        f = -ut * y / nu + magUp / ut + 1 / E * (fkUu - 1.0 / 6.0 * kUu * kUu * kUu)
+        df = y / nu + magUp / (ut * ut) + 1 / E * kUu * fkUu / ut
+        utn = ut + f / df
+        err = np.abs(np.real((ut - utn) / ut))
+        ut = np.where(done, ut, utn)
+        done = done | (np.real(ut) <= ROOTVSMALL) | (err <= WF["tol"])
+    ut = np.where(active, _max(ut, 0 * ut), 0 * ut)
+    return _max(ut * ut / (magGradU + ROOTVSMALL) - nu, 0 * ut)
+
+
+# ----------------------------------------------------------------------------- FV operators
+class Ops:
+    def __init__(self, g):
+        self.g = g
+        self.oi = g.own[: g.nIF]
+        self.ni = g.nei
+        self.bc = g.bcell
+
+    def interp(self, xc):
+        g = self.g
+        w = g.w if xc.ndim == 1 else g.w.reshape((-1,) + (1,) * (xc.ndim - 1))
+        return w * xc[self.oi] + (1 - w) * xc[self.ni]
+
+    def surface_sum(self, fi, fb):
+        """sum over faces of a face field (owner +, neighbour -, boundary +)."""
+        g = self.g
+        return sadd(self.oi, fi, g.nC) - sadd(self.ni, fi, g.nC) + sadd(self.bc, fb, g.nC)
+
+    def grad_scalar(self, xc, xb):
+        g = self.g
+        fi = g.Sf[: g.nIF] * self.interp(xc)[:, None]
+        fb = g.bSf * xb[:, None]
+        return self.surface_sum(fi, fb) / g.V[:, None]
+
+    def grad_vector(self, Xc, Xb):
+        """gradU[c,i,j] = d_i U_j = 1/V sum Sf_i U_j."""
+        g = self.g
+        Xf = self.interp(Xc)
+        fi = g.Sf[: g.nIF, :, None] * Xf[:, None, :]
+        fb = g.bSf[:, :, None] * Xb[:, None, :]
+        return self.surface_sum(fi, fb) / g.V[:, None, None]
+
+
+def dev2T(gradU):
+    """dev2(T(gradU)) = gradU^T - (2/3) tr(gradU) I."""
+    T = np.swapaxes(gradU, -1, -2)
+    tr = np.trace(gradU, axis1=-2, axis2=-1)
+    out = T.copy()
+    for d in range(3):
+        out[..., d, d] = out[..., d, d] - (2.0 / 3.0) * tr
+    return out
+
+
+def relax_diag(D0, sumOff, iC_b, bcell, alpha, nC):
+    """fvMatrix::relax restated: returns relaxed diagonal D (source gets (D-D0)*psi)."""
+    cmax = np.max(np.abs(np.real(iC_b)), axis=1) if iC_b.ndim == 2 else np.abs(np.real(iC_b))
+    # pick the component entries (complex-safe) realising max |.| and min
+    if iC_b.ndim == 2:
+        imax = np.argmax(np.abs(np.real(iC_b)), axis=1)
+        imin = np.argmin(np.real(iC_b), axis=1)
+        r = np.arange(iC_b.shape[0])
+        vmax = _abs(iC_b[r, imax])
+        vmin = iC_b[r, imin]
+    else:
+        vmax = _abs(iC_b)
+        vmin = iC_b
+    D = D0 + sadd(bcell, vmax, nC)
+    D = _max(_abs(D), sumOff)
+    D = D / alpha
+    D = D - sadd(bcell, vmin, nC)
+    return D
+
+
+# ----------------------------------------------------------------------------- DASimpleFoam + SA
+def unpack_simple(W, N, F):
+    U = W[: 3 * N].reshape(N, 3)
+    p = W[3 * N : 4 * N]
+    nuT = W[4 * N : 5 * N]
+    phi = W[5 * N : 5 * N + F]
+    return U, p, nuT, phi
+
+
+def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "nuTildaRes", "phiRes"),
+                    use_constrain_hbya=True, return_parts=False):
+    """R(W) for DASimpleFoam + Spalart-Allmaras in DAIndex 'state' ordering:
+    [URes (3N, xyz interleaved) | pRes (N) | nuTildaRes (N) | phiRes (F, internal then boundary)]."""
+    N, F, nIF, nBF = g.nC, g.nF, g.nIF, g.nBF
+    ops = Ops(g)
+    oi, ni, bcell = ops.oi, ops.ni, ops.bc
+    U, p, nuT, phi = unpack_simple(W, N, F)
+    dt = W.dtype
+    nu = case.nu
+    phi_i, phi_b = phi[:nIF], phi[nIF:]
+    bt = BCTable(case, g, ("U", "p", "nuTilda", "nut"))
+    delta = g.bDeltaCoeffs
+    V = g.V
+
+    # ---- correctBoundaryConditions (DAResidualSimpleFoam.C:250-265, DASpalartAllmaras.C:235-243)
+    Ub, UvIC, UvBC, UgIC, UgBC = bc_vector(bt.code["U"], bt.val["U"], U[bcell], delta, phi_b, g.bnf)
+    pb, pvIC, pvBC, pgIC, pgBC = bc_scalar(bt.code["p"], bt.val["p"], p[bcell], delta, phi_b)
+    nb, nvIC, nvBC, ngIC, ngBC = bc_scalar(bt.code["nuTilda"], bt.val["nuTilda"], nuT[bcell], delta, phi_b)
+
+    # ---- correctNut (DASpalartAllmaras.C:215-233): nut = nuTilda*fv1(chi), then nut BCs
+    chi = nuT / nu
+    fv1 = fv1_of(chi)
+    nut = nuT * fv1
+    nut_b = nb * fv1_of(nb / nu)  # calculated patches
+    cn = bt.code["nut"]
+    nut_b = np.where(cn == NUT_LOWRE_WALL, 0.0 * nut_b, nut_b)
+    nut_b = np.where(cn == NUT_SYMMETRY, nut[bcell], nut_b)
+    wf = cn == NUT_SPALDING_WALL
+    if wf.any():
+        dU = U[bcell][wf] - Ub[wf]
+        magUp = np.sqrt((dU * dU).sum(1) + 0.0)
+        magGradU = magUp * delta[wf]
+        ywf = np.abs(((g.Cf[nIF:][wf] - g.C[bcell][wf]) * g.bnf[wf]).sum(1))
+        nw = spalding_nut(magUp, magGradU, ywf, nu)
+        tmp = nut_b.astype(dt)
+        tmp[wf] = nw
+        nut_b = tmp
+    nuEff = nu + nut
+    nuEff_b = nu + nut_b
+
+    # ---- gradients (Gauss linear) and their boundary values (GaussGrad::correctBoundaryConditions)
+    gradU = ops.grad_vector(U, Ub)
+    gradP = ops.grad_scalar(p, pb)
+    snGradU_b = UgIC * U[bcell] + UgBC
+    gUc = gradU[bcell]
+    n_b = g.bnf
+    ngU = np.einsum("fk,fkj->fj", n_b, gUc)
+    gradU_b = gUc + n_b[:, :, None] * (snGradU_b - ngU)[:, None, :]
+
+    # =================================================================== UEqn
+    # fvm::div(phi,U) [bounded Gauss upwind weights; linearUpwindV explicit correction unless PC]
+    wu = (np.real(phi_i) >= 0).astype(float)  # upwind weights = pos0(flux)
+    lower = -wu * phi_i  # coefficient of owner value in neighbour's equation
+    upper = lower + phi_i  # coefficient of neighbour value in owner's equation
+    diag = sadd(oi, -lower, N) + sadd(ni, -upper, N)
+    # bounded: - fvm::Sp(fvc::surfaceIntegrate(phi), U)
+    sumPhi = ops.surface_sum(phi_i, phi_b)
+    diag = diag - sumPhi
+    iC = phi_b[:, None] * UvIC  # internalCoeffs (vector per boundary face)
+    bC = -phi_b[:, None] * UvBC  # boundaryCoeffs
+    src = np.zeros((N, 3), dtype=dt)
+    if not isPC:
+        pos = np.real(phi_i) > 0
+        d_o = g.Cf[:nIF] - g.C[oi]
+        d_n = g.Cf[:nIF] - g.C[ni]
+        c_o = np.einsum("fi,fij->fj", d_o, gradU[oi])
+        c_n = np.einsum("fi,fij->fj", d_n, gradU[ni])
+        wl = g.w[:, None]
+        m_o = (1.0 - wl) * (U[ni] - U[oi])
+        m_n = wl * (U[oi] - U[ni])
+        corr = np.where(pos[:, None], c_o, c_n)
+        mx = np.where(pos[:, None], m_o, m_n)
+        sfc = (corr * corr).sum(1)
+        mxc = (corr * mx).sum(1)
+        scale = np.where(
+            np.real(sfc) > 0,
+            np.where(np.real(mxc) < 0, 0.0 * mxc, np.where(np.real(sfc) > np.real(mxc), mxc / (sfc + VSMALL), 1.0 + 0 * mxc)),
+            1.0 + 0 * mxc,
+        )
+        corr = corr * scale[:, None]
+        fcorr = phi_i[:, None] * corr
+        src = src - (sadd(oi, fcorr, N) - sadd(ni, fcorr, N))
+    # - fvm::laplacian(nuEff, U)  (Gauss linear corrected)
+    gam = ops.interp(nuEff) * g.magSf[:nIF]
+    gam_b = nuEff_b * g.bMagSf
+    cdiff = gam * g.nonOrthDeltaCoeffs
+    upper = upper - cdiff
+    lower = lower - cdiff
+    diag = diag + sadd(oi, cdiff, N) + sadd(ni, cdiff, N)
+    gradUf = ops.interp(gradU)
+    fcorrL = gam[:, None] * np.einsum("fi,fij->fj", g.nonOrthCorr, gradUf)
+    src = src + (sadd(oi, fcorrL, N) - sadd(ni, fcorrL, N))
+    iC = iC - gam_b[:, None] * UgIC
+    bC = bC + gam_b[:, None] * UgBC
+    # - fvc::div(nuEff*dev2(T(grad(U))))  (explicit, Gauss linear)
+    tau = nuEff[:, None, None] * dev2T(gradU)
+    tau_b = nuEff_b[:, None, None] * dev2T(gradU_b)
+    tf = np.einsum("fi,fij->fj", g.Sf[:nIF], ops.interp(tau))
+    tb = np.einsum("fi,fij->fj", g.bSf, tau_b)
+    src = src + ops.surface_sum(tf, tb)
+    # UEqn.relax()
+    D0 = diag
+    sumOff = sadd(oi, _abs(upper), N) + sadd(ni, _abs(lower), N)
+    alphaU = case.relax["U"]
+    D = relax_diag(D0, sumOff, iC, bcell, alphaU, N)
+    src = src + (D - D0)[:, None] * U
+    # (UEqn & U) + grad(p)
+    offU = sadd(oi, upper[:, None] * U[ni], N) + sadd(ni, lower[:, None] * U[oi], N)
+    bdiag = sadd(bcell, iC, N)  # (N,3)
+    bsrc = sadd(bcell, bC, N)
+    URes = ((D[:, None] + bdiag) * U + offU - src - bsrc) / V[:, None] + gradP
+    # A, H (fvMatrix::A/H with component-averaged boundary diagonal)
+    avgb = bdiag.sum(1) / 3.0
+    A = (D + avgb) / V
+    H = ((avgb[:, None] - bdiag) * U - offU + src + bsrc) / V[:, None]
+    rAU = 1.0 / A
+    HbyA = rAU[:, None] * H
+
+    # =================================================================== pEqn
+    # boundary HbyA: extrapolated (zero-gradient; symmetry transform on symmetry patches),
+    # constrainHbyA: U_b on non-assignable (fixedValue) patches (DAResidualSimpleFoam.C:163-178)
+    cU = bt.code["U"]
+    HbyA_b = HbyA[bcell].copy()
+    symU = cU == BC_SYMMETRY
+    if symU.any():
+        hn = (HbyA_b[symU] * n_b[symU]).sum(1)[:, None]
+        HbyA_b[symU] = HbyA_b[symU] - n_b[symU] * hn
+    if use_constrain_hbya:
+        fx = cU == BC_FIXED_VALUE
+        HbyA_b[fx] = Ub[fx]
+    phiHbyA_i = (ops.interp(HbyA) * g.Sf[:nIF]).sum(1)
+    phiHbyA_b = (HbyA_b * g.bSf).sum(1)
+    # (adjustPhi / setReference are no-ops: p has a fixedValue patch -> !p.needReference())
+    rAUf = ops.interp(rAU)
+    rAU_b = rAU[bcell]
+    gp = rAUf * g.magSf[:nIF]
+    gp_b = rAU_b * g.bMagSf
+    # fvm::laplacian(rAU, p): flux() = upper*(pN - pO) + faceFluxCorrection ; boundary iC*p_c - bC
+    gradPf = ops.interp(gradP)
+    flux_i = gp * g.nonOrthDeltaCoeffs * (p[ni] - p[oi]) + gp * (g.nonOrthCorr * gradPf).sum(1)
+    flux_b = gp_b * (pgIC * p[bcell] + pgBC)
+    # pRes = pEqn & p = (laplacian(rAU,p) - div(phiHbyA)) / V
+    pRes = (ops.surface_sum(flux_i, flux_b) - ops.surface_sum(phiHbyA_i, phiHbyA_b)) / V
+    # phiRes = phiHbyA - pEqn.flux() - phi
+    phiRes = np.concatenate([phiHbyA_i - flux_i - phi_i, phiHbyA_b - flux_b - phi_b])
+
+    # =================================================================== SA (DASpalartAllmaras.C:407-488)
+    gradN = ops.grad_scalar(nuT, nb)
+    y = case.y_wall
+    k2y2 = (SA["kappa"] * y) ** 2
+    skew = 0.5 * (gradU - np.swapaxes(gradU, 1, 2))
+    Omega = np.sqrt(2.0) * np.sqrt((skew * skew).sum((1, 2)) + 0.0)
+    fv2 = 1.0 - chi / (1.0 + chi * fv1)
+    Stilda = _max(Omega + fv2 * nuT / k2y2, SA["Cs"] * Omega)
+    r = _min(nuT / (_max(Stilda, SMALL + 0 * Stilda) * k2y2), 10.0 + 0 * Stilda)
+    gg = r + SA["Cw2"] * (r**6 - r)
+    fw = gg * ((1.0 + SA["Cw3"] ** 6) / (gg**6 + SA["Cw3"] ** 6)) ** (1.0 / 6.0)
+    # div(phi,nuTilda): bounded Gauss upwind (same for PC)
+    lo = -wu * phi_i
+    up = lo + phi_i
+    dN = sadd(oi, -lo, N) + sadd(ni, -up, N) - sumPhi
+    iCn = phi_b * nvIC
+    bCn = -phi_b * nvBC
+    # - laplacian(DnuTildaEff, nuTilda)
+    Dn = (nuT + nu) / SA["sigmaNut"]
+    Dn_b = (nb + nu) / SA["sigmaNut"]
+    gn = ops.interp(Dn) * g.magSf[:nIF]
+    gn_b = Dn_b * g.bMagSf
+    cd = gn * g.nonOrthDeltaCoeffs
+    up = up - cd
+    lo = lo - cd
+    dN = dN + sadd(oi, cd, N) + sadd(ni, cd, N)
+    fcn = gn * (g.nonOrthCorr * ops.interp(gradN)).sum(1)
+    sN = sadd(oi, fcn, N) - sadd(ni, fcn, N)
+    iCn = iCn - gn_b * ngIC
+    bCn = bCn + gn_b * ngBC
+    offN = sadd(oi, up * nuT[ni], N) + sadd(ni, lo * nuT[oi], N)
+    bdN = sadd(bcell, iCn, N)
+    bsN = sadd(bcell, bCn, N)
+    conv_diff = ((dN + bdN) * nuT + offN - sN - bsN) / V
+    nuTildaRes = (
+        conv_diff
+        - SA["Cb2"] / SA["sigmaNut"] * (gradN * gradN).sum(1)
+        - SA["Cb1"] * Stilda * nuT
+        + SA["Cw1"] * fw * nuT / (y * y) * nuT
+    )
+    # (relax() leaves M & psi unchanged)
+
+    # ---- normalisation macros (DAMacroFunctions.H:28-51)
+    if "URes" not in normalize:
+        URes = URes * V[:, None]
+    if "pRes" not in normalize:
+        pRes = pRes * V
+    if "nuTildaRes" not in normalize:
+        nuTildaRes = nuTildaRes * V
+    if "phiRes" in normalize:
+        phiRes = phiRes / g.magSf
+    R = np.concatenate([URes.ravel(), pRes, nuTildaRes, phiRes])
+    if return_parts:
+        parts = dict(
+            Ub=Ub, pb=pb, nuTildab=nb, nut=nut, nut_b=nut_b, gradU=gradU, gradP=gradP, gradN=gradN,
+            D=D, A=A, H=H, rAU=rAU, HbyA=HbyA, phiHbyA=np.concatenate([phiHbyA_i, phiHbyA_b]),
+            URes=URes, pRes=pRes, nuTildaRes=nuTildaRes, phiRes=phiRes, Stilda=Stilda, fw=fw,
+        )
+        return R, parts
+    return R
+
+
+# ----------------------------------------------------------------------------- DAScalarTransportFoam
+def scalar_transport_residual(case, g, W, isPC=False, normalize=("TRes",)):
+    """TRes = (ddt(T) + div(phi,T) - laplacian(DT,T)) & T  (reference
+    DAResidualScalarTransportFoam.C:72-83); ddt: Euler; div: Gauss upwind; laplacian:
+    Gauss linear corrected; phi is a frozen field (not a state, DAStateInfoScalarTransportFoam.C:40)."""
+    N, F, nIF = g.nC, g.nF, g.nIF
+    ops = Ops(g)
+    oi, ni, bcell = ops.oi, ops.ni, ops.bc
+    T = W
+    phi = case.phi
+    phi_i, phi_b = phi[:nIF], phi[nIF:]
+    bt = BCTable(case, g, ("T",))
+    Tb, vIC, vBC, gIC, gBC = bc_scalar(bt.code["T"], bt.val["T"], T[bcell], g.bDeltaCoeffs, phi_b)
+    wu = (phi_i >= 0).astype(float)
+    lo = -wu * phi_i
+    up = lo + phi_i
+    d = sadd(oi, -lo, N) + sadd(ni, -up, N)
+    iC = phi_b * vIC
+    bC = -phi_b * vBC
+    gam = case.DT * g.magSf[:nIF]
+    gam_b = case.DT * g.bMagSf
+    cd = gam * g.nonOrthDeltaCoeffs
+    up = up - cd
+    lo = lo - cd
+    d = d + sadd(oi, cd, N) + sadd(ni, cd, N)
+    gradT = ops.grad_scalar(T, Tb)
+    fc = gam * (g.nonOrthCorr * ops.interp(gradT)).sum(1)
+    s = sadd(oi, fc, N) - sadd(ni, fc, N)
+    iC = iC - gam_b * gIC
+    bC = bC + gam_b * gBC
+    # ddt (Euler)
+    d = d + g.V / case.deltaT
+    s = s + g.V / case.deltaT * case.T_old
+    off = sadd(oi, up * T[ni], N) + sadd(ni, lo * T[oi], N)
+    R = ((d + sadd(bcell, iC, N)) * T + off - s - sadd(bcell, bC, N)) / g.V
+    if "TRes" not in normalize:
+        R = R * g.V
+    return R
+
+
+def residual(case, g, W, isPC=False, **kw):
+    """DAResidual::masterFunction restated (reference DAResidual.C:100-171)."""
+    if case.solver_name == "DASimpleFoam":
+        return simple_residual(case, g, W, isPC=isPC, **kw)
+    if case.solver_name == "DAScalarTransportFoam":
+        return scalar_transport_residual(case, g, W, isPC=isPC, **kw)
+    raise ValueError(case.solver_name)
