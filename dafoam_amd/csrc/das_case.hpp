@@ -1,0 +1,53 @@
+// Case parameters shared by the device driver and the host-emulation test harness.
+#pragma once
+#include "das_kernels.hpp"
+
+namespace das {
+
+struct CaseParams {
+    int solver = DAS_SOLVER_SIMPLEFOAM;
+    double nu = 1.5e-5, relax_U = 0.7, relax_nuTilda = 0.7, relax_T = 1.0, DT = 0.01, deltaT = 1.0;
+    std::vector<double> phi_frozen, T_old;
+    void from_case(const das_case_t* c) {
+        solver = c->solver;
+        nu = c->nu;
+        relax_U = c->relax_U;
+        relax_nuTilda = c->relax_nuTilda;
+        relax_T = c->relax_T;
+        DT = c->DT;
+        deltaT = c->deltaT;
+        if (c->phi_frozen) phi_frozen.assign(c->phi_frozen, c->phi_frozen + c->n_faces);
+        if (c->T_old) T_old.assign(c->T_old, c->T_old + c->n_cells);
+        if (solver == DAS_SOLVER_SCALARTRANSPORTFOAM)
+            DAS_CHECK(!phi_frozen.empty() && !T_old.empty(), DAS_ERR_ARG, "DAScalarTransportFoam needs phi_frozen and T_old");
+    }
+};
+
+inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC) {
+    ResParams p;
+    p.nu = cp.nu;
+    p.alphaU = cp.relax_U;
+    p.alphaN = cp.relax_nuTilda;
+    p.DT = cp.DT;
+    p.deltaT = cp.deltaT;
+    p.isPC = isPC;
+    p.constrainHbyA = (int)opt.geti("useConstrainHbyA");
+    p.normU = opt.list_has("normalizeResiduals", "URes");
+    p.normP = opt.list_has("normalizeResiduals", "pRes");
+    p.normN = opt.list_has("normalizeResiduals", "nuTildaRes");
+    p.normPhi = opt.list_has("normalizeResiduals", "phiRes");
+    p.normT = opt.list_has("normalizeResiduals", "TRes");
+    return p;
+}
+
+inline DevMesh host_view(const Mesh& m) {
+    DevMesh d;
+    d.nC = m.nC; d.nF = m.nF; d.nIF = m.nIF;
+    d.fg = m.fg.data(); d.cg = m.cg.data();
+    d.cf_ptr = m.cf_ptr.data(); d.cf_face = m.cf_face.data(); d.cf_other = m.cf_other.data();
+    d.owner = m.owner.data(); d.neigh = m.neighbour.data();
+    d.bpatch = m.bface_patch.data(); d.bc = m.bc.data();
+    return d;
+}
+
+}  // namespace das

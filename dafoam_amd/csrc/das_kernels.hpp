@@ -1,0 +1,563 @@
+// Residual kernel bodies R(W) for the MI355X adjoint hot path, templated on the scalar type
+// (double, or Dual<K> for the coloured forward-mode Jacobian assembly).
+//
+// What is evaluated (reference file:line):
+//   DAResidualSimpleFoam::calcResiduals        src/adjoint/DAResidual/DAResidualSimpleFoam.C:106-237
+//   DASpalartAllmaras::calcResiduals/correctNut src/adjoint/DAModel/DATurbulenceModel/DASpalartAllmaras.C:124-178,215-233,407-488
+//   DATurbulenceModel::divDevRhoReff            src/adjoint/DAModel/DATurbulenceModel/DATurbulenceModel.C:378-408
+//   nutUSpaldingWallFunction calcNut/calcUTau   src/adjoint/DAMisc/nutUSpaldingWallFunctionDF/...DF.C:42-150
+//   DAResidualScalarTransportFoam::calcResiduals src/adjoint/DAResidual/DAResidualScalarTransportFoam.C:57-84
+//   residual normalisation macros               src/include/DAMacroFunctions.H:28-51
+// The OpenFOAM operators behind those lines (fvm::div/laplacian, fvc::grad, fvMatrix::A/H/flux/&/relax,
+// constrainHbyA, patch-field coefficients) are un-vendored; their semantics for the canonical scheme set are
+// documented in DESIGN.md and restated independently by oracle/residual.py.
+//
+// Design (MI355X): every kernel is cell- or face-centric *gather* (no atomics, deterministic): a cell walks
+// its face list, reads the neighbour cell's record through L2, and recomputes face quantities on the fly
+// instead of materialising face-coefficient arrays in HBM.  Boundary conditions are re-evaluated inline from
+// the owner cell's values, so no boundary-field arrays exist.  One residual evaluation = 4 launches:
+//   k_grad (Gauss gradients, nut) -> k_cell (U-eqn A/H/URes + SA) -> k_face (phiHbyA, p-flux, phiRes)
+//   -> k_pres (pRes).
+#pragma once
+#include "das_common.hpp"
+#include "das_dual.hpp"
+
+namespace das {
+
+struct DevMesh {
+    int nC, nF, nIF;
+    const FaceGeom* fg;
+    const CellGeom* cg;
+    const int* cf_ptr;
+    const int* cf_face;
+    const int* cf_other;
+    const int* owner;
+    const int* neigh;
+    const int* bpatch;  // boundary face -> patch
+    const PatchBC* bc;
+};
+
+struct ResParams {
+    double nu, alphaU, alphaN, DT, deltaT;
+    int isPC, constrainHbyA;
+    int normU, normP, normN, normPhi, normT;  // 1 = residual listed in normalizeResiduals
+};
+
+// SA constants (reference DASpalartAllmaras.C:47-80)
+#define SA_SIGMA 0.66666
+#define SA_KAPPA 0.41
+#define SA_CB1 0.1355
+#define SA_CB2 0.622
+#define SA_CW2 0.3
+#define SA_CW3 2.0
+#define SA_CV1 7.1
+#define SA_CS 0.3
+#define SA_CW1 (SA_CB1 / (SA_KAPPA * SA_KAPPA) + (1.0 + SA_CB2) / SA_SIGMA)
+#define DAS_VSMALL 1e-300
+#define DAS_SMALL 1e-15
+#define DAS_ROOTVSMALL 1e-150
+
+template <class T>
+DAS_HD T fv1_of(const T& chi) {
+    T chi3 = chi * chi * chi;
+    return chi3 / (chi3 + SA_CV1 * SA_CV1 * SA_CV1);
+}
+
+// ---- patch-field coefficients: x_b = vic*x_c + vbc ; snGrad_b = gic*x_c + gbc ---------------------
+template <class T>
+struct ScalarBC {
+    T xb;
+    double vic, vbc, gic, gbc;
+};
+template <class T>
+DAS_HD void bc_scalar(int code, double value, double delta, double phib, const T& xc, ScalarBC<T>& o) {
+    double f = 0.0;
+    if (code == DAS_BC_FIXED_VALUE) f = 1.0;
+    else if (code == DAS_BC_INLET_OUTLET) f = phib >= 0.0 ? 0.0 : 1.0;
+    o.vic = 1.0 - f;
+    o.vbc = f * value;
+    o.gic = -f * delta;
+    o.gbc = f * delta * value;
+    o.xb = o.vic * xc + o.vbc;
+}
+template <class T>
+struct VectorBC {
+    T xb[3];
+    double vic[3], gic[3];
+    T vbc[3], gbc[3];
+};
+template <class T>
+DAS_HD void bc_vector(int code, const double* value, double delta, double phib, const double* n, const T* Xc, VectorBC<T>& o) {
+    if (code == DAS_BC_SYMMETRY) {
+        // basicSymmetry/transformFvPatchField: x_b = X - n (n.X); snGradTransformDiag = |n|
+        T nX = n[0] * Xc[0] + n[1] * Xc[1] + n[2] * Xc[2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double sd = fabs(n[k]);
+            o.xb[k] = Xc[k] - n[k] * nX;
+            o.vic[k] = 1.0 - sd;
+            o.vbc[k] = o.xb[k] - o.vic[k] * Xc[k];
+            o.gic[k] = -delta * sd;
+            o.gbc[k] = (-n[k] * delta) * nX - o.gic[k] * Xc[k];
+        }
+        return;
+    }
+    double f = 0.0;
+    if (code == DAS_BC_FIXED_VALUE) f = 1.0;
+    else if (code == DAS_BC_INLET_OUTLET) f = phib >= 0.0 ? 0.0 : 1.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        o.vic[k] = 1.0 - f;
+        o.vbc[k] = T(f * value[k]);
+        o.gic[k] = -f * delta;
+        o.gbc[k] = T(f * delta * value[k]);
+        o.xb[k] = o.vic[k] * Xc[k] + o.vbc[k];
+    }
+}
+
+// nutUSpaldingWallFunction (reference ...DF.C:42-150); laminar seed (:117-118), maxIter 10, tol 1e-14
+template <class T>
+DAS_HD T spalding_nut(const T& magUp, const T& magGradU, double y, double nu) {
+    const double kappa = 0.41, E = 9.8;
+    T ut = dsqrt(nu * magGradU);
+    if (!(val(ut) > DAS_ROOTVSMALL)) return T(0.0);
+    for (int it = 0; it < 10; it++) {
+        T kUu = dmin(kappa * magUp / ut, 50.0);
+        T fkUu = dexp(kUu) - 1.0 - kUu * (1.0 + 0.5 * kUu);
+        T f = -(ut * (y / nu)) + magUp / ut + (1.0 / E) * (fkUu - (1.0 / 6.0) * kUu * kUu * kUu);
+        T df = y / nu + magUp / (ut * ut) + (1.0 / E) * kUu * fkUu / ut;
+        T utn = ut + f / df;
+        double err = fabs((val(ut) - val(utn)) / val(ut));
+        ut = utn;
+        if (val(ut) <= DAS_ROOTVSMALL || err <= 1e-14) break;
+    }
+    ut = dmax(ut, 0.0);
+    return dmax(ut * ut / (magGradU + DAS_ROOTVSMALL) - nu, 0.0);
+}
+
+template <class T>
+struct BFace {
+    VectorBC<T> U;
+    ScalarBC<T> p, n;
+    T nut_b;
+    double nrm[3];
+};
+
+// evaluate all patch fields of one boundary face from the owner cell's values
+template <class T>
+DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc, double nu, const T* Uc, const T& pc,
+                       const T& nc, const T& nut_c, double phib, BFace<T>& o) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) o.nrm[k] = g.Sf[k] / g.magSf;
+    bc_vector<T>(bc.U_code, bc.U_val, g.nod, phib, o.nrm, Uc, o.U);
+    bc_scalar<T>(bc.p_code, bc.p_val, g.nod, phib, pc, o.p);
+    bc_scalar<T>(bc.nuTilda_code, bc.nuTilda_val, g.nod, phib, nc, o.n);
+    if (bc.nut_code == DAS_NUT_LOWRE_WALL) o.nut_b = T(0.0);
+    else if (bc.nut_code == DAS_NUT_SYMMETRY) o.nut_b = nut_c;
+    else if (bc.nut_code == DAS_NUT_SPALDING_WALL) {
+        T d0 = Uc[0] - o.U.xb[0], d1 = Uc[1] - o.U.xb[1], d2 = Uc[2] - o.U.xb[2];
+        T magUp = dsqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        T magGradU = magUp * g.nod;
+        double yw = fabs((g.Cf[0] - cgc.C[0]) * o.nrm[0] + (g.Cf[1] - cgc.C[1]) * o.nrm[1] + (g.Cf[2] - cgc.C[2]) * o.nrm[2]);
+        o.nut_b = spalding_nut<T>(magUp, magGradU, yw, nu);
+    } else {
+        o.nut_b = o.n.xb * fv1_of<T>(o.n.xb / nu);
+    }
+}
+
+// ================================================================================ k_grad
+// per cell: nut = nuTilda*fv1 ; Gauss-linear gradients of U, p, nuTilda
+template <class T>
+DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W, T* nut, T* gradU, T* gradP, T* gradN) {
+    const long long N = m.nC;
+    const CellGeom& cgc = m.cg[c];
+    T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
+    T pc = W[3 * N + c], nc = W[4 * N + c];
+    T nut_c = nc * fv1_of<T>(nc / prm.nu);
+    nut[c] = nut_c;
+    T gU[9], gP[3], gN[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) gU[k] = T(0.0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { gP[k] = T(0.0); gN[k] = T(0.0); }
+    for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
+        int fe = m.cf_face[s];
+        int f = fe & 0x7fffffff;
+        bool nb = fe < 0;
+        const FaceGeom& g = m.fg[f];
+        T Uf[3], pf, nf;
+        double sg = nb ? -1.0 : 1.0;
+        if (f < m.nIF) {
+            int o = m.cf_other[s];
+            double wc = nb ? 1.0 - g.w : g.w;
+#pragma unroll
+            for (int k = 0; k < 3; k++) Uf[k] = wc * Uc[k] + (1.0 - wc) * W[3LL * o + k];
+            pf = wc * pc + (1.0 - wc) * W[3 * N + o];
+            nf = wc * nc + (1.0 - wc) * W[4 * N + o];
+        } else {
+            BFace<T> b;
+            eval_bface<T>(m.bc[m.bpatch[f - m.nIF]], g, cgc, prm.nu, Uc, pc, nc, nut_c, val(W[5 * N + f]), b);
+#pragma unroll
+            for (int k = 0; k < 3; k++) Uf[k] = b.U.xb[k];
+            pf = b.p.xb;
+            nf = b.n.xb;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double S = sg * g.Sf[i];
+#pragma unroll
+            for (int j = 0; j < 3; j++) gU[3 * i + j] += S * Uf[j];
+            gP[i] += S * pf;
+            gN[i] += S * nf;
+        }
+    }
+    double rV = 1.0 / cgc.V;
+#pragma unroll
+    for (int k = 0; k < 9; k++) gradU[9LL * c + k] = gU[k] * rV;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { gradP[3LL * c + k] = gP[k] * rV; gradN[3LL * c + k] = gN[k] * rV; }
+}
+
+// tau = nuEff * dev2(T(gradU)) ; g[3*i+j] = d_i U_j
+template <class T>
+DAS_HD void dev2T_scaled(const T* g, const T& nuEff, T* tau) {
+    T tr23 = (2.0 / 3.0) * (g[0] + g[4] + g[8]);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            T t = g[3 * j + i];
+            if (i == j) t = t - tr23;
+            tau[3 * i + j] = nuEff * t;
+        }
+}
+
+// ================================================================================ k_cell
+// per cell: U-equation (diag/off-diag/source incl. boundary coeffs), relax, URes, rAU, HbyA and the SA residual
+template <class T>
+DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const T* gradP,
+                      const T* gradN, T* R, T* rAU, T* HbyA) {
+    const long long N = m.nC;
+    const CellGeom& cgc = m.cg[c];
+    const double nu = prm.nu;
+    T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
+    T pc = W[3 * N + c], nc = W[4 * N + c];
+    T nut_c = nut[c];
+    T nuEff_c = nu + nut_c;
+    T gUc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) gUc[k] = gradU[9LL * c + k];
+    T gNc[3] = {gradN[3LL * c], gradN[3LL * c + 1], gradN[3LL * c + 2]};
+    T tau_c[9];
+    dev2T_scaled<T>(gUc, nuEff_c, tau_c);
+    T Dn_c = (nc + nu) * (1.0 / SA_SIGMA);
+
+    T D0(0.0), sumOff(0.0), sumPhi(0.0), vmaxs(0.0), vmins(0.0);
+    T offU[3], src[3], bdiag[3], bsrc[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { offU[k] = T(0.0); src[k] = T(0.0); bdiag[k] = T(0.0); bsrc[k] = T(0.0); }
+    T dN(0.0), offN(0.0), sN(0.0), bdN(0.0), bsN(0.0);
+
+    for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
+        int fe = m.cf_face[s];
+        int f = fe & 0x7fffffff;
+        bool nb = fe < 0;
+        const FaceGeom& g = m.fg[f];
+        T phi = W[5 * N + f];
+        double sg = nb ? -1.0 : 1.0;
+        if (f < m.nIF) {
+            int o = m.cf_other[s];
+            const CellGeom& cgo = m.cg[o];
+            double pv = val(phi);
+            double wu = pv >= 0.0 ? 1.0 : 0.0;  // upwind weight of the owner value = pos0(flux)
+            T dcoef, off;
+            if (!nb) { dcoef = wu * phi; off = (1.0 - wu) * phi; }
+            else { dcoef = -((1.0 - wu) * phi); off = -(wu * phi); }
+            sumPhi += sg * phi;
+            T Uo[3] = {W[3LL * o], W[3LL * o + 1], W[3LL * o + 2]};
+            T nuT_o = W[4 * N + o];
+            T nuEff_o = nu + nut[o];
+            T gUo[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) gUo[k] = gradU[9LL * o + k];
+            const double wl = g.w;
+            // weights of this cell's and the other cell's value in the linear face interpolate
+            const double wc = nb ? 1.0 - wl : wl, wo = 1.0 - wc;
+            // ---- momentum diffusion  -fvm::laplacian(nuEff,U)  (Gauss linear corrected)
+            T gam = (wc * nuEff_c + wo * nuEff_o) * g.magSf;
+            T cd = gam * g.nod;
+            T offTot = off - cd;
+            D0 += dcoef + cd;
+            sumOff += dabs(offTot);
+#pragma unroll
+            for (int k = 0; k < 3; k++) offU[k] += offTot * Uo[k];
+            // ---- linearUpwindV explicit correction (skipped for the PC residual: div(pc) = upwind)
+            if (!prm.isPC) {
+                bool pos = pv > 0.0;
+                bool upIsC = (pos != nb);  // upwind cell is the owner when flux > 0
+                const T* gUp = upIsC ? gUc : gUo;
+                const double* Cup = upIsC ? cgc.C : cgo.C;
+                double d[3] = {g.Cf[0] - Cup[0], g.Cf[1] - Cup[1], g.Cf[2] - Cup[2]};
+                T corr[3], mx[3];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    corr[j] = d[0] * gUp[j] + d[1] * gUp[3 + j] + d[2] * gUp[6 + j];
+                    // owner/neighbour values
+                    T UO = nb ? Uo[j] : Uc[j];
+                    T UN = nb ? Uc[j] : Uo[j];
+                    mx[j] = pos ? (1.0 - wl) * (UN - UO) : wl * (UO - UN);
+                }
+                T sfc = corr[0] * corr[0] + corr[1] * corr[1] + corr[2] * corr[2];
+                T mxc = corr[0] * mx[0] + corr[1] * mx[1] + corr[2] * mx[2];
+                if (val(sfc) > 0.0) {
+                    if (val(mxc) < 0.0) { corr[0] = T(0.0); corr[1] = T(0.0); corr[2] = T(0.0); }
+                    else if (val(sfc) > val(mxc)) {
+                        T sc = mxc / (sfc + DAS_VSMALL);
+                        corr[0] = corr[0] * sc; corr[1] = corr[1] * sc; corr[2] = corr[2] * sc;
+                    }
+                }
+                T pout = sg * phi;
+#pragma unroll
+                for (int j = 0; j < 3; j++) src[j] -= pout * corr[j];
+            }
+            // ---- non-orthogonal correction of the laplacian and the explicit dev2 stress term
+            T tau_o[9];
+            dev2T_scaled<T>(gUo, nuEff_o, tau_o);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                T cvg = g.corr[0] * (wc * gUc[j] + wo * gUo[j]) + g.corr[1] * (wc * gUc[3 + j] + wo * gUo[3 + j])
+                        + g.corr[2] * (wc * gUc[6 + j] + wo * gUo[6 + j]);
+                T tf = g.Sf[0] * (wc * tau_c[j] + wo * tau_o[j]) + g.Sf[1] * (wc * tau_c[3 + j] + wo * tau_o[3 + j])
+                       + g.Sf[2] * (wc * tau_c[6 + j] + wo * tau_o[6 + j]);
+                src[j] += sg * (gam * cvg + tf);
+            }
+            // ---- SA convection (bounded upwind) + diffusion
+            T Dn_o = (nuT_o + nu) * (1.0 / SA_SIGMA);
+            T gn = (wc * Dn_c + wo * Dn_o) * g.magSf;
+            T cdn = gn * g.nod;
+            dN += dcoef + cdn;
+            offN += (off - cdn) * nuT_o;
+            T cvn = g.corr[0] * (wc * gNc[0] + wo * gradN[3LL * o]) + g.corr[1] * (wc * gNc[1] + wo * gradN[3LL * o + 1])
+                    + g.corr[2] * (wc * gNc[2] + wo * gradN[3LL * o + 2]);
+            sN += sg * (gn * cvn);
+        } else {
+            BFace<T> b;
+            double pv = val(phi);
+            eval_bface<T>(m.bc[m.bpatch[f - m.nIF]], g, cgc, nu, Uc, pc, nc, nut_c, pv, b);
+            sumPhi += phi;
+            T nuEff_b = nu + b.nut_b;
+            T gam_b = nuEff_b * g.magSf;
+            T iC[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                iC[k] = phi * b.U.vic[k] - gam_b * b.U.gic[k];
+                bdiag[k] += iC[k];
+                bsrc[k] += gam_b * b.U.gbc[k] - phi * b.U.vbc[k];
+            }
+            T a0 = dabs(iC[0]), a1 = dabs(iC[1]), a2 = dabs(iC[2]);
+            T vmx = a0;
+            if (val(a1) > val(vmx)) vmx = a1;
+            if (val(a2) > val(vmx)) vmx = a2;
+            T vmn = iC[0];
+            if (val(iC[1]) < val(vmn)) vmn = iC[1];
+            if (val(iC[2]) < val(vmn)) vmn = iC[2];
+            vmaxs += vmx;
+            vmins += vmn;
+            // boundary gradient (GaussGrad::correctBoundaryConditions) for the dev2 term
+            T gUb[9], dsn[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                T snG = b.U.gic[j] * Uc[j] + b.U.gbc[j];
+                T ngU = b.nrm[0] * gUc[j] + b.nrm[1] * gUc[3 + j] + b.nrm[2] * gUc[6 + j];
+                dsn[j] = snG - ngU;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) gUb[3 * i + j] = gUc[3 * i + j] + b.nrm[i] * dsn[j];
+            T tau_b[9];
+            dev2T_scaled<T>(gUb, nuEff_b, tau_b);
+#pragma unroll
+            for (int j = 0; j < 3; j++) src[j] += g.Sf[0] * tau_b[j] + g.Sf[1] * tau_b[3 + j] + g.Sf[2] * tau_b[6 + j];
+            // SA boundary coefficients
+            T gn_b = (b.n.xb + nu) * (g.magSf / SA_SIGMA);
+            bdN += phi * b.n.vic - gn_b * b.n.gic;
+            bsN += gn_b * b.n.gbc - phi * b.n.vbc;
+        }
+    }
+    // bounded Gauss: - fvm::Sp(div(phi))
+    D0 -= sumPhi;
+    dN -= sumPhi;
+    // fvMatrix::relax (see DESIGN.md "relax"): diagonal dominance fix-up with boundary max/min contributions
+    T D = dmax(dabs(D0 + vmaxs), sumOff) * (1.0 / prm.alphaU) - vmins;
+    T dD = D - D0;
+    const double rV = 1.0 / cgc.V;
+    T avgb = (bdiag[0] + bdiag[1] + bdiag[2]) * (1.0 / 3.0);
+    T A = (D + avgb) * rV;
+    T rA = 1.0 / A;
+    rAU[c] = rA;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        T sk = src[k] + dD * Uc[k];
+        T ures = ((D + bdiag[k]) * Uc[k] + offU[k] - sk - bsrc[k]) * rV + gradP[3LL * c + k];
+        if (!prm.normU) ures = ures * cgc.V;
+        R[3LL * c + k] = ures;
+        T H = ((avgb - bdiag[k]) * Uc[k] - offU[k] + sk + bsrc[k]) * rV;
+        HbyA[3LL * c + k] = rA * H;
+    }
+    // ---- SA source terms (DASpalartAllmaras.C:124-178,445-485)
+    const double y = cgc.y;
+    const double k2y2 = (SA_KAPPA * y) * (SA_KAPPA * y);
+    T chi = nc / nu;
+    T fv1 = fv1_of<T>(chi);
+    T fv2 = 1.0 - chi / (1.0 + chi * fv1);
+    T w01 = 0.5 * (gUc[1] - gUc[3]), w02 = 0.5 * (gUc[2] - gUc[6]), w12 = 0.5 * (gUc[5] - gUc[7]);
+    T Omega = 1.4142135623730951 * dsqrt(2.0 * (w01 * w01 + w02 * w02 + w12 * w12));
+    T Stilda = dmax(Omega + fv2 * nc / k2y2, SA_CS * Omega);
+    T r = dmin(nc / (dmax(Stilda, DAS_SMALL) * k2y2), 10.0);
+    T r2 = r * r, r6 = r2 * r2 * r2;
+    T gg = r + SA_CW2 * (r6 - r);
+    T g2 = gg * gg, g6 = g2 * g2 * g2;
+    const double cw36 = SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3;
+    T fw = gg * dpow((1.0 + cw36) / (g6 + cw36), 1.0 / 6.0);
+    T convdiff = ((dN + bdN) * nc + offN - sN - bsN) * rV;
+    T nres = convdiff - (SA_CB2 / SA_SIGMA) * (gNc[0] * gNc[0] + gNc[1] * gNc[1] + gNc[2] * gNc[2]) - SA_CB1 * Stilda * nc
+             + SA_CW1 * fw * nc / (y * y) * nc;
+    if (!prm.normN) nres = nres * cgc.V;
+    R[4 * N + c] = nres;
+}
+
+// ================================================================================ k_face
+// per face: phiHbyA, pressure flux, q = flux - phiHbyA (consumed by k_pres) and phiRes
+template <class T>
+DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradP, const T* rAU,
+                      const T* HbyA, T* q, T* R) {
+    const long long N = m.nC;
+    const FaceGeom& g = m.fg[f];
+    T phiHbyA, flux;
+    if (f < m.nIF) {
+        int o = m.owner[f], n = m.neigh[f];
+        const double wl = g.w, wn = 1.0 - g.w;
+        phiHbyA = g.Sf[0] * (wl * HbyA[3LL * o] + wn * HbyA[3LL * n]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * HbyA[3LL * n + 1])
+                  + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * HbyA[3LL * n + 2]);
+        T gp = (wl * rAU[o] + wn * rAU[n]) * g.magSf;
+        T cg = g.corr[0] * (wl * gradP[3LL * o] + wn * gradP[3LL * n]) + g.corr[1] * (wl * gradP[3LL * o + 1] + wn * gradP[3LL * n + 1])
+               + g.corr[2] * (wl * gradP[3LL * o + 2] + wn * gradP[3LL * n + 2]);
+        flux = gp * (g.nod * (W[3 * N + n] - W[3 * N + o]) + cg);
+    } else {
+        int c = m.owner[f];
+        const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
+        T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
+        T pc = W[3 * N + c], nc = W[4 * N + c];
+        BFace<T> b;
+        eval_bface<T>(bc, g, m.cg[c], prm.nu, Uc, pc, nc, nut[c], val(W[5 * N + f]), b);
+        T Hb[3] = {HbyA[3LL * c], HbyA[3LL * c + 1], HbyA[3LL * c + 2]};
+        if (bc.U_code == DAS_BC_SYMMETRY) {
+            T hn = b.nrm[0] * Hb[0] + b.nrm[1] * Hb[1] + b.nrm[2] * Hb[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) Hb[k] = Hb[k] - b.nrm[k] * hn;
+        }
+        if (prm.constrainHbyA && bc.U_code == DAS_BC_FIXED_VALUE) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) Hb[k] = b.U.xb[k];
+        }
+        phiHbyA = g.Sf[0] * Hb[0] + g.Sf[1] * Hb[1] + g.Sf[2] * Hb[2];
+        flux = rAU[c] * g.magSf * (b.p.gic * pc + b.p.gbc);
+    }
+    q[f] = flux - phiHbyA;
+    T pr = phiHbyA - flux - W[5 * N + f];
+    if (prm.normPhi) pr = pr * (1.0 / g.magSf);
+    R[5 * N + f] = pr;
+}
+
+// ================================================================================ k_pres
+template <class T>
+DAS_HD void body_pres(int c, const DevMesh& m, const ResParams& prm, const T* q, T* R) {
+    const long long N = m.nC;
+    T s(0.0);
+    for (int k = m.cf_ptr[c]; k < m.cf_ptr[c + 1]; k++) {
+        int fe = m.cf_face[k];
+        int f = fe & 0x7fffffff;
+        if (fe < 0) s -= q[f];
+        else s += q[f];
+    }
+    if (prm.normP) s = s * (1.0 / m.cg[c].V);
+    R[3 * N + c] = s;
+}
+
+// ================================================================================ DAScalarTransportFoam
+template <class T>
+DAS_HD void body_gradT(int c, const DevMesh& m, const ResParams& prm, const T* W, const double* phiF, T* gradT) {
+    const CellGeom& cgc = m.cg[c];
+    T Tc = W[c];
+    T gT[3] = {T(0.0), T(0.0), T(0.0)};
+    for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
+        int fe = m.cf_face[s];
+        int f = fe & 0x7fffffff;
+        bool nb = fe < 0;
+        const FaceGeom& g = m.fg[f];
+        double sg = nb ? -1.0 : 1.0;
+        T Tf;
+        if (f < m.nIF) {
+            double wc = nb ? 1.0 - g.w : g.w;
+            Tf = wc * Tc + (1.0 - wc) * W[m.cf_other[s]];
+        } else {
+            const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
+            ScalarBC<T> b;
+            bc_scalar<T>(bc.T_code, bc.T_val, g.nod, phiF[f], Tc, b);
+            Tf = b.xb;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) gT[i] += (sg * g.Sf[i]) * Tf;
+    }
+    double rV = 1.0 / cgc.V;
+#pragma unroll
+    for (int i = 0; i < 3; i++) gradT[3LL * c + i] = gT[i] * rV;
+}
+
+// TRes = (ddt(T) + div(phi,T) - laplacian(DT,T)) & T   (Euler, Gauss upwind, Gauss linear corrected)
+template <class T>
+DAS_HD void body_T(int c, const DevMesh& m, const ResParams& prm, const T* W, const double* phiF, const double* Told,
+                   const T* gradT, T* R) {
+    const CellGeom& cgc = m.cg[c];
+    T Tc = W[c];
+    T d(0.0), off(0.0), sS(0.0), bd(0.0), bs(0.0);
+    for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
+        int fe = m.cf_face[s];
+        int f = fe & 0x7fffffff;
+        bool nb = fe < 0;
+        const FaceGeom& g = m.fg[f];
+        double sg = nb ? -1.0 : 1.0;
+        double phi = phiF[f];
+        if (f < m.nIF) {
+            int o = m.cf_other[s];
+            double wu = phi >= 0.0 ? 1.0 : 0.0;
+            double dcoef, offc;
+            if (!nb) { dcoef = wu * phi; offc = (1.0 - wu) * phi; }
+            else { dcoef = -(1.0 - wu) * phi; offc = -wu * phi; }
+            double gam = prm.DT * g.magSf;
+            double cd = gam * g.nod;
+            d += dcoef + cd;
+            off += (offc - cd) * W[o];
+            double wc = nb ? 1.0 - g.w : g.w, wo = 1.0 - wc;
+            T cv = g.corr[0] * (wc * gradT[3LL * c] + wo * gradT[3LL * o]) + g.corr[1] * (wc * gradT[3LL * c + 1] + wo * gradT[3LL * o + 1])
+                   + g.corr[2] * (wc * gradT[3LL * c + 2] + wo * gradT[3LL * o + 2]);
+            sS += (sg * gam) * cv;
+        } else {
+            const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
+            ScalarBC<T> b;
+            bc_scalar<T>(bc.T_code, bc.T_val, g.nod, phi, Tc, b);
+            double gam_b = prm.DT * g.magSf;
+            bd += phi * b.vic - gam_b * b.gic;
+            bs += gam_b * b.gbc - phi * b.vbc;
+        }
+    }
+    double rdt = cgc.V / prm.deltaT;
+    d += rdt;
+    sS += rdt * Told[c];
+    T res = ((d + bd) * Tc + off - sS - bs) * (1.0 / cgc.V);
+    if (!prm.normT) res = res * cgc.V;
+    R[c] = res;
+}
+
+}  // namespace das

@@ -1,0 +1,197 @@
+/*
+ * dafoam_amd.h - C-ABI of the MI355X-native discrete-adjoint hot path.
+ *
+ * Drop-in boundary: these entry points are what the reference's Cython layer
+ * (reference src/pyDASolvers/pyDASolvers.pyx:45-114 extern block, :117-482 class
+ * pyDASolvers, wrapping src/pyDASolvers/DASolvers.H) would bind for the adjoint
+ * path.  Conventions follow the reference: caller-owned
+ * 1-D contiguous float64 buffers borrowed for the call and written in place;
+ * strings are NUL-terminated char*; soft failures are integer returns; hard
+ * failures return a negative code and set das_last_error() (the reference
+ * aborts the process via OpenFOAM FatalError, e.g. DASolver.C:992-993).
+ * No exceptions, no C++/torch types cross this boundary.
+ *
+ * PETSc objects of the reference API (Mat dRdWT / Mat dRdWTPC / KSP, created by the
+ * Python caller in reference dafoam/mphys/mphys_dafoam.py:468-475,519-529) are
+ * replaced by opaque device-resident handles das_mat_t / das_ksp_t.
+ *
+ * All compute entry points run on the GPU; they FAIL (return DAS_ERR_NO_DEVICE)
+ * when no HIP device is present - there is no CPU fallback.
+ */
+#ifndef DAFOAM_AMD_H
+#define DAFOAM_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAS_OK 0
+#define DAS_ERR_ARG -1
+#define DAS_ERR_NO_DEVICE -2
+#define DAS_ERR_HIP -3
+#define DAS_ERR_STATE -4
+#define DAS_ERR_INTERNAL -5
+
+/* solver ids (reference run-time selection by "solverName", DASolver.C:122-152) */
+#define DAS_SOLVER_SIMPLEFOAM 0          /* DASimpleFoam + SpalartAllmaras */
+#define DAS_SOLVER_SCALARTRANSPORTFOAM 1 /* DAScalarTransportFoam */
+
+/* patch types */
+#define DAS_PATCH_PATCH 0
+#define DAS_PATCH_WALL 1
+#define DAS_PATCH_SYMMETRY 2
+
+/* boundary-condition codes per patch and field */
+#define DAS_BC_FIXED_VALUE 0
+#define DAS_BC_ZERO_GRADIENT 1
+#define DAS_BC_INLET_OUTLET 2
+#define DAS_BC_SYMMETRY 3
+/* nut patch treatment (reference DAField.C:1155-1218, DAMisc/nutUSpaldingWallFunctionDF) */
+#define DAS_NUT_CALCULATED 0
+#define DAS_NUT_LOWRE_WALL 1
+#define DAS_NUT_SPALDING_WALL 2
+#define DAS_NUT_SYMMETRY 3
+
+typedef struct das_solver das_solver_t; /* replaces Foam::DASolvers (DASolvers.H) */
+typedef struct das_mat das_mat_t;       /* replaces PETSc Mat dRdWT / dRdWTPC */
+typedef struct das_ksp das_ksp_t;       /* replaces PETSc KSP */
+
+/* What the reference reads from the OpenFOAM case directory (constant/polyMesh, 0/,
+ * constant/transportProperties, system/fvSolution) for this path, as plain arrays. */
+typedef struct das_case {
+    int solver; /* DAS_SOLVER_* */
+    int n_points, n_faces, n_internal_faces, n_cells, n_patches;
+    const double* points;  /* 3*n_points */
+    const int* face_ptr;   /* n_faces+1 (CSR into face_pts) */
+    const int* face_pts;   /* point ids */
+    const int* owner;      /* n_faces */
+    const int* neighbour;  /* n_internal_faces */
+    const int* patch_start; /* n_patches, absolute face index */
+    const int* patch_size;
+    const int* patch_type; /* DAS_PATCH_* */
+    /* per-patch BC tables; *_val: 3 doubles per patch for U, 1 otherwise */
+    const int* bc_U_code;
+    const double* bc_U_val;
+    const int* bc_p_code;
+    const double* bc_p_val;
+    const int* bc_nuTilda_code;
+    const double* bc_nuTilda_val;
+    const int* bc_nut_code;
+    const int* bc_T_code;
+    const double* bc_T_val;
+    double nu;
+    double relax_U, relax_nuTilda, relax_T;
+    double DT, deltaT;        /* DAScalarTransportFoam */
+    const double* y_wall;     /* n_cells, frozen wall distance (may be NULL for ScalarTransport) */
+    const double* phi_frozen; /* n_faces, DAScalarTransportFoam only */
+    const double* T_old;      /* n_cells, DAScalarTransportFoam only */
+} das_case_t;
+
+const char* das_last_error(void);
+int das_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; never fails) */
+int das_device_count(void);
+
+/* ---- construction / options ------------------------------------------------------------
+ * das_create      <- pyDASolvers.__init__(argsAll, pyOptions)   pyDASolvers.pyx:134-153
+ * das_init_solver <- pyDASolvers.initSolver()                    pyDASolvers.pyx:155 (DASolver::initSolver)
+ * das_set_option_* <- pyDASolvers.updateDAOption(pyOptions)      pyDASolvers.pyx:355 (flattened "a.b" keys of DAOPTION,
+ *                     reference dafoam/pyDAFoam.py:39-661; lists are comma-joined strings) */
+das_solver_t* das_create(const das_case_t* c);
+void das_destroy(das_solver_t* s);
+int das_set_option_double(das_solver_t* s, const char* key, double v);
+int das_set_option_int(das_solver_t* s, const char* key, long long v);
+int das_set_option_str(das_solver_t* s, const char* key, const char* v);
+int das_get_option_double(das_solver_t* s, const char* key, double* v);
+int das_init_solver(das_solver_t* s, int device);
+
+/* ---- sizes: getNLocalAdjointStates/getNLocalCells/getNGlobalCells/getNLocalPoints  pyDASolvers.pyx:305-317 */
+long long das_get_n_local_adjoint_states(das_solver_t* s);
+long long das_get_n_local_cells(das_solver_t* s);
+long long das_get_n_global_cells(das_solver_t* s);
+long long das_get_n_local_points(das_solver_t* s);
+long long das_get_n_local_faces(das_solver_t* s);
+
+/* ---- host-side mesh geometry (fvMesh metrics; no GPU needed) - used by tests and input generators */
+int das_get_geometry(das_solver_t* s, double* Sf /*3F*/, double* Cf /*3F*/, double* C /*3N*/, double* V /*N*/,
+                     double* weights /*Fi*/, double* nonOrthDeltaCoeffs /*Fi*/, double* nonOrthCorr /*3Fi*/,
+                     double* bDeltaCoeffs /*Fb*/);
+
+/* ---- state / residual access -------------------------------------------------------------
+ * das_update_of_fields <- updateOFFields(states)   pyDASolvers.pyx:268   (DAField::stateVec2OFField)
+ * das_get_of_fields    <- getOFFields(states)      pyDASolvers.pyx:273
+ * das_get_residuals    <- getResiduals(residuals)  pyDASolvers.pyx:184   (DASolver.C:1157-1236; isPC=0)
+ * das_calc_residuals   : same with explicit isPC (DAResidual::masterFunction, DAResidual.C:100-171) */
+int das_update_of_fields(das_solver_t* s, const double* states);
+int das_get_of_fields(das_solver_t* s, double* states);
+int das_get_residuals(das_solver_t* s, double* residuals);
+int das_calc_residuals(das_solver_t* s, int isPC, double* residuals);
+
+/* ---- connectivity + colouring ------------------------------------------------------------
+ * das_run_coloring <- runColoring()  pyDASolvers.pyx:161  (DASolver.C:708-743, DAJacCon, DAColoring)
+ * Host graph work; needs no GPU.  The getters expose dRdWCon and the colour vector (the reference
+ * writes them as dRdWCon.bin / dRdWColoring_<np>.bin, DAJacCon.C:1886-1975,2580-2586). */
+int das_run_coloring(das_solver_t* s);
+int das_get_n_colors(das_solver_t* s, int isPC);
+long long das_get_con_nnz(das_solver_t* s, int isPC);
+int das_get_con(das_solver_t* s, int isPC, long long* rowptr /*n+1*/, int* colidx /*nnz*/);
+int das_get_colors(das_solver_t* s, int isPC, int* colors /*n*/);
+
+/* ---- Jacobians ---------------------------------------------------------------------------
+ * das_calc_drdwt <- calcdRdWT(isPC, Mat dRdWT)  pyDASolvers.pyx:237 (DASolver.C:948-1089, DAPartDeriv.C:350-473).
+ *   mode: 0 = coloured one-sided finite differences (reference behaviour, step adjPartDerivFDStep.State),
+ *         1 = coloured dual-number (forward-mode AD) perturbations - exact derivatives on the same colouring.
+ *   Result: transposed CSR on the device, entry (j,i) = s_j dR_i/dW_j. */
+int das_calc_drdwt(das_solver_t* s, int isPC, int mode, das_mat_t** out);
+long long das_mat_rows(das_mat_t* m);
+long long das_mat_nnz(das_mat_t* m);
+int das_mat_export(das_mat_t* m, long long* rowptr, int* colidx, double* vals);
+/* y = A x on host buffers (testing) */
+int das_mat_mult(das_mat_t* m, const double* x, double* y);
+void das_mat_destroy(das_mat_t* m);
+
+/* das_initialize_drdwt_matrix_free <- initializedRdWTMatrixFree()  pyDASolvers.pyx:253 (DASolver.C:1321-1351):
+ *   the reference creates a PETSc MatShell whose MULT replays a CoDiPack reverse tape; here the operator is
+ *   assembled once per call with dual numbers (mode 1, isPC=0 schemes) and applied as a device SpMV.
+ * das_destroy_drdwt_matrix_free    <- destroydRdWTMatrixFree()      pyDASolvers.pyx:256 */
+int das_initialize_drdwt_matrix_free(das_solver_t* s);
+int das_destroy_drdwt_matrix_free(das_solver_t* s);
+
+/* das_calc_jac_t_vec_product <- calcJacTVecProduct(inputName,inputType,inputs,outputName,outputType,seeds,product)
+ *   pyDASolvers.pyx:208-235 (DASolver.C:1690-1839).  Supported pair on this path: inputType "stateVar",
+ *   outputType "residual": product = D_s (dR/dW)^T seeds  (normalizeJacTVecProduct, DASolver.C:1443-1553). */
+int das_get_input_size(das_solver_t* s, const char* inputName, const char* inputType);
+int das_get_output_size(das_solver_t* s, const char* outputName, const char* outputType);
+int das_calc_jac_t_vec_product(das_solver_t* s, const char* inputName, const char* inputType, const double* inputs,
+                               const char* outputName, const char* outputType, const double* seeds, double* product);
+/* same product on device buffers (no copies; used by bench.py); d_x,d_y: n doubles in HBM */
+int das_drdwt_mult_device(das_solver_t* s, const double* d_x, double* d_y);
+
+/* ---- Krylov solve ------------------------------------------------------------------------
+ * das_create_ml_rksp_matrix_free <- createMLRKSPMatrixFree(Mat jacPCMat, KSP ksp) pyDASolvers.pyx:259
+ *     (DASolver.C:1102-1119 -> DALinearEqn::createMLRKSP, DALinearEqn.C:28-339): right-preconditioned
+ *     restarted GMRES, PC = block (additive-Schwarz-like) ILU(pcFillLevel) of jacPCMat.
+ * das_solve_linear_eqn <- solveLinearEqn(KSP, Vec rhs, Vec sol) pyDASolvers.pyx:265 (DALinearEqn.C:341-437);
+ *     returns 0 converged / 1 failed by the reference's gmresTolDiff rule (:422-434), <0 on error. */
+int das_create_ml_rksp_matrix_free(das_solver_t* s, das_mat_t* pc, das_ksp_t** ksp);
+int das_solve_linear_eqn(das_solver_t* s, das_ksp_t* ksp, const double* rhs, double* sol);
+int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, double* seconds);
+int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
+/* run exactly `iters` GMRES iterations on device-resident rhs/sol (bench.py "step"); no convergence exit */
+int das_ksp_run_fixed_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rhs, double* d_sol, int iters);
+void das_ksp_destroy(das_ksp_t* k);
+
+/* ---- timing (getElapsedClockTime/getElapsedCpuTime pyDASolvers.pyx:332-336) and kernel timers */
+double das_get_elapsed_clock_time(das_solver_t* s);
+double das_get_elapsed_cpu_time(das_solver_t* s);
+/* average duration [ms] of the named kernel family measured with HIP events on the launch stream since
+ * the last reset: "spmv", "pc", "residual" ; returns <0 if never launched */
+double das_timer_avg_ms(das_solver_t* s, const char* name);
+long long das_timer_count(das_solver_t* s, const char* name);
+void das_timer_reset(das_solver_t* s);
+void das_timer_enable(das_solver_t* s, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,49 @@
+// TEST HARNESS ONLY (never linked into libdafoam_amd.so, never used by the product path).
+// Runs the *same* templated kernel bodies that the HIP kernels wrap (csrc/das_kernels.hpp) in plain host
+// loops so that the CPU-only test tier can check them against the oracle (tests/test_kernel_bodies_cpu.py).
+#include "../../dafoam_amd/csrc/das_case.hpp"
+
+using namespace das;
+
+template <class T>
+static void eval(const Mesh& mesh, const CaseParams& cp, const ResParams& prm, const std::vector<T>& W, std::vector<T>& R) {
+    DevMesh m = host_view(mesh);
+    const long long N = m.nC;
+    if (cp.solver == DAS_SOLVER_SIMPLEFOAM) {
+        std::vector<T> nut(N), gU(9 * N), gP(3 * N), gN(3 * N), rAU(N), HbyA(3 * N), q(m.nF);
+        for (int c = 0; c < m.nC; c++) body_grad<T>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data());
+        for (int c = 0; c < m.nC; c++)
+            body_cell<T>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), R.data(), rAU.data(), HbyA.data());
+        for (int f = 0; f < m.nF; f++) body_face<T>(f, m, prm, W.data(), nut.data(), gP.data(), rAU.data(), HbyA.data(), q.data(), R.data());
+        for (int c = 0; c < m.nC; c++) body_pres<T>(c, m, prm, q.data(), R.data());
+    } else {
+        std::vector<T> gT(3 * N);
+        for (int c = 0; c < m.nC; c++) body_gradT<T>(c, m, prm, W.data(), cp.phi_frozen.data(), gT.data());
+        for (int c = 0; c < m.nC; c++) body_T<T>(c, m, prm, W.data(), cp.phi_frozen.data(), cp.T_old.data(), gT.data(), R.data());
+    }
+}
+
+extern "C" int emu_residual(const das_case_t* c, const double* Win, long long n, int isPC, const double* dir, double* Rv, double* Rd) {
+    try {
+        Mesh mesh;
+        mesh.build(c);
+        CaseParams cp;
+        cp.from_case(c);
+        Options opt;
+        ResParams prm = make_params(cp, opt, isPC);
+        if (!dir) {
+            std::vector<double> W(Win, Win + n), R(n);
+            eval<double>(mesh, cp, prm, W, R);
+            for (long long i = 0; i < n; i++) Rv[i] = R[i];
+        } else {
+            std::vector<Dual<1>> W(n), R(n);
+            for (long long i = 0; i < n; i++) { W[i].v = Win[i]; W[i].d[0] = dir[i]; }
+            eval<Dual<1>>(mesh, cp, prm, W, R);
+            for (long long i = 0; i < n; i++) { Rv[i] = R[i].v; Rd[i] = R[i].d[0]; }
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "emu_residual: %s\n", e.what());
+        return -1;
+    }
+}
