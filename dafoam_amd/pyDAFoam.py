@@ -1,0 +1,239 @@
+"""Host-side mirror of the reference's ``dafoam/pyDAFoam.py`` for the adjoint hot path: the ``DAOPTION``
+defaults/keys that the path consumes and the ``PYDAFOAM`` driver methods its callers use
+(reference dafoam/pyDAFoam.py:39-661 DAOPTION, :664-2295 PYDAFOAM; callers: dafoam/mphys/mphys_dafoam.py:433-612).
+
+Only hot-path behaviour is implemented: option dict with type checking and first-level
+sub-dict merging (pyDAFoam.py:1993-2033), getStates/setStates (:2090-2109), array2Vec/vec2Array (:2167-2199),
+and ``solveAdjoint`` which performs the exact call sequence of ``DAFoamSolver.solve_linear``
+(mphys_dafoam.py:433-574: runColoring -> calcdRdWT(1, dRdWTPC) -> createMLRKSPMatrixFree ->
+initializedRdWTMatrixFree -> solveLinearEqn -> destroydRdWTMatrixFree).
+"""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+from .pyDASolvers import KSP, Mat, Vec, pyDASolvers
+
+
+class Error(Exception):
+    """Format the error message in a box (reference pyDAFoam.py Error class)."""
+
+    def __init__(self, message):
+        msg = "\n+" + "-" * 78 + "+" + "\n" + "| pyDAFoam Error: "
+        i = 19
+        for word in message.split():
+            if len(word) + i + 1 > 78:
+                msg += " " * (78 - i) + "|\n| " + word + " "
+                i = 1 + len(word) + 1
+            else:
+                msg += word + " "
+                i += len(word) + 1
+        msg += " " * (78 - i) + "|\n" + "+" + "-" * 78 + "+" + "\n"
+        print(msg)
+        Exception.__init__(self, message)
+
+
+class DAOPTION(object):
+    """Defaults of every option the adjoint hot path reads; names, nesting and values are the reference's
+    (dafoam/pyDAFoam.py:59-661, line numbers in comments)."""
+
+    def __init__(self):
+        self.solverName = "DASimpleFoam"  # :77
+        self.primalMinResTol = 1.0e-8  # :116-121
+        self.primalBC = {}  # :150
+        self.normalizeStates = {}  # :334
+        self.function = {}
+        self.inputInfo = {}
+        self.outputInfo = {}
+        self.discipline = "aero"  # :386
+        self.adjPartDerivFDStep = {"State": 1.0e-6}  # :390-392
+        self.transonicPCOption = -1  # :396
+        self.adjPCLag = 10000  # :417
+        self.useAD = {"mode": "reverse", "dvName": "None", "seedIndex": -9999}  # :426
+        self.useConstrainHbyA = True  # :433
+        self.debug = False  # :506
+        self.writeJacobians = ["None"]  # :510
+        self.printInterval = 100  # :514
+        self.adjUseColoring = True  # :521
+        self.adjEqnSolMethod = "Krylov"
+        self.adjEqnOption = {  # :526-548
+            "globalPCIters": 0,
+            "asmOverlap": 1,
+            "localPCIters": 1,
+            "jacMatReOrdering": "rcm",
+            "pcFillLevel": 1,
+            "gmresMaxIters": 1000,
+            "gmresRestart": 1000,
+            "gmresRelTol": 1.0e-6,
+            "gmresAbsTol": 1.0e-14,
+            "gmresTolDiff": 1.0e2,
+            "useNonZeroInitGuess": False,
+            "useMGSO": False,
+            "printInfo": 1,
+            "fpMaxIters": 1000,
+            "fpRelTol": 1e-6,
+            "fpMinResTolDiff": 1.0e2,
+            "fpPCUpwind": False,
+            "dynAdjustTol": False,
+            "KSPCalcEigen": 0,
+            "KSPCalcSingularVal": 0,
+            "readPCMat": 0,
+        }
+        self.normalizeResiduals = [  # :551-563
+            "URes", "pRes", "p_rghRes", "nuTildaRes", "phiRes", "TRes", "DRes", "kRes", "omegaRes", "epsilonRes", "alpha.waterRes",
+        ]
+        self.maxResConLv4JacPCMat = {  # :568-582
+            "pRes": 2, "phiRes": 1, "URes": 2, "TRes": 2, "nuTildaRes": 2, "kRes": 2, "epsilonRes": 2, "omegaRes": 2,
+            "p_rghRes": 2, "DRes": 2, "gammaIntRes": 2, "ReThetatRes": 2, "alpha.waterRes": 2,
+        }
+        self.jacLowerBounds = {"dRdW": 1.0e-30, "dRdWPC": 1.0e-30}  # :586-589
+        self.decomposeParDict = {  # :597-604
+            "method": "scotch",
+            "simpleCoeffs": {"n": [2, 2, 1], "delta": 0.001},
+            "kahipCoeffs": {"config": "fast", "imbalance": 0.01},
+            "preservePatches": ["None"],
+            "singleProcessorFaceSets": ["None"],
+            "args": ["None"],
+        }
+        self.adjStateOrdering = "state"  # :608
+        self.writeAdjointFields = False
+        self.maxCorrectBCCalls = 2  # :628
+        self.writeMinorIterations = False
+        # MI355X-specific additions (not in the reference)
+        self.amd = {"pcBlockCells": 4096, "jacMode": 1, "pcJacMode": 0}
+        self.amdDevice = 0
+
+
+class PYDAFOAM(object):
+    """Main driver (reference PYDAFOAM, pyDAFoam.py:664).  ``case`` replaces the OpenFOAM case directory."""
+
+    def __init__(self, comm=None, options=None, case=None):
+        assert options is not None, "options must be provided (reference pyDAFoam.py:679-686)"
+        self.name = "PYDAFOAM"
+        self.dtype = "d"  # pyDAFoam.py:713
+        self.comm = comm
+        self.defaultOptions = self._getDefOptions()
+        self.imOptions = self._getImmutableOptions()
+        self.options = copy.deepcopy(self.defaultOptions)
+        for name, value in options.items():
+            self._initOption(name, value)
+        self._case = case
+        self._initSolver()
+        self.dRdWTPC = None
+        self.ksp = None
+        self.nSolveAdjoints = 0
+        self.runColoring = True
+
+    # ---------------------------------------------------------------- options (pyDAFoam.py:823-844,1892-2033,2201-2208)
+    def _getDefOptions(self):
+        d = DAOPTION()
+        out = {}
+        for key in vars(d):
+            v = getattr(d, key)
+            out[key] = [type(v), v]
+        return out
+
+    def _getImmutableOptions(self):
+        return ()
+
+    def _initOption(self, name, value):
+        if name not in self.defaultOptions:
+            raise Error("Option '%-30s' is not a valid %s option." % (name, self.name))
+        if name in self.imOptions:
+            raise Error("Option '%-35s' cannot be modified after the solver is created." % name)
+        if isinstance(value, self.defaultOptions[name][0]):
+            if isinstance(value, dict):
+                for subKey in value:
+                    self.options[name][1][subKey] = value[subKey]
+            else:
+                self.options[name][1] = value
+        else:
+            raise Error(
+                "Datatype for Option %-35s was not valid \n Expected data type is %-47s \n Received data type is %-47s"
+                % (name, self.defaultOptions[name][0], type(value))
+            )
+
+    def getOption(self, name):
+        if name in self.defaultOptions:
+            return self.options[name][1]
+        raise Error("%s is not a valid option name." % name)
+
+    def setOption(self, name, value):
+        """Merge up to three sub-dict levels (pyDAFoam.py:1892-1991); call updateDAOption() to push to the solver."""
+        if name not in self.defaultOptions:
+            raise Error("Option '%-30s' is not a valid %s option." % (name, self.name))
+        if not isinstance(value, self.defaultOptions[name][0]):
+            raise Error("Datatype for Option %-35s was not valid" % name)
+        if isinstance(value, dict):
+            def merge(dst, src):
+                for k, v in src.items():
+                    if isinstance(v, dict) and isinstance(dst.get(k), dict):
+                        merge(dst[k], v)
+                    else:
+                        dst[k] = v
+            merge(self.options[name][1], value)
+        else:
+            self.options[name][1] = value
+
+    def updateDAOption(self):
+        plain = {k: v[1] for k, v in self.options.items()}
+        self.solver.updateDAOption(plain)
+
+    # ---------------------------------------------------------------- solver init (pyDAFoam.py:1417-1452)
+    def _initSolver(self):
+        solverName = self.getOption("solverName")
+        plain = {k: v[1] for k, v in self.options.items()}
+        solverArg = (solverName + " -python").encode()
+        self.solver = pyDASolvers(solverArg, plain, case=self._case)
+        # the reference keeps a second, CoDiPack-typed instance (solverAD); here one GPU object serves both roles
+        self.solverAD = self.solver
+        self.solver.initSolver()
+
+    # ---------------------------------------------------------------- states / vectors
+    def getStates(self):
+        n = self.solver.getNLocalAdjointStates()
+        states = np.zeros(n, self.dtype)
+        self.solver.getOFFields(states)
+        return states
+
+    def setStates(self, states):
+        self.solver.updateOFFields(states)
+        self.solverAD.updateOFFields(states)
+
+    def getNLocalAdjointStates(self):
+        return self.solver.getNLocalAdjointStates()
+
+    def vec2Array(self, vec):
+        Istart, Iend = vec.getOwnershipRange()
+        array1 = np.zeros(Iend - Istart, self.dtype)
+        array1[:] = vec.array[Istart:Iend]
+        return array1
+
+    def array2Vec(self, array1):
+        vec = Vec(len(array1))
+        vec.array[:] = array1
+        return vec
+
+    # ---------------------------------------------------------------- adjoint (mphys_dafoam.py:433-574 sequence)
+    def solveAdjoint(self, dFdWArray):
+        """psi with D_s (dR/dW)^T psi = dFdW (dFdW already state-scaled like the output of
+        calcJacTVecProduct(stateVar -> function), DASolver.C:1820).  Returns (psi, fail)."""
+        dFdW = self.array2Vec(np.ascontiguousarray(dFdWArray, dtype=np.float64))
+        if self.getOption("adjUseColoring") and self.runColoring:
+            self.solver.runColoring()
+            self.runColoring = False
+        adjPCLag = self.getOption("adjPCLag")
+        if self.nSolveAdjoints % adjPCLag == 0 or self.dRdWTPC is None:
+            self.dRdWTPC = Mat().create()
+            self.solver.calcdRdWT(1, self.dRdWTPC)
+            self.ksp = KSP().create()
+            self.solverAD.createMLRKSPMatrixFree(self.dRdWTPC, self.ksp)
+        self.solverAD.initializedRdWTMatrixFree()
+        psi = Vec(len(dFdWArray))
+        psi.set(0)
+        fail = self.solverAD.solveLinearEqn(self.ksp, dFdW, psi)
+        self.solverAD.destroydRdWTMatrixFree()
+        self.nSolveAdjoints += 1
+        return self.vec2Array(psi), fail

@@ -1,0 +1,391 @@
+"""Host-side mirror of the reference's Cython boundary class ``pyDASolvers``
+(reference src/pyDASolvers/pyDASolvers.pyx:117-482) for the adjoint hot path.
+
+Same method names, argument meaning and error behaviour as the reference for the hot-path subset
+(SURVEY.md section 8b); every method forwards to the C-ABI of include/dafoam_amd.h, which runs on the GPU.
+PETSc is not part of this stack (north star: "no PETSc"): the ``Mat``/``Vec``/``KSP`` objects the reference's
+callers create with petsc4py (reference dafoam/mphys/mphys_dafoam.py:468-475,519-529, dafoam/pyDAFoam.py:2132-2199)
+are replaced by the light stand-ins below that expose the handful of methods those callers use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import CaseStruct, check, dptr, lib
+from .meshgen import FoamCase
+
+
+# ----------------------------------------------------------------------------- PETSc stand-ins
+class Vec:
+    """Stand-in for petsc4py.PETSc.Vec as used by pyDAFoam.array2Vec/vec2Array (pyDAFoam.py:2167-2199)."""
+
+    def __init__(self, n=0):
+        self.array = np.zeros(int(n), dtype=np.float64)
+
+    @classmethod
+    def createSeq(cls, n, bsize=1, comm=None):
+        return cls(n)
+
+    def setSizes(self, size, bsize=1):
+        n = size[0] if isinstance(size, (tuple, list)) else size
+        self.array = np.zeros(int(n), dtype=np.float64)
+
+    def setFromOptions(self):
+        pass
+
+    def getOwnershipRange(self):
+        return 0, self.array.size
+
+    def getSize(self):
+        return self.array.size
+
+    def set(self, v):
+        self.array[:] = v
+
+    def zeroEntries(self):
+        self.array[:] = 0.0
+
+    def duplicate(self):
+        return Vec(self.array.size)
+
+    def copy(self, other=None):
+        if other is None:
+            o = Vec(self.array.size)
+            o.array[:] = self.array
+            return o
+        other.array[:] = self.array
+        return other
+
+    def axpy(self, a, x):
+        self.array += a * x.array
+
+    def scale(self, a):
+        self.array *= a
+
+    def norm(self, norm_type=2):
+        return float(np.linalg.norm(self.array))
+
+    def assemblyBegin(self):
+        pass
+
+    def assemblyEnd(self):
+        pass
+
+    def __getitem__(self, i):
+        return self.array[i]
+
+    def __setitem__(self, i, v):
+        self.array[i] = v
+
+    def destroy(self):
+        self.array = np.zeros(0)
+
+
+class Mat:
+    """Stand-in for the PETSc Mat dRdWT/dRdWTPC handle (device-resident CSR owned by the C-ABI)."""
+
+    def __init__(self):
+        self.handle = None
+
+    def create(self, comm=None):
+        return self
+
+    def _set(self, h):
+        self.destroy()
+        self.handle = h
+
+    def getSize(self):
+        n = lib().das_mat_rows(self.handle)
+        return n, n
+
+    def getInfo(self):
+        return {"nz_used": float(lib().das_mat_nnz(self.handle))}
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+
+        L = lib()
+        n, nnz = L.das_mat_rows(self.handle), L.das_mat_nnz(self.handle)
+        rp = np.empty(n + 1, np.int64)
+        ci = np.empty(nnz, np.int32)
+        v = np.empty(nnz, np.float64)
+        check(L.das_mat_export(self.handle, rp.ctypes.data_as(_capi.c_ll_p), ci.ctypes.data_as(_capi.c_int_p), dptr(v)))
+        return sp.csr_matrix((v, ci, rp), shape=(n, n))
+
+    def mult(self, x: Vec, y: Vec):
+        check(lib().das_mat_mult(self.handle, dptr(x.array), dptr(y.array)))
+
+    def destroy(self):
+        if self.handle:
+            lib().das_mat_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class KSP:
+    """Stand-in for PETSc.KSP (created by the caller, configured by createMLRKSPMatrixFree)."""
+
+    def __init__(self):
+        self.handle = None
+        self._tols = {}
+
+    def create(self, comm=None):
+        return self
+
+    def setTolerances(self, rtol=None, atol=None, divtol=None, max_it=None):
+        # mphys_dafoam.py:597-611 adjusts tolerances on the KSP; forwarded to adjEqnOption at solve time
+        if rtol is not None:
+            self._tols["adjEqnOption.gmresRelTol"] = float(rtol)
+        if atol is not None:
+            self._tols["adjEqnOption.gmresAbsTol"] = float(atol)
+        if max_it is not None:
+            self._tols["adjEqnOption.gmresMaxIters"] = int(max_it)
+
+    def getIterationNumber(self):
+        it = C.c_int(0)
+        check(lib().das_ksp_get_info(self.handle, C.byref(it), None, None, None))
+        return it.value
+
+    def getResidualNorm(self):
+        r = C.c_double(0)
+        check(lib().das_ksp_get_info(self.handle, None, None, C.byref(r), None))
+        return r.value
+
+    def info(self):
+        it, r0, r, sec = C.c_int(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        check(lib().das_ksp_get_info(self.handle, C.byref(it), C.byref(r0), C.byref(r), C.byref(sec)))
+        return dict(iters=it.value, res0=r0.value, res=r.value, seconds=sec.value)
+
+    def history(self):
+        buf = np.zeros(self.getIterationNumber() + 2)
+        m = check(lib().das_ksp_get_history(self.handle, dptr(buf), buf.size))
+        return buf[:m]
+
+    def destroy(self):
+        if self.handle:
+            lib().das_ksp_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def _flatten(prefix, obj, out):
+    for k, v in obj.items():
+        key = f"{prefix}.{k}" if prefix else k
+        if isinstance(v, dict):
+            _flatten(key, v, out)
+        else:
+            out[key] = v
+
+
+# ----------------------------------------------------------------------------- pyDASolvers
+class pyDASolvers:
+    """GPU-backed replacement of the reference's ``pyDASolvers`` extension class.
+
+    ``argsAll`` is the reference's command string (``b"DASimpleFoam -python"``, pyDAFoam.py:1425-1430); its first
+    token must agree with ``pyOptions["solverName"]``.  The reference reads the mesh and fields from the OpenFOAM
+    case in the working directory; here the same data arrives as a :class:`~dafoam_amd.meshgen.FoamCase`
+    (``case=`` keyword or ``pyOptions["amdCase"]``).
+    """
+
+    def __init__(self, argsAll, pyOptions, case: FoamCase = None):
+        if isinstance(argsAll, bytes):
+            argsAll = argsAll.decode()
+        self._args = argsAll
+        case = case if case is not None else pyOptions.get("amdCase")
+        if case is None:
+            raise ValueError("pyDASolvers: a FoamCase is required (case= or pyOptions['amdCase'])")
+        solver = argsAll.split()[0] if argsAll else case.solver_name
+        if solver not in ("DASolvers", case.solver_name):
+            raise ValueError(f"argsAll solver {solver} != case solver {case.solver_name}")
+        self._case = case
+        self._cs = CaseStruct(case)
+        L = lib()
+        self._h = L.das_create(self._cs.byref())
+        if not self._h:
+            raise _capi.DASError(L.das_last_error().decode())
+        self._inited = False
+        self._device = int(pyOptions.get("amdDevice", 0)) if isinstance(pyOptions, dict) else 0
+        self.updateDAOption(pyOptions)
+        if case.states is not None:
+            self.updateOFFields(np.ascontiguousarray(case.states, dtype=np.float64))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().das_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def initSolver(self):
+        check(lib().das_init_solver(self._h, self._device))
+        self._inited = True
+
+    def updateDAOption(self, pyOptions):
+        """pyDASolvers.pyx:355; nested dict -> flattened "a.b" keys (values may be the reference's
+        [type, value] pairs produced by pyDAFoam._getDefOptions, pyDAFoam.py:823-844)."""
+        flat = {}
+        opts = {k: (v[1] if isinstance(v, list) and len(v) == 2 and isinstance(v[0], type) else v) for k, v in pyOptions.items()}
+        _flatten("", {k: v for k, v in opts.items() if not k.startswith("amdCase")}, flat)
+        L = lib()
+        for k, v in flat.items():
+            kb = k.encode()
+            if isinstance(v, bool):
+                check(L.das_set_option_int(self._h, kb, int(v)))
+            elif isinstance(v, int):
+                check(L.das_set_option_int(self._h, kb, v))
+            elif isinstance(v, float):
+                check(L.das_set_option_double(self._h, kb, v))
+            elif isinstance(v, str):
+                check(L.das_set_option_str(self._h, kb, v.encode()))
+            elif isinstance(v, (list, tuple)) and all(isinstance(x, str) for x in v):
+                check(L.das_set_option_str(self._h, kb, ",".join(v).encode()))
+            # other option kinds (nested function dicts, ...) are outside the hot path
+
+    def printAllOptions(self):
+        print("dafoam_amd options are held by the C-ABI; see DAOPTION for defaults")
+
+    # -- sizes -------------------------------------------------------------------------------
+    def getNLocalAdjointStates(self):
+        return int(lib().das_get_n_local_adjoint_states(self._h))
+
+    def getNLocalAdjointBoundaryStates(self):
+        m = self._case.mesh
+        nb = m.n_faces - m.n_internal_faces
+        return (5 if self._case.solver_name == "DASimpleFoam" else 1) * nb
+
+    def getNLocalCells(self):
+        return int(lib().das_get_n_local_cells(self._h))
+
+    def getNGlobalCells(self):
+        return int(lib().das_get_n_global_cells(self._h))
+
+    def getNLocalPoints(self):
+        return int(lib().das_get_n_local_points(self._h))
+
+    def getInputSize(self, inputName, inputType):
+        return check(lib().das_get_input_size(self._h, inputName.encode(), inputType.encode()))
+
+    def getOutputSize(self, outputName, outputType):
+        return check(lib().das_get_output_size(self._h, outputName.encode(), outputType.encode()))
+
+    # -- states / residuals --------------------------------------------------------------------
+    def updateOFFields(self, states):
+        assert len(states) == self.getNLocalAdjointStates(), "invalid array size!"
+        check(lib().das_update_of_fields(self._h, dptr(states)))
+
+    def getOFFields(self, states):
+        assert len(states) == self.getNLocalAdjointStates(), "invalid array size!"
+        check(lib().das_get_of_fields(self._h, dptr(states)))
+
+    def getResiduals(self, residuals):
+        assert len(residuals) == self.getNLocalAdjointStates(), "invalid input array size!"
+        check(lib().das_get_residuals(self._h, dptr(residuals)))
+
+    def calcResiduals(self, isPC, residuals):
+        assert len(residuals) == self.getNLocalAdjointStates(), "invalid input array size!"
+        check(lib().das_calc_residuals(self._h, int(isPC), dptr(residuals)))
+
+    def updateStateBoundaryConditions(self):
+        # boundary values are recomputed inline by every kernel from the state vector: nothing to do
+        return None
+
+    def getOFMeshPoints(self, points):
+        assert len(points) == self.getNLocalPoints() * 3, "invalid array size!"
+        points[:] = self._case.mesh.points.ravel()
+
+    def geometry(self):
+        """fvMesh metrics computed by the library (host side)."""
+        m = self._case.mesh
+        F, Fi, N = m.n_faces, m.n_internal_faces, m.n_cells
+        out = dict(Sf=np.zeros(3 * F), Cf=np.zeros(3 * F), C=np.zeros(3 * N), V=np.zeros(N), w=np.zeros(Fi),
+                   nonOrthDeltaCoeffs=np.zeros(Fi), nonOrthCorr=np.zeros(3 * Fi), bDeltaCoeffs=np.zeros(F - Fi))
+        check(lib().das_get_geometry(self._h, *[dptr(out[k]) for k in
+                                                ("Sf", "Cf", "C", "V", "w", "nonOrthDeltaCoeffs", "nonOrthCorr", "bDeltaCoeffs")]))
+        return out
+
+    # -- colouring / Jacobians -------------------------------------------------------------------
+    def runColoring(self):
+        check(lib().das_run_coloring(self._h))
+
+    def getColoring(self):
+        n = self.getNLocalAdjointStates()
+        col = np.zeros(n, np.int32)
+        check(lib().das_get_colors(self._h, 0, col.ctypes.data_as(_capi.c_int_p)))
+        return col, check(lib().das_get_n_colors(self._h, 0))
+
+    def getConnectivity(self, isPC=0):
+        import scipy.sparse as sp
+
+        n = self.getNLocalAdjointStates()
+        nnz = check(lib().das_get_con_nnz(self._h, int(isPC)))
+        rp = np.zeros(n + 1, np.int64)
+        ci = np.zeros(nnz, np.int32)
+        check(lib().das_get_con(self._h, int(isPC), rp.ctypes.data_as(_capi.c_ll_p), ci.ctypes.data_as(_capi.c_int_p)))
+        return sp.csr_matrix((np.ones(nnz, np.int8), ci, rp), shape=(n, n))
+
+    def calcdRdWT(self, isPC, dRdWT: Mat, mode=None):
+        """pyDASolvers.pyx:237.  mode None: the reference's behaviour for the PC (coloured FD) and exact
+        dual-number assembly for isPC=0."""
+        if mode is None:
+            mode = 0 if isPC else 1
+        h = C.c_void_p()
+        check(lib().das_calc_drdwt(self._h, int(isPC), int(mode), C.byref(h)))
+        dRdWT._set(h)
+
+    def initializedRdWTMatrixFree(self):
+        check(lib().das_initialize_drdwt_matrix_free(self._h))
+
+    def destroydRdWTMatrixFree(self):
+        check(lib().das_destroy_drdwt_matrix_free(self._h))
+
+    def calcJacTVecProduct(self, inputName, inputType, inputs, outputName, outputType, seeds, product):
+        inputSize = self.getInputSize(inputName, inputType)
+        outputSize = self.getOutputSize(outputName, outputType)
+        assert len(inputs) == inputSize, "invalid input array size!"
+        assert len(seeds) == outputSize, "invalid seed array size!"
+        assert len(product) == inputSize, "invalid product array size!"
+        check(lib().das_calc_jac_t_vec_product(
+            self._h, inputName.encode(), inputType.encode(), dptr(inputs), outputName.encode(), outputType.encode(), dptr(seeds), dptr(product)))
+
+    # -- Krylov ----------------------------------------------------------------------------------
+    def createMLRKSPMatrixFree(self, jacPCMat: Mat, myKSP: KSP):
+        h = C.c_void_p()
+        check(lib().das_create_ml_rksp_matrix_free(self._h, jacPCMat.handle, C.byref(h)))
+        myKSP.destroy()
+        myKSP.handle = h
+        myKSP._pc = jacPCMat  # keep the PC matrix alive as long as the KSP
+
+    def updateKSPPCMat(self, PCMat: Mat, myKSP: KSP):
+        self.createMLRKSPMatrixFree(PCMat, myKSP)
+
+    def solveLinearEqn(self, myKSP: KSP, rhsVec: Vec, solVec: Vec):
+        L = lib()
+        for k, v in myKSP._tols.items():
+            (L.das_set_option_int if isinstance(v, int) else L.das_set_option_double)(self._h, k.encode(), v)
+        return check(L.das_solve_linear_eqn(self._h, myKSP.handle, dptr(rhsVec.array), dptr(solVec.array)))
+
+    # -- timing ----------------------------------------------------------------------------------
+    def getElapsedClockTime(self):
+        return lib().das_get_elapsed_clock_time(self._h)
+
+    def getElapsedCpuTime(self):
+        return lib().das_get_elapsed_cpu_time(self._h)
+
+    # -- not on the hot path -----------------------------------------------------------------------
+    def solvePrimal(self):
+        raise NotImplementedError("primal solve is upstream of the adjoint hot path (SURVEY.md section 8f)")

@@ -1,0 +1,177 @@
+"""ORACLE (test infrastructure only - never imported by the product path).
+
+CPU restatement of the reference's Krylov solve (reference src/adjoint/DALinearEqn/DALinearEqn.C:28-339
+createMLRKSP: restarted GMRES, right preconditioning, classical Gram-Schmidt with refinement, ILU(k)
+sub-solves, unpreconditioned residual norm; :341-437 solveLinearEqn with the gmresTolDiff failure rule
+:422-434; defaults reference dafoam/pyDAFoam.py:526-548).  PETSc itself is un-vendored: PARITY UNPINNED;
+the solver is pinned by scipy's sparse direct solve in tests/ (psi is preconditioner independent).
+
+The C kernels live in oracle/csrc/oracle_linalg.c (built on demand with gcc into oracle/_build/).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "csrc", "oracle_linalg.c")
+_SO = os.path.join(_HERE, "_build", "liboracle_linalg.so")
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_lp = C.POINTER(C.c_longlong)
+
+
+def build(force=False):
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", _SO, _SRC, "-lm"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.csr_spmv.argtypes = [C.c_longlong, _lp, _ip, _dp, _dp, _dp]
+        L.ilu_symbolic.restype = C.c_void_p
+        L.ilu_symbolic.argtypes = [C.c_longlong, _lp, _ip, C.c_int]
+        L.ilu_nnz.restype = C.c_longlong
+        L.ilu_nnz.argtypes = [C.c_void_p]
+        L.ilu_get.argtypes = [C.c_void_p, _lp, _ip, _lp]
+        L.ilu_free.argtypes = [C.c_void_p]
+        L.ilu_numeric.restype = C.c_int
+        L.ilu_numeric.argtypes = [C.c_longlong, _lp, _ip, _dp, _lp, _ip, _lp, _dp, C.c_double]
+        L.ilu_solve.argtypes = [C.c_longlong, _lp, _ip, _lp, _dp, _dp, _dp]
+        L.multi_dot.argtypes = [C.c_longlong, C.c_int, _dp, _dp, _dp]
+        L.multi_axpy.argtypes = [C.c_longlong, C.c_int, _dp, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class CSR:
+    def __init__(self, A):
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        self.n = A.shape[0]
+        self.rp = A.indptr.astype(np.int64)
+        self.ci = A.indices.astype(np.int32)
+        self.v = np.ascontiguousarray(A.data, dtype=np.float64)
+
+    def matvec(self, x):
+        y = np.empty(self.n)
+        lib().csr_spmv(self.n, _p(self.rp, _lp), _p(self.ci, _ip), _p(self.v, _dp), _p(np.ascontiguousarray(x), _dp), _p(y, _dp))
+        return y
+
+
+class ILU:
+    """ILU(k) of a CSR matrix (natural ordering), optional block-Jacobi restriction:
+    blocks = array of block id per row -> entries coupling different blocks are dropped before
+    factorisation (additive Schwarz with zero overlap, one block per 'subdomain')."""
+
+    def __init__(self, A, fill=0, blocks=None, shift=1e-12):
+        A = sp.csr_matrix(A)
+        if blocks is not None:
+            A = A.tocoo()
+            keep = blocks[A.row] == blocks[A.col]
+            A = sp.csr_matrix((A.data[keep], (A.row[keep], A.col[keep])), shape=A.shape)
+        A.sort_indices()
+        a = CSR(A)
+        L = lib()
+        h = L.ilu_symbolic(a.n, _p(a.rp, _lp), _p(a.ci, _ip), fill)
+        nnz = L.ilu_nnz(h)
+        self.n = a.n
+        self.rp = np.empty(a.n + 1, np.int64)
+        self.ci = np.empty(nnz, np.int32)
+        self.diag = np.empty(a.n, np.int64)
+        L.ilu_get(h, _p(self.rp, _lp), _p(self.ci, _ip), _p(self.diag, _lp))
+        L.ilu_free(h)
+        self.v = np.empty(nnz)
+        self.nshift = L.ilu_numeric(
+            a.n, _p(a.rp, _lp), _p(a.ci, _ip), _p(a.v, _dp), _p(self.rp, _lp), _p(self.ci, _ip), _p(self.diag, _lp), _p(self.v, _dp), shift
+        )
+
+    def solve(self, b):
+        x = np.empty(self.n)
+        lib().ilu_solve(self.n, _p(self.rp, _lp), _p(self.ci, _ip), _p(self.diag, _lp), _p(self.v, _dp), _p(np.ascontiguousarray(b), _dp), _p(x, _dp))
+        return x
+
+
+def gmres(matvec, rhs, pc_solve=None, x0=None, restart=1000, max_iters=1000, rel_tol=1e-6, abs_tol=1e-14, tol_diff=1e2,
+          fixed_iters=None):
+    """Right-preconditioned restarted GMRES, CGS with one refinement pass (CGS2), Givens rotations,
+    unpreconditioned residual norm.  Returns (x, info) with info = dict(iters, res0, res, hist, fail)
+    where fail follows the reference rule DALinearEqn.C:422-434."""
+    n = rhs.size
+    x = np.zeros(n) if x0 is None else x0.copy()
+    M = pc_solve if pc_solve is not None else (lambda v: v)
+    L = lib()
+    r = rhs - matvec(x) if x0 is not None else rhs.copy()
+    beta = np.linalg.norm(r)
+    res0 = beta
+    hist = [beta]
+    its = 0
+    target = max(rel_tol * res0, abs_tol)
+    done = beta <= target and fixed_iters is None
+    while not done:
+        m = min(restart, (fixed_iters if fixed_iters is not None else max_iters) - its)
+        if m <= 0:
+            break
+        V = np.zeros((m + 1, n))
+        H = np.zeros((m + 1, m))
+        cs = np.zeros(m)
+        sn = np.zeros(m)
+        gvec = np.zeros(m + 1)
+        V[0] = r / beta
+        gvec[0] = beta
+        j = 0
+        while j < m:
+            w = matvec(M(V[j]))
+            h = np.empty(j + 1)
+            L.multi_dot(n, j + 1, _p(V, _dp), _p(w, _dp), _p(h, _dp))
+            L.multi_axpy(n, j + 1, _p(V, _dp), _p(h, _dp), _p(w, _dp))
+            h2 = np.empty(j + 1)
+            L.multi_dot(n, j + 1, _p(V, _dp), _p(w, _dp), _p(h2, _dp))
+            L.multi_axpy(n, j + 1, _p(V, _dp), _p(h2, _dp), _p(w, _dp))
+            h += h2
+            hn = np.linalg.norm(w)
+            H[: j + 1, j] = h
+            H[j + 1, j] = hn
+            if hn > 0:
+                V[j + 1] = w / hn
+            for i in range(j):
+                t = cs[i] * H[i, j] + sn[i] * H[i + 1, j]
+                H[i + 1, j] = -sn[i] * H[i, j] + cs[i] * H[i + 1, j]
+                H[i, j] = t
+            d = np.hypot(H[j, j], H[j + 1, j])
+            cs[j], sn[j] = H[j, j] / d, H[j + 1, j] / d
+            H[j, j] = d
+            H[j + 1, j] = 0.0
+            gvec[j + 1] = -sn[j] * gvec[j]
+            gvec[j] = cs[j] * gvec[j]
+            its += 1
+            j += 1
+            res = abs(gvec[j])
+            hist.append(res)
+            if fixed_iters is None and (res <= target or its >= max_iters):
+                break
+        y = np.linalg.solve(np.triu(H[:j, :j]), gvec[:j])
+        x = x + M(V[:j].T @ y)
+        r = rhs - matvec(x)
+        beta = np.linalg.norm(r)
+        hist[-1] = beta
+        if fixed_iters is not None:
+            done = its >= fixed_iters
+        else:
+            done = beta <= target or its >= max_iters
+    res = hist[-1]
+    fail = int((res / res0 / rel_tol > tol_diff) and (res / abs_tol > tol_diff)) if res0 > 0 else 0
+    return x, dict(iters=its, res0=res0, res=res, hist=np.array(hist), fail=fail)

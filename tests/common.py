@@ -1,0 +1,20 @@
+import numpy as np
+
+NORM_STATES = {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0}  # reference tests/runRegTests_AeroOpt.py:83
+
+
+def blocks(case, g):
+    N = g.nC
+    if case.solver_name == "DASimpleFoam":
+        return (("U", slice(0, 3 * N)), ("p", slice(3 * N, 4 * N)), ("nuTilda", slice(4 * N, 5 * N)), ("phi", slice(5 * N, 5 * N + g.nF)))
+    return (("T", slice(0, N)),)
+
+
+def relerr(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def options(case, **extra):
+    o = {"solverName": case.solver_name, "normalizeStates": dict(NORM_STATES, T=1.0), "adjEqnOption": {"printInfo": 0}}
+    o.update(extra)
+    return o

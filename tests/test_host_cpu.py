@@ -1,0 +1,138 @@
+"""CPU tier: host logic of the product (mesh metrics, connectivity, colouring, option surface), the C-ABI
+library (loads, exports every declared symbol, fails loudly without a GPU) and the kernel *bodies* run through
+the host-emulation harness (tests/hostemu) against the oracle.  No GPU compute here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from common import NORM_STATES, blocks, options, relerr
+from dafoam_amd import _capi
+from dafoam_amd._capi import CaseStruct, das_case_t, dptr
+from dafoam_amd.meshgen import channel_case, scalar_transport_case
+from dafoam_amd.pyDASolvers import pyDASolvers
+from oracle import jacobian as J
+from oracle.foam_mesh import Geometry
+from oracle.residual import residual
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAS_GPU = _capi.lib().das_device_count() > 0
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dafoam_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(das_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_capi.declared_symbols()), declared ^ set(_capi.declared_symbols())
+    L = C.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _capi.lib().das_version() >= 100
+
+
+@pytest.mark.skipif(HAS_GPU, reason="only meaningful on a CPU-only host")
+def test_compute_path_fails_loudly_without_gpu():
+    case = channel_case(4, 4, 3)
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    with pytest.raises(_capi.DASError, match="no HIP device"):
+        s.initSolver()
+    with pytest.raises(_capi.DASError, match="das_init_solver has not been called"):
+        s.getResiduals(np.zeros(s.getNLocalAdjointStates()))
+
+
+@pytest.mark.parametrize("solver", ["DASimpleFoam", "DAScalarTransportFoam"])
+def test_mesh_metrics_connectivity_and_colouring_match_oracle(solver):
+    case = channel_case(7, 6, 5) if solver == "DASimpleFoam" else scalar_transport_case(6, 5, 4)
+    s = pyDASolvers((solver + " -python").encode(), options(case), case=case)
+    g = Geometry(case.mesh)
+    geo = s.geometry()
+    assert np.abs(geo["Sf"].reshape(-1, 3) - g.Sf).max() < 1e-15
+    assert np.abs(geo["C"].reshape(-1, 3) - g.C).max() < 1e-13
+    assert relerr(geo["V"], g.V) < 1e-13 and relerr(geo["w"], g.w) < 1e-13
+    assert relerr(geo["nonOrthDeltaCoeffs"], g.nonOrthDeltaCoeffs) < 1e-12
+    assert np.abs(geo["nonOrthCorr"].reshape(-1, 3) - g.nonOrthCorr).max() < 1e-11
+    assert relerr(geo["bDeltaCoeffs"], g.bDeltaCoeffs) < 1e-12
+    assert s.getNLocalAdjointStates() == case.states.size
+    s.runColoring()
+    for pc in (0, 1):
+        assert (s.getConnectivity(pc) != J.connectivity(case, g, isPC=bool(pc))).nnz == 0
+    col, nc = s.getColoring()
+    assert J.validate_coloring(J.connectivity(case, g), col.astype(np.int64)) and nc == col.max() + 1
+
+
+def test_option_surface_and_type_checks():
+    from dafoam_amd.pyDAFoam import DAOPTION, Error, PYDAFOAM
+
+    d = DAOPTION()
+    # defaults of the reference (dafoam/pyDAFoam.py:526-548, 390-392, 568-589, 608, 628)
+    assert d.adjEqnOption["gmresRestart"] == 1000 and d.adjEqnOption["gmresRelTol"] == 1e-6
+    assert d.adjEqnOption["pcFillLevel"] == 1 and d.adjEqnOption["asmOverlap"] == 1
+    assert d.adjPartDerivFDStep == {"State": 1e-6} and d.jacLowerBounds["dRdWPC"] == 1e-30
+    assert d.maxResConLv4JacPCMat["pRes"] == 2 and d.maxResConLv4JacPCMat["phiRes"] == 1
+    assert d.adjStateOrdering == "state" and d.maxCorrectBCCalls == 2 and d.useConstrainHbyA is True
+    case = channel_case(4, 4, 3)
+    if not HAS_GPU:
+        with pytest.raises(Exception):
+            PYDAFOAM(options=options(case), case=case)  # init must fail loudly without a GPU
+    with pytest.raises(Error):
+        PYDAFOAM(options={"adjEqnOption": 3}, case=case)  # type mismatch (pyDAFoam.py:2029-2033)
+    with pytest.raises(Error):
+        PYDAFOAM(options={"noSuchOption": 1}, case=case)
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    with pytest.raises(_capi.DASError):
+        s.updateDAOption({"adjStateOrdering": "cell"})  # not implemented -> loud error
+    v = C.c_double()
+    _capi.check(_capi.lib().das_get_option_double(s._h, b"normalizeStates.U", C.byref(v)))
+    assert v.value == 10.0
+    x = np.zeros(s.getNLocalAdjointStates())
+    s.getOFFields(x)
+    assert np.array_equal(x, case.states)
+    with pytest.raises(AssertionError):
+        s.updateOFFields(np.zeros(3))  # invalid array size, like pyDASolvers.pyx:269
+
+
+# ---- kernel bodies through the host-emulation harness ------------------------------------------------
+def _emu():
+    L = C.CDLL(os.path.join(ROOT, "tests", "hostemu", "libhostemu.so"))
+    L.emu_residual.argtypes = [C.POINTER(das_case_t), _capi.c_double_p, C.c_longlong, C.c_int, _capi.c_double_p, _capi.c_double_p, _capi.c_double_p]
+    return L
+
+
+def _emu_res(case, W, isPC=0, d=None):
+    cs = CaseStruct(case)
+    n = W.size
+    Rv, Rd = np.zeros(n), np.zeros(n)
+    rc = _emu().emu_residual(cs.byref(), dptr(W), n, isPC, dptr(d) if d is not None else None, dptr(Rv), dptr(Rd))
+    assert rc == 0
+    return Rv, Rd
+
+
+@pytest.mark.parametrize("wall_function", [False, True])
+@pytest.mark.parametrize("isPC", [0, 1])
+def test_kernel_bodies_match_oracle_simplefoam(wall_function, isPC):
+    case = channel_case(7, 7, 7, wall_function=wall_function)
+    g = Geometry(case.mesh)
+    W = case.states
+    Ro = residual(case, g, W, isPC=bool(isPC))
+    Rv, _ = _emu_res(case, W, isPC)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rv[sl], Ro[sl]) < 1e-12, nm
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(W.size) * J.state_scales(case, g, NORM_STATES)
+    cs = residual(case, g, W + 1j * 1e-30 * v, isPC=bool(isPC)).imag / 1e-30
+    _, Rd = _emu_res(case, W, isPC, v)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rd[sl], cs[sl]) < 1e-10, nm
+
+
+def test_kernel_bodies_match_oracle_scalar_transport():
+    case = scalar_transport_case(8, 7, 6)
+    g = Geometry(case.mesh)
+    W = case.states
+    Rv, _ = _emu_res(case, W)
+    assert relerr(Rv, residual(case, g, W)) < 1e-13
+    v = np.random.default_rng(0).standard_normal(W.size)
+    _, Rd = _emu_res(case, W, 0, v)
+    assert relerr(Rd, residual(case, g, W + 1j * 1e-30 * v).imag / 1e-30) < 1e-12

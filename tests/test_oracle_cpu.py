@@ -1,0 +1,142 @@
+"""CPU tier: pins the oracle itself (parity with the reference is UNPINNED - see oracle/ headers - so the
+oracle is anchored by algebraic identities and by the reference's own structural numbers)."""
+import numpy as np
+import pytest
+import scipy.sparse.linalg as spla
+
+from common import NORM_STATES, blocks, relerr
+from dafoam_amd.meshgen import channel_case, scalar_transport_case
+from oracle import jacobian as J
+from oracle import linear as OL
+from oracle.foam_mesh import Geometry
+from oracle.residual import residual
+
+
+def test_glibc_tiebreak_restatement_matches_libc():
+    # reference DAColoring.C:270-275: srand(i); rand() % nColG
+    seeds = [0, 1, 2, 3, 17, 1000, 123456, 2**31 - 1]
+    assert list(J.glibc_first_rand(np.array(seeds))) == [J.libc_first_rand(s) for s in seeds]
+
+
+def test_geometry_identities():
+    case = channel_case(6, 5, 4)
+    g = Geometry(case.mesh)
+    # closed cells: sum of outward face vectors = 0 ; box volume by divergence theorem
+    acc = np.zeros((g.nC, 3))
+    np.add.at(acc, g.own, g.Sf)
+    np.add.at(acc, g.nei, -g.Sf[: g.nIF])
+    assert np.abs(acc).max() < 1e-15
+    vol = (g.Cf[g.nIF:] * g.Sf[g.nIF:]).sum() / 3.0
+    assert abs(vol - g.V.sum()) < 1e-12 * vol
+    assert np.all(g.V > 0) and np.all((g.w > 0) & (g.w < 1))
+
+
+@pytest.mark.parametrize("wall_function", [False, True])
+@pytest.mark.parametrize("isPC", [False, True])
+def test_complex_step_equals_finite_difference(wall_function, isPC):
+    case = channel_case(6, 6, 5, wall_function=wall_function)
+    g = Geometry(case.mesh)
+    W = case.states
+    rng = np.random.default_rng(1)
+    sc = J.state_scales(case, g, NORM_STATES)
+    v = rng.standard_normal(W.size) * sc
+    cs = residual(case, g, W + 1j * 1e-30 * v, isPC=isPC).imag / 1e-30
+    eps = 1e-6
+    fd = (residual(case, g, W + eps * v, isPC=isPC) - residual(case, g, W - eps * v, isPC=isPC)) / (2 * eps)
+    assert relerr(fd, cs) < 1e-7
+
+
+def test_stencil_row_lengths_match_reference_tables():
+    # interior hex rows URes 95, pRes 275 (PC 161), phiRes 149 (PC 71), nuTildaRes 52
+    case = channel_case(9, 9, 9)
+    g = Geometry(case.mesh)
+    N = g.nC
+    c = 4 + 9 * (4 + 9 * 4)
+    f = np.nonzero((g.own[: g.nIF] == c) & (g.nei == c + 1))[0][0]
+    for pc, want in ((False, (95, 275, 52, 149)), (True, (95, 161, 52, 71))):
+        rl = np.diff(J.connectivity(case, g, isPC=pc).indptr)
+        assert (rl[3 * c], rl[3 * N + c], rl[4 * N + c], rl[5 * N + f]) == want
+
+
+@pytest.mark.parametrize("solver", ["DASimpleFoam", "DAScalarTransportFoam"])
+def test_bruteforce_jacobian_inside_stencil_and_equals_coloured(solver):
+    case = channel_case(4, 4, 3) if solver == "DASimpleFoam" else scalar_transport_case(5, 4, 3)
+    g = Geometry(case.mesh)
+    W = case.states
+    sc = J.state_scales(case, g, dict(NORM_STATES, T=1.0))
+    con = J.connectivity(case, g)
+    A_bf = J.jacobian_bruteforce(case, g, W, sc)
+    pat = con.T.toarray() > 0
+    assert not np.any((np.abs(A_bf) > 0) & ~pat), "residual depends on a state outside the reference stencil tables"
+    col, nc = J.d2_coloring(con)  # the reference's sweep algorithm
+    assert J.validate_coloring(con, col)
+    A = J.jacobian_colored(case, g, W, con, col, sc, mode="cs", lower_bound=0).toarray()
+    assert np.abs(A - A_bf).max() <= 1e-12 * np.abs(A_bf).max()
+    Afd = J.jacobian_colored(case, g, W, con, col, sc, mode="fd", lower_bound=0).toarray()
+    assert np.abs(Afd - A_bf).max() <= 1e-4 * np.abs(A_bf).max()
+    # greedy colouring gives the same Jacobian (colours are not observable in the result)
+    col2, _ = J.greedy_coloring(con)
+    A2 = J.jacobian_colored(case, g, W, con, col2, sc, mode="cs", lower_bound=0).toarray()
+    assert np.abs(A2 - A_bf).max() <= 1e-12 * np.abs(A_bf).max()
+
+
+def test_colored_columns_example_of_reference_docstring():
+    # DAPartDeriv::setPartDerivMat docstring example (DAPartDeriv.C:130-166)
+    import scipy.sparse as sp
+
+    con = sp.csr_matrix(np.array([[1, 0, 0, 0], [0, 1, 1, 0], [0, 0, 1, 0], [0, 0, 0, 1]]))
+    colors = np.array([0, 0, 1, 0])
+    assert J.validate_coloring(con, colors)
+    assert not J.validate_coloring(con, np.array([0, 1, 1, 0]))
+    assert list(J.colored_columns(con, colors, 0)) == [0, 1, -1, 3]
+    assert list(J.colored_columns(con, colors, 1)) == [-1, 2, 2, -1]
+
+
+def test_ilu_full_fill_is_lu_and_gmres_matches_direct():
+    rng = np.random.default_rng(0)
+    import scipy.sparse as sp
+
+    n = 80
+    A = sp.random(n, n, 0.1, random_state=3).toarray() + 4 * np.eye(n)
+    b = rng.standard_normal(n)
+    assert relerr(OL.ILU(A, fill=n).solve(b), np.linalg.solve(A, b)) < 1e-12
+    x, info = OL.gmres(lambda v: A @ v, b, OL.ILU(A, fill=0).solve, rel_tol=1e-12, restart=30)
+    assert relerr(x, np.linalg.solve(A, b)) < 1e-9 and info["fail"] == 0
+    # failure rule of the reference (DALinearEqn.C:422-434)
+    x, info = OL.gmres(lambda v: A @ v, b, None, rel_tol=1e-14, max_iters=2, restart=2)
+    assert info["fail"] == 1
+
+
+def test_oracle_adjoint_small_channel():
+    case = channel_case(6, 6, 5)
+    g = Geometry(case.mesh)
+    W = case.states
+    sc = J.state_scales(case, g, NORM_STATES)
+    con = J.connectivity(case, g)
+    col, _ = J.greedy_coloring(con)
+    A = J.jacobian_colored(case, g, W, con, col, sc, mode="cs", lower_bound=0)
+    P = J.jacobian_colored(case, g, W, J.connectivity(case, g, isPC=True), col, sc, mode="fd", isPC=True)
+    rhs = np.zeros(W.size)
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= sc
+    psi = spla.spsolve(A.tocsc(), rhs)
+    x, info = OL.gmres(OL.CSR(A).matvec, rhs, OL.ILU(P, fill=0).solve, rel_tol=1e-10, restart=300)
+    assert info["fail"] == 0 and relerr(x, psi) < 1e-7
+    # dot-product test <psi, J v> = <J^T psi, v>  (J v by complex step, J^T psi from the assembled matrix)
+    rng = np.random.default_rng(2)
+    v, ps = rng.standard_normal(W.size), rng.standard_normal(W.size)
+    Jv = residual(case, g, W + 1j * 1e-30 * (sc * v)).imag / 1e-30
+    assert abs(ps @ Jv - (A @ ps) @ v) < 1e-10 * abs(ps @ Jv)
+
+
+def test_golden_fixture_regression():
+    """tests/golden/oracle_channel_443.npz is produced by tests/golden/make_golden.py from the oracle (the
+    reference cannot be run here); it freezes the oracle against silent edits."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_channel_443.npz"))
+    case = channel_case(4, 4, 3)
+    g = Geometry(case.mesh)
+    assert relerr(case.states, z["W"]) < 1e-15
+    assert relerr(residual(case, g, case.states), z["R"]) < 1e-13
+    assert relerr(residual(case, g, case.states, isPC=True), z["R_pc"]) < 1e-13
