@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""bench.py - adjoint hot-path benchmark (BASELINE.json metric: adjoint GMRES iterations/s + dRdWTPsi GB/s).
+
+One "step" = one right-preconditioned GMRES iteration of the adjoint solve (block-ILU(0) apply + dRdW^T.z SpMV +
+CGS2 orthogonalisation + norm) on the device-resident system assembled by coloured dual-number / FD perturbation
+of the HIP residual.  Inputs (matrices, rhs, Krylov basis) are resident in HBM when the timed region starts.
+
+  python bench.py --gpus 1 --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = transposed-CSR SpMV, HIP-event timed on the
+launch stream) and `cpu_baseline` (the oracle's C kernels on the host, bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nx", type=int, default=int(os.environ.get("DAS_BENCH_NX", 100)))
+    ap.add_argument("--ny", type=int, default=int(os.environ.get("DAS_BENCH_NY", 50)))
+    ap.add_argument("--nz", type=int, default=int(os.environ.get("DAS_BENCH_NZ", 40)))
+    ap.add_argument("--cpu-sample-iters", type=int, default=int(os.environ.get("DAS_BENCH_CPU_ITERS", 6)))
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+
+    ge.build()
+    from dafoam_amd import _capi
+    from dafoam_amd.meshgen import channel_case
+    from dafoam_amd.pyDAFoam import PYDAFOAM
+    from dafoam_amd.pyDASolvers import KSP, Mat
+
+    t_setup = time.time()
+    # weak scaling: every rank owns a same-size cell partition (slab along x) of the global channel
+    case = channel_case(a.nx, a.ny, a.nz, lengths=(2.0 * world, 0.2, 0.2), grading_y=4.0, seed=rank)
+    ncell = case.mesh.n_cells
+    opts = {
+        "solverName": "DASimpleFoam",
+        "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0},
+        "adjEqnOption": {"gmresRestart": max(a.steps, a.warmup, 1), "gmresMaxIters": 100000, "gmresRelTol": 1e-30,
+                         "gmresAbsTol": 1e-300, "printInfo": 0},
+        "amdDevice": local_rank,
+    }
+    D = PYDAFOAM(options=opts, case=case)
+    L = _capi.lib()
+    h = D.solver._h
+    n = D.getNLocalAdjointStates()
+    t0 = time.time()
+    D.solver.runColoring()
+    t_color = time.time() - t0
+    _, ncolors = D.solver.getColoring()
+    t0 = time.time()
+    pc = Mat()
+    D.solver.calcdRdWT(1, pc)
+    t_pcmat = time.time() - t0
+    ksp = KSP()
+    t0 = time.time()
+    D.solverAD.createMLRKSPMatrixFree(pc, ksp)
+    t_ilu = time.time() - t0
+    t0 = time.time()
+    D.solverAD.initializedRdWTMatrixFree()
+    t_op = time.time() - t0
+    # operator nnz
+    op_nnz = None
+    # rhs on the device (torch owns the buffers; the C-ABI gets raw pointers)
+    rng = np.random.default_rng(1234 + rank)
+    rhs = torch.from_numpy(rng.standard_normal(n)).cuda()
+    sol = torch.zeros(n, dtype=torch.float64, device="cuda")
+    setup_s = time.time() - t_setup
+
+    def run(iters):
+        rc = L.das_ksp_run_fixed_device(h, ksp.handle, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()), int(iters))
+        if rc < 0:
+            raise RuntimeError(L.das_last_error().decode())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if a.warmup > 0:
+        run(a.warmup)
+    L.das_timer_reset(h)
+    L.das_timer_enable(h, 1)
+    barrier()
+    t0 = time.perf_counter()
+    run(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    L.das_timer_enable(h, 0)
+    spmv_ms = L.das_timer_avg_ms(h, b"spmv")
+    spmv_cnt = L.das_timer_count(h, b"spmv")
+    pc_ms = L.das_timer_avg_ms(h, b"pc")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # operator size (for the algorithmic-bytes formula of SURVEY.md section 8d / BASELINE.md section 3)
+    opmat_nnz = int(L.das_get_con_nnz(h, 0))
+    # the operator drops exact zeros (jacLowerBounds 1e-30): use its true nnz
+    op_nnz = int(L.das_op_nnz(h))
+    spmv_bytes = 12.0 * op_nnz + 4.0 * (n + 1) + 16.0 * n
+    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms and spmv_ms > 0 else None
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if not a.no_cpu and world == 1:
+            cpu = cpu_baseline(D, pc, a.cpu_sample_iters, n)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "spmv_traffic_bytes.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "adjoint_gmres_iterations_per_sec",
+            "value": a.steps * 1.0 / dt,
+            "unit": "iter/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"DASimpleFoam+SA adjoint, synthetic bump-channel hex mesh {a.nx}x{a.ny}x{a.nz} = {ncell} cells per GPU "
+                            f"(stand-in for BASELINE configs[1] NACA0012 ~200k cells: same solver, 8 states/cell, reference stencil tables)",
+                "cells_per_gpu": ncell,
+                "states_per_gpu": n,
+                "dRdWT_nnz": op_nnz,
+                "dRdWT_structural_nnz": opmat_nnz,
+                "colors": int(ncolors),
+                "gmres_restart": max(a.steps, a.warmup, 1),
+                "pc": "block-ILU(0) of FD dRdWTPC, one workgroup per block",
+                "setup_seconds": {"total": setup_s, "coloring_host": t_color, "dRdWTPC_fd": t_pcmat, "ilu_host": t_ilu, "dRdWT_dual": t_op},
+                "dRdWTPsi_GBps": achieved,
+                "spmv_ms": spmv_ms,
+                "pc_apply_ms": pc_ms,
+            },
+            "roofline": {
+                "kernel": "k_spmv (dRdW^T.psi, transposed CSR fp64/int32)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                "traffic": traffic,
+                "launches_timed": int(spmv_cnt),
+                "algorithmic_bytes_per_launch": spmv_bytes,
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    return out
+
+
+def cpu_baseline(D, pc, iters, n):
+    """The oracle's C kernels (oracle/csrc/oracle_linalg.c: CSR SpMV, ILU(0) solve, CGS2) timed on ONE host core on
+    the same matrices (exported from HBM): `iters` GMRES iterations.  kind = "port" (CPU restatement, not DAFoam)."""
+    from oracle import linear as OL
+    from dafoam_amd.pyDASolvers import Mat
+    import ctypes as C
+    from dafoam_amd import _capi
+
+    t0 = time.time()
+    # export the operator: re-assemble into a Mat handle to read it back
+    A = Mat()
+    D.solver.calcdRdWT(0, A, mode=1)
+    Ah = A.to_scipy()
+    Ph = pc.to_scipy()
+    A.destroy()
+    ilu = OL.ILU(Ph, fill=0)
+    Ac = OL.CSR(Ah)
+    rng = np.random.default_rng(1234)
+    rhs = rng.standard_normal(n)
+    prep = time.time() - t0
+    t0 = time.perf_counter()
+    x, info = OL.gmres(Ac.matvec, rhs, ilu.solve, restart=iters, fixed_iters=iters)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    Ac.matvec(rhs)
+    t_spmv = time.perf_counter() - t1
+    return {
+        "value": iters / dt,
+        "unit": "iter/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{iters} GMRES iterations (oracle C SpMV + ILU(0) + CGS2, gcc -O3 -march=native) on the same dRdWT/dRdWTPC "
+                  f"matrices copied back from HBM; one oracle SpMV = {t_spmv*1e3:.1f} ms; export+ILU prep {prep:.1f} s (untimed)",
+        "spmv_GBps": (12.0 * Ah.nnz + 4.0 * (n + 1) + 16.0 * n) / t_spmv / 1e9,
+    }
+
+
+if __name__ == "__main__":
+    main()

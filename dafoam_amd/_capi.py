@@ -169,6 +169,7 @@ _SIGS = {
     "das_mat_destroy": (None, [_VP]),
     "das_initialize_drdwt_matrix_free": (C.c_int, [_VP]),
     "das_destroy_drdwt_matrix_free": (C.c_int, [_VP]),
+    "das_op_nnz": (C.c_longlong, [_VP]),
     "das_get_input_size": (C.c_int, [_VP, C.c_char_p, C.c_char_p]),
     "das_get_output_size": (C.c_int, [_VP, C.c_char_p, C.c_char_p]),
     "das_calc_jac_t_vec_product": (

@@ -1090,6 +1090,8 @@ int das_destroy_drdwt_matrix_free(das_solver_t* s) {
     DAS_CATCH
 }
 
+long long das_op_nnz(das_solver_t* s) { return (s && s->op) ? s->op->m.nnz : -1; }
+
 int das_get_input_size(das_solver_t* s, const char* inputName, const char* inputType) {
     DAS_TRY
     DAS_CHECK(s && inputType, DAS_ERR_ARG, "null argument");

@@ -156,6 +156,8 @@ void das_mat_destroy(das_mat_t* m);
  * das_destroy_drdwt_matrix_free    <- destroydRdWTMatrixFree()      pyDASolvers.pyx:256 */
 int das_initialize_drdwt_matrix_free(das_solver_t* s);
 int das_destroy_drdwt_matrix_free(das_solver_t* s);
+/* nnz of the assembled matrix-free operator (after the jacLowerBounds filter), -1 if not initialised */
+long long das_op_nnz(das_solver_t* s);
 
 /* das_calc_jac_t_vec_product <- calcJacTVecProduct(inputName,inputType,inputs,outputName,outputType,seeds,product)
  *   pyDASolvers.pyx:208-235 (DASolver.C:1690-1839).  Supported pair on this path: inputType "stateVar",
