@@ -179,6 +179,9 @@ _SIGS = {
     "das_drdwt_mult_device": (C.c_int, [_VP, _VP, _VP]),
     "das_create_ml_rksp_matrix_free": (C.c_int, [_VP, _VP, C.POINTER(_VP)]),
     "das_solve_linear_eqn": (C.c_int, [_VP, _VP, c_double_p, c_double_p]),
+    "das_ksp_apply_pc": (C.c_int, [_VP, _VP, c_double_p, c_double_p]),
+    "das_ksp_get_n_blocks": (C.c_int, [_VP]),
+    "das_ksp_get_blocks": (C.c_int, [_VP, c_int_p, c_ll_p]),
     "das_ksp_get_info": (C.c_int, [_VP, c_int_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_get_history": (C.c_int, [_VP, c_double_p, C.c_int]),
     "das_ksp_run_fixed_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),

@@ -568,9 +568,34 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     std::vector<double> av = A.val.to_host();
     const Mesh& m = s->mesh;
     long long bc = std::max<long long>(64, s->opt.geti("amd.pcBlockCells"));
-    int nB = (int)((m.nC + bc - 1) / bc);
-    // balance block sizes
-    bc = (m.nC + nB - 1) / nB;
+    // compact sub-domains by recursive coordinate bisection of the cell centres (the reference decomposes with
+    // scotch, pyDAFoam.py:597-604; RCB gives comparable compact blocks without a graph library)
+    std::vector<int> cellOrder(m.nC);
+    std::iota(cellOrder.begin(), cellOrder.end(), 0);
+    std::vector<long long> cboff;  // block offsets into cellOrder
+    {
+        struct Range { long long b, e; };
+        std::vector<Range> stack{{0, (long long)m.nC}}, leaves;
+        while (!stack.empty()) {
+            Range r = stack.back();
+            stack.pop_back();
+            if (r.e - r.b <= bc) { leaves.push_back(r); continue; }
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (long long q = r.b; q < r.e; q++)
+                for (int d = 0; d < 3; d++) { double x = m.cg[cellOrder[q]].C[d]; lo[d] = std::min(lo[d], x); hi[d] = std::max(hi[d], x); }
+            int dim = 0;
+            for (int d = 1; d < 3; d++) if (hi[d] - lo[d] > hi[dim] - lo[dim]) dim = d;
+            long long mid = (r.b + r.e) / 2;
+            std::nth_element(cellOrder.begin() + r.b, cellOrder.begin() + mid, cellOrder.begin() + r.e,
+                             [&](int a, int b2) { double xa = m.cg[a].C[dim], xb = m.cg[b2].C[dim]; return xa < xb || (xa == xb && a < b2); });
+            stack.push_back({mid, r.e});
+            stack.push_back({r.b, mid});
+        }
+        std::sort(leaves.begin(), leaves.end(), [](const Range& a, const Range& b2) { return a.b < b2.b; });
+        for (auto& r : leaves) { std::sort(cellOrder.begin() + r.b, cellOrder.begin() + r.e); cboff.push_back(r.b); }
+        cboff.push_back(m.nC);
+    }
+    int nB = (int)cboff.size() - 1;
     // permuted ordering: block by block, cell by cell: cell states then phi of owned faces
     std::vector<int> gidx;
     gidx.reserve(n);
@@ -580,10 +605,10 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     for (const StateDef& sd : s->st_full.states) if (sd.kind == KIND_FACE) hasFace = true;
     if (hasFace) for (int f = 0; f < m.nF; f++) owned[m.owner[f]].push_back(f);
     for (int b = 0; b < nB; b++) {
-        long long c0 = (long long)b * bc, c1 = std::min<long long>(m.nC, c0 + bc);
-        for (long long c = c0; c < c1; c++) {
+        for (long long q = cboff[b]; q < cboff[b + 1]; q++) {
+            long long c = cellOrder[q];
             for (const StateDef& sd : s->st_full.states) {
-                if (sd.kind == KIND_VEC) for (int q = 0; q < 3; q++) gidx.push_back((int)(sd.offset + 3 * c + q));
+                if (sd.kind == KIND_VEC) for (int k2 = 0; k2 < 3; k2++) gidx.push_back((int)(sd.offset + 3 * c + k2));
                 else if (sd.kind == KIND_SCL) gidx.push_back((int)(sd.offset + c));
             }
             for (const StateDef& sd : s->st_full.states)
@@ -1156,6 +1181,28 @@ int das_solve_linear_eqn(das_solver_t* s, das_ksp_t* ksp, const double* rhs, dou
     if (s->opt.geti("adjEqnOption.printInfo"))
         fprintf(stderr, "Main iteration %d KSP Residual norm %14.12e %.2f s\n", ksp->iters, ksp->res, ksp->seconds);
     return rc;
+    DAS_CATCH
+}
+int das_ksp_apply_pc(das_solver_t* s, das_ksp_t* ksp, const double* x, double* y) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(ksp && x && y, DAS_ERR_ARG, "null argument");
+    DevBuf<double> dx(s->n), dy(s->n);
+    dx.upload(x, s->n);
+    DAS_HIP(hipDeviceSynchronize());
+    pc_apply(s, ksp, dx.p, dy.p);
+    DAS_HIP(hipStreamSynchronize(s->stream));
+    dy.download(y, s->n);
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_ksp_get_n_blocks(das_ksp_t* ksp) { return ksp ? ksp->pc.nBlocks : -1; }
+int das_ksp_get_blocks(das_ksp_t* ksp, int* perm, long long* block_off) {
+    DAS_TRY
+    DAS_CHECK(ksp && perm && block_off, DAS_ERR_ARG, "null argument");
+    ksp->pc.gidx.download(perm, ksp->pc.n);
+    ksp->pc.boff.download(block_off, ksp->pc.nBlocks + 1);
+    return DAS_OK;
     DAS_CATCH
 }
 int das_ksp_get_info(das_ksp_t* k, int* iters, double* res0, double* res, double* seconds) {

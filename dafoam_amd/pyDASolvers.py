@@ -164,6 +164,20 @@ class KSP:
         check(lib().das_ksp_get_info(self.handle, C.byref(it), C.byref(r0), C.byref(r), C.byref(sec)))
         return dict(iters=it.value, res0=r0.value, res=r.value, seconds=sec.value)
 
+    def blocks(self):
+        L = lib()
+        nb = check(L.das_ksp_get_n_blocks(self.handle))
+        n = self._n
+        perm = np.zeros(n, np.int32)
+        off = np.zeros(nb + 1, np.int64)
+        check(L.das_ksp_get_blocks(self.handle, perm.ctypes.data_as(_capi.c_int_p), off.ctypes.data_as(_capi.c_ll_p)))
+        return perm, off
+
+    def applyPC(self, solver, x):
+        y = np.zeros_like(x)
+        check(lib().das_ksp_apply_pc(solver._h, self.handle, dptr(np.ascontiguousarray(x)), dptr(y)))
+        return y
+
     def history(self):
         buf = np.zeros(self.getIterationNumber() + 2)
         m = check(lib().das_ksp_get_history(self.handle, dptr(buf), buf.size))
@@ -369,6 +383,7 @@ class pyDASolvers:
         myKSP.destroy()
         myKSP.handle = h
         myKSP._pc = jacPCMat  # keep the PC matrix alive as long as the KSP
+        myKSP._n = self.getNLocalAdjointStates()
 
     def updateKSPPCMat(self, PCMat: Mat, myKSP: KSP):
         self.createMLRKSPMatrixFree(PCMat, myKSP)

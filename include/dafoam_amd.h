@@ -177,6 +177,11 @@ int das_drdwt_mult_device(das_solver_t* s, const double* d_x, double* d_y);
  *     returns 0 converged / 1 failed by the reference's gmresTolDiff rule (:422-434), <0 on error. */
 int das_create_ml_rksp_matrix_free(das_solver_t* s, das_mat_t* pc, das_ksp_t** ksp);
 int das_solve_linear_eqn(das_solver_t* s, das_ksp_t* ksp, const double* rhs, double* sol);
+/* preconditioner introspection (tests): y = M^{-1} x on host buffers; block layout of the additive-Schwarz PC:
+ * perm[n] = global state index at each permuted position, block_off[nBlocks+1] offsets into perm */
+int das_ksp_apply_pc(das_solver_t* s, das_ksp_t* ksp, const double* x, double* y);
+int das_ksp_get_n_blocks(das_ksp_t* ksp);
+int das_ksp_get_blocks(das_ksp_t* ksp, int* perm, long long* block_off);
 int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, double* seconds);
 int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
 /* run exactly `iters` GMRES iterations on device-resident rhs/sol (bench.py "step"); no convergence exit */

@@ -1,0 +1,41 @@
+"""Dev tool: full adjoint solve on a synthetic channel, prints setup/solve timings and convergence."""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, nargs=3, default=[100, 50, 40])
+ap.add_argument("--block", type=int, nargs="+", default=[4096])
+ap.add_argument("--rtol", type=float, default=1e-6)
+ap.add_argument("--restart", type=int, default=200)
+ap.add_argument("--maxit", type=int, default=600)
+ap.add_argument("--grading", type=float, default=4.0)
+ap.add_argument("--wf", action="store_true")
+a = ap.parse_args()
+import __graft_entry__ as ge
+ge.build()
+from dafoam_amd.meshgen import channel_case
+from dafoam_amd.pyDAFoam import PYDAFOAM
+from dafoam_amd.pyDASolvers import KSP, Mat, Vec
+from dafoam_amd import _capi
+case = channel_case(*a.n, lengths=(2.0, 0.2, 0.2), grading_y=a.grading, wall_function=a.wf)
+opts = {"solverName": "DASimpleFoam", "debug": True, "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0},
+        "adjEqnOption": {"gmresRestart": a.restart, "gmresMaxIters": a.maxit, "gmresRelTol": a.rtol, "printInfo": 0}}
+D = PYDAFOAM(options=opts, case=case)
+n = D.getNLocalAdjointStates()
+t = time.time(); D.solver.runColoring(); print(f"coloring {time.time()-t:.2f}s")
+pc = Mat(); t = time.time(); D.solver.calcdRdWT(1, pc); print(f"dRdWTPC {time.time()-t:.2f}s nnz {pc.getInfo()['nz_used']:.3g}")
+t = time.time(); D.solverAD.initializedRdWTMatrixFree(); print(f"dRdWT {time.time()-t:.2f}s")
+N = case.mesh.n_cells
+rhs = np.zeros(n); rhs[0:3 * N:3] = 1.0 / N
+L = _capi.lib()
+for b in a.block:
+    D.solver.updateDAOption({"amd": {"pcBlockCells": b}})
+    ksp = KSP(); t = time.time(); D.solverAD.createMLRKSPMatrixFree(pc, ksp); t_ilu = time.time() - t
+    x = Vec(n); r = Vec(n); r.array[:] = rhs
+    L.das_timer_reset(D.solver._h); L.das_timer_enable(D.solver._h, 1)
+    t = time.time(); fail = D.solverAD.solveLinearEqn(ksp, r, x); ts = time.time() - t
+    info = ksp.info()
+    print(f"block {b}: ilu {t_ilu:.2f}s  iters {info['iters']} fail {fail} relres {info['res']/info['res0']:.2e} solve {ts:.3f}s "
+          f"-> {info['iters']/ts:.1f} it/s  spmv {L.das_timer_avg_ms(D.solver._h,b'spmv'):.3f} ms pc {L.das_timer_avg_ms(D.solver._h,b'pc'):.3f} ms")
+    L.das_timer_enable(D.solver._h, 0)
