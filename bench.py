@@ -55,13 +55,13 @@ def main():
 
     ge.build()
     from dafoam_amd import _capi
-    from dafoam_amd.meshgen import channel_case
+    from dafoam_amd.meshgen import bench_channel_case
     from dafoam_amd.pyDAFoam import PYDAFOAM
     from dafoam_amd.pyDASolvers import KSP, Mat
 
     t_setup = time.time()
-    # weak scaling: every rank owns a same-size cell partition (slab along x) of the global channel
-    case = channel_case(a.nx, a.ny, a.nz, lengths=(2.0 * world, 0.2, 0.2), grading_y=4.0, seed=rank)
+    # state = prolongation of a converged coarse primal (dafoam_amd/data/channel_primal_coarse.npz)
+    case = bench_channel_case(a.nx, a.ny, a.nz)
     ncell = case.mesh.n_cells
     opts = {
         "solverName": "DASimpleFoam",
@@ -159,7 +159,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"DASimpleFoam+SA adjoint, synthetic bump-channel hex mesh {a.nx}x{a.ny}x{a.nz} = {ncell} cells per GPU "
+                "workload": f"DASimpleFoam+SA adjoint, bump-channel hex mesh (state: prolonged converged coarse primal) {a.nx}x{a.ny}x{a.nz} = {ncell} cells per GPU "
                             f"(stand-in for BASELINE configs[1] NACA0012 ~200k cells: same solver, 8 states/cell, reference stencil tables)",
                 "cells_per_gpu": ncell,
                 "states_per_gpu": n,

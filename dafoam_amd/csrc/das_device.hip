@@ -252,30 +252,37 @@ __global__ void k_mul(long long n, const double* __restrict__ s, double* __restr
     if (k < n) y[k] *= s[k];
 }
 
-// ---- block-ILU(0) apply: one workgroup per additive-Schwarz block, level-scheduled inside the workgroup ----
-// Unknowns are stored block-contiguously in a permuted work vector; rows of a level are independent.
-// GROUP lanes cooperate on one row.
+// ---- RAS/ILU(k) apply: one workgroup per (overlapping) additive-Schwarz block, level-scheduled inside the workgroup ----
+// Restricted additive Schwarz: the block solves on its extended (core + overlap) unknowns and writes back only the
+// core part (PETSc's default PC_ASM_RESTRICT, reference DALinearEqn.C:199-216).  The block's work vector lives in
+// LDS when it fits (<= 160 KiB), otherwise in a global scratch vector.  GROUP lanes cooperate on one row; rows of
+// one level are independent.
 #define PC_THREADS 1024
 #define PC_GROUP 16
 struct PCView {
     int nBlocks;
-    const long long* boff;    // nBlocks+1: offset of the block's unknowns in the permuted ordering
-    const int* gidx;          // permuted position -> global state index
-    const long long* frp;     // factor row pointers (permuted row order), n+1
-    const int* fci;           // factor column = permuted global position
+    const long long* boff;    // nBlocks+1: offset of the block's (extended) unknowns
+    const int* gidx;          // extended position -> global state index (gather)
+    const int* gout;          // extended position -> global state index if owned by the block's core, else -1
+    const long long* frp;     // factor row pointers over extended positions (n_ext+1)
+    const int* fci;           // factor column = block-local index
     const double* fv;
     const long long* fdiag;   // position of the diagonal in row
-    const int* Lrows;         // rows (permuted positions) sorted by (block, L-level)
+    const int* Lrows;         // block-local row ids sorted by L-level
     const long long* Llev;    // level pointers into Lrows, concatenated per block
     const long long* LlevOff; // nBlocks+1: offsets into Llev
     const int* Urows;
     const long long* Ulev;
     const long long* UlevOff;
 };
-__global__ __launch_bounds__(PC_THREADS) void k_bilu_apply(PCView P, const double* __restrict__ b, double* __restrict__ xw, double* __restrict__ out) {
+template <bool USE_LDS>
+__global__ __launch_bounds__(PC_THREADS) void k_ras_apply(PCView P, const double* __restrict__ b, double* __restrict__ xglob, double* __restrict__ out) {
+    extern __shared__ double xs[];
     const int blk = blockIdx.x;
-    const long long o0 = P.boff[blk], o1 = P.boff[blk + 1];
-    for (long long i = o0 + threadIdx.x; i < o1; i += PC_THREADS) xw[i] = b[P.gidx[i]];
+    const long long o0 = P.boff[blk];
+    const int nloc = (int)(P.boff[blk + 1] - o0);
+    double* xw = USE_LDS ? xs : xglob + o0;
+    for (int i = threadIdx.x; i < nloc; i += PC_THREADS) xw[i] = b[P.gidx[o0 + i]];
     __syncthreads();
     const int grp = threadIdx.x / PC_GROUP, gl = threadIdx.x % PC_GROUP, ngrp = PC_THREADS / PC_GROUP;
     // forward: L (unit diagonal)
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_bilu_apply(PCView P, const doubl
         for (long long r = r0 + grp; r < r1; r += ngrp) {
             int i = P.Lrows[r];
             double s = 0.0;
-            for (long long k = P.frp[i] + gl; k < P.fdiag[i]; k += PC_GROUP) s += P.fv[k] * xw[P.fci[k]];
+            for (long long k = P.frp[o0 + i] + gl; k < P.fdiag[o0 + i]; k += PC_GROUP) s += P.fv[k] * xw[P.fci[k]];
 #pragma unroll
             for (int o = PC_GROUP / 2; o > 0; o >>= 1) s += __shfl_down(s, o, PC_GROUP);
             if (gl == 0) xw[i] -= s;
@@ -297,14 +304,18 @@ __global__ __launch_bounds__(PC_THREADS) void k_bilu_apply(PCView P, const doubl
         for (long long r = r0 + grp; r < r1; r += ngrp) {
             int i = P.Urows[r];
             double s = 0.0;
-            for (long long k = P.fdiag[i] + 1 + gl; k < P.frp[i + 1]; k += PC_GROUP) s += P.fv[k] * xw[P.fci[k]];
+            const long long d = P.fdiag[o0 + i];
+            for (long long k = d + 1 + gl; k < P.frp[o0 + i + 1]; k += PC_GROUP) s += P.fv[k] * xw[P.fci[k]];
 #pragma unroll
             for (int o = PC_GROUP / 2; o > 0; o >>= 1) s += __shfl_down(s, o, PC_GROUP);
-            if (gl == 0) xw[i] = (xw[i] - s) / P.fv[P.fdiag[i]];
+            if (gl == 0) xw[i] = (xw[i] - s) / P.fv[d];
         }
         __syncthreads();
     }
-    for (long long i = o0 + threadIdx.x; i < o1; i += PC_THREADS) out[P.gidx[i]] = xw[i];
+    for (int i = threadIdx.x; i < nloc; i += PC_THREADS) {
+        int g = P.gout[o0 + i];
+        if (g >= 0) out[g] = xw[i];
+    }
 }
 
 // =====================================================================================================
@@ -365,15 +376,19 @@ struct ConDev {  // device copy of a JacCon (assembly maps + transposed structur
 };
 
 struct BlockILU {
-    long long n = 0;
+    long long n = 0, next = 0;
     int nBlocks = 0;
     long long fnnz = 0;
+    int maxLocal = 0;  // largest number of unknowns in one block
     DevBuf<long long> boff, frp, fdiag, Llev, LlevOff, Ulev, UlevOff;
-    DevBuf<int> gidx, fci, Lrows, Urows;
+    DevBuf<int> gidx, gout, fci, Lrows, Urows;
     DevBuf<double> fv, xw;
     PCView view;
     int maxLevels = 0;
+    bool useLDS = false;
     double setup_seconds = 0;
+    std::vector<int> h_core_perm;           // host copies for introspection (tests)
+    std::vector<long long> h_core_off;
 };
 
 }  // namespace das
@@ -555,10 +570,84 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
     return out.release();
 }
 
-// ---- block ILU(0) setup (host factorisation, one-off per PC matrix) ---------------------------------------------
-// PC structure follows the reference's ASM(ILU) idea (DALinearEqn.C:199-299): independent sub-domain factorisations;
-// here a sub-domain = a block of consecutive cells handled by one workgroup (zero overlap), ILU(0) on the dRdWTPC
-// pattern, unknowns ordered cell-by-cell inside the block (cf. adjStateOrdering "cell", DAIndex.C:602-651).
+// ---- RAS + ILU(k) setup (host, OpenMP over blocks; one-off per PC matrix) ----------------------------------------
+// Mirrors the reference's PC stack (DALinearEqn.C:199-299): additive Schwarz with overlap `asmOverlap` (here: cell
+// rings around an RCB sub-domain, restricted variant) and ILU(`pcFillLevel`) sub-solves with a non-zero pivot shift.
+// Unknowns are ordered cell-by-cell inside a block (cf. adjStateOrdering "cell", DAIndex.C:602-651), which the oracle
+// study in DESIGN.md section 6 shows to be the better ILU ordering for this system.
+namespace {
+struct BlockFactor {
+    std::vector<int> gidx, gout;         // extended unknowns (global ids), owned flag
+    std::vector<long long> frp, fdiag;   // local CSR of the factor
+    std::vector<int> fci;
+    std::vector<double> fv;
+    std::vector<int> Lrows, Urows;
+    std::vector<long long> Llev, Ulev;   // local level pointers (into Lrows/Urows)
+    int nshift = 0;
+};
+
+// symbolic ILU(k) by level of fill on a sorted local CSR pattern (Saad, Alg. 10.5 structure)
+static void ilu_symbolic(int nl, const std::vector<long long>& rp, const std::vector<int>& ci, int lfill, std::vector<long long>& frp,
+                         std::vector<int>& fci, std::vector<long long>& fdiag) {
+    frp.assign(nl + 1, 0);
+    fdiag.assign(nl, -1);
+    fci.clear();
+    if (lfill <= 0) {
+        fci.reserve(ci.size() + nl);
+        for (int i = 0; i < nl; i++) {
+            bool hasd = false;
+            long long b0 = (long long)fci.size();
+            for (long long q = rp[i]; q < rp[i + 1]; q++) {
+                if (!hasd && ci[q] > i) { fdiag[i] = (long long)fci.size(); fci.push_back(i); hasd = true; }
+                if (ci[q] == i) { fdiag[i] = (long long)fci.size(); hasd = true; }
+                fci.push_back(ci[q]);
+            }
+            if (!hasd) { fdiag[i] = (long long)fci.size(); fci.push_back(i); }
+            (void)b0;
+            frp[i + 1] = (long long)fci.size();
+        }
+        return;
+    }
+    std::vector<int> flev;  // level of each stored entry
+    std::vector<int> wlev(nl, -1), list;
+    fci.reserve(ci.size() * 3);
+    flev.reserve(ci.size() * 3);
+    for (int i = 0; i < nl; i++) {
+        list.clear();
+        bool hasd = false;
+        for (long long q = rp[i]; q < rp[i + 1]; q++) {
+            int j = ci[q];
+            if (wlev[j] < 0) { wlev[j] = 0; list.push_back(j); }
+            if (j == i) hasd = true;
+        }
+        if (!hasd) { wlev[i] = 0; list.push_back(i); }
+        std::sort(list.begin(), list.end());
+        size_t pos = 0;
+        while (pos < list.size() && list[pos] < i) {
+            int k = list[pos];
+            int lk = wlev[k];
+            bool added = false;
+            for (long long q = fdiag[k] + 1; q < frp[k + 1]; q++) {
+                int j = fci[q];
+                int nlv = lk + flev[q] + 1;
+                if (nlv > lfill) continue;
+                if (wlev[j] < 0) { wlev[j] = nlv; list.push_back(j); added = true; }
+                else if (nlv < wlev[j]) wlev[j] = nlv;
+            }
+            if (added) std::sort(list.begin() + pos + 1, list.end());
+            pos++;
+        }
+        for (int j : list) {
+            if (j == i) fdiag[i] = (long long)fci.size();
+            fci.push_back(j);
+            flev.push_back(wlev[j]);
+            wlev[j] = -1;
+        }
+        frp[i + 1] = (long long)fci.size();
+    }
+}
+}  // namespace
+
 static void setup_block_ilu(das_solver* s, das_ksp* k) {
     double t0 = wall_seconds();
     const Mat& A = k->pcmat->m;
@@ -567,12 +656,14 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     std::vector<int> ci = A.col.to_host();
     std::vector<double> av = A.val.to_host();
     const Mesh& m = s->mesh;
-    long long bc = std::max<long long>(64, s->opt.geti("amd.pcBlockCells"));
+    const long long bc = std::max<long long>(64, s->opt.geti("amd.pcBlockCells"));
+    const int overlap = (int)std::max<long long>(0, s->opt.geti("adjEqnOption.asmOverlap"));
+    const int lfill = (int)std::max<long long>(0, s->opt.geti("adjEqnOption.pcFillLevel"));
     // compact sub-domains by recursive coordinate bisection of the cell centres (the reference decomposes with
     // scotch, pyDAFoam.py:597-604; RCB gives comparable compact blocks without a graph library)
     std::vector<int> cellOrder(m.nC);
     std::iota(cellOrder.begin(), cellOrder.end(), 0);
-    std::vector<long long> cboff;  // block offsets into cellOrder
+    std::vector<long long> cboff;
     {
         struct Range { long long b, e; };
         std::vector<Range> stack{{0, (long long)m.nC}}, leaves;
@@ -595,143 +686,202 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
         for (auto& r : leaves) { std::sort(cellOrder.begin() + r.b, cellOrder.begin() + r.e); cboff.push_back(r.b); }
         cboff.push_back(m.nC);
     }
-    int nB = (int)cboff.size() - 1;
-    // permuted ordering: block by block, cell by cell: cell states then phi of owned faces
-    std::vector<int> gidx;
-    gidx.reserve(n);
-    std::vector<long long> boff(nB + 1, 0);
+    const int nB = (int)cboff.size() - 1;
     std::vector<std::vector<int>> owned(m.nC);
     bool hasFace = false;
     for (const StateDef& sd : s->st_full.states) if (sd.kind == KIND_FACE) hasFace = true;
     if (hasFace) for (int f = 0; f < m.nF; f++) owned[m.owner[f]].push_back(f);
-    for (int b = 0; b < nB; b++) {
-        for (long long q = cboff[b]; q < cboff[b + 1]; q++) {
-            long long c = cellOrder[q];
-            for (const StateDef& sd : s->st_full.states) {
-                if (sd.kind == KIND_VEC) for (int k2 = 0; k2 < 3; k2++) gidx.push_back((int)(sd.offset + 3 * c + k2));
-                else if (sd.kind == KIND_SCL) gidx.push_back((int)(sd.offset + c));
-            }
-            for (const StateDef& sd : s->st_full.states)
-                if (sd.kind == KIND_FACE) for (int f : owned[c]) gidx.push_back((int)(sd.offset + f));
-        }
-        boff[b + 1] = (long long)gidx.size();
-    }
-    DAS_CHECK((long long)gidx.size() == n, DAS_ERR_INTERNAL, "block permutation does not cover all states");
-    std::vector<int> pos(n), blkOf(n);
-    for (long long p = 0; p < n; p++) pos[gidx[p]] = (int)p;
-    for (int b = 0; b < nB; b++) for (long long p = boff[b]; p < boff[b + 1]; p++) blkOf[p] = b;
-    // permuted, block-restricted pattern (ILU(0)): row p = global row gidx[p]; keep columns in the same block
-    std::vector<long long> frp(n + 1, 0), fdiag(n, -1);
-    for (long long p = 0; p < n; p++) {
-        int g = gidx[p];
-        int b = blkOf[p];
-        long long cnt = 0;
-        bool hasd = false;
-        for (long long q = rp[g]; q < rp[g + 1]; q++) {
-            int pc = pos[ci[q]];
-            if (blkOf[pc] == b) { cnt++; if (pc == p) hasd = true; }
-        }
-        if (!hasd) cnt++;
-        frp[p + 1] = frp[p] + cnt;
-    }
-    long long fnnz = frp[n];
-    std::vector<int> fci(fnnz);
-    std::vector<double> fv(fnnz);
+
+    std::vector<BlockFactor> BF(nB);
+    std::string err;
+#pragma omp parallel
     {
+        std::vector<int> cmark(m.nC, -1);
+        std::vector<int> loc(n, -1);
+        std::vector<int> ext, frontier, nxt;
+        std::vector<long long> lrp;
+        std::vector<int> lci;
+        std::vector<double> lv;
         std::vector<std::pair<int, double>> row;
-        for (long long p = 0; p < n; p++) {
-            int g = gidx[p], b = blkOf[p];
-            row.clear();
-            bool hasd = false;
-            for (long long q = rp[g]; q < rp[g + 1]; q++) {
-                int pc = pos[ci[q]];
-                if (blkOf[pc] == b) { row.push_back({pc, av[q]}); if (pc == p) hasd = true; }
-            }
-            if (!hasd) row.push_back({(int)p, 0.0});
-            std::sort(row.begin(), row.end());
-            long long o = frp[p];
-            for (size_t t = 0; t < row.size(); t++) {
-                fci[o + t] = row[t].first;
-                fv[o + t] = row[t].second;
-                if (row[t].first == p) fdiag[p] = o + t;
-            }
-        }
-    }
-    // numeric ILU(0), IKJ, block-local (rows only reference columns of their own block)
-    {
-        std::vector<long long> where(n, -1);
-        int nshift = 0;
-        for (long long i = 0; i < n; i++) {
-            for (long long q = frp[i]; q < frp[i + 1]; q++) where[fci[q]] = q;
-            for (long long q = frp[i]; q < fdiag[i]; q++) {
-                int kk = fci[q];
-                double lik = fv[q] / fv[fdiag[kk]];
-                fv[q] = lik;
-                if (lik == 0.0) continue;
-                for (long long r = fdiag[kk] + 1; r < frp[kk + 1]; r++) {
-                    long long d = where[fci[r]];
-                    if (d >= 0) fv[d] -= lik * fv[r];
-                }
-            }
-            double piv = fv[fdiag[i]];
-            if (std::fabs(piv) < 1e-300 || piv != piv) { fv[fdiag[i]] = (piv < 0 ? -1.0 : 1.0) * 1e-12; nshift++; }  // MAT_SHIFT_NONZERO analogue
-            for (long long q = frp[i]; q < frp[i + 1]; q++) where[fci[q]] = -1;
-        }
-        if (nshift && s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] block ILU: %d zero pivots shifted\n", nshift);
-    }
-    // level schedules per block
-    std::vector<int> lev(n, 0);
-    std::vector<int> Lrows(n), Urows(n);
-    std::vector<long long> Llev, LlevOff(nB + 1, 0), Ulev, UlevOff(nB + 1, 0);
-    int maxLv = 0;
-    auto schedule = [&](bool lower, std::vector<int>& rows, std::vector<long long>& levp, std::vector<long long>& levOff) {
+        std::vector<long long> where;
+        std::vector<int> lev;
+#pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < nB; b++) {
-            long long o0 = boff[b], o1 = boff[b + 1];
-            int nl = 0;
-            if (lower) {
-                for (long long i = o0; i < o1; i++) {
-                    int l = 0;
-                    for (long long q = frp[i]; q < fdiag[i]; q++) l = std::max(l, lev[fci[q]] + 1);
-                    lev[i] = l;
-                    nl = std::max(nl, l + 1);
+            try {
+                BlockFactor& F = BF[b];
+                // core + overlap rings of cells
+                ext.clear();
+                frontier.clear();
+                for (long long q = cboff[b]; q < cboff[b + 1]; q++) { int c = cellOrder[q]; cmark[c] = b; ext.push_back(c); frontier.push_back(c); }
+                const size_t ncore = ext.size();
+                for (int ring = 0; ring < overlap; ring++) {
+                    nxt.clear();
+                    for (int c : frontier)
+                        for (int q = m.cc_ptr[c]; q < m.cc_ptr[c + 1]; q++) {
+                            int y = m.cc[q];
+                            if (cmark[y] != b) { cmark[y] = b; ext.push_back(y); nxt.push_back(y); }
+                        }
+                    frontier.swap(nxt);
                 }
-            } else {
-                for (long long i = o1 - 1; i >= o0; i--) {
-                    int l = 0;
-                    for (long long q = fdiag[i] + 1; q < frp[i + 1]; q++) l = std::max(l, lev[fci[q]] + 1);
-                    lev[i] = l;
-                    nl = std::max(nl, l + 1);
+                // mark core membership: core cells are the first ncore entries of ext; sort all ext cells
+                std::vector<char> isCore(ext.size(), 0);
+                {
+                    std::vector<std::pair<int, char>> tmp(ext.size());
+                    for (size_t q = 0; q < ext.size(); q++) tmp[q] = {ext[q], (char)(q < ncore)};
+                    std::sort(tmp.begin(), tmp.end());
+                    for (size_t q = 0; q < ext.size(); q++) { ext[q] = tmp[q].first; isCore[q] = tmp[q].second; }
                 }
+                // unknown list, cell by cell
+                for (size_t q = 0; q < ext.size(); q++) {
+                    long long c = ext[q];
+                    auto push = [&](long long g) { F.gidx.push_back((int)g); F.gout.push_back(isCore[q] ? (int)g : -1); };
+                    for (const StateDef& sd : s->st_full.states) {
+                        if (sd.kind == KIND_VEC) for (int k2 = 0; k2 < 3; k2++) push(sd.offset + 3 * c + k2);
+                        else if (sd.kind == KIND_SCL) push(sd.offset + c);
+                    }
+                    for (const StateDef& sd : s->st_full.states)
+                        if (sd.kind == KIND_FACE) for (int f : owned[c]) push(sd.offset + f);
+                }
+                const int nl = (int)F.gidx.size();
+                for (int p = 0; p < nl; p++) loc[F.gidx[p]] = p;
+                // local matrix (block-restricted rows of dRdWTPC), sorted columns
+                lrp.assign(nl + 1, 0);
+                lci.clear();
+                lv.clear();
+                for (int p = 0; p < nl; p++) {
+                    int g = F.gidx[p];
+                    row.clear();
+                    for (long long q = rp[g]; q < rp[g + 1]; q++) {
+                        int lc = loc[ci[q]];
+                        if (lc >= 0) row.push_back({lc, av[q]});
+                    }
+                    std::sort(row.begin(), row.end());
+                    for (auto& e : row) { lci.push_back(e.first); lv.push_back(e.second); }
+                    lrp[p + 1] = (long long)lci.size();
+                }
+                for (int p = 0; p < nl; p++) loc[F.gidx[p]] = -1;
+                // symbolic + numeric ILU(k)
+                ilu_symbolic(nl, lrp, lci, lfill, F.frp, F.fci, F.fdiag);
+                F.fv.assign(F.fci.size(), 0.0);
+                where.assign(nl, -1);
+                for (int i = 0; i < nl; i++) {
+                    for (long long q = F.frp[i]; q < F.frp[i + 1]; q++) where[F.fci[q]] = q;
+                    for (long long q = lrp[i]; q < lrp[i + 1]; q++) F.fv[where[lci[q]]] = lv[q];
+                    for (long long q = F.frp[i]; q < F.fdiag[i]; q++) {
+                        int kk = F.fci[q];
+                        double lik = F.fv[q] / F.fv[F.fdiag[kk]];
+                        F.fv[q] = lik;
+                        if (lik == 0.0) continue;
+                        for (long long r = F.fdiag[kk] + 1; r < F.frp[kk + 1]; r++) {
+                            long long d = where[F.fci[r]];
+                            if (d >= 0) F.fv[d] -= lik * F.fv[r];
+                        }
+                    }
+                    double piv = F.fv[F.fdiag[i]];
+                    if (std::fabs(piv) < 1e-300 || piv != piv) { F.fv[F.fdiag[i]] = (piv < 0 ? -1.0 : 1.0) * 1e-12; F.nshift++; }  // MAT_SHIFT_NONZERO analogue
+                    for (long long q = F.frp[i]; q < F.frp[i + 1]; q++) where[F.fci[q]] = -1;
+                }
+                // level schedules
+                auto schedule = [&](bool lower, std::vector<int>& rows, std::vector<long long>& levp) {
+                    lev.assign(nl, 0);
+                    int nlv = 0;
+                    if (lower) {
+                        for (int i = 0; i < nl; i++) {
+                            int l = 0;
+                            for (long long q = F.frp[i]; q < F.fdiag[i]; q++) l = std::max(l, lev[F.fci[q]] + 1);
+                            lev[i] = l;
+                            nlv = std::max(nlv, l + 1);
+                        }
+                    } else {
+                        for (int i = nl - 1; i >= 0; i--) {
+                            int l = 0;
+                            for (long long q = F.fdiag[i] + 1; q < F.frp[i + 1]; q++) l = std::max(l, lev[F.fci[q]] + 1);
+                            lev[i] = l;
+                            nlv = std::max(nlv, l + 1);
+                        }
+                    }
+                    levp.assign(nlv + 1, 0);
+                    for (int i = 0; i < nl; i++) levp[lev[i] + 1]++;
+                    for (int l = 0; l < nlv; l++) levp[l + 1] += levp[l];
+                    rows.assign(nl, 0);
+                    std::vector<long long> fill(levp.begin(), levp.end() - 1);
+                    for (int i = 0; i < nl; i++) rows[fill[lev[i]]++] = i;
+                };
+                schedule(true, F.Lrows, F.Llev);
+                schedule(false, F.Urows, F.Ulev);
+            } catch (const std::exception& e) {
+#pragma omp critical
+                err = e.what();
             }
-            maxLv = std::max(maxLv, nl);
-            std::vector<long long> cnt(nl + 1, 0);
-            for (long long i = o0; i < o1; i++) cnt[lev[i] + 1]++;
-            for (int l = 0; l < nl; l++) cnt[l + 1] += cnt[l];
-            levOff[b] = (long long)levp.size();
-            for (int l = 0; l <= nl; l++) levp.push_back(o0 + cnt[l]);
-            std::vector<long long> fill(cnt.begin(), cnt.end() - 1);
-            for (long long i = o0; i < o1; i++) rows[o0 + fill[lev[i]]++] = (int)i;
         }
-        levOff[nB] = (long long)levp.size();
-    };
-    schedule(true, Lrows, Llev, LlevOff);
-    schedule(false, Urows, Ulev, UlevOff);
+    }
+    DAS_CHECK(err.empty(), DAS_ERR_INTERNAL, "block ILU setup failed: " + err);
+    // concatenate
     BlockILU& P = k->pc;
-    P.n = n; P.nBlocks = nB; P.fnnz = fnnz; P.maxLevels = maxLv;
-    P.boff.upload(boff); P.gidx.upload(gidx); P.frp.upload(frp); P.fci.upload(fci); P.fv.upload(fv); P.fdiag.upload(fdiag);
+    std::vector<long long> boff(nB + 1, 0), frp, fdiag, Llev, LlevOff(nB + 1, 0), Ulev, UlevOff(nB + 1, 0);
+    std::vector<int> gidx, gout, fci, Lrows, Urows;
+    std::vector<double> fv;
+    long long next = 0, fnnz = 0;
+    int maxLocal = 0, maxLv = 0, nshift = 0;
+    for (int b = 0; b < nB; b++) { next += (long long)BF[b].gidx.size(); fnnz += (long long)BF[b].fci.size(); }
+    DAS_CHECK(fnnz < (1LL << 62), DAS_ERR_INTERNAL, "factor too large");
+    gidx.reserve(next); gout.reserve(next); frp.reserve(next + 1); fdiag.reserve(next); fci.reserve(fnnz); fv.reserve(fnnz);
+    Lrows.reserve(next); Urows.reserve(next);
+    frp.push_back(0);
+    P.h_core_perm.clear();
+    P.h_core_off.assign(1, 0);
+    for (int b = 0; b < nB; b++) {
+        BlockFactor& F = BF[b];
+        const long long ebase = (long long)fci.size();
+        const long long rbase = (long long)Lrows.size();
+        const int nl = (int)F.gidx.size();
+        maxLocal = std::max(maxLocal, nl);
+        nshift += F.nshift;
+        gidx.insert(gidx.end(), F.gidx.begin(), F.gidx.end());
+        gout.insert(gout.end(), F.gout.begin(), F.gout.end());
+        for (int g : F.gout) if (g >= 0) P.h_core_perm.push_back(g);
+        P.h_core_off.push_back((long long)P.h_core_perm.size());
+        for (int i = 0; i < nl; i++) { frp.push_back(ebase + F.frp[i + 1]); fdiag.push_back(ebase + F.fdiag[i]); }
+        fci.insert(fci.end(), F.fci.begin(), F.fci.end());
+        fv.insert(fv.end(), F.fv.begin(), F.fv.end());
+        LlevOff[b] = (long long)Llev.size();
+        for (long long x : F.Llev) Llev.push_back(rbase + x);
+        UlevOff[b] = (long long)Ulev.size();
+        for (long long x : F.Ulev) Ulev.push_back(rbase + x);
+        Lrows.insert(Lrows.end(), F.Lrows.begin(), F.Lrows.end());
+        Urows.insert(Urows.end(), F.Urows.begin(), F.Urows.end());
+        maxLv = std::max<int>(maxLv, std::max((int)F.Llev.size(), (int)F.Ulev.size()) - 1);
+        boff[b + 1] = boff[b] + nl;
+        F = BlockFactor();  // free
+    }
+    LlevOff[nB] = (long long)Llev.size();
+    UlevOff[nB] = (long long)Ulev.size();
+    DAS_CHECK((long long)P.h_core_perm.size() == n, DAS_ERR_INTERNAL, "block cores do not cover all states exactly once");
+    P.n = n; P.next = next; P.nBlocks = nB; P.fnnz = fnnz; P.maxLevels = maxLv; P.maxLocal = maxLocal;
+    P.boff.upload(boff); P.gidx.upload(gidx); P.gout.upload(gout); P.frp.upload(frp); P.fci.upload(fci); P.fv.upload(fv); P.fdiag.upload(fdiag);
     P.Lrows.upload(Lrows); P.Llev.upload(Llev); P.LlevOff.upload(LlevOff);
     P.Urows.upload(Urows); P.Ulev.upload(Ulev); P.UlevOff.upload(UlevOff);
-    P.xw.alloc(n);
-    P.view = PCView{nB, P.boff.p, P.gidx.p, P.frp.p, P.fci.p, P.fv.p, P.fdiag.p, P.Lrows.p, P.Llev.p, P.LlevOff.p, P.Urows.p, P.Ulev.p, P.UlevOff.p};
+    P.useLDS = (size_t)maxLocal * sizeof(double) <= 160 * 1024;
+    if (!P.useLDS) P.xw.alloc(next);
+    else {
+        DAS_HIP(hipFuncSetAttribute((const void*)k_ras_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    P.view = PCView{nB, P.boff.p, P.gidx.p, P.gout.p, P.frp.p, P.fci.p, P.fv.p, P.fdiag.p, P.Lrows.p, P.Llev.p, P.LlevOff.p, P.Urows.p, P.Ulev.p, P.UlevOff.p};
     P.setup_seconds = wall_seconds() - t0;
     if (s->opt.geti("debug"))
-        fprintf(stderr, "[dafoam_amd] block ILU(0): %d blocks, nnz(LU)=%lld, max levels %d, %.2f s\n", nB, fnnz, maxLv, P.setup_seconds);
+        fprintf(stderr, "[dafoam_amd] RAS(overlap %d)+ILU(%d): %d blocks, n_ext=%lld (%.2fx), nnz(LU)=%lld, max block %d unknowns (%s), max levels %d, "
+                        "%d shifted pivots, %.2f s\n", overlap, lfill, nB, next, (double)next / n, fnnz, maxLocal, P.useLDS ? "LDS" : "global", maxLv, nshift,
+                P.setup_seconds);
 }
 
 static void pc_apply(das_solver* s, das_ksp* k, const double* b, double* x) {
     hipEvent_t ev = nullptr;
     s->timer.begin("pc", s->stream, ev);
-    hipLaunchKernelGGL(k_bilu_apply, dim3(k->pc.nBlocks), dim3(PC_THREADS), 0, s->stream, k->pc.view, b, k->pc.xw.p, x);
+    if (k->pc.useLDS)
+        hipLaunchKernelGGL(k_ras_apply<true>, dim3(k->pc.nBlocks), dim3(PC_THREADS), (size_t)k->pc.maxLocal * sizeof(double), s->stream, k->pc.view, b,
+                           (double*)nullptr, x);
+    else
+        hipLaunchKernelGGL(k_ras_apply<false>, dim3(k->pc.nBlocks), dim3(PC_THREADS), 0, s->stream, k->pc.view, b, k->pc.xw.p, x);
     s->timer.end("pc", s->stream, ev);
 }
 
@@ -1200,8 +1350,8 @@ int das_ksp_get_n_blocks(das_ksp_t* ksp) { return ksp ? ksp->pc.nBlocks : -1; }
 int das_ksp_get_blocks(das_ksp_t* ksp, int* perm, long long* block_off) {
     DAS_TRY
     DAS_CHECK(ksp && perm && block_off, DAS_ERR_ARG, "null argument");
-    ksp->pc.gidx.download(perm, ksp->pc.n);
-    ksp->pc.boff.download(block_off, ksp->pc.nBlocks + 1);
+    std::copy(ksp->pc.h_core_perm.begin(), ksp->pc.h_core_perm.end(), perm);
+    std::copy(ksp->pc.h_core_off.begin(), ksp->pc.h_core_off.end(), block_off);
     return DAS_OK;
     DAS_CATCH
 }

@@ -380,6 +380,73 @@ def channel_case(
     return case
 
 
+def _logical_centres(nx, ny, nz, i0=0, i1=None, nx_global=None):
+    """logical (xi,eta,zeta) in [0,1]^3 of the cell centres of an index sub-block (x range [i0,i1) of nx_global)."""
+    nxg = nx if nx_global is None else nx_global
+    i1 = nx if i1 is None else i1
+    return (np.arange(i0, i1) + 0.5) / nxg, (np.arange(ny) + 0.5) / ny, (np.arange(nz) + 0.5) / nz
+
+
+def prolong_channel_state(case: FoamCase, dims, coarse, i0=0, nx_global=None):
+    """Replace the synthetic state of a channel case by the prolongation (tri-linear in logical block coordinates)
+    of a converged coarse-mesh primal solution `coarse` = dict(dims=(cx,cy,cz), W=...) of the SAME channel geometry
+    (fixture dafoam_amd/data/channel_primal_coarse.npz, produced with the oracle's SIMPLE solver by
+    tests/golden/make_primal_fixture.py).  The face flux is rebuilt as interp(U).Sf (boundary: U_b.Sf).
+    A nearly-converged state is what the adjoint is linearised about in practice (the primal solve is upstream of
+    the hot path); Jacobians of arbitrary synthetic fields are not representative (unstable ILU pivots)."""
+    from scipy.interpolate import RegularGridInterpolator
+
+    nx, ny, nz = dims
+    cx, cy, cz = [int(v) for v in coarse["dims"]]
+    Wc = np.asarray(coarse["W"])
+    Nc = cx * cy * cz
+    xs, ys, zs = _logical_centres(cx, cy, cz)
+    xf, yf, zf = _logical_centres(nx, ny, nz, i0, i0 + nx, nx_global or nx)
+    X, Y, Z = np.meshgrid(xf, yf, zf, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+
+    def field(v):
+        a = v.reshape(cz, cy, cx).transpose(2, 1, 0)
+        f = RegularGridInterpolator((xs, ys, zs), a, bounds_error=False, fill_value=None)
+        return f(pts).reshape(nx, ny, nz).transpose(2, 1, 0).ravel()
+
+    U = np.stack([field(Wc[k : 3 * Nc : 3]) for k in range(3)], 1)
+    p = field(Wc[3 * Nc : 4 * Nc])
+    nt = np.maximum(field(Wc[4 * Nc : 5 * Nc]), 1e-12)
+    mesh = case.mesh
+    g = _InputGeometry(mesh)
+    nIF = mesh.n_internal_faces
+    own, nei = mesh.owner, mesh.neighbour
+    Uf = g.w[:, None] * U[own[:nIF]] + (1 - g.w[:, None]) * U[nei]
+    phi = np.zeros(mesh.n_faces)
+    phi[:nIF] = np.einsum("ij,ij->i", Uf, g.Sf[:nIF])
+    for pt in mesh.patches:
+        sl = slice(pt.start, pt.start + pt.size)
+        code, val = case.bcs[pt.name]["U"]
+        if code == BC_FIXED_VALUE:
+            phi[sl] = g.Sf[sl] @ np.asarray(val, dtype=float)
+        elif code == BC_SYMMETRY:
+            phi[sl] = 0.0
+        else:  # zeroGradient / inletOutlet: extrapolated cell velocity (outflow)
+            phi[sl] = np.einsum("ij,ij->i", U[own[sl]], g.Sf[sl])
+    case.states = np.concatenate([U.ravel(), p, nt, phi])
+    return case
+
+
+def load_coarse_primal():
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "channel_primal_coarse.npz"))
+    return {"dims": tuple(int(v) for v in z["dims"]), "W": z["W"], "lengths": tuple(z["lengths"]), "grading_y": float(z["grading_y"])}
+
+
+def bench_channel_case(nx, ny, nz, wall_function=False):
+    """DASimpleFoam+SA channel at bench scale with a nearly-converged state (see prolong_channel_state)."""
+    c = load_coarse_primal()
+    case = channel_case(nx, ny, nz, lengths=c["lengths"], grading_y=c["grading_y"], wall_function=wall_function, perturb=0.0)
+    return prolong_channel_state(case, (nx, ny, nz), c)
+
+
 def scalar_transport_case(nx=18, ny=17, nz=16, lengths=(1.0, 0.5, 0.5), DT=0.01, deltaT=0.05, seed=0) -> FoamCase:
     """DAScalarTransportFoam box (BASELINE.json configs[0]: 18x17x16 = 4896 cells).
     phi from uniform U=(1,0,0); T = smooth blob advected 'a few steps' (T_old shifted)."""

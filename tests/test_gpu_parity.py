@@ -8,7 +8,7 @@ import pytest
 import scipy.sparse.linalg as spla
 
 from common import NORM_STATES, blocks, options, relerr
-from dafoam_amd.meshgen import channel_case, scalar_transport_case
+from dafoam_amd.meshgen import bench_channel_case, channel_case, scalar_transport_case
 from oracle import jacobian as J
 from oracle import linear as OL
 from oracle.foam_mesh import Geometry
@@ -22,6 +22,25 @@ def make(case, **extra):
     from dafoam_amd.pyDAFoam import PYDAFOAM
 
     return PYDAFOAM(options=options(case, **extra), case=case)
+
+
+_PRIMAL_CACHE = {}
+
+
+def converged_case(dims, wall_function=False, **kw):
+    """Channel case whose state is a CONVERGED primal (oracle SIMPLE solver): the adjoint is linearised about a
+    converged flow in the reference (solve_linear runs after solve_nonlinear, mphys_dafoam.py:314-433)."""
+    from oracle.primal import solve_primal
+
+    key = (dims, wall_function, tuple(sorted(kw.items())))
+    if key not in _PRIMAL_CACHE:
+        case = channel_case(*dims, wall_function=wall_function, perturb=0.0, **kw)
+        g = Geometry(case.mesh)
+        W, hist = solve_primal(case, g, max_iters=800, tol=1e-11)
+        assert np.all(hist[-1] < 1e-7 * hist[0] + 1e-12), hist[-1]
+        case.states = W
+        _PRIMAL_CACHE[key] = case
+    return _PRIMAL_CACHE[key]
 
 
 def oracle_mats(case, g, pc_mode="fd"):
@@ -147,8 +166,13 @@ def test_jac_t_vec_product_and_dot_product_identity():
 
 @pytest.mark.parametrize("wall_function", [False, True])
 def test_adjoint_vector_parity_simplefoam(wall_function):
-    case = channel_case(8, 8, 6, wall_function=wall_function)
+    case = converged_case((10, 8, 6), wall_function=wall_function, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
     g = Geometry(case.mesh)
+    # R(W*) = 0: the HIP residual vanishes at the oracle's converged SIMPLE fixed point
+    D0 = make(case)
+    R = np.zeros(case.states.size)
+    D0.solver.getResiduals(R)
+    assert np.abs(R).max() < 1e-6
     sc, con, col, A = oracle_mats(case, g)
     rhs = np.zeros(A.shape[0])
     rhs[0 : 3 * g.nC : 3] = g.V
@@ -179,14 +203,18 @@ def test_adjoint_scalar_transport_config0():
     assert fail == 0 and relerr(psi, psi_o) <= 1e-8
 
 
-@pytest.mark.parametrize("dims,block", [((6, 6, 5), 4096), ((8, 8, 6), 100), ((24, 20, 16), 2048)])
-def test_block_ilu_apply_matches_oracle(dims, block):
-    """The GPU preconditioner apply (block ILU(0), level-scheduled) against the oracle's ILU(0) on the same
-    dRdWTPC matrix, same block partition and ordering."""
+@pytest.mark.parametrize("dims,block,overlap,fill", [((6, 6, 5), 4096, 0, 0), ((8, 8, 6), 100, 1, 0), ((8, 8, 6), 150, 1, 1),
+                                                     ((8, 8, 6), 100, 2, 1), ((24, 20, 16), 1024, 1, 0)])
+def test_ras_ilu_apply_matches_oracle(dims, block, overlap, fill):
+    """The GPU preconditioner apply (restricted additive Schwarz over RCB blocks + `overlap` cell rings, ILU(fill),
+    level-scheduled in LDS) against the oracle's ILU(k) (oracle/csrc/oracle_linalg.c) on the same dRdWTPC matrix
+    with the same blocks and the same cell-by-cell ordering."""
     from dafoam_amd.pyDASolvers import KSP, Mat
 
     case = channel_case(*dims, grading_y=2.0)
-    D = make(case, amd={"pcBlockCells": block})
+    g = Geometry(case.mesh)
+    N, F = g.nC, g.nF
+    D = make(case, amd={"pcBlockCells": block}, adjEqnOption={"asmOverlap": overlap, "pcFillLevel": fill, "printInfo": 0})
     D.solver.runColoring()
     pc = Mat()
     D.solver.calcdRdWT(1, pc)
@@ -195,15 +223,27 @@ def test_block_ilu_apply_matches_oracle(dims, block):
     perm, off = ksp.blocks()
     n = perm.size
     assert sorted(perm.tolist()) == list(range(n))
-    P = pc.to_scipy()
-    Pp = P[perm][:, perm]
-    bl = np.zeros(n, dtype=np.int64)
-    for b in range(off.size - 1):
-        bl[off[b] : off[b + 1]] = b
-    ilu = OL.ILU(Pp, fill=0, blocks=bl)
+    P = pc.to_scipy().tocsr()
+    owned_faces = [[] for _ in range(N)]
+    for f in range(F):
+        owned_faces[g.own[f]].append(f)
     x = np.random.default_rng(0).standard_normal(n)
     y_o = np.zeros(n)
-    y_o[perm] = ilu.solve(x[perm])
+    for b in range(off.size - 1):
+        core_states = perm[off[b] : off[b + 1]]
+        core = np.zeros(N, bool)
+        core[core_states[core_states < 3 * N] // 3] = True
+        ext = core.copy()
+        for _ in range(overlap):
+            ext = ext | (g.cellCells @ ext.astype(np.int8) > 0)
+        idx, own_mask = [], []
+        for c in np.nonzero(ext)[0]:
+            st = [3 * c, 3 * c + 1, 3 * c + 2, 3 * N + c, 4 * N + c] + [5 * N + f for f in owned_faces[c]]
+            idx += st
+            own_mask += [core[c]] * len(st)
+        idx, own_mask = np.array(idx), np.array(own_mask)
+        z = OL.ILU(P[idx][:, idx], fill=fill).solve(x[idx])
+        y_o[idx[own_mask]] = z[own_mask]
     y = ksp.applyPC(D.solver, x)
     assert relerr(y, y_o) < 1e-9
 
@@ -225,8 +265,9 @@ def test_gmres_failure_rule_and_restart():
 def test_size_independent_properties_larger_mesh():
     """At a size where the oracle Jacobian would take minutes: linearity of dRdW^T.psi, FD-vs-dual agreement of
     J^T psi via the dot-product identity with a GPU residual difference, and GMRES residual reduction."""
-    case = channel_case(24, 20, 16, grading_y=3.0)
-    D = make(case, adjEqnOption={"gmresRelTol": 1e-8, "printInfo": 0, "gmresMaxIters": 1500})
+    case = bench_channel_case(32, 20, 16)
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-8, "printInfo": 0, "gmresMaxIters": 1500, "gmresRestart": 300},
+             amd={"pcBlockCells": 1024})
     n = case.states.size
     rng = np.random.default_rng(7)
     a, b = rng.standard_normal(n), rng.standard_normal(n)

@@ -11,14 +11,17 @@ ap.add_argument("--restart", type=int, default=200)
 ap.add_argument("--maxit", type=int, default=600)
 ap.add_argument("--grading", type=float, default=4.0)
 ap.add_argument("--wf", action="store_true")
+ap.add_argument("--overlap", type=int, nargs="+", default=[1])
+ap.add_argument("--fill", type=int, nargs="+", default=[0])
+ap.add_argument("--lx", type=float, default=2.0)
 a = ap.parse_args()
 import __graft_entry__ as ge
 ge.build()
-from dafoam_amd.meshgen import channel_case
+from dafoam_amd.meshgen import channel_case, bench_channel_case
 from dafoam_amd.pyDAFoam import PYDAFOAM
 from dafoam_amd.pyDASolvers import KSP, Mat, Vec
 from dafoam_amd import _capi
-case = channel_case(*a.n, lengths=(2.0, 0.2, 0.2), grading_y=a.grading, wall_function=a.wf)
+case = bench_channel_case(*a.n, wall_function=a.wf)
 opts = {"solverName": "DASimpleFoam", "debug": True, "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0},
         "adjEqnOption": {"gmresRestart": a.restart, "gmresMaxIters": a.maxit, "gmresRelTol": a.rtol, "printInfo": 0}}
 D = PYDAFOAM(options=opts, case=case)
@@ -29,13 +32,15 @@ t = time.time(); D.solverAD.initializedRdWTMatrixFree(); print(f"dRdWT {time.tim
 N = case.mesh.n_cells
 rhs = np.zeros(n); rhs[0:3 * N:3] = 1.0 / N
 L = _capi.lib()
-for b in a.block:
-    D.solver.updateDAOption({"amd": {"pcBlockCells": b}})
+import itertools
+for b, ov, fl in itertools.product(a.block, a.overlap, a.fill):
+    D.solver.updateDAOption({"amd": {"pcBlockCells": b}, "adjEqnOption": {"asmOverlap": ov, "pcFillLevel": fl}})
     ksp = KSP(); t = time.time(); D.solverAD.createMLRKSPMatrixFree(pc, ksp); t_ilu = time.time() - t
     x = Vec(n); r = Vec(n); r.array[:] = rhs
     L.das_timer_reset(D.solver._h); L.das_timer_enable(D.solver._h, 1)
     t = time.time(); fail = D.solverAD.solveLinearEqn(ksp, r, x); ts = time.time() - t
     info = ksp.info()
-    print(f"block {b}: ilu {t_ilu:.2f}s  iters {info['iters']} fail {fail} relres {info['res']/info['res0']:.2e} solve {ts:.3f}s "
+    h = ksp.history(); print("   hist", " ".join(f"{v/h[0]:.1e}" for v in h[::max(1,len(h)//12)]))
+    print(f"block {b} overlap {ov} fill {fl}: ilu {t_ilu:.2f}s  iters {info['iters']} fail {fail} relres {info['res']/info['res0']:.2e} solve {ts:.3f}s "
           f"-> {info['iters']/ts:.1f} it/s  spmv {L.das_timer_avg_ms(D.solver._h,b'spmv'):.3f} ms pc {L.das_timer_avg_ms(D.solver._h,b'pc'):.3f} ms")
     L.das_timer_enable(D.solver._h, 0)
