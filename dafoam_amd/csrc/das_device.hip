@@ -252,66 +252,96 @@ __global__ void k_mul(long long n, const double* __restrict__ s, double* __restr
     if (k < n) y[k] *= s[k];
 }
 
-// ---- RAS/ILU(k) apply: one workgroup per (overlapping) additive-Schwarz block, level-scheduled inside the workgroup ----
+// ---- RAS/ILU(k) apply: one workgroup per (overlapping) additive-Schwarz block -------------------------------------
 // Restricted additive Schwarz: the block solves on its extended (core + overlap) unknowns and writes back only the
-// core part (PETSc's default PC_ASM_RESTRICT, reference DALinearEqn.C:199-216).  The block's work vector lives in
-// LDS when it fits (<= 160 KiB), otherwise in a global scratch vector.  GROUP lanes cooperate on one row; rows of
-// one level are independent.
+// core part (PETSc's default PC_ASM_RESTRICT, reference DALinearEqn.C:199-216).
+//
+// MI355X design of the triangular solves: level scheduling has O(10^3) levels of only a few rows each, so the cost is
+// the dependent-latency chain per level, not bandwidth.  Therefore
+//   * the block's work vector lives in LDS (<= 160 KiB) - dependent reads are LDS reads;
+//   * the factor is stored as ONE entry stream per block sorted by (level, row): {value fp64, row u16, col u16}; a level
+//     is a contiguous range of the stream, every thread owns the entries e = tid (mod T) and applies
+//     x[row] -= val * x[col] with an LDS fp64 atomic (rows of a level are independent, so only same-row partial
+//     sums collide);
+//   * U rows are pre-divided by their pivot and x is scaled by 1/pivot once before the backward sweep, so each level
+//     needs exactly one workgroup barrier;
+//   * entry loads do not depend on x: each thread keeps its next PF entries in registers (software prefetch), so the
+//     HBM/L2 latency is overlapped with the barriers of the preceding levels.
+#ifndef PC_THREADS
 #define PC_THREADS 1024
-#define PC_GROUP 16
+#endif
+#ifndef PC_PF
+#define PC_PF 8
+#endif
 struct PCView {
     int nBlocks;
-    const long long* boff;    // nBlocks+1: offset of the block's (extended) unknowns
-    const int* gidx;          // extended position -> global state index (gather)
-    const int* gout;          // extended position -> global state index if owned by the block's core, else -1
-    const long long* frp;     // factor row pointers over extended positions (n_ext+1)
-    const int* fci;           // factor column = block-local index
-    const double* fv;
-    const long long* fdiag;   // position of the diagonal in row
-    const int* Lrows;         // block-local row ids sorted by L-level
-    const long long* Llev;    // level pointers into Lrows, concatenated per block
-    const long long* LlevOff; // nBlocks+1: offsets into Llev
-    const int* Urows;
-    const long long* Ulev;
-    const long long* UlevOff;
+    const long long* boff;     // nBlocks+1: offset of the block's (extended) unknowns
+    const int* gidx;           // extended position -> global state index (gather)
+    const int* gout;           // extended position -> global state index if owned by the block's core, else -1
+    const double* invd;        // 1/pivot per extended position
+    // L and U entry streams
+    const double* sval[2];
+    const unsigned* srowcol[2];  // row | col << 16 (block-local)
+    const long long* slev[2];    // level pointers into the streams (absolute entry offsets), concatenated per block
+    const long long* slevOff[2]; // nBlocks+1 offsets into slev
+    double* xglob;             // global scratch when a block does not fit into LDS
 };
+
 template <bool USE_LDS>
-__global__ __launch_bounds__(PC_THREADS) void k_ras_apply(PCView P, const double* __restrict__ b, double* __restrict__ xglob, double* __restrict__ out) {
+__device__ __forceinline__ void ras_sweep(const double* __restrict__ sval, const unsigned* __restrict__ src, const long long* __restrict__ lev,
+                                          long long l0, long long l1, double* xw, int* lvl) {
+    // level pointers of this block -> LDS (relative to the block's first entry), so that the per-level loop never
+    // issues a dependent global load (which would also drain the prefetch queue through s_waitcnt vmcnt(0))
+    const long long ebeg = lev[l0];
+    const int nlev = (int)(l1 - l0);  // number of pointers
+    for (int k = threadIdx.x; k < nlev; k += PC_THREADS) lvl[k] = (int)(lev[l0 + k] - ebeg);
+    __syncthreads();
+    const int eend = lvl[nlev - 1];
+    const double* __restrict__ bv = sval + ebeg;
+    const unsigned* __restrict__ br = src + ebeg;
+    int e = threadIdx.x;
+    double pv[PC_PF];
+    unsigned pr[PC_PF];
+#pragma unroll
+    for (int k = 0; k < PC_PF; k++) {
+        int ee = e + k * PC_THREADS;
+        pv[k] = ee < eend ? bv[ee] : 0.0;
+        pr[k] = ee < eend ? br[ee] : 0u;
+    }
+    for (int lv = 0; lv < nlev - 1; lv++) {
+        const int e1 = lvl[lv + 1];
+        while (e < e1) {
+            const double v = pv[0];
+            const unsigned rc = pr[0];
+#pragma unroll
+            for (int k = 0; k < PC_PF - 1; k++) { pv[k] = pv[k + 1]; pr[k] = pr[k + 1]; }
+            const int en = e + PC_PF * PC_THREADS;
+            pv[PC_PF - 1] = en < eend ? bv[en] : 0.0;
+            pr[PC_PF - 1] = en < eend ? br[en] : 0u;
+            const double contrib = -v * xw[rc >> 16];
+            if (USE_LDS) __hip_atomic_fetch_add(&xw[rc & 0xffffu], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else atomicAdd(&xw[rc & 0xffffu], contrib);
+            e += PC_THREADS;
+        }
+        __syncthreads();
+    }
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(PC_THREADS) void k_ras_apply(PCView P, const double* __restrict__ b, double* __restrict__ out, int maxLev) {
     extern __shared__ double xs[];
     const int blk = blockIdx.x;
     const long long o0 = P.boff[blk];
     const int nloc = (int)(P.boff[blk + 1] - o0);
-    double* xw = USE_LDS ? xs : xglob + o0;
+    int* lvl = (int*)xs;                                   // maxLev+2 ints, padded to 8 bytes
+    double* xlds = xs + ((maxLev + 2 + 1) >> 1);
+    double* xw = USE_LDS ? xlds : P.xglob + o0;
     for (int i = threadIdx.x; i < nloc; i += PC_THREADS) xw[i] = b[P.gidx[o0 + i]];
     __syncthreads();
-    const int grp = threadIdx.x / PC_GROUP, gl = threadIdx.x % PC_GROUP, ngrp = PC_THREADS / PC_GROUP;
-    // forward: L (unit diagonal)
-    for (long long lv = P.LlevOff[blk]; lv < P.LlevOff[blk + 1] - 1; lv++) {
-        long long r0 = P.Llev[lv], r1 = P.Llev[lv + 1];
-        for (long long r = r0 + grp; r < r1; r += ngrp) {
-            int i = P.Lrows[r];
-            double s = 0.0;
-            for (long long k = P.frp[o0 + i] + gl; k < P.fdiag[o0 + i]; k += PC_GROUP) s += P.fv[k] * xw[P.fci[k]];
-#pragma unroll
-            for (int o = PC_GROUP / 2; o > 0; o >>= 1) s += __shfl_down(s, o, PC_GROUP);
-            if (gl == 0) xw[i] -= s;
-        }
-        __syncthreads();
-    }
-    // backward: U
-    for (long long lv = P.UlevOff[blk]; lv < P.UlevOff[blk + 1] - 1; lv++) {
-        long long r0 = P.Ulev[lv], r1 = P.Ulev[lv + 1];
-        for (long long r = r0 + grp; r < r1; r += ngrp) {
-            int i = P.Urows[r];
-            double s = 0.0;
-            const long long d = P.fdiag[o0 + i];
-            for (long long k = d + 1 + gl; k < P.frp[o0 + i + 1]; k += PC_GROUP) s += P.fv[k] * xw[P.fci[k]];
-#pragma unroll
-            for (int o = PC_GROUP / 2; o > 0; o >>= 1) s += __shfl_down(s, o, PC_GROUP);
-            if (gl == 0) xw[i] = (xw[i] - s) / P.fv[d];
-        }
-        __syncthreads();
-    }
+    ras_sweep<USE_LDS>(P.sval[0], P.srowcol[0], P.slev[0], P.slevOff[0][blk], P.slevOff[0][blk + 1], xw, lvl);
+    for (int i = threadIdx.x; i < nloc; i += PC_THREADS) xw[i] *= P.invd[o0 + i];
+    __syncthreads();
+    ras_sweep<USE_LDS>(P.sval[1], P.srowcol[1], P.slev[1], P.slevOff[1][blk], P.slevOff[1][blk + 1], xw, lvl);
     for (int i = threadIdx.x; i < nloc; i += PC_THREADS) {
         int g = P.gout[o0 + i];
         if (g >= 0) out[g] = xw[i];
@@ -380,9 +410,10 @@ struct BlockILU {
     int nBlocks = 0;
     long long fnnz = 0;
     int maxLocal = 0;  // largest number of unknowns in one block
-    DevBuf<long long> boff, frp, fdiag, Llev, LlevOff, Ulev, UlevOff;
-    DevBuf<int> gidx, gout, fci, Lrows, Urows;
-    DevBuf<double> fv, xw;
+    DevBuf<long long> boff, slev[2], slevOff[2];
+    DevBuf<int> gidx, gout;
+    DevBuf<unsigned> srowcol[2];
+    DevBuf<double> sval[2], invd, xw;
     PCView view;
     int maxLevels = 0;
     bool useLDS = false;
@@ -816,57 +847,66 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
         }
     }
     DAS_CHECK(err.empty(), DAS_ERR_INTERNAL, "block ILU setup failed: " + err);
-    // concatenate
+    // concatenate into per-block entry streams sorted by (level, row)
     BlockILU& P = k->pc;
-    std::vector<long long> boff(nB + 1, 0), frp, fdiag, Llev, LlevOff(nB + 1, 0), Ulev, UlevOff(nB + 1, 0);
-    std::vector<int> gidx, gout, fci, Lrows, Urows;
-    std::vector<double> fv;
+    std::vector<long long> boff(nB + 1, 0), slev[2], slevOff[2];
+    std::vector<int> gidx, gout;
+    std::vector<double> invd, sval[2];
+    std::vector<unsigned> src[2];
     long long next = 0, fnnz = 0;
     int maxLocal = 0, maxLv = 0, nshift = 0;
     for (int b = 0; b < nB; b++) { next += (long long)BF[b].gidx.size(); fnnz += (long long)BF[b].fci.size(); }
-    DAS_CHECK(fnnz < (1LL << 62), DAS_ERR_INTERNAL, "factor too large");
-    gidx.reserve(next); gout.reserve(next); frp.reserve(next + 1); fdiag.reserve(next); fci.reserve(fnnz); fv.reserve(fnnz);
-    Lrows.reserve(next); Urows.reserve(next);
-    frp.push_back(0);
+    gidx.reserve(next); gout.reserve(next); invd.reserve(next);
+    for (int t = 0; t < 2; t++) { sval[t].reserve(fnnz / 2 + 16); src[t].reserve(fnnz / 2 + 16); slevOff[t].assign(nB + 1, 0); }
     P.h_core_perm.clear();
     P.h_core_off.assign(1, 0);
     for (int b = 0; b < nB; b++) {
         BlockFactor& F = BF[b];
-        const long long ebase = (long long)fci.size();
-        const long long rbase = (long long)Lrows.size();
         const int nl = (int)F.gidx.size();
+        DAS_CHECK(nl <= 65535, DAS_ERR_ARG, "preconditioner block larger than 65535 unknowns: reduce amd.pcBlockCells");
         maxLocal = std::max(maxLocal, nl);
         nshift += F.nshift;
         gidx.insert(gidx.end(), F.gidx.begin(), F.gidx.end());
         gout.insert(gout.end(), F.gout.begin(), F.gout.end());
         for (int g : F.gout) if (g >= 0) P.h_core_perm.push_back(g);
         P.h_core_off.push_back((long long)P.h_core_perm.size());
-        for (int i = 0; i < nl; i++) { frp.push_back(ebase + F.frp[i + 1]); fdiag.push_back(ebase + F.fdiag[i]); }
-        fci.insert(fci.end(), F.fci.begin(), F.fci.end());
-        fv.insert(fv.end(), F.fv.begin(), F.fv.end());
-        LlevOff[b] = (long long)Llev.size();
-        for (long long x : F.Llev) Llev.push_back(rbase + x);
-        UlevOff[b] = (long long)Ulev.size();
-        for (long long x : F.Ulev) Ulev.push_back(rbase + x);
-        Lrows.insert(Lrows.end(), F.Lrows.begin(), F.Lrows.end());
-        Urows.insert(Urows.end(), F.Urows.begin(), F.Urows.end());
+        for (int i = 0; i < nl; i++) invd.push_back(1.0 / F.fv[F.fdiag[i]]);
+        // L stream
+        slevOff[0][b] = (long long)slev[0].size();
+        for (size_t l = 0; l + 1 < F.Llev.size(); l++) {
+            slev[0].push_back((long long)sval[0].size());
+            for (long long r = F.Llev[l]; r < F.Llev[l + 1]; r++) {
+                int i = F.Lrows[r];
+                for (long long q = F.frp[i]; q < F.fdiag[i]; q++) { sval[0].push_back(F.fv[q]); src[0].push_back((unsigned)i | ((unsigned)F.fci[q] << 16)); }
+            }
+        }
+        slev[0].push_back((long long)sval[0].size());
+        // U stream (rows pre-divided by the pivot)
+        slevOff[1][b] = (long long)slev[1].size();
+        for (size_t l = 0; l + 1 < F.Ulev.size(); l++) {
+            slev[1].push_back((long long)sval[1].size());
+            for (long long r = F.Ulev[l]; r < F.Ulev[l + 1]; r++) {
+                int i = F.Urows[r];
+                const double idg = 1.0 / F.fv[F.fdiag[i]];
+                for (long long q = F.fdiag[i] + 1; q < F.frp[i + 1]; q++) { sval[1].push_back(F.fv[q] * idg); src[1].push_back((unsigned)i | ((unsigned)F.fci[q] << 16)); }
+            }
+        }
+        slev[1].push_back((long long)sval[1].size());
         maxLv = std::max<int>(maxLv, std::max((int)F.Llev.size(), (int)F.Ulev.size()) - 1);
         boff[b + 1] = boff[b] + nl;
         F = BlockFactor();  // free
     }
-    LlevOff[nB] = (long long)Llev.size();
-    UlevOff[nB] = (long long)Ulev.size();
+    for (int t = 0; t < 2; t++) slevOff[t][nB] = (long long)slev[t].size();
     DAS_CHECK((long long)P.h_core_perm.size() == n, DAS_ERR_INTERNAL, "block cores do not cover all states exactly once");
     P.n = n; P.next = next; P.nBlocks = nB; P.fnnz = fnnz; P.maxLevels = maxLv; P.maxLocal = maxLocal;
-    P.boff.upload(boff); P.gidx.upload(gidx); P.gout.upload(gout); P.frp.upload(frp); P.fci.upload(fci); P.fv.upload(fv); P.fdiag.upload(fdiag);
-    P.Lrows.upload(Lrows); P.Llev.upload(Llev); P.LlevOff.upload(LlevOff);
-    P.Urows.upload(Urows); P.Ulev.upload(Ulev); P.UlevOff.upload(UlevOff);
-    P.useLDS = (size_t)maxLocal * sizeof(double) <= 160 * 1024;
+    P.boff.upload(boff); P.gidx.upload(gidx); P.gout.upload(gout); P.invd.upload(invd);
+    for (int t = 0; t < 2; t++) { P.sval[t].upload(sval[t]); P.srowcol[t].upload(src[t]); P.slev[t].upload(slev[t]); P.slevOff[t].upload(slevOff[t]); }
+    P.useLDS = (size_t)maxLocal * sizeof(double) + (size_t)(maxLv + 4) * sizeof(int) + 16 <= 160 * 1024;
     if (!P.useLDS) P.xw.alloc(next);
-    else {
-        DAS_HIP(hipFuncSetAttribute((const void*)k_ras_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
-    P.view = PCView{nB, P.boff.p, P.gidx.p, P.gout.p, P.frp.p, P.fci.p, P.fv.p, P.fdiag.p, P.Lrows.p, P.Llev.p, P.LlevOff.p, P.Urows.p, P.Ulev.p, P.UlevOff.p};
+    else DAS_HIP(hipFuncSetAttribute((const void*)k_ras_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    P.view.nBlocks = nB; P.view.boff = P.boff.p; P.view.gidx = P.gidx.p; P.view.gout = P.gout.p; P.view.invd = P.invd.p;
+    for (int t = 0; t < 2; t++) { P.view.sval[t] = P.sval[t].p; P.view.srowcol[t] = P.srowcol[t].p; P.view.slev[t] = P.slev[t].p; P.view.slevOff[t] = P.slevOff[t].p; }
+    P.view.xglob = P.xw.p;
     P.setup_seconds = wall_seconds() - t0;
     if (s->opt.geti("debug"))
         fprintf(stderr, "[dafoam_amd] RAS(overlap %d)+ILU(%d): %d blocks, n_ext=%lld (%.2fx), nnz(LU)=%lld, max block %d unknowns (%s), max levels %d, "
@@ -877,11 +917,13 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
 static void pc_apply(das_solver* s, das_ksp* k, const double* b, double* x) {
     hipEvent_t ev = nullptr;
     s->timer.begin("pc", s->stream, ev);
+    const int mlv = k->pc.maxLevels;
+    const size_t lvlBytes = (size_t)((mlv + 2 + 1) >> 1) * sizeof(double);
     if (k->pc.useLDS)
-        hipLaunchKernelGGL(k_ras_apply<true>, dim3(k->pc.nBlocks), dim3(PC_THREADS), (size_t)k->pc.maxLocal * sizeof(double), s->stream, k->pc.view, b,
-                           (double*)nullptr, x);
+        hipLaunchKernelGGL(k_ras_apply<true>, dim3(k->pc.nBlocks), dim3(PC_THREADS), lvlBytes + (size_t)k->pc.maxLocal * sizeof(double), s->stream,
+                           k->pc.view, b, x, mlv);
     else
-        hipLaunchKernelGGL(k_ras_apply<false>, dim3(k->pc.nBlocks), dim3(PC_THREADS), 0, s->stream, k->pc.view, b, k->pc.xw.p, x);
+        hipLaunchKernelGGL(k_ras_apply<false>, dim3(k->pc.nBlocks), dim3(PC_THREADS), lvlBytes, s->stream, k->pc.view, b, x, mlv);
     s->timer.end("pc", s->stream, ev);
 }
 
