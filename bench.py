@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--nz", type=int, default=int(os.environ.get("DAS_BENCH_NZ", 40)))
     ap.add_argument("--cpu-sample-iters", type=int, default=int(os.environ.get("DAS_BENCH_CPU_ITERS", 6)))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--block", type=int, default=int(os.environ.get("DAS_BENCH_BLOCK", 1024)))
+    ap.add_argument("--overlap", type=int, default=int(os.environ.get("DAS_BENCH_OVERLAP", 1)))
+    ap.add_argument("--fill", type=int, default=int(os.environ.get("DAS_BENCH_FILL", 1)))
     return ap.parse_args()
 
 
@@ -60,18 +63,30 @@ def main():
     from dafoam_amd.pyDASolvers import KSP, Mat
 
     t_setup = time.time()
-    # state = prolongation of a converged coarse primal (dafoam_amd/data/channel_primal_coarse.npz)
-    case = bench_channel_case(a.nx, a.ny, a.nz)
-    ncell = case.mesh.n_cells
     opts = {
         "solverName": "DASimpleFoam",
         "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0},
         "adjEqnOption": {"gmresRestart": max(a.steps, a.warmup, 1), "gmresMaxIters": 100000, "gmresRelTol": 1e-30,
-                         "gmresAbsTol": 1e-300, "printInfo": 0},
+                         "gmresAbsTol": 1e-300, "printInfo": 0, "asmOverlap": a.overlap, "pcFillLevel": a.fill},
+        "amd": {"pcBlockCells": a.block},
         "amdDevice": local_rank,
     }
-    D = PYDAFOAM(options=opts, case=case)
     L = _capi.lib()
+    sharded = None
+    if world > 1:
+        # weak scaling: the global channel has nx*world cell columns, every rank owns nx of them (+3 ghost layers);
+        # halo reduction over RCCL p2p, dots over RCCL all-reduce (dafoam_amd/distributed.py)
+        from dafoam_amd.distributed import ShardedAdjoint
+
+        sharded = ShardedAdjoint(a.nx * world, a.ny, a.nz, opts, device_index=local_rank)
+        D = sharded.D
+        case = sharded.case
+        ncell = a.nx * a.ny * a.nz
+    else:
+        # state = prolongation of a converged coarse primal (dafoam_amd/data/channel_primal_coarse.npz)
+        case = bench_channel_case(a.nx, a.ny, a.nz)
+        ncell = case.mesh.n_cells
+        D = PYDAFOAM(options=opts, case=case)
     h = D.solver._h
     n = D.getNLocalAdjointStates()
     t0 = time.time()
@@ -89,11 +104,12 @@ def main():
     t0 = time.time()
     D.solverAD.initializedRdWTMatrixFree()
     t_op = time.time() - t0
-    # operator nnz
-    op_nnz = None
     # rhs on the device (torch owns the buffers; the C-ABI gets raw pointers)
     rng = np.random.default_rng(1234 + rank)
-    rhs = torch.from_numpy(rng.standard_normal(n)).cuda()
+    rhs_h = rng.standard_normal(n)
+    if sharded is not None:
+        rhs_h = np.where(sharded.owned, rhs_h, 0.0)
+    rhs = torch.from_numpy(rhs_h).cuda()
     sol = torch.zeros(n, dtype=torch.float64, device="cuda")
     setup_s = time.time() - t_setup
 
@@ -167,7 +183,8 @@ def main():
                 "dRdWT_structural_nnz": opmat_nnz,
                 "colors": int(ncolors),
                 "gmres_restart": max(a.steps, a.warmup, 1),
-                "pc": "block-ILU(0) of FD dRdWTPC, one workgroup per block",
+                "pc": f"RAS(overlap {a.overlap} cell ring)+ILU({a.fill}) of FD dRdWTPC, RCB blocks of <= {a.block} cells, one workgroup per block",
+                "halo_ms": L.das_timer_avg_ms(h, b"halo") if world > 1 else None,
                 "setup_seconds": {"total": setup_s, "coloring_host": t_color, "dRdWTPC_fd": t_pcmat, "ilu_host": t_ilu, "dRdWT_dual": t_op},
                 "dRdWTPsi_GBps": achieved,
                 "spmv_ms": spmv_ms,

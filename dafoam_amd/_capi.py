@@ -186,6 +186,9 @@ _SIGS = {
     "das_ksp_get_history": (C.c_int, [_VP, c_double_p, C.c_int]),
     "das_ksp_run_fixed_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),
     "das_ksp_destroy": (None, [_VP]),
+    "das_set_owned_mask": (C.c_int, [_VP, C.POINTER(C.c_ubyte)]),
+    "das_set_comm": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "das_set_stream": (C.c_int, [_VP, _VP]),
     "das_get_elapsed_clock_time": (C.c_double, [_VP]),
     "das_get_elapsed_cpu_time": (C.c_double, [_VP]),
     "das_timer_avg_ms": (C.c_double, [_VP, C.c_char_p]),

@@ -143,21 +143,26 @@ __global__ void k_scatter_fd(long long n, const double* __restrict__ R, const do
     if (p >= 0) vals[rc_dest[p]] = (R[i] - R0[i]) * rdelta;
 }
 // jacLowerBound filter (reference DAPartDeriv.C:192): keep |v| > bound or diagonal
+// (multi-GPU: columns = residuals not owned by this rank are dropped; `owned` may be null)
+__device__ __forceinline__ bool keep_entry(long long i, int c, double v, double bound, bool useBound, const unsigned char* owned) {
+    if (owned && !owned[c]) return false;
+    return !useBound || fabs(v) > bound || c == i;
+}
 __global__ void k_count_keep(long long n, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v, double bound,
-                             int* cnt) {
+                             bool useBound, const unsigned char* __restrict__ owned, int* cnt) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c = 0;
-    for (long long k = rp[i]; k < rp[i + 1]; k++) c += (fabs(v[k]) > bound || ci[k] == i) ? 1 : 0;
+    for (long long k = rp[i]; k < rp[i + 1]; k++) c += keep_entry(i, ci[k], v[k], bound, useBound, owned) ? 1 : 0;
     cnt[i] = c;
 }
 __global__ void k_compact(long long n, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v, double bound,
-                          const long long* __restrict__ nrp, int* nci, double* nv) {
+                          bool useBound, const unsigned char* __restrict__ owned, const long long* __restrict__ nrp, int* nci, double* nv) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     long long o = nrp[i];
     for (long long k = rp[i]; k < rp[i + 1]; k++)
-        if (fabs(v[k]) > bound || ci[k] == i) { nci[o] = ci[k]; nv[o] = v[k]; o++; }
+        if (keep_entry(i, ci[k], v[k], bound, useBound, owned)) { nci[o] = ci[k]; nv[o] = v[k]; o++; }
 }
 
 // =====================================================================================================
@@ -468,6 +473,12 @@ struct das_solver {
     ConDev cd[2];
     std::unique_ptr<das_mat> op;  // matrix-free operator (dual-number assembled dRdW^T)
     hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<unsigned char> owned;  // per state; empty = single-domain
+    DevBuf<unsigned char> d_owned;
+    das_halo_cb halo_cb = nullptr;
+    das_allreduce_cb allreduce_cb = nullptr;
+    void* comm_user = nullptr;
     KernelTimer timer;
     double t0_wall = 0;
     std::clock_t t0_cpu = 0;
@@ -541,6 +552,12 @@ static void spmv(das_solver* s, const Mat& A, const double* x, double* y) {
     s->timer.begin("spmv", s->stream, ev);
     hipLaunchKernelGGL(k_spmv_wave, dim3(nblk(A.n, 4)), dim3(256), 0, s->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y);
     s->timer.end("spmv", s->stream, ev);
+    if (s->halo_cb) {  // ghost-row contributions -> owner ranks (one neighbour exchange per product)
+        hipEvent_t eh = nullptr;
+        s->timer.begin("halo", s->stream, eh);
+        s->halo_cb(y, s->comm_user);
+        s->timer.end("halo", s->stream, eh);
+    }
 }
 
 // ---- coloured assembly: DAPartDeriv::calcPartDerivMat (reference DAPartDeriv.C:350-473) -----------------------
@@ -579,14 +596,17 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
     std::unique_ptr<das_mat> out(new das_mat);
     Mat& M = out->m;
     M.n = n;
-    if (bound < 1.0e-16) {
+    const bool masked = !s->owned.empty();
+    const bool useBound = !(bound < 1.0e-16);
+    if (!useBound && !masked) {
         M.nnz = jc.nnz;
         M.rowptr.upload(jc.t_rowptr);
         M.col.upload(jc.t_col);
         M.val = std::move(vals);
     } else {
         DevBuf<int> cnt(n);
-        hipLaunchKernelGGL(k_count_keep, dim3(nblk(n, B)), dim3(B), 0, st, n, c.t_rowptr.p, c.t_col.p, vals.p, bound, cnt.p);
+        hipLaunchKernelGGL(k_count_keep, dim3(nblk(n, B)), dim3(B), 0, st, n, c.t_rowptr.p, c.t_col.p, vals.p, bound, useBound,
+                           masked ? s->d_owned.p : (const unsigned char*)nullptr, cnt.p);
         DAS_HIP(hipStreamSynchronize(st));
         std::vector<int> hc = cnt.to_host();
         std::vector<long long> nrp(n + 1, 0);
@@ -595,7 +615,8 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
         M.rowptr.upload(nrp);
         M.col.alloc(M.nnz);
         M.val.alloc(M.nnz);
-        hipLaunchKernelGGL(k_compact, dim3(nblk(n, B)), dim3(B), 0, st, n, c.t_rowptr.p, c.t_col.p, vals.p, bound, M.rowptr.p, M.col.p, M.val.p);
+        hipLaunchKernelGGL(k_compact, dim3(nblk(n, B)), dim3(B), 0, st, n, c.t_rowptr.p, c.t_col.p, vals.p, bound, useBound,
+                           masked ? s->d_owned.p : (const unsigned char*)nullptr, M.rowptr.p, M.col.p, M.val.p);
     }
     DAS_HIP(hipStreamSynchronize(st));
     return out.release();
@@ -692,12 +713,25 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     const int lfill = (int)std::max<long long>(0, s->opt.geti("adjEqnOption.pcFillLevel"));
     // compact sub-domains by recursive coordinate bisection of the cell centres (the reference decomposes with
     // scotch, pyDAFoam.py:597-604; RCB gives comparable compact blocks without a graph library)
-    std::vector<int> cellOrder(m.nC);
-    std::iota(cellOrder.begin(), cellOrder.end(), 0);
+    // multi-GPU: only cells owned by this rank take part (block-Jacobi across ranks, like the reference's one
+    // ASM sub-domain per MPI rank); a cell is owned iff its first cell-state is owned
+    std::vector<char> cellOwned(m.nC, 1);
+    long long nOwnedStates = n;
+    if (!s->owned.empty()) {
+        const StateDef& s0 = s->st_full.states[0];
+        const int stride = s0.kind == KIND_VEC ? 3 : 1;
+        for (int c = 0; c < m.nC; c++) cellOwned[c] = s->owned[s0.offset + (long long)stride * c] ? 1 : 0;
+        nOwnedStates = 0;
+        for (unsigned char o : s->owned) nOwnedStates += o ? 1 : 0;
+    }
+    std::vector<int> cellOrder;
+    cellOrder.reserve(m.nC);
+    for (int c = 0; c < m.nC; c++) if (cellOwned[c]) cellOrder.push_back(c);
+    const long long nOwnedCells = (long long)cellOrder.size();
     std::vector<long long> cboff;
     {
         struct Range { long long b, e; };
-        std::vector<Range> stack{{0, (long long)m.nC}}, leaves;
+        std::vector<Range> stack{{0, nOwnedCells}}, leaves;
         while (!stack.empty()) {
             Range r = stack.back();
             stack.pop_back();
@@ -715,7 +749,7 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
         }
         std::sort(leaves.begin(), leaves.end(), [](const Range& a, const Range& b2) { return a.b < b2.b; });
         for (auto& r : leaves) { std::sort(cellOrder.begin() + r.b, cellOrder.begin() + r.e); cboff.push_back(r.b); }
-        cboff.push_back(m.nC);
+        cboff.push_back(nOwnedCells);
     }
     const int nB = (int)cboff.size() - 1;
     std::vector<std::vector<int>> owned(m.nC);
@@ -750,7 +784,7 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
                     for (int c : frontier)
                         for (int q = m.cc_ptr[c]; q < m.cc_ptr[c + 1]; q++) {
                             int y = m.cc[q];
-                            if (cmark[y] != b) { cmark[y] = b; ext.push_back(y); nxt.push_back(y); }
+                            if (cmark[y] != b && cellOwned[y]) { cmark[y] = b; ext.push_back(y); nxt.push_back(y); }
                         }
                     frontier.swap(nxt);
                 }
@@ -765,7 +799,11 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
                 // unknown list, cell by cell
                 for (size_t q = 0; q < ext.size(); q++) {
                     long long c = ext[q];
-                    auto push = [&](long long g) { F.gidx.push_back((int)g); F.gout.push_back(isCore[q] ? (int)g : -1); };
+                    auto push = [&](long long g) {
+                        if (!s->owned.empty() && !s->owned[g]) return;  // e.g. cut-patch faces of the extended mesh
+                        F.gidx.push_back((int)g);
+                        F.gout.push_back(isCore[q] ? (int)g : -1);
+                    };
                     for (const StateDef& sd : s->st_full.states) {
                         if (sd.kind == KIND_VEC) for (int k2 = 0; k2 < 3; k2++) push(sd.offset + 3 * c + k2);
                         else if (sd.kind == KIND_SCL) push(sd.offset + c);
@@ -897,7 +935,7 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
         F = BlockFactor();  // free
     }
     for (int t = 0; t < 2; t++) slevOff[t][nB] = (long long)slev[t].size();
-    DAS_CHECK((long long)P.h_core_perm.size() == n, DAS_ERR_INTERNAL, "block cores do not cover all states exactly once");
+    DAS_CHECK((long long)P.h_core_perm.size() == nOwnedStates, DAS_ERR_INTERNAL, "block cores do not cover all owned states exactly once");
     P.n = n; P.next = next; P.nBlocks = nB; P.fnnz = fnnz; P.maxLevels = maxLv; P.maxLocal = maxLocal;
     P.boff.upload(boff); P.gidx.upload(gidx); P.gout.upload(gout); P.invd.upload(invd);
     for (int t = 0; t < 2; t++) { P.sval[t].upload(sval[t]); P.srowcol[t].upload(src[t]); P.slev[t].upload(slev[t]); P.slevOff[t].upload(slevOff[t]); }
@@ -941,6 +979,7 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
         k->restart = (int)restart;
         k->V.alloc((restart + 1) * n);
         k->w.alloc(n); k->z.alloc(n); k->r.alloc(n); k->xdev.alloc(n); k->bdev.alloc(n);
+        k->z.zero();  // multi-GPU: ghost entries are never written by the PC and must stay zero
         int nb = nblk(n, MD_CHUNK);
         k->partial.alloc((size_t)(restart + 2) * nb);
         k->hdev.alloc(restart + 2);
@@ -953,6 +992,7 @@ static void multidot(das_solver* s, das_ksp* k, int m, const double* w, double* 
     int nb = nblk(n, MD_CHUNK);
     hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, n, m, k->V.p, n, w, k->partial.p, nb);
     hipLaunchKernelGGL(k_reduce, dim3(m + 1), dim3(256), 0, s->stream, nb, k->partial.p, k->hdev.p);
+    if (s->allreduce_cb) s->allreduce_cb(k->hdev.p, m + 1, s->comm_user);
     DAS_HIP(hipMemcpyAsync(h_host, k->hdev.p, (m + 1) * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     DAS_HIP(hipStreamSynchronize(s->stream));
 }
@@ -1096,7 +1136,7 @@ das_solver_t* das_create(const das_case_t* c) {
 }
 void das_destroy(das_solver_t* s) {
     if (!s) return;
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->stream && s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
 int das_set_option_double(das_solver_t* s, const char* key, double v) {
@@ -1144,6 +1184,8 @@ int das_init_solver(das_solver_t* s, int device) {
     DAS_HIP(hipSetDevice(device));
     s->device = device;
     DAS_HIP(hipStreamCreate(&s->stream));
+    s->own_stream = true;
+    if (!s->owned.empty()) s->d_owned.upload(s->owned);
     const Mesh& m = s->mesh;
     s->d_fg.upload(m.fg); s->d_cg.upload(m.cg);
     s->d_cf_ptr.upload(m.cf_ptr); s->d_cf_face.upload(m.cf_face); s->d_cf_other.upload(m.cf_other);
@@ -1422,6 +1464,34 @@ int das_ksp_run_fixed_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rh
     DAS_CATCH
 }
 void das_ksp_destroy(das_ksp_t* k) { delete k; }
+
+int das_set_owned_mask(das_solver_t* s, const unsigned char* owned) {
+    DAS_TRY
+    DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
+    if (!owned) { s->owned.clear(); return DAS_OK; }
+    s->owned.assign(owned, owned + s->n);
+    if (s->inited) s->d_owned.upload(s->owned);
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_set_comm(das_solver_t* s, das_halo_cb halo, das_allreduce_cb allreduce, void* user) {
+    DAS_TRY
+    DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
+    s->halo_cb = halo;
+    s->allreduce_cb = allreduce;
+    s->comm_user = user;
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_set_stream(das_solver_t* s, void* hip_stream) {
+    DAS_TRY
+    need_init(s);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    s->stream = (hipStream_t)hip_stream;
+    s->own_stream = false;
+    return DAS_OK;
+    DAS_CATCH
+}
 
 double das_get_elapsed_clock_time(das_solver_t* s) { return s ? wall_seconds() - s->t0_wall : -1.0; }
 double das_get_elapsed_cpu_time(das_solver_t* s) { return s ? (double)(std::clock() - s->t0_cpu) / CLOCKS_PER_SEC : -1.0; }

@@ -1,0 +1,234 @@
+"""Cell-partition sharding of the adjoint hot path across GPUs (one process per GPU, torch.distributed).
+
+Reference: MPI domain decomposition (one OpenFOAM sub-domain per rank; processor patches + PETSc VecScatter,
+SURVEY.md section 2.3).  MI355X design:
+
+  * every rank holds an EXTENDED sub-mesh = its owned cells + GHOST_LAYERS (=3, the stencil depth of pRes,
+    reference DAStateInfoSimpleFoam.C:86-93) layers of ghost cells; residuals of owned cells are exact on it;
+  * each rank colours and assembles its own rows independently (colours are not shared between ranks);
+    the assembled operator is A_ext^T : rows = all extended states, columns = owned residuals;
+  * dRdW^T.x = local SpMV over the extended rows followed by ONE halo *reduction* (ghost-row contributions are
+    sent to the owner rank and added there) - grouped point-to-point over xGMI (each neighbour pair has its own
+    link); dots/norms = one small all-reduce per fused multi-dot;
+  * the preconditioner (RAS/ILU blocks) is built on owned cells only: no communication in the PC.
+
+The partition implemented here is a slab decomposition along x of the structured channel generators
+(dafoam_amd.meshgen); the halo machinery itself only needs (owner rank, global key) per extended state.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+GHOST_LAYERS = 3
+_KEY = 1 << 40
+
+
+@dataclass
+class SlabPartition:
+    NX: int
+    NY: int
+    NZ: int
+    rank: int
+    world: int
+    G: int = GHOST_LAYERS
+
+    def __post_init__(self):
+        assert self.NX % self.world == 0, "NX must be divisible by the number of ranks"
+        w = self.NX // self.world
+        assert w >= self.G, "slab thinner than the ghost depth"
+        self.i0, self.i1 = self.rank * w, (self.rank + 1) * w
+        self.e0, self.e1 = max(0, self.i0 - self.G), min(self.NX, self.i1 + self.G)
+        self.nxl = self.e1 - self.e0
+
+    def rank_of_column(self, gi):
+        return gi // (self.NX // self.world)
+
+
+def state_table(part: SlabPartition, mesh):
+    """Per extended state (DAIndex 'state' ordering of DASimpleFoam): global key, owner rank (-1 = cut face: belongs to
+    nobody), owned flag."""
+    N, F, nIF = mesh.n_cells, mesh.n_faces, mesh.n_internal_faces
+    nxl, NY, NX = part.nxl, part.NY, part.NX
+    c = np.arange(N)
+    il, j, k = c % nxl, (c // nxl) % NY, c // (nxl * NY)
+    gi = il + part.e0
+    cg = gi + NX * (j + NY * k)
+    crank = part.rank_of_column(gi)
+    own = mesh.owner.astype(np.int64)
+    nei = mesh.neighbour.astype(np.int64)
+    d = np.zeros(F, dtype=np.int64)
+    diff = nei - own[:nIF]
+    d[:nIF] = np.where(diff == 1, 0, np.where(diff == nxl, 1, 2))
+    assert np.all((diff == 1) | (diff == nxl) | (diff == nxl * NY))
+    is_cut = np.zeros(F, dtype=bool)
+    for pi, p in enumerate(mesh.patches):
+        sl = slice(p.start, p.start + p.size)
+        d[sl] = 3 + pi
+        if (pi == 0 and part.e0 > 0) or (pi == 1 and part.e1 < NX):
+            is_cut[sl] = True
+    fkey = (5 + d) * _KEY + cg[own]
+    frank = np.where(is_cut, -1, crank[own])
+    key = np.concatenate([0 * _KEY + np.repeat(cg, 3) * 3 + np.tile(np.arange(3), N), 3 * _KEY + cg, 4 * _KEY + cg, fkey])
+    # U keys: kind 0 with 3*cg+comp keeps the three components distinct
+    owner_rank = np.concatenate([np.repeat(crank, 3), crank, crank, frank])
+    return key, owner_rank, owner_rank == part.rank
+
+
+class HaloExchange:
+    """Halo reduction of ghost-row contributions (torch tensors, CPU or GPU).  Works with any backend that has
+    isend/irecv (nccl on GPUs = RCCL over xGMI; gloo in the CPU tests, staging GPU tensors through the host)."""
+
+    def __init__(self, key, owner_rank, rank, world, device="cpu"):
+        import torch
+        import torch.distributed as dist
+
+        self.rank, self.world = rank, world
+        self.device = device
+        self.n = key.size
+        ghost = (owner_rank != rank)
+        self.ghost_idx = torch.from_numpy(np.nonzero(ghost)[0]).to(device)
+        # what I hold for others (ghost states owned by q), sorted by key
+        send_keys = {}
+        self.send_idx = {}
+        for q in range(world):
+            if q == rank:
+                continue
+            sel = np.nonzero(owner_rank == q)[0]
+            if sel.size:
+                o = np.argsort(key[sel], kind="stable")
+                self.send_idx[q] = torch.from_numpy(sel[o]).to(device)
+                send_keys[q] = key[sel][o]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, send_keys)
+        lookup = dict(zip(key.tolist(), range(key.size)))
+        self.recv_idx = {}
+        for q in range(world):
+            if q == rank or rank not in gathered[q]:
+                continue
+            ks = gathered[q][rank]
+            idx = np.fromiter((lookup[kk] for kk in ks.tolist()), dtype=np.int64, count=ks.size)
+            assert np.all(owner_rank[idx] == rank), "peer lists a state as mine that I do not own"
+            self.recv_idx[q] = torch.from_numpy(idx).to(device)
+        self.peers = sorted(set(self.send_idx) | set(self.recv_idx))
+        self.stage = dist.get_backend() == "gloo" and str(device) != "cpu"
+        self.bytes_per_exchange = 8 * sum(int(v.numel()) for v in self.send_idx.values())
+
+    def reduce_(self, w):
+        """w (n,) : add ghost-row values into their owners, then zero the local ghost rows."""
+        import torch
+        import torch.distributed as dist
+
+        ops, recv_bufs, keep = [], {}, []
+        for q in self.peers:
+            if q in self.send_idx:
+                sb = w.index_select(0, self.send_idx[q])
+                if self.stage:
+                    sb = sb.cpu()
+                keep.append(sb)
+                ops.append(dist.P2POp(dist.isend, sb, q))
+            if q in self.recv_idx:
+                rb = torch.empty(self.recv_idx[q].numel(), dtype=w.dtype, device="cpu" if self.stage else w.device)
+                recv_bufs[q] = rb
+                ops.append(dist.P2POp(dist.irecv, rb, q))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        for q, rb in recv_bufs.items():
+            w.index_add_(0, self.recv_idx[q], rb.to(w.device))
+        if self.ghost_idx.numel():
+            w.index_fill_(0, self.ghost_idx, 0.0)
+        return w
+
+
+class _DevPtr:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+_HALO_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_ARED_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class ShardedAdjoint:
+    """One rank of the sharded adjoint: extended-mesh case -> PYDAFOAM on this rank's GPU with owned mask, stream and
+    communication callbacks installed."""
+
+    def __init__(self, NX, NY, NZ, options, device_index=0, wall_function=False, state="prolonged"):
+        import torch
+        import torch.distributed as dist
+
+        from . import _capi
+        from .meshgen import channel_case, load_coarse_primal, prolong_channel_state
+        from .pyDAFoam import PYDAFOAM
+
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        part = self.part = SlabPartition(NX, NY, NZ, self.rank, self.world)
+        co = load_coarse_primal()
+        case = channel_case(part.nxl, NY, NZ, lengths=co["lengths"], grading_y=co["grading_y"], wall_function=wall_function, perturb=0.0,
+                            x_range=(part.e0, part.e1, NX))
+        if state == "prolonged":
+            prolong_channel_state(case, (part.nxl, NY, NZ), co, i0=part.e0, nx_global=NX)
+        self.case = case
+        self.key, self.owner_rank, self.owned = state_table(part, case.mesh)
+        opts = dict(options)
+        opts["amdDevice"] = device_index
+        self.D = PYDAFOAM(options=opts, case=case)
+        L = self.L = _capi.lib()
+        h = self.h = self.D.solver._h
+        mask = np.ascontiguousarray(self.owned.astype(np.uint8))
+        _capi.check(L.das_set_owned_mask(h, mask.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        self.dev = torch.device("cuda", device_index)
+        self.halo = HaloExchange(self.key, self.owner_rank, self.rank, self.world, device=self.dev)
+        _capi.check(L.das_set_stream(h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+        n = self.n = self.key.size
+        stage = dist.get_backend() == "gloo"
+
+        def halo_cb(ptr, _user):
+            w = torch.as_tensor(_DevPtr(ptr, n), device=self.dev)
+            self.halo.reduce_(w)
+
+        def ared_cb(ptr, m, _user):
+            t = torch.as_tensor(_DevPtr(ptr, m), device=self.dev)
+            if stage:
+                c = t.cpu()
+                dist.all_reduce(c)
+                t.copy_(c)
+            else:
+                dist.all_reduce(t)
+
+        self._cb = (_HALO_CB(halo_cb), _ARED_CB(ared_cb))  # keep alive
+        _capi.check(L.das_set_comm(h, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
+        self.n_owned = int(self.owned.sum())
+
+    # ------------------------------------------------------------------ solve_linear sequence on the shard
+    def setup(self):
+        from .pyDASolvers import KSP, Mat
+
+        D = self.D
+        D.solver.runColoring()
+        self.pc = Mat()
+        D.solver.calcdRdWT(1, self.pc)
+        self.ksp = KSP()
+        D.solverAD.createMLRKSPMatrixFree(self.pc, self.ksp)
+        D.solverAD.initializedRdWTMatrixFree()
+
+    def solve(self, rhs_ext):
+        """rhs_ext: extended-length vector (ghost entries ignored).  Returns (psi_ext with zero ghosts, fail)."""
+        from .pyDASolvers import Vec
+
+        b = Vec(self.n)
+        b.array[:] = np.where(self.owned, rhs_ext, 0.0)
+        x = Vec(self.n)
+        fail = self.D.solverAD.solveLinearEqn(self.ksp, b, x)
+        return x.array.copy(), fail
+
+    def run_fixed(self, d_rhs, d_sol, iters):
+        from . import _capi
+
+        rc = self.L.das_ksp_run_fixed_device(self.h, self.ksp.handle, C.c_void_p(d_rhs.data_ptr()), C.c_void_p(d_sol.data_ptr()), int(iters))
+        if rc < 0:
+            raise _capi.DASError(self.L.das_last_error().decode())
+        return rc

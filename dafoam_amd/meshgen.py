@@ -93,8 +93,11 @@ def hex_block(
     patch_names=("inlet", "outlet", "bottom", "top", "front", "back"),
     patch_types=("patch", "patch", "wall", "wall", "symmetry", "symmetry"),
     grading_y: float = 1.0,
+    x_range=None,
 ) -> PolyMesh:
     """Structured nx*ny*nz hex block emitted as an unstructured polyMesh.
+    x_range=(e0, e1, NX): emit only the cell columns e0 <= i < e1 of a global block with NX cells in x (nx must be
+    e1-e0); point coordinates are those of the global lattice, so sub-blocks of different ranks coincide.
 
     mapping: optional function on the (P,3) unit-box point array (after scaling)
     used to bend/skew the block (creates non-orthogonality).
@@ -103,6 +106,10 @@ def hex_block(
     """
     Lx, Ly, Lz = lengths
     xs = np.linspace(0.0, Lx, nx + 1)
+    if x_range is not None:
+        e0, e1, NXg = x_range
+        assert nx == e1 - e0
+        xs = np.linspace(0.0, Lx, NXg + 1)[e0 : e1 + 1]
     if grading_y != 1.0:
         t = np.linspace(-1.0, 1.0, ny + 1)
         beta = np.log(grading_y)
@@ -304,6 +311,7 @@ def channel_case(
     side_walls=False,
     seed=0,
     perturb=0.02,
+    x_range=None,
 ) -> FoamCase:
     """DASimpleFoam + SA channel (7x7x7 = 343 cells mirrors the reference's
     ConvergentChannel size, tests/runRegTests_DASimpleFoamForward.py:32; U0/nu/nuTilda0
@@ -312,7 +320,7 @@ def channel_case(
     path) with a seeded perturbation so that no term degenerates."""
     types = ("patch", "patch", "wall", "wall") + (("wall", "wall") if side_walls else ("symmetry", "symmetry"))
     mesh = hex_block(
-        nx, ny, nz, lengths, bump_mapping(bump, skew, lengths[0], lengths[1]), patch_types=types, grading_y=grading_y
+        nx, ny, nz, lengths, bump_mapping(bump, skew, lengths[0], lengths[1]), patch_types=types, grading_y=grading_y, x_range=x_range
     )
     g = _InputGeometry(mesh)
     wall_nut = NUT_SPALDING_WALL if wall_function else NUT_LOWRE_WALL
@@ -345,6 +353,14 @@ def channel_case(
                 "nuTilda": (BC_SYMMETRY, 0.0),
                 "nut": (NUT_SYMMETRY, 0.0),
             }
+    # artificial cut patches of a rank's extended sub-mesh (multi-GPU): everything zero-gradient; their values never
+    # reach an owned residual row (ghost depth = stencil depth)
+    cut = {"U": (BC_ZERO_GRADIENT, (0.0, 0.0, 0.0)), "p": (BC_ZERO_GRADIENT, 0.0), "nuTilda": (BC_ZERO_GRADIENT, 0.0), "nut": (NUT_CALCULATED, 0.0)}
+    if x_range is not None:
+        if x_range[0] > 0:
+            bcs["inlet"] = dict(cut)
+        if x_range[1] < x_range[2]:
+            bcs["outlet"] = dict(cut)
     y = wall_distance(mesh, g.C, g.Cf, g.Sf)
     case = FoamCase(mesh=mesh, solver_name="DASimpleFoam", nu=nu, bcs=bcs, y_wall=y)
     # smooth synthetic state: turbulent-like profile in wall distance + perturbation
@@ -369,9 +385,9 @@ def channel_case(
     phi[:nIF] = np.einsum("ij,ij->i", Uf, g.Sf[:nIF])
     for pt in mesh.patches:
         sl = slice(pt.start, pt.start + pt.size)
-        if pt.name == "inlet":
+        if pt.name == "inlet" and bcs["inlet"]["U"][0] == BC_FIXED_VALUE:
             phi[sl] = U0 * g.Sf[sl, 0]
-        elif pt.name == "outlet":
+        elif pt.name in ("inlet", "outlet"):
             phi[sl] = np.einsum("ij,ij->i", U[own[sl]], g.Sf[sl])
         else:
             phi[sl] = 0.0

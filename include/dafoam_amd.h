@@ -188,6 +188,21 @@ int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
 int das_ksp_run_fixed_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rhs, double* d_sol, int iters);
 void das_ksp_destroy(das_ksp_t* k);
 
+/* ---- multi-GPU sharding (one process per GPU; reference: MPI domain decomposition, one OpenFOAM sub-domain per rank) ----
+ * The solver instance holds the rank's EXTENDED sub-mesh (owned cells + ghost layers).  owned[j] != 0 marks the
+ * states/residuals this rank owns (DAIndex ordering of the extended mesh).  With a mask set:
+ *   - assembled matrices keep only columns (residuals) owned by this rank (rows = all extended states),
+ *   - the preconditioner is built on owned cells only,
+ *   - after every operator product the halo callback is invoked on the device vector so that ghost-row
+ *     contributions can be sent to their owner ranks and added there (then zeroed locally),
+ *   - every fused dot-product result (device buffer of n doubles) goes through the all-reduce callback.
+ * Callbacks run on the stream given to das_set_stream (pass the communication library's current stream). */
+typedef void (*das_halo_cb)(double* d_vec, void* user);
+typedef void (*das_allreduce_cb)(double* d_buf, int n, void* user);
+int das_set_owned_mask(das_solver_t* s, const unsigned char* owned /* n states */);
+int das_set_comm(das_solver_t* s, das_halo_cb halo, das_allreduce_cb allreduce, void* user);
+int das_set_stream(das_solver_t* s, void* hip_stream);
+
 /* ---- timing (getElapsedClockTime/getElapsedCpuTime pyDASolvers.pyx:332-336) and kernel timers */
 double das_get_elapsed_clock_time(das_solver_t* s);
 double das_get_elapsed_cpu_time(das_solver_t* s);

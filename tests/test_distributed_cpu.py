@@ -1,0 +1,107 @@
+"""CPU tier, world_size 2 over gloo: the sharding logic of dafoam_amd.distributed (slab partition with 3 ghost
+layers, ownership, global keys, halo reduction) checked with the ORACLE as the local operator:
+  * residuals of owned cells evaluated on the extended sub-mesh == global residual (ghost depth = stencil depth),
+  * owned states of the two ranks partition the global state vector,
+  * local (A_ext^T restricted to owned columns) @ psi followed by the halo reduction == global dRdW^T psi."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from common import NORM_STATES
+
+NX, NY, NZ = 8, 4, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dafoam_amd.distributed import HaloExchange, SlabPartition, state_table
+        from dafoam_amd.meshgen import channel_case
+        from oracle import jacobian as J
+        from oracle.foam_mesh import Geometry
+        from oracle.residual import residual
+
+        kw = dict(lengths=(2.0, 0.2, 0.2), grading_y=2.0, perturb=0.0)
+        gcase = channel_case(NX, NY, NZ, **kw)
+        gpart = SlabPartition(NX, NY, NZ, 0, 1)
+        gkey, _, _ = state_table(gpart, gcase.mesh)
+        glook = dict(zip(gkey.tolist(), range(gkey.size)))
+        part = SlabPartition(NX, NY, NZ, rank, world)
+        case = channel_case(part.nxl, NY, NZ, x_range=(part.e0, part.e1, NX), **kw)
+        key, orank, owned = state_table(part, case.mesh)
+        # states / wall distance of the extended mesh taken from the global case (exact consistency)
+        notcut = orank >= 0
+        gidx = np.array([glook.get(k, -1) for k in key.tolist()])
+        assert np.all(gidx[notcut] >= 0)
+        W = case.states.copy()
+        W[notcut] = gcase.states[gidx[notcut]]
+        ncell = case.mesh.n_cells
+        ckey = key[3 * ncell : 4 * ncell] - 3 * (1 << 40)
+        case.y_wall = gcase.y_wall[ckey]
+        case.states = W
+        g = Geometry(case.mesh)
+        gg = Geometry(gcase.mesh)
+        # 1. owned residual rows are exact
+        R = residual(case, g, W)
+        Rg = residual(gcase, gg, gcase.states)
+        err_res = np.abs(R[owned] - Rg[gidx[owned]]).max() / np.abs(Rg).max()
+        # 2. sharded product
+        sc = J.state_scales(case, g, NORM_STATES)
+        con = J.connectivity(case, g)
+        col, _ = J.greedy_coloring(con)
+        A = J.jacobian_colored(case, g, W, con, col, sc, mode="cs", lower_bound=0).tocsc()
+        A = A[:, np.nonzero(owned)[0]]  # columns = owned residuals
+        scg = J.state_scales(gcase, gg, NORM_STATES)
+        cong = J.connectivity(gcase, gg)
+        colg, _ = J.greedy_coloring(cong)
+        Ag = J.jacobian_colored(gcase, gg, gcase.states, cong, colg, scg, mode="cs", lower_bound=0)
+        psi_g = np.random.default_rng(0).standard_normal(gkey.size)
+        psi_owned = psi_g[gidx[owned]]
+        w = torch.from_numpy(A @ psi_owned)
+        halo = HaloExchange(key, orank, rank, world)
+        halo.reduce_(w)
+        w = w.numpy()
+        ref = (Ag @ psi_g)[gidx[owned]]
+        err_prod = np.abs(w[owned] - ref).max() / np.abs(ref).max()
+        ghost_zero = float(np.abs(w[~owned]).max()) if (~owned).any() else 0.0
+        nown = torch.tensor([int(owned.sum())])
+        dist.all_reduce(nown)
+        q.put((rank, err_res, err_prod, ghost_zero, int(nown.item()), gkey.size, halo.bytes_per_exchange))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_product_matches_global_oracle():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err_res, err_prod, ghost_zero, nown, nglob, nbytes in res:
+        assert err_res < 1e-12, (rank, err_res)
+        assert err_prod < 1e-11, (rank, err_prod)
+        assert ghost_zero == 0.0
+        assert nown == nglob
+        assert nbytes > 0
