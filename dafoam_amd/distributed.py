@@ -156,7 +156,10 @@ class ShardedAdjoint:
     """One rank of the sharded adjoint: extended-mesh case -> PYDAFOAM on this rank's GPU with owned mask, stream and
     communication callbacks installed."""
 
-    def __init__(self, NX, NY, NZ, options, device_index=0, wall_function=False, state="prolonged"):
+    def __init__(self, NX, NY, NZ, options, device_index=0, wall_function=False, state="prolonged", global_state=None,
+                 case_kw=None):
+        """global_state: optional (global_keys, global_W, global_yWall) - the extended states are then taken from a
+        global state vector (e.g. a converged primal) instead of the prolonged fixture."""
         import torch
         import torch.distributed as dist
 
@@ -167,12 +170,24 @@ class ShardedAdjoint:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         part = self.part = SlabPartition(NX, NY, NZ, self.rank, self.world)
         co = load_coarse_primal()
-        case = channel_case(part.nxl, NY, NZ, lengths=co["lengths"], grading_y=co["grading_y"], wall_function=wall_function, perturb=0.0,
-                            x_range=(part.e0, part.e1, NX))
-        if state == "prolonged":
+        kw = dict(lengths=co["lengths"], grading_y=co["grading_y"])
+        kw.update(case_kw or {})
+        case = channel_case(part.nxl, NY, NZ, wall_function=wall_function, perturb=0.0, x_range=(part.e0, part.e1, NX), **kw)
+        self.key, self.owner_rank, self.owned = state_table(part, case.mesh)
+        if global_state is not None:
+            gkey, gW, gy = global_state
+            look = dict(zip(np.asarray(gkey).tolist(), range(len(gkey))))
+            notcut = self.owner_rank >= 0
+            gi = np.array([look.get(k, -1) for k in self.key.tolist()])
+            assert np.all(gi[notcut] >= 0)
+            W = case.states.copy()
+            W[notcut] = np.asarray(gW)[gi[notcut]]
+            nc = case.mesh.n_cells
+            case.states = W
+            case.y_wall = np.asarray(gy)[self.key[3 * nc : 4 * nc] - 3 * _KEY]
+        elif state == "prolonged":
             prolong_channel_state(case, (part.nxl, NY, NZ), co, i0=part.e0, nx_global=NX)
         self.case = case
-        self.key, self.owner_rank, self.owned = state_table(part, case.mesh)
         opts = dict(options)
         opts["amdDevice"] = device_index
         self.D = PYDAFOAM(options=opts, case=case)
