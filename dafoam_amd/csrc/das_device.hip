@@ -168,19 +168,48 @@ __global__ void k_compact(long long n, const long long* __restrict__ rp, const i
 // =====================================================================================================
 // linear algebra kernels
 // =====================================================================================================
-// y = A x, CSR, one 64-lane wavefront per row (rows of dRdW^T hold ~50-280 entries), 4 rows per workgroup
+// y = A x, transposed-CSR dRdW^T (rows hold ~50-280 entries): SPMV_LANES lanes cooperate on one row, 256-thread
+// workgroups.  The matrix is streamed exactly once (non-temporal loads, so that it does not evict the gathered x
+// entries from the per-XCD L2); x is gathered through L2.
+#ifndef SPMV_LANES
+#define SPMV_LANES 32
+#endif
+#ifndef SPMV_NT
+#define SPMV_NT 0
+#endif
 __global__ __launch_bounds__(256) void k_spmv_wave(long long n, const long long* __restrict__ rp, const int* __restrict__ ci,
                                                    const double* __restrict__ v, const double* __restrict__ x, double* __restrict__ y) {
-    long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
+    constexpr int RPB = 256 / SPMV_LANES;
+    long long row = (long long)blockIdx.x * RPB + (threadIdx.x / SPMV_LANES);
+    const int lane = threadIdx.x % SPMV_LANES;
     if (row >= n) return;
-    long long b = rp[row], e = rp[row + 1];
-    double s = 0.0;
-    for (long long k = b + lane; k < e; k += 64) s += v[k] * x[ci[k]];
+    const long long b = rp[row], e = rp[row + 1];
+    double s0 = 0.0, s1 = 0.0;
+    long long k = b + lane;
+    for (; k + SPMV_LANES < e; k += 2 * SPMV_LANES) {
+#if SPMV_NT
+        const double v0 = __builtin_nontemporal_load(v + k), v1 = __builtin_nontemporal_load(v + k + SPMV_LANES);
+        const int c0 = __builtin_nontemporal_load(ci + k), c1 = __builtin_nontemporal_load(ci + k + SPMV_LANES);
+#else
+        const double v0 = v[k], v1 = v[k + SPMV_LANES];
+        const int c0 = ci[k], c1 = ci[k + SPMV_LANES];
+#endif
+        s0 += v0 * x[c0];
+        s1 += v1 * x[c1];
+    }
+    if (k < e) {
+#if SPMV_NT
+        s0 += __builtin_nontemporal_load(v + k) * x[__builtin_nontemporal_load(ci + k)];
+#else
+        s0 += v[k] * x[ci[k]];
+#endif
+    }
+    double sacc = s0 + s1;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if (lane == 0) y[row] = s;
+    for (int o = SPMV_LANES / 2; o > 0; o >>= 1) sacc += __shfl_down(sacc, o, SPMV_LANES);
+    if (lane == 0) y[row] = sacc;
 }
+#define SPMV_GRID(n) dim3(nblk((n), 256 / SPMV_LANES))
 
 // partial[i*nb + blk] = sum over this block's chunk of V_i . w   (i < m); last slot (i == m) = w . w
 #define MD_CHUNK 1024
@@ -284,51 +313,84 @@ struct PCView {
     const int* gidx;           // extended position -> global state index (gather)
     const int* gout;           // extended position -> global state index if owned by the block's core, else -1
     const double* invd;        // 1/pivot per extended position
-    // L and U entry streams
+    // L and U entry streams (values fp64 or fp32: `svalf` is used when factor32 is set)
+    int factor32;
     const double* sval[2];
+    const float* svalf[2];
     const unsigned* srowcol[2];  // row | col << 16 (block-local)
     const long long* slev[2];    // level pointers into the streams (absolute entry offsets), concatenated per block
     const long long* slevOff[2]; // nBlocks+1 offsets into slev
     double* xglob;             // global scratch when a block does not fit into LDS
 };
 
+// x[row] -= v * x[col] for one entry per lane (LDS fp64 atomic: rows of a level are independent, only partial sums of
+// the same row collide).  A wave-level segmented pre-reduction was measured and is slower.
 template <bool USE_LDS>
-__device__ __forceinline__ void ras_sweep(const double* __restrict__ sval, const unsigned* __restrict__ src, const long long* __restrict__ lev,
+__device__ __forceinline__ void ras_apply_entry(double* xw, double v, unsigned rc, bool valid) {
+    if (!valid) return;
+    const double contrib = -v * xw[rc >> 16];
+#ifdef PC_EXP_NOATOMIC
+    xw[rc & 0xffffu] = contrib;  // timing experiment only (wrong results)
+#else
+    if (USE_LDS) __hip_atomic_fetch_add(&xw[rc & 0xffffu], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicAdd(&xw[rc & 0xffffu], contrib);
+#endif
+}
+
+// One triangular sweep over a block's level-sorted entry stream.  Software pipeline over LEVELS: slot d of a
+// compile-time ring of PC_PF slots holds this thread's entry of level lv0+d; after consuming it the slot is refilled
+// with the entry of level lv0+d+PC_PF.  Everything in the loop body is straight-line code: the host splits levels
+// into pieces of <= PC_THREADS entries (one entry per thread per level) and the level list is padded with empty
+// levels, so the refill loads are UNCONDITIONAL (clamped address + validity flag).  This matters on CDNA: a load
+// inside a conditional forces the compiler's s_waitcnt insertion to assume it may not have been issued, which
+// degrades every later wait to vmcnt(0) and serialises the prefetch ring.
+template <bool USE_LDS, class VT>
+__device__ __forceinline__ void ras_sweep(const VT* __restrict__ sval, const unsigned* __restrict__ src, const long long* __restrict__ lev,
                                           long long l0, long long l1, double* xw, int* lvl) {
-    // level pointers of this block -> LDS (relative to the block's first entry), so that the per-level loop never
-    // issues a dependent global load (which would also drain the prefetch queue through s_waitcnt vmcnt(0))
     const long long ebeg = lev[l0];
-    const int nlev = (int)(l1 - l0);  // number of pointers
-    for (int k = threadIdx.x; k < nlev; k += PC_THREADS) lvl[k] = (int)(lev[l0 + k] - ebeg);
+    const int nptr = (int)(l1 - l0);
+    const int NL = nptr - 1;
+    const int eend = (int)(lev[l1 - 1] - ebeg);
+    if (eend <= 0) return;  // uniform
+    const int NLpad = ((NL + PC_PF - 1) / PC_PF) * PC_PF;
+    // level pointers -> LDS (relative to the block's first entry), padded with empty levels
+    for (int k = threadIdx.x; k < NLpad + PC_PF + 1; k += PC_THREADS) lvl[k] = k < nptr ? (int)(lev[l0 + k] - ebeg) : eend;
     __syncthreads();
-    const int eend = lvl[nlev - 1];
-    const double* __restrict__ bv = sval + ebeg;
+    const VT* __restrict__ bv = sval + ebeg;
     const unsigned* __restrict__ br = src + ebeg;
-    int e = threadIdx.x;
-    double pv[PC_PF];
-    unsigned pr[PC_PF];
+    const unsigned INVALID = 0xffffffffu;
+    const int tid = (int)threadIdx.x;
+    VT sv[PC_PF];
+    unsigned sr[PC_PF];
 #pragma unroll
-    for (int k = 0; k < PC_PF; k++) {
-        int ee = e + k * PC_THREADS;
-        pv[k] = ee < eend ? bv[ee] : 0.0;
-        pr[k] = ee < eend ? br[ee] : 0u;
+    for (int d = 0; d < PC_PF; d++) {
+        const int ee = lvl[d] + tid;
+        const bool ok = ee < lvl[d + 1];
+        const int ec = ee < eend ? ee : eend - 1;
+        sv[d] = bv[ec];
+        const unsigned r = br[ec];
+        sr[d] = ok ? r : INVALID;
     }
-    for (int lv = 0; lv < nlev - 1; lv++) {
-        const int e1 = lvl[lv + 1];
-        while (e < e1) {
-            const double v = pv[0];
-            const unsigned rc = pr[0];
+    for (int lv0 = 0; lv0 < NLpad; lv0 += PC_PF) {
 #pragma unroll
-            for (int k = 0; k < PC_PF - 1; k++) { pv[k] = pv[k + 1]; pr[k] = pr[k + 1]; }
-            const int en = e + PC_PF * PC_THREADS;
-            pv[PC_PF - 1] = en < eend ? bv[en] : 0.0;
-            pr[PC_PF - 1] = en < eend ? br[en] : 0u;
-            const double contrib = -v * xw[rc >> 16];
-            if (USE_LDS) __hip_atomic_fetch_add(&xw[rc & 0xffffu], contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else atomicAdd(&xw[rc & 0xffffu], contrib);
-            e += PC_THREADS;
+        for (int d = 0; d < PC_PF; d++) {
+            const int lq = lv0 + d + PC_PF;
+            const double v = (double)sv[d];
+            const unsigned rc = sr[d];
+            // refill first (independent of the LDS work below)
+            const int ee = lvl[lq] + tid;
+            const bool ok = ee < lvl[lq + 1];
+            const int ec = ee < eend ? ee : eend - 1;
+            sv[d] = bv[ec];
+            const unsigned r = br[ec];
+            sr[d] = ok ? r : INVALID;
+#ifndef PC_EXP_NOENTRIES
+            ras_apply_entry<USE_LDS>(xw, v, rc, rc != INVALID);
+#endif
+#ifndef PC_EXP_NOBARRIER
+            __syncthreads();
+#endif
         }
-        __syncthreads();
     }
 }
 
@@ -338,15 +400,17 @@ __global__ __launch_bounds__(PC_THREADS) void k_ras_apply(PCView P, const double
     const int blk = blockIdx.x;
     const long long o0 = P.boff[blk];
     const int nloc = (int)(P.boff[blk + 1] - o0);
-    int* lvl = (int*)xs;                                   // maxLev+2 ints, padded to 8 bytes
-    double* xlds = xs + ((maxLev + 2 + 1) >> 1);
+    int* lvl = (int*)xs;                                   // level pointers (+ padding levels), padded to 8 bytes
+    double* xlds = xs + ((maxLev + 2 * PC_PF + 4) >> 1);
     double* xw = USE_LDS ? xlds : P.xglob + o0;
     for (int i = threadIdx.x; i < nloc; i += PC_THREADS) xw[i] = b[P.gidx[o0 + i]];
     __syncthreads();
-    ras_sweep<USE_LDS>(P.sval[0], P.srowcol[0], P.slev[0], P.slevOff[0][blk], P.slevOff[0][blk + 1], xw, lvl);
+    if (P.factor32) ras_sweep<USE_LDS, float>(P.svalf[0], P.srowcol[0], P.slev[0], P.slevOff[0][blk], P.slevOff[0][blk + 1], xw, lvl);
+    else ras_sweep<USE_LDS, double>(P.sval[0], P.srowcol[0], P.slev[0], P.slevOff[0][blk], P.slevOff[0][blk + 1], xw, lvl);
     for (int i = threadIdx.x; i < nloc; i += PC_THREADS) xw[i] *= P.invd[o0 + i];
     __syncthreads();
-    ras_sweep<USE_LDS>(P.sval[1], P.srowcol[1], P.slev[1], P.slevOff[1][blk], P.slevOff[1][blk + 1], xw, lvl);
+    if (P.factor32) ras_sweep<USE_LDS, float>(P.svalf[1], P.srowcol[1], P.slev[1], P.slevOff[1][blk], P.slevOff[1][blk + 1], xw, lvl);
+    else ras_sweep<USE_LDS, double>(P.sval[1], P.srowcol[1], P.slev[1], P.slevOff[1][blk], P.slevOff[1][blk + 1], xw, lvl);
     for (int i = threadIdx.x; i < nloc; i += PC_THREADS) {
         int g = P.gout[o0 + i];
         if (g >= 0) out[g] = xw[i];
@@ -419,6 +483,8 @@ struct BlockILU {
     DevBuf<int> gidx, gout;
     DevBuf<unsigned> srowcol[2];
     DevBuf<double> sval[2], invd, xw;
+    DevBuf<float> svalf[2];
+    bool factor32 = false;
     PCView view;
     int maxLevels = 0;
     bool useLDS = false;
@@ -440,7 +506,7 @@ struct das_ksp {
     BlockILU pc;
     int restart = 0;
     DevBuf<double> V, w, z, r, xdev, bdev, partial, hdev;
-    int iters = 0;
+    int iters = 0, nrefine = 0;
     double res0 = 0, res = 0, seconds = 0;
     std::vector<double> hist;
 };
@@ -518,12 +584,19 @@ static void ensure_coloring(das_solver* s) {
     double t = wall_seconds();
     s->st_full = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, false);
     s->st_pc = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, true);
+    double t1 = wall_seconds();
     s->con_full.build(s->mesh, s->st_full);
     s->con_pc.build(s->mesh, s->st_pc);
+    double t2 = wall_seconds();
     s->nColors = d2_coloring(s->con_full, s->colors);
+    double t3 = wall_seconds();
     DAS_CHECK(validate_coloring(s->con_full, s->colors), DAS_ERR_INTERNAL, "Conflicting Colors Found!");
+    double t4 = wall_seconds();
     s->con_full.build_transpose_and_maps(s->colors);
     s->con_pc.build_transpose_and_maps(s->colors);
+    if (s->opt.geti("debug"))
+        fprintf(stderr, "[dafoam_amd] runColoring: pattern %.2f s, colouring %.2f s, validate %.2f s, transpose+maps %.2f s\n", t2 - t1, t3 - t2,
+                t4 - t3, wall_seconds() - t4);
     s->colored = true;
     for (int k = 0; k < 2; k++) s->cd[k].ready = false;
     if (s->opt.geti("debug"))
@@ -550,7 +623,7 @@ static ConDev& ensure_con_dev(das_solver* s, int isPC) {
 static void spmv(das_solver* s, const Mat& A, const double* x, double* y) {
     hipEvent_t ev = nullptr;
     s->timer.begin("spmv", s->stream, ev);
-    hipLaunchKernelGGL(k_spmv_wave, dim3(nblk(A.n, 4)), dim3(256), 0, s->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y);
+    hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(A.n), dim3(256), 0, s->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y);
     s->timer.end("spmv", s->stream, ev);
     if (s->halo_cb) {  // ghost-row contributions -> owner ranks (one neighbour exchange per product)
         hipEvent_t eh = nullptr;
@@ -910,27 +983,39 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
         P.h_core_off.push_back((long long)P.h_core_perm.size());
         for (int i = 0; i < nl; i++) invd.push_back(1.0 / F.fv[F.fdiag[i]]);
         // L stream
+        // (levels are split into pieces of <= PC_THREADS entries: one entry per thread per level in the kernel)
+        auto push_entry = [&](int t, double v, unsigned rc, long long& inLevel) {
+            if (inLevel == PC_THREADS) { slev[t].push_back((long long)sval[t].size()); inLevel = 0; }
+            sval[t].push_back(v);
+            src[t].push_back(rc);
+            inLevel++;
+        };
+        int nLv[2] = {0, 0};
         slevOff[0][b] = (long long)slev[0].size();
         for (size_t l = 0; l + 1 < F.Llev.size(); l++) {
             slev[0].push_back((long long)sval[0].size());
+            long long inLevel = 0;
             for (long long r = F.Llev[l]; r < F.Llev[l + 1]; r++) {
                 int i = F.Lrows[r];
-                for (long long q = F.frp[i]; q < F.fdiag[i]; q++) { sval[0].push_back(F.fv[q]); src[0].push_back((unsigned)i | ((unsigned)F.fci[q] << 16)); }
+                for (long long q = F.frp[i]; q < F.fdiag[i]; q++) push_entry(0, F.fv[q], (unsigned)i | ((unsigned)F.fci[q] << 16), inLevel);
             }
         }
         slev[0].push_back((long long)sval[0].size());
+        nLv[0] = (int)(slev[0].size() - slevOff[0][b]) - 1;
         // U stream (rows pre-divided by the pivot)
         slevOff[1][b] = (long long)slev[1].size();
         for (size_t l = 0; l + 1 < F.Ulev.size(); l++) {
             slev[1].push_back((long long)sval[1].size());
+            long long inLevel = 0;
             for (long long r = F.Ulev[l]; r < F.Ulev[l + 1]; r++) {
                 int i = F.Urows[r];
                 const double idg = 1.0 / F.fv[F.fdiag[i]];
-                for (long long q = F.fdiag[i] + 1; q < F.frp[i + 1]; q++) { sval[1].push_back(F.fv[q] * idg); src[1].push_back((unsigned)i | ((unsigned)F.fci[q] << 16)); }
+                for (long long q = F.fdiag[i] + 1; q < F.frp[i + 1]; q++) push_entry(1, F.fv[q] * idg, (unsigned)i | ((unsigned)F.fci[q] << 16), inLevel);
             }
         }
         slev[1].push_back((long long)sval[1].size());
-        maxLv = std::max<int>(maxLv, std::max((int)F.Llev.size(), (int)F.Ulev.size()) - 1);
+        nLv[1] = (int)(slev[1].size() - slevOff[1][b]) - 1;
+        maxLv = std::max<int>(maxLv, std::max(nLv[0], nLv[1]));
         boff[b + 1] = boff[b] + nl;
         F = BlockFactor();  // free
     }
@@ -938,12 +1023,26 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     DAS_CHECK((long long)P.h_core_perm.size() == nOwnedStates, DAS_ERR_INTERNAL, "block cores do not cover all owned states exactly once");
     P.n = n; P.next = next; P.nBlocks = nB; P.fnnz = fnnz; P.maxLevels = maxLv; P.maxLocal = maxLocal;
     P.boff.upload(boff); P.gidx.upload(gidx); P.gout.upload(gout); P.invd.upload(invd);
-    for (int t = 0; t < 2; t++) { P.sval[t].upload(sval[t]); P.srowcol[t].upload(src[t]); P.slev[t].upload(slev[t]); P.slevOff[t].upload(slevOff[t]); }
-    P.useLDS = (size_t)maxLocal * sizeof(double) + (size_t)(maxLv + 4) * sizeof(int) + 16 <= 160 * 1024;
+    // mixed precision: the factors of the (approximate) preconditioner may be stored in fp32 - the operator, the
+    // Krylov vectors and the block work vector stay fp64 (amd.pcFactorFP32; SURVEY.md section 7 "hard parts")
+    P.factor32 = s->opt.geti("amd.pcFactorFP32") != 0;
+    for (int t = 0; t < 2; t++) {
+        if (P.factor32) {
+            std::vector<float> f(sval[t].begin(), sval[t].end());
+            P.svalf[t].upload(f);
+            P.sval[t].release();
+        } else {
+            P.sval[t].upload(sval[t]);
+            P.svalf[t].release();
+        }
+        P.srowcol[t].upload(src[t]); P.slev[t].upload(slev[t]); P.slevOff[t].upload(slevOff[t]);
+    }
+    P.useLDS = (size_t)maxLocal * sizeof(double) + (size_t)(maxLv + 2 * PC_PF + 8) * sizeof(int) + 16 <= 160 * 1024;
     if (!P.useLDS) P.xw.alloc(next);
     else DAS_HIP(hipFuncSetAttribute((const void*)k_ras_apply<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     P.view.nBlocks = nB; P.view.boff = P.boff.p; P.view.gidx = P.gidx.p; P.view.gout = P.gout.p; P.view.invd = P.invd.p;
-    for (int t = 0; t < 2; t++) { P.view.sval[t] = P.sval[t].p; P.view.srowcol[t] = P.srowcol[t].p; P.view.slev[t] = P.slev[t].p; P.view.slevOff[t] = P.slevOff[t].p; }
+    P.view.factor32 = P.factor32 ? 1 : 0;
+    for (int t = 0; t < 2; t++) { P.view.sval[t] = P.sval[t].p; P.view.svalf[t] = P.svalf[t].p; P.view.srowcol[t] = P.srowcol[t].p; P.view.slev[t] = P.slev[t].p; P.view.slevOff[t] = P.slevOff[t].p; }
     P.view.xglob = P.xw.p;
     P.setup_seconds = wall_seconds() - t0;
     if (s->opt.geti("debug"))
@@ -956,7 +1055,7 @@ static void pc_apply(das_solver* s, das_ksp* k, const double* b, double* x) {
     hipEvent_t ev = nullptr;
     s->timer.begin("pc", s->stream, ev);
     const int mlv = k->pc.maxLevels;
-    const size_t lvlBytes = (size_t)((mlv + 2 + 1) >> 1) * sizeof(double);
+    const size_t lvlBytes = (size_t)((mlv + 2 * PC_PF + 4) >> 1) * sizeof(double);
     if (k->pc.useLDS)
         hipLaunchKernelGGL(k_ras_apply<true>, dim3(k->pc.nBlocks), dim3(PC_THREADS), lvlBytes + (size_t)k->pc.maxLocal * sizeof(double), s->stream,
                            k->pc.view, b, x, mlv);
@@ -1009,6 +1108,8 @@ static int run_gmres(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x
     const long long maxIts = fixed_iters > 0 ? fixed_iters : s->opt.geti("adjEqnOption.gmresMaxIters");
     const double rtol = s->opt.getd("adjEqnOption.gmresRelTol"), atol = s->opt.getd("adjEqnOption.gmresAbsTol");
     const bool nonzeroGuess = s->opt.geti("adjEqnOption.useNonZeroInitGuess") != 0;
+    const bool alwaysRefine = s->opt.geti("amd.cgsAlwaysRefine") != 0;
+    k->nrefine = 0;
     double t0 = wall_seconds();
     std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), hh(m + 2), h2(m + 2), y(m);
     k->hist.clear();
@@ -1039,16 +1140,27 @@ static int run_gmres(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x
             double* vj = k->V.p + (long long)j * n;
             pc_apply(s, k, vj, k->z.p);
             spmv(s, A, k->z.p, k->w.p);
+            // classical Gram-Schmidt, one fused pass: h = V^T w and w.w; refinement only if needed (reference:
+            // KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160): refine when the projected vector keeps less than half
+            // of its squared norm, i.e. ||w - V h||^2 (= w.w - h.h) < h.h
             multidot(s, k, j + 1, k->w.p, hh.data());
             hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
-            multidot(s, k, j + 1, k->w.p, h2.data());
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
-            // norm after the second projection: ||w||^2 = w.w(before 2nd) - sum h2^2 is unsafe; recompute
-            double hn2;
-            {
+            double hsq = 0.0;
+            for (int i = 0; i <= j; i++) hsq += hh[i] * hh[i];
+            const double ww = hh[j + 1];
+            double est = ww - hsq;
+            double hn;
+            std::fill(h2.begin(), h2.end(), 0.0);
+            if (alwaysRefine || !(est > hsq) || !(est > 0.0)) {
+                multidot(s, k, j + 1, k->w.p, h2.data());
+                hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
+                double hn2;
                 multidot(s, k, 0, k->w.p, &hn2);
+                hn = std::sqrt(std::max(hn2, 0.0));
+                k->nrefine++;
+            } else {
+                hn = std::sqrt(est);
             }
-            double hn = std::sqrt(std::max(hn2, 0.0));
             for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = hh[i] + h2[i];
             H[(size_t)(j + 1) * m + j] = hn;
             if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, k->w.p, k->V.p + (long long)(j + 1) * n);
@@ -1326,7 +1438,7 @@ int das_mat_mult(das_mat_t* m, const double* x, double* y) {
     DAS_CHECK(m && x && y, DAS_ERR_ARG, "null argument");
     DevBuf<double> dx(m->m.n), dy(m->m.n);
     dx.upload(x, m->m.n);
-    hipLaunchKernelGGL(k_spmv_wave, dim3(nblk(m->m.n, 4)), dim3(256), 0, 0, m->m.n, m->m.rowptr.p, m->m.col.p, m->m.val.p, dx.p, dy.p);
+    hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(m->m.n), dim3(256), 0, 0, m->m.n, m->m.rowptr.p, m->m.col.p, m->m.val.p, dx.p, dy.p);
     DAS_HIP(hipDeviceSynchronize());
     dy.download(y, m->m.n);
     return DAS_OK;

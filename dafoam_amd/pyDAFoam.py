@@ -102,7 +102,7 @@ class DAOPTION(object):
         self.maxCorrectBCCalls = 2  # :628
         self.writeMinorIterations = False
         # MI355X-specific additions (not in the reference)
-        self.amd = {"pcBlockCells": 1024, "jacMode": 1, "pcJacMode": 0}
+        self.amd = {"pcBlockCells": 1024, "jacMode": 1, "pcJacMode": 0, "pcFactorFP32": 0, "cgsAlwaysRefine": 0}
         self.amdDevice = 0
 
 

@@ -203,9 +203,9 @@ def test_adjoint_scalar_transport_config0():
     assert fail == 0 and relerr(psi, psi_o) <= 1e-8
 
 
-@pytest.mark.parametrize("dims,block,overlap,fill", [((6, 6, 5), 4096, 0, 0), ((8, 8, 6), 100, 1, 0), ((8, 8, 6), 150, 1, 1),
-                                                     ((8, 8, 6), 100, 2, 1), ((24, 20, 16), 1024, 1, 0)])
-def test_ras_ilu_apply_matches_oracle(dims, block, overlap, fill):
+@pytest.mark.parametrize("dims,block,overlap,fill,fp32", [((6, 6, 5), 4096, 0, 0, 0), ((8, 8, 6), 100, 1, 0, 0), ((8, 8, 6), 150, 1, 1, 0),
+                                                          ((8, 8, 6), 100, 2, 1, 0), ((24, 20, 16), 1024, 1, 0, 0), ((8, 8, 6), 150, 1, 1, 1)])
+def test_ras_ilu_apply_matches_oracle(dims, block, overlap, fill, fp32):
     """The GPU preconditioner apply (restricted additive Schwarz over RCB blocks + `overlap` cell rings, ILU(fill),
     level-scheduled in LDS) against the oracle's ILU(k) (oracle/csrc/oracle_linalg.c) on the same dRdWTPC matrix
     with the same blocks and the same cell-by-cell ordering."""
@@ -214,7 +214,7 @@ def test_ras_ilu_apply_matches_oracle(dims, block, overlap, fill):
     case = channel_case(*dims, grading_y=2.0)
     g = Geometry(case.mesh)
     N, F = g.nC, g.nF
-    D = make(case, amd={"pcBlockCells": block}, adjEqnOption={"asmOverlap": overlap, "pcFillLevel": fill, "printInfo": 0})
+    D = make(case, amd={"pcBlockCells": block, "pcFactorFP32": fp32}, adjEqnOption={"asmOverlap": overlap, "pcFillLevel": fill, "printInfo": 0})
     D.solver.runColoring()
     pc = Mat()
     D.solver.calcdRdWT(1, pc)
@@ -245,7 +245,7 @@ def test_ras_ilu_apply_matches_oracle(dims, block, overlap, fill):
         z = OL.ILU(P[idx][:, idx], fill=fill).solve(x[idx])
         y_o[idx[own_mask]] = z[own_mask]
     y = ksp.applyPC(D.solver, x)
-    assert relerr(y, y_o) < 1e-9
+    assert relerr(y, y_o) < (1e-2 if fp32 else 1e-9)  # fp32 factor storage: preconditioner-only approximation
 
 
 def test_gmres_failure_rule_and_restart():
