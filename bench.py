@@ -148,6 +148,7 @@ def main():
     op_nnz = int(L.das_op_nnz(h))
     spmv_bytes = 12.0 * op_nnz + 4.0 * (n + 1) + 16.0 * n
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms and spmv_ms > 0 else None
+    pc_bytes = 12.0 * L.das_ksp_get_factor_nnz(ksp.handle) + 16.0 * L.das_ksp_get_n_ext(ksp.handle)
 
     out = None
     if rank == 0:
@@ -200,6 +201,16 @@ def main():
                 "traffic": traffic,
                 "launches_timed": int(spmv_cnt),
                 "algorithmic_bytes_per_launch": spmv_bytes,
+            },
+            "roofline_pc": {
+                "kernel": "k_ras_apply (RAS+ILU(k) level-scheduled triangular solves; largest share of an iteration)",
+                "bound": "hbm",
+                "achieved": pc_bytes / (pc_ms * 1e-3) / 1e9 if pc_ms and pc_ms > 0 else None,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": pc_bytes / (pc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pc_ms and pc_ms > 0 else None,
+                "algorithmic_bytes_per_launch": pc_bytes,
+                "note": "12 B per factor entry (fp64 value + 2x u16 index) + 16 B per extended unknown; measured to be bound by the per-level LDS dependency chain, not by bytes",
             },
             "cpu_baseline": cpu,
         }

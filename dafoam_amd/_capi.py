@@ -181,6 +181,8 @@ _SIGS = {
     "das_solve_linear_eqn": (C.c_int, [_VP, _VP, c_double_p, c_double_p]),
     "das_ksp_apply_pc": (C.c_int, [_VP, _VP, c_double_p, c_double_p]),
     "das_ksp_get_n_blocks": (C.c_int, [_VP]),
+    "das_ksp_get_factor_nnz": (C.c_longlong, [_VP]),
+    "das_ksp_get_n_ext": (C.c_longlong, [_VP]),
     "das_ksp_get_blocks": (C.c_int, [_VP, c_int_p, c_ll_p]),
     "das_ksp_get_info": (C.c_int, [_VP, c_int_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_get_history": (C.c_int, [_VP, c_double_p, C.c_int]),

@@ -1543,6 +1543,8 @@ int das_ksp_apply_pc(das_solver_t* s, das_ksp_t* ksp, const double* x, double* y
     DAS_CATCH
 }
 int das_ksp_get_n_blocks(das_ksp_t* ksp) { return ksp ? ksp->pc.nBlocks : -1; }
+long long das_ksp_get_factor_nnz(das_ksp_t* ksp) { return ksp ? ksp->pc.fnnz : -1; }
+long long das_ksp_get_n_ext(das_ksp_t* ksp) { return ksp ? ksp->pc.next : -1; }
 int das_ksp_get_blocks(das_ksp_t* ksp, int* perm, long long* block_off) {
     DAS_TRY
     DAS_CHECK(ksp && perm && block_off, DAS_ERR_ARG, "null argument");

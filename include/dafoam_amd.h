@@ -181,6 +181,9 @@ int das_solve_linear_eqn(das_solver_t* s, das_ksp_t* ksp, const double* rhs, dou
  * perm[n] = global state index at each permuted position, block_off[nBlocks+1] offsets into perm */
 int das_ksp_apply_pc(das_solver_t* s, das_ksp_t* ksp, const double* x, double* y);
 int das_ksp_get_n_blocks(das_ksp_t* ksp);
+/* nnz(L+U) summed over all (overlapping) blocks and total extended unknowns of the preconditioner */
+long long das_ksp_get_factor_nnz(das_ksp_t* ksp);
+long long das_ksp_get_n_ext(das_ksp_t* ksp);
 int das_ksp_get_blocks(das_ksp_t* ksp, int* perm, long long* block_off);
 int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, double* seconds);
 int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
