@@ -396,6 +396,49 @@ def channel_case(
     return case
 
 
+def renumber_case(case: FoamCase, seed=0) -> FoamCase:
+    """Randomly renumber the cells (and therefore re-sort/re-orient the internal faces to keep OpenFOAM's
+    upper-triangular order) - produces a genuinely unstructured numbering of the same mesh and state."""
+    import copy
+
+    m = case.mesh
+    N, F, nIF = m.n_cells, m.n_faces, m.n_internal_faces
+    rng = np.random.default_rng(seed)
+    new_of_old = rng.permutation(N)
+    o = new_of_old[m.owner[:nIF]]
+    n = new_of_old[m.neighbour]
+    flip = o > n
+    no, nn = np.where(flip, n, o), np.where(flip, o, n)
+    order = np.lexsort((nn, no))
+    nv = np.diff(m.face_ptr)
+    assert np.all(nv == nv[0])
+    k = int(nv[0])
+    fp = m.face_pts.reshape(F, k).copy()
+    fp[:nIF][flip] = fp[:nIF][flip][:, ::-1]
+    face_perm = np.concatenate([order, np.arange(nIF, F)])  # new face -> old face
+    mesh = PolyMesh(points=m.points.copy(), face_ptr=m.face_ptr.copy(), face_pts=np.ascontiguousarray(fp[face_perm].ravel()),
+                    owner=np.concatenate([no[order], new_of_old[m.owner[nIF:]]]).astype(np.int32), neighbour=nn[order].astype(np.int32),
+                    patches=copy.deepcopy(m.patches))
+    out = copy.copy(case)
+    out.mesh = mesh
+    old_of_new = np.argsort(new_of_old)
+    if case.y_wall is not None:
+        out.y_wall = case.y_wall[old_of_new]
+    if case.T_old is not None:
+        out.T_old = case.T_old[old_of_new]
+    sign = np.ones(F)
+    sign[:nIF] = np.where(flip[order], -1.0, 1.0)
+    if case.phi is not None:
+        out.phi = case.phi[face_perm] * sign
+    W = case.states
+    if case.solver_name == "DASimpleFoam":
+        U = W[: 3 * N].reshape(N, 3)[old_of_new]
+        out.states = np.concatenate([U.ravel(), W[3 * N : 4 * N][old_of_new], W[4 * N : 5 * N][old_of_new], W[5 * N :][face_perm] * sign])
+    else:
+        out.states = W[old_of_new]
+    return out
+
+
 def _logical_centres(nx, ny, nz, i0=0, i1=None, nx_global=None):
     """logical (xi,eta,zeta) in [0,1]^3 of the cell centres of an index sub-block (x range [i0,i1) of nx_global)."""
     nxg = nx if nx_global is None else nx_global

@@ -225,12 +225,28 @@ class PYDAFOAM(object):
             self.solver.runColoring()
             self.runColoring = False
         adjPCLag = self.getOption("adjPCLag")
+        writeJac = self.getOption("writeJacobians")
         if self.nSolveAdjoints % adjPCLag == 0 or self.dRdWTPC is None:
             self.dRdWTPC = Mat().create()
             self.solver.calcdRdWT(1, self.dRdWTPC)
+            if "dRdWTPC" in writeJac or "all" in writeJac:  # DASolver.C:1080-1085 (matName dRdWTPC when isPC=1)
+                from .petsc_io import write_mat
+
+                write_mat("dRdWTPC.bin", self.dRdWTPC.to_scipy())
             self.ksp = KSP().create()
             self.solverAD.createMLRKSPMatrixFree(self.dRdWTPC, self.ksp)
         self.solverAD.initializedRdWTMatrixFree()
+        if "dRdWT" in writeJac or "all" in writeJac:
+            from .petsc_io import write_mat
+
+            tmp = Mat().create()
+            self.solver.calcdRdWT(0, tmp)
+            write_mat("dRdWT.bin", tmp.to_scipy())
+            tmp.destroy()
+        if "dRdWColoring" in writeJac or "all" in writeJac:  # DAJacCon.C:1943,1973-1975: colours stored as doubles
+            from .petsc_io import write_vec
+
+            write_vec("dRdWColoring_1.bin", self.solver.getColoring()[0].astype(float))
         psi = Vec(len(dFdWArray))
         psi.set(0)
         fail = self.solverAD.solveLinearEqn(self.ksp, dFdW, psi)

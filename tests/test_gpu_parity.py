@@ -8,7 +8,7 @@ import pytest
 import scipy.sparse.linalg as spla
 
 from common import NORM_STATES, blocks, options, relerr
-from dafoam_amd.meshgen import bench_channel_case, channel_case, scalar_transport_case
+from dafoam_amd.meshgen import bench_channel_case, channel_case, renumber_case, scalar_transport_case
 from oracle import jacobian as J
 from oracle import linear as OL
 from oracle.foam_mesh import Geometry
@@ -72,6 +72,28 @@ def test_residual_parity_scalar_transport_config0():
     R = np.zeros(case.states.size)
     D.solver.getResiduals(R)
     assert relerr(R, residual(case, g, case.states)) < 1e-13
+
+
+def test_unstructured_renumbering_gpu():
+    """Randomly renumbered (genuinely unstructured) mesh: residual, dual Jacobian and adjoint against the oracle."""
+    from dafoam_amd.pyDASolvers import Mat
+
+    case = renumber_case(converged_case((8, 6, 5), wall_function=True, lengths=(1.0, 0.2, 0.2), grading_y=2.0), seed=5)
+    g = Geometry(case.mesh)
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0}, jacLowerBounds={"dRdW": 0.0, "dRdWPC": 0.0}, amd={"pcBlockCells": 100})
+    R = np.zeros(case.states.size)
+    D.solver.getResiduals(R)
+    assert np.abs(R).max() < 1e-6 and relerr(R, residual(case, g, case.states)) < 1e-6
+    sc, con, col, A = oracle_mats(case, g)
+    D.solver.runColoring()
+    M = Mat()
+    D.solver.calcdRdWT(0, M, mode=1)
+    assert np.abs((M.to_scipy() - A).tocsr().data).max() <= 1e-10 * np.abs(A.data).max()
+    rhs = np.zeros(A.shape[0])
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= sc
+    psi, fail = D.solveAdjoint(rhs)
+    assert fail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-6
 
 
 def test_normalize_residuals_option():
