@@ -13,6 +13,9 @@
 // (stateBoundaryCon, DAJacCon.C:800-1205) has no counterpart.
 #include "das_jaccon.hpp"
 
+#include <omp.h>
+#include <cstdlib>
+
 #include <algorithm>
 #include <numeric>
 
@@ -148,45 +151,83 @@ void JacCon::build(const Mesh& m, const Stencil& st) {
     DAS_CHECK(n < 2147483647LL, DAS_ERR_ARG, "state count exceeds int32 column indices");
     rowptr.assign(n + 1, 0);
     anchor.assign(n, 0);
-    col.clear();
-    col.reserve((size_t)m.nC * 1100);
-    RowBuilder rb(m, st);
-    std::vector<int> row;
-    long long r = 0;
-    for (size_t b = 0; b < st.states.size(); b++) {
-        const StateDef& s = st.states[b];
-        // a face state must only appear once in the emit order check
-        if (s.kind == KIND_FACE) {
-            for (int f = 0; f < m.nF; f++) {
-                rb.begin();
-                bool bnd = f >= m.nIF;
-                int cn = bnd ? m.owner[f] : m.neighbour[f];
-                rb.add((int)b, cn, bnd);
-                if (!bnd) rb.add((int)b, m.owner[f], false);
-                row.clear();
-                rb.emit(row);
-                col.insert(col.end(), row.begin(), row.end());
-                anchor[r] = m.owner[f];
-                rowptr[++r] = (long long)col.size();
+    // work items: (state block, entity index) in row order; rows of one item are consecutive
+    struct Item { int block; int ent; long long row0; };
+    // chunks of entities per block, processed in parallel, concatenated in order
+    const int nthreads = std::max(1, omp_get_max_threads());
+    struct Chunk { int block; int e0, e1; long long row0; std::vector<int> col; std::vector<int> rowlen; };
+    std::vector<Chunk> chunks;
+    {
+        long long r = 0;
+        for (size_t b = 0; b < st.states.size(); b++) {
+            const StateDef& s = st.states[b];
+            const int nent = s.kind == KIND_FACE ? m.nF : m.nC;
+            const int ncomp = s.kind == KIND_VEC ? 3 : 1;
+            const int nch = std::max(1, std::min(nent, nthreads * 4));
+            for (int c = 0; c < nch; c++) {
+                Chunk ch;
+                ch.block = (int)b;
+                ch.e0 = (int)((long long)nent * c / nch);
+                ch.e1 = (int)((long long)nent * (c + 1) / nch);
+                ch.row0 = r + (long long)ch.e0 * ncomp;
+                chunks.push_back(std::move(ch));
             }
-        } else {
-            int ncomp = s.kind == KIND_VEC ? 3 : 1;
-            for (int c = 0; c < m.nC; c++) {
+            r += (long long)nent * ncomp;
+        }
+        DAS_CHECK(r == n, DAS_ERR_INTERNAL, "row count mismatch in JacCon::build");
+    }
+#pragma omp parallel
+    {
+        RowBuilder rb(m, st);
+        std::vector<int> row;
+#pragma omp for schedule(dynamic, 1)
+        for (long long ci = 0; ci < (long long)chunks.size(); ci++) {
+            Chunk& ch = chunks[ci];
+            const StateDef& s = st.states[ch.block];
+            const int ncomp = s.kind == KIND_VEC ? 3 : 1;
+            ch.col.reserve((size_t)(ch.e1 - ch.e0) * ncomp * 160);
+            for (int e = ch.e0; e < ch.e1; e++) {
                 rb.begin();
-                rb.add((int)b, c, false);
+                int anch;
+                if (s.kind == KIND_FACE) {
+                    bool bnd = e >= m.nIF;
+                    int cn = bnd ? m.owner[e] : m.neighbour[e];
+                    rb.add(ch.block, cn, bnd);
+                    if (!bnd) rb.add(ch.block, m.owner[e], false);
+                    anch = m.owner[e];
+                } else {
+                    rb.add(ch.block, e, false);
+                    anch = e;
+                }
                 row.clear();
                 rb.emit(row);
                 for (int k = 0; k < ncomp; k++) {
-                    col.insert(col.end(), row.begin(), row.end());
-                    anchor[r] = c;
-                    rowptr[++r] = (long long)col.size();
+                    ch.col.insert(ch.col.end(), row.begin(), row.end());
+                    ch.rowlen.push_back((int)row.size());
+                    anchor[ch.row0 + (long long)(e - ch.e0) * ncomp + k] = anch;
                 }
             }
         }
     }
-    DAS_CHECK(r == n, DAS_ERR_INTERNAL, "row count mismatch in JacCon::build");
-    nnz = (long long)col.size();
-    col.shrink_to_fit();
+    // concatenate
+    long long total = 0;
+    for (auto& ch : chunks) total += (long long)ch.col.size();
+    col.resize(total);
+    {
+        long long off = 0;
+        std::vector<long long> choff(chunks.size());
+        for (size_t ci = 0; ci < chunks.size(); ci++) { choff[ci] = off; off += (long long)chunks[ci].col.size(); }
+#pragma omp parallel for schedule(dynamic, 1)
+        for (long long ci = 0; ci < (long long)chunks.size(); ci++) {
+            Chunk& ch = chunks[ci];
+            std::copy(ch.col.begin(), ch.col.end(), col.begin() + choff[ci]);
+            long long o = choff[ci];
+            for (size_t k = 0; k < ch.rowlen.size(); k++) { rowptr[ch.row0 + (long long)k] = o; o += ch.rowlen[k]; }
+            std::vector<int>().swap(ch.col);
+        }
+    }
+    rowptr[n] = total;
+    nnz = total;
 }
 
 static bool is_subset(const int* a, long long na, const int* b, long long nb) {
@@ -233,25 +274,77 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors) {
         for (long long r : keep)
             for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) crow[pos[con.col[k]]++] = r;
     }
-    std::vector<long long> forb(4096, -1);
-    int ncol = 0;
-    for (long long j = 0; j < n; j++) {
+    // speculative parallel greedy (Gebremedhin-Manne): chunks of columns are first-fit coloured concurrently against a
+    // shared (racy) colour array, then conflicts (two columns of one kept row with the same colour) are detected in
+    // parallel, the higher-index column of each conflict is un-coloured and the (few) leftovers are coloured serially.
+    auto color_column = [&](long long j, std::vector<long long>& forb, long long stamp) {
         for (long long q = cptr[j]; q < cptr[j + 1]; q++) {
             long long r = crow[q];
             for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) {
                 int c = colors[con.col[k]];
                 if (c >= 0) {
                     if ((size_t)c >= forb.size()) forb.resize(2 * c + 2, -1);
-                    forb[c] = j;
+                    forb[c] = stamp;
                 }
             }
         }
         int c = 0;
-        while ((size_t)c < forb.size() && forb[c] == j) c++;
-        if ((size_t)c >= forb.size()) forb.resize(2 * c + 2, -1);
+        while ((size_t)c < forb.size() && forb[c] == stamp) c++;
         colors[j] = c;
-        if (c + 1 > ncol) ncol = c + 1;
+    };
+    const int nth = std::max(1, omp_get_max_threads());
+    // Columns are grouped by the cell they live in (anchor) and the cell range is cut into spatially contiguous
+    // chunks, so concurrent threads only interact near chunk boundaries (few conflicts, near-serial colour count).
+    // Opt-in (DAS_PARALLEL_COLORING=1): ~3-4x faster but ~15 % more colours than the serial first-fit, and every
+    // colour costs one residual evaluation per Jacobian build (the colouring itself is computed once per mesh).
+    const char* pc_env = getenv("DAS_PARALLEL_COLORING");
+    const bool par = nth > 1 && pc_env && pc_env[0] == '1';
+    if (par) {
+        const int T = std::min(nth, 32);
+        std::vector<std::vector<long long>> chunkCols(T);
+        for (long long j = 0; j < n; j++) chunkCols[(long long)con.anchor[j] * T / nAnch].push_back(j);
+#pragma omp parallel num_threads(T)
+        {
+            std::vector<long long> forb(4096, -1);
+#pragma omp for schedule(static, 1)
+            for (int t = 0; t < T; t++)
+                for (long long j : chunkCols[t]) color_column(j, forb, j);
+        }
+        for (int pass = 0; pass < 100; pass++) {
+            std::vector<long long> redo;
+#pragma omp parallel
+            {
+                std::vector<long long> seen;  // colour -> column seen in this row
+                std::vector<long long> mine;
+#pragma omp for schedule(dynamic, 256)
+                for (long long q = 0; q < (long long)keep.size(); q++) {
+                    long long r = keep[q];
+                    seen.assign(seen.size(), -1);
+                    for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) {
+                        int j = con.col[k];
+                        int c = colors[j];
+                        if (c < 0) continue;
+                        if ((size_t)c >= seen.size()) seen.resize(2 * c + 2, -1);
+                        if (seen[c] >= 0 && seen[c] != j) mine.push_back(std::max<long long>(seen[c], j));
+                        else seen[c] = j;
+                    }
+                }
+#pragma omp critical
+                redo.insert(redo.end(), mine.begin(), mine.end());
+            }
+            if (redo.empty()) break;
+            std::sort(redo.begin(), redo.end());
+            redo.erase(std::unique(redo.begin(), redo.end()), redo.end());
+            for (long long j : redo) colors[j] = -1;
+            std::vector<long long> forb(4096, -1);
+            for (long long j : redo) color_column(j, forb, j);
+        }
+    } else {
+        std::vector<long long> forb(4096, -1);
+        for (long long j = 0; j < n; j++) color_column(j, forb, j);
     }
+    int ncol = 0;
+    for (long long j = 0; j < n; j++) ncol = std::max(ncol, colors[j] + 1);
     DAS_CHECK(ncol < 65535, DAS_ERR_INTERNAL, "more than 65534 colours");
     return ncol;
 }
@@ -273,27 +366,51 @@ bool validate_coloring(const JacCon& con, const std::vector<int>& colors) {
 void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
     DAS_CHECK(nnz < 4294967295LL, DAS_ERR_ARG, "pattern nnz exceeds uint32 assembly map");
     t_rowptr.assign(n + 1, 0);
-    for (long long k = 0; k < nnz; k++) t_rowptr[col[k] + 1]++;
-    for (long long j = 0; j < n; j++) t_rowptr[j + 1] += t_rowptr[j];
+    // column counts (parallel, atomic increments), prefix sum
+    {
+        std::vector<int> cnt(n, 0);
+#pragma omp parallel for schedule(static)
+        for (long long k = 0; k < nnz; k++) {
+#pragma omp atomic
+            cnt[col[k]]++;
+        }
+        for (long long j = 0; j < n; j++) t_rowptr[j + 1] = t_rowptr[j] + cnt[j];
+    }
     t_col.assign(nnz, 0);
+    // unordered parallel fill, then sort every transposed row (rows of dRdW^T become sorted by residual index)
+    {
+        std::vector<int> fillpos(n, 0);
+#pragma omp parallel for schedule(static)
+        for (long long r = 0; r < n; r++)
+            for (long long k = rowptr[r]; k < rowptr[r + 1]; k++) {
+                int j = col[k];
+                int p;
+#pragma omp atomic capture
+                p = fillpos[j]++;
+                t_col[t_rowptr[j] + p] = (int)r;
+            }
+#pragma omp parallel for schedule(dynamic, 1024)
+        for (long long j = 0; j < n; j++) std::sort(t_col.begin() + t_rowptr[j], t_col.begin() + t_rowptr[j + 1]);
+    }
     rc_dest.assign(nnz, 0);
     rc_color.assign(nnz, 0);
-    std::vector<long long> pos(t_rowptr.begin(), t_rowptr.end() - 1);
-    for (long long r = 0; r < n; r++)
-        for (long long k = rowptr[r]; k < rowptr[r + 1]; k++) {
-            long long d = pos[col[k]]++;
-            t_col[d] = (int)r;  // rows visited ascending -> transposed rows are sorted
-            rc_dest[k] = (unsigned)d;
-            rc_color[k] = (unsigned short)colors[col[k]];
+#pragma omp parallel
+    {
+        std::vector<std::pair<unsigned short, unsigned>> tmp;
+#pragma omp for schedule(dynamic, 1024)
+        for (long long r = 0; r < n; r++) {
+            long long b = rowptr[r], e = rowptr[r + 1];
+            tmp.resize(e - b);
+            for (long long k = b; k < e; k++) {
+                int j = col[k];
+                const int* tb = t_col.data() + t_rowptr[j];
+                const int* te = t_col.data() + t_rowptr[j + 1];
+                long long d = t_rowptr[j] + (std::lower_bound(tb, te, (int)r) - tb);
+                tmp[k - b] = {(unsigned short)colors[j], (unsigned)d};
+            }
+            std::sort(tmp.begin(), tmp.end());  // by colour
+            for (long long k = b; k < e; k++) { rc_color[k] = tmp[k - b].first; rc_dest[k] = tmp[k - b].second; }
         }
-    // sort each row's (colour,dest) by colour
-    std::vector<std::pair<unsigned short, unsigned>> tmp;
-    for (long long r = 0; r < n; r++) {
-        long long b = rowptr[r], e = rowptr[r + 1];
-        tmp.resize(e - b);
-        for (long long k = b; k < e; k++) tmp[k - b] = {rc_color[k], rc_dest[k]};
-        std::sort(tmp.begin(), tmp.end());
-        for (long long k = b; k < e; k++) { rc_color[k] = tmp[k - b].first; rc_dest[k] = tmp[k - b].second; }
     }
 }
 
