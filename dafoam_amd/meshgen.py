@@ -50,7 +50,9 @@ class PolyMesh:
 
     @property
     def n_cells(self) -> int:
-        return int(self.owner.max()) + 1 if self.owner.size else 0
+        if not self.owner.size:
+            return 0
+        return int(max(self.owner.max(), self.neighbour.max() if self.neighbour.size else 0)) + 1
 
     @property
     def n_faces(self) -> int:
