@@ -15,7 +15,7 @@ from .meshgen import FoamCase
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdafoam_amd.so")
 
-SOLVER_IDS = {"DASimpleFoam": 0, "DAScalarTransportFoam": 1}
+SOLVER_IDS = {"DASimpleFoam": 0, "DAScalarTransportFoam": 1, "DARhoSimpleFoam": 2}
 PATCH_TYPES = {"patch": 0, "wall": 1, "symmetry": 2}
 
 c_double_p = C.POINTER(C.c_double)
@@ -57,6 +57,11 @@ class das_case_t(C.Structure):
         ("y_wall", c_double_p),
         ("phi_frozen", c_double_p),
         ("T_old", c_double_p),
+        ("Cp", C.c_double),
+        ("molWeight", C.c_double),
+        ("mu", C.c_double),
+        ("Pr", C.c_double),
+        ("Prt", C.c_double),
     ]
 
 
@@ -128,6 +133,8 @@ class CaseStruct:
         s.relax_T = case.relax.get("T", 1.0)
         s.DT = case.DT
         s.deltaT = case.deltaT
+        th = getattr(case, "thermo", None) or {}
+        s.Cp, s.molWeight, s.mu, s.Pr, s.Prt = (th.get("Cp", 1005.0), th.get("molWeight", 28.96), th.get("mu", 1.8e-5), th.get("Pr", 0.7), th.get("Prt", 1.0))
 
     def byref(self):
         return C.byref(self.struct)

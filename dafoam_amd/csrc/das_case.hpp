@@ -7,6 +7,7 @@ namespace das {
 struct CaseParams {
     int solver = DAS_SOLVER_SIMPLEFOAM;
     double nu = 1.5e-5, relax_U = 0.7, relax_nuTilda = 0.7, relax_T = 1.0, DT = 0.01, deltaT = 1.0;
+    double Cp = 1005.0, molWeight = 28.96, mu = 1.8e-5, Pr = 0.7, Prt = 1.0;
     std::vector<double> phi_frozen, T_old;
     void from_case(const das_case_t* c) {
         solver = c->solver;
@@ -16,6 +17,10 @@ struct CaseParams {
         relax_T = c->relax_T;
         DT = c->DT;
         deltaT = c->deltaT;
+        if (solver == DAS_SOLVER_RHOSIMPLEFOAM) {
+            Cp = c->Cp; molWeight = c->molWeight; mu = c->mu; Pr = c->Pr; Prt = c->Prt;
+            DAS_CHECK(Cp > 0 && molWeight > 0 && mu > 0 && Pr > 0 && Prt > 0, DAS_ERR_ARG, "DARhoSimpleFoam needs positive Cp, molWeight, mu, Pr, Prt");
+        }
         if (c->phi_frozen) phi_frozen.assign(c->phi_frozen, c->phi_frozen + c->n_faces);
         if (c->T_old) T_old.assign(c->T_old, c->T_old + c->n_cells);
         if (solver == DAS_SOLVER_SCALARTRANSPORTFOAM)
@@ -37,6 +42,16 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.normN = opt.list_has("normalizeResiduals", "nuTildaRes");
     p.normPhi = opt.list_has("normalizeResiduals", "phiRes");
     p.normT = opt.list_has("normalizeResiduals", "TRes");
+    const bool rho = cp.solver == DAS_SOLVER_RHOSIMPLEFOAM;
+    p.offP = 3;
+    p.offT = rho ? 4 : 0;
+    p.offN = rho ? 5 : 4;
+    p.offPhi = rho ? 6 : 5;
+    p.Cp = cp.Cp;
+    p.Rgas = 8314.47 / cp.molWeight;  // Foam::constant::thermodynamic::RR / molWeight
+    p.mu = cp.mu;
+    p.Pr = cp.Pr;
+    p.Prt = cp.Prt;
     return p;
 }
 

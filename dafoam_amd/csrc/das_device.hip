@@ -22,27 +22,27 @@ namespace das {
 // =====================================================================================================
 // kernel wrappers around the templated bodies
 // =====================================================================================================
-template <class T>
-__global__ __launch_bounds__(256) void k_grad(DevMesh m, ResParams prm, const T* __restrict__ W, T* nut, T* gU, T* gP, T* gN) {
+template <class T, bool RHO>
+__global__ __launch_bounds__(256) void k_grad(DevMesh m, ResParams prm, const T* __restrict__ W, T* nut, T* gU, T* gP, T* gN, T* gH) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < m.nC) body_grad<T>(c, m, prm, W, nut, gU, gP, gN);
+    if (c < m.nC) body_grad<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH);
 }
-template <class T>
+template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_cell(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gU, const T* gP,
-                                              const T* gN, T* R, T* rAU, T* HbyA) {
+                                              const T* gN, const T* gH, T* R, T* rAU, T* HbyA) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < m.nC) body_cell<T>(c, m, prm, W, nut, gU, gP, gN, R, rAU, HbyA);
+    if (c < m.nC) body_cell<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, R, rAU, HbyA);
 }
-template <class T>
+template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_face(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gP, const T* rAU,
                                               const T* HbyA, T* q, T* R) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < m.nF) body_face<T>(f, m, prm, W, nut, gP, rAU, HbyA, q, R);
+    if (f < m.nF) body_face<T, RHO>(f, m, prm, W, nut, gP, rAU, HbyA, q, R);
 }
-template <class T>
+template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_pres(DevMesh m, ResParams prm, const T* q, T* R) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < m.nC) body_pres<T>(c, m, prm, q, R);
+    if (c < m.nC) body_pres<T, RHO>(c, m, prm, q, R);
 }
 template <class T>
 __global__ __launch_bounds__(256) void k_gradT(DevMesh m, ResParams prm, const T* __restrict__ W, const double* phiF, T* gT) {
@@ -58,12 +58,13 @@ __global__ __launch_bounds__(256) void k_T(DevMesh m, ResParams prm, const T* __
 
 template <class T>
 struct ResWork {
-    DevBuf<T> nut, gU, gP, gN, rAU, HbyA, q, gT;
+    DevBuf<T> nut, gU, gP, gN, gH, rAU, HbyA, q, gT;
     void ensure(int solver, long long N, long long F) {
-        if (solver == DAS_SOLVER_SIMPLEFOAM) {
+        if (solver == DAS_SOLVER_SIMPLEFOAM || solver == DAS_SOLVER_RHOSIMPLEFOAM) {
             if (nut.n != (size_t)N) {
                 nut.alloc(N); gU.alloc(9 * N); gP.alloc(3 * N); gN.alloc(3 * N); rAU.alloc(N); HbyA.alloc(3 * N); q.alloc(F);
             }
+            if (solver == DAS_SOLVER_RHOSIMPLEFOAM && gH.n != (size_t)(3 * N)) gH.alloc(3 * N);
         } else if (gT.n != (size_t)(3 * N)) gT.alloc(3 * N);
     }
 };
@@ -77,11 +78,17 @@ static void eval_residual(const DevMesh& dm, const CaseParams& cp, const ResPara
     wk.ensure(cp.solver, dm.nC, dm.nF);
     const int B = 256;
     if (cp.solver == DAS_SOLVER_SIMPLEFOAM) {
-        hipLaunchKernelGGL(k_grad<T>, dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p);
-        hipLaunchKernelGGL(k_cell<T>, dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, R, wk.rAU.p,
-                           wk.HbyA.p);
-        hipLaunchKernelGGL(k_face<T>, dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
-        hipLaunchKernelGGL(k_pres<T>, dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, wk.q.p, R);
+        hipLaunchKernelGGL((k_grad<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, (T*)nullptr);
+        hipLaunchKernelGGL((k_cell<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p,
+                           (const T*)nullptr, R, wk.rAU.p, wk.HbyA.p);
+        hipLaunchKernelGGL((k_face<T, false>), dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
+        hipLaunchKernelGGL((k_pres<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, wk.q.p, R);
+    } else if (cp.solver == DAS_SOLVER_RHOSIMPLEFOAM) {
+        hipLaunchKernelGGL((k_grad<T, true>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, wk.gH.p);
+        hipLaunchKernelGGL((k_cell<T, true>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p,
+                           (const T*)wk.gH.p, R, wk.rAU.p, wk.HbyA.p);
+        hipLaunchKernelGGL((k_face<T, true>), dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
+        hipLaunchKernelGGL((k_pres<T, true>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, wk.q.p, R);
     } else {
         hipLaunchKernelGGL(k_gradT<T>, dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, d_phiF, wk.gT.p);
         hipLaunchKernelGGL(k_T<T>, dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, d_phiF, d_Told, wk.gT.p, R);
@@ -1235,7 +1242,7 @@ das_solver_t* das_create(const das_case_t* c) {
         s->t0_cpu = std::clock();
         s->cp.from_case(c);
         s->mesh.build(c);
-        s->opt.s["solverName"] = c->solver == DAS_SOLVER_SIMPLEFOAM ? "DASimpleFoam" : "DAScalarTransportFoam";
+        s->opt.s["solverName"] = c->solver == DAS_SOLVER_SIMPLEFOAM ? "DASimpleFoam" : (c->solver == DAS_SOLVER_RHOSIMPLEFOAM ? "DARhoSimpleFoam" : "DAScalarTransportFoam");
         s->st_full = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, false);
         s->n = s->st_full.n;
         s->h_W.assign(s->n, 0.0);

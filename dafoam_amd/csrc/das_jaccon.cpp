@@ -51,6 +51,20 @@ Stencil make_stencil(int solver, int nC, int nF, const Options& opt, bool isPC) 
                         bits({"U"})};                                                                // pRes
         st.levels[2] = {bits({"U", "nuTilda", "phi"}), bits({"U", "nuTilda"}), bits({"nuTilda"})};    // nuTildaRes
         st.levels[3] = {bits({"U", "p", "nuTilda", "phi"}), bits({"U", "p", "nuTilda"}), bits({"U"})};  // phiRes
+    } else if (solver == DAS_SOLVER_RHOSIMPLEFOAM) {
+        // DAStateInfoRhoSimpleFoam.C:40-47,79-116 and the compressible SA table DASpalartAllmaras.C:364-383
+        add_state("U", KIND_VEC);
+        add_state("p", KIND_SCL);
+        add_state("T", KIND_SCL);
+        add_state("nuTilda", KIND_SCL);
+        add_state("phi", KIND_FACE);
+        st.levels.resize(5);
+        st.levels[0] = {bits({"U", "p", "T", "nuTilda", "phi"}), bits({"U", "p", "T", "nuTilda"}), bits({"U", "T"})};                        // URes
+        st.levels[1] = {bits({"U", "p", "T", "nuTilda", "phi"}), bits({"U", "p", "T", "nuTilda", "phi"}), bits({"U", "p", "T", "nuTilda"}),
+                        bits({"U"})};                                                                                                   // pRes
+        st.levels[2] = {bits({"U", "p", "T", "nuTilda", "phi"}), bits({"U", "p", "T", "nuTilda"}), bits({"U", "p", "T"})};                  // TRes
+        st.levels[3] = {bits({"U", "T", "p", "nuTilda", "phi"}), bits({"U", "T", "p", "nuTilda"}), bits({"T", "p", "nuTilda"})};            // nuTildaRes
+        st.levels[4] = {bits({"U", "p", "T", "nuTilda", "phi"}), bits({"U", "p", "T", "nuTilda"}), bits({"U", "T"})};                       // phiRes
     } else if (solver == DAS_SOLVER_SCALARTRANSPORTFOAM) {
         add_state("T", KIND_SCL);
         st.levels.resize(1);

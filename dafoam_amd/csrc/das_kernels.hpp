@@ -41,7 +41,13 @@ struct ResParams {
     double nu, alphaU, alphaN, DT, deltaT;
     int isPC, constrainHbyA;
     int normU, normP, normN, normPhi, normT;  // 1 = residual listed in normalizeResiduals
+    // state-block offsets in units of nC (DAIndex "state" ordering): SimpleFoam [U|p|nuTilda|phi] = 3,-,4,5;
+    // RhoSimpleFoam [U|p|T|nuTilda|phi] = 3,4,5,6
+    int offP, offT, offN, offPhi;
+    // perfect-gas / hConst / const-transport thermo (reference DAResidual.C:179-293)
+    double Cp, Rgas, mu, Pr, Prt;
 };
+#define DAS_TREF 298.15
 
 // SA constants (reference DASpalartAllmaras.C:47-80)
 #define SA_SIGMA 0.66666
@@ -117,7 +123,7 @@ DAS_HD void bc_vector(int code, const double* value, double delta, double phib, 
 
 // nutUSpaldingWallFunction (reference ...DF.C:42-150); laminar seed (:117-118), maxIter 10, tol 1e-14
 template <class T>
-DAS_HD T spalding_nut(const T& magUp, const T& magGradU, double y, double nu) {
+DAS_HD T spalding_nut(const T& magUp, const T& magGradU, double y, const T& nu) {
     const double kappa = 0.41, E = 9.8;
     T ut = dsqrt(nu * magGradU);
     if (!(val(ut) > DAS_ROOTVSMALL)) return T(0.0);
@@ -125,7 +131,7 @@ DAS_HD T spalding_nut(const T& magUp, const T& magGradU, double y, double nu) {
         T kUu = dmin(kappa * magUp / ut, 50.0);
         T fkUu = dexp(kUu) - 1.0 - kUu * (1.0 + 0.5 * kUu);
         T f = -(ut * (y / nu)) + magUp / ut + (1.0 / E) * (fkUu - (1.0 / 6.0) * kUu * kUu * kUu);
-        T df = y / nu + magUp / (ut * ut) + (1.0 / E) * kUu * fkUu / ut;
+        T df = (y / nu) + magUp / (ut * ut) + (1.0 / E) * kUu * fkUu / ut;
         T utn = ut + f / df;
         double err = fabs((val(ut) - val(utn)) / val(ut));
         ut = utn;
@@ -139,19 +145,31 @@ template <class T>
 struct BFace {
     VectorBC<T> U;
     ScalarBC<T> p, n;
+    ScalarBC<T> Tt, he;  // compressible only
+    T rho_b, nu_b;       // compressible only (incompressible: rho_b = 1, nu_b = nu)
     T nut_b;
     double nrm[3];
 };
 
 // evaluate all patch fields of one boundary face from the owner cell's values
-template <class T>
-DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc, double nu, const T* Uc, const T& pc,
-                       const T& nc, const T& nut_c, double phib, BFace<T>& o) {
+template <class T, bool RHO>
+DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc, const ResParams& prm, const T* Uc, const T& pc,
+                       const T& Tc, const T& nc, const T& nut_c, double phib, BFace<T>& o) {
 #pragma unroll
     for (int k = 0; k < 3; k++) o.nrm[k] = g.Sf[k] / g.magSf;
     bc_vector<T>(bc.U_code, bc.U_val, g.nod, phib, o.nrm, Uc, o.U);
     bc_scalar<T>(bc.p_code, bc.p_val, g.nod, phib, pc, o.p);
     bc_scalar<T>(bc.nuTilda_code, bc.nuTilda_val, g.nod, phib, nc, o.n);
+    if (RHO) {
+        bc_scalar<T>(bc.T_code, bc.T_val, g.nod, phib, Tc, o.Tt);
+        T hec = prm.Cp * (Tc - DAS_TREF);
+        bc_scalar<T>(bc.T_code, prm.Cp * (bc.T_val - DAS_TREF), g.nod, phib, hec, o.he);
+        o.rho_b = o.p.xb / (prm.Rgas * o.Tt.xb);
+        o.nu_b = prm.mu / o.rho_b;
+    } else {
+        o.rho_b = T(1.0);
+        o.nu_b = T(prm.nu);
+    }
     if (bc.nut_code == DAS_NUT_LOWRE_WALL) o.nut_b = T(0.0);
     else if (bc.nut_code == DAS_NUT_SYMMETRY) o.nut_b = nut_c;
     else if (bc.nut_code == DAS_NUT_SPALDING_WALL) {
@@ -159,48 +177,52 @@ DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc
         T magUp = dsqrt(d0 * d0 + d1 * d1 + d2 * d2);
         T magGradU = magUp * g.nod;
         double yw = fabs((g.Cf[0] - cgc.C[0]) * o.nrm[0] + (g.Cf[1] - cgc.C[1]) * o.nrm[1] + (g.Cf[2] - cgc.C[2]) * o.nrm[2]);
-        o.nut_b = spalding_nut<T>(magUp, magGradU, yw, nu);
+        o.nut_b = spalding_nut<T>(magUp, magGradU, yw, o.nu_b);
     } else {
-        o.nut_b = o.n.xb * fv1_of<T>(o.n.xb / nu);
+        o.nut_b = o.n.xb * fv1_of<T>(o.n.xb / o.nu_b);
     }
 }
 
 // ================================================================================ k_grad
-// per cell: nut = nuTilda*fv1 ; Gauss-linear gradients of U, p, nuTilda
-template <class T>
-DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W, T* nut, T* gradU, T* gradP, T* gradN) {
+// per cell: nut = nuTilda*fv1 ; Gauss-linear gradients of U, p, nuTilda (and he = Cp (T - Tref) when RHO)
+template <class T, bool RHO>
+DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W, T* nut, T* gradU, T* gradP, T* gradN, T* gradH) {
     const long long N = m.nC;
     const CellGeom& cgc = m.cg[c];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
-    T pc = W[3 * N + c], nc = W[4 * N + c];
-    T nut_c = nc * fv1_of<T>(nc / prm.nu);
+    T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
+    T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
+    T nu_c = RHO ? prm.mu * (prm.Rgas * Tc) / pc : T(prm.nu);
+    T nut_c = nc * fv1_of<T>(nc / nu_c);
     nut[c] = nut_c;
-    T gU[9], gP[3], gN[3];
+    T gU[9], gP[3], gN[3], gH[3];
 #pragma unroll
     for (int k = 0; k < 9; k++) gU[k] = T(0.0);
 #pragma unroll
-    for (int k = 0; k < 3; k++) { gP[k] = T(0.0); gN[k] = T(0.0); }
+    for (int k = 0; k < 3; k++) { gP[k] = T(0.0); gN[k] = T(0.0); gH[k] = T(0.0); }
     for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
         int fe = m.cf_face[s];
         int f = fe & 0x7fffffff;
         bool nb = fe < 0;
         const FaceGeom& g = m.fg[f];
-        T Uf[3], pf, nf;
+        T Uf[3], pf, nf, hf(0.0);
         double sg = nb ? -1.0 : 1.0;
         if (f < m.nIF) {
             int o = m.cf_other[s];
             double wc = nb ? 1.0 - g.w : g.w;
 #pragma unroll
             for (int k = 0; k < 3; k++) Uf[k] = wc * Uc[k] + (1.0 - wc) * W[3LL * o + k];
-            pf = wc * pc + (1.0 - wc) * W[3 * N + o];
-            nf = wc * nc + (1.0 - wc) * W[4 * N + o];
+            pf = wc * pc + (1.0 - wc) * W[prm.offP * N + o];
+            nf = wc * nc + (1.0 - wc) * W[prm.offN * N + o];
+            if (RHO) hf = prm.Cp * (wc * Tc + (1.0 - wc) * W[prm.offT * N + o] - DAS_TREF);
         } else {
             BFace<T> b;
-            eval_bface<T>(m.bc[m.bpatch[f - m.nIF]], g, cgc, prm.nu, Uc, pc, nc, nut_c, val(W[5 * N + f]), b);
+            eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, cgc, prm, Uc, pc, Tc, nc, nut_c, val(W[prm.offPhi * N + f]), b);
 #pragma unroll
             for (int k = 0; k < 3; k++) Uf[k] = b.U.xb[k];
             pf = b.p.xb;
             nf = b.n.xb;
+            if (RHO) hf = b.he.xb;
         }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -209,13 +231,18 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
             for (int j = 0; j < 3; j++) gU[3 * i + j] += S * Uf[j];
             gP[i] += S * pf;
             gN[i] += S * nf;
+            if (RHO) gH[i] += S * hf;
         }
     }
     double rV = 1.0 / cgc.V;
 #pragma unroll
     for (int k = 0; k < 9; k++) gradU[9LL * c + k] = gU[k] * rV;
 #pragma unroll
-    for (int k = 0; k < 3; k++) { gradP[3LL * c + k] = gP[k] * rV; gradN[3LL * c + k] = gN[k] * rV; }
+    for (int k = 0; k < 3; k++) {
+        gradP[3LL * c + k] = gP[k] * rV;
+        gradN[3LL * c + k] = gN[k] * rV;
+        if (RHO) gradH[3LL * c + k] = gH[k] * rV;
+    }
 }
 
 // tau = nuEff * dev2(T(gradU)) ; g[3*i+j] = d_i U_j
@@ -233,37 +260,45 @@ DAS_HD void dev2T_scaled(const T* g, const T& nuEff, T* tau) {
 }
 
 // ================================================================================ k_cell
-// per cell: U-equation (diag/off-diag/source incl. boundary coeffs), relax, URes, rAU, HbyA and the SA residual
-template <class T>
+// per cell: U-equation (diag/off-diag/source incl. boundary coeffs), relax, URes, rAU, HbyA, the SA residual and
+// (RHO) the energy residual TRes = EEqn & he.  RHO: phi is the mass flux, muEff = mu + rho nut replaces nuEff.
+template <class T, bool RHO>
 DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const T* gradP,
-                      const T* gradN, T* R, T* rAU, T* HbyA) {
+                      const T* gradN, const T* gradH, T* R, T* rAU, T* HbyA) {
     const long long N = m.nC;
     const CellGeom& cgc = m.cg[c];
-    const double nu = prm.nu;
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
-    T pc = W[3 * N + c], nc = W[4 * N + c];
+    T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
+    T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
+    T rho_c = RHO ? pc / (prm.Rgas * Tc) : T(1.0);
+    T nu_c = RHO ? prm.mu / rho_c : T(prm.nu);
     T nut_c = nut[c];
-    T nuEff_c = nu + nut_c;
+    T muEff_c = rho_c * (nu_c + nut_c);
     T gUc[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) gUc[k] = gradU[9LL * c + k];
     T gNc[3] = {gradN[3LL * c], gradN[3LL * c + 1], gradN[3LL * c + 2]};
     T tau_c[9];
-    dev2T_scaled<T>(gUc, nuEff_c, tau_c);
-    T Dn_c = (nc + nu) * (1.0 / SA_SIGMA);
+    dev2T_scaled<T>(gUc, muEff_c, tau_c);
+    T Dn_c = rho_c * (nc + nu_c) * (1.0 / SA_SIGMA);
+    // energy (RHO)
+    T he_c = RHO ? prm.Cp * (Tc - DAS_TREF) : T(0.0);
+    T aEff_c = RHO ? prm.mu / prm.Pr + rho_c * nut_c * (1.0 / prm.Prt) : T(0.0);
+    T K_c = RHO ? 0.5 * (Uc[0] * Uc[0] + Uc[1] * Uc[1] + Uc[2] * Uc[2]) : T(0.0);
 
     T D0(0.0), sumOff(0.0), sumPhi(0.0), vmaxs(0.0), vmins(0.0);
     T offU[3], src[3], bdiag[3], bsrc[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) { offU[k] = T(0.0); src[k] = T(0.0); bdiag[k] = T(0.0); bsrc[k] = T(0.0); }
     T dN(0.0), offN(0.0), sN(0.0), bdN(0.0), bsN(0.0);
+    T dE(0.0), offE(0.0), sE(0.0), bdE(0.0), bsE(0.0);
 
     for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
         int fe = m.cf_face[s];
         int f = fe & 0x7fffffff;
         bool nb = fe < 0;
         const FaceGeom& g = m.fg[f];
-        T phi = W[5 * N + f];
+        T phi = W[prm.offPhi * N + f];
         double sg = nb ? -1.0 : 1.0;
         if (f < m.nIF) {
             int o = m.cf_other[s];
@@ -275,16 +310,22 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             else { dcoef = -((1.0 - wu) * phi); off = -(wu * phi); }
             sumPhi += sg * phi;
             T Uo[3] = {W[3LL * o], W[3LL * o + 1], W[3LL * o + 2]};
-            T nuT_o = W[4 * N + o];
-            T nuEff_o = nu + nut[o];
+            T nuT_o = W[prm.offN * N + o];
+            T rho_o(1.0), nu_o(prm.nu), T_o(0.0);
+            if (RHO) {
+                T_o = W[prm.offT * N + o];
+                rho_o = W[prm.offP * N + o] / (prm.Rgas * T_o);
+                nu_o = prm.mu / rho_o;
+            }
+            T nut_o = nut[o];
+            T muEff_o = rho_o * (nu_o + nut_o);
             T gUo[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) gUo[k] = gradU[9LL * o + k];
             const double wl = g.w;
-            // weights of this cell's and the other cell's value in the linear face interpolate
             const double wc = nb ? 1.0 - wl : wl, wo = 1.0 - wc;
-            // ---- momentum diffusion  -fvm::laplacian(nuEff,U)  (Gauss linear corrected)
-            T gam = (wc * nuEff_c + wo * nuEff_o) * g.magSf;
+            // ---- momentum diffusion  -fvm::laplacian(rho nuEff,U)  (Gauss linear corrected)
+            T gam = (wc * muEff_c + wo * muEff_o) * g.magSf;
             T cd = gam * g.nod;
             T offTot = off - cd;
             D0 += dcoef + cd;
@@ -302,7 +343,6 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     corr[j] = d[0] * gUp[j] + d[1] * gUp[3 + j] + d[2] * gUp[6 + j];
-                    // owner/neighbour values
                     T UO = nb ? Uo[j] : Uc[j];
                     T UN = nb ? Uc[j] : Uo[j];
                     mx[j] = pos ? (1.0 - wl) * (UN - UO) : wl * (UO - UN);
@@ -322,7 +362,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             }
             // ---- non-orthogonal correction of the laplacian and the explicit dev2 stress term
             T tau_o[9];
-            dev2T_scaled<T>(gUo, nuEff_o, tau_o);
+            dev2T_scaled<T>(gUo, muEff_o, tau_o);
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 T cvg = g.corr[0] * (wc * gUc[j] + wo * gUo[j]) + g.corr[1] * (wc * gUc[3 + j] + wo * gUo[3 + j])
@@ -332,7 +372,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 src[j] += sg * (gam * cvg + tf);
             }
             // ---- SA convection (bounded upwind) + diffusion
-            T Dn_o = (nuT_o + nu) * (1.0 / SA_SIGMA);
+            T Dn_o = rho_o * (nuT_o + nu_o) * (1.0 / SA_SIGMA);
             T gn = (wc * Dn_c + wo * Dn_o) * g.magSf;
             T cdn = gn * g.nod;
             dN += dcoef + cdn;
@@ -340,13 +380,30 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             T cvn = g.corr[0] * (wc * gNc[0] + wo * gradN[3LL * o]) + g.corr[1] * (wc * gNc[1] + wo * gradN[3LL * o + 1])
                     + g.corr[2] * (wc * gNc[2] + wo * gradN[3LL * o + 2]);
             sN += sg * (gn * cvn);
+            // ---- energy: div(phi,he) upwind + fvc::div(phi,K) upwind - laplacian(alphaEff, he)
+            if (RHO) {
+                T he_o = prm.Cp * (T_o - DAS_TREF);
+                T aEff_o = prm.mu / prm.Pr + rho_o * nut_o * (1.0 / prm.Prt);
+                T ga = (wc * aEff_c + wo * aEff_o) * g.magSf;
+                T cde = ga * g.nod;
+                dE += dcoef + cde;
+                offE += (off - cde) * he_o;
+                T cve = g.corr[0] * (wc * gradH[3LL * c] + wo * gradH[3LL * o]) + g.corr[1] * (wc * gradH[3LL * c + 1] + wo * gradH[3LL * o + 1])
+                        + g.corr[2] * (wc * gradH[3LL * c + 2] + wo * gradH[3LL * o + 2]);
+                sE += sg * (ga * cve);
+                T K_o = 0.5 * (Uo[0] * Uo[0] + Uo[1] * Uo[1] + Uo[2] * Uo[2]);
+                // upwind face value of K: owner value if flux >= 0
+                bool ownerIsC = !nb;
+                T Kf = ((pv >= 0.0) == ownerIsC) ? K_c : K_o;
+                sE -= (sg * phi) * Kf;
+            }
         } else {
             BFace<T> b;
             double pv = val(phi);
-            eval_bface<T>(m.bc[m.bpatch[f - m.nIF]], g, cgc, nu, Uc, pc, nc, nut_c, pv, b);
+            eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, cgc, prm, Uc, pc, Tc, nc, nut_c, pv, b);
             sumPhi += phi;
-            T nuEff_b = nu + b.nut_b;
-            T gam_b = nuEff_b * g.magSf;
+            T muEff_b = b.rho_b * (b.nu_b + b.nut_b);
+            T gam_b = muEff_b * g.magSf;
             T iC[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -376,13 +433,20 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
 #pragma unroll
                 for (int j = 0; j < 3; j++) gUb[3 * i + j] = gUc[3 * i + j] + b.nrm[i] * dsn[j];
             T tau_b[9];
-            dev2T_scaled<T>(gUb, nuEff_b, tau_b);
+            dev2T_scaled<T>(gUb, muEff_b, tau_b);
 #pragma unroll
             for (int j = 0; j < 3; j++) src[j] += g.Sf[0] * tau_b[j] + g.Sf[1] * tau_b[3 + j] + g.Sf[2] * tau_b[6 + j];
             // SA boundary coefficients
-            T gn_b = (b.n.xb + nu) * (g.magSf / SA_SIGMA);
+            T gn_b = b.rho_b * (b.n.xb + b.nu_b) * (g.magSf / SA_SIGMA);
             bdN += phi * b.n.vic - gn_b * b.n.gic;
             bsN += gn_b * b.n.gbc - phi * b.n.vbc;
+            if (RHO) {
+                T ga_b = (prm.mu / prm.Pr + b.rho_b * b.nut_b * (1.0 / prm.Prt)) * g.magSf;
+                bdE += phi * b.he.vic - ga_b * b.he.gic;
+                bsE += ga_b * b.he.gbc - phi * b.he.vbc;
+                T Kb = 0.5 * (b.U.xb[0] * b.U.xb[0] + b.U.xb[1] * b.U.xb[1] + b.U.xb[2] * b.U.xb[2]);
+                sE -= phi * Kb;
+            }
         }
     }
     // bounded Gauss: - fvm::Sp(div(phi))
@@ -405,10 +469,16 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
         T H = ((avgb - bdiag[k]) * Uc[k] - offU[k] + sk + bsrc[k]) * rV;
         HbyA[3LL * c + k] = rA * H;
     }
+    if (RHO) {
+        dE -= sumPhi;
+        T tres = ((dE + bdE) * he_c + offE - sE - bsE) * rV;
+        if (!prm.normT) tres = tres * cgc.V;
+        R[prm.offT * N + c] = tres;
+    }
     // ---- SA source terms (DASpalartAllmaras.C:124-178,445-485)
     const double y = cgc.y;
     const double k2y2 = (SA_KAPPA * y) * (SA_KAPPA * y);
-    T chi = nc / nu;
+    T chi = nc / nu_c;
     T fv1 = fv1_of<T>(chi);
     T fv2 = 1.0 - chi / (1.0 + chi * fv1);
     T w01 = 0.5 * (gUc[1] - gUc[3]), w02 = 0.5 * (gUc[2] - gUc[6]), w12 = 0.5 * (gUc[5] - gUc[7]);
@@ -421,15 +491,15 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     const double cw36 = SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3;
     T fw = gg * dpow((1.0 + cw36) / (g6 + cw36), 1.0 / 6.0);
     T convdiff = ((dN + bdN) * nc + offN - sN - bsN) * rV;
-    T nres = convdiff - (SA_CB2 / SA_SIGMA) * (gNc[0] * gNc[0] + gNc[1] * gNc[1] + gNc[2] * gNc[2]) - SA_CB1 * Stilda * nc
-             + SA_CW1 * fw * nc / (y * y) * nc;
+    T nres = convdiff - rho_c * ((SA_CB2 / SA_SIGMA) * (gNc[0] * gNc[0] + gNc[1] * gNc[1] + gNc[2] * gNc[2]) + SA_CB1 * Stilda * nc)
+             + SA_CW1 * rho_c * fw * nc / (y * y) * nc;
     if (!prm.normN) nres = nres * cgc.V;
-    R[4 * N + c] = nres;
+    R[prm.offN * N + c] = nres;
 }
 
 // ================================================================================ k_face
 // per face: phiHbyA, pressure flux, q = flux - phiHbyA (consumed by k_pres) and phiRes
-template <class T>
+template <class T, bool RHO>
 DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradP, const T* rAU,
                       const T* HbyA, T* q, T* R) {
     const long long N = m.nC;
@@ -440,17 +510,24 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
         const double wl = g.w, wn = 1.0 - g.w;
         phiHbyA = g.Sf[0] * (wl * HbyA[3LL * o] + wn * HbyA[3LL * n]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * HbyA[3LL * n + 1])
                   + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * HbyA[3LL * n + 2]);
-        T gp = (wl * rAU[o] + wn * rAU[n]) * g.magSf;
+        T ro(1.0), rn(1.0);
+        if (RHO) {
+            ro = W[prm.offP * N + o] / (prm.Rgas * W[prm.offT * N + o]);
+            rn = W[prm.offP * N + n] / (prm.Rgas * W[prm.offT * N + n]);
+            phiHbyA = (wl * ro + wn * rn) * phiHbyA;
+        }
+        T gp = (wl * (ro * rAU[o]) + wn * (rn * rAU[n])) * g.magSf;
         T cg = g.corr[0] * (wl * gradP[3LL * o] + wn * gradP[3LL * n]) + g.corr[1] * (wl * gradP[3LL * o + 1] + wn * gradP[3LL * n + 1])
                + g.corr[2] * (wl * gradP[3LL * o + 2] + wn * gradP[3LL * n + 2]);
-        flux = gp * (g.nod * (W[3 * N + n] - W[3 * N + o]) + cg);
+        flux = gp * (g.nod * (W[prm.offP * N + n] - W[prm.offP * N + o]) + cg);
     } else {
         int c = m.owner[f];
         const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
         T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
-        T pc = W[3 * N + c], nc = W[4 * N + c];
+        T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
+        T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
         BFace<T> b;
-        eval_bface<T>(bc, g, m.cg[c], prm.nu, Uc, pc, nc, nut[c], val(W[5 * N + f]), b);
+        eval_bface<T, RHO>(bc, g, m.cg[c], prm, Uc, pc, Tc, nc, nut[c], val(W[prm.offPhi * N + f]), b);
         T Hb[3] = {HbyA[3LL * c], HbyA[3LL * c + 1], HbyA[3LL * c + 2]};
         if (bc.U_code == DAS_BC_SYMMETRY) {
             T hn = b.nrm[0] * Hb[0] + b.nrm[1] * Hb[1] + b.nrm[2] * Hb[2];
@@ -461,17 +538,18 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
 #pragma unroll
             for (int k = 0; k < 3; k++) Hb[k] = b.U.xb[k];
         }
-        phiHbyA = g.Sf[0] * Hb[0] + g.Sf[1] * Hb[1] + g.Sf[2] * Hb[2];
-        flux = rAU[c] * g.magSf * (b.p.gic * pc + b.p.gbc);
+        phiHbyA = b.rho_b * (g.Sf[0] * Hb[0] + g.Sf[1] * Hb[1] + g.Sf[2] * Hb[2]);
+        flux = (b.rho_b * rAU[c]) * g.magSf * (b.p.gic * pc + b.p.gbc);
     }
     q[f] = flux - phiHbyA;
-    T pr = phiHbyA - flux - W[5 * N + f];
+    T pr = phiHbyA - flux - W[prm.offPhi * N + f];
     if (prm.normPhi) pr = pr * (1.0 / g.magSf);
-    R[5 * N + f] = pr;
+    R[prm.offPhi * N + f] = pr;
 }
 
 // ================================================================================ k_pres
-template <class T>
+// incompressible: pRes = (laplacian(rAU,p) - div(phiHbyA))/V = sum(q)/V ; compressible: pEqn = div(phiHbyA) - laplacian -> -sum(q)/V
+template <class T, bool RHO>
 DAS_HD void body_pres(int c, const DevMesh& m, const ResParams& prm, const T* q, T* R) {
     const long long N = m.nC;
     T s(0.0);
@@ -481,8 +559,9 @@ DAS_HD void body_pres(int c, const DevMesh& m, const ResParams& prm, const T* q,
         if (fe < 0) s -= q[f];
         else s += q[f];
     }
+    if (RHO) s = -s;
     if (prm.normP) s = s * (1.0 / m.cg[c].V);
-    R[3 * N + c] = s;
+    R[prm.offP * N + c] = s;
 }
 
 // ================================================================================ DAScalarTransportFoam

@@ -84,6 +84,8 @@ class FoamCase:
     deltaT: float = 1.0
     phi: Optional[np.ndarray] = None  # frozen face flux (ScalarTransport)
     T_old: Optional[np.ndarray] = None
+    # compressible thermo (hePsiThermo/perfectGas/hConst/const transport, reference DAResidual.C:179-293)
+    thermo: Dict[str, float] = field(default_factory=lambda: {"Cp": 1005.0, "molWeight": 28.96, "mu": 1.8e-5, "Pr": 0.7, "Prt": 1.0})
 
 
 def hex_block(
@@ -295,6 +297,8 @@ def n_states(case: FoamCase) -> int:
         return m.n_cells
     if case.solver_name == "DASimpleFoam":
         return 5 * m.n_cells + m.n_faces
+    if case.solver_name == "DARhoSimpleFoam":
+        return 6 * m.n_cells + m.n_faces
     raise ValueError(case.solver_name)
 
 
@@ -506,6 +510,36 @@ def bench_channel_case(nx, ny, nz, wall_function=False):
     c = load_coarse_primal()
     case = channel_case(nx, ny, nz, lengths=c["lengths"], grading_y=c["grading_y"], wall_function=wall_function, perturb=0.0)
     return prolong_channel_state(case, (nx, ny, nz), c)
+
+
+def rho_channel_case(nx=7, ny=7, nz=7, lengths=(1.0, 0.2, 0.1), U0=50.0, p0=101325.0, T0=300.0, nuTilda0=4.5e-5, wall_function=False,
+                     grading_y=1.0, bump=0.1, skew=0.15, perturb=0.0, seed=0) -> FoamCase:
+    """DARhoSimpleFoam + SA channel (subsonic, perfect gas): states [U | p | T | nuTilda | phi(mass flux)].
+    Free-stream values follow the reference's compressible tests (p 101325, T 300; tests/runRegTests_DARhoSimpleFoam*.py)."""
+    base = channel_case(nx, ny, nz, lengths=lengths, U0=U0, nuTilda0=nuTilda0, wall_function=wall_function, grading_y=grading_y, bump=bump,
+                        skew=skew, perturb=perturb, seed=seed)
+    mesh = base.mesh
+    N, F = mesh.n_cells, mesh.n_faces
+    bcs = base.bcs
+    bcs["inlet"]["T"] = (BC_FIXED_VALUE, T0)
+    bcs["outlet"]["T"] = (BC_INLET_OUTLET, T0)
+    bcs["outlet"]["p"] = (BC_FIXED_VALUE, p0)
+    for nm in ("bottom", "top", "front", "back"):
+        bcs[nm]["T"] = (BC_SYMMETRY, 0.0) if bcs[nm]["U"][0] == BC_SYMMETRY else (BC_ZERO_GRADIENT, 0.0)
+    case = FoamCase(mesh=mesh, solver_name="DARhoSimpleFoam", nu=base.nu, bcs=bcs, y_wall=base.y_wall)
+    case.relax = {"U": 0.7, "nuTilda": 0.7, "T": 0.9}
+    W = base.states
+    U = W[: 3 * N].reshape(N, 3)
+    pk = W[3 * N : 4 * N]  # kinematic pressure perturbation of the incompressible synthetic field
+    nuT = W[4 * N : 5 * N]
+    phiv = W[5 * N :]
+    R = 8314.47 / case.thermo["molWeight"]
+    rho0 = p0 / (R * T0)
+    g = _InputGeometry(mesh)
+    p = p0 + rho0 * pk
+    T = T0 * (1.0 + 0.01 * np.sin(np.pi * g.C[:, 0] / lengths[0]) * np.cos(np.pi * g.C[:, 1] / lengths[1]))
+    case.states = np.concatenate([U.ravel(), p, T, nuT, rho0 * phiv])
+    return case
 
 
 def scalar_transport_case(nx=18, ny=17, nz=16, lengths=(1.0, 0.5, 0.5), DT=0.01, deltaT=0.05, seed=0) -> FoamCase:

@@ -280,7 +280,7 @@ class pyDASolvers:
     def getNLocalAdjointBoundaryStates(self):
         m = self._case.mesh
         nb = m.n_faces - m.n_internal_faces
-        return (5 if self._case.solver_name == "DASimpleFoam" else 1) * nb
+        return {"DASimpleFoam": 5, "DARhoSimpleFoam": 6}.get(self._case.solver_name, 1) * nb
 
     def getNLocalCells(self):
         return int(lib().das_get_n_local_cells(self._h))

@@ -35,6 +35,7 @@ extern "C" {
 /* solver ids (reference run-time selection by "solverName", DASolver.C:122-152) */
 #define DAS_SOLVER_SIMPLEFOAM 0          /* DASimpleFoam + SpalartAllmaras */
 #define DAS_SOLVER_SCALARTRANSPORTFOAM 1 /* DAScalarTransportFoam */
+#define DAS_SOLVER_RHOSIMPLEFOAM 2       /* DARhoSimpleFoam + SpalartAllmaras (perfect gas, hConst, const transport) */
 
 /* patch types */
 #define DAS_PATCH_PATCH 0
@@ -85,6 +86,9 @@ typedef struct das_case {
     const double* y_wall;     /* n_cells, frozen wall distance (may be NULL for ScalarTransport) */
     const double* phi_frozen; /* n_faces, DAScalarTransportFoam only */
     const double* T_old;      /* n_cells, DAScalarTransportFoam only */
+    /* DARhoSimpleFoam thermophysicalProperties (reference DAResidual.C:179-293): Cp [J/kg/K], molWeight [kg/kmol],
+     * mu [Pa s], Pr, Prt */
+    double Cp, molWeight, mu, Pr, Prt;
 } das_case_t;
 
 const char* das_last_error(void);

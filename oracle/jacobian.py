@@ -40,6 +40,15 @@ STENCIL = {
         "phiRes": [["U", "p", "nuTilda", "phi"], ["U", "p", "nuTilda"], ["U"]],
         "nuTildaRes": [["U", "nuTilda", "phi"], ["U", "nuTilda"], ["nuTilda"]],
     },
+    # DAStateInfoRhoSimpleFoam.C:40-47,79-116 + compressible SA (DASpalartAllmaras.C:364-383)
+    "DARhoSimpleFoam": {
+        "states": [("U", "vec"), ("p", "scl"), ("T", "scl"), ("nuTilda", "scl"), ("phi", "face")],
+        "URes": [["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda"], ["U", "T"]],
+        "pRes": [["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda"], ["U"]],
+        "TRes": [["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda"], ["U", "p", "T"]],
+        "nuTildaRes": [["U", "T", "p", "nuTilda", "phi"], ["U", "T", "p", "nuTilda"], ["T", "p", "nuTilda"]],
+        "phiRes": [["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda"], ["U", "T"]],
+    },
     "DAScalarTransportFoam": {
         "states": [("T", "scl")],
         "TRes": [["T"], ["T"], ["T"]],

@@ -1,0 +1,237 @@
+"""ORACLE (test infrastructure only - never imported by the product path).
+
+CPU (numpy) restatement of the compressible residual R(W) of DARhoSimpleFoam + Spalart-Allmaras:
+
+  * DAResidualRhoSimpleFoam::calcResiduals      reference src/adjoint/DAResidual/DAResidualRhoSimpleFoam.C:84-211
+  * DAResidual::updateThermoVars                reference src/adjoint/DAResidual/DAResidual.C:179-293
+        (hePsiThermo, pureMixture, perfectGas, hConst, const transport: psi = 1/(R T), rho = psi p,
+         he = Cp (T - 298.15) [sensible enthalpy], nu = mu/rho, alpha = mu/Pr)
+  * DASpalartAllmaras::calcResiduals (compressible form with rho)   reference DASpalartAllmaras.C:407-488
+  * DATurbulenceModel::divDevRhoReff / correctAlphat / alphaEff      reference DATurbulenceModel.C:195-257,378-408
+  * state layout [U | p | T | nuTilda | phi]    reference DAStateInfoRhoSimpleFoam.C:40-47, DAIndex.C:43-63,188-258
+
+Canonical schemes: div(phi,U) bounded Gauss linearUpwindV grad(U) (upwind for the PC);
+div(phi,h), div(phi,nuTilda), div(phi,K) [fvc]: (bounded) Gauss upwind; laplacians Gauss linear corrected;
+div(((rho*nuEff)*dev2(T(grad(U))))) Gauss linear.  phi is the MASS flux.
+The he patch fields mirror the T patch fields (fixedEnergy / gradientEnergy / mixedEnergy).
+PARITY UNPINNED (see oracle/README.md); dtype generic (complex step).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from dafoam_amd.meshgen import BC_FIXED_VALUE, BC_SYMMETRY, NUT_LOWRE_WALL, NUT_SPALDING_WALL, NUT_SYMMETRY
+
+from .residual import SA, SMALL, VSMALL, BCTable, Ops, _abs, _max, _min, bc_scalar, bc_vector, dev2T, fv1_of, relax_diag, sadd, spalding_nut
+
+RR = 8314.47  # Foam::constant::thermodynamic::RR [J/(kmol K)]
+TREF = 298.15
+
+
+def unpack_rho(W, N, F):
+    U = W[: 3 * N].reshape(N, 3)
+    p = W[3 * N : 4 * N]
+    T = W[4 * N : 5 * N]
+    nuT = W[5 * N : 6 * N]
+    phi = W[6 * N : 6 * N + F]
+    return U, p, T, nuT, phi
+
+
+def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "nuTildaRes", "phiRes"), use_constrain_hbya=True,
+                        return_parts=False):
+    N, F, nIF, nBF = g.nC, g.nF, g.nIF, g.nBF
+    ops = Ops(g)
+    oi, ni, bcell = ops.oi, ops.ni, ops.bc
+    U, p, T, nuT, phi = unpack_rho(W, N, F)
+    dt = W.dtype
+    th = case.thermo
+    Cp, mu, Pr, Prt = th["Cp"], th["mu"], th["Pr"], th["Prt"]
+    R = RR / th["molWeight"]
+    phi_i, phi_b = phi[:nIF], phi[nIF:]
+    bt = BCTable(case, g, ("U", "p", "T", "nuTilda", "nut"))
+    delta = g.bDeltaCoeffs
+    V = g.V
+    n_b = g.bnf
+
+    # ---- state BCs
+    Ub, UvIC, UvBC, UgIC, UgBC = bc_vector(bt.code["U"], bt.val["U"], U[bcell], delta, phi_b, n_b)
+    pb, pvIC, pvBC, pgIC, pgBC = bc_scalar(bt.code["p"], bt.val["p"], p[bcell], delta, phi_b)
+    Tb, TvIC, TvBC, TgIC, TgBC = bc_scalar(bt.code["T"], bt.val["T"], T[bcell], delta, phi_b)
+    nb, nvIC, nvBC, ngIC, ngBC = bc_scalar(bt.code["nuTilda"], bt.val["nuTilda"], nuT[bcell], delta, phi_b)
+    # ---- updateThermoVars
+    rho = p / (R * T)
+    rho_b = pb / (R * Tb)
+    he = Cp * (T - TREF)
+    heb, hvIC, hvBC, hgIC, hgBC = bc_scalar(bt.code["T"], Cp * (bt.val["T"] - TREF), he[bcell], delta, phi_b)
+    nu = mu / rho
+    nu_b = mu / rho_b
+    # ---- correctNut / correctAlphat
+    nut = nuT * fv1_of(nuT / nu)
+    nut_b = nb * fv1_of(nb / nu_b)
+    cn = bt.code["nut"]
+    nut_b = np.where(cn == NUT_LOWRE_WALL, 0.0 * nut_b, nut_b)
+    nut_b = np.where(cn == NUT_SYMMETRY, nut[bcell], nut_b)
+    wf = cn == NUT_SPALDING_WALL
+    if wf.any():
+        dU = U[bcell][wf] - Ub[wf]
+        magUp = np.sqrt((dU * dU).sum(1) + 0.0)
+        ywf = np.abs(((g.Cf[nIF:][wf] - g.C[bcell][wf]) * n_b[wf]).sum(1))
+        tmp = nut_b.astype(dt)
+        tmp[wf] = spalding_nut(magUp, magUp * delta[wf], ywf, nu_b[wf])
+        nut_b = tmp
+    muEff = rho * (nu + nut)  # rho*nuEff
+    muEff_b = rho_b * (nu_b + nut_b)
+    alphaEff = mu / Pr + rho * nut / Prt
+    alphaEff_b = mu / Pr + rho_b * nut_b / Prt
+
+    gradU = ops.grad_vector(U, Ub)
+    gradP = ops.grad_scalar(p, pb)
+    snGradU_b = UgIC * U[bcell] + UgBC
+    gUc = gradU[bcell]
+    ngU = np.einsum("fk,fkj->fj", n_b, gUc)
+    gradU_b = gUc + n_b[:, :, None] * (snGradU_b - ngU)[:, None, :]
+
+    # =================================================================== UEqn
+    wu = (np.real(phi_i) >= 0).astype(float)
+    lower = -wu * phi_i
+    upper = lower + phi_i
+    diag = sadd(oi, -lower, N) + sadd(ni, -upper, N)
+    sumPhi = ops.surface_sum(phi_i, phi_b)
+    diag = diag - sumPhi
+    iC = phi_b[:, None] * UvIC
+    bC = -phi_b[:, None] * UvBC
+    src = np.zeros((N, 3), dtype=dt)
+    if not isPC:
+        pos = np.real(phi_i) > 0
+        d_o, d_n = g.Cf[:nIF] - g.C[oi], g.Cf[:nIF] - g.C[ni]
+        c_o = np.einsum("fi,fij->fj", d_o, gradU[oi])
+        c_n = np.einsum("fi,fij->fj", d_n, gradU[ni])
+        wl = g.w[:, None]
+        corr = np.where(pos[:, None], c_o, c_n)
+        mx = np.where(pos[:, None], (1.0 - wl) * (U[ni] - U[oi]), wl * (U[oi] - U[ni]))
+        sfc, mxc = (corr * corr).sum(1), (corr * mx).sum(1)
+        scale = np.where(np.real(sfc) > 0, np.where(np.real(mxc) < 0, 0.0 * mxc, np.where(np.real(sfc) > np.real(mxc), mxc / (sfc + VSMALL), 1.0 + 0 * mxc)),
+                         1.0 + 0 * mxc)
+        fcorr = phi_i[:, None] * corr * scale[:, None]
+        src = src - (sadd(oi, fcorr, N) - sadd(ni, fcorr, N))
+    gam = ops.interp(muEff) * g.magSf[:nIF]
+    gam_b = muEff_b * g.bMagSf
+    cdiff = gam * g.nonOrthDeltaCoeffs
+    upper, lower = upper - cdiff, lower - cdiff
+    diag = diag + sadd(oi, cdiff, N) + sadd(ni, cdiff, N)
+    fcorrL = gam[:, None] * np.einsum("fi,fij->fj", g.nonOrthCorr, ops.interp(gradU))
+    src = src + (sadd(oi, fcorrL, N) - sadd(ni, fcorrL, N))
+    iC = iC - gam_b[:, None] * UgIC
+    bC = bC + gam_b[:, None] * UgBC
+    tau = muEff[:, None, None] * dev2T(gradU)
+    tau_b = muEff_b[:, None, None] * dev2T(gradU_b)
+    src = src + ops.surface_sum(np.einsum("fi,fij->fj", g.Sf[:nIF], ops.interp(tau)), np.einsum("fi,fij->fj", g.bSf, tau_b))
+    D0 = diag
+    sumOff = sadd(oi, _abs(upper), N) + sadd(ni, _abs(lower), N)
+    D = relax_diag(D0, sumOff, iC, bcell, case.relax["U"], N)
+    src = src + (D - D0)[:, None] * U
+    offU = sadd(oi, upper[:, None] * U[ni], N) + sadd(ni, lower[:, None] * U[oi], N)
+    bdiag = sadd(bcell, iC, N)
+    bsrc = sadd(bcell, bC, N)
+    URes = ((D[:, None] + bdiag) * U + offU - src - bsrc) / V[:, None] + gradP
+    avgb = bdiag.sum(1) / 3.0
+    A = (D + avgb) / V
+    H = ((avgb[:, None] - bdiag) * U - offU + src + bsrc) / V[:, None]
+    rAU = 1.0 / A
+    HbyA = rAU[:, None] * H
+
+    # =================================================================== EEqn (& he)
+    gradHe = ops.grad_scalar(he, heb)
+    loE = -wu * phi_i
+    upE = loE + phi_i
+    dE = sadd(oi, -loE, N) + sadd(ni, -upE, N) - sumPhi
+    iCe = phi_b * hvIC
+    bCe = -phi_b * hvBC
+    ga = ops.interp(alphaEff) * g.magSf[:nIF]
+    ga_b = alphaEff_b * g.bMagSf
+    cde = ga * g.nonOrthDeltaCoeffs
+    upE, loE = upE - cde, loE - cde
+    dE = dE + sadd(oi, cde, N) + sadd(ni, cde, N)
+    fce = ga * (g.nonOrthCorr * ops.interp(gradHe)).sum(1)
+    sE = sadd(oi, fce, N) - sadd(ni, fce, N)
+    iCe = iCe - ga_b * hgIC
+    bCe = bCe + ga_b * hgBC
+    # + fvc::div(phi, K), K = 0.5|U|^2, upwind face value
+    K = 0.5 * (U * U).sum(1)
+    Kb = 0.5 * (Ub * Ub).sum(1)
+    Kf = np.where(np.real(phi_i) >= 0, K[oi], K[ni])
+    sE = sE - ops.surface_sum(phi_i * Kf, phi_b * Kb)
+    offE = sadd(oi, upE * he[ni], N) + sadd(ni, loE * he[oi], N)
+    TRes = ((dE + sadd(bcell, iCe, N)) * he + offE - sE - sadd(bcell, bCe, N)) / V
+
+    # =================================================================== pEqn
+    cU = bt.code["U"]
+    HbyA_b = HbyA[bcell].copy()
+    symU = cU == BC_SYMMETRY
+    if symU.any():
+        hn = (HbyA_b[symU] * n_b[symU]).sum(1)[:, None]
+        HbyA_b[symU] = HbyA_b[symU] - n_b[symU] * hn
+    if use_constrain_hbya:
+        fx = cU == BC_FIXED_VALUE
+        HbyA_b[fx] = Ub[fx]
+    phiHbyA_i = ops.interp(rho) * (ops.interp(HbyA) * g.Sf[:nIF]).sum(1)
+    phiHbyA_b = rho_b * (HbyA_b * g.bSf).sum(1)
+    rr = rho * rAU
+    gp = ops.interp(rr) * g.magSf[:nIF]
+    gp_b = rho_b * rAU[bcell] * g.bMagSf
+    gradPf = ops.interp(gradP)
+    flux_i = gp * g.nonOrthDeltaCoeffs * (p[ni] - p[oi]) + gp * (g.nonOrthCorr * gradPf).sum(1)
+    flux_b = gp_b * (pgIC * p[bcell] + pgBC)
+    # pEqn = div(phiHbyA) - laplacian(rhorAUf, p);  pRes = pEqn & p
+    pRes = (ops.surface_sum(phiHbyA_i, phiHbyA_b) - ops.surface_sum(flux_i, flux_b)) / V
+    # phiRes = phiHbyA + pEqn.flux() - phi,  pEqn.flux() = -flux
+    phiRes = np.concatenate([phiHbyA_i - flux_i - phi_i, phiHbyA_b - flux_b - phi_b])
+
+    # =================================================================== SA (compressible form)
+    gradN = ops.grad_scalar(nuT, nb)
+    y = case.y_wall
+    k2y2 = (SA["kappa"] * y) ** 2
+    chi = nuT / nu
+    fv1 = fv1_of(chi)
+    skew = 0.5 * (gradU - np.swapaxes(gradU, 1, 2))
+    Omega = np.sqrt(2.0) * np.sqrt((skew * skew).sum((1, 2)) + 0.0)
+    fv2 = 1.0 - chi / (1.0 + chi * fv1)
+    Stilda = _max(Omega + fv2 * nuT / k2y2, SA["Cs"] * Omega)
+    r = _min(nuT / (_max(Stilda, SMALL + 0 * Stilda) * k2y2), 10.0 + 0 * Stilda)
+    gg = r + SA["Cw2"] * (r**6 - r)
+    fw = gg * ((1.0 + SA["Cw3"] ** 6) / (gg**6 + SA["Cw3"] ** 6)) ** (1.0 / 6.0)
+    lo = -wu * phi_i
+    up = lo + phi_i
+    dN = sadd(oi, -lo, N) + sadd(ni, -up, N) - sumPhi
+    iCn = phi_b * nvIC
+    bCn = -phi_b * nvBC
+    Dn = rho * (nuT + nu) / SA["sigmaNut"]
+    Dn_b = rho_b * (nb + nu_b) / SA["sigmaNut"]
+    gn = ops.interp(Dn) * g.magSf[:nIF]
+    gn_b = Dn_b * g.bMagSf
+    cd = gn * g.nonOrthDeltaCoeffs
+    up, lo = up - cd, lo - cd
+    dN = dN + sadd(oi, cd, N) + sadd(ni, cd, N)
+    fcn = gn * (g.nonOrthCorr * ops.interp(gradN)).sum(1)
+    sN = sadd(oi, fcn, N) - sadd(ni, fcn, N)
+    iCn = iCn - gn_b * ngIC
+    bCn = bCn + gn_b * ngBC
+    offN = sadd(oi, up * nuT[ni], N) + sadd(ni, lo * nuT[oi], N)
+    conv_diff = ((dN + sadd(bcell, iCn, N)) * nuT + offN - sN - sadd(bcell, bCn, N)) / V
+    nuTildaRes = (conv_diff - SA["Cb2"] / SA["sigmaNut"] * rho * (gradN * gradN).sum(1) - SA["Cb1"] * rho * Stilda * nuT
+                  + SA["Cw1"] * rho * fw * nuT / (y * y) * nuT)
+
+    if "URes" not in normalize:
+        URes = URes * V[:, None]
+    if "pRes" not in normalize:
+        pRes = pRes * V
+    if "TRes" not in normalize:
+        TRes = TRes * V
+    if "nuTildaRes" not in normalize:
+        nuTildaRes = nuTildaRes * V
+    if "phiRes" in normalize:
+        phiRes = phiRes / g.magSf
+    Rv = np.concatenate([URes.ravel(), pRes, TRes, nuTildaRes, phiRes])
+    if return_parts:
+        return Rv, dict(rho=rho, he=he, nut=nut, rAU=rAU, HbyA=HbyA, URes=URes, pRes=pRes, TRes=TRes, nuTildaRes=nuTildaRes, phiRes=phiRes)
+    return Rv

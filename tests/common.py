@@ -3,8 +3,18 @@ import numpy as np
 NORM_STATES = {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0}  # reference tests/runRegTests_AeroOpt.py:83
 
 
+NORM_STATES_RHO = {"U": 50.0, "p": 1.0e5, "T": 300.0, "nuTilda": 1e-3, "phi": 1.0}
+
+
+def norm_states(case):
+    return NORM_STATES_RHO if case.solver_name == "DARhoSimpleFoam" else dict(NORM_STATES, T=1.0)
+
+
 def blocks(case, g):
     N = g.nC
+    if case.solver_name == "DARhoSimpleFoam":
+        return (("U", slice(0, 3 * N)), ("p", slice(3 * N, 4 * N)), ("T", slice(4 * N, 5 * N)), ("nuTilda", slice(5 * N, 6 * N)),
+                ("phi", slice(6 * N, 6 * N + g.nF)))
     if case.solver_name == "DASimpleFoam":
         return (("U", slice(0, 3 * N)), ("p", slice(3 * N, 4 * N)), ("nuTilda", slice(4 * N, 5 * N)), ("phi", slice(5 * N, 5 * N + g.nF)))
     return (("T", slice(0, N)),)
@@ -15,6 +25,6 @@ def relerr(a, b):
 
 
 def options(case, **extra):
-    o = {"solverName": case.solver_name, "normalizeStates": dict(NORM_STATES, T=1.0), "adjEqnOption": {"printInfo": 0}}
+    o = {"solverName": case.solver_name, "normalizeStates": dict(norm_states(case)), "adjEqnOption": {"printInfo": 0}}
     o.update(extra)
     return o

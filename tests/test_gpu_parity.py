@@ -7,8 +7,8 @@ import numpy as np
 import pytest
 import scipy.sparse.linalg as spla
 
-from common import NORM_STATES, blocks, options, relerr
-from dafoam_amd.meshgen import bench_channel_case, channel_case, renumber_case, scalar_transport_case
+from common import NORM_STATES, blocks, norm_states, options, relerr
+from dafoam_amd.meshgen import bench_channel_case, channel_case, renumber_case, rho_channel_case, scalar_transport_case
 from oracle import jacobian as J
 from oracle import linear as OL
 from oracle.foam_mesh import Geometry
@@ -44,7 +44,7 @@ def converged_case(dims, wall_function=False, **kw):
 
 
 def oracle_mats(case, g, pc_mode="fd"):
-    sc = J.state_scales(case, g, dict(NORM_STATES, T=1.0))
+    sc = J.state_scales(case, g, norm_states(case))
     con = J.connectivity(case, g)
     col, _ = J.greedy_coloring(con)
     A = J.jacobian_colored(case, g, case.states, con, col, sc, mode="cs", lower_bound=0)
@@ -86,6 +86,42 @@ def test_unstructured_renumbering_gpu():
     assert np.abs(R).max() < 1e-6 and relerr(R, residual(case, g, case.states)) < 1e-6
     sc, con, col, A = oracle_mats(case, g)
     D.solver.runColoring()
+    M = Mat()
+    D.solver.calcdRdWT(0, M, mode=1)
+    assert np.abs((M.to_scipy() - A).tocsr().data).max() <= 1e-10 * np.abs(A.data).max()
+    rhs = np.zeros(A.shape[0])
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= sc
+    psi, fail = D.solveAdjoint(rhs)
+    assert fail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-6
+
+
+@pytest.mark.parametrize("wall_function", [False, True])
+def test_rhosimplefoam_residual_jacobian_adjoint(wall_function):
+    """DARhoSimpleFoam + SA (compressible, BASELINE configs[3] solver): residual (PC and non-PC), dual-number dRdWT and
+    the adjoint vector at a converged primal state against the oracle."""
+    from dafoam_amd.pyDASolvers import Mat
+    from oracle.primal import solve_primal
+
+    case = rho_channel_case(8, 6, 5, wall_function=wall_function, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    # synthetic state first: residual parity away from R = 0
+    syn = rho_channel_case(8, 6, 5, wall_function=wall_function, lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.02)
+    Ds = make(syn)
+    R = np.zeros(syn.states.size)
+    for pc in (0, 1):
+        Ds.solver.calcResiduals(pc, R)
+        Ro = residual(syn, g, syn.states, isPC=bool(pc))
+        for nm, sl in blocks(syn, g):
+            assert relerr(R[sl], Ro[sl]) < 1e-11, (pc, nm)
+    W, hist = solve_primal(case, g, max_iters=800, tol=1e-11)
+    case.states = W
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0}, jacLowerBounds={"dRdW": 0.0, "dRdWPC": 0.0})
+    D.solver.getResiduals(R)
+    assert relerr(R, residual(case, g, W)) < 1e-5 or np.abs(R).max() < 1e-3  # both ~0 at the fixed point
+    sc, con, col, A = oracle_mats(case, g)
+    D.solver.runColoring()
+    assert (D.solver.getConnectivity(0) != con).nnz == 0
     M = Mat()
     D.solver.calcdRdWT(0, M, mode=1)
     assert np.abs((M.to_scipy() - A).tocsr().data).max() <= 1e-10 * np.abs(A.data).max()

@@ -8,10 +8,10 @@ import re
 import numpy as np
 import pytest
 
-from common import NORM_STATES, blocks, options, relerr
+from common import NORM_STATES, NORM_STATES_RHO, blocks, options, relerr
 from dafoam_amd import _capi
 from dafoam_amd._capi import CaseStruct, das_case_t, dptr
-from dafoam_amd.meshgen import channel_case, renumber_case, scalar_transport_case
+from dafoam_amd.meshgen import channel_case, renumber_case, rho_channel_case, scalar_transport_case
 from dafoam_amd.pyDASolvers import pyDASolvers
 from oracle import jacobian as J
 from oracle.foam_mesh import Geometry
@@ -42,9 +42,10 @@ def test_compute_path_fails_loudly_without_gpu():
         s.getResiduals(np.zeros(s.getNLocalAdjointStates()))
 
 
-@pytest.mark.parametrize("solver", ["DASimpleFoam", "DAScalarTransportFoam"])
+@pytest.mark.parametrize("solver", ["DASimpleFoam", "DAScalarTransportFoam", "DARhoSimpleFoam"])
 def test_mesh_metrics_connectivity_and_colouring_match_oracle(solver):
-    case = channel_case(7, 6, 5) if solver == "DASimpleFoam" else scalar_transport_case(6, 5, 4)
+    case = {"DASimpleFoam": lambda: channel_case(7, 6, 5), "DAScalarTransportFoam": lambda: scalar_transport_case(6, 5, 4),
+            "DARhoSimpleFoam": lambda: rho_channel_case(6, 5, 4)}[solver]()
     s = pyDASolvers((solver + " -python").encode(), options(case), case=case)
     g = Geometry(case.mesh)
     geo = s.geometry()
@@ -185,3 +186,21 @@ def test_petsc_binary_io_roundtrip_and_layout(tmp_path):
     assert not pio.vecdiff(pv, tmp_path / "w.bin", verbose=False)
     with pytest.raises(ValueError):
         pio.read_mat(pv)
+
+
+@pytest.mark.parametrize("wall_function", [False, True])
+@pytest.mark.parametrize("isPC", [0, 1])
+def test_kernel_bodies_match_oracle_rhosimplefoam(wall_function, isPC):
+    """DARhoSimpleFoam (compressible) kernel bodies vs oracle/residual_rho.py: values and dual tangents."""
+    case = rho_channel_case(7, 6, 5, wall_function=wall_function, perturb=0.02)
+    g = Geometry(case.mesh)
+    W = case.states
+    Ro = residual(case, g, W, isPC=bool(isPC))
+    Rv, _ = _emu_res(case, W, isPC)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rv[sl], Ro[sl]) < 1e-11, nm
+    v = np.random.default_rng(3).standard_normal(W.size) * J.state_scales(case, g, NORM_STATES_RHO)
+    cs = residual(case, g, W + 1j * 1e-30 * v, isPC=bool(isPC)).imag / 1e-30
+    _, Rd = _emu_res(case, W, isPC, v)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rd[sl], cs[sl]) < 1e-10, nm

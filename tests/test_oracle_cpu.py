@@ -5,7 +5,7 @@ import pytest
 import scipy.sparse.linalg as spla
 
 from common import NORM_STATES, blocks, relerr
-from dafoam_amd.meshgen import channel_case, scalar_transport_case
+from dafoam_amd.meshgen import channel_case, rho_channel_case, scalar_transport_case
 from oracle import jacobian as J
 from oracle import linear as OL
 from oracle.foam_mesh import Geometry
@@ -58,12 +58,15 @@ def test_stencil_row_lengths_match_reference_tables():
         assert (rl[3 * c], rl[3 * N + c], rl[4 * N + c], rl[5 * N + f]) == want
 
 
-@pytest.mark.parametrize("solver", ["DASimpleFoam", "DAScalarTransportFoam"])
+@pytest.mark.parametrize("solver", ["DASimpleFoam", "DAScalarTransportFoam", "DARhoSimpleFoam"])
 def test_bruteforce_jacobian_inside_stencil_and_equals_coloured(solver):
-    case = channel_case(4, 4, 3) if solver == "DASimpleFoam" else scalar_transport_case(5, 4, 3)
+    case = {"DASimpleFoam": lambda: channel_case(4, 4, 3), "DAScalarTransportFoam": lambda: scalar_transport_case(5, 4, 3),
+            "DARhoSimpleFoam": lambda: rho_channel_case(4, 4, 3, perturb=0.02)}[solver]()
     g = Geometry(case.mesh)
     W = case.states
-    sc = J.state_scales(case, g, dict(NORM_STATES, T=1.0))
+    from common import norm_states
+
+    sc = J.state_scales(case, g, norm_states(case))
     con = J.connectivity(case, g)
     A_bf = J.jacobian_bruteforce(case, g, W, sc)
     pat = con.T.toarray() > 0
@@ -140,3 +143,15 @@ def test_golden_fixture_regression():
     assert relerr(case.states, z["W"]) < 1e-15
     assert relerr(residual(case, g, case.states), z["R"]) < 1e-13
     assert relerr(residual(case, g, case.states, isPC=True), z["R_pc"]) < 1e-13
+
+
+def test_primal_fixed_point_is_residual_zero():
+    """The oracle's SIMPLE loops (oracle/primal.py) converge to R(W*) = 0 for the residual definitions of
+    DAResidualSimpleFoam.C:106-237 / DAResidualRhoSimpleFoam.C:84-211 (pin (ii))."""
+    from oracle.primal import solve_primal
+
+    for case in (channel_case(8, 6, 5, perturb=0.0, lengths=(1.0, 0.2, 0.2), grading_y=2.0),
+                 rho_channel_case(8, 6, 5, lengths=(1.0, 0.2, 0.2), grading_y=2.0)):
+        g = Geometry(case.mesh)
+        W, hist = solve_primal(case, g, max_iters=800, tol=1e-10)
+        assert np.all(hist[-1] < 1e-8 * hist[0]), (case.solver_name, hist[-1] / hist[0])
