@@ -83,7 +83,7 @@ def test_unstructured_renumbering_gpu():
     D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0}, jacLowerBounds={"dRdW": 0.0, "dRdWPC": 0.0}, amd={"pcBlockCells": 100})
     R = np.zeros(case.states.size)
     D.solver.getResiduals(R)
-    assert np.abs(R).max() < 1e-6 and relerr(R, residual(case, g, case.states)) < 1e-6
+    assert np.abs(R).max() < 1e-6 and np.abs(R - residual(case, g, case.states)).max() < 1e-9  # both ~0 at the fixed point
     sc, con, col, A = oracle_mats(case, g)
     D.solver.runColoring()
     M = Mat()
@@ -118,7 +118,7 @@ def test_rhosimplefoam_residual_jacobian_adjoint(wall_function):
     case.states = W
     D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0}, jacLowerBounds={"dRdW": 0.0, "dRdWPC": 0.0})
     D.solver.getResiduals(R)
-    assert relerr(R, residual(case, g, W)) < 1e-5 or np.abs(R).max() < 1e-3  # both ~0 at the fixed point
+    assert np.abs(R - residual(case, g, W)).max() < 1e-6 * np.abs(residual(syn, g, syn.states)).max()  # both ~0 at the fixed point
     sc, con, col, A = oracle_mats(case, g)
     D.solver.runColoring()
     assert (D.solver.getConnectivity(0) != con).nnz == 0
