@@ -716,6 +716,11 @@ struct BlockFactor {
     std::vector<int> Lrows, Urows;
     std::vector<long long> Llev, Ulev;   // local level pointers (into Lrows/Urows)
     int nshift = 0;
+    long long nnzLU = 0;
+    // level-sorted entry streams (built inside the parallel block loop), [0] = L, [1] = U
+    std::vector<double> sval[2], invd;
+    std::vector<unsigned> src[2];
+    std::vector<long long> slev[2];      // block-relative level pointers, levels split into <= PC_THREADS entries
 };
 
 // symbolic ILU(k) by level of fill on a sorted local CSR pattern (Saad, Alg. 10.5 structure)
@@ -742,33 +747,43 @@ static void ilu_symbolic(int nl, const std::vector<long long>& rp, const std::ve
     }
     std::vector<int> flev;  // level of each stored entry
     std::vector<int> wlev(nl, -1), list;
+    std::vector<int> heap;  // min-heap of pending pivot columns (< i)
     fci.reserve(ci.size() * 3);
     flev.reserve(ci.size() * 3);
+    auto cmp = [](int a, int b) { return a > b; };
     for (int i = 0; i < nl; i++) {
         list.clear();
+        heap.clear();
         bool hasd = false;
         for (long long q = rp[i]; q < rp[i + 1]; q++) {
             int j = ci[q];
-            if (wlev[j] < 0) { wlev[j] = 0; list.push_back(j); }
+            if (wlev[j] < 0) {
+                wlev[j] = 0;
+                list.push_back(j);
+                if (j < i) heap.push_back(j);
+            }
             if (j == i) hasd = true;
         }
         if (!hasd) { wlev[i] = 0; list.push_back(i); }
-        std::sort(list.begin(), list.end());
-        size_t pos = 0;
-        while (pos < list.size() && list[pos] < i) {
-            int k = list[pos];
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        // pivots in increasing column order; fill created by pivot k only has columns > k, so a heap suffices
+        while (!heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), cmp);
+            int k = heap.back();
+            heap.pop_back();
             int lk = wlev[k];
-            bool added = false;
             for (long long q = fdiag[k] + 1; q < frp[k + 1]; q++) {
                 int j = fci[q];
                 int nlv = lk + flev[q] + 1;
                 if (nlv > lfill) continue;
-                if (wlev[j] < 0) { wlev[j] = nlv; list.push_back(j); added = true; }
-                else if (nlv < wlev[j]) wlev[j] = nlv;
+                if (wlev[j] < 0) {
+                    wlev[j] = nlv;
+                    list.push_back(j);
+                    if (j < i) { heap.push_back(j); std::push_heap(heap.begin(), heap.end(), cmp); }
+                } else if (nlv < wlev[j]) wlev[j] = nlv;
             }
-            if (added) std::sort(list.begin() + pos + 1, list.end());
-            pos++;
         }
+        std::sort(list.begin(), list.end());
         for (int j : list) {
             if (j == i) fdiag[i] = (long long)fci.size();
             fci.push_back(j);
@@ -839,6 +854,7 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
 
     std::vector<BlockFactor> BF(nB);
     std::string err;
+    const double t_prep = wall_seconds();
 #pragma omp parallel
     {
         std::vector<int> cmark(m.nC, -1);
@@ -958,6 +974,37 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
                 };
                 schedule(true, F.Lrows, F.Llev);
                 schedule(false, F.Urows, F.Ulev);
+                // entry streams sorted by (level, row); levels split into pieces of <= PC_THREADS entries (one entry per
+                // thread per level in the kernel); U rows pre-divided by the pivot
+                DAS_CHECK(nl <= 65535, DAS_ERR_ARG, "preconditioner block larger than 65535 unknowns: reduce amd.pcBlockCells");
+                F.invd.resize(nl);
+                for (int i = 0; i < nl; i++) F.invd[i] = 1.0 / F.fv[F.fdiag[i]];
+                for (int t = 0; t < 2; t++) {
+                    const std::vector<long long>& lv = t == 0 ? F.Llev : F.Ulev;
+                    const std::vector<int>& rows = t == 0 ? F.Lrows : F.Urows;
+                    F.sval[t].reserve(F.fci.size() / 2 + 16);
+                    F.src[t].reserve(F.fci.size() / 2 + 16);
+                    for (size_t l = 0; l + 1 < lv.size(); l++) {
+                        F.slev[t].push_back((long long)F.sval[t].size());
+                        long long inLevel = 0;
+                        for (long long r = lv[l]; r < lv[l + 1]; r++) {
+                            const int i = rows[r];
+                            const long long q0 = t == 0 ? F.frp[i] : F.fdiag[i] + 1;
+                            const long long q1 = t == 0 ? F.fdiag[i] : F.frp[i + 1];
+                            const double scale = t == 0 ? 1.0 : F.invd[i];
+                            for (long long q = q0; q < q1; q++) {
+                                if (inLevel == PC_THREADS) { F.slev[t].push_back((long long)F.sval[t].size()); inLevel = 0; }
+                                F.sval[t].push_back(F.fv[q] * scale);
+                                F.src[t].push_back((unsigned)i | ((unsigned)F.fci[q] << 16));
+                                inLevel++;
+                            }
+                        }
+                    }
+                    F.slev[t].push_back((long long)F.sval[t].size());
+                }
+                F.nnzLU = (long long)F.fci.size();
+                std::vector<long long>().swap(F.frp); std::vector<long long>().swap(F.fdiag); std::vector<int>().swap(F.fci);
+                std::vector<double>().swap(F.fv); std::vector<int>().swap(F.Lrows); std::vector<int>().swap(F.Urows);
             } catch (const std::exception& e) {
 #pragma omp critical
                 err = e.what();
@@ -965,68 +1012,51 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
         }
     }
     DAS_CHECK(err.empty(), DAS_ERR_INTERNAL, "block ILU setup failed: " + err);
-    // concatenate into per-block entry streams sorted by (level, row)
+    const double t_fact = wall_seconds();
+    // concatenate the per-block streams (offsets by prefix sums, copies in parallel)
     BlockILU& P = k->pc;
-    std::vector<long long> boff(nB + 1, 0), slev[2], slevOff[2];
-    std::vector<int> gidx, gout;
-    std::vector<double> invd, sval[2];
-    std::vector<unsigned> src[2];
+    std::vector<long long> boff(nB + 1, 0), eoff[2], loff[2], slev[2], slevOff[2];
     long long next = 0, fnnz = 0;
     int maxLocal = 0, maxLv = 0, nshift = 0;
-    for (int b = 0; b < nB; b++) { next += (long long)BF[b].gidx.size(); fnnz += (long long)BF[b].fci.size(); }
-    gidx.reserve(next); gout.reserve(next); invd.reserve(next);
-    for (int t = 0; t < 2; t++) { sval[t].reserve(fnnz / 2 + 16); src[t].reserve(fnnz / 2 + 16); slevOff[t].assign(nB + 1, 0); }
-    P.h_core_perm.clear();
+    for (int t = 0; t < 2; t++) { eoff[t].assign(nB + 1, 0); loff[t].assign(nB + 1, 0); }
     P.h_core_off.assign(1, 0);
     for (int b = 0; b < nB; b++) {
-        BlockFactor& F = BF[b];
+        const BlockFactor& F = BF[b];
         const int nl = (int)F.gidx.size();
-        DAS_CHECK(nl <= 65535, DAS_ERR_ARG, "preconditioner block larger than 65535 unknowns: reduce amd.pcBlockCells");
+        boff[b + 1] = boff[b] + nl;
         maxLocal = std::max(maxLocal, nl);
         nshift += F.nshift;
-        gidx.insert(gidx.end(), F.gidx.begin(), F.gidx.end());
-        gout.insert(gout.end(), F.gout.begin(), F.gout.end());
-        for (int g : F.gout) if (g >= 0) P.h_core_perm.push_back(g);
-        P.h_core_off.push_back((long long)P.h_core_perm.size());
-        for (int i = 0; i < nl; i++) invd.push_back(1.0 / F.fv[F.fdiag[i]]);
-        // L stream
-        // (levels are split into pieces of <= PC_THREADS entries: one entry per thread per level in the kernel)
-        auto push_entry = [&](int t, double v, unsigned rc, long long& inLevel) {
-            if (inLevel == PC_THREADS) { slev[t].push_back((long long)sval[t].size()); inLevel = 0; }
-            sval[t].push_back(v);
-            src[t].push_back(rc);
-            inLevel++;
-        };
-        int nLv[2] = {0, 0};
-        slevOff[0][b] = (long long)slev[0].size();
-        for (size_t l = 0; l + 1 < F.Llev.size(); l++) {
-            slev[0].push_back((long long)sval[0].size());
-            long long inLevel = 0;
-            for (long long r = F.Llev[l]; r < F.Llev[l + 1]; r++) {
-                int i = F.Lrows[r];
-                for (long long q = F.frp[i]; q < F.fdiag[i]; q++) push_entry(0, F.fv[q], (unsigned)i | ((unsigned)F.fci[q] << 16), inLevel);
-            }
+        fnnz += F.nnzLU;
+        long long ncore = 0;
+        for (int g : F.gout) ncore += g >= 0 ? 1 : 0;
+        P.h_core_off.push_back(P.h_core_off.back() + ncore);
+        for (int t = 0; t < 2; t++) {
+            eoff[t][b + 1] = eoff[t][b] + (long long)F.sval[t].size();
+            loff[t][b + 1] = loff[t][b] + (long long)F.slev[t].size();
+            maxLv = std::max<int>(maxLv, (int)F.slev[t].size() - 1);
         }
-        slev[0].push_back((long long)sval[0].size());
-        nLv[0] = (int)(slev[0].size() - slevOff[0][b]) - 1;
-        // U stream (rows pre-divided by the pivot)
-        slevOff[1][b] = (long long)slev[1].size();
-        for (size_t l = 0; l + 1 < F.Ulev.size(); l++) {
-            slev[1].push_back((long long)sval[1].size());
-            long long inLevel = 0;
-            for (long long r = F.Ulev[l]; r < F.Ulev[l + 1]; r++) {
-                int i = F.Urows[r];
-                const double idg = 1.0 / F.fv[F.fdiag[i]];
-                for (long long q = F.fdiag[i] + 1; q < F.frp[i + 1]; q++) push_entry(1, F.fv[q] * idg, (unsigned)i | ((unsigned)F.fci[q] << 16), inLevel);
-            }
-        }
-        slev[1].push_back((long long)sval[1].size());
-        nLv[1] = (int)(slev[1].size() - slevOff[1][b]) - 1;
-        maxLv = std::max<int>(maxLv, std::max(nLv[0], nLv[1]));
-        boff[b + 1] = boff[b] + nl;
-        F = BlockFactor();  // free
     }
-    for (int t = 0; t < 2; t++) slevOff[t][nB] = (long long)slev[t].size();
+    next = boff[nB];
+    std::vector<int> gidx(next), gout(next);
+    std::vector<double> invd(next), sval[2];
+    std::vector<unsigned> src[2];
+    P.h_core_perm.assign(P.h_core_off.back(), 0);
+    for (int t = 0; t < 2; t++) { sval[t].resize(eoff[t][nB]); src[t].resize(eoff[t][nB]); slev[t].resize(loff[t][nB]); slevOff[t] = loff[t]; }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < nB; b++) {
+        BlockFactor& F = BF[b];
+        std::copy(F.gidx.begin(), F.gidx.end(), gidx.begin() + boff[b]);
+        std::copy(F.gout.begin(), F.gout.end(), gout.begin() + boff[b]);
+        std::copy(F.invd.begin(), F.invd.end(), invd.begin() + boff[b]);
+        long long pc = P.h_core_off[b];
+        for (int g : F.gout) if (g >= 0) P.h_core_perm[pc++] = g;
+        for (int t = 0; t < 2; t++) {
+            std::copy(F.sval[t].begin(), F.sval[t].end(), sval[t].begin() + eoff[t][b]);
+            std::copy(F.src[t].begin(), F.src[t].end(), src[t].begin() + eoff[t][b]);
+            for (size_t q = 0; q < F.slev[t].size(); q++) slev[t][loff[t][b] + q] = eoff[t][b] + F.slev[t][q];
+        }
+        F = BlockFactor();
+    }
     DAS_CHECK((long long)P.h_core_perm.size() == nOwnedStates, DAS_ERR_INTERNAL, "block cores do not cover all owned states exactly once");
     P.n = n; P.next = next; P.nBlocks = nB; P.fnnz = fnnz; P.maxLevels = maxLv; P.maxLocal = maxLocal;
     P.boff.upload(boff); P.gidx.upload(gidx); P.gout.upload(gout); P.invd.upload(invd);
@@ -1054,8 +1084,9 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     P.setup_seconds = wall_seconds() - t0;
     if (s->opt.geti("debug"))
         fprintf(stderr, "[dafoam_amd] RAS(overlap %d)+ILU(%d): %d blocks, n_ext=%lld (%.2fx), nnz(LU)=%lld, max block %d unknowns (%s), max levels %d, "
-                        "%d shifted pivots, %.2f s\n", overlap, lfill, nB, next, (double)next / n, fnnz, maxLocal, P.useLDS ? "LDS" : "global", maxLv, nshift,
-                P.setup_seconds);
+                        "%d shifted pivots, %.2f s (download+partition %.2f, factorise %.2f, streams+upload %.2f)\n", overlap, lfill, nB, next,
+                (double)next / n, fnnz, maxLocal, P.useLDS ? "LDS" : "global", maxLv, nshift, P.setup_seconds, t_prep - t0, t_fact - t_prep,
+                wall_seconds() - t_fact);
 }
 
 static void pc_apply(das_solver* s, das_ksp* k, const double* b, double* x) {
