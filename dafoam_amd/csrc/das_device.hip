@@ -44,6 +44,43 @@ __global__ __launch_bounds__(256) void k_pres(DevMesh m, ResParams prm, const T*
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_pres<T, RHO>(c, m, prm, q, R);
 }
+// force objective: value (atomic sum) and coloured dual-number gradient scatter
+template <bool RHO>
+__global__ __launch_bounds__(256) void k_force_value(DevMesh m, ResParams prm, const double* __restrict__ W, const double* nut, const double* gU,
+                                                     const int* __restrict__ faces, int nfaces, double d0, double d1, double d2, double scale, double* out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nfaces) return;
+    double dir[3] = {d0, d1, d2};
+    double v = body_force<double, RHO>(faces[k], m, prm, W, nut, gU, dir, scale);
+    atomicAdd(out, v);
+}
+// the derivative of F_f w.r.t. the (unique) state of colour `col` in the stencil of face f (cell c and its face
+// neighbours: U, p, (T), nuTilda) is accumulated into dFdW
+template <bool RHO>
+__global__ __launch_bounds__(256) void k_force_grad(DevMesh m, ResParams prm, const Dual<1>* __restrict__ W, const Dual<1>* nut, const Dual<1>* gU,
+                                                    const int* __restrict__ faces, int nfaces, double d0, double d1, double d2, double scale,
+                                                    const int* __restrict__ colors, int col, double* dFdW) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nfaces) return;
+    double dir[3] = {d0, d1, d2};
+    const int f = faces[k];
+    Dual<1> v = body_force<Dual<1>, RHO>(f, m, prm, W, nut, gU, dir, scale);
+    if (v.d[0] == 0.0) return;
+    const long long N = m.nC;
+    const int c = m.owner[f];
+    const int nsc = RHO ? 3 : 2;  // scalar cell blocks after U
+    auto try_cell = [&](int x) -> bool {
+        for (int q = 0; q < 3; q++) if (colors[3LL * x + q] == col) { atomicAdd(&dFdW[3LL * x + q], v.d[0]); return true; }
+        for (int b = 0; b < nsc; b++) if (colors[(3 + b) * N + x] == col) { atomicAdd(&dFdW[(3 + b) * N + x], v.d[0]); return true; }
+        return false;
+    };
+    if (try_cell(c)) return;
+    for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
+        int o = m.cf_other[s];
+        if (o >= 0 && try_cell(o)) return;
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_gradT(DevMesh m, ResParams prm, const T* __restrict__ W, const double* phiF, T* gT) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -545,6 +582,8 @@ struct das_solver {
     DevBuf<Dual<1>> d_Wd, d_Rd;
     ConDev cd[2];
     std::unique_ptr<das_mat> op;  // matrix-free operator (dual-number assembled dRdW^T)
+    struct ForceFn { std::vector<int> faces; double dir[3]; double scale; DevBuf<int> d_faces; };
+    std::map<std::string, ForceFn> functions;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<unsigned char> owned;  // per state; empty = single-domain
@@ -1499,6 +1538,81 @@ int das_destroy_drdwt_matrix_free(das_solver_t* s) {
     DAS_CATCH
 }
 
+// ---- objective functions (reference "function" option dict, DAFunctionForce) ------------------------------------------
+int das_define_force_function(das_solver_t* s, const char* name, const int* patch_ids, int npatch, const double* direction, double scale) {
+    DAS_TRY
+    DAS_CHECK(s && name && patch_ids && direction && npatch > 0, DAS_ERR_ARG, "bad argument");
+    DAS_CHECK(s->cp.solver == DAS_SOLVER_SIMPLEFOAM || s->cp.solver == DAS_SOLVER_RHOSIMPLEFOAM, DAS_ERR_ARG, "force needs a flow solver");
+    double mag = std::sqrt(direction[0] * direction[0] + direction[1] * direction[1] + direction[2] * direction[2]);
+    DAS_CHECK(std::fabs(mag - 1.0) <= 1.0e-8, DAS_ERR_ARG, std::string("the magnitude of the direction parameter in ") + name + " is not 1.0!");
+    das_solver::ForceFn& fn = s->functions[name];
+    fn.faces.clear();
+    for (int k = 0; k < npatch; k++) {
+        int p = patch_ids[k];
+        DAS_CHECK(p >= 0 && p < s->mesh.nPatch, DAS_ERR_ARG, "patch id out of range");
+        for (int q = 0; q < s->mesh.patch_size[p]; q++) fn.faces.push_back(s->mesh.patch_start[p] + q);
+    }
+    for (int k = 0; k < 3; k++) fn.dir[k] = direction[k];
+    fn.scale = scale;
+    if (s->inited) fn.d_faces.upload(fn.faces);
+    return DAS_OK;
+    DAS_CATCH
+}
+static das_solver::ForceFn& get_function(das_solver* s, const char* name) {
+    auto it = s->functions.find(name ? name : "");
+    DAS_CHECK(it != s->functions.end(), DAS_ERR_ARG, std::string("function not defined: ") + (name ? name : "(null)"));
+    if (it->second.d_faces.n != it->second.faces.size()) it->second.d_faces.upload(it->second.faces);
+    return it->second;
+}
+int das_calc_function(das_solver_t* s, const char* name, double* value) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(value, DAS_ERR_ARG, "null output");
+    das_solver::ForceFn& fn = get_function(s, name);
+    ResParams prm = make_params(s->cp, s->opt, 0);
+    const bool rho = s->cp.solver == DAS_SOLVER_RHOSIMPLEFOAM;
+    s->wk.ensure(s->cp.solver, s->dm.nC, s->dm.nF);
+    const int B = 256, nf = (int)fn.faces.size();
+    DAS_HIP(hipMemsetAsync(s->d_tmp1.p, 0, sizeof(double), s->stream));
+    if (rho) {
+        hipLaunchKernelGGL((k_grad<double, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
+        hipLaunchKernelGGL((k_force_value<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale, s->d_tmp1.p);
+    } else {
+        hipLaunchKernelGGL((k_grad<double, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, (double*)nullptr);
+        hipLaunchKernelGGL((k_force_value<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale, s->d_tmp1.p);
+    }
+    DAS_HIP(hipMemcpyAsync(value, s->d_tmp1.p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    DAS_HIP(hipStreamSynchronize(s->stream));
+    return DAS_OK;
+    DAS_CATCH
+}
+// product_j = seed * s_j dF/dW_j : coloured forward-mode gradient of the objective (one k_grad + one k_force per colour)
+static void function_gradient(das_solver* s, const char* name, double seed, double* product) {
+    need_init(s);
+    das_solver::ForceFn& fn = get_function(s, name);
+    ensure_con_dev(s, 0);
+    ResParams prm = make_params(s->cp, s->opt, 0);
+    const bool rho = s->cp.solver == DAS_SOLVER_RHOSIMPLEFOAM;
+    const long long n = s->n;
+    if (s->d_Wd.n != (size_t)n) { s->d_Wd.alloc(n); s->d_Rd.alloc(n); }
+    s->wk1.ensure(s->cp.solver, s->dm.nC, s->dm.nF);
+    DAS_HIP(hipMemsetAsync(s->d_tmp2.p, 0, n * sizeof(double), s->stream));
+    const int B = 256, nf = (int)fn.faces.size();
+    for (int col = 0; col < s->nColors; col++) {
+        hipLaunchKernelGGL(k_seed<1>, dim3(nblk(n, B)), dim3(B), 0, s->stream, n, s->d_W.p, s->d_colors.p, s->d_scale.p, col, s->d_Wd.p);
+        if (rho) {
+            hipLaunchKernelGGL((k_grad<Dual<1>, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
+            hipLaunchKernelGGL((k_force_grad<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale * seed, s->d_colors.p, col, s->d_tmp2.p);
+        } else {
+            hipLaunchKernelGGL((k_grad<Dual<1>, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, (Dual<1>*)nullptr);
+            hipLaunchKernelGGL((k_force_grad<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale * seed, s->d_colors.p, col, s->d_tmp2.p);
+        }
+    }
+    DAS_HIP(hipGetLastError());
+    DAS_HIP(hipMemcpyAsync(product, s->d_tmp2.p, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    DAS_HIP(hipStreamSynchronize(s->stream));
+}
+
 long long das_op_nnz(das_solver_t* s) { return (s && s->op) ? s->op->m.nnz : -1; }
 
 int das_get_input_size(das_solver_t* s, const char* inputName, const char* inputType) {
@@ -1511,6 +1625,7 @@ int das_get_input_size(das_solver_t* s, const char* inputName, const char* input
 int das_get_output_size(das_solver_t* s, const char* outputName, const char* outputType) {
     DAS_TRY
     DAS_CHECK(s && outputType, DAS_ERR_ARG, "null argument");
+    if (std::string(outputType) == "function") return 1;
     DAS_CHECK(std::string(outputType) == "residual", DAS_ERR_ARG, std::string("outputType not supported on this path: ") + outputType);
     return (int)s->n;
     DAS_CATCH
@@ -1520,8 +1635,16 @@ int das_calc_jac_t_vec_product(das_solver_t* s, const char* inputName, const cha
     DAS_TRY
     need_init(s);
     DAS_CHECK(inputType && outputType && inputs && seeds && product, DAS_ERR_ARG, "null argument");
-    DAS_CHECK(std::string(inputType) == "stateVar" && std::string(outputType) == "residual", DAS_ERR_ARG,
-              "calcJacTVecProduct: only (stateVar -> residual) is implemented on the GPU path");
+    DAS_CHECK(std::string(inputType) == "stateVar", DAS_ERR_ARG, "calcJacTVecProduct: only stateVar inputs are implemented on the GPU path");
+    if (std::string(outputType) == "function") {
+        // dFdW^T * seed, state-scaled (reference DASolver.C:1690-1839 with DAOutputFunction, normalizeJacTVecProduct :1443-1553)
+        s->h_W.assign(inputs, inputs + s->n);
+        s->d_W.upload(s->h_W);
+        function_gradient(s, outputName, seeds[0], product);
+        return DAS_OK;
+    }
+    DAS_CHECK(std::string(outputType) == "residual", DAS_ERR_ARG,
+              "calcJacTVecProduct: only (stateVar -> residual | function) is implemented on the GPU path");
     // DAInputStateVar::run assigns the inputs to the states (reference DASolver.C:1690-1839)
     s->h_W.assign(inputs, inputs + s->n);
     s->d_W.upload(s->h_W);

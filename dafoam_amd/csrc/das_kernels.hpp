@@ -564,6 +564,48 @@ DAS_HD void body_pres(int c, const DevMesh& m, const ResParams& prm, const T* q,
     R[prm.offP * N + c] = s;
 }
 
+// ================================================================================ force objective
+// DAFunctionForce::calcFunction (reference src/adjoint/DAFunction/DAFunctionForce.C:79-158) for one boundary face:
+//   F_f = scale * ( S_f p_b + S_f . devRhoReff_b ) . dir,  devRhoReff = (-rho nuEff) dev(twoSymm(grad U))
+//   (reference DATurbulenceModel.C:360-376), boundary field from the boundary values of nuEff, rho and grad(U).
+template <class T, bool RHO>
+DAS_HD T body_force(int f, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const double* dir, double scale) {
+    const long long N = m.nC;
+    const FaceGeom& g = m.fg[f];
+    const int c = m.owner[f];
+    T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
+    T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
+    T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
+    BFace<T> b;
+    eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, m.cg[c], prm, Uc, pc, Tc, nc, nut[c], val(W[prm.offPhi * N + f]), b);
+    T gUb[9], dsn[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        T snG = b.U.gic[j] * Uc[j] + b.U.gbc[j];
+        T ngU = b.nrm[0] * gradU[9LL * c + j] + b.nrm[1] * gradU[9LL * c + 3 + j] + b.nrm[2] * gradU[9LL * c + 6 + j];
+        dsn[j] = snG - ngU;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) gUb[3 * i + j] = gradU[9LL * c + 3 * i + j] + b.nrm[i] * dsn[j];
+    T muEff_b = b.rho_b * (b.nu_b + b.nut_b);
+    T tr3 = (2.0 / 3.0) * (gUb[0] + gUb[4] + gUb[8]);  // tr(twoSymm)/3
+    T acc(0.0);
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        T fT(0.0);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            T sij = gUb[3 * i + j] + gUb[3 * j + i];
+            if (i == j) sij = sij - tr3;
+            fT += g.Sf[i] * sij;
+        }
+        acc += dir[j] * (g.Sf[j] * b.p.xb - muEff_b * fT);
+    }
+    return scale * acc;
+}
+
 // ================================================================================ DAScalarTransportFoam
 template <class T>
 DAS_HD void body_gradT(int c, const DevMesh& m, const ResParams& prm, const T* W, const double* phiF, T* gradT) {

@@ -233,6 +233,7 @@ class pyDASolvers:
         self._inited = False
         self._device = int(pyOptions.get("amdDevice", 0)) if isinstance(pyOptions, dict) else 0
         self.updateDAOption(pyOptions)
+        self._define_functions(pyOptions.get("function") if isinstance(pyOptions, dict) else None)
         if case.states is not None:
             self.updateOFFields(np.ascontiguousarray(case.states, dtype=np.float64))
 
@@ -254,7 +255,7 @@ class pyDASolvers:
         [type, value] pairs produced by pyDAFoam._getDefOptions, pyDAFoam.py:823-844)."""
         flat = {}
         opts = {k: (v[1] if isinstance(v, list) and len(v) == 2 and isinstance(v[0], type) else v) for k, v in pyOptions.items()}
-        _flatten("", {k: v for k, v in opts.items() if not k.startswith("amdCase")}, flat)
+        _flatten("", {k: v for k, v in opts.items() if not k.startswith("amdCase") and k not in ("function", "inputInfo", "outputInfo", "primalBC")}, flat)
         L = lib()
         for k, v in flat.items():
             kb = k.encode()
@@ -268,7 +269,7 @@ class pyDASolvers:
                 check(L.das_set_option_str(self._h, kb, v.encode()))
             elif isinstance(v, (list, tuple)) and all(isinstance(x, str) for x in v):
                 check(L.das_set_option_str(self._h, kb, ",".join(v).encode()))
-            # other option kinds (nested function dicts, ...) are outside the hot path
+            # other option kinds (lists of numbers, ...) are not forwarded
 
     def printAllOptions(self):
         print("dafoam_amd options are held by the C-ABI; see DAOPTION for defaults")
@@ -375,6 +376,25 @@ class pyDASolvers:
         assert len(product) == inputSize, "invalid product array size!"
         check(lib().das_calc_jac_t_vec_product(
             self._h, inputName.encode(), inputType.encode(), dptr(inputs), outputName.encode(), outputType.encode(), dptr(seeds), dptr(product)))
+
+    # -- objective functions ------------------------------------------------------------------------
+    def _define_functions(self, functions):
+        """"function" option dict (reference pyDAFoam.py DAOPTION.function): only type "force" with
+        directionMode "fixedDirection" is on this path."""
+        names = [p.name for p in self._case.mesh.patches]
+        for fname, fd in (functions or {}).items():
+            if fd.get("type") != "force":
+                raise NotImplementedError(f"function type {fd.get('type')} is outside the GPU hot path")
+            if fd.get("directionMode", "fixedDirection") != "fixedDirection":
+                raise NotImplementedError("only directionMode fixedDirection is implemented")
+            ids = np.array([names.index(p) for p in fd["patches"]], dtype=np.int32)
+            d = np.ascontiguousarray(fd["direction"], dtype=np.float64)
+            check(lib().das_define_force_function(self._h, fname.encode(), ids.ctypes.data_as(_capi.c_int_p), ids.size, dptr(d), float(fd.get("scale", 1.0))))
+
+    def calcFunction(self, functionName):
+        v = C.c_double(0.0)
+        check(lib().das_calc_function(self._h, functionName.encode(), C.byref(v)))
+        return v.value
 
     # -- Krylov ----------------------------------------------------------------------------------
     def createMLRKSPMatrixFree(self, jacPCMat: Mat, myKSP: KSP):

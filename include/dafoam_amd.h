@@ -163,9 +163,17 @@ int das_destroy_drdwt_matrix_free(das_solver_t* s);
 /* nnz of the assembled matrix-free operator (after the jacLowerBounds filter), -1 if not initialised */
 long long das_op_nnz(das_solver_t* s);
 
+/* ---- objective functions (adjoint right-hand side producers) -----------------------------------------------
+ * das_define_force_function <- the "function" option entry {type: force, patches, directionMode: fixedDirection,
+ *     direction, scale} consumed by DAFunctionForce (reference src/adjoint/DAFunction/DAFunctionForce.C:20-77)
+ * das_calc_function         <- calcFunction(functionName)  pyDASolvers.pyx (DAFunctionForce::calcFunction :79-158) */
+int das_define_force_function(das_solver_t* s, const char* name, const int* patch_ids, int npatch, const double* direction, double scale);
+int das_calc_function(das_solver_t* s, const char* name, double* value);
+
 /* das_calc_jac_t_vec_product <- calcJacTVecProduct(inputName,inputType,inputs,outputName,outputType,seeds,product)
  *   pyDASolvers.pyx:208-235 (DASolver.C:1690-1839).  Supported pair on this path: inputType "stateVar",
- *   outputType "residual": product = D_s (dR/dW)^T seeds  (normalizeJacTVecProduct, DASolver.C:1443-1553). */
+ *   outputType "residual": product = D_s (dR/dW)^T seeds  (normalizeJacTVecProduct, DASolver.C:1443-1553);
+ *   outputType "function" (outputName = function name, one seed): product = seed * D_s dF/dW  (mphys_dafoam.py:746-801). */
 int das_get_input_size(das_solver_t* s, const char* inputName, const char* inputType);
 int das_get_output_size(das_solver_t* s, const char* outputName, const char* outputType);
 int das_calc_jac_t_vec_product(das_solver_t* s, const char* inputName, const char* inputType, const double* inputs,

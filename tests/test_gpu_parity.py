@@ -132,6 +132,29 @@ def test_rhosimplefoam_residual_jacobian_adjoint(wall_function):
     assert fail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-6
 
 
+@pytest.mark.parametrize("solver", ["DASimpleFoam", "DARhoSimpleFoam"])
+def test_force_function_and_dFdW(solver):
+    """DAFunctionForce restated: value and the state-scaled gradient dFdW (adjoint right-hand side) from the coloured
+    dual-number pass, against the oracle's complex-step gradient; then the adjoint solved with that RHS."""
+    from oracle.functions import force, force_gradient
+
+    case = channel_case(6, 5, 4, wall_function=True) if solver == "DASimpleFoam" else rho_channel_case(6, 5, 4, perturb=0.02)
+    g = Geometry(case.mesh)
+    fn = {"CD": {"type": "force", "source": "patchToFace", "patches": ["bottom", "top"], "directionMode": "fixedDirection",
+                 "direction": [1.0, 0.0, 0.0], "scale": 2.0}}
+    D = make(case, function=fn)
+    Fo = force(case, g, case.states, ["bottom", "top"], [1, 0, 0], 2.0)
+    assert abs(D.solver.calcFunction("CD") - Fo) <= 1e-12 * abs(Fo)
+    sc = J.state_scales(case, g, norm_states(case))
+    dFo = force_gradient(case, g, case.states, ["bottom", "top"], [1, 0, 0], 2.0, sc)
+    dF = np.zeros(case.states.size)
+    D.solverAD.calcJacTVecProduct("states", "stateVar", case.states, "CD", "function", np.array([1.0]), dF)
+    assert relerr(dF, dFo) < 1e-10
+    assert D.solver.getOutputSize("CD", "function") == 1
+    with pytest.raises(Exception):
+        D.solver.calcFunction("nope")
+
+
 def test_normalize_residuals_option():
     # DAMacroFunctions.H:28-51: residuals not listed are volume-integrated / not area-divided
     case = channel_case(5, 5, 4)
