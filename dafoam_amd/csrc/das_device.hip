@@ -1538,6 +1538,39 @@ int das_destroy_drdwt_matrix_free(das_solver_t* s) {
     DAS_CATCH
 }
 
+int das_calc_drdwold_t_psi(das_solver_t* s, int oldTimeLevel, const double* psi, double* out) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(psi && out, DAS_ERR_ARG, "null argument");
+    DAS_CHECK(oldTimeLevel == 1 || oldTimeLevel == 2, DAS_ERR_ARG, "oldTimeLevel must be 1 (W0) or 2 (W00)");
+    const long long n = s->n;
+    if (s->cp.solver != DAS_SOLVER_SCALARTRANSPORTFOAM || oldTimeLevel == 2) {
+        std::fill(out, out + n, 0.0);  // steady residuals / Euler scheme: no W00 dependence
+        return DAS_OK;
+    }
+    // R_i = ((V/dt)(T_i - T0_i) + ...)/V (normalised) -> dR_i/dT0_j = -delta_ij/dt (x V if TRes is not normalised)
+    DAS_HIP(hipMemcpyAsync(s->d_tmp1.p, psi, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    std::vector<double> coef(n);
+    const bool norm = s->opt.list_has("normalizeResiduals", "TRes");
+    for (long long j = 0; j < n; j++) coef[j] = -s->h_scale[j] / s->cp.deltaT * (norm ? 1.0 : s->mesh.cg[j].V);
+    s->d_tmp2.upload(coef);
+    hipLaunchKernelGGL(k_mul, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, s->d_tmp2.p, s->d_tmp1.p);
+    DAS_HIP(hipMemcpyAsync(out, s->d_tmp1.p, n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    DAS_HIP(hipStreamSynchronize(s->stream));
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_set_old_time_fields(das_solver_t* s, const double* phi_frozen, const double* T_old) {
+    DAS_TRY
+    DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
+    DAS_CHECK(s->cp.solver == DAS_SOLVER_SCALARTRANSPORTFOAM, DAS_ERR_ARG, "old-time fields only exist for DAScalarTransportFoam");
+    if (phi_frozen) s->cp.phi_frozen.assign(phi_frozen, phi_frozen + s->mesh.nF);
+    if (T_old) s->cp.T_old.assign(T_old, T_old + s->mesh.nC);
+    if (s->inited) { s->d_phiF.upload(s->cp.phi_frozen); s->d_Told.upload(s->cp.T_old); }
+    return DAS_OK;
+    DAS_CATCH
+}
+
 // ---- objective functions (reference "function" option dict, DAFunctionForce) ------------------------------------------
 int das_define_force_function(das_solver_t* s, const char* name, const int* patch_ids, int npatch, const double* direction, double scale) {
     DAS_TRY

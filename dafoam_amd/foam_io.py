@@ -1,0 +1,315 @@
+"""OpenFOAM ASCII case IO for the hot path's inputs: constant/polyMesh/{points,faces,owner,
+neighbour,boundary}, 0/<field> files (internalField + boundaryField) and constant/transportProperties:nu.
+
+The reference gets these through OpenFOAM's own readers when DASolver constructs argList/Time/fvMesh
+(reference src/include/createMeshPython.H / createFields*.H via DASolver::initSolver, e.g. DASimpleFoam.C:81-121);
+this module makes the same data available as a :class:`dafoam_amd.meshgen.FoamCase` so that an existing case
+directory can drive the GPU path.  ASCII only (uncompressed), uniform or nonuniform List fields, the patch-field types
+of SURVEY.md Appendix B (fixedValue, zeroGradient, inletOutlet, symmetry/symmetryPlane, noSlip, calculated,
+nutUSpaldingWallFunction, nutLowReWallFunction, fixedValue nut = 0).
+"""
+from __future__ import annotations
+
+import os
+import re
+
+import numpy as np
+
+from .meshgen import (
+    BC_FIXED_VALUE, BC_INLET_OUTLET, BC_SYMMETRY, BC_ZERO_GRADIENT, NUT_CALCULATED, NUT_LOWRE_WALL, NUT_SPALDING_WALL, NUT_SYMMETRY,
+    FoamCase, Patch, PolyMesh,
+)
+
+_HEADER = """/*--------------------------------*- C++ -*----------------------------------*\\
+| dafoam_amd foam_io                                                          |
+\\*---------------------------------------------------------------------------*/
+FoamFile
+{{
+    version     2.0;
+    format      ascii;
+    class       {cls};
+    location    "{loc}";
+    object      {obj};
+}}
+// * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * * //
+
+"""
+
+
+def _strip(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//.*?$", "", text, flags=re.M)
+    m = re.search(r"FoamFile\s*\{.*?\}", text, flags=re.S)
+    if m:
+        text = text[: m.start()] + text[m.end():]
+    return text
+
+
+def _list_body(text):
+    """'N ( ... )' -> (N, body string)"""
+    m = re.search(r"(\d+)\s*\(", text)
+    if not m:
+        raise ValueError("no list found")
+    n = int(m.group(1))
+    start = m.end()
+    depth, i = 1, start
+    while depth and i < len(text):
+        c = text[i]
+        depth += c == "("
+        depth -= c == ")"
+        i += 1
+    return n, text[start : i - 1]
+
+
+def read_points(path):
+    n, body = _list_body(_strip(open(path).read()))
+    a = np.array(re.sub(r"[()]", " ", body).split(), dtype=np.float64).reshape(-1, 3)
+    assert a.shape[0] == n, f"{path}: expected {n} points, found {a.shape[0]}"
+    return a
+
+
+def read_labels(path):
+    n, body = _list_body(_strip(open(path).read()))
+    a = np.array(body.split(), dtype=np.int64)
+    assert a.size == n, f"{path}: expected {n} labels, found {a.size}"
+    return a.astype(np.int32)
+
+
+def read_faces(path):
+    n, body = _list_body(_strip(open(path).read()))
+    ptr, pts = [0], []
+    for m in re.finditer(r"(\d+)\s*\(([^()]*)\)", body):
+        k = int(m.group(1))
+        v = m.group(2).split()
+        assert len(v) == k
+        pts.extend(int(x) for x in v)
+        ptr.append(len(pts))
+    assert len(ptr) - 1 == n, f"{path}: expected {n} faces, found {len(ptr)-1}"
+    return np.array(ptr, dtype=np.int32), np.array(pts, dtype=np.int32)
+
+
+def _parse_dict_entries(body):
+    """name { key value; ... } blocks -> dict of dicts (values as strings)."""
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][\w.:]*)\s*\{([^{}]*)\}", body):
+        d = {}
+        for e in re.finditer(r"([A-Za-z_]\w*)\s+([^;]*);", m.group(2)):
+            d[e.group(1)] = e.group(2).strip()
+        out[m.group(1)] = d
+    return out
+
+
+def read_boundary(path):
+    n, body = _list_body(_strip(open(path).read()))
+    ent = _parse_dict_entries(body)
+    assert len(ent) == n, f"{path}: expected {n} patches, found {len(ent)}"
+    patches = []
+    for name, d in ent.items():
+        t = d.get("type", "patch")
+        t = {"symmetryPlane": "symmetry", "empty": "symmetry"}.get(t, t)
+        if t not in ("patch", "wall", "symmetry"):
+            raise NotImplementedError(f"patch type {t} of {name} is outside the hot path (processor/cyclic patches: see DESIGN.md)")
+        patches.append(Patch(name, t, int(d["startFace"]), int(d["nFaces"])))
+    patches.sort(key=lambda p: p.start)
+    return patches
+
+
+def read_polymesh(case_dir):
+    pm = os.path.join(case_dir, "constant", "polyMesh")
+    fptr, fpts = read_faces(os.path.join(pm, "faces"))
+    mesh = PolyMesh(points=read_points(os.path.join(pm, "points")), face_ptr=fptr, face_pts=fpts, owner=read_labels(os.path.join(pm, "owner")),
+                    neighbour=read_labels(os.path.join(pm, "neighbour")), patches=read_boundary(os.path.join(pm, "boundary")))
+    nB = sum(p.size for p in mesh.patches)
+    assert mesh.n_internal_faces + nB == mesh.n_faces, "boundary does not cover all boundary faces"
+    return mesh
+
+
+def write_polymesh(case_dir, mesh: PolyMesh):
+    pm = os.path.join(case_dir, "constant", "polyMesh")
+    os.makedirs(pm, exist_ok=True)
+    with open(os.path.join(pm, "points"), "w") as f:
+        f.write(_HEADER.format(cls="vectorField", loc="constant/polyMesh", obj="points"))
+        f.write(f"{mesh.n_points}\n(\n" + "\n".join("(%.17g %.17g %.17g)" % tuple(p) for p in mesh.points) + "\n)\n")
+    with open(os.path.join(pm, "faces"), "w") as f:
+        f.write(_HEADER.format(cls="faceList", loc="constant/polyMesh", obj="faces"))
+        rows = []
+        for k in range(mesh.n_faces):
+            v = mesh.face_pts[mesh.face_ptr[k] : mesh.face_ptr[k + 1]]
+            rows.append(f"{len(v)}(" + " ".join(str(int(x)) for x in v) + ")")
+        f.write(f"{mesh.n_faces}\n(\n" + "\n".join(rows) + "\n)\n")
+    for nm, arr in (("owner", mesh.owner), ("neighbour", mesh.neighbour)):
+        with open(os.path.join(pm, nm), "w") as f:
+            f.write(_HEADER.format(cls="labelList", loc="constant/polyMesh", obj=nm))
+            f.write(f"{arr.size}\n(\n" + "\n".join(str(int(x)) for x in arr) + "\n)\n")
+    with open(os.path.join(pm, "boundary"), "w") as f:
+        f.write(_HEADER.format(cls="polyBoundaryMesh", loc="constant/polyMesh", obj="boundary"))
+        f.write(f"{len(mesh.patches)}\n(\n")
+        for p in mesh.patches:
+            f.write(f"    {p.name}\n    {{\n        type            {p.type};\n        nFaces          {p.size};\n        startFace       {p.start};\n    }}\n")
+        f.write(")\n")
+
+
+# ----------------------------------------------------------------------------- fields
+def _parse_value(s, ncomp):
+    s = s.strip()
+    if s.startswith("uniform"):
+        v = np.array(re.sub(r"[()]", " ", s[len("uniform"):]).split(), dtype=np.float64)
+        return v if ncomp == 3 else float(v[0])
+    raise NotImplementedError(f"only uniform patch values are supported: {s[:40]}")
+
+
+def read_field(path, n_cells, ncomp):
+    """returns (internal (n_cells[,3]) array, {patch: dict(type=..., value=...)})"""
+    text = _strip(open(path).read())
+    m = re.search(r"internalField\s+(uniform\s+[^;]+|nonuniform\s+List<\w+>\s*)", text)
+    if not m:
+        raise ValueError(f"{path}: no internalField")
+    if m.group(1).startswith("uniform"):
+        v = _parse_value(m.group(1), ncomp)
+        internal = np.tile(np.atleast_1d(v), (n_cells, 1)) if ncomp == 3 else np.full(n_cells, v)
+    else:
+        n, body = _list_body(text[m.end():])
+        internal = np.array(re.sub(r"[()]", " ", body).split(), dtype=np.float64)
+        internal = internal.reshape(n, 3) if ncomp == 3 else internal
+        assert internal.shape[0] == n_cells
+    bm = re.search(r"boundaryField\s*\{", text)
+    depth, i = 1, bm.end()
+    while depth:
+        depth += text[i] == "{"
+        depth -= text[i] == "}"
+        i += 1
+    bfield = {}
+    for name, d in _parse_dict_entries(text[bm.end() : i - 1]).items():
+        e = {"type": d.get("type", "zeroGradient")}
+        for key in ("value", "inletValue"):
+            if key in d:
+                e[key] = _parse_value(d[key], ncomp)
+        bfield[name] = e
+    return internal, bfield
+
+
+_SCALAR_BC = {"fixedValue": BC_FIXED_VALUE, "zeroGradient": BC_ZERO_GRADIENT, "inletOutlet": BC_INLET_OUTLET, "symmetry": BC_SYMMETRY,
+              "symmetryPlane": BC_SYMMETRY, "empty": BC_SYMMETRY, "calculated": BC_ZERO_GRADIENT}
+_NUT_BC = {"calculated": NUT_CALCULATED, "nutUSpaldingWallFunction": NUT_SPALDING_WALL, "nutUSpaldingWallFunctionDF": NUT_SPALDING_WALL,
+           "nutLowReWallFunction": NUT_LOWRE_WALL, "symmetry": NUT_SYMMETRY, "symmetryPlane": NUT_SYMMETRY, "empty": NUT_SYMMETRY,
+           "zeroGradient": NUT_CALCULATED}
+
+
+def _bc_entry(e, vec):
+    t = e["type"]
+    if t == "noSlip":
+        return (BC_FIXED_VALUE, (0.0, 0.0, 0.0) if vec else 0.0)
+    if t not in _SCALAR_BC:
+        raise NotImplementedError(f"patch field type {t} is outside the hot path")
+    code = _SCALAR_BC[t]
+    v = e.get("inletValue" if t == "inletOutlet" else "value", np.zeros(3) if vec else 0.0)
+    return (code, tuple(np.atleast_1d(v)) if vec else float(v))
+
+
+def read_case(case_dir, solver_name="DASimpleFoam", time="0", y_wall=None) -> FoamCase:
+    """DASimpleFoam / DARhoSimpleFoam case directory -> FoamCase (phi = interp(U).Sf if 0/phi is absent)."""
+    from .meshgen import _InputGeometry, wall_distance
+
+    mesh = read_polymesh(case_dir)
+    N, F, nIF = mesh.n_cells, mesh.n_faces, mesh.n_internal_faces
+    t = os.path.join(case_dir, time)
+    U, bU = read_field(os.path.join(t, "U"), N, 3)
+    p, bp = read_field(os.path.join(t, "p"), N, 1)
+    nuT, bn = read_field(os.path.join(t, "nuTilda"), N, 1)
+    _, bnut = read_field(os.path.join(t, "nut"), N, 1)
+    bcs = {}
+    for pt in mesh.patches:
+        nm = pt.name
+        e = {"U": _bc_entry(bU[nm], True), "p": _bc_entry(bp[nm], False), "nuTilda": _bc_entry(bn[nm], False)}
+        nt = bnut[nm]["type"]
+        if nt == "fixedValue":
+            e["nut"] = (NUT_LOWRE_WALL, 0.0)
+        elif nt in _NUT_BC:
+            e["nut"] = (_NUT_BC[nt], 0.0)
+        else:
+            raise NotImplementedError(f"nut patch type {nt}")
+        bcs[nm] = e
+    tp = _strip(open(os.path.join(case_dir, "constant", "transportProperties")).read())
+    m = re.search(r"\bnu\s+(?:\[[^\]]*\]\s*)?([-+0-9.eE]+)\s*;", tp)
+    nu = float(m.group(1)) if m else 1.5e-5
+    g = _InputGeometry(mesh)
+    if y_wall is None:
+        y_wall = wall_distance(mesh, g.C, g.Cf, g.Sf)
+    case = FoamCase(mesh=mesh, solver_name=solver_name, nu=nu, bcs=bcs, y_wall=y_wall)
+    phi_path = os.path.join(t, "phi")
+    if os.path.exists(phi_path):
+        text = _strip(open(phi_path).read())
+        m = re.search(r"internalField\s+nonuniform\s+List<scalar>\s*", text)
+        n, body = _list_body(text[m.end():])
+        phi = np.zeros(F)
+        phi[:nIF] = np.array(body.split(), dtype=np.float64)
+    else:
+        own, nei = mesh.owner, mesh.neighbour
+        Uf = g.w[:, None] * U[own[:nIF]] + (1 - g.w[:, None]) * U[nei]
+        phi = np.zeros(F)
+        phi[:nIF] = np.einsum("ij,ij->i", Uf, g.Sf[:nIF])
+        for pt in mesh.patches:
+            sl = slice(pt.start, pt.start + pt.size)
+            code, val = bcs[pt.name]["U"]
+            if code == BC_FIXED_VALUE:
+                phi[sl] = g.Sf[sl] @ np.asarray(val, dtype=float)
+            elif code != BC_SYMMETRY:
+                phi[sl] = np.einsum("ij,ij->i", U[own[sl]], g.Sf[sl])
+    case.states = np.concatenate([U.ravel(), p, nuT, phi])
+    return case
+
+
+def write_case(case_dir, case: FoamCase, time="0"):
+    """Write a DASimpleFoam FoamCase as an OpenFOAM ASCII case (mesh, 0/U p nuTilda nut, transportProperties)."""
+    mesh = case.mesh
+    write_polymesh(case_dir, mesh)
+    N = mesh.n_cells
+    W = case.states
+    U, p, nuT = W[: 3 * N].reshape(N, 3), W[3 * N : 4 * N], W[4 * N : 5 * N]
+    tdir = os.path.join(case_dir, time)
+    os.makedirs(tdir, exist_ok=True)
+    names = {BC_FIXED_VALUE: "fixedValue", BC_ZERO_GRADIENT: "zeroGradient", BC_INLET_OUTLET: "inletOutlet", BC_SYMMETRY: "symmetry"}
+    nutn = {NUT_CALCULATED: "calculated", NUT_LOWRE_WALL: "nutLowReWallFunction", NUT_SPALDING_WALL: "nutUSpaldingWallFunction", NUT_SYMMETRY: "symmetry"}
+
+    def fmt(v):
+        return "(%.17g %.17g %.17g)" % tuple(v) if np.ndim(v) else "%.17g" % v
+
+    def write(name, cls, internal, field):
+        with open(os.path.join(tdir, name), "w") as f:
+            f.write(_HEADER.format(cls=cls, loc=time, obj=name))
+            f.write("dimensions      [0 0 0 0 0 0 0];\n\n")
+            if internal is None:
+                f.write("internalField   uniform 0;\n\n")
+            else:
+                typ = "vector" if internal.ndim == 2 else "scalar"
+                f.write(f"internalField   nonuniform List<{typ}>\n{internal.shape[0]}\n(\n" + "\n".join(fmt(v) for v in internal) + "\n)\n;\n\n")
+            f.write("boundaryField\n{\n")
+            for pt in mesh.patches:
+                code, val = case.bcs[pt.name][field]
+                f.write(f"    {pt.name}\n    {{\n")
+                if field == "nut":
+                    f.write(f"        type            {nutn[code]};\n")
+                    if code != NUT_SYMMETRY:
+                        f.write("        value           uniform 0;\n")
+                else:
+                    f.write(f"        type            {names[code]};\n")
+                    if code == BC_FIXED_VALUE:
+                        f.write(f"        value           uniform {fmt(np.asarray(val)) if np.ndim(val) else fmt(val)};\n")
+                    if code == BC_INLET_OUTLET:
+                        f.write(f"        inletValue      uniform {fmt(np.asarray(val)) if np.ndim(val) else fmt(val)};\n")
+                        f.write(f"        value           uniform {fmt(np.asarray(val)) if np.ndim(val) else fmt(val)};\n")
+                f.write("    }\n")
+            f.write("}\n")
+
+    write("U", "volVectorField", U, "U")
+    write("p", "volScalarField", p, "p")
+    write("nuTilda", "volScalarField", nuT, "nuTilda")
+    write("nut", "volScalarField", None, "nut")
+    os.makedirs(os.path.join(case_dir, "constant"), exist_ok=True)
+    with open(os.path.join(case_dir, "constant", "transportProperties"), "w") as f:
+        f.write(_HEADER.format(cls="dictionary", loc="constant", obj="transportProperties"))
+        f.write(f"transportModel  Newtonian;\n\nnu              [0 2 -1 0 0 0 0] {case.nu:.17g};\n")
+    nIF = mesh.n_internal_faces
+    with open(os.path.join(tdir, "phi"), "w") as f:
+        f.write(_HEADER.format(cls="surfaceScalarField", loc=time, obj="phi"))
+        f.write(f"dimensions      [0 3 -1 0 0 0 0];\n\ninternalField   nonuniform List<scalar>\n{nIF}\n(\n" + "\n".join("%.17g" % v for v in W[5 * N : 5 * N + nIF]) + "\n)\n;\n")

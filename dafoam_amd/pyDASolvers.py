@@ -232,6 +232,11 @@ class pyDASolvers:
             raise _capi.DASError(L.das_last_error().decode())
         self._inited = False
         self._device = int(pyOptions.get("amdDevice", 0)) if isinstance(pyOptions, dict) else 0
+        # adjStateOrdering (reference DAIndex.C:188-397,518-661): the library works in "state" ordering; "cell"
+        # ordering is provided at this boundary as a permutation of every state-length array
+        self._perm = None
+        if isinstance(pyOptions, dict) and pyOptions.get("adjStateOrdering", "state") == "cell":
+            self._perm = self._cell_ordering_permutation()
         self.updateDAOption(pyOptions)
         self._define_functions(pyOptions.get("function") if isinstance(pyOptions, dict) else None)
         if case.states is not None:
@@ -245,6 +250,42 @@ class pyDASolvers:
         except Exception:
             pass
 
+    # -- adjStateOrdering "cell" ----------------------------------------------------------------------
+    def _cell_ordering_permutation(self):
+        """perm[k] = index in "state" ordering of the k-th entry of the "cell" ordering: per cell its cell states
+        (volVector, volScalar, model) followed by the phi of the faces it owns (DAIndex.C:602-651)."""
+        m = self._case.mesh
+        N, F = m.n_cells, m.n_faces
+        layout = {"DASimpleFoam": (1, 2), "DARhoSimpleFoam": (1, 3), "DAScalarTransportFoam": (0, 1)}[self._case.solver_name]
+        nvec, nscl = layout
+        has_phi = self._case.solver_name != "DAScalarTransportFoam"
+        owned = [[] for _ in range(N)]
+        if has_phi:
+            for f in range(F):
+                owned[m.owner[f]].append(f)
+        perm = []
+        for c in range(N):
+            for v in range(nvec):
+                perm += [3 * N * v + 3 * c + k for k in range(3)]
+            for b in range(nscl):
+                perm.append(3 * N * nvec + b * N + c)
+            perm += [3 * N * nvec + nscl * N + f for f in owned[c]]
+        return np.array(perm, dtype=np.int64)
+
+    def _to_state(self, a):
+        if self._perm is None:
+            return a
+        out = np.empty_like(a)
+        out[self._perm] = a
+        return out
+
+    def _from_state(self, a_state, out):
+        if self._perm is None:
+            if out is not a_state:
+                out[:] = a_state
+        else:
+            out[:] = a_state[self._perm]
+
     # -- lifecycle -------------------------------------------------------------------------
     def initSolver(self):
         check(lib().das_init_solver(self._h, self._device))
@@ -256,6 +297,8 @@ class pyDASolvers:
         flat = {}
         opts = {k: (v[1] if isinstance(v, list) and len(v) == 2 and isinstance(v[0], type) else v) for k, v in pyOptions.items()}
         _flatten("", {k: v for k, v in opts.items() if not k.startswith("amdCase") and k not in ("function", "inputInfo", "outputInfo", "primalBC")}, flat)
+        if flat.get("adjStateOrdering") == "cell" and getattr(self, "_perm", None) is not None:
+            flat.pop("adjStateOrdering")  # handled at this boundary (permutation); the library stays in "state" ordering
         L = lib()
         for k, v in flat.items():
             kb = k.encode()
@@ -301,19 +344,25 @@ class pyDASolvers:
     # -- states / residuals --------------------------------------------------------------------
     def updateOFFields(self, states):
         assert len(states) == self.getNLocalAdjointStates(), "invalid array size!"
-        check(lib().das_update_of_fields(self._h, dptr(states)))
+        check(lib().das_update_of_fields(self._h, dptr(np.ascontiguousarray(self._to_state(states)))))
 
     def getOFFields(self, states):
         assert len(states) == self.getNLocalAdjointStates(), "invalid array size!"
-        check(lib().das_get_of_fields(self._h, dptr(states)))
+        tmp = np.zeros(len(states)) if self._perm is not None else states
+        check(lib().das_get_of_fields(self._h, dptr(tmp)))
+        self._from_state(tmp, states)
 
     def getResiduals(self, residuals):
         assert len(residuals) == self.getNLocalAdjointStates(), "invalid input array size!"
-        check(lib().das_get_residuals(self._h, dptr(residuals)))
+        tmp = np.zeros(len(residuals)) if self._perm is not None else residuals
+        check(lib().das_get_residuals(self._h, dptr(tmp)))
+        self._from_state(tmp, residuals)
 
     def calcResiduals(self, isPC, residuals):
         assert len(residuals) == self.getNLocalAdjointStates(), "invalid input array size!"
-        check(lib().das_calc_residuals(self._h, int(isPC), dptr(residuals)))
+        tmp = np.zeros(len(residuals)) if self._perm is not None else residuals
+        check(lib().das_calc_residuals(self._h, int(isPC), dptr(tmp)))
+        self._from_state(tmp, residuals)
 
     def updateStateBoundaryConditions(self):
         # boundary values are recomputed inline by every kernel from the state vector: nothing to do
@@ -374,8 +423,23 @@ class pyDASolvers:
         assert len(inputs) == inputSize, "invalid input array size!"
         assert len(seeds) == outputSize, "invalid seed array size!"
         assert len(product) == inputSize, "invalid product array size!"
+        seeds_s = np.ascontiguousarray(self._to_state(seeds)) if outputType == "residual" else seeds
+        tmp = np.zeros(len(product)) if self._perm is not None else product
         check(lib().das_calc_jac_t_vec_product(
-            self._h, inputName.encode(), inputType.encode(), dptr(inputs), outputName.encode(), outputType.encode(), dptr(seeds), dptr(product)))
+            self._h, inputName.encode(), inputType.encode(), dptr(np.ascontiguousarray(self._to_state(inputs))), outputName.encode(),
+            outputType.encode(), dptr(seeds_s), dptr(tmp)))
+        self._from_state(tmp, product)
+
+    def calcdRdWOldTPsiAD(self, oldTimeLevel, psi, dRdWOldTPsi):
+        assert len(psi) == self.getNLocalAdjointStates(), "invalid input array size!"
+        assert len(dRdWOldTPsi) == self.getNLocalAdjointStates(), "invalid seed array size!"
+        tmp = np.zeros(len(psi)) if self._perm is not None else dRdWOldTPsi
+        check(lib().das_calc_drdwold_t_psi(self._h, int(oldTimeLevel), dptr(np.ascontiguousarray(self._to_state(psi))), dptr(tmp)))
+        self._from_state(tmp, dRdWOldTPsi)
+
+    def setOldTimeFields(self, phi=None, T_old=None):
+        check(lib().das_set_old_time_fields(self._h, dptr(np.ascontiguousarray(phi)) if phi is not None else None,
+                                            dptr(np.ascontiguousarray(T_old)) if T_old is not None else None))
 
     # -- objective functions ------------------------------------------------------------------------
     def _define_functions(self, functions):
@@ -412,7 +476,12 @@ class pyDASolvers:
         L = lib()
         for k, v in myKSP._tols.items():
             (L.das_set_option_int if isinstance(v, int) else L.das_set_option_double)(self._h, k.encode(), v)
-        return check(L.das_solve_linear_eqn(self._h, myKSP.handle, dptr(rhsVec.array), dptr(solVec.array)))
+        if self._perm is None:
+            return check(L.das_solve_linear_eqn(self._h, myKSP.handle, dptr(rhsVec.array), dptr(solVec.array)))
+        rhs, sol = np.ascontiguousarray(self._to_state(rhsVec.array)), np.ascontiguousarray(self._to_state(solVec.array))
+        rc = check(L.das_solve_linear_eqn(self._h, myKSP.handle, dptr(rhs), dptr(sol)))
+        self._from_state(sol, solVec.array)
+        return rc
 
     # -- timing ----------------------------------------------------------------------------------
     def getElapsedClockTime(self):

@@ -163,6 +163,15 @@ int das_destroy_drdwt_matrix_free(das_solver_t* s);
 /* nnz of the assembled matrix-free operator (after the jacLowerBounds filter), -1 if not initialised */
 long long das_op_nnz(das_solver_t* s);
 
+/* ---- unsteady adjoint terms (DAScalarTransportFoam, BASELINE configs[0]) ---------------------------------------------
+ * das_calc_drdwold_t_psi <- calcdRdWOldTPsiAD(oldTimeLevel, psi, dRdWOldTPsi)  pyDASolvers.pyx:240 (DASolver.C:1910-1969):
+ *     D_s (dR/dW_old)^T psi for oldTimeLevel 1 (W0) or 2 (W00).  Euler ddt: dR/dT0 = -1/deltaT (per-volume residual),
+ *     level 2 and steady solvers give zero.
+ * das_set_old_time_fields: frozen flux and old-time temperature of the current time step (the reference re-reads them
+ *     from disk, readStateVars DASolver.C:3193). */
+int das_calc_drdwold_t_psi(das_solver_t* s, int oldTimeLevel, const double* psi, double* out);
+int das_set_old_time_fields(das_solver_t* s, const double* phi_frozen /* n_faces or NULL */, const double* T_old /* n_cells or NULL */);
+
 /* ---- objective functions (adjoint right-hand side producers) -----------------------------------------------
  * das_define_force_function <- the "function" option entry {type: force, patches, directionMode: fixedDirection,
  *     direction, scale} consumed by DAFunctionForce (reference src/adjoint/DAFunction/DAFunctionForce.C:20-77)

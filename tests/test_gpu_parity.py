@@ -329,6 +329,70 @@ def test_ras_ilu_apply_matches_oracle(dims, block, overlap, fill, fp32):
     assert relerr(y, y_o) < (1e-2 if fp32 else 1e-9)  # fp32 factor storage: preconditioner-only approximation
 
 
+def test_cell_state_ordering():
+    """adjStateOrdering "cell" (reference DAIndex.C:602-651): every state-length array crosses the boundary in the
+    cell-by-cell ordering; results are the permuted "state"-ordering results."""
+    case = converged_case((8, 6, 5), lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    Ds = make(case, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0})
+    Dc = make(case, adjStateOrdering="cell", adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0})
+    perm = Dc.solver._perm
+    n = case.states.size
+    assert np.array_equal(Dc.getStates(), case.states[perm])
+    syn = channel_case(8, 6, 5, lengths=(1.0, 0.2, 0.2), grading_y=2.0).states
+    Rs, Rc = np.zeros(n), np.zeros(n)
+    Ds.setStates(syn)
+    Dc.setStates(syn[perm])
+    Ds.solver.getResiduals(Rs)
+    Dc.solver.getResiduals(Rc)
+    assert np.array_equal(Rc, Rs[perm])
+    Ds.setStates(case.states)
+    Dc.setStates(case.states[perm])
+    psi = np.random.default_rng(0).standard_normal(n)
+    ps, pc = np.zeros(n), np.zeros(n)
+    Ds.solverAD.calcJacTVecProduct("s", "stateVar", case.states, "r", "residual", psi, ps)
+    Dc.solverAD.calcJacTVecProduct("s", "stateVar", case.states[perm], "r", "residual", psi[perm], pc)
+    assert relerr(pc, ps[perm]) < 1e-13
+    g = Geometry(case.mesh)
+    rhs = np.zeros(n)
+    rhs[0 : 3 * g.nC : 3] = g.V * 10.0
+    xs, fs = Ds.solveAdjoint(rhs)
+    xc, fc = Dc.solveAdjoint(rhs[perm])
+    assert fs == 0 and fc == 0 and relerr(xc, xs[perm]) < 1e-7
+
+
+def test_unsteady_terms_scalar_transport():
+    """calcdRdWOldTPsiAD (reference DASolver.C:1910-1969) for the Euler-ddt scalar transport residual and the old-time
+    field setter, against complex-step derivatives of the oracle w.r.t. T_old."""
+    import copy
+
+    case = scalar_transport_case(7, 6, 5)
+    g = Geometry(case.mesh)
+    D = make(case)
+    n = case.states.size
+    psi = np.random.default_rng(1).standard_normal(n)
+    out = np.zeros(n)
+    D.solverAD.calcdRdWOldTPsiAD(1, psi, out)
+    # oracle: dR/dT_old by complex step (diagonal), transposed product
+    ref = np.zeros(n)
+    c2 = copy.copy(case)
+    for j in range(0, n, 7):  # sample of columns
+        To = case.T_old.astype(np.complex128)
+        To[j] += 1e-30j
+        c2.T_old = To
+        ref[j] = (residual(c2, g, case.states.astype(np.complex128)).imag / 1e-30) @ psi
+    idx = np.arange(0, n, 7)
+    assert relerr(out[idx], ref[idx]) < 1e-12
+    D.solverAD.calcdRdWOldTPsiAD(2, psi, out)
+    assert np.all(out == 0.0)
+    # new time level: residual follows the updated old-time field
+    T_old2 = case.T_old * 1.1 + 0.01
+    D.solver.setOldTimeFields(T_old=T_old2)
+    c2.T_old = T_old2
+    R = np.zeros(n)
+    D.solver.getResiduals(R)
+    assert relerr(R, residual(c2, g, case.states)) < 1e-13
+
+
 def test_gmres_failure_rule_and_restart():
     case = channel_case(6, 6, 5)
     g = Geometry(case.mesh)
