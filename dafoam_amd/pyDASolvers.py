@@ -239,8 +239,8 @@ class pyDASolvers:
             self._perm = self._cell_ordering_permutation()
         self.updateDAOption(pyOptions)
         self._define_functions(pyOptions.get("function") if isinstance(pyOptions, dict) else None)
-        if case.states is not None:
-            self.updateOFFields(np.ascontiguousarray(case.states, dtype=np.float64))
+        if case.states is not None:  # FoamCase.states is always in "state" ordering (input data)
+            check(lib().das_update_of_fields(self._h, dptr(np.ascontiguousarray(case.states, dtype=np.float64))))
 
     def __del__(self):
         try:
