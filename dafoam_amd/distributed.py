@@ -247,3 +247,168 @@ class ShardedAdjoint:
         if rc < 0:
             raise _capi.DASError(self.L.das_last_error().decode())
         return rc
+
+
+# =================================================================================================================
+# General (unstructured) partitions: sub-mesh extraction with ghost rings
+# =================================================================================================================
+def rcb_partition(centres, nparts):
+    """Recursive coordinate bisection of cell centres into `nparts` (power of two not required) balanced parts
+    (the reference decomposes with scotch, pyDAFoam.py:597-604)."""
+    part = np.zeros(len(centres), dtype=np.int32)
+
+    def rec(idx, p0, np_):
+        if np_ == 1:
+            part[idx] = p0
+            return
+        nl = np_ // 2
+        ext = centres[idx].max(0) - centres[idx].min(0)
+        d = int(np.argmax(ext))
+        o = np.argsort(centres[idx, d], kind="stable")
+        k = len(idx) * nl // np_
+        rec(idx[o[:k]], p0, nl)
+        rec(idx[o[k:]], p0 + nl, np_ - nl)
+
+    rec(np.arange(len(centres)), 0, nparts)
+    return part
+
+
+def extract_submesh(case, part, rank, G=GHOST_LAYERS):
+    """Extended sub-mesh of `rank`: owned cells (part == rank) + G rings of ghost cells, as a FoamCase in OpenFOAM
+    ordering.  Faces whose other cell lies outside the extended set become a trailing zero-gradient patch "ghostcut".
+    Returns (sub_case, info) with info: cell_g (local->global cell), face_g (local->global face), face_sign (+1/-1, -1 if
+    the local orientation is flipped), is_cut (local face), key / owner_rank / owned per extended state (global DAIndex
+    index as key)."""
+    import copy
+
+    import scipy.sparse as sp
+
+    from .meshgen import BC_ZERO_GRADIENT, NUT_CALCULATED, FoamCase, Patch, PolyMesh
+
+    m = case.mesh
+    N, F, nIF = m.n_cells, m.n_faces, m.n_internal_faces
+    own, nei = m.owner.astype(np.int64), m.neighbour.astype(np.int64)
+    A = sp.coo_matrix((np.ones(nIF, np.int8), (own[:nIF], nei)), shape=(N, N)).tocsr()
+    A = (A + A.T).tocsr()
+    ext = part == rank
+    for _ in range(G):
+        ext = ext | (A @ ext.astype(np.int8) > 0)
+    cell_g = np.nonzero(ext)[0]  # ascending global ids -> monotone renumbering keeps owner < neighbour
+    loc = np.full(N, -1, dtype=np.int64)
+    loc[cell_g] = np.arange(cell_g.size)
+    o_in = ext[own]
+    n_in = np.zeros(F, bool)
+    n_in[:nIF] = ext[nei]
+    f_int = np.nonzero(o_in[:nIF] & n_in[:nIF])[0]
+    lo, ln = loc[own[f_int]], loc[nei[f_int]]
+    order = np.lexsort((ln, lo))
+    f_int = f_int[order]
+    faces_g = [f_int]
+    signs = [np.ones(f_int.size)]
+    owners_l = [loc[own[f_int]]]
+    patches = []
+    start = f_int.size
+    for p in m.patches:
+        fs = np.arange(p.start, p.start + p.size)
+        fs = fs[o_in[fs]]
+        patches.append(Patch(p.name, p.type, start, fs.size))
+        faces_g.append(fs)
+        signs.append(np.ones(fs.size))
+        owners_l.append(loc[own[fs]])
+        start += fs.size
+    # cut faces: internal global faces with exactly one cell inside the extended set
+    cut_o = np.nonzero(o_in[:nIF] & ~n_in[:nIF])[0]  # inside cell is the global owner -> orientation kept
+    cut_n = np.nonzero(~o_in[:nIF] & n_in[:nIF])[0]  # inside cell is the global neighbour -> flip
+    fcut = np.concatenate([cut_o, cut_n])
+    scut = np.concatenate([np.ones(cut_o.size), -np.ones(cut_n.size)])
+    ocut = np.concatenate([loc[own[cut_o]], loc[nei[cut_n]]])
+    oc = np.lexsort((fcut, ocut))
+    patches.append(Patch("ghostcut", "patch", start, fcut.size))
+    faces_g.append(fcut[oc])
+    signs.append(scut[oc])
+    owners_l.append(ocut[oc])
+    face_g = np.concatenate(faces_g)
+    face_sign = np.concatenate(signs)
+    owner_l = np.concatenate(owners_l).astype(np.int32)
+    is_cut = np.zeros(face_g.size, bool)
+    is_cut[start:] = True
+    # face vertex lists (flip orientation where needed); compact the points
+    nv = np.diff(m.face_ptr)
+    assert np.all(nv == nv[0]), "extract_submesh handles uniform polygons (hex meshes)"
+    k = int(nv[0])
+    fp = m.face_pts.reshape(F, k)[face_g].copy()
+    flip = face_sign < 0
+    fp[flip] = fp[flip][:, ::-1]
+    used = np.unique(fp)
+    pmap = np.full(m.n_points, -1, dtype=np.int64)
+    pmap[used] = np.arange(used.size)
+    sub = PolyMesh(points=m.points[used].copy(), face_ptr=(k * np.arange(face_g.size + 1)).astype(np.int32),
+                   face_pts=np.ascontiguousarray(pmap[fp].ravel().astype(np.int32)), owner=owner_l,
+                   neighbour=loc[nei[f_int]].astype(np.int32), patches=patches)
+    # case data
+    sc = copy.copy(case)
+    sc.mesh = sub
+    sc.bcs = dict(case.bcs)
+    sc.bcs["ghostcut"] = {"U": (BC_ZERO_GRADIENT, (0.0, 0.0, 0.0)), "p": (BC_ZERO_GRADIENT, 0.0), "T": (BC_ZERO_GRADIENT, 0.0),
+                          "nuTilda": (BC_ZERO_GRADIENT, 0.0), "nut": (NUT_CALCULATED, 0.0)}
+    sc.y_wall = None if case.y_wall is None else case.y_wall[cell_g]
+    nl = cell_g.size
+    W = case.states
+    solver = case.solver_name
+    nsc = {"DASimpleFoam": 2, "DARhoSimpleFoam": 3}[solver]
+    blocks_g = [np.repeat(3 * cell_g, 3) + np.tile(np.arange(3), nl)] + [(3 + b) * N + cell_g for b in range(nsc)] + [(3 + nsc) * N + face_g]
+    key = np.concatenate(blocks_g)
+    sgn = np.concatenate([np.ones(key.size - face_g.size), face_sign])
+    sc.states = W[key] * sgn
+    crank = part[cell_g]
+    frank = np.where(is_cut, -1, part[own[face_g]])
+    owner_rank = np.concatenate([np.repeat(crank, 3)] + [crank] * nsc + [frank])
+    info = dict(cell_g=cell_g, face_g=face_g, face_sign=face_sign, is_cut=is_cut, key=key, owner_rank=owner_rank, owned=owner_rank == rank,
+                state_sign=sgn)
+    return sc, info
+
+
+class ShardedAdjointGeneral(ShardedAdjoint):
+    """Sharded adjoint for an ARBITRARY global case and cell partition vector (every rank holds the global case, e.g.
+    read with dafoam_amd.foam_io.read_case, extracts its extended sub-mesh and proceeds like ShardedAdjoint)."""
+
+    def __init__(self, global_case, part, options, device_index=0):
+        import torch
+        import torch.distributed as dist
+
+        from . import _capi
+        from .pyDAFoam import PYDAFOAM
+
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        assert int(part.max()) + 1 <= self.world
+        case, info = extract_submesh(global_case, np.asarray(part), self.rank)
+        self.case, self.info = case, info
+        self.key, self.owner_rank, self.owned = info["key"], info["owner_rank"], info["owned"]
+        opts = dict(options)
+        opts["amdDevice"] = device_index
+        self.D = PYDAFOAM(options=opts, case=case)
+        L = self.L = _capi.lib()
+        h = self.h = self.D.solver._h
+        mask = np.ascontiguousarray(self.owned.astype(np.uint8))
+        _capi.check(L.das_set_owned_mask(h, mask.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        self.dev = torch.device("cuda", device_index)
+        self.halo = HaloExchange(self.key, self.owner_rank, self.rank, self.world, device=self.dev)
+        _capi.check(L.das_set_stream(h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+        n = self.n = self.key.size
+        stage = dist.get_backend() == "gloo"
+
+        def halo_cb(ptr, _user):
+            self.halo.reduce_(torch.as_tensor(_DevPtr(ptr, n), device=self.dev))
+
+        def ared_cb(ptr, m_, _user):
+            t = torch.as_tensor(_DevPtr(ptr, m_), device=self.dev)
+            if stage:
+                c = t.cpu()
+                dist.all_reduce(c)
+                t.copy_(c)
+            else:
+                dist.all_reduce(t)
+
+        self._cb = (_HALO_CB(halo_cb), _ARED_CB(ared_cb))
+        _capi.check(L.das_set_comm(h, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
+        self.n_owned = int(self.owned.sum())

@@ -64,6 +64,65 @@ def _worker(rank, world, port, q, gstate):
         dist.destroy_process_group()
 
 
+def _worker_general(rank, world, port, q, gcase, part):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from dafoam_amd.distributed import ShardedAdjointGeneral
+
+        S = ShardedAdjointGeneral(gcase, part, OPTS, device_index=0)
+        S.setup()
+        rhs = np.zeros(S.n)
+        N = gcase.mesh.n_cells
+        ux = (S.key < 3 * N) & (S.key % 3 == 0)
+        rhs[ux] = 1.0 + 0.5 * np.sin(1e-2 * (S.key[ux] // 3))
+        psi, fail = S.solve(rhs)
+        info = S.ksp.info()
+        q.put((rank, S.key[S.owned], psi[S.owned], fail, info["iters"], info["res"] / info["res0"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_general_partition_unstructured():
+    """RCB partition of a randomly renumbered mesh through extract_submesh (no structured assumption)."""
+    import torch.multiprocessing as mp
+
+    from dafoam_amd.distributed import rcb_partition
+    from dafoam_amd.meshgen import renumber_case
+    from dafoam_amd.pyDAFoam import PYDAFOAM
+    from oracle.foam_mesh import Geometry
+
+    gcase = renumber_case(_converged_global(), seed=4)
+    part = rcb_partition(Geometry(gcase.mesh).C, 2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_general, args=(r, 2, port, q, gcase, part)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    n = gcase.states.size
+    N = gcase.mesh.n_cells
+    rhs = np.zeros(n)
+    rhs[0 : 3 * N : 3] = 1.0 + 0.5 * np.sin(1e-2 * np.arange(N))
+    D = PYDAFOAM(options=OPTS, case=gcase)
+    psi_g, fail_g = D.solveAdjoint(rhs)
+    assert fail_g == 0, D.ksp.info()
+    psi_s = np.full(n, np.nan)
+    for rank, keys, psi, fail, iters, relres in res:
+        assert fail == 0 and relres < 1e-8, (rank, fail, iters, relres)
+        psi_s[keys] = psi
+    assert not np.isnan(psi_s).any() and relerr(psi_s, psi_g) <= 1e-6
+
+
 def test_two_rank_sharded_adjoint_matches_single_domain():
     import torch.multiprocessing as mp
 
