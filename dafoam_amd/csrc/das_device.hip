@@ -216,10 +216,13 @@ __global__ void k_compact(long long n, const long long* __restrict__ rp, const i
 // workgroups.  The matrix is streamed exactly once (non-temporal loads, so that it does not evict the gathered x
 // entries from the per-XCD L2); x is gathered through L2.
 #ifndef SPMV_LANES
-#define SPMV_LANES 32
+#define SPMV_LANES 16
 #endif
 #ifndef SPMV_NT
 #define SPMV_NT 0
+#endif
+#ifndef SPMV_UNROLL
+#define SPMV_UNROLL 4
 #endif
 __global__ __launch_bounds__(256) void k_spmv_wave(long long n, const long long* __restrict__ rp, const int* __restrict__ ci,
                                                    const double* __restrict__ v, const double* __restrict__ x, double* __restrict__ y) {
@@ -228,27 +231,31 @@ __global__ __launch_bounds__(256) void k_spmv_wave(long long n, const long long*
     const int lane = threadIdx.x % SPMV_LANES;
     if (row >= n) return;
     const long long b = rp[row], e = rp[row + 1];
-    double s0 = 0.0, s1 = 0.0;
+    double acc[SPMV_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SPMV_UNROLL; u++) acc[u] = 0.0;
     long long k = b + lane;
-    for (; k + SPMV_LANES < e; k += 2 * SPMV_LANES) {
+    // main loop: SPMV_UNROLL independent (value, column, x) gathers in flight per lane
+    for (; k + (SPMV_UNROLL - 1) * SPMV_LANES < e; k += SPMV_UNROLL * SPMV_LANES) {
+        double vv[SPMV_UNROLL];
+        int cc[SPMV_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SPMV_UNROLL; u++) {
 #if SPMV_NT
-        const double v0 = __builtin_nontemporal_load(v + k), v1 = __builtin_nontemporal_load(v + k + SPMV_LANES);
-        const int c0 = __builtin_nontemporal_load(ci + k), c1 = __builtin_nontemporal_load(ci + k + SPMV_LANES);
+            vv[u] = __builtin_nontemporal_load(v + k + u * SPMV_LANES);
+            cc[u] = __builtin_nontemporal_load(ci + k + u * SPMV_LANES);
 #else
-        const double v0 = v[k], v1 = v[k + SPMV_LANES];
-        const int c0 = ci[k], c1 = ci[k + SPMV_LANES];
+            vv[u] = v[k + u * SPMV_LANES];
+            cc[u] = ci[k + u * SPMV_LANES];
 #endif
-        s0 += v0 * x[c0];
-        s1 += v1 * x[c1];
+        }
+#pragma unroll
+        for (int u = 0; u < SPMV_UNROLL; u++) acc[u] += vv[u] * x[cc[u]];
     }
-    if (k < e) {
-#if SPMV_NT
-        s0 += __builtin_nontemporal_load(v + k) * x[__builtin_nontemporal_load(ci + k)];
-#else
-        s0 += v[k] * x[ci[k]];
-#endif
-    }
-    double sacc = s0 + s1;
+    for (; k < e; k += SPMV_LANES) acc[0] += v[k] * x[ci[k]];
+    double sacc = acc[0];
+#pragma unroll
+    for (int u = 1; u < SPMV_UNROLL; u++) sacc += acc[u];
 #pragma unroll
     for (int o = SPMV_LANES / 2; o > 0; o >>= 1) sacc += __shfl_down(sacc, o, SPMV_LANES);
     if (lane == 0) y[row] = sacc;
