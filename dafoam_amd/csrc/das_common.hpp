@@ -109,6 +109,9 @@ struct PatchBC {  // per patch, small table
     int U_code, p_code, nuTilda_code, nut_code, T_code;
     double U_val[3];
     double p_val, nuTilda_val, T_val;
+    // tangent of the patch values (forward-mode seed for dR/d(BC value); zero except inside das_calc_drdbc)
+    double dU_val[3];
+    double dp_val, dnuTilda_val, dT_val;
 };
 
 // ---- host mesh (fvMesh equivalent) ------------------------------------------------------------

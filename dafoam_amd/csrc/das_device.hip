@@ -54,6 +54,29 @@ __global__ __launch_bounds__(256) void k_force_value(DevMesh m, ResParams prm, c
     double v = body_force<double, RHO>(faces[k], m, prm, W, nut, gU, dir, scale);
     atomicAdd(out, v);
 }
+// tangent of the force for seeded boundary values (dF/d(BC value), one forward pass)
+template <bool RHO>
+__global__ __launch_bounds__(256) void k_force_tangent(DevMesh m, ResParams prm, const Dual<1>* __restrict__ W, const Dual<1>* nut, const Dual<1>* gU,
+                                                       const int* __restrict__ faces, int nfaces, double d0, double d1, double d2, double scale, double* out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nfaces) return;
+    double dir[3] = {d0, d1, d2};
+    Dual<1> v = body_force<Dual<1>, RHO>(faces[k], m, prm, W, nut, gU, dir, scale);
+    if (v.d[0] != 0.0) atomicAdd(out, v.d[0]);
+}
+// out += sum_i psi_i * dR_i  (dR = tangent part of a dual residual)
+__global__ __launch_bounds__(256) void k_tangent_dot(long long n, const Dual<1>* __restrict__ R, const double* __restrict__ psi, double* out) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += psi[i] * R[i].d[0];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, sh[0]);
+}
 // the derivative of F_f w.r.t. the (unique) state of colour `col` in the stencil of face f (cell c and its face
 // neighbours: U, p, (T), nuTilda) is accumulated into dFdW
 template <bool RHO>
@@ -146,6 +169,22 @@ __global__ void k_seed(long long n, const double* __restrict__ W, const int* __r
     int c = colors[j] - c0;
     if (c >= 0 && c < K) w.d[c] = scale[j];
     Wd[j] = w;
+}
+__global__ void k_lift(long long n, const double* __restrict__ W, Dual<1>* Wd) {
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) Wd[j] = Dual<1>(W[j]);
+}
+// W + eps (s o v): tangent = s_j v_j (forward-mode directional derivative dR/dW . (s o v))
+__global__ void k_seed_dir(long long n, const double* __restrict__ W, const double* __restrict__ scale, const double* __restrict__ v, Dual<1>* Wd) {
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    Dual<1> w(W[j]);
+    w.d[0] = scale[j] * v[j];
+    Wd[j] = w;
+}
+__global__ void k_tangent_out(long long n, const Dual<1>* __restrict__ R, double* out) {
+    long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = R[j].d[0];
 }
 __global__ void k_perturb(long long n, const double* __restrict__ W, const int* __restrict__ colors, const double* __restrict__ scale, int c,
                           double delta, double* Wp) {
@@ -1655,6 +1694,108 @@ static void function_gradient(das_solver* s, const char* name, double seed, doub
 
 long long das_op_nnz(das_solver_t* s) { return (s && s->op) ? s->op->m.nnz : -1; }
 
+// ---- boundary-value inputs (reference DAInputPatchVelocity.C:33-135, DAInputPatchVar.C) ---------------------------
+static int bc_field_id(const char* field) {
+    std::string f = field ? field : "";
+    if (f == "U") return 0;
+    if (f == "p") return 1;
+    if (f == "nuTilda") return 2;
+    if (f == "T") return 3;
+    throw Error(DAS_ERR_ARG, "patch field not supported: " + f);
+}
+static void check_patches(das_solver* s, const int* patches, int np) {
+    DAS_CHECK(patches && np > 0, DAS_ERR_ARG, "no patches given");
+    for (int i = 0; i < np; i++) DAS_CHECK(patches[i] >= 0 && patches[i] < s->mesh.nPatch, DAS_ERR_ARG, "patch id out of range");
+}
+int das_set_patch_value(das_solver_t* s, const int* patches, int np, const char* field, const double* value) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(value, DAS_ERR_ARG, "null value");
+    check_patches(s, patches, np);
+    const int fid = bc_field_id(field);
+    for (int i = 0; i < np; i++) {
+        PatchBC& b = s->mesh.bc[patches[i]];
+        const int code = fid == 0 ? b.U_code : fid == 1 ? b.p_code : fid == 2 ? b.nuTilda_code : b.T_code;
+        // the reference accepts fixedValue and inletOutlet patches only (DAInputPatchVelocity.C:84-131)
+        DAS_CHECK(code == DAS_BC_FIXED_VALUE || code == DAS_BC_INLET_OUTLET, DAS_ERR_ARG,
+                  "patch type not valid! only support fixedValue or inletOutlet");
+        if (fid == 0) for (int k = 0; k < 3; k++) b.U_val[k] = value[k];
+        else if (fid == 1) b.p_val = value[0];
+        else if (fid == 2) b.nuTilda_val = value[0];
+        else b.T_val = value[0];
+    }
+    DAS_HIP(hipStreamSynchronize(s->stream));
+    s->d_bc.upload(s->mesh.bc);
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_get_patch_value(das_solver_t* s, int patch, const char* field, double* value) {
+    DAS_TRY
+    DAS_CHECK(s && value, DAS_ERR_ARG, "null argument");
+    check_patches(s, &patch, 1);
+    const int fid = bc_field_id(field);
+    const PatchBC& b = s->mesh.bc[patch];
+    if (fid == 0) for (int k = 0; k < 3; k++) value[k] = b.U_val[k];
+    else value[0] = fid == 1 ? b.p_val : fid == 2 ? b.nuTilda_val : b.T_val;
+    return DAS_OK;
+    DAS_CATCH
+}
+// product = seeds^T (dOutput/d(patch value) . tangent): ONE forward-mode pass of the residual (or of the objective)
+// with the tangent seeded in the patch table -- the scalar-input counterpart of the coloured state Jacobian.
+int das_calc_dbc_product(das_solver_t* s, const int* patches, int np, const char* field, const double* tangent, const char* outputName,
+                         const char* outputType, const double* seeds, double* product) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(tangent && outputType && seeds && product, DAS_ERR_ARG, "null argument");
+    check_patches(s, patches, np);
+    const int fid = bc_field_id(field);
+    const std::string ot = outputType;
+    DAS_CHECK(ot == "residual" || ot == "function", DAS_ERR_ARG, "outputType not supported on this path: " + ot);
+    std::vector<PatchBC> bc = s->mesh.bc;
+    for (int i = 0; i < np; i++) {
+        PatchBC& b = bc[patches[i]];
+        if (fid == 0) for (int k = 0; k < 3; k++) b.dU_val[k] = tangent[k];
+        else if (fid == 1) b.dp_val = tangent[0];
+        else if (fid == 2) b.dnuTilda_val = tangent[0];
+        else b.dT_val = tangent[0];
+    }
+    const long long n = s->n;
+    const int B = 256;
+    hipStream_t st = s->stream;
+    DAS_HIP(hipStreamSynchronize(st));
+    s->d_bc.upload(bc);
+    struct Restore {
+        das_solver* s;
+        ~Restore() { (void)hipStreamSynchronize(s->stream); s->d_bc.upload(s->mesh.bc); }
+    } restore{s};
+    ResParams prm = make_params(s->cp, s->opt, 0);
+    const bool rho = s->cp.solver == DAS_SOLVER_RHOSIMPLEFOAM;
+    if (s->d_Wd.n != (size_t)n) { s->d_Wd.alloc(n); s->d_Rd.alloc(n); }
+    hipLaunchKernelGGL(k_lift, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_W.p, s->d_Wd.p);  // states carry no tangent
+    DAS_HIP(hipMemsetAsync(s->d_tmp1.p, 0, sizeof(double), st));
+    if (ot == "residual") {
+        eval_residual<Dual<1>>(s->dm, s->cp, prm, s->d_Wd.p, s->d_Rd.p, s->wk1, s->d_phiF.p, s->d_Told.p, st);
+        DAS_HIP(hipMemcpyAsync(s->d_tmp2.p, seeds, n * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_tangent_dot, dim3(1024), dim3(256), 0, st, n, s->d_Rd.p, s->d_tmp2.p, s->d_tmp1.p);
+    } else {
+        das_solver::ForceFn& fn = get_function(s, outputName);
+        s->wk1.ensure(s->cp.solver, s->dm.nC, s->dm.nF);
+        const int nf = (int)fn.faces.size();
+        if (rho) {
+            hipLaunchKernelGGL((k_grad<Dual<1>, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
+            hipLaunchKernelGGL((k_force_tangent<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale * seeds[0], s->d_tmp1.p);
+        } else {
+            hipLaunchKernelGGL((k_grad<Dual<1>, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, (Dual<1>*)nullptr);
+            hipLaunchKernelGGL((k_force_tangent<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale * seeds[0], s->d_tmp1.p);
+        }
+    }
+    DAS_HIP(hipGetLastError());
+    DAS_HIP(hipMemcpyAsync(product, s->d_tmp1.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
+    return DAS_OK;
+    DAS_CATCH
+}
+
 int das_get_input_size(das_solver_t* s, const char* inputName, const char* inputType) {
     DAS_TRY
     DAS_CHECK(s && inputType, DAS_ERR_ARG, "null argument");
@@ -1693,6 +1834,27 @@ int das_calc_jac_t_vec_product(das_solver_t* s, const char* inputName, const cha
     spmv(s, A->m, s->d_tmp1.p, s->d_tmp2.p);
     DAS_HIP(hipMemcpyAsync(product, s->d_tmp2.p, s->n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     DAS_HIP(hipStreamSynchronize(s->stream));
+    return DAS_OK;
+    DAS_CATCH
+}
+// product_i = sum_j dR_i/dW_j s_j v_j : ONE forward-mode residual pass, no colouring, no matrix (the untransposed
+// companion of dRdW^T psi; exact, so  a.(J v) == (J^T a).v  holds to round-off and checks colouring + scatter maps)
+int das_calc_jac_vec_product(das_solver_t* s, const double* v, double* product) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(v && product, DAS_ERR_ARG, "null argument");
+    const long long n = s->n;
+    const int B = 256;
+    hipStream_t st = s->stream;
+    ResParams prm = make_params(s->cp, s->opt, 0);
+    if (s->d_Wd.n != (size_t)n) { s->d_Wd.alloc(n); s->d_Rd.alloc(n); }
+    DAS_HIP(hipMemcpyAsync(s->d_tmp1.p, v, n * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_seed_dir, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_W.p, s->d_scale.p, s->d_tmp1.p, s->d_Wd.p);
+    eval_residual<Dual<1>>(s->dm, s->cp, prm, s->d_Wd.p, s->d_Rd.p, s->wk1, s->d_phiF.p, s->d_Told.p, st);
+    hipLaunchKernelGGL(k_tangent_out, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_Rd.p, s->d_tmp2.p);
+    DAS_HIP(hipGetLastError());
+    DAS_HIP(hipMemcpyAsync(product, s->d_tmp2.p, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
     return DAS_OK;
     DAS_CATCH
 }

@@ -101,6 +101,11 @@ template <int K> DAS_HD Dual<K>& operator-=(Dual<K>& a, double b) { a.v -= b; re
 template <int K> DAS_HD Dual<K>& operator*=(Dual<K>& a, const Dual<K>& b) { a = a * b; return a; }
 template <int K> DAS_HD Dual<K>& operator*=(Dual<K>& a, double b) { a = a * b; return a; }
 
+// value with a prescribed first tangent (forward-mode seeding of parameters, e.g. boundary values)
+template <class T> struct MkSeed;
+template <> struct MkSeed<double> { static DAS_HD double make(double v, double) { return v; } };
+template <int K> struct MkSeed<Dual<K>> { static DAS_HD Dual<K> make(double v, double dv) { Dual<K> r(v); r.d[0] = dv; return r; } };
+
 // elementary functions (generic names usable with double as well)
 DAS_HD double dsqrt(double a) { return sqrt(a); }
 DAS_HD double dexp(double a) { return exp(a); }

@@ -73,17 +73,19 @@ DAS_HD T fv1_of(const T& chi) {
 template <class T>
 struct ScalarBC {
     T xb;
-    double vic, vbc, gic, gbc;
+    double vic, gic;
+    T vbc, gbc;  // carry the tangent of the patch value (dR/d(BC value) seeds)
 };
 template <class T>
-DAS_HD void bc_scalar(int code, double value, double delta, double phib, const T& xc, ScalarBC<T>& o) {
+DAS_HD void bc_scalar(int code, double value, double dvalue, double delta, double phib, const T& xc, ScalarBC<T>& o) {
     double f = 0.0;
     if (code == DAS_BC_FIXED_VALUE) f = 1.0;
     else if (code == DAS_BC_INLET_OUTLET) f = phib >= 0.0 ? 0.0 : 1.0;
+    const T val = MkSeed<T>::make(value, dvalue);
     o.vic = 1.0 - f;
-    o.vbc = f * value;
+    o.vbc = f * val;
     o.gic = -f * delta;
-    o.gbc = f * delta * value;
+    o.gbc = (f * delta) * val;
     o.xb = o.vic * xc + o.vbc;
 }
 template <class T>
@@ -93,7 +95,7 @@ struct VectorBC {
     T vbc[3], gbc[3];
 };
 template <class T>
-DAS_HD void bc_vector(int code, const double* value, double delta, double phib, const double* n, const T* Xc, VectorBC<T>& o) {
+DAS_HD void bc_vector(int code, const double* value, const double* dvalue, double delta, double phib, const double* n, const T* Xc, VectorBC<T>& o) {
     if (code == DAS_BC_SYMMETRY) {
         // basicSymmetry/transformFvPatchField: x_b = X - n (n.X); snGradTransformDiag = |n|
         T nX = n[0] * Xc[0] + n[1] * Xc[1] + n[2] * Xc[2];
@@ -113,10 +115,11 @@ DAS_HD void bc_vector(int code, const double* value, double delta, double phib, 
     else if (code == DAS_BC_INLET_OUTLET) f = phib >= 0.0 ? 0.0 : 1.0;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
+        const T val = MkSeed<T>::make(value[k], dvalue[k]);
         o.vic[k] = 1.0 - f;
-        o.vbc[k] = T(f * value[k]);
+        o.vbc[k] = f * val;
         o.gic[k] = -f * delta;
-        o.gbc[k] = T(f * delta * value[k]);
+        o.gbc[k] = (f * delta) * val;
         o.xb[k] = o.vic[k] * Xc[k] + o.vbc[k];
     }
 }
@@ -157,13 +160,13 @@ DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc
                        const T& Tc, const T& nc, const T& nut_c, double phib, BFace<T>& o) {
 #pragma unroll
     for (int k = 0; k < 3; k++) o.nrm[k] = g.Sf[k] / g.magSf;
-    bc_vector<T>(bc.U_code, bc.U_val, g.nod, phib, o.nrm, Uc, o.U);
-    bc_scalar<T>(bc.p_code, bc.p_val, g.nod, phib, pc, o.p);
-    bc_scalar<T>(bc.nuTilda_code, bc.nuTilda_val, g.nod, phib, nc, o.n);
+    bc_vector<T>(bc.U_code, bc.U_val, bc.dU_val, g.nod, phib, o.nrm, Uc, o.U);
+    bc_scalar<T>(bc.p_code, bc.p_val, bc.dp_val, g.nod, phib, pc, o.p);
+    bc_scalar<T>(bc.nuTilda_code, bc.nuTilda_val, bc.dnuTilda_val, g.nod, phib, nc, o.n);
     if (RHO) {
-        bc_scalar<T>(bc.T_code, bc.T_val, g.nod, phib, Tc, o.Tt);
+        bc_scalar<T>(bc.T_code, bc.T_val, bc.dT_val, g.nod, phib, Tc, o.Tt);
         T hec = prm.Cp * (Tc - DAS_TREF);
-        bc_scalar<T>(bc.T_code, prm.Cp * (bc.T_val - DAS_TREF), g.nod, phib, hec, o.he);
+        bc_scalar<T>(bc.T_code, prm.Cp * (bc.T_val - DAS_TREF), prm.Cp * bc.dT_val, g.nod, phib, hec, o.he);
         o.rho_b = o.p.xb / (prm.Rgas * o.Tt.xb);
         o.nu_b = prm.mu / o.rho_b;
     } else {
@@ -625,7 +628,7 @@ DAS_HD void body_gradT(int c, const DevMesh& m, const ResParams& prm, const T* W
         } else {
             const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
             ScalarBC<T> b;
-            bc_scalar<T>(bc.T_code, bc.T_val, g.nod, phiF[f], Tc, b);
+            bc_scalar<T>(bc.T_code, bc.T_val, bc.dT_val, g.nod, phiF[f], Tc, b);
             Tf = b.xb;
         }
 #pragma unroll
@@ -667,7 +670,7 @@ DAS_HD void body_T(int c, const DevMesh& m, const ResParams& prm, const T* W, co
         } else {
             const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
             ScalarBC<T> b;
-            bc_scalar<T>(bc.T_code, bc.T_val, g.nod, phi, Tc, b);
+            bc_scalar<T>(bc.T_code, bc.T_val, bc.dT_val, g.nod, phi, Tc, b);
             double gam_b = prm.DT * g.magSf;
             bd += phi * b.vic - gam_b * b.gic;
             bs += gam_b * b.gbc - phi * b.vbc;

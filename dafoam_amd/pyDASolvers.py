@@ -239,6 +239,7 @@ class pyDASolvers:
             self._perm = self._cell_ordering_permutation()
         self.updateDAOption(pyOptions)
         self._define_functions(pyOptions.get("function") if isinstance(pyOptions, dict) else None)
+        self._inputInfo = dict(pyOptions.get("inputInfo") or {}) if isinstance(pyOptions, dict) else {}
         if case.states is not None:  # FoamCase.states is always in "state" ordering (input data)
             check(lib().das_update_of_fields(self._h, dptr(np.ascontiguousarray(case.states, dtype=np.float64))))
 
@@ -336,7 +337,59 @@ class pyDASolvers:
         return int(lib().das_get_n_local_points(self._h))
 
     def getInputSize(self, inputName, inputType):
+        if inputType == "patchVelocity":  # [UMag, AoA(deg)]  (reference DAInputPatchVelocity.H size() = 2)
+            return 2
+        if inputType == "patchVar":  # reference DAInputPatchVar.H: 1 (scalar) or 3 (vector)
+            return 3 if self._input_entry(inputName, inputType)["varType"] == "vector" else 1
         return check(lib().das_get_input_size(self._h, inputName.encode(), inputType.encode()))
+
+    # -- boundary-value inputs (reference src/adjoint/DAInput/DAInputPatchVelocity.C, DAInputPatchVar.C) ---------
+    def _input_entry(self, inputName, inputType):
+        if inputName not in self._inputInfo:
+            raise _capi.DASError(f"inputInfo has no entry {inputName}")
+        e = self._inputInfo[inputName]
+        if e.get("type") != inputType:
+            raise _capi.DASError(f"inputInfo[{inputName}].type is {e.get('type')}, not {inputType}")
+        if inputType == "patchVar" and e.get("varType") not in ("scalar", "vector"):
+            raise _capi.DASError("varType not valid")
+        return e
+
+    def _patch_ids(self, entry):
+        names = [p.name for p in self._case.mesh.patches]
+        return np.array([names.index(p) for p in entry["patches"]], dtype=np.int32)
+
+    def _patch_input_tangents(self, inputName, inputType, inputs):
+        """(field, value[3], [tangent_i[3] for each input component])"""
+        e = self._input_entry(inputName, inputType)
+        if inputType == "patchVelocity":
+            ax = {"x": 0, "y": 1, "z": 2}
+            fi, ni = ax[e["flowAxis"]], ax[e["normalAxis"]]
+            ids = self._patch_ids(e)
+            cur = np.zeros(3)
+            check(lib().das_get_patch_value(self._h, int(ids[0]), b"U", dptr(cur)))
+            a = float(inputs[1]) * np.pi / 180.0
+            val = cur.copy()
+            val[fi], val[ni] = inputs[0] * np.cos(a), inputs[0] * np.sin(a)
+            t_mag, t_aoa = np.zeros(3), np.zeros(3)
+            t_mag[fi], t_mag[ni] = np.cos(a), np.sin(a)
+            t_aoa[fi], t_aoa[ni] = -inputs[0] * np.sin(a) * np.pi / 180.0, inputs[0] * np.cos(a) * np.pi / 180.0
+            return "U", val, [t_mag, t_aoa]
+        name = e["varName"]
+        if e["varType"] == "vector":
+            return name, np.asarray(inputs, dtype=np.float64).copy(), [np.eye(3)[k].copy() for k in range(3)]
+        return name, np.array([float(inputs[0]), 0.0, 0.0]), [np.array([1.0, 0.0, 0.0])]
+
+    def setSolverInput(self, inputName, inputType, inputSize, inputs, seeds=None):
+        """DAInput::run (reference pyDASolvers.pyx:164-182): assign the input to the solver.  (Forward-mode seeds
+        belong to the reference's ADF build and are ignored here.)"""
+        assert len(inputs) == inputSize, "invalid input array size!"
+        if inputType == "stateVar":
+            return self.updateOFFields(np.ascontiguousarray(inputs, dtype=np.float64))
+        if inputType not in ("patchVelocity", "patchVar"):
+            raise _capi.DASError(f"inputType not supported on this path: {inputType}")
+        field, val, _ = self._patch_input_tangents(inputName, inputType, inputs)
+        ids = self._patch_ids(self._inputInfo[inputName])
+        check(lib().das_set_patch_value(self._h, ids.ctypes.data_as(_capi.c_int_p), ids.size, field.encode(), dptr(np.ascontiguousarray(val))))
 
     def getOutputSize(self, outputName, outputType):
         return check(lib().das_get_output_size(self._h, outputName.encode(), outputType.encode()))
@@ -424,10 +477,30 @@ class pyDASolvers:
         assert len(seeds) == outputSize, "invalid seed array size!"
         assert len(product) == inputSize, "invalid product array size!"
         seeds_s = np.ascontiguousarray(self._to_state(seeds)) if outputType == "residual" else seeds
+        if inputType in ("patchVelocity", "patchVar"):
+            # run(input), then one forward-mode pass per input component
+            self.setSolverInput(inputName, inputType, inputSize, inputs)
+            field, _, tangents = self._patch_input_tangents(inputName, inputType, inputs)
+            ids = self._patch_ids(self._inputInfo[inputName])
+            out = C.c_double(0.0)
+            for i, t in enumerate(tangents):
+                check(lib().das_calc_dbc_product(self._h, ids.ctypes.data_as(_capi.c_int_p), ids.size, field.encode(), dptr(np.ascontiguousarray(t)),
+                                                 outputName.encode(), outputType.encode(), dptr(np.ascontiguousarray(seeds_s, dtype=np.float64)), C.byref(out)))
+                product[i] = out.value
+            return
         tmp = np.zeros(len(product)) if self._perm is not None else product
         check(lib().das_calc_jac_t_vec_product(
             self._h, inputName.encode(), inputType.encode(), dptr(np.ascontiguousarray(self._to_state(inputs))), outputName.encode(),
             outputType.encode(), dptr(seeds_s), dptr(tmp)))
+        self._from_state(tmp, product)
+
+    def calcJacVecProduct(self, v, product):
+        """Forward-mode dR/dW (s o v) at the current states: one dual-number residual pass (no colouring, no matrix)."""
+        n = self.getNLocalAdjointStates()
+        assert len(v) == n, "invalid input array size!"
+        assert len(product) == n, "invalid product array size!"
+        tmp = np.zeros(n) if self._perm is not None else product
+        check(lib().das_calc_jac_vec_product(self._h, dptr(np.ascontiguousarray(self._to_state(v))), dptr(tmp)))
         self._from_state(tmp, product)
 
     def calcdRdWOldTPsiAD(self, oldTimeLevel, psi, dRdWOldTPsi):

@@ -176,6 +176,21 @@ int das_set_old_time_fields(das_solver_t* s, const double* phi_frozen /* n_faces
  * das_define_force_function <- the "function" option entry {type: force, patches, directionMode: fixedDirection,
  *     direction, scale} consumed by DAFunctionForce (reference src/adjoint/DAFunction/DAFunctionForce.C:20-77)
  * das_calc_function         <- calcFunction(functionName)  pyDASolvers.pyx (DAFunctionForce::calcFunction :79-158) */
+/* das_calc_jac_vec_product <- the forward-mode (ADF build) directional derivative of the residuals, DASolver.C:1364-1441
+ *                             run forward: product_i = sum_j dR_i/dW_j s_j v_j at the current states.  One dual-number
+ *                             residual pass; no colouring and no matrix are involved. */
+int das_calc_jac_vec_product(das_solver_t* s, const double* v, double* product);
+/* Boundary-value design inputs.
+ * das_set_patch_value   <- DAInputPatchVelocity::run / DAInputPatchVar::run (src/adjoint/DAInput/DAInputPatchVelocity.C:33-135):
+ *                          assigns the (ref)value of fixedValue / inletOutlet patches; any other patch type is an error.
+ *                          field: "U" (value[3]) | "p" | "nuTilda" | "T" (value[1]).
+ * das_calc_dbc_product  <- calcJacTVecProduct(inputType = patchVelocity | patchVar) pyDASolvers.pyx:208-235:
+ *                          product[0] = seeds^T (dOutput/d(patch value) . tangent), outputType "residual" (seeds: n,
+ *                          host) or "function" (seeds: 1).  One forward-mode (dual number) pass. */
+int das_set_patch_value(das_solver_t* s, const int* patch_ids, int npatch, const char* field, const double* value);
+int das_get_patch_value(das_solver_t* s, int patch_id, const char* field, double* value);
+int das_calc_dbc_product(das_solver_t* s, const int* patch_ids, int npatch, const char* field, const double* tangent, const char* outputName,
+                         const char* outputType, const double* seeds, double* product);
 int das_define_force_function(das_solver_t* s, const char* name, const int* patch_ids, int npatch, const double* direction, double scale);
 int das_calc_function(das_solver_t* s, const char* name, double* value);
 

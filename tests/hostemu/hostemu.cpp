@@ -54,3 +54,28 @@ extern "C" int emu_residual(const das_case_t* c, const double* Win, long long n,
         return -1;
     }
 }
+
+// dR/d(patch value).tangent through the dual-number BC seeds (the product path's das_calc_dbc_product pass)
+extern "C" int emu_residual_bc(const das_case_t* c, const double* Win, long long n, int patch, int field, const double* tangent, double* Rd) {
+    try {
+        Mesh mesh;
+        mesh.build(c);
+        CaseParams cp;
+        cp.from_case(c);
+        Options opt;
+        ResParams prm = make_params(cp, opt, 0);
+        PatchBC& b = mesh.bc[patch];
+        if (field == 0) for (int k = 0; k < 3; k++) b.dU_val[k] = tangent[k];
+        else if (field == 1) b.dp_val = tangent[0];
+        else if (field == 2) b.dnuTilda_val = tangent[0];
+        else b.dT_val = tangent[0];
+        std::vector<Dual<1>> W(n), R(n);
+        for (long long i = 0; i < n; i++) W[i] = Dual<1>(Win[i]);
+        eval<Dual<1>>(mesh, cp, prm, W, R);
+        for (long long i = 0; i < n; i++) Rd[i] = R[i].d[0];
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "emu_residual_bc: %s\n", e.what());
+        return -1;
+    }
+}

@@ -329,6 +329,130 @@ def test_ras_ilu_apply_matches_oracle(dims, block, overlap, fill, fp32):
     assert relerr(y, y_o) < (1e-2 if fp32 else 1e-9)  # fp32 factor storage: preconditioner-only approximation
 
 
+def _with_inlet(case, Umag, aoa_deg):
+    import copy
+
+    c2 = copy.copy(case)
+    c2.bcs = copy.deepcopy(case.bcs)
+    a = aoa_deg * np.pi / 180.0
+    c2.bcs["inlet"]["U"] = (case.bcs["inlet"]["U"][0], (Umag * np.cos(a), Umag * np.sin(a), 0.0))
+    return c2
+
+
+def test_total_derivative_patch_velocity_vs_primal_fd():
+    """End to end, like the reference's regression tests (tests/runRegTests_DASimpleFoam*.py compare adjoint totals
+    with forward-mode totals): dCD/d[UMag, AoA] = dF/dx - psi^T dR/dx from the GPU adjoint
+    (calcJacTVecProduct patchVelocity -> function/residual, DAInputPatchVelocity.C:33-135) against central
+    differences of the oracle's CONVERGED primal.  Also checks each partial against the oracle."""
+    from oracle.functions import force
+    from oracle.primal import solve_primal
+
+    case = converged_case((10, 8, 6), lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    W = case.states
+    walls = [p.name for p in case.mesh.patches if p.type == "wall"]
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-12, "gmresAbsTol": 1e-16, "gmresMaxIters": 400, "printInfo": 0},
+             function={"CD": {"type": "force", "source": "patchToFace", "patches": walls, "directionMode": "fixedDirection",
+                              "direction": [1.0, 0.0, 0.0], "scale": 1.0}},
+             inputInfo={"patchV": {"type": "patchVelocity", "patches": ["inlet"], "flowAxis": "x", "normalAxis": "y"}})
+    n = W.size
+    x0 = np.array([10.0, 0.0])
+    assert D.solverAD.getInputSize("patchV", "patchVelocity") == 2
+    dFdW = np.zeros(n)
+    D.solverAD.calcJacTVecProduct("states", "stateVar", W, "CD", "function", np.ones(1), dFdW)
+    psi, fail = D.solveAdjoint(dFdW)
+    assert fail == 0
+    dFdx, pRx = np.zeros(2), np.zeros(2)
+    D.solverAD.calcJacTVecProduct("patchV", "patchVelocity", x0, "CD", "function", np.ones(1), dFdx)
+    D.solverAD.calcJacTVecProduct("patchV", "patchVelocity", x0, "residual", "residual", psi, pRx)
+    total = dFdx - pRx
+    # partials against the oracle (central differences of the residual / objective w.r.t. the patch table)
+    for k, h in ((0, 1e-4), (1, 1e-3)):
+        e = np.eye(2)[k]
+        cp_, cm_ = _with_inlet(case, *(x0 + h * e)), _with_inlet(case, *(x0 - h * e))
+        ref_R = psi @ ((residual(cp_, g, W) - residual(cm_, g, W)) / (2 * h))
+        ref_F = (force(cp_, g, W, walls, [1.0, 0, 0]) - force(cm_, g, W, walls, [1.0, 0, 0])) / (2 * h)
+        assert abs(pRx[k] - ref_R) < 1e-6 * abs(ref_R), (k, pRx[k], ref_R)
+        assert abs(dFdx[k] - ref_F) < 1e-6 * abs(ref_R), (k, dFdx[k], ref_F)
+    # totals against finite differences of the converged primal
+    for k, h, tol in ((0, 1e-2, 2e-5), (1, 0.05, 1e-2)):  # AoA: upwind-direction kinks make the FD itself noisy (0.3 %)
+        e = np.eye(2)[k]
+        Fs = []
+        for sgn in (1, -1):
+            c3 = _with_inlet(case, *(x0 + sgn * h * e))
+            W3, _ = solve_primal(c3, g, W0=W, max_iters=2000, tol=1e-12)
+            Fs.append(force(c3, g, W3, walls, [1.0, 0, 0]))
+        fd = (Fs[0] - Fs[1]) / (2 * h)
+        assert abs(total[k] - fd) < tol * abs(fd), (k, total[k], fd)
+    # DAInput::run semantics: the patch value is assigned by the product call; unsupported patch types are errors
+    from dafoam_amd._capi import DASError
+    D2 = make(case, inputInfo={"w": {"type": "patchVar", "patches": ["bottom"], "varName": "p", "varType": "scalar"}})
+    with pytest.raises(DASError, match="patch type not valid"):
+        D2.solver.setSolverInput("w", "patchVar", 1, np.array([1.0]))
+
+
+@pytest.mark.parametrize("kind", ["simple", "rho", "scalar"])
+def test_forward_mode_jac_vec_product(kind):
+    """calcJacVecProduct (one dual-number residual pass) against the oracle's complex-step directional derivative, and
+    the exact identity a.(J v) = (J^T a).v with the coloured transposed operator."""
+    case = {"simple": lambda: channel_case(8, 7, 6, wall_function=True), "rho": lambda: rho_channel_case(7, 6, 5, perturb=0.02),  # no exact ties (max/abs kinks)
+            "scalar": lambda: scalar_transport_case(8, 7, 6)}[kind]()
+    g = Geometry(case.mesh)
+    D = make(case)
+    W = case.states
+    n = W.size
+    sc = J.state_scales(case, g, norm_states(case))
+    rng = np.random.default_rng(5)
+    v, a = rng.standard_normal(n), rng.standard_normal(n)
+    Jv = np.zeros(n)
+    D.solver.calcJacVecProduct(v, Jv)
+    ref = residual(case, g, W + 1j * 1e-30 * sc * v).imag / 1e-30
+    assert relerr(Jv, ref) < 1e-10
+    pa = np.zeros(n)
+    D.solverAD.calcJacTVecProduct("s", "stateVar", W, "r", "residual", a, pa)
+    assert abs(a @ Jv - pa @ v) <= 1e-11 * np.linalg.norm(a) * np.linalg.norm(Jv)
+
+
+def test_size_independent_properties_bench_size():
+    """BASELINE.json's bench configuration (100x50x40 = 200k cells, 1.6 M states, 2.1e8 Jacobian non-zeros), where no
+    oracle Jacobian is affordable: linearity, the dot-product identity against a central difference of the GPU
+    residual is replaced by the exact forward-mode identity (every colour and every scatter slot takes part in a random
+    product), and consistency of the GMRES
+    residual recurrence with an independently recomputed true residual after a bounded number of iterations."""
+    case = bench_channel_case(100, 50, 40)
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-30, "gmresAbsTol": 1e-30, "printInfo": 0, "gmresMaxIters": 60, "gmresRestart": 60})
+    n = case.states.size
+    W = case.states
+    rng = np.random.default_rng(11)
+    a, b = rng.standard_normal(n), rng.standard_normal(n)
+    pa, pb, pab = np.zeros(n), np.zeros(n), np.zeros(n)
+    D.solverAD.calcJacTVecProduct("s", "stateVar", W, "r", "residual", a, pa)
+    D.solverAD.calcJacTVecProduct("s", "stateVar", W, "r", "residual", b, pb)
+    D.solverAD.calcJacTVecProduct("s", "stateVar", W, "r", "residual", 2.0 * a - 3.0 * b, pab)
+    assert relerr(pab, 2.0 * pa - 3.0 * pb) < 1e-12
+    g = Geometry(case.mesh)
+    sc = J.state_scales(case, g, NORM_STATES)
+    # exact dot-product identity: forward-mode J (s o v) from ONE dual pass (no colouring, no scatter maps) against the
+    # coloured, scattered, transposed operator.  (Central differences of the residual are useless here: a random
+    # perturbation flips the sign of thousands of near-zero cross-stream fluxes, i.e. upwind kinks.)
+    for seed in (0, 1):
+        v = np.random.default_rng(seed).standard_normal(n)
+        Jv = np.zeros(n)
+        D.solver.calcJacVecProduct(v, Jv)
+        assert abs(a @ Jv - pa @ v) <= 1e-10 * np.linalg.norm(a) * np.linalg.norm(Jv)
+    rhs = np.zeros(n)
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= sc
+    psi, fail = D.solveAdjoint(rhs)
+    info = D.ksp.info()
+    assert fail == 1 and info["iters"] == 60  # iteration cap reached: the reference's failure rule (DALinearEqn.C:422-434)
+    assert info["res"] < 0.9 * info["res0"]
+    chk = np.zeros(n)
+    D.solverAD.calcJacTVecProduct("s", "stateVar", W, "r", "residual", psi, chk)
+    true_res = np.linalg.norm(chk - rhs)
+    assert abs(true_res - info["res"]) <= 1e-6 * info["res0"], (true_res, info)
+
+
 def test_cell_state_ordering():
     """adjStateOrdering "cell" (reference DAIndex.C:602-651): every state-length array crosses the boundary in the
     cell-by-cell ordering; results are the permuted "state"-ordering results."""

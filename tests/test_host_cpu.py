@@ -149,6 +149,40 @@ def test_kernel_bodies_match_oracle_scalar_transport():
     assert relerr(Rd, residual(case, g, W + 1j * 1e-30 * v).imag / 1e-30) < 1e-12
 
 
+@pytest.mark.parametrize("kind", ["simple", "rho"])
+def test_kernel_bodies_bc_value_tangent(kind):
+    """dR/d(patch value): the dual-number BC seeds of the kernel bodies vs central differences of the oracle with the
+    patch table perturbed (inlet U, outlet p / inletOutlet refValue, inlet nuTilda, inlet T)."""
+    import copy
+    case = channel_case(7, 6, 5, wall_function=True) if kind == "simple" else rho_channel_case(7, 6, 5)
+    g = Geometry(case.mesh)
+    W = case.states
+    L = _emu()
+    L.emu_residual_bc.argtypes = [C.POINTER(das_case_t), _capi.c_double_p, C.c_longlong, C.c_int, C.c_int, _capi.c_double_p, _capi.c_double_p]
+    names = [p.name for p in case.mesh.patches]
+    probes = [("inlet", "U", 0, np.array([0.8, 0.3, -0.2])), ("inlet", "nuTilda", 2, np.array([1.0, 0, 0])),
+              ("outlet", "p", 1, np.array([1.0, 0, 0])), ("outlet", "U", 0, np.array([0.5, -0.4, 0.1]))]
+    if kind == "rho":
+        probes.append(("inlet", "T", 3, np.array([1.0, 0, 0])))
+    for pname, field, fid, t in probes:
+        code, v0 = case.bcs[pname][field]
+        Rd = np.zeros(W.size)
+        assert L.emu_residual_bc(CaseStruct(case).byref(), dptr(W), W.size, names.index(pname), fid, dptr(t), dptr(Rd)) == 0
+        vmax = float(np.max(np.abs(v0)))
+        h = 1e-4 * vmax if vmax > 0 else 1e-6
+        Rpm = []
+        for sgn in (1, -1):
+            c2 = copy.copy(case)
+            c2.bcs = copy.deepcopy(case.bcs)
+            c2.bcs[pname][field] = (code, (np.asarray(v0, dtype=float) + sgn * h * t) if field == "U" else float(v0) + sgn * h * t[0])
+            Rpm.append(residual(c2, g, W))
+        fd = (Rpm[0] - Rpm[1]) / (2 * h)
+        if code in (0, 2) and np.abs(fd).max() > 0:  # fixedValue / inletOutlet carry a value
+            assert relerr(Rd, fd) < 1e-6, (pname, field)
+        else:
+            assert np.abs(Rd).max() == 0.0 and np.abs(fd).max() < 1e-9, (pname, field)
+
+
 def test_unstructured_renumbering_invariance():
     """Random cell renumbering (faces re-sorted / re-oriented): the oracle residual is the permuted residual, the
     kernel bodies agree with the oracle on the renumbered mesh, and connectivity/colouring stay valid - nothing

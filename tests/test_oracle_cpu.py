@@ -155,3 +155,44 @@ def test_primal_fixed_point_is_residual_zero():
         g = Geometry(case.mesh)
         W, hist = solve_primal(case, g, max_iters=800, tol=1e-10)
         assert np.all(hist[-1] < 1e-8 * hist[0]), (case.solver_name, hist[-1] / hist[0])
+
+
+def test_adjoint_total_derivative_matches_primal_fd():
+    """The oracle adjoint (dRdW^T psi = dFdW; dF/dx = -psi^T dR/dx) reproduces the finite-difference sensitivity of
+    the CONVERGED oracle primal w.r.t. the inlet velocity: pins residual, Jacobian, objective and primal against
+    each other the way the reference's regression totals do (tests/runRegTests_DASimpleFoam.py)."""
+    import copy
+
+    import scipy.sparse.linalg as spla
+
+    from oracle.functions import force, force_gradient
+    from oracle.primal import solve_primal
+
+    case = channel_case(8, 6, 5, perturb=0.0, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    W, hist = solve_primal(case, g, max_iters=2000, tol=1e-12)
+    walls = [p.name for p in case.mesh.patches if p.type == "wall"]
+    d = [1.0, 0.0, 0.0]
+    sc = J.state_scales(case, g, NORM_STATES)
+    con = J.connectivity(case, g)
+    col, _ = J.greedy_coloring(con)
+    A = J.jacobian_colored(case, g, W, con, col, sc, mode="cs", lower_bound=0)
+    psi = spla.spsolve(A.tocsc(), force_gradient(case, g, W, walls, d, 1.0, sc))
+
+    def with_U(Umag):
+        c2 = copy.copy(case)
+        c2.bcs = copy.deepcopy(case.bcs)
+        c2.bcs["inlet"]["U"] = (case.bcs["inlet"]["U"][0], (Umag, 0.0, 0.0))
+        return c2
+
+    h = 1e-4
+    cp_, cm_ = with_U(10 + h), with_U(10 - h)
+    total = (force(cp_, g, W, walls, d) - force(cm_, g, W, walls, d)) / (2 * h) - psi @ ((residual(cp_, g, W) - residual(cm_, g, W)) / (2 * h))
+    hh = 1e-2
+    Fs = []
+    for sgn in (1, -1):
+        c3 = with_U(10 + sgn * hh)
+        W3, _ = solve_primal(c3, g, W0=W, max_iters=2000, tol=1e-12)
+        Fs.append(force(c3, g, W3, walls, d))
+    fd = (Fs[0] - Fs[1]) / (2 * hh)
+    assert abs(total - fd) < 2e-5 * abs(fd), (total, fd)
