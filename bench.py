@@ -54,9 +54,20 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # host-side setup (pattern build, ILU factorisation) is OpenMP-parallel: give every rank its share of the cores
+    # (torch.distributed.run exports OMP_NUM_THREADS=1 when it is unset; the library reads it when it is loaded below)
+    if world > 1:
+        os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
+
     import __graft_entry__ as ge
 
-    ge.build()
+    # the .so files travel prebuilt; if they have to be (re)built, one rank per node does it
+    if local_rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    if local_rank != 0:
+        ge.build()
     from dafoam_amd import _capi
     from dafoam_amd.meshgen import bench_channel_case
     from dafoam_amd.pyDAFoam import PYDAFOAM

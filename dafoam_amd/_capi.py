@@ -164,6 +164,7 @@ _SIGS = {
     "das_get_residuals": (C.c_int, [_VP, c_double_p]),
     "das_calc_residuals": (C.c_int, [_VP, C.c_int, c_double_p]),
     "das_run_coloring": (C.c_int, [_VP]),
+    "das_set_coloring": (C.c_int, [_VP, c_int_p]),
     "das_get_n_colors": (C.c_int, [_VP, C.c_int]),
     "das_get_con_nnz": (C.c_longlong, [_VP, C.c_int]),
     "das_get_con": (C.c_int, [_VP, C.c_int, c_ll_p, c_int_p]),

@@ -671,8 +671,10 @@ static void compute_scales(das_solver* s) {
     if (s->inited) s->d_scale.upload(s->h_scale);
 }
 
-static void ensure_coloring(das_solver* s) {
-    if (s->colored) return;
+// preset != nullptr: colours read from a dRdWColoring file (reference DAJacCon::readJacConColoring :1980-2019) - they
+// are validated against the connectivity exactly like the reference does (DAColoring::validateColoring)
+static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
+    if (s->colored && !preset) return;
     double t = wall_seconds();
     s->st_full = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, false);
     s->st_pc = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, true);
@@ -680,7 +682,17 @@ static void ensure_coloring(das_solver* s) {
     s->con_full.build(s->mesh, s->st_full);
     s->con_pc.build(s->mesh, s->st_pc);
     double t2 = wall_seconds();
-    s->nColors = d2_coloring(s->con_full, s->colors);
+    if (preset) {
+        s->colors.assign(preset, preset + s->n);
+        int mx = -1;
+        for (long long j = 0; j < s->n; j++) {
+            DAS_CHECK(s->colors[j] >= 0 && s->colors[j] < 65535, DAS_ERR_ARG, "colour out of range in the supplied colouring");
+            mx = std::max(mx, s->colors[j]);
+        }
+        s->nColors = mx + 1;
+    } else {
+        s->nColors = d2_coloring(s->con_full, s->colors);
+    }
     double t3 = wall_seconds();
     DAS_CHECK(validate_coloring(s->con_full, s->colors), DAS_ERR_INTERNAL, "Conflicting Colors Found!");
     double t4 = wall_seconds();
@@ -1504,6 +1516,14 @@ int das_run_coloring(das_solver_t* s) {
     DAS_TRY
     DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
     ensure_coloring(s);
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_set_coloring(das_solver_t* s, const int* colors) {
+    DAS_TRY
+    DAS_CHECK(s && colors, DAS_ERR_ARG, "null argument");
+    s->colored = false;
+    ensure_coloring(s, colors);
     return DAS_OK;
     DAS_CATCH
 }

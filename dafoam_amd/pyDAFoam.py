@@ -104,6 +104,9 @@ class DAOPTION(object):
         # MI355X-specific additions (not in the reference)
         self.amd = {"pcBlockCells": 1024, "jacMode": 1, "pcJacMode": 0, "pcFactorFP32": 0, "cgsAlwaysRefine": 0}
         self.amdDevice = 0
+        ## directory of the dRdWColoring_<nProcs>.bin cache (the reference keeps it in the case directory,
+        ## DAJacCon.C:1886-2019); "" = do not cache
+        self.amdColoringDir = ""
 
 
 class PYDAFOAM(object):
@@ -222,7 +225,7 @@ class PYDAFOAM(object):
         calcJacTVecProduct(stateVar -> function), DASolver.C:1820).  Returns (psi, fail)."""
         dFdW = self.array2Vec(np.ascontiguousarray(dFdWArray, dtype=np.float64))
         if self.getOption("adjUseColoring") and self.runColoring:
-            self.solver.runColoring()
+            self.solver.runColoring(cacheDir=self.getOption("amdColoringDir") or None)
             self.runColoring = False
         adjPCLag = self.getOption("adjPCLag")
         writeJac = self.getOption("writeJacobians")

@@ -436,8 +436,34 @@ class pyDASolvers:
         return out
 
     # -- colouring / Jacobians -------------------------------------------------------------------
-    def runColoring(self):
+    def runColoring(self, cacheDir=None, nProcs=1, rank=0):
+        """DASolver::runColoring (DASolver.C:708-745).  With cacheDir the colouring is kept like the reference keeps
+        it, as a PETSc binary Vec `dRdWColoring_<nProcs>.bin` (`DAJacCon.C:1886-2019`; one file per rank here, suffix
+        `_<rank>` when nProcs > 1): read + validated if present and of the right size, computed and written otherwise.
+        A file that does not validate (different mesh) is recomputed, not trusted."""
+        if cacheDir is None:
+            return check(lib().das_run_coloring(self._h))
+        import os
+
+        from . import petsc_io
+
+        name = f"dRdWColoring_{nProcs}" + (f"_{rank}" if nProcs > 1 else "") + ".bin"
+        path = os.path.join(cacheDir, name)
+        n = self.getNLocalAdjointStates()
+        if os.path.exists(path):
+            try:
+                col = petsc_io.read_vec(path)
+                if col.size == n and np.all(col == np.round(col)):
+                    ci = np.ascontiguousarray(col, dtype=np.int32)
+                    check(lib().das_set_coloring(self._h, ci.ctypes.data_as(_capi.c_int_p)))
+                    return
+            except (_capi.DASError, ValueError, OSError):
+                pass  # stale / foreign cache: fall through and recompute
         check(lib().das_run_coloring(self._h))
+        col, _ = self.getColoring()
+        tmp = path + f".tmp{os.getpid()}"
+        petsc_io.write_vec(tmp, col.astype(np.float64))
+        os.replace(tmp, path)
 
     def getColoring(self):
         n = self.getNLocalAdjointStates()

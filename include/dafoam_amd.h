@@ -136,6 +136,9 @@ int das_calc_residuals(das_solver_t* s, int isPC, double* residuals);
  * Host graph work; needs no GPU.  The getters expose dRdWCon and the colour vector (the reference
  * writes them as dRdWCon.bin / dRdWColoring_<np>.bin, DAJacCon.C:1886-1975,2580-2586). */
 int das_run_coloring(das_solver_t* s);
+/* das_set_coloring <- DAJacCon::readJacConColoring (DAJacCon.C:1980-2019): colours read back from a dRdWColoring_n.bin
+ *                      cache; validated against the freshly built connectivity ("Conflicting Colors Found!" otherwise). */
+int das_set_coloring(das_solver_t* s, const int* colors);
 int das_get_n_colors(das_solver_t* s, int isPC);
 long long das_get_con_nnz(das_solver_t* s, int isPC);
 int das_get_con(das_solver_t* s, int isPC, long long* rowptr /*n+1*/, int* colidx /*nnz*/);

@@ -205,6 +205,39 @@ def test_unstructured_renumbering_invariance():
     assert J.validate_coloring(J.connectivity(case, g), col.astype(np.int64))
 
 
+def test_coloring_cache_roundtrip_and_validation(tmp_path):
+    """dRdWColoring_<nProcs>.bin cache (reference DAJacCon.C:1886-2019): written as a PETSc Vec, read back and
+    validated; a file that does not validate against the connectivity is recomputed, a conflicting colouring handed
+    to the C-ABI is rejected with the reference's message."""
+    from dafoam_amd import petsc_io
+
+    case = channel_case(6, 5, 4, wall_function=True)
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    s.runColoring(cacheDir=str(tmp_path))
+    f = tmp_path / "dRdWColoring_1.bin"
+    assert f.exists()
+    col, nc = s.getColoring()
+    assert np.array_equal(petsc_io.read_vec(str(f)), col.astype(np.float64))
+    # a second solver picks the cached colours up (a permuted-but-valid colouring proves the file is what is used)
+    perm = np.random.default_rng(0).permutation(nc)
+    petsc_io.write_vec(str(f), perm[col].astype(np.float64))
+    s2 = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    s2.runColoring(cacheDir=str(tmp_path))
+    col2, nc2 = s2.getColoring()
+    assert nc2 == nc and np.array_equal(col2, perm[col])
+    g = Geometry(case.mesh)
+    assert J.validate_coloring(J.connectivity(case, g), col2.astype(np.int64))
+    # conflicting colours: rejected by the library; the cache path falls back to a fresh colouring
+    bad = np.zeros(col.size, dtype=np.int32)
+    with pytest.raises(_capi.DASError, match="Conflicting Colors Found"):
+        _capi.check(_capi.lib().das_set_coloring(s2._h, bad.ctypes.data_as(_capi.c_int_p)))
+    petsc_io.write_vec(str(f), bad.astype(np.float64))
+    s3 = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    s3.runColoring(cacheDir=str(tmp_path))
+    col3, _ = s3.getColoring()
+    assert np.array_equal(col3, col) and np.array_equal(petsc_io.read_vec(str(f)), col.astype(np.float64))
+
+
 def test_petsc_binary_io_roundtrip_and_layout(tmp_path):
     """PETSc binary Vec/Mat (big-endian, classids 1211214 / 1211216 - SURVEY.md Appendix D)."""
     import scipy.sparse as sp
