@@ -15,7 +15,7 @@ from .meshgen import FoamCase
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdafoam_amd.so")
 
-SOLVER_IDS = {"DASimpleFoam": 0, "DAScalarTransportFoam": 1, "DARhoSimpleFoam": 2}
+SOLVER_IDS = {"DASimpleFoam": 0, "DAScalarTransportFoam": 1, "DARhoSimpleFoam": 2, "DATurboFoam": 3}
 PATCH_TYPES = {"patch": 0, "wall": 1, "symmetry": 2}
 
 c_double_p = C.POINTER(C.c_double)
@@ -62,6 +62,12 @@ class das_case_t(C.Structure):
         ("mu", C.c_double),
         ("Pr", C.c_double),
         ("Prt", C.c_double),
+        ("mrf_active", C.c_int),
+        ("mrf_omega", C.c_double * 3),
+        ("mrf_origin", C.c_double * 3),
+        ("patch_mrf_rotating", c_int_p),
+        ("transonic", C.c_int),
+        ("transonic_pc_option", C.c_int),
     ]
 
 
@@ -135,6 +141,16 @@ class CaseStruct:
         s.deltaT = case.deltaT
         th = getattr(case, "thermo", None) or {}
         s.Cp, s.molWeight, s.mu, s.Pr, s.Prt = (th.get("Cp", 1005.0), th.get("molWeight", 28.96), th.get("mu", 1.8e-5), th.get("Pr", 0.7), th.get("Prt", 1.0))
+        mrf = getattr(case, "mrf", None)
+        s.mrf_active = 1 if mrf else 0
+        if mrf:
+            for i in range(3):
+                s.mrf_omega[i] = float(mrf["omega"][i])
+                s.mrf_origin[i] = float(mrf.get("origin", (0.0, 0.0, 0.0))[i])
+            k["patch_mrf_rotating"] = np.array([0 if p.name in mrf.get("nonRotatingPatches", ()) else 1 for p in m.patches], dtype=np.int32)
+            s.patch_mrf_rotating = _ip(k["patch_mrf_rotating"])
+        s.transonic = 1 if getattr(case, "transonic", False) else 0
+        s.transonic_pc_option = int(getattr(case, "transonic_pc_option", 1))
 
     def byref(self):
         return C.byref(self.struct)

@@ -8,6 +8,8 @@ struct CaseParams {
     int solver = DAS_SOLVER_SIMPLEFOAM;
     double nu = 1.5e-5, relax_U = 0.7, relax_nuTilda = 0.7, relax_T = 1.0, DT = 0.01, deltaT = 1.0;
     double Cp = 1005.0, molWeight = 28.96, mu = 1.8e-5, Pr = 0.7, Prt = 1.0;
+    int mrf = 0, transonic = 0, transonicPC = 1;
+    double om[3] = {0, 0, 0}, org[3] = {0, 0, 0};
     std::vector<double> phi_frozen, T_old;
     void from_case(const das_case_t* c) {
         solver = c->solver;
@@ -17,9 +19,16 @@ struct CaseParams {
         relax_T = c->relax_T;
         DT = c->DT;
         deltaT = c->deltaT;
-        if (solver == DAS_SOLVER_RHOSIMPLEFOAM) {
+        if (DAS_IS_COMPRESSIBLE(solver)) {
+            mrf = c->mrf_active != 0;
+            for (int k = 0; k < 3; k++) { om[k] = c->mrf_omega[k]; org[k] = c->mrf_origin[k]; }
+            DAS_CHECK(!mrf || c->patch_mrf_rotating, DAS_ERR_ARG, "MRF needs the per-patch rotating flags");
+            transonic = (solver == DAS_SOLVER_TURBOFOAM) && c->transonic != 0;
+            transonicPC = c->transonic_pc_option;
             Cp = c->Cp; molWeight = c->molWeight; mu = c->mu; Pr = c->Pr; Prt = c->Prt;
-            DAS_CHECK(Cp > 0 && molWeight > 0 && mu > 0 && Pr > 0 && Prt > 0, DAS_ERR_ARG, "DARhoSimpleFoam needs positive Cp, molWeight, mu, Pr, Prt");
+            DAS_CHECK(Cp > 0 && molWeight > 0 && mu > 0 && Pr > 0 && Prt > 0, DAS_ERR_ARG, "DARhoSimpleFoam/DATurboFoam need positive Cp, molWeight, mu, Pr, Prt");
+        } else {
+            DAS_CHECK(!c->mrf_active, DAS_ERR_ARG, "MRF is implemented for the compressible solvers only");
         }
         if (c->phi_frozen) phi_frozen.assign(c->phi_frozen, c->phi_frozen + c->n_faces);
         if (c->T_old) T_old.assign(c->T_old, c->T_old + c->n_cells);
@@ -42,7 +51,7 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.normN = opt.list_has("normalizeResiduals", "nuTildaRes");
     p.normPhi = opt.list_has("normalizeResiduals", "phiRes");
     p.normT = opt.list_has("normalizeResiduals", "TRes");
-    const bool rho = cp.solver == DAS_SOLVER_RHOSIMPLEFOAM;
+    const bool rho = DAS_IS_COMPRESSIBLE(cp.solver);
     p.offP = 3;
     p.offT = rho ? 4 : 0;
     p.offN = rho ? 5 : 4;
@@ -52,6 +61,13 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.mu = cp.mu;
     p.Pr = cp.Pr;
     p.Prt = cp.Prt;
+    p.turbo = cp.solver == DAS_SOLVER_TURBOFOAM;
+    p.transonic = cp.transonic;
+    p.transonicPC = cp.transonicPC;
+    p.mrf = cp.mrf;
+    p.wTU = nullptr;
+    p.wRAtU = nullptr;
+    for (int k = 0; k < 3; k++) { p.om[k] = cp.om[k]; p.org[k] = cp.org[k]; }
     return p;
 }
 

@@ -112,6 +112,7 @@ struct PatchBC {  // per patch, small table
     // tangent of the patch values (forward-mode seed for dR/d(BC value); zero except inside das_calc_drdbc)
     double dU_val[3];
     double dp_val, dnuTilda_val, dT_val;
+    int mrf_included;  // 1 = the patch rotates with the MRF zone (MRFZone includedFaces)
 };
 
 // ---- host mesh (fvMesh equivalent) ------------------------------------------------------------

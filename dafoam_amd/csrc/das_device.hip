@@ -25,19 +25,19 @@ namespace das {
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_grad(DevMesh m, ResParams prm, const T* __restrict__ W, T* nut, T* gU, T* gP, T* gN, T* gH) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < m.nC) body_grad<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH);
+    if (c < m.nC) body_grad<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, (T*)prm.wTU);
 }
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_cell(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gU, const T* gP,
                                               const T* gN, const T* gH, T* R, T* rAU, T* HbyA) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < m.nC) body_cell<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, R, rAU, HbyA);
+    if (c < m.nC) body_cell<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, R, rAU, HbyA, (const T*)prm.wTU, (T*)prm.wRAtU);
 }
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_face(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gP, const T* rAU,
                                               const T* HbyA, T* q, T* R) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < m.nF) body_face<T, RHO>(f, m, prm, W, nut, gP, rAU, HbyA, q, R);
+    if (f < m.nF) body_face<T, RHO>(f, m, prm, W, nut, gP, rAU, HbyA, q, R, (const T*)prm.wRAtU);
 }
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_pres(DevMesh m, ResParams prm, const T* q, T* R) {
@@ -118,14 +118,22 @@ __global__ __launch_bounds__(256) void k_T(DevMesh m, ResParams prm, const T* __
 
 template <class T>
 struct ResWork {
-    DevBuf<T> nut, gU, gP, gN, gH, rAU, HbyA, q, gT;
+    DevBuf<T> nut, gU, gP, gN, gH, rAU, HbyA, q, gT, TU, rAtU;
     void ensure(int solver, long long N, long long F) {
-        if (solver == DAS_SOLVER_SIMPLEFOAM || solver == DAS_SOLVER_RHOSIMPLEFOAM) {
+        if (solver == DAS_SOLVER_SIMPLEFOAM || DAS_IS_COMPRESSIBLE(solver)) {
             if (nut.n != (size_t)N) {
                 nut.alloc(N); gU.alloc(9 * N); gP.alloc(3 * N); gN.alloc(3 * N); rAU.alloc(N); HbyA.alloc(3 * N); q.alloc(F);
             }
-            if (solver == DAS_SOLVER_RHOSIMPLEFOAM && gH.n != (size_t)(3 * N)) gH.alloc(3 * N);
+            if (DAS_IS_COMPRESSIBLE(solver) && gH.n != (size_t)(3 * N)) gH.alloc(3 * N);
+            if (solver == DAS_SOLVER_TURBOFOAM && TU.n != (size_t)(3 * N)) { TU.alloc(3 * N); rAtU.alloc(N); }
         } else if (gT.n != (size_t)(3 * N)) gT.alloc(3 * N);
+    }
+    // work arrays referenced through ResParams (DATurboFoam)
+    ResParams bind(int solver, long long N, long long F, ResParams prm) {
+        ensure(solver, N, F);
+        prm.wTU = TU.p;
+        prm.wRAtU = rAtU.p;
+        return prm;
     }
 };
 
@@ -133,9 +141,9 @@ static inline int nblk(long long n, int b) { return (int)((n + b - 1) / b); }
 
 // one residual evaluation R(W): DAResidual::masterFunction (reference DAResidual.C:100-171)
 template <class T>
-static void eval_residual(const DevMesh& dm, const CaseParams& cp, const ResParams& prm, const T* W, T* R, ResWork<T>& wk,
+static void eval_residual(const DevMesh& dm, const CaseParams& cp, const ResParams& prm_in, const T* W, T* R, ResWork<T>& wk,
                           const double* d_phiF, const double* d_Told, hipStream_t st) {
-    wk.ensure(cp.solver, dm.nC, dm.nF);
+    const ResParams prm = wk.bind(cp.solver, dm.nC, dm.nF, prm_in);
     const int B = 256;
     if (cp.solver == DAS_SOLVER_SIMPLEFOAM) {
         hipLaunchKernelGGL((k_grad<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, (T*)nullptr);
@@ -143,7 +151,7 @@ static void eval_residual(const DevMesh& dm, const CaseParams& cp, const ResPara
                            (const T*)nullptr, R, wk.rAU.p, wk.HbyA.p);
         hipLaunchKernelGGL((k_face<T, false>), dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
         hipLaunchKernelGGL((k_pres<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, wk.q.p, R);
-    } else if (cp.solver == DAS_SOLVER_RHOSIMPLEFOAM) {
+    } else if (DAS_IS_COMPRESSIBLE(cp.solver)) {
         hipLaunchKernelGGL((k_grad<T, true>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, wk.gH.p);
         hipLaunchKernelGGL((k_cell<T, true>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p,
                            (const T*)wk.gH.p, R, wk.rAU.p, wk.HbyA.p);
@@ -1370,7 +1378,7 @@ das_solver_t* das_create(const das_case_t* c) {
         s->t0_cpu = std::clock();
         s->cp.from_case(c);
         s->mesh.build(c);
-        s->opt.s["solverName"] = c->solver == DAS_SOLVER_SIMPLEFOAM ? "DASimpleFoam" : (c->solver == DAS_SOLVER_RHOSIMPLEFOAM ? "DARhoSimpleFoam" : "DAScalarTransportFoam");
+        s->opt.s["solverName"] = c->solver == DAS_SOLVER_SIMPLEFOAM ? "DASimpleFoam" : (c->solver == DAS_SOLVER_RHOSIMPLEFOAM ? "DARhoSimpleFoam" : (c->solver == DAS_SOLVER_TURBOFOAM ? "DATurboFoam" : "DAScalarTransportFoam"));
         s->st_full = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, false);
         s->n = s->st_full.n;
         s->h_W.assign(s->n, 0.0);
@@ -1641,7 +1649,7 @@ int das_set_old_time_fields(das_solver_t* s, const double* phi_frozen, const dou
 int das_define_force_function(das_solver_t* s, const char* name, const int* patch_ids, int npatch, const double* direction, double scale) {
     DAS_TRY
     DAS_CHECK(s && name && patch_ids && direction && npatch > 0, DAS_ERR_ARG, "bad argument");
-    DAS_CHECK(s->cp.solver == DAS_SOLVER_SIMPLEFOAM || s->cp.solver == DAS_SOLVER_RHOSIMPLEFOAM, DAS_ERR_ARG, "force needs a flow solver");
+    DAS_CHECK(s->cp.solver == DAS_SOLVER_SIMPLEFOAM || DAS_IS_COMPRESSIBLE(s->cp.solver), DAS_ERR_ARG, "force needs a flow solver");
     double mag = std::sqrt(direction[0] * direction[0] + direction[1] * direction[1] + direction[2] * direction[2]);
     DAS_CHECK(std::fabs(mag - 1.0) <= 1.0e-8, DAS_ERR_ARG, std::string("the magnitude of the direction parameter in ") + name + " is not 1.0!");
     das_solver::ForceFn& fn = s->functions[name];
@@ -1668,9 +1676,8 @@ int das_calc_function(das_solver_t* s, const char* name, double* value) {
     need_init(s);
     DAS_CHECK(value, DAS_ERR_ARG, "null output");
     das_solver::ForceFn& fn = get_function(s, name);
-    ResParams prm = make_params(s->cp, s->opt, 0);
-    const bool rho = s->cp.solver == DAS_SOLVER_RHOSIMPLEFOAM;
-    s->wk.ensure(s->cp.solver, s->dm.nC, s->dm.nF);
+    const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
+    ResParams prm = s->wk.bind(s->cp.solver, s->dm.nC, s->dm.nF, make_params(s->cp, s->opt, 0));
     const int B = 256, nf = (int)fn.faces.size();
     DAS_HIP(hipMemsetAsync(s->d_tmp1.p, 0, sizeof(double), s->stream));
     if (rho) {
@@ -1690,11 +1697,10 @@ static void function_gradient(das_solver* s, const char* name, double seed, doub
     need_init(s);
     das_solver::ForceFn& fn = get_function(s, name);
     ensure_con_dev(s, 0);
-    ResParams prm = make_params(s->cp, s->opt, 0);
-    const bool rho = s->cp.solver == DAS_SOLVER_RHOSIMPLEFOAM;
+    ResParams prm = s->wk1.bind(s->cp.solver, s->dm.nC, s->dm.nF, make_params(s->cp, s->opt, 0));
+    const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
     const long long n = s->n;
     if (s->d_Wd.n != (size_t)n) { s->d_Wd.alloc(n); s->d_Rd.alloc(n); }
-    s->wk1.ensure(s->cp.solver, s->dm.nC, s->dm.nF);
     DAS_HIP(hipMemsetAsync(s->d_tmp2.p, 0, n * sizeof(double), s->stream));
     const int B = 256, nf = (int)fn.faces.size();
     for (int col = 0; col < s->nColors; col++) {
@@ -1789,7 +1795,7 @@ int das_calc_dbc_product(das_solver_t* s, const int* patches, int np, const char
         ~Restore() { (void)hipStreamSynchronize(s->stream); s->d_bc.upload(s->mesh.bc); }
     } restore{s};
     ResParams prm = make_params(s->cp, s->opt, 0);
-    const bool rho = s->cp.solver == DAS_SOLVER_RHOSIMPLEFOAM;
+    const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
     if (s->d_Wd.n != (size_t)n) { s->d_Wd.alloc(n); s->d_Rd.alloc(n); }
     hipLaunchKernelGGL(k_lift, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_W.p, s->d_Wd.p);  // states carry no tangent
     DAS_HIP(hipMemsetAsync(s->d_tmp1.p, 0, sizeof(double), st));
@@ -1799,7 +1805,7 @@ int das_calc_dbc_product(das_solver_t* s, const int* patches, int np, const char
         hipLaunchKernelGGL(k_tangent_dot, dim3(1024), dim3(256), 0, st, n, s->d_Rd.p, s->d_tmp2.p, s->d_tmp1.p);
     } else {
         das_solver::ForceFn& fn = get_function(s, outputName);
-        s->wk1.ensure(s->cp.solver, s->dm.nC, s->dm.nF);
+        prm = s->wk1.bind(s->cp.solver, s->dm.nC, s->dm.nF, prm);
         const int nf = (int)fn.faces.size();
         if (rho) {
             hipLaunchKernelGGL((k_grad<Dual<1>, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);

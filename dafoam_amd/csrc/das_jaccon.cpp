@@ -51,7 +51,7 @@ Stencil make_stencil(int solver, int nC, int nF, const Options& opt, bool isPC) 
                         bits({"U"})};                                                                // pRes
         st.levels[2] = {bits({"U", "nuTilda", "phi"}), bits({"U", "nuTilda"}), bits({"nuTilda"})};    // nuTildaRes
         st.levels[3] = {bits({"U", "p", "nuTilda", "phi"}), bits({"U", "p", "nuTilda"}), bits({"U"})};  // phiRes
-    } else if (solver == DAS_SOLVER_RHOSIMPLEFOAM) {
+    } else if (DAS_IS_COMPRESSIBLE(solver)) {  // DAStateInfoTurboFoam.C:82-119 carries the same level table
         // DAStateInfoRhoSimpleFoam.C:40-47,79-116 and the compressible SA table DASpalartAllmaras.C:364-383
         add_state("U", KIND_VEC);
         add_state("p", KIND_SCL);

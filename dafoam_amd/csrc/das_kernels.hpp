@@ -8,6 +8,9 @@
 //   nutUSpaldingWallFunction calcNut/calcUTau   src/adjoint/DAMisc/nutUSpaldingWallFunctionDF/...DF.C:42-150
 //   DAResidualScalarTransportFoam::calcResiduals src/adjoint/DAResidual/DAResidualScalarTransportFoam.C:57-84
 //   residual normalisation macros               src/include/DAMacroFunctions.H:28-51
+//   DAResidualRhoSimpleFoam::calcResiduals      src/adjoint/DAResidual/DAResidualRhoSimpleFoam.C:84-211   (RHO = true)
+//   DAResidualTurboFoam::calcResiduals          src/adjoint/DAResidual/DAResidualTurboFoam.C:66-233       (RHO = true, prm.turbo)
+//   MRF (OpenFOAM MRFZone: addCoriolis, makeRelativeRhoFlux, correctBoundaryVelocity; one zone = the mesh)
 // The OpenFOAM operators behind those lines (fvm::div/laplacian, fvc::grad, fvMatrix::A/H/flux/&/relax,
 // constrainHbyA, patch-field coefficients) are un-vendored; their semantics for the canonical scheme set are
 // documented in DESIGN.md and restated independently by oracle/residual.py.
@@ -46,8 +49,28 @@ struct ResParams {
     int offP, offT, offN, offPhi;
     // perfect-gas / hConst / const-transport thermo (reference DAResidual.C:179-293)
     double Cp, Rgas, mu, Pr, Prt;
+    // DATurboFoam switches and the MRF zone (angular velocity, origin)
+    int turbo, transonic, transonicPC, mrf;
+    double om[3], org[3];
+    // DATurboFoam work arrays of the launch (typed by the kernel's scalar type): Teff.U per cell (3N), 1/AtU per cell (N)
+    void* wTU;
+    void* wRAtU;
 };
 #define DAS_TREF 298.15
+
+// Omega x (x - origin)
+DAS_HD void mrf_velocity(const ResParams& prm, const double* x, double* v) {
+    const double r0 = x[0] - prm.org[0], r1 = x[1] - prm.org[1], r2 = x[2] - prm.org[2];
+    v[0] = prm.om[1] * r2 - prm.om[2] * r1;
+    v[1] = prm.om[2] * r0 - prm.om[0] * r2;
+    v[2] = prm.om[0] * r1 - prm.om[1] * r0;
+}
+// (Omega x (Cf - origin)) . Sf : what makeRelative subtracts per unit density
+DAS_HD double mrf_face_flux(const ResParams& prm, const FaceGeom& g) {
+    double v[3];
+    mrf_velocity(prm, g.Cf, v);
+    return v[0] * g.Sf[0] + v[1] * g.Sf[1] + v[2] * g.Sf[2];
+}
 
 // SA constants (reference DASpalartAllmaras.C:47-80)
 #define SA_SIGMA 0.66666
@@ -160,7 +183,15 @@ DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc
                        const T& Tc, const T& nc, const T& nut_c, double phib, BFace<T>& o) {
 #pragma unroll
     for (int k = 0; k < 3; k++) o.nrm[k] = g.Sf[k] / g.magSf;
-    bc_vector<T>(bc.U_code, bc.U_val, bc.dU_val, g.nod, phib, o.nrm, Uc, o.U);
+    if (RHO && prm.mrf && bc.mrf_included && bc.U_code == DAS_BC_FIXED_VALUE) {
+        // MRFZone::correctBoundaryVelocity: fixedValue patches that rotate with the zone carry Omega x r
+        double uw[3];
+        const double zero[3] = {0.0, 0.0, 0.0};
+        mrf_velocity(prm, g.Cf, uw);
+        bc_vector<T>(bc.U_code, uw, zero, g.nod, phib, o.nrm, Uc, o.U);
+    } else {
+        bc_vector<T>(bc.U_code, bc.U_val, bc.dU_val, g.nod, phib, o.nrm, Uc, o.U);
+    }
     bc_scalar<T>(bc.p_code, bc.p_val, bc.dp_val, g.nod, phib, pc, o.p);
     bc_scalar<T>(bc.nuTilda_code, bc.nuTilda_val, bc.dnuTilda_val, g.nod, phib, nc, o.n);
     if (RHO) {
@@ -186,10 +217,28 @@ DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc
     }
 }
 
+// q = Teff . U with Teff = muEff dev(twoSymm(grad U))  (= -devRhoReff, symmetric); g[3*i+j] = d_i U_j
+template <class T>
+DAS_HD void teff_dot_u(const T* g, const T& muEff, const T* U, T* q) {
+    T tr3 = (2.0 / 3.0) * (g[0] + g[4] + g[8]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        T acc(0.0);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            T sij = g[3 * i + j] + g[3 * j + i];
+            if (i == j) sij = sij - tr3;
+            acc += sij * U[j];
+        }
+        q[i] = muEff * acc;
+    }
+}
+
 // ================================================================================ k_grad
 // per cell: nut = nuTilda*fv1 ; Gauss-linear gradients of U, p, nuTilda (and he = Cp (T - Tref) when RHO)
 template <class T, bool RHO>
-DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W, T* nut, T* gradU, T* gradP, T* gradN, T* gradH) {
+DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W, T* nut, T* gradU, T* gradP, T* gradN, T* gradH,
+                      T* TU = nullptr) {
     const long long N = m.nC;
     const CellGeom& cgc = m.cg[c];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
@@ -246,6 +295,15 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
         gradN[3LL * c + k] = gN[k] * rV;
         if (RHO) gradH[3LL * c + k] = gH[k] * rV;
     }
+    if (RHO && prm.turbo) {  // viscous-work vector Teff.U of the cell (EEqn: - fvc::div(Teff.T() & U))
+#pragma unroll
+        for (int k = 0; k < 9; k++) gU[k] = gU[k] * rV;
+        T rho_c = pc / (prm.Rgas * Tc);
+        T q[3];
+        teff_dot_u<T>(gU, rho_c * (nu_c + nut_c), Uc, q);
+#pragma unroll
+        for (int k = 0; k < 3; k++) TU[3LL * c + k] = q[k];
+    }
 }
 
 // tau = nuEff * dev2(T(gradU)) ; g[3*i+j] = d_i U_j
@@ -267,7 +325,7 @@ DAS_HD void dev2T_scaled(const T* g, const T& nuEff, T* tau) {
 // (RHO) the energy residual TRes = EEqn & he.  RHO: phi is the mass flux, muEff = mu + rho nut replaces nuEff.
 template <class T, bool RHO>
 DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const T* gradP,
-                      const T* gradN, const T* gradH, T* R, T* rAU, T* HbyA) {
+                      const T* gradN, const T* gradH, T* R, T* rAU, T* HbyA, const T* TU = nullptr, T* rAtU = nullptr) {
     const long long N = m.nC;
     const CellGeom& cgc = m.cg[c];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
@@ -289,7 +347,11 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     T aEff_c = RHO ? prm.mu / prm.Pr + rho_c * nut_c * (1.0 / prm.Prt) : T(0.0);
     T K_c = RHO ? 0.5 * (Uc[0] * Uc[0] + Uc[1] * Uc[1] + Uc[2] * Uc[2]) : T(0.0);
 
-    T D0(0.0), sumOff(0.0), sumPhi(0.0), vmaxs(0.0), vmins(0.0);
+    const bool turbo = RHO && prm.turbo;
+    const bool mrf = RHO && prm.mrf;
+    double vC_c[3] = {0.0, 0.0, 0.0};
+    if (mrf) mrf_velocity(prm, cgc.C, vC_c);
+    T D0(0.0), sumOff(0.0), sumPhi(0.0), vmaxs(0.0), vmins(0.0), sumOffSigned(0.0);
     T offU[3], src[3], bdiag[3], bsrc[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) { offU[k] = T(0.0); src[k] = T(0.0); bdiag[k] = T(0.0); bsrc[k] = T(0.0); }
@@ -333,6 +395,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             T offTot = off - cd;
             D0 += dcoef + cd;
             sumOff += dabs(offTot);
+            sumOffSigned += offTot;
 #pragma unroll
             for (int k = 0; k < 3; k++) offU[k] += offTot * Uo[k];
             // ---- linearUpwindV explicit correction (skipped for the PC residual: div(pc) = upwind)
@@ -399,6 +462,20 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 bool ownerIsC = !nb;
                 T Kf = ((pv >= 0.0) == ownerIsC) ? K_c : K_o;
                 sE -= (sg * phi) * Kf;
+                if (turbo) {
+                    // - fvc::div(Teff.T() & U) (Gauss linear) and + fvc::div(p (U - URel)), U - URel = Omega x r
+                    T qf = g.Sf[0] * (wc * TU[3LL * c] + wo * TU[3LL * o]) + g.Sf[1] * (wc * TU[3LL * c + 1] + wo * TU[3LL * o + 1])
+                           + g.Sf[2] * (wc * TU[3LL * c + 2] + wo * TU[3LL * o + 2]);
+                    sE += sg * qf;
+                    if (mrf) {
+                        double vC_o[3];
+                        mrf_velocity(prm, cgo.C, vC_o);
+                        T p_o = W[prm.offP * N + o];
+                        T wf = g.Sf[0] * (wc * (pc * vC_c[0]) + wo * (p_o * vC_o[0])) + g.Sf[1] * (wc * (pc * vC_c[1]) + wo * (p_o * vC_o[1]))
+                               + g.Sf[2] * (wc * (pc * vC_c[2]) + wo * (p_o * vC_o[2]));
+                        sE -= sg * wf;
+                    }
+                }
             }
         } else {
             BFace<T> b;
@@ -449,12 +526,34 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 bsE += ga_b * b.he.gbc - phi * b.he.vbc;
                 T Kb = 0.5 * (b.U.xb[0] * b.U.xb[0] + b.U.xb[1] * b.U.xb[1] + b.U.xb[2] * b.U.xb[2]);
                 sE -= phi * Kb;
+                if (turbo) {
+                    T qb[3];
+                    teff_dot_u<T>(gUb, muEff_b, b.U.xb, qb);
+                    sE += g.Sf[0] * qb[0] + g.Sf[1] * qb[1] + g.Sf[2] * qb[2];
+                    if (mrf) {
+                        const PatchBC& pb_ = m.bc[m.bpatch[f - m.nIF]];
+                        T wb[3];
+                        if (pb_.mrf_included) { wb[0] = b.U.xb[0]; wb[1] = b.U.xb[1]; wb[2] = b.U.xb[2]; }
+                        else {
+                            double vF[3];
+                            mrf_velocity(prm, g.Cf, vF);
+                            wb[0] = T(vF[0]); wb[1] = T(vF[1]); wb[2] = T(vF[2]);
+                        }
+                        sE -= b.p.xb * (g.Sf[0] * wb[0] + g.Sf[1] * wb[1] + g.Sf[2] * wb[2]);
+                    }
+                }
             }
         }
     }
     // bounded Gauss: - fvm::Sp(div(phi))
     D0 -= sumPhi;
     dN -= sumPhi;
+    if (mrf) {  // + MRF.DDt(rho, U): source -= V rho (Omega x U)   (MRFZone::addCoriolis)
+        const T rv = cgc.V * rho_c;
+        src[0] -= rv * (prm.om[1] * Uc[2] - prm.om[2] * Uc[1]);
+        src[1] -= rv * (prm.om[2] * Uc[0] - prm.om[0] * Uc[2]);
+        src[2] -= rv * (prm.om[0] * Uc[1] - prm.om[1] * Uc[0]);
+    }
     // fvMatrix::relax (see DESIGN.md "relax"): diagonal dominance fix-up with boundary max/min contributions
     T D = dmax(dabs(D0 + vmaxs), sumOff) * (1.0 / prm.alphaU) - vmins;
     T dD = D - D0;
@@ -463,6 +562,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     T A = (D + avgb) * rV;
     T rA = 1.0 / A;
     rAU[c] = rA;
+    if (turbo) rAtU[c] = 1.0 / (A + sumOffSigned * rV);  // AtU = AU - H1, H1 = -sum(off-diagonal)/V  (fvMatrix::H1)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         T sk = src[k] + dD * Uc[k];
@@ -504,10 +604,79 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
 // per face: phiHbyA, pressure flux, q = flux - phiHbyA (consumed by k_pres) and phiRes
 template <class T, bool RHO>
 DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradP, const T* rAU,
-                      const T* HbyA, T* q, T* R) {
+                      const T* HbyA, T* q, T* R, const T* rAtU = nullptr) {
     const long long N = m.nC;
     const FaceGeom& g = m.fg[f];
     T phiHbyA, flux;
+    const bool turbo = RHO && prm.turbo;
+    const double rel = (RHO && prm.mrf) ? mrf_face_flux(prm, g) : 0.0;
+    if (turbo) {
+        // DAResidualTurboFoam.C:146-212.  "phiHbyA" below is what enters div(): phiHbyA (+ SIMPLEC correction), or the
+        // convective flux phid_f p_upwind of fvm::div(phid,p) in the transonic form.
+        T snGradP, rho_f;
+        if (f < m.nIF) {
+            int o = m.owner[f], n = m.neigh[f];
+            const double wl = g.w, wn = 1.0 - g.w;
+            T po = W[prm.offP * N + o], pn = W[prm.offP * N + n];
+            T psio = 1.0 / (prm.Rgas * W[prm.offT * N + o]), psin = 1.0 / (prm.Rgas * W[prm.offT * N + n]);
+            T ro = po * psio, rn = pn * psin;
+            T cg = g.corr[0] * (wl * gradP[3LL * o] + wn * gradP[3LL * n]) + g.corr[1] * (wl * gradP[3LL * o + 1] + wn * gradP[3LL * n + 1])
+                   + g.corr[2] * (wl * gradP[3LL * o + 2] + wn * gradP[3LL * n + 2]);
+            snGradP = g.nod * (pn - po) + cg;
+            rho_f = wl * ro + wn * rn;
+            if (!prm.transonic) {
+                phiHbyA = g.Sf[0] * (wl * (ro * HbyA[3LL * o]) + wn * (rn * HbyA[3LL * n]))
+                          + g.Sf[1] * (wl * (ro * HbyA[3LL * o + 1]) + wn * (rn * HbyA[3LL * n + 1]))
+                          + g.Sf[2] * (wl * (ro * HbyA[3LL * o + 2]) + wn * (rn * HbyA[3LL * n + 2])) - rho_f * rel;
+                T dr = wl * (ro * (rAtU[o] - rAU[o])) + wn * (rn * (rAtU[n] - rAU[n]));
+                phiHbyA += dr * snGradP * g.magSf;
+                flux = (wl * (ro * rAtU[o]) + wn * (rn * rAtU[n])) * g.magSf * snGradP;
+            } else {
+                T hs = g.Sf[0] * (wl * HbyA[3LL * o] + wn * HbyA[3LL * n]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * HbyA[3LL * n + 1])
+                       + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * HbyA[3LL * n + 2]);
+                T phid = (wl * psio + wn * psin) * (hs - rel);
+                phiHbyA = phid * (val(phid) >= 0.0 ? po : pn);
+                flux = (wl * (ro * rAU[o]) + wn * (rn * rAU[n])) * g.magSf * snGradP;
+            }
+        } else {
+            int c = m.owner[f];
+            const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
+            T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
+            T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c], Tc = W[prm.offT * N + c];
+            BFace<T> b;
+            eval_bface<T, RHO>(bc, g, m.cg[c], prm, Uc, pc, Tc, nc, nut[c], val(W[prm.offPhi * N + f]), b);
+            T Hb[3] = {HbyA[3LL * c], HbyA[3LL * c + 1], HbyA[3LL * c + 2]};
+            if (bc.U_code == DAS_BC_SYMMETRY) {
+                T hn = b.nrm[0] * Hb[0] + b.nrm[1] * Hb[1] + b.nrm[2] * Hb[2];
+#pragma unroll
+                for (int k = 0; k < 3; k++) Hb[k] = Hb[k] - b.nrm[k] * hn;
+            }
+            if (prm.constrainHbyA && bc.U_code == DAS_BC_FIXED_VALUE) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) Hb[k] = b.U.xb[k];
+            }
+            snGradP = b.p.gic * pc + b.p.gbc;
+            T hs = g.Sf[0] * Hb[0] + g.Sf[1] * Hb[1] + g.Sf[2] * Hb[2];
+            const bool incl = prm.mrf && bc.mrf_included;
+            if (!prm.transonic) {
+                phiHbyA = incl ? T(0.0) : b.rho_b * (hs - rel);
+                phiHbyA += (b.rho_b * (rAtU[c] - rAU[c])) * snGradP * g.magSf;
+                flux = (b.rho_b * rAtU[c]) * g.magSf * snGradP;
+            } else {
+                T psib = 1.0 / (prm.Rgas * b.Tt.xb);
+                T phid = incl ? T(0.0) : psib * (hs - rel);
+                phiHbyA = phid * b.p.xb;
+                flux = (b.rho_b * rAU[c]) * g.magSf * snGradP;
+            }
+        }
+        if (prm.transonic && prm.isPC && prm.transonicPC == 1) phiHbyA = T(0.0);  // the PC drops div(phid,p)
+        q[f] = flux - phiHbyA;
+        T pr = phiHbyA - flux - W[prm.offPhi * N + f];
+        if (prm.transonic && prm.isPC && prm.transonicPC == 2) pr = W[prm.offPhi * N + f];  // phiRes = phi
+        if (prm.normPhi) pr = pr * (1.0 / g.magSf);
+        R[prm.offPhi * N + f] = pr;
+        return;
+    }
     if (f < m.nIF) {
         int o = m.owner[f], n = m.neigh[f];
         const double wl = g.w, wn = 1.0 - g.w;
@@ -517,7 +686,7 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
         if (RHO) {
             ro = W[prm.offP * N + o] / (prm.Rgas * W[prm.offT * N + o]);
             rn = W[prm.offP * N + n] / (prm.Rgas * W[prm.offT * N + n]);
-            phiHbyA = (wl * ro + wn * rn) * phiHbyA;
+            phiHbyA = (wl * ro + wn * rn) * (phiHbyA - rel);  // MRF.makeRelative(interpolate(rho), phiHbyA)
         }
         T gp = (wl * (ro * rAU[o]) + wn * (rn * rAU[n])) * g.magSf;
         T cg = g.corr[0] * (wl * gradP[3LL * o] + wn * gradP[3LL * n]) + g.corr[1] * (wl * gradP[3LL * o + 1] + wn * gradP[3LL * n + 1])
@@ -541,7 +710,8 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
 #pragma unroll
             for (int k = 0; k < 3; k++) Hb[k] = b.U.xb[k];
         }
-        phiHbyA = b.rho_b * (g.Sf[0] * Hb[0] + g.Sf[1] * Hb[1] + g.Sf[2] * Hb[2]);
+        phiHbyA = b.rho_b * (g.Sf[0] * Hb[0] + g.Sf[1] * Hb[1] + g.Sf[2] * Hb[2] - rel);
+        if (RHO && prm.mrf && bc.mrf_included) phiHbyA = T(0.0);  // relative flux through a patch that rotates with the zone
         flux = (b.rho_b * rAU[c]) * g.magSf * (b.p.gic * pc + b.p.gbc);
     }
     q[f] = flux - phiHbyA;

@@ -130,6 +130,7 @@ void Mesh::build(const das_case_t* c) {
         b.T_val = c->bc_T_val ? c->bc_T_val[p] : 0.0;
         b.dU_val[0] = b.dU_val[1] = b.dU_val[2] = 0.0;
         b.dp_val = b.dnuTilda_val = b.dT_val = 0.0;
+        b.mrf_included = (c->mrf_active && c->patch_mrf_rotating) ? (c->patch_mrf_rotating[p] != 0) : 0;
     }
     DAS_CHECK(expect == nF, DAS_ERR_ARG, "patches do not cover all boundary faces");
     compute_geometry(c->y_wall);

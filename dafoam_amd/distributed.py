@@ -352,10 +352,13 @@ def extract_submesh(case, part, rank, G=GHOST_LAYERS):
     sc.bcs["ghostcut"] = {"U": (BC_ZERO_GRADIENT, (0.0, 0.0, 0.0)), "p": (BC_ZERO_GRADIENT, 0.0), "T": (BC_ZERO_GRADIENT, 0.0),
                           "nuTilda": (BC_ZERO_GRADIENT, 0.0), "nut": (NUT_CALCULATED, 0.0)}
     sc.y_wall = None if case.y_wall is None else case.y_wall[cell_g]
+    if getattr(case, "mrf", None):  # cut faces are interior faces of the zone: relative flux as for internal faces
+        sc.mrf = dict(case.mrf)
+        sc.mrf["nonRotatingPatches"] = list(case.mrf.get("nonRotatingPatches", ())) + ["ghostcut"]
     nl = cell_g.size
     W = case.states
     solver = case.solver_name
-    nsc = {"DASimpleFoam": 2, "DARhoSimpleFoam": 3}[solver]
+    nsc = {"DASimpleFoam": 2, "DARhoSimpleFoam": 3, "DATurboFoam": 3}[solver]
     blocks_g = [np.repeat(3 * cell_g, 3) + np.tile(np.arange(3), nl)] + [(3 + b) * N + cell_g for b in range(nsc)] + [(3 + nsc) * N + face_g]
     key = np.concatenate(blocks_g)
     sgn = np.concatenate([np.ones(key.size - face_g.size), face_sign])

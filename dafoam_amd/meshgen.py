@@ -86,6 +86,11 @@ class FoamCase:
     T_old: Optional[np.ndarray] = None
     # compressible thermo (hePsiThermo/perfectGas/hConst/const transport, reference DAResidual.C:179-293)
     thermo: Dict[str, float] = field(default_factory=lambda: {"Cp": 1005.0, "molWeight": 28.96, "mu": 1.8e-5, "Pr": 0.7, "Prt": 1.0})
+    # constant/MRFProperties (one zone = the whole mesh): {"omega": (3,), "origin": (3,), "nonRotatingPatches": [names]}
+    mrf: Optional[dict] = None
+    # system/fvSolution SIMPLE.transonic and the reference option transonicPCOption (DATurboFoam)
+    transonic: bool = False
+    transonic_pc_option: int = 1
 
 
 def hex_block(
@@ -297,7 +302,7 @@ def n_states(case: FoamCase) -> int:
         return m.n_cells
     if case.solver_name == "DASimpleFoam":
         return 5 * m.n_cells + m.n_faces
-    if case.solver_name == "DARhoSimpleFoam":
+    if case.solver_name in ("DARhoSimpleFoam", "DATurboFoam"):
         return 6 * m.n_cells + m.n_faces
     raise ValueError(case.solver_name)
 
@@ -539,6 +544,21 @@ def rho_channel_case(nx=7, ny=7, nz=7, lengths=(1.0, 0.2, 0.1), U0=50.0, p0=1013
     p = p0 + rho0 * pk
     T = T0 * (1.0 + 0.01 * np.sin(np.pi * g.C[:, 0] / lengths[0]) * np.cos(np.pi * g.C[:, 1] / lengths[1]))
     case.states = np.concatenate([U.ravel(), p, T, nuT, rho0 * phiv])
+    return case
+
+
+def turbo_channel_case(nx=7, ny=7, nz=7, omega=(60.0, 0.0, 0.0), origin=(0.0, -0.3, 0.0), transonic=False, mrf=True,
+                       solver_name="DATurboFoam", **kw) -> FoamCase:
+    """DATurboFoam (or DARhoSimpleFoam with MRF) on the compressible channel: one MRF zone covering the mesh, rotating
+    about `omega` through `origin`; inlet, outlet and the top wall (a stationary shroud) are nonRotatingPatches, the
+    bottom wall (hub) and the symmetry planes rotate with the zone (reference tests/runRegTests_DATurboFoam*.py,
+    runUnitTests_DARhoSimpleFoamMRF.py use constant/MRFProperties of the CompressorFluid case)."""
+    case = rho_channel_case(nx, ny, nz, **kw)
+    case.solver_name = solver_name
+    if mrf:
+        case.mrf = {"omega": tuple(float(x) for x in omega), "origin": tuple(float(x) for x in origin),
+                    "nonRotatingPatches": ["inlet", "outlet", "top"]}
+    case.transonic = bool(transonic)
     return case
 
 

@@ -36,6 +36,8 @@ extern "C" {
 #define DAS_SOLVER_SIMPLEFOAM 0          /* DASimpleFoam + SpalartAllmaras */
 #define DAS_SOLVER_SCALARTRANSPORTFOAM 1 /* DAScalarTransportFoam */
 #define DAS_SOLVER_RHOSIMPLEFOAM 2       /* DARhoSimpleFoam + SpalartAllmaras (perfect gas, hConst, const transport) */
+#define DAS_SOLVER_TURBOFOAM 3          /* DATurboFoam + SpalartAllmaras: SIMPLEC-consistent / transonic pEqn, "h" energy, MRF */
+#define DAS_IS_COMPRESSIBLE(s) ((s) == DAS_SOLVER_RHOSIMPLEFOAM || (s) == DAS_SOLVER_TURBOFOAM)
 
 /* patch types */
 #define DAS_PATCH_PATCH 0
@@ -89,6 +91,15 @@ typedef struct das_case {
     /* DARhoSimpleFoam thermophysicalProperties (reference DAResidual.C:179-293): Cp [J/kg/K], molWeight [kg/kmol],
      * mu [Pa s], Pr, Prt */
     double Cp, molWeight, mu, Pr, Prt;
+    /* constant/MRFProperties, one zone covering the mesh (OpenFOAM MRFZone; used by DARhoSimpleFoam and DATurboFoam,
+     * reference DAResidualRhoSimpleFoam.C:123,186, DAResidualTurboFoam.C:107,130,161,200): angular velocity vector
+     * [rad/s], origin, and per patch 1 = the patch rotates with the zone (not listed in nonRotatingPatches) */
+    int mrf_active;
+    double mrf_omega[3], mrf_origin[3];
+    const int* patch_mrf_rotating; /* n_patches, may be NULL when mrf_active == 0 */
+    /* DATurboFoam: system/fvSolution SIMPLE.transonic and the reference option transonicPCOption (-1/0: keep
+     * div(phid,p) in the PC, 1: drop it, 2: additionally phiRes = phi) */
+    int transonic, transonic_pc_option;
 } das_case_t;
 
 const char* das_last_error(void);

@@ -21,7 +21,7 @@ def force(case, g, W, patches, direction, scale=1.0):
     N, F, nIF = g.nC, g.nF, g.nIF
     ops = Ops(g)
     bcell = ops.bc
-    rho_solver = case.solver_name == "DARhoSimpleFoam"
+    rho_solver = case.solver_name in ("DARhoSimpleFoam", "DATurboFoam")
     if rho_solver:
         from .residual_rho import RR, unpack_rho
 

@@ -49,6 +49,15 @@ STENCIL = {
         "nuTildaRes": [["U", "T", "p", "nuTilda", "phi"], ["U", "T", "p", "nuTilda"], ["T", "p", "nuTilda"]],
         "phiRes": [["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda"], ["U", "T"]],
     },
+    # DAStateInfoTurboFoam.C:44-49,82-119 (the level table equals the RhoSimpleFoam one) + compressible SA
+    "DATurboFoam": {
+        "states": [("U", "vec"), ("p", "scl"), ("T", "scl"), ("nuTilda", "scl"), ("phi", "face")],
+        "URes": [["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda"], ["U", "T"]],
+        "pRes": [["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda"], ["U"]],
+        "TRes": [["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda"], ["U", "p", "T"]],
+        "nuTildaRes": [["U", "T", "p", "nuTilda", "phi"], ["U", "T", "p", "nuTilda"], ["T", "p", "nuTilda"]],
+        "phiRes": [["U", "p", "T", "nuTilda", "phi"], ["U", "p", "T", "nuTilda"], ["U", "T"]],
+    },
     "DAScalarTransportFoam": {
         "states": [("T", "scl")],
         "TRes": [["T"], ["T"], ["T"]],

@@ -505,7 +505,7 @@ def residual(case, g, W, isPC=False, **kw):
         return simple_residual(case, g, W, isPC=isPC, **kw)
     if case.solver_name == "DAScalarTransportFoam":
         return scalar_transport_residual(case, g, W, isPC=isPC, **kw)
-    if case.solver_name == "DARhoSimpleFoam":
+    if case.solver_name in ("DARhoSimpleFoam", "DATurboFoam"):
         from .residual_rho import rho_simple_residual
 
         return rho_simple_residual(case, g, W, isPC=isPC, **kw)

@@ -14,6 +14,16 @@ Canonical schemes: div(phi,U) bounded Gauss linearUpwindV grad(U) (u
 div(phi,h), div(phi,nuTilda), div(phi,K) [fvc]: (bounded) Gauss upwind; laplacians Gauss linear corrected;
 div(((rho*nuEff)*dev2(T(grad(U))))) Gauss linear.  phi is the MASS flux.
 The he patch fields mirror the T patch fields (fixedEnergy / gradientEnergy / mixedEnergy).
+
+DATurboFoam (turbo=True) restates DAResidualTurboFoam::calcResiduals (reference DAResidualTurboFoam.C:66-233) on the same
+state layout (DAStateInfoTurboFoam.C:44-49): SIMPLEC-consistent pressure equation (AtU = AU - H1), optional transonic
+pEqn (fvm::div(phid,p), Gauss upwind; transonicPCOption 1/2 for the PC), the "h" energy equation with viscous work
+-div(Teff.T() & U) and the MRF pressure-work term div(p (U - URel)).
+MRF (case.mrf = {omega, origin, nonRotatingPatches}; one zone = the whole mesh) follows OpenFOAM's MRFZone:
+Coriolis source rho (Omega x U) (MRFZone::addCoriolis), relative mass flux phi -= rho_f (Omega x r).Sf on internal
+and excluded patch faces, 0 on included (rotating) patch faces (makeRelativeRhoFlux), U_b = Omega x r on included
+fixedValue patches (correctBoundaryVelocity).  Used by DARhoSimpleFoam too (DAResidualRhoSimpleFoam.C:123,186).
+Coupled (cyclic) patches are not restated.
 PARITY UNPINNED (see oracle/README.md); dtype generic (complex step).
 """
 from __future__ import annotations
@@ -37,8 +47,32 @@ def unpack_rho(W, N, F):
     return U, p, T, nuT, phi
 
 
+def mrf_fields(case, g):
+    """Geometry-only MRF quantities (one zone covering the mesh), or None."""
+    m = getattr(case, "mrf", None)
+    if not m:
+        return None
+    om = np.asarray(m["omega"], dtype=float)
+    o = np.asarray(m.get("origin", (0.0, 0.0, 0.0)), dtype=float)
+    nIF = g.nIF
+    vF = np.cross(om, g.Cf - o)
+    Sf_all = np.concatenate([g.Sf[:nIF], g.bSf])
+    rel = (vF * Sf_all).sum(1)
+    incl = np.zeros(g.nBF, bool)
+    sl = g.patch_slices()
+    for pch in case.mesh.patches:
+        if pch.name not in m.get("nonRotatingPatches", ()):
+            incl[sl[pch.name]] = True
+    return dict(om=om, vC=np.cross(om, g.C - o), vFb=vF[nIF:], rel_i=rel[:nIF], rel_b=rel[nIF:], incl=incl)
+
+
 def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "nuTildaRes", "phiRes"), use_constrain_hbya=True,
-                        return_parts=False):
+                        return_parts=False, turbo=None):
+    if turbo is None:
+        turbo = case.solver_name == "DATurboFoam"
+    transonic = bool(turbo and getattr(case, "transonic", False))
+    tpc = int(getattr(case, "transonic_pc_option", 1))
+    mrf = mrf_fields(case, g)
     N, F, nIF, nBF = g.nC, g.nF, g.nIF, g.nBF
     ops = Ops(g)
     oi, ni, bcell = ops.oi, ops.ni, ops.bc
@@ -53,6 +87,9 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
     V = g.V
     n_b = g.bnf
 
+    if mrf is not None:  # MRFZone::correctBoundaryVelocity: rotating (included) fixedValue patches move with the zone
+        rot = mrf["incl"] & (bt.code["U"] == BC_FIXED_VALUE)
+        bt.val["U"] = np.where(rot[:, None], mrf["vFb"], bt.val["U"])
     # ---- state BCs
     Ub, UvIC, UvBC, UgIC, UgBC = bc_vector(bt.code["U"], bt.val["U"], U[bcell], delta, phi_b, n_b)
     pb, pvIC, pvBC, pgIC, pgBC = bc_scalar(bt.code["p"], bt.val["p"], p[bcell], delta, phi_b)
@@ -126,6 +163,8 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
     tau = muEff[:, None, None] * dev2T(gradU)
     tau_b = muEff_b[:, None, None] * dev2T(gradU_b)
     src = src + ops.surface_sum(np.einsum("fi,fij->fj", g.Sf[:nIF], ops.interp(tau)), np.einsum("fi,fij->fj", g.bSf, tau_b))
+    if mrf is not None:  # + MRF.DDt(rho, U): source -= V rho (Omega x U)
+        src = src - (V * rho)[:, None] * np.cross(mrf["om"], U)
     D0 = diag
     sumOff = sadd(oi, _abs(upper), N) + sadd(ni, _abs(lower), N)
     D = relax_diag(D0, sumOff, iC, bcell, case.relax["U"], N)
@@ -139,6 +178,8 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
     H = ((avgb[:, None] - bdiag) * U - offU + src + bsrc) / V[:, None]
     rAU = 1.0 / A
     HbyA = rAU[:, None] * H
+    # fvMatrix::H1(): minus the sum of the off-diagonal coefficients, per volume (SIMPLEC: AtU = AU - H1)
+    H1 = -(sadd(oi, upper, N) + sadd(ni, lower, N)) / V
 
     # =================================================================== EEqn (& he)
     gradHe = ops.grad_scalar(he, heb)
@@ -161,6 +202,21 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
     Kb = 0.5 * (Ub * Ub).sum(1)
     Kf = np.where(np.real(phi_i) >= 0, K[oi], K[ni])
     sE = sE - ops.surface_sum(phi_i * Kf, phi_b * Kb)
+    if turbo:
+        # - fvc::div(Teff.T() & U), Teff = -devRhoReff = muEff dev(twoSymm(grad U))  (Gauss linear)
+        def teff(mu_, gU_):
+            ts = gU_ + np.swapaxes(gU_, 1, 2)
+            tr = np.einsum("cii->c", ts)
+            return mu_[:, None, None] * (ts - (tr / 3.0)[:, None, None] * np.eye(3))
+
+        q = np.einsum("cij,cj->ci", teff(muEff, gradU), U)
+        q_b = np.einsum("fij,fj->fi", teff(muEff_b, gradU_b), Ub)
+        sE = sE + ops.surface_sum((g.Sf[:nIF] * ops.interp(q)).sum(1), (g.bSf * q_b).sum(1))
+        if mrf is not None:
+            # + fvc::div(p (U - URel)):  U - URel = Omega x r (cells and every patch face of the zone)
+            w_ = p[:, None] * mrf["vC"]
+            w_b = pb[:, None] * np.where(mrf["incl"][:, None], Ub, mrf["vFb"])
+            sE = sE - ops.surface_sum((g.Sf[:nIF] * ops.interp(w_)).sum(1), (g.bSf * w_b).sum(1))
     offE = sadd(oi, upE * he[ni], N) + sadd(ni, loE * he[oi], N)
     TRes = ((dE + sadd(bcell, iCe, N)) * he + offE - sE - sadd(bcell, bCe, N)) / V
 
@@ -174,18 +230,60 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
     if use_constrain_hbya:
         fx = cU == BC_FIXED_VALUE
         HbyA_b[fx] = Ub[fx]
-    phiHbyA_i = ops.interp(rho) * (ops.interp(HbyA) * g.Sf[:nIF]).sum(1)
-    phiHbyA_b = rho_b * (HbyA_b * g.bSf).sum(1)
-    rr = rho * rAU
-    gp = ops.interp(rr) * g.magSf[:nIF]
-    gp_b = rho_b * rAU[bcell] * g.bMagSf
+    psi = 1.0 / (R * T)
+    psi_b = 1.0 / (R * Tb)
+    rel_i = mrf["rel_i"] if mrf is not None else 0.0
+    rel_b = mrf["rel_b"] if mrf is not None else 0.0
+    incl = mrf["incl"] if mrf is not None else np.zeros(nBF, bool)
     gradPf = ops.interp(gradP)
-    flux_i = gp * g.nonOrthDeltaCoeffs * (p[ni] - p[oi]) + gp * (g.nonOrthCorr * gradPf).sum(1)
-    flux_b = gp_b * (pgIC * p[bcell] + pgBC)
-    # pEqn = div(phiHbyA) - laplacian(rhorAUf, p);  pRes = pEqn & p
-    pRes = (ops.surface_sum(phiHbyA_i, phiHbyA_b) - ops.surface_sum(flux_i, flux_b)) / V
-    # phiRes = phiHbyA + pEqn.flux() - phi,  pEqn.flux() = -flux
-    phiRes = np.concatenate([phiHbyA_i - flux_i - phi_i, phiHbyA_b - flux_b - phi_b])
+    snGradP_i = g.nonOrthDeltaCoeffs * (p[ni] - p[oi]) + (g.nonOrthCorr * gradPf).sum(1)
+    snGradP_b = pgIC * p[bcell] + pgBC
+    if not turbo:
+        phiHbyA_i = ops.interp(rho) * (ops.interp(HbyA) * g.Sf[:nIF]).sum(1) - ops.interp(rho) * rel_i
+        phiHbyA_b = np.where(incl, 0.0 * rho_b, rho_b * (HbyA_b * g.bSf).sum(1) - rho_b * rel_b)
+        rr = rho * rAU
+        gp = ops.interp(rr) * g.magSf[:nIF]
+        gp_b = rho_b * rAU[bcell] * g.bMagSf
+        flux_i = gp * snGradP_i
+        flux_b = gp_b * snGradP_b
+        # pEqn = div(phiHbyA) - laplacian(rhorAUf, p);  pRes = pEqn & p
+        pRes = (ops.surface_sum(phiHbyA_i, phiHbyA_b) - ops.surface_sum(flux_i, flux_b)) / V
+        # phiRes = phiHbyA + pEqn.flux() - phi,  pEqn.flux() = -flux
+        phiRes = np.concatenate([phiHbyA_i - flux_i - phi_i, phiHbyA_b - flux_b - phi_b])
+    elif not transonic:
+        AtU = A - H1
+        rhoHbyA = rho[:, None] * HbyA
+        phiHbyA_i = (ops.interp(rhoHbyA) * g.Sf[:nIF]).sum(1) - ops.interp(rho) * rel_i
+        phiHbyA_b = np.where(incl, 0.0 * rho_b, rho_b * (HbyA_b * g.bSf).sum(1) - rho_b * rel_b)
+        dr = rho / AtU - rho / A
+        dr_b = rho_b * (1.0 / AtU[bcell] - 1.0 / A[bcell])
+        phiHbyA_i = phiHbyA_i + ops.interp(dr) * snGradP_i * g.magSf[:nIF]
+        phiHbyA_b = phiHbyA_b + dr_b * snGradP_b * g.bMagSf
+        gp = ops.interp(rho / AtU) * g.magSf[:nIF]
+        gp_b = rho_b / AtU[bcell] * g.bMagSf
+        flux_i = gp * snGradP_i
+        flux_b = gp_b * snGradP_b
+        pRes = (ops.surface_sum(phiHbyA_i, phiHbyA_b) - ops.surface_sum(flux_i, flux_b)) / V
+        phiRes = np.concatenate([phiHbyA_i - flux_i - phi_i, phiHbyA_b - flux_b - phi_b])
+    else:
+        # phid = interpolate(psi) (interpolate(HbyA) & Sf), made relative with interpolate(psi)
+        phid_i = ops.interp(psi) * ((ops.interp(HbyA) * g.Sf[:nIF]).sum(1) - rel_i)
+        phid_b = np.where(incl, 0.0 * psi_b, psi_b * ((HbyA_b * g.bSf).sum(1) - rel_b))
+        # fvm::div(phid, p) Gauss upwind: face flux phid_f p_upwind (boundary: phid_b p_b)
+        pf = np.where(np.real(phid_i) >= 0, p[oi], p[ni])
+        conv_i = phid_i * pf
+        conv_b = phid_b * pb
+        if isPC and tpc == 1:  # transonicPCOption 1: the PC drops div(phid,p)
+            conv_i, conv_b = 0.0 * conv_i, 0.0 * conv_b
+        gp = ops.interp(rho * rAU) * g.magSf[:nIF]
+        gp_b = rho_b * rAU[bcell] * g.bMagSf
+        flux_i = gp * snGradP_i
+        flux_b = gp_b * snGradP_b
+        pRes = (ops.surface_sum(conv_i, conv_b) - ops.surface_sum(flux_i, flux_b)) / V
+        if isPC and tpc == 2:  # transonicPCOption 2: phiRes = phi
+            phiRes = np.concatenate([phi_i, phi_b]).astype(dt)
+        else:
+            phiRes = np.concatenate([conv_i - flux_i - phi_i, conv_b - flux_b - phi_b])
 
     # =================================================================== SA (compressible form)
     gradN = ops.grad_scalar(nuT, nb)

@@ -7,12 +7,12 @@ NORM_STATES_RHO = {"U": 50.0, "p": 1.0e5, "T": 300.0, "nuTilda": 1e-3, "phi": 1.
 
 
 def norm_states(case):
-    return NORM_STATES_RHO if case.solver_name == "DARhoSimpleFoam" else dict(NORM_STATES, T=1.0)
+    return NORM_STATES_RHO if case.solver_name in ("DARhoSimpleFoam", "DATurboFoam") else dict(NORM_STATES, T=1.0)
 
 
 def blocks(case, g):
     N = g.nC
-    if case.solver_name == "DARhoSimpleFoam":
+    if case.solver_name in ("DARhoSimpleFoam", "DATurboFoam"):
         return (("U", slice(0, 3 * N)), ("p", slice(3 * N, 4 * N)), ("T", slice(4 * N, 5 * N)), ("nuTilda", slice(5 * N, 6 * N)),
                 ("phi", slice(6 * N, 6 * N + g.nF)))
     if case.solver_name == "DASimpleFoam":

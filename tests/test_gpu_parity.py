@@ -8,7 +8,7 @@ import pytest
 import scipy.sparse.linalg as spla
 
 from common import NORM_STATES, blocks, norm_states, options, relerr
-from dafoam_amd.meshgen import bench_channel_case, channel_case, renumber_case, rho_channel_case, scalar_transport_case
+from dafoam_amd.meshgen import bench_channel_case, channel_case, renumber_case, rho_channel_case, scalar_transport_case, turbo_channel_case
 from oracle import jacobian as J
 from oracle import linear as OL
 from oracle.foam_mesh import Geometry
@@ -125,6 +125,46 @@ def test_rhosimplefoam_residual_jacobian_adjoint(wall_function):
     M = Mat()
     D.solver.calcdRdWT(0, M, mode=1)
     assert np.abs((M.to_scipy() - A).tocsr().data).max() <= 1e-10 * np.abs(A.data).max()
+    rhs = np.zeros(A.shape[0])
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= sc
+    psi, fail = D.solveAdjoint(rhs)
+    assert fail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-6
+
+
+@pytest.mark.parametrize("variant", ["rho_mrf", "turbo", "turbo_transonic"])
+def test_turbofoam_and_mrf_residual_jacobian_adjoint(variant):
+    """DATurboFoam (BASELINE configs[4] solver: SIMPLEC-consistent or transonic pEqn, "h" energy with viscous and MRF
+    pressure work, MRF Coriolis / relative flux / rotating walls) and DARhoSimpleFoam with MRF: residual (PC and non-PC),
+    connectivity, dual-number dRdWT and the adjoint vector against the oracle (no converged turbo primal exists in the
+    oracle, so the linearisation point is the synthetic state)."""
+    from dafoam_amd.pyDASolvers import Mat
+
+    kw = {"rho_mrf": dict(solver_name="DARhoSimpleFoam"), "turbo": {}, "turbo_transonic": dict(transonic=True)}[variant]
+    case = turbo_channel_case(8, 6, 5, wall_function=True, lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.02, **kw)
+    g = Geometry(case.mesh)
+    W = case.states
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0, "gmresMaxIters": 600, "gmresRestart": 300},
+             jacLowerBounds={"dRdW": 0.0, "dRdWPC": 0.0})
+    R = np.zeros(W.size)
+    for pc in (0, 1):
+        D.solver.calcResiduals(pc, R)
+        Ro = residual(case, g, W, isPC=bool(pc))
+        for nm, sl in blocks(case, g):
+            assert relerr(R[sl], Ro[sl]) < 1e-11, (pc, nm)
+    sc, con, col, A = oracle_mats(case, g)
+    D.solver.runColoring()
+    assert (D.solver.getConnectivity(0) != con).nnz == 0
+    M = Mat()
+    D.solver.calcdRdWT(0, M, mode=1)
+    assert np.abs((M.to_scipy() - A).tocsr().data).max() <= 1e-10 * np.abs(A.data).max()
+    # exact forward/transposed identity on this solver too
+    rng = np.random.default_rng(2)
+    v, a = rng.standard_normal(W.size), rng.standard_normal(W.size)
+    Jv, pa = np.zeros(W.size), np.zeros(W.size)
+    D.solver.calcJacVecProduct(v, Jv)
+    D.solverAD.calcJacTVecProduct("s", "stateVar", W, "r", "residual", a, pa)
+    assert abs(a @ Jv - pa @ v) <= 1e-11 * np.linalg.norm(a) * np.linalg.norm(Jv)
     rhs = np.zeros(A.shape[0])
     rhs[0 : 3 * g.nC : 3] = g.V
     rhs *= sc

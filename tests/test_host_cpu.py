@@ -11,7 +11,7 @@ import pytest
 from common import NORM_STATES, NORM_STATES_RHO, blocks, options, relerr
 from dafoam_amd import _capi
 from dafoam_amd._capi import CaseStruct, das_case_t, dptr
-from dafoam_amd.meshgen import channel_case, renumber_case, rho_channel_case, scalar_transport_case
+from dafoam_amd.meshgen import channel_case, renumber_case, rho_channel_case, scalar_transport_case, turbo_channel_case
 from dafoam_amd.pyDASolvers import pyDASolvers
 from oracle import jacobian as J
 from oracle.foam_mesh import Geometry
@@ -281,6 +281,67 @@ def test_kernel_bodies_match_oracle_rhosimplefoam(wall_function, isPC):
     _, Rd = _emu_res(case, W, isPC, v)
     for nm, sl in blocks(case, g):
         assert relerr(Rd[sl], cs[sl]) < 1e-10, nm
+
+
+@pytest.mark.parametrize("variant", ["rho_mrf", "turbo", "turbo_nomrf", "turbo_transonic", "turbo_transonic_pc2"])
+@pytest.mark.parametrize("isPC", [0, 1])
+def test_kernel_bodies_match_oracle_turbofoam_and_mrf(variant, isPC):
+    """DATurboFoam (SIMPLEC-consistent / transonic pEqn, "h" energy with viscous and MRF pressure work) and the MRF
+    terms of DARhoSimpleFoam: kernel bodies vs oracle/residual_rho.py, values and dual tangents."""
+    kw = {"rho_mrf": dict(solver_name="DARhoSimpleFoam"), "turbo": {}, "turbo_nomrf": dict(mrf=False),
+          "turbo_transonic": dict(transonic=True), "turbo_transonic_pc2": dict(transonic=True)}[variant]
+    case = turbo_channel_case(6, 5, 4, wall_function=True, perturb=0.02, **kw)
+    if variant == "turbo_transonic_pc2":
+        case.transonic_pc_option = 2
+    g = Geometry(case.mesh)
+    W = case.states
+    Ro = residual(case, g, W, isPC=bool(isPC))
+    Rv, _ = _emu_res(case, W, isPC)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rv[sl], Ro[sl]) < 1e-11, nm
+    v = np.random.default_rng(3).standard_normal(W.size) * J.state_scales(case, g, NORM_STATES_RHO)
+    cs = residual(case, g, W + 1j * 1e-30 * v, isPC=bool(isPC)).imag / 1e-30
+    _, Rd = _emu_res(case, W, isPC, v)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rd[sl], cs[sl]) < 1e-10, nm
+
+
+def test_turbofoam_connectivity_and_coloring_host():
+    """dRdWCon of DATurboFoam (DAStateInfoTurboFoam.C:82-119) from the C++ pattern builder equals the oracle's; the
+    brute-force oracle Jacobian has no entry outside it (SIMPLEC, viscous-work and MRF terms stay inside the stencil)."""
+    case = turbo_channel_case(5, 4, 4, wall_function=True, perturb=0.02)
+    g = Geometry(case.mesh)
+    s = pyDASolvers(b"DATurboFoam -python", options(case), case=case)
+    s.runColoring()
+    for pc in (0, 1):
+        assert (s.getConnectivity(pc) != J.connectivity(case, g, isPC=bool(pc))).nnz == 0
+    col, nc = s.getColoring()
+    con = J.connectivity(case, g)
+    assert J.validate_coloring(con, col.astype(np.int64))
+    sc = J.state_scales(case, g, NORM_STATES_RHO)
+    Jb = J.jacobian_bruteforce(case, g, case.states, sc)
+    outside = np.where(np.asarray(con.T.todense()) != 0, 0.0, Jb)
+    assert np.abs(outside).max() == 0.0
+
+
+def test_turbofoam_mrf_terms_are_active():
+    """The MRF / turbo switches change the residual blocks they should (guards against silently inactive branches)."""
+    base = turbo_channel_case(5, 4, 4, mrf=False, solver_name="DARhoSimpleFoam", perturb=0.02)
+    g = Geometry(base.mesh)
+    W = base.states
+    R0 = residual(base, g, W)
+    mrf = turbo_channel_case(5, 4, 4, solver_name="DARhoSimpleFoam", perturb=0.02)
+    tur = turbo_channel_case(5, 4, 4, mrf=False, perturb=0.02)
+    trn = turbo_channel_case(5, 4, 4, mrf=False, transonic=True, perturb=0.02)
+    Rm, Rt, Rn = residual(mrf, g, W), residual(tur, g, W), residual(trn, g, W)
+    b = dict(blocks(base, g))
+    assert relerr(Rm[b["U"]], R0[b["U"]]) > 1e-3 and relerr(Rm[b["phi"]], R0[b["phi"]]) > 1e-3  # Coriolis, relative flux
+    assert np.array_equal(Rt[b["U"]], R0[b["U"]]) and np.array_equal(Rt[b["nuTilda"]], R0[b["nuTilda"]])
+    assert relerr(Rt[b["T"]], R0[b["T"]]) > 1e-6  # viscous work
+    assert relerr(Rt[b["p"]], R0[b["p"]]) > 1e-6 and relerr(Rn[b["p"]], Rt[b["p"]]) > 1e-6  # SIMPLEC form / transonic form
+    # rotating hub: U_b = Omega x r on the included fixedValue wall shows up in the wall-adjacent momentum residual
+    own_bottom = g.own[g.patch_slices()["bottom"].start + g.nIF : g.patch_slices()["bottom"].stop + g.nIF]
+    assert np.abs((Rm - R0)[: 3 * g.nC].reshape(-1, 3)[own_bottom]).max() > 0
 
 
 def test_openfoam_case_io_roundtrip(tmp_path):
