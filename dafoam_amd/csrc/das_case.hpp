@@ -19,16 +19,16 @@ struct CaseParams {
         relax_T = c->relax_T;
         DT = c->DT;
         deltaT = c->deltaT;
-        if (DAS_IS_COMPRESSIBLE(solver)) {
+        if (solver != DAS_SOLVER_SCALARTRANSPORTFOAM) {
             mrf = c->mrf_active != 0;
             for (int k = 0; k < 3; k++) { om[k] = c->mrf_omega[k]; org[k] = c->mrf_origin[k]; }
             DAS_CHECK(!mrf || c->patch_mrf_rotating, DAS_ERR_ARG, "MRF needs the per-patch rotating flags");
+        }
+        if (DAS_IS_COMPRESSIBLE(solver)) {
             transonic = (solver == DAS_SOLVER_TURBOFOAM) && c->transonic != 0;
             transonicPC = c->transonic_pc_option;
             Cp = c->Cp; molWeight = c->molWeight; mu = c->mu; Pr = c->Pr; Prt = c->Prt;
             DAS_CHECK(Cp > 0 && molWeight > 0 && mu > 0 && Pr > 0 && Prt > 0, DAS_ERR_ARG, "DARhoSimpleFoam/DATurboFoam need positive Cp, molWeight, mu, Pr, Prt");
-        } else {
-            DAS_CHECK(!c->mrf_active, DAS_ERR_ARG, "MRF is implemented for the compressible solvers only");
         }
         if (c->phi_frozen) phi_frozen.assign(c->phi_frozen, c->phi_frozen + c->n_faces);
         if (c->T_old) T_old.assign(c->T_old, c->T_old + c->n_cells);
@@ -66,7 +66,6 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.transonicPC = cp.transonicPC;
     p.mrf = cp.mrf;
     p.wTU = nullptr;
-    p.wRAtU = nullptr;
     for (int k = 0; k < 3; k++) { p.om[k] = cp.om[k]; p.org[k] = cp.org[k]; }
     return p;
 }

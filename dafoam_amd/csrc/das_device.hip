@@ -31,13 +31,13 @@ template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_cell(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gU, const T* gP,
                                               const T* gN, const T* gH, T* R, T* rAU, T* HbyA) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < m.nC) body_cell<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, R, rAU, HbyA, (const T*)prm.wTU, (T*)prm.wRAtU);
+    if (c < m.nC) body_cell<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, R, rAU, HbyA, (const T*)prm.wTU);
 }
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_face(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gP, const T* rAU,
                                               const T* HbyA, T* q, T* R) {
     int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < m.nF) body_face<T, RHO>(f, m, prm, W, nut, gP, rAU, HbyA, q, R, (const T*)prm.wRAtU);
+    if (f < m.nF) body_face<T, RHO>(f, m, prm, W, nut, gP, rAU, HbyA, q, R);
 }
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_pres(DevMesh m, ResParams prm, const T* q, T* R) {
@@ -118,21 +118,20 @@ __global__ __launch_bounds__(256) void k_T(DevMesh m, ResParams prm, const T* __
 
 template <class T>
 struct ResWork {
-    DevBuf<T> nut, gU, gP, gN, gH, rAU, HbyA, q, gT, TU, rAtU;
+    DevBuf<T> nut, gU, gP, gN, gH, rAU, HbyA, q, gT, TU;
     void ensure(int solver, long long N, long long F) {
         if (solver == DAS_SOLVER_SIMPLEFOAM || DAS_IS_COMPRESSIBLE(solver)) {
             if (nut.n != (size_t)N) {
                 nut.alloc(N); gU.alloc(9 * N); gP.alloc(3 * N); gN.alloc(3 * N); rAU.alloc(N); HbyA.alloc(3 * N); q.alloc(F);
             }
             if (DAS_IS_COMPRESSIBLE(solver) && gH.n != (size_t)(3 * N)) gH.alloc(3 * N);
-            if (solver == DAS_SOLVER_TURBOFOAM && TU.n != (size_t)(3 * N)) { TU.alloc(3 * N); rAtU.alloc(N); }
+            if (solver == DAS_SOLVER_TURBOFOAM && TU.n != (size_t)(3 * N)) TU.alloc(3 * N);
         } else if (gT.n != (size_t)(3 * N)) gT.alloc(3 * N);
     }
-    // work arrays referenced through ResParams (DATurboFoam)
+    // work array referenced through ResParams (DATurboFoam)
     ResParams bind(int solver, long long N, long long F, ResParams prm) {
         ensure(solver, N, F);
         prm.wTU = TU.p;
-        prm.wRAtU = rAtU.p;
         return prm;
     }
 };

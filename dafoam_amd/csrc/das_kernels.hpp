@@ -52,9 +52,8 @@ struct ResParams {
     // DATurboFoam switches and the MRF zone (angular velocity, origin)
     int turbo, transonic, transonicPC, mrf;
     double om[3], org[3];
-    // DATurboFoam work arrays of the launch (typed by the kernel's scalar type): Teff.U per cell (3N), 1/AtU per cell (N)
+    // DATurboFoam work array of the launch (typed by the kernel's scalar type): Teff.U per cell (3N)
     void* wTU;
-    void* wRAtU;
 };
 #define DAS_TREF 298.15
 
@@ -183,7 +182,7 @@ DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc
                        const T& Tc, const T& nc, const T& nut_c, double phib, BFace<T>& o) {
 #pragma unroll
     for (int k = 0; k < 3; k++) o.nrm[k] = g.Sf[k] / g.magSf;
-    if (RHO && prm.mrf && bc.mrf_included && bc.U_code == DAS_BC_FIXED_VALUE) {
+    if (prm.mrf && bc.mrf_included && bc.U_code == DAS_BC_FIXED_VALUE) {
         // MRFZone::correctBoundaryVelocity: fixedValue patches that rotate with the zone carry Omega x r
         double uw[3];
         const double zero[3] = {0.0, 0.0, 0.0};
@@ -325,7 +324,7 @@ DAS_HD void dev2T_scaled(const T* g, const T& nuEff, T* tau) {
 // (RHO) the energy residual TRes = EEqn & he.  RHO: phi is the mass flux, muEff = mu + rho nut replaces nuEff.
 template <class T, bool RHO>
 DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const T* gradP,
-                      const T* gradN, const T* gradH, T* R, T* rAU, T* HbyA, const T* TU = nullptr, T* rAtU = nullptr) {
+                      const T* gradN, const T* gradH, T* R, T* rAU, T* HbyA, const T* TU = nullptr) {
     const long long N = m.nC;
     const CellGeom& cgc = m.cg[c];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
@@ -348,10 +347,10 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     T K_c = RHO ? 0.5 * (Uc[0] * Uc[0] + Uc[1] * Uc[1] + Uc[2] * Uc[2]) : T(0.0);
 
     const bool turbo = RHO && prm.turbo;
-    const bool mrf = RHO && prm.mrf;
+    const bool mrf = prm.mrf != 0;
     double vC_c[3] = {0.0, 0.0, 0.0};
     if (mrf) mrf_velocity(prm, cgc.C, vC_c);
-    T D0(0.0), sumOff(0.0), sumPhi(0.0), vmaxs(0.0), vmins(0.0), sumOffSigned(0.0);
+    T D0(0.0), sumOff(0.0), sumPhi(0.0), vmaxs(0.0), vmins(0.0);
     T offU[3], src[3], bdiag[3], bsrc[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) { offU[k] = T(0.0); src[k] = T(0.0); bdiag[k] = T(0.0); bsrc[k] = T(0.0); }
@@ -395,7 +394,6 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             T offTot = off - cd;
             D0 += dcoef + cd;
             sumOff += dabs(offTot);
-            sumOffSigned += offTot;
 #pragma unroll
             for (int k = 0; k < 3; k++) offU[k] += offTot * Uo[k];
             // ---- linearUpwindV explicit correction (skipped for the PC residual: div(pc) = upwind)
@@ -562,7 +560,6 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     T A = (D + avgb) * rV;
     T rA = 1.0 / A;
     rAU[c] = rA;
-    if (turbo) rAtU[c] = 1.0 / (A + sumOffSigned * rV);  // AtU = AU - H1, H1 = -sum(off-diagonal)/V  (fvMatrix::H1)
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         T sk = src[k] + dD * Uc[k];
@@ -604,12 +601,12 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
 // per face: phiHbyA, pressure flux, q = flux - phiHbyA (consumed by k_pres) and phiRes
 template <class T, bool RHO>
 DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradP, const T* rAU,
-                      const T* HbyA, T* q, T* R, const T* rAtU = nullptr) {
+                      const T* HbyA, T* q, T* R) {
     const long long N = m.nC;
     const FaceGeom& g = m.fg[f];
     T phiHbyA, flux;
     const bool turbo = RHO && prm.turbo;
-    const double rel = (RHO && prm.mrf) ? mrf_face_flux(prm, g) : 0.0;
+    const double rel = prm.mrf ? mrf_face_flux(prm, g) : 0.0;
     if (turbo) {
         // DAResidualTurboFoam.C:146-212.  "phiHbyA" below is what enters div(): phiHbyA (+ SIMPLEC correction), or the
         // convective flux phid_f p_upwind of fvm::div(phid,p) in the transonic form.
@@ -628,9 +625,10 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
                 phiHbyA = g.Sf[0] * (wl * (ro * HbyA[3LL * o]) + wn * (rn * HbyA[3LL * n]))
                           + g.Sf[1] * (wl * (ro * HbyA[3LL * o + 1]) + wn * (rn * HbyA[3LL * n + 1]))
                           + g.Sf[2] * (wl * (ro * HbyA[3LL * o + 2]) + wn * (rn * HbyA[3LL * n + 2])) - rho_f * rel;
-                T dr = wl * (ro * (rAtU[o] - rAU[o])) + wn * (rn * (rAtU[n] - rAU[n]));
-                phiHbyA += dr * snGradP * g.magSf;
-                flux = (wl * (ro * rAtU[o]) + wn * (rn * rAtU[n])) * g.magSf * snGradP;
+                // SIMPLEC-consistent form (AtU = AU - H1): interpolate(rho/AtU - rho/AU) snGrad(p) |Sf| is added to phiHbyA
+                // and to the laplacian(rho/AtU, p) flux alike, so it cancels identically in pRes and phiRes (linear
+                // interpolation is linear); what remains is the rho/AU flux.  The oracle keeps both terms.
+                flux = (wl * (ro * rAU[o]) + wn * (rn * rAU[n])) * g.magSf * snGradP;
             } else {
                 T hs = g.Sf[0] * (wl * HbyA[3LL * o] + wn * HbyA[3LL * n]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * HbyA[3LL * n + 1])
                        + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * HbyA[3LL * n + 2]);
@@ -660,8 +658,7 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
             const bool incl = prm.mrf && bc.mrf_included;
             if (!prm.transonic) {
                 phiHbyA = incl ? T(0.0) : b.rho_b * (hs - rel);
-                phiHbyA += (b.rho_b * (rAtU[c] - rAU[c])) * snGradP * g.magSf;
-                flux = (b.rho_b * rAtU[c]) * g.magSf * snGradP;
+                flux = (b.rho_b * rAU[c]) * g.magSf * snGradP;
             } else {
                 T psib = 1.0 / (prm.Rgas * b.Tt.xb);
                 T phid = incl ? T(0.0) : psib * (hs - rel);
@@ -683,10 +680,11 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
         phiHbyA = g.Sf[0] * (wl * HbyA[3LL * o] + wn * HbyA[3LL * n]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * HbyA[3LL * n + 1])
                   + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * HbyA[3LL * n + 2]);
         T ro(1.0), rn(1.0);
+        phiHbyA = phiHbyA - rel;  // MRF.makeRelative(phiHbyA) / makeRelative(interpolate(rho), phiHbyA)
         if (RHO) {
             ro = W[prm.offP * N + o] / (prm.Rgas * W[prm.offT * N + o]);
             rn = W[prm.offP * N + n] / (prm.Rgas * W[prm.offT * N + n]);
-            phiHbyA = (wl * ro + wn * rn) * (phiHbyA - rel);  // MRF.makeRelative(interpolate(rho), phiHbyA)
+            phiHbyA = (wl * ro + wn * rn) * phiHbyA;
         }
         T gp = (wl * (ro * rAU[o]) + wn * (rn * rAU[n])) * g.magSf;
         T cg = g.corr[0] * (wl * gradP[3LL * o] + wn * gradP[3LL * n]) + g.corr[1] * (wl * gradP[3LL * o + 1] + wn * gradP[3LL * n + 1])
@@ -711,7 +709,7 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
             for (int k = 0; k < 3; k++) Hb[k] = b.U.xb[k];
         }
         phiHbyA = b.rho_b * (g.Sf[0] * Hb[0] + g.Sf[1] * Hb[1] + g.Sf[2] * Hb[2] - rel);
-        if (RHO && prm.mrf && bc.mrf_included) phiHbyA = T(0.0);  // relative flux through a patch that rotates with the zone
+        if (prm.mrf && bc.mrf_included) phiHbyA = T(0.0);  // relative flux through a patch that rotates with the zone
         flux = (b.rho_b * rAU[c]) * g.magSf * (b.p.gic * pc + b.p.gbc);
     }
     q[f] = flux - phiHbyA;

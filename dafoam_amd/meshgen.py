@@ -91,6 +91,8 @@ class FoamCase:
     # system/fvSolution SIMPLE.transonic and the reference option transonicPCOption (DATurboFoam)
     transonic: bool = False
     transonic_pc_option: int = 1
+    # system/fvSolution SIMPLE.consistent (SIMPLEC form of the DASimpleFoam pressure equation, DAResidualSimpleFoam.C:187-194)
+    simple_consistent: bool = False
 
 
 def hex_block(

@@ -265,6 +265,14 @@ def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "nuTildaR
     delta = g.bDeltaCoeffs
     V = g.V
 
+    # ---- MRF (OpenFOAM MRFZone, one zone = the mesh; DAResidualSimpleFoam.C:139,182,245) and SIMPLEC (:187-194)
+    from .residual_rho import mrf_fields  # geometry-only helper shared with the compressible restatement
+
+    mrf = mrf_fields(case, g)
+    consistent = bool(getattr(case, "simple_consistent", False))
+    if mrf is not None:  # correctBoundaryVelocity
+        rot = mrf["incl"] & (bt.code["U"] == BC_FIXED_VALUE)
+        bt.val["U"] = np.where(rot[:, None], mrf["vFb"], bt.val["U"])
     # ---- correctBoundaryConditions (DAResidualSimpleFoam.C:250-265, DASpalartAllmaras.C:235-243)
     Ub, UvIC, UvBC, UgIC, UgBC = bc_vector(bt.code["U"], bt.val["U"], U[bcell], delta, phi_b, g.bnf)
     pb, pvIC, pvBC, pgIC, pgBC = bc_scalar(bt.code["p"], bt.val["p"], p[bcell], delta, phi_b)
@@ -351,6 +359,8 @@ def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "nuTildaR
     tf = np.einsum("fi,fij->fj", g.Sf[:nIF], ops.interp(tau))
     tb = np.einsum("fi,fij->fj", g.bSf, tau_b)
     src = src + ops.surface_sum(tf, tb)
+    if mrf is not None:  # + MRF.DDt(U): source -= V (Omega x U)
+        src = src - V[:, None] * np.cross(mrf["om"], U)
     # UEqn.relax()
     D0 = diag
     sumOff = sadd(oi, _abs(upper), N) + sadd(ni, _abs(lower), N)
@@ -383,15 +393,24 @@ def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "nuTildaR
         HbyA_b[fx] = Ub[fx]
     phiHbyA_i = (ops.interp(HbyA) * g.Sf[:nIF]).sum(1)
     phiHbyA_b = (HbyA_b * g.bSf).sum(1)
+    if mrf is not None:  # MRF.makeRelative(phiHbyA)
+        phiHbyA_i = phiHbyA_i - mrf["rel_i"]
+        phiHbyA_b = np.where(mrf["incl"], 0.0 * phiHbyA_b, phiHbyA_b - mrf["rel_b"])
     # (adjustPhi / setReference are no-ops: p has a fixedValue patch -> !p.needReference())
-    rAUf = ops.interp(rAU)
-    rAU_b = rAU[bcell]
-    gp = rAUf * g.magSf[:nIF]
-    gp_b = rAU_b * g.bMagSf
-    # fvm::laplacian(rAU, p): flux() = upper*(pN - pO) + faceFluxCorrection ; boundary iC*p_c - bC
     gradPf = ops.interp(gradP)
-    flux_i = gp * g.nonOrthDeltaCoeffs * (p[ni] - p[oi]) + gp * (g.nonOrthCorr * gradPf).sum(1)
-    flux_b = gp_b * (pgIC * p[bcell] + pgBC)
+    snGradP_i = g.nonOrthDeltaCoeffs * (p[ni] - p[oi]) + (g.nonOrthCorr * gradPf).sum(1)
+    snGradP_b = pgIC * p[bcell] + pgBC
+    rAtU = rAU
+    if consistent:  # SIMPLEC: rAtU = 1/(1/rAU - H1), H1 = -sum(off-diagonal)/V
+        H1 = -(sadd(oi, upper, N) + sadd(ni, lower, N)) / V
+        rAtU = 1.0 / (A - H1)
+        phiHbyA_i = phiHbyA_i + ops.interp(rAtU - rAU) * snGradP_i * g.magSf[:nIF]
+        phiHbyA_b = phiHbyA_b + (rAtU - rAU)[bcell] * snGradP_b * g.bMagSf
+    gp = ops.interp(rAtU) * g.magSf[:nIF]
+    gp_b = rAtU[bcell] * g.bMagSf
+    # fvm::laplacian(rAtU, p): flux() = upper*(pN - pO) + faceFluxCorrection ; boundary iC*p_c - bC
+    flux_i = gp * snGradP_i
+    flux_b = gp_b * snGradP_b
     # pRes = pEqn & p = (laplacian(rAU,p) - div(phiHbyA)) / V
     pRes = (ops.surface_sum(flux_i, flux_b) - ops.surface_sum(phiHbyA_i, phiHbyA_b)) / V
     # phiRes = phiHbyA - pEqn.flux() - phi

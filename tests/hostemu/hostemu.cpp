@@ -17,13 +17,12 @@ static void eval(const Mesh& mesh, const CaseParams& cp, const ResParams& prm, c
         for (int f = 0; f < m.nF; f++) body_face<T, false>(f, m, prm, W.data(), nut.data(), gP.data(), rAU.data(), HbyA.data(), q.data(), R.data());
         for (int c = 0; c < m.nC; c++) body_pres<T, false>(c, m, prm, q.data(), R.data());
     } else if (DAS_IS_COMPRESSIBLE(cp.solver)) {
-        std::vector<T> nut(N), gU(9 * N), gP(3 * N), gN(3 * N), gH(3 * N), rAU(N), HbyA(3 * N), q(m.nF), TU(3 * N), rAtU(N);
+        std::vector<T> nut(N), gU(9 * N), gP(3 * N), gN(3 * N), gH(3 * N), rAU(N), HbyA(3 * N), q(m.nF), TU(3 * N);
         for (int c = 0; c < m.nC; c++) body_grad<T, true>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), gH.data(), TU.data());
         for (int c = 0; c < m.nC; c++)
             body_cell<T, true>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), gH.data(), R.data(), rAU.data(), HbyA.data(),
-                               TU.data(), rAtU.data());
-        for (int f = 0; f < m.nF; f++)
-            body_face<T, true>(f, m, prm, W.data(), nut.data(), gP.data(), rAU.data(), HbyA.data(), q.data(), R.data(), rAtU.data());
+                               TU.data());
+        for (int f = 0; f < m.nF; f++) body_face<T, true>(f, m, prm, W.data(), nut.data(), gP.data(), rAU.data(), HbyA.data(), q.data(), R.data());
         for (int c = 0; c < m.nC; c++) body_pres<T, true>(c, m, prm, q.data(), R.data());
     } else {
         std::vector<T> gT(3 * N);

@@ -132,7 +132,7 @@ def test_rhosimplefoam_residual_jacobian_adjoint(wall_function):
     assert fail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-6
 
 
-@pytest.mark.parametrize("variant", ["rho_mrf", "turbo", "turbo_transonic"])
+@pytest.mark.parametrize("variant", ["simple_mrf", "rho_mrf", "turbo", "turbo_transonic"])
 def test_turbofoam_and_mrf_residual_jacobian_adjoint(variant):
     """DATurboFoam (BASELINE configs[4] solver: SIMPLEC-consistent or transonic pEqn, "h" energy with viscous and MRF
     pressure work, MRF Coriolis / relative flux / rotating walls) and DARhoSimpleFoam with MRF: residual (PC and non-PC),
@@ -140,8 +140,13 @@ def test_turbofoam_and_mrf_residual_jacobian_adjoint(variant):
     oracle, so the linearisation point is the synthetic state)."""
     from dafoam_amd.pyDASolvers import Mat
 
-    kw = {"rho_mrf": dict(solver_name="DARhoSimpleFoam"), "turbo": {}, "turbo_transonic": dict(transonic=True)}[variant]
-    case = turbo_channel_case(8, 6, 5, wall_function=True, lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.02, **kw)
+    if variant == "simple_mrf":  # DASimpleFoam with MRF (DAResidualSimpleFoam.C:139,182,245)
+        case = channel_case(8, 6, 5, wall_function=True, lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.02)
+        case.mrf = {"omega": (20.0, 0.0, 0.0), "origin": (0.0, -0.3, 0.0), "nonRotatingPatches": ["inlet", "outlet", "top"]}
+        case.simple_consistent = True
+    else:
+        kw = {"rho_mrf": dict(solver_name="DARhoSimpleFoam"), "turbo": {}, "turbo_transonic": dict(transonic=True)}[variant]
+        case = turbo_channel_case(8, 6, 5, wall_function=True, lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.02, **kw)
     g = Geometry(case.mesh)
     W = case.states
     D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0, "gmresMaxIters": 600, "gmresRestart": 300},

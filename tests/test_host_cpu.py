@@ -306,6 +306,32 @@ def test_kernel_bodies_match_oracle_turbofoam_and_mrf(variant, isPC):
         assert relerr(Rd[sl], cs[sl]) < 1e-10, nm
 
 
+def test_simplefoam_mrf_and_simplec():
+    """DASimpleFoam with MRF (DAResidualSimpleFoam.C:139,182,245): kernel bodies vs oracle, values and dual tangents.
+    SIMPLEC (`consistent`, :187-194) cancels identically in pRes and phiRes: interpolate(rAtU - rAU) snGrad(p) is added to
+    phiHbyA and to the laplacian flux alike (linear interpolation is linear), which the oracle confirms to round-off -
+    the kernels therefore need no rAtU for this solver."""
+    case = channel_case(6, 5, 4, wall_function=True, perturb=0.02)
+    g = Geometry(case.mesh)
+    W = case.states
+    R0 = residual(case, g, W)
+    case.simple_consistent = True
+    Rc = residual(case, g, W)
+    assert np.abs(Rc - R0).max() <= 1e-12 * np.abs(R0).max()
+    case.mrf = {"omega": (20.0, 0.0, 0.0), "origin": (0.0, -0.3, 0.0), "nonRotatingPatches": ["inlet", "outlet", "top"]}
+    for isPC in (0, 1):
+        Ro = residual(case, g, W, isPC=bool(isPC))
+        assert relerr(Ro, R0) > 1e-3
+        Rv, _ = _emu_res(case, W, isPC)
+        for nm, sl in blocks(case, g):
+            assert relerr(Rv[sl], Ro[sl]) < 1e-12, nm
+        v = np.random.default_rng(3).standard_normal(W.size) * J.state_scales(case, g, NORM_STATES)
+        cs = residual(case, g, W + 1j * 1e-30 * v, isPC=bool(isPC)).imag / 1e-30
+        _, Rd = _emu_res(case, W, isPC, v)
+        for nm, sl in blocks(case, g):
+            assert relerr(Rd[sl], cs[sl]) < 1e-10, nm
+
+
 def test_turbofoam_connectivity_and_coloring_host():
     """dRdWCon of DATurboFoam (DAStateInfoTurboFoam.C:82-119) from the C++ pattern builder equals the oracle's; the
     brute-force oracle Jacobian has no entry outside it (SIMPLEC, viscous-work and MRF terms stay inside the stencil)."""
