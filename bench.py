@@ -50,9 +50,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    # debugging aids for boxes with a single GPU (never set by the driver): all ranks on device 0, host-staged gloo
+    backend = os.environ.get("DAS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("DAS_BENCH_ONE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     # host-side setup (pattern build, ILU factorisation) is OpenMP-parallel: give every rank its share of the cores
     # (torch.distributed.run exports OMP_NUM_THREADS=1 when it is unset; the library reads it when it is loaded below)
@@ -80,7 +86,7 @@ def main():
         "adjEqnOption": {"gmresRestart": max(a.steps, a.warmup, 1), "gmresMaxIters": 100000, "gmresRelTol": 1e-30,
                          "gmresAbsTol": 1e-300, "printInfo": 0, "asmOverlap": a.overlap, "pcFillLevel": a.fill},
         "amd": {"pcBlockCells": a.block},
-        "amdDevice": local_rank,
+        "amdDevice": dev_index,
     }
     L = _capi.lib()
     sharded = None
@@ -89,7 +95,7 @@ def main():
         # halo reduction over RCCL p2p, dots over RCCL all-reduce (dafoam_amd/distributed.py)
         from dafoam_amd.distributed import ShardedAdjoint
 
-        sharded = ShardedAdjoint(a.nx * world, a.ny, a.nz, opts, device_index=local_rank)
+        sharded = ShardedAdjoint(a.nx * world, a.ny, a.nz, opts, device_index=dev_index)
         D = sharded.D
         case = sharded.case
         ncell = a.nx * a.ny * a.nz
@@ -148,7 +154,7 @@ def main():
     spmv_ms = L.das_timer_avg_ms(h, b"spmv")
     spmv_cnt = L.das_timer_count(h, b"spmv")
     pc_ms = L.das_timer_avg_ms(h, b"pc")
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
