@@ -441,6 +441,27 @@ __device__ __forceinline__ void ras_apply_entry(double* xw, double v, unsigned r
 // levels, so the refill loads are UNCONDITIONAL (clamped address + validity flag).  This matters on CDNA: a load
 // inside a conditional forces the compiler's s_waitcnt insertion to assume it may not have been issued, which
 // degrades every later wait to vmcnt(0) and serialises the prefetch ring.
+// 32-bit-lane loads of the factor values: an fp64 value travels as two dwords (lo, hi).  With global_load_dwordx2 in
+// the ring the compiler's s_waitcnt insertion emits vmcnt(1..4) inside the steady-state loop (a drain of the ring on
+// every trip); with dword loads only it emits the exact vmcnt(2*PF-2) / vmcnt(3*PF-3) - inspected in the gfx950 ISA.
+template <class VT> struct RingVal;
+template <> struct RingVal<float> {
+    unsigned a;
+    __device__ __forceinline__ void load(const float* __restrict__ p, int e) { a = __float_as_uint(p[e]); }
+    __device__ __forceinline__ double get() const { return (double)__uint_as_float(a); }
+    __device__ __forceinline__ void clear() { a = 0u; }
+};
+template <> struct RingVal<double> {
+    unsigned lo, hi;
+    __device__ __forceinline__ void load(const double* __restrict__ p, int e) {
+        const unsigned* __restrict__ q = reinterpret_cast<const unsigned*>(p);
+        lo = q[2 * (long long)e];
+        hi = q[2 * (long long)e + 1];
+    }
+    __device__ __forceinline__ double get() const { return __hiloint2double((int)hi, (int)lo); }
+    __device__ __forceinline__ void clear() { lo = 0u; hi = 0u; }
+};
+
 template <bool USE_LDS, class VT>
 __device__ __forceinline__ void ras_sweep(const VT* __restrict__ sval, const unsigned* __restrict__ src, const long long* __restrict__ lev,
                                           long long l0, long long l1, double* xw, int* lvl) {
@@ -455,35 +476,27 @@ __device__ __forceinline__ void ras_sweep(const VT* __restrict__ sval, const uns
     __syncthreads();
     const VT* __restrict__ bv = sval + ebeg;
     const unsigned* __restrict__ br = src + ebeg;
-    const unsigned INVALID = 0xffffffffu;
     const int tid = (int)threadIdx.x;
-    VT sv[PC_PF];
+    RingVal<VT> sv[PC_PF];
     unsigned sr[PC_PF];
+    bool sok[PC_PF];  // validity lives in its own (load-independent) flag: no ALU touches a loaded register before use
 #pragma unroll
-    for (int d = 0; d < PC_PF; d++) {
-        const int ee = lvl[d] + tid;
-        const bool ok = ee < lvl[d + 1];
-        const int ec = ee < eend ? ee : eend - 1;
-        sv[d] = bv[ec];
-        const unsigned r = br[ec];
-        sr[d] = ok ? r : INVALID;
-    }
-    for (int lv0 = 0; lv0 < NLpad; lv0 += PC_PF) {
+    for (int d = 0; d < PC_PF; d++) { sv[d].clear(); sr[d] = 0u; sok[d] = false; }
+    // The ring is primed by a first trip that only refills (all slots invalid) instead of a separate prologue: the
+    // compiler's s_waitcnt insertion merges the pending-load state of every loop entry, and a prologue whose loads are
+    // scheduled in a different order than the steady state degrades the header waits to (almost) vmcnt(0).
+    for (int lv0 = -PC_PF; lv0 < NLpad; lv0 += PC_PF) {
 #pragma unroll
         for (int d = 0; d < PC_PF; d++) {
             const int lq = lv0 + d + PC_PF;
-            const double v = (double)sv[d];
-            const unsigned rc = sr[d];
-            // refill first (independent of the LDS work below)
+            // consume, then refill the same slot: the refill loads target the registers the next trip reads, so no
+            // register copies (which would need s_waitcnt vmcnt(0)) appear on the loop back-edge
+            ras_apply_entry<USE_LDS>(xw, sv[d].get(), sr[d], sok[d]);
             const int ee = lvl[lq] + tid;
-            const bool ok = ee < lvl[lq + 1];
+            sok[d] = ee < lvl[lq + 1];
             const int ec = ee < eend ? ee : eend - 1;
-            sv[d] = bv[ec];
-            const unsigned r = br[ec];
-            sr[d] = ok ? r : INVALID;
-#ifndef PC_EXP_NOENTRIES
-            ras_apply_entry<USE_LDS>(xw, v, rc, rc != INVALID);
-#endif
+            sv[d].load(bv, ec);
+            sr[d] = br[ec];
 #ifndef PC_EXP_NOBARRIER
             __syncthreads();
 #endif
