@@ -199,38 +199,20 @@ __global__ void k_perturb(long long n, const double* __restrict__ W, const int* 
     if (j >= n) return;
     Wp[j] = W[j] + (colors[j] == c ? delta * scale[j] : 0.0);
 }
-// binary search of colour c in the colour-sorted entries of row i -> destination in the transposed value array
-__device__ __forceinline__ long long find_color(const unsigned short* __restrict__ rc_color, long long b, long long e, int c) {
-    long long lo = b, hi = e;
-    while (lo < hi) {
-        long long mid = (lo + hi) >> 1;
-        if ((int)rc_color[mid] < c) lo = mid + 1;
-        else hi = mid;
-    }
-    return (lo < e && (int)rc_color[lo] == c) ? lo : -1;
+// setPartDerivMat (reference DAPartDeriv.C:109-208): the derivative of residual row[q] w.r.t. its (unique) column of the
+// current colour goes to entry dest[q] of the transposed Jacobian; q runs over the colour's entry list only
+__global__ void k_scatter_dual(long long cnt, const Dual<1>* __restrict__ R, const int* __restrict__ row, const unsigned* __restrict__ dest,
+                               double* vals) {
+    long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < cnt) vals[dest[q]] = R[row[q]].d[0];
 }
-// setPartDerivMat (reference DAPartDeriv.C:109-208): row i of the coloured residual derivative goes to entry
-// (coloredColumn[i], i) of the transposed Jacobian
-template <int K>
-__global__ void k_scatter_dual(long long n, const Dual<K>* __restrict__ R, const long long* __restrict__ rowptr,
-                               const unsigned short* __restrict__ rc_color, const unsigned* __restrict__ rc_dest, int c0, int ncol, double* vals) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    long long b = rowptr[i], e = rowptr[i + 1];
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        if (c0 + k >= ncol) break;
-        long long p = find_color(rc_color, b, e, c0 + k);
-        if (p >= 0) vals[rc_dest[p]] = R[i].d[k];
+__global__ void k_scatter_fd(long long cnt, const double* __restrict__ R, const double* __restrict__ R0, double rdelta,
+                             const int* __restrict__ row, const unsigned* __restrict__ dest, double* vals) {
+    long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < cnt) {
+        const int i = row[q];
+        vals[dest[q]] = (R[i] - R0[i]) * rdelta;
     }
-}
-__global__ void k_scatter_fd(long long n, const double* __restrict__ R, const double* __restrict__ R0, double rdelta,
-                             const long long* __restrict__ rowptr, const unsigned short* __restrict__ rc_color,
-                             const unsigned* __restrict__ rc_dest, int c, double* vals) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    long long p = find_color(rc_color, rowptr[i], rowptr[i + 1], c);
-    if (p >= 0) vals[rc_dest[p]] = (R[i] - R0[i]) * rdelta;
 }
 // jacLowerBound filter (reference DAPartDeriv.C:192): keep |v| > bound or diagonal
 // (multi-GPU: columns = residuals not owned by this rank are dropped; `owned` may be null)
@@ -578,9 +560,9 @@ struct KernelTimer {
 
 struct ConDev {  // device copy of a JacCon (assembly maps + transposed structure)
     bool ready = false;
-    DevBuf<long long> rowptr, t_rowptr;
-    DevBuf<unsigned short> rc_color;
-    DevBuf<unsigned> rc_dest;
+    DevBuf<long long> t_rowptr;
+    DevBuf<int> cl_row;
+    DevBuf<unsigned> cl_dest;
     DevBuf<int> t_col;
 };
 
@@ -733,11 +715,10 @@ static ConDev& ensure_con_dev(das_solver* s, int isPC) {
     ConDev& c = s->cd[isPC ? 1 : 0];
     if (!c.ready) {
         const JacCon& j = isPC ? s->con_pc : s->con_full;
-        c.rowptr.upload(j.rowptr);
-        c.rc_color.upload(j.rc_color);
-        c.rc_dest.upload(j.rc_dest);
+        c.cl_row.upload(j.cl_row.data(), j.cl_row.size());
+        c.cl_dest.upload(j.cl_dest.data(), j.cl_dest.size());
         c.t_rowptr.upload(j.t_rowptr);
-        c.t_col.upload(j.t_col);
+        c.t_col.upload(j.t_col.data(), j.t_col.size());
         s->d_colors.upload(s->colors);
         c.ready = true;
     }
@@ -773,8 +754,9 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
         for (int col = 0; col < s->nColors; col++) {
             hipLaunchKernelGGL(k_seed<1>, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_W.p, s->d_colors.p, s->d_scale.p, col, s->d_Wd.p);
             eval_residual<Dual<1>>(s->dm, s->cp, prm, s->d_Wd.p, s->d_Rd.p, s->wk1, s->d_phiF.p, s->d_Told.p, st);
-            hipLaunchKernelGGL(k_scatter_dual<1>, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_Rd.p, c.rowptr.p, c.rc_color.p, c.rc_dest.p, col,
-                               s->nColors, vals.p);
+            const long long q0 = jc.cl_ptr[col], cnt = jc.cl_ptr[col + 1] - q0;
+            if (cnt > 0)
+                hipLaunchKernelGGL(k_scatter_dual, dim3(nblk(cnt, B)), dim3(B), 0, st, cnt, s->d_Rd.p, c.cl_row.p + q0, c.cl_dest.p + q0, vals.p);
         }
     } else {
         const double delta = s->opt.getd("adjPartDerivFDStep.State");
@@ -783,8 +765,10 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
         for (int col = 0; col < s->nColors; col++) {
             hipLaunchKernelGGL(k_perturb, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_W.p, s->d_colors.p, s->d_scale.p, col, delta, s->d_Wp.p);
             eval_residual<double>(s->dm, s->cp, prm, s->d_Wp.p, s->d_R.p, s->wk, s->d_phiF.p, s->d_Told.p, st);
-            hipLaunchKernelGGL(k_scatter_fd, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_R.p, s->d_R0.p, 1.0 / delta, c.rowptr.p, c.rc_color.p,
-                               c.rc_dest.p, col, vals.p);
+            const long long q0 = jc.cl_ptr[col], cnt = jc.cl_ptr[col + 1] - q0;
+            if (cnt > 0)
+                hipLaunchKernelGGL(k_scatter_fd, dim3(nblk(cnt, B)), dim3(B), 0, st, cnt, s->d_R.p, s->d_R0.p, 1.0 / delta, c.cl_row.p + q0,
+                                   c.cl_dest.p + q0, vals.p);
         }
     }
     DAS_HIP(hipGetLastError());
@@ -798,7 +782,7 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
     if (!useBound && !masked) {
         M.nnz = jc.nnz;
         M.rowptr.upload(jc.t_rowptr);
-        M.col.upload(jc.t_col);
+        M.col.upload(jc.t_col.data(), jc.t_col.size());
         M.val = std::move(vals);
     } else {
         DevBuf<int> cnt(n);
@@ -917,8 +901,10 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     const Mat& A = k->pcmat->m;
     const long long n = A.n;
     std::vector<long long> rp = A.rowptr.to_host();
-    std::vector<int> ci = A.col.to_host();
-    std::vector<double> av = A.val.to_host();
+    uvector<int> ci(A.col.n);  // uninitialised: filled by the download (no serial zero-fill of GB-sized buffers)
+    uvector<double> av(A.val.n);
+    A.col.download(ci.data(), ci.size());
+    A.val.download(av.data(), av.size());
     const Mesh& m = s->mesh;
     const long long bc = std::max<long long>(64, s->opt.geti("amd.pcBlockCells"));
     const int overlap = (int)std::max<long long>(0, s->opt.geti("adjEqnOption.asmOverlap"));
@@ -1155,10 +1141,9 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     }
     next = boff[nB];
     std::vector<int> gidx(next), gout(next);
-    std::vector<double> invd(next), sval[2];
-    std::vector<unsigned> src[2];
+    std::vector<double> invd(next);
     P.h_core_perm.assign(P.h_core_off.back(), 0);
-    for (int t = 0; t < 2; t++) { sval[t].resize(eoff[t][nB]); src[t].resize(eoff[t][nB]); slev[t].resize(loff[t][nB]); slevOff[t] = loff[t]; }
+    for (int t = 0; t < 2; t++) { slev[t].resize(loff[t][nB]); slevOff[t] = loff[t]; }
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < nB; b++) {
         BlockFactor& F = BF[b];
@@ -1167,12 +1152,8 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
         std::copy(F.invd.begin(), F.invd.end(), invd.begin() + boff[b]);
         long long pc = P.h_core_off[b];
         for (int g : F.gout) if (g >= 0) P.h_core_perm[pc++] = g;
-        for (int t = 0; t < 2; t++) {
-            std::copy(F.sval[t].begin(), F.sval[t].end(), sval[t].begin() + eoff[t][b]);
-            std::copy(F.src[t].begin(), F.src[t].end(), src[t].begin() + eoff[t][b]);
+        for (int t = 0; t < 2; t++)
             for (size_t q = 0; q < F.slev[t].size(); q++) slev[t][loff[t][b] + q] = eoff[t][b] + F.slev[t][q];
-        }
-        F = BlockFactor();
     }
     DAS_CHECK((long long)P.h_core_perm.size() == nOwnedStates, DAS_ERR_INTERNAL, "block cores do not cover all owned states exactly once");
     P.n = n; P.next = next; P.nBlocks = nB; P.fnnz = fnnz; P.maxLevels = maxLv; P.maxLocal = maxLocal;
@@ -1180,16 +1161,32 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     // mixed precision: the factors of the (approximate) preconditioner may be stored in fp32 - the operator, the
     // Krylov vectors and the block work vector stay fp64 (amd.pcFactorFP32; SURVEY.md section 7 "hard parts")
     P.factor32 = s->opt.geti("amd.pcFactorFP32") != 0;
+    // the entry streams (GBs) go from the per-block vectors straight into their slice of the device buffers: no
+    // concatenated host copy (its serial first-touch used to cost seconds)
     for (int t = 0; t < 2; t++) {
-        if (P.factor32) {
-            std::vector<float> f(sval[t].begin(), sval[t].end());
-            P.svalf[t].upload(f);
-            P.sval[t].release();
-        } else {
-            P.sval[t].upload(sval[t]);
-            P.svalf[t].release();
+        const size_t tot = (size_t)eoff[t][nB];
+        if (P.factor32) { P.svalf[t].alloc(tot); P.sval[t].release(); }
+        else { P.sval[t].alloc(tot); P.svalf[t].release(); }
+        P.srowcol[t].alloc(tot);
+        P.slev[t].upload(slev[t]); P.slevOff[t].upload(slevOff[t]);
+    }
+    {
+        std::vector<float> f32;
+        for (int b = 0; b < nB; b++) {
+            BlockFactor& F = BF[b];
+            for (int t = 0; t < 2; t++) {
+                const size_t cnt = F.sval[t].size();
+                if (!cnt) continue;
+                if (P.factor32) {
+                    f32.assign(F.sval[t].begin(), F.sval[t].end());
+                    DAS_HIP(hipMemcpy(P.svalf[t].p + eoff[t][b], f32.data(), cnt * sizeof(float), hipMemcpyHostToDevice));
+                } else {
+                    DAS_HIP(hipMemcpy(P.sval[t].p + eoff[t][b], F.sval[t].data(), cnt * sizeof(double), hipMemcpyHostToDevice));
+                }
+                DAS_HIP(hipMemcpy(P.srowcol[t].p + eoff[t][b], F.src[t].data(), cnt * sizeof(unsigned), hipMemcpyHostToDevice));
+            }
+            F = BlockFactor();
         }
-        P.srowcol[t].upload(src[t]); P.slev[t].upload(slev[t]); P.slevOff[t].upload(slevOff[t]);
     }
     P.useLDS = (size_t)maxLocal * sizeof(double) + (size_t)(maxLv + 2 * PC_PF + 8) * sizeof(int) + 16 <= 160 * 1024;
     if (!P.useLDS) P.xw.alloc(next);

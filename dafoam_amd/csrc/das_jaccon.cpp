@@ -288,9 +288,11 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors) {
         for (long long r : keep)
             for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) crow[pos[con.col[k]]++] = r;
     }
-    // speculative parallel greedy (Gebremedhin-Manne): chunks of columns are first-fit coloured concurrently against a
-    // shared (racy) colour array, then conflicts (two columns of one kept row with the same colour) are detected in
-    // parallel, the higher-index column of each conflict is un-coloured and the (few) leftovers are coloured serially.
+    // speculative parallel greedy (Gebremedhin-Manne), opt-in: chunks of columns are first-fit coloured concurrently
+    // against a shared (racy) colour array, then conflicts (two columns of one kept row with the same colour) are
+    // detected in parallel, the higher-index column of each conflict is un-coloured and the (few) leftovers are coloured
+    // serially.  (A deterministic variant in which chunks ignore each other was measured: with a 3-ring stencil almost
+    // every column of a 200k-cell mesh lies near a chunk boundary and the serial fix-up costs more than it saves.)
     auto color_column = [&](long long j, std::vector<long long>& forb, long long stamp) {
         for (long long q = cptr[j]; q < cptr[j + 1]; q++) {
             long long r = crow[q];
@@ -309,8 +311,9 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors) {
     const int nth = std::max(1, omp_get_max_threads());
     // Columns are grouped by the cell they live in (anchor) and the cell range is cut into spatially contiguous
     // chunks, so concurrent threads only interact near chunk boundaries (few conflicts, near-serial colour count).
-    // Opt-in (DAS_PARALLEL_COLORING=1): ~3-4x faster but ~15 % more colours than the serial first-fit, and every
-    // colour costs one residual evaluation per Jacobian build (the colouring itself is computed once per mesh).
+    // Opt-in (DAS_PARALLEL_COLORING=1): ~3.5x faster for ~11 % more colours (451-457 vs 410 at 200k cells), but the
+    // colour labels depend on thread timing (the Jacobians do not: columns of one colour never share a row).  The
+    // default stays the deterministic serial first-fit; repeated runs use the dRdWColoring cache instead.
     const char* pc_env = getenv("DAS_PARALLEL_COLORING");
     const bool par = nth > 1 && pc_env && pc_env[0] == '1';
     if (par) {
@@ -354,8 +357,26 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors) {
             for (long long j : redo) color_column(j, forb, j);
         }
     } else {
+        // serial first-fit.  Consecutive columns with the same kept-row list (the xyz components of a cell's U) see the
+        // same neighbourhood: its forbidden set is gathered once and extended by the colours just handed out - the
+        // result is identical to colouring them one by one, at a third of the gathers.
         std::vector<long long> forb(4096, -1);
-        for (long long j = 0; j < n; j++) color_column(j, forb, j);
+        long long j = 0;
+        while (j < n) {
+            color_column(j, forb, j);
+            long long g = j + 1;
+            const long long len = cptr[j + 1] - cptr[j];
+            while (g < n && cptr[g + 1] - cptr[g] == len && std::equal(crow.begin() + cptr[j], crow.begin() + cptr[j + 1], crow.begin() + cptr[g])) {
+                const int cprev = colors[g - 1];
+                if ((size_t)cprev >= forb.size()) forb.resize(2 * cprev + 2, -1);
+                forb[cprev] = j;  // stamp of the group
+                int c = 0;
+                while ((size_t)c < forb.size() && forb[c] == j) c++;
+                colors[g] = c;
+                g++;
+            }
+            j = g;
+        }
     }
     int ncol = 0;
     for (long long j = 0; j < n; j++) ncol = std::max(ncol, colors[j] + 1);
@@ -379,53 +400,80 @@ bool validate_coloring(const JacCon& con, const std::vector<int>& colors) {
 
 void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
     DAS_CHECK(nnz < 4294967295LL, DAS_ERR_ARG, "pattern nnz exceeds uint32 assembly map");
+    // Stable parallel counting transpose: the rows are cut into T contiguous chunks; pass 1 counts the entries of every
+    // column per chunk, a prefix over (column, chunk) gives each chunk its start inside every transposed row, pass 2
+    // lets every chunk fill its rows in ascending order.  Transposed rows come out sorted by residual index and the
+    // destination of every pattern entry is known at fill time (no atomics, no per-row sort, no binary search).
+    const bool dbg = getenv("DAS_DEBUG_TIMING") != nullptr;
+    double tt = wall_seconds();
+    auto lap = [&](const char* what) { if (dbg) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]   maps: %s %.2f s\n", what, t2 - tt); tt = t2; } };
+    const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 16LL, n}));
+    std::vector<long long> r0(T + 1);
+    for (int t = 0; t <= T; t++) r0[t] = n * t / T;
+    std::vector<std::vector<int>> cnt(T);
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; t++) {
+        cnt[t].assign(n, 0);
+        for (long long k = rowptr[r0[t]]; k < rowptr[r0[t + 1]]; k++) cnt[t][col[k]]++;
+    }
+    lap("count");
     t_rowptr.assign(n + 1, 0);
-    // column counts (parallel, atomic increments), prefix sum
-    {
-        std::vector<int> cnt(n, 0);
-#pragma omp parallel for schedule(static)
-        for (long long k = 0; k < nnz; k++) {
-#pragma omp atomic
-            cnt[col[k]]++;
-        }
-        for (long long j = 0; j < n; j++) t_rowptr[j + 1] = t_rowptr[j] + cnt[j];
+    for (long long j = 0; j < n; j++) {
+        long long tot = 0;
+        for (int t = 0; t < T; t++) tot += cnt[t][j];
+        t_rowptr[j + 1] = t_rowptr[j] + tot;
     }
-    t_col.assign(nnz, 0);
-    // unordered parallel fill, then sort every transposed row (rows of dRdW^T become sorted by residual index)
-    {
-        std::vector<int> fillpos(n, 0);
+    // cnt[t][j] := offset of chunk t inside transposed row j
 #pragma omp parallel for schedule(static)
-        for (long long r = 0; r < n; r++)
+    for (long long j = 0; j < n; j++) {
+        int acc = 0;
+        for (int t = 0; t < T; t++) { int c = cnt[t][j]; cnt[t][j] = acc; acc += c; }
+    }
+    lap("prefix");
+    t_col.resize(nnz);
+    uvector<unsigned> dest(nnz);
+    lap("alloc");
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; t++) {
+        std::vector<int>& pos = cnt[t];
+        for (long long r = r0[t]; r < r0[t + 1]; r++)
             for (long long k = rowptr[r]; k < rowptr[r + 1]; k++) {
-                int j = col[k];
-                int p;
-#pragma omp atomic capture
-                p = fillpos[j]++;
-                t_col[t_rowptr[j] + p] = (int)r;
+                const int j = col[k];
+                const long long d = t_rowptr[j] + pos[j]++;
+                t_col[d] = (int)r;
+                dest[k] = (unsigned)d;
             }
-#pragma omp parallel for schedule(dynamic, 1024)
-        for (long long j = 0; j < n; j++) std::sort(t_col.begin() + t_rowptr[j], t_col.begin() + t_rowptr[j + 1]);
     }
-    rc_dest.assign(nnz, 0);
-    rc_color.assign(nnz, 0);
-#pragma omp parallel
-    {
-        std::vector<std::pair<unsigned short, unsigned>> tmp;
-#pragma omp for schedule(dynamic, 1024)
-        for (long long r = 0; r < n; r++) {
-            long long b = rowptr[r], e = rowptr[r + 1];
-            tmp.resize(e - b);
-            for (long long k = b; k < e; k++) {
-                int j = col[k];
-                const int* tb = t_col.data() + t_rowptr[j];
-                const int* te = t_col.data() + t_rowptr[j + 1];
-                long long d = t_rowptr[j] + (std::lower_bound(tb, te, (int)r) - tb);
-                tmp[k - b] = {(unsigned short)colors[j], (unsigned)d};
+    cnt.clear();
+    lap("fill");
+    // group the pattern entries by the colour of their column: stable chunked counting sort (same chunks as above)
+    int ncol = 0;
+    for (long long jj = 0; jj < n; jj++) ncol = std::max(ncol, colors[jj] + 1);
+    std::vector<std::vector<long long>> hist(T, std::vector<long long>(ncol, 0));
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; t++)
+        for (long long k = rowptr[r0[t]]; k < rowptr[r0[t + 1]]; k++) hist[t][colors[col[k]]]++;
+    cl_ptr.assign(ncol + 1, 0);
+    for (int c = 0; c < ncol; c++) {
+        long long acc = cl_ptr[c];
+        for (int t = 0; t < T; t++) { long long h = hist[t][c]; hist[t][c] = acc; acc += h; }
+        cl_ptr[c + 1] = acc;
+    }
+    lap("hist");
+    cl_row.resize(nnz);
+    cl_dest.resize(nnz);
+    lap("alloc2");
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+    for (int t = 0; t < T; t++) {
+        std::vector<long long>& pos = hist[t];
+        for (long long r = r0[t]; r < r0[t + 1]; r++)
+            for (long long k = rowptr[r]; k < rowptr[r + 1]; k++) {
+                const long long q = pos[colors[col[k]]]++;
+                cl_row[q] = (int)r;
+                cl_dest[q] = dest[k];
             }
-            std::sort(tmp.begin(), tmp.end());  // by colour
-            for (long long k = b; k < e; k++) { rc_color[k] = tmp[k - b].first; rc_dest[k] = tmp[k - b].second; }
-        }
     }
+    lap("group");
 }
 
 }  // namespace das

@@ -1,5 +1,8 @@
 // Jacobian connectivity (dRdWCon), colouring and assembly maps - host graph work, one-off per mesh.
 #pragma once
+#include <memory>
+#include <type_traits>
+#include <utility>
 #include "das_common.hpp"
 
 namespace das {
@@ -22,18 +25,33 @@ struct Stencil {
 
 Stencil make_stencil(int solver, int nC, int nF, const Options& opt, bool isPC);
 
+// std::vector whose resize() leaves trivially-constructible elements uninitialised: the big index arrays are written
+// in full by parallel loops, and a serial zero-fill (page faults of GBs of fresh memory) used to cost more than the
+// loops themselves
+template <class T>
+struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using uvector = std::vector<T, default_init_allocator<T>>;
+
 struct JacCon {
     long long n = 0, nnz = 0;
     std::vector<long long> rowptr;  // rows = residuals
-    std::vector<int> col;           // sorted state indices
+    uvector<int> col;               // sorted state indices
     std::vector<int> anchor;        // per row: the cell it is anchored at (cell rows: the cell; face rows: owner)
     // transposed structure (rows = states j, cols = residual i), CSR
     std::vector<long long> t_rowptr;
-    std::vector<int> t_col;
-    // assembly map: for pattern entry e (row-major), rc_dest[e] = index into the transposed value
-    // array, entries of a row sorted by rc_color (the colour of their column)
-    std::vector<unsigned short> rc_color;
-    std::vector<unsigned> rc_dest;
+    uvector<int> t_col;
+    // assembly map, grouped by COLOUR: the pattern entries whose column has colour c are cl_ptr[c]..cl_ptr[c+1]; entry q
+    // takes the derivative of residual cl_row[q] (its coloured column is unique) to position cl_dest[q] of the
+    // transposed value array (setPartDerivMat, reference DAPartDeriv.C:109-208).  One scatter launch per colour then
+    // touches exactly the rows that colour reaches - no search.
+    std::vector<long long> cl_ptr;
+    uvector<int> cl_row;
+    uvector<unsigned> cl_dest;
     void build(const Mesh& m, const Stencil& st);
     void build_transpose_and_maps(const std::vector<int>& colors);
 };
