@@ -181,6 +181,7 @@ _SIGS = {
     "das_calc_residuals": (C.c_int, [_VP, C.c_int, c_double_p]),
     "das_run_coloring": (C.c_int, [_VP]),
     "das_set_coloring": (C.c_int, [_VP, c_int_p]),
+    "das_debug_factor_block": (C.c_int, [C.c_int, c_ll_p, c_int_p, c_double_p, C.c_int, c_double_p, c_ll_p, c_int_p, c_int_p]),
     "das_get_n_colors": (C.c_int, [_VP, C.c_int]),
     "das_get_con_nnz": (C.c_longlong, [_VP, C.c_int]),
     "das_get_con": (C.c_int, [_VP, C.c_int, c_ll_p, c_int_p]),

@@ -17,6 +17,8 @@
 #include "das_case.hpp"
 #include "das_jaccon.hpp"
 
+#include <omp.h>
+
 namespace das {
 
 // =====================================================================================================
@@ -846,6 +848,31 @@ static void ilu_symbolic(int nl, const std::vector<long long>& rp, const std::ve
         }
         return;
     }
+    if (lfill == 1) {
+        // ILU(1): a fill entry (i,j) needs a pivot k < min(i,j) with a_ik != 0 and a_kj != 0 ORIGINAL entries (level
+        // 0 + 0 + 1), and level-1 entries create no further fill: row i = A(i) united with the upper parts of the rows
+        // k < i of A(i).  No level bookkeeping, no heap (the default fill level; 3-4x cheaper than the general sweep).
+        std::vector<long long> aup(nl);  // first entry of A's row k with column > k
+        for (int k = 0; k < nl; k++) aup[k] = std::upper_bound(ci.begin() + rp[k], ci.begin() + rp[k + 1], k) - ci.begin();
+        std::vector<int> mark(nl, -1), list;
+        fci.reserve(ci.size() * 3);
+        for (int i = 0; i < nl; i++) {
+            list.clear();
+            for (long long q = rp[i]; q < rp[i + 1]; q++) { const int j = ci[q]; if (mark[j] != i) { mark[j] = i; list.push_back(j); } }
+            if (mark[i] != i) { mark[i] = i; list.push_back(i); }
+            for (long long q = rp[i]; q < rp[i + 1] && ci[q] < i; q++) {
+                const int k = ci[q];
+                for (long long r = aup[k]; r < rp[k + 1]; r++) { const int j = ci[r]; if (mark[j] != i) { mark[j] = i; list.push_back(j); } }
+            }
+            std::sort(list.begin(), list.end());
+            for (int j : list) {
+                if (j == i) fdiag[i] = (long long)fci.size();
+                fci.push_back(j);
+            }
+            frp[i + 1] = (long long)fci.size();
+        }
+        return;
+    }
     std::vector<int> flev;  // level of each stored entry
     std::vector<int> wlev(nl, -1), list;
     std::vector<int> heap;  // min-heap of pending pivot columns (< i)
@@ -895,6 +922,94 @@ static void ilu_symbolic(int nl, const std::vector<long long>& rp, const std::ve
     }
 }
 }  // namespace
+
+// symbolic + numeric ILU(k) of one block-local CSR (sorted columns), level schedules and the level-sorted entry streams
+// the kernel consumes.  `tim` (optional, 4 doubles) accumulates seconds: symbolic, numeric, schedules, streams.
+static void factor_local(int nl, const std::vector<long long>& lrp, const std::vector<int>& lci, const std::vector<double>& lv, int lfill,
+                         BlockFactor& F, std::vector<long long>& where, std::vector<int>& lev, double* tim) {
+    double tq = tim ? wall_seconds() : 0.0;
+    auto lap = [&](int k) { if (tim) { double t2 = wall_seconds(); tim[k] += t2 - tq; tq = t2; } };
+    ilu_symbolic(nl, lrp, lci, lfill, F.frp, F.fci, F.fdiag);
+    lap(0);
+    F.fv.assign(F.fci.size(), 0.0);
+    where.assign(nl, -1);
+    for (int i = 0; i < nl; i++) {
+        for (long long q = F.frp[i]; q < F.frp[i + 1]; q++) where[F.fci[q]] = q;
+        for (long long q = lrp[i]; q < lrp[i + 1]; q++) F.fv[where[lci[q]]] = lv[q];
+        for (long long q = F.frp[i]; q < F.fdiag[i]; q++) {
+            int kk = F.fci[q];
+            double lik = F.fv[q] / F.fv[F.fdiag[kk]];
+            F.fv[q] = lik;
+            if (lik == 0.0) continue;
+            for (long long r = F.fdiag[kk] + 1; r < F.frp[kk + 1]; r++) {
+                long long d = where[F.fci[r]];
+                if (d >= 0) F.fv[d] -= lik * F.fv[r];
+            }
+        }
+        double piv = F.fv[F.fdiag[i]];
+        if (std::fabs(piv) < 1e-300 || piv != piv) { F.fv[F.fdiag[i]] = (piv < 0 ? -1.0 : 1.0) * 1e-12; F.nshift++; }  // MAT_SHIFT_NONZERO analogue
+        for (long long q = F.frp[i]; q < F.frp[i + 1]; q++) where[F.fci[q]] = -1;
+    }
+    lap(1);
+    // level schedules
+    auto schedule = [&](bool lower, std::vector<int>& rows, std::vector<long long>& levp) {
+        lev.assign(nl, 0);
+        int nlv = 0;
+        if (lower) {
+            for (int i = 0; i < nl; i++) {
+                int l = 0;
+                for (long long q = F.frp[i]; q < F.fdiag[i]; q++) l = std::max(l, lev[F.fci[q]] + 1);
+                lev[i] = l;
+                nlv = std::max(nlv, l + 1);
+            }
+        } else {
+            for (int i = nl - 1; i >= 0; i--) {
+                int l = 0;
+                for (long long q = F.fdiag[i] + 1; q < F.frp[i + 1]; q++) l = std::max(l, lev[F.fci[q]] + 1);
+                lev[i] = l;
+                nlv = std::max(nlv, l + 1);
+            }
+        }
+        levp.assign(nlv + 1, 0);
+        for (int i = 0; i < nl; i++) levp[lev[i] + 1]++;
+        for (int l = 0; l < nlv; l++) levp[l + 1] += levp[l];
+        rows.assign(nl, 0);
+        std::vector<long long> fill(levp.begin(), levp.end() - 1);
+        for (int i = 0; i < nl; i++) rows[fill[lev[i]]++] = i;
+    };
+    schedule(true, F.Lrows, F.Llev);
+    schedule(false, F.Urows, F.Ulev);
+    lap(2);
+    // entry streams sorted by (level, row); levels split into pieces of <= PC_THREADS entries (one entry per
+    // thread per level in the kernel); U rows pre-divided by the pivot
+    DAS_CHECK(nl <= 65535, DAS_ERR_ARG, "preconditioner block larger than 65535 unknowns: reduce amd.pcBlockCells");
+    F.invd.resize(nl);
+    for (int i = 0; i < nl; i++) F.invd[i] = 1.0 / F.fv[F.fdiag[i]];
+    for (int t = 0; t < 2; t++) {
+        const std::vector<long long>& lv = t == 0 ? F.Llev : F.Ulev;
+        const std::vector<int>& rows = t == 0 ? F.Lrows : F.Urows;
+        F.sval[t].reserve(F.fci.size() / 2 + 16);
+        F.src[t].reserve(F.fci.size() / 2 + 16);
+        for (size_t l = 0; l + 1 < lv.size(); l++) {
+            F.slev[t].push_back((long long)F.sval[t].size());
+            long long inLevel = 0;
+            for (long long r = lv[l]; r < lv[l + 1]; r++) {
+                const int i = rows[r];
+                const long long q0 = t == 0 ? F.frp[i] : F.fdiag[i] + 1;
+                const long long q1 = t == 0 ? F.fdiag[i] : F.frp[i + 1];
+                const double scale = t == 0 ? 1.0 : F.invd[i];
+                for (long long q = q0; q < q1; q++) {
+                    if (inLevel == PC_THREADS) { F.slev[t].push_back((long long)F.sval[t].size()); inLevel = 0; }
+                    F.sval[t].push_back(F.fv[q] * scale);
+                    F.src[t].push_back((unsigned)i | ((unsigned)F.fci[q] << 16));
+                    inLevel++;
+                }
+            }
+        }
+        F.slev[t].push_back((long long)F.sval[t].size());
+    }
+    lap(3);
+}
 
 static void setup_block_ilu(das_solver* s, das_ksp* k) {
     double t0 = wall_seconds();
@@ -958,7 +1073,10 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     std::vector<BlockFactor> BF(nB);
     std::string err;
     const double t_prep = wall_seconds();
-#pragma omp parallel
+    // every block touches ~100 MB of fresh host memory; beyond a few dozen threads the kernel's page-fault / mmap paths
+    // serialise (measured on the 256-core MI355X host), hence the cap amd.setupThreads
+    const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
+#pragma omp parallel num_threads(nthr)
     {
         std::vector<int> cmark(m.nC, -1);
         std::vector<int> loc(n, -1);
@@ -1028,83 +1146,7 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
                     lrp[p + 1] = (long long)lci.size();
                 }
                 for (int p = 0; p < nl; p++) loc[F.gidx[p]] = -1;
-                // symbolic + numeric ILU(k)
-                ilu_symbolic(nl, lrp, lci, lfill, F.frp, F.fci, F.fdiag);
-                F.fv.assign(F.fci.size(), 0.0);
-                where.assign(nl, -1);
-                for (int i = 0; i < nl; i++) {
-                    for (long long q = F.frp[i]; q < F.frp[i + 1]; q++) where[F.fci[q]] = q;
-                    for (long long q = lrp[i]; q < lrp[i + 1]; q++) F.fv[where[lci[q]]] = lv[q];
-                    for (long long q = F.frp[i]; q < F.fdiag[i]; q++) {
-                        int kk = F.fci[q];
-                        double lik = F.fv[q] / F.fv[F.fdiag[kk]];
-                        F.fv[q] = lik;
-                        if (lik == 0.0) continue;
-                        for (long long r = F.fdiag[kk] + 1; r < F.frp[kk + 1]; r++) {
-                            long long d = where[F.fci[r]];
-                            if (d >= 0) F.fv[d] -= lik * F.fv[r];
-                        }
-                    }
-                    double piv = F.fv[F.fdiag[i]];
-                    if (std::fabs(piv) < 1e-300 || piv != piv) { F.fv[F.fdiag[i]] = (piv < 0 ? -1.0 : 1.0) * 1e-12; F.nshift++; }  // MAT_SHIFT_NONZERO analogue
-                    for (long long q = F.frp[i]; q < F.frp[i + 1]; q++) where[F.fci[q]] = -1;
-                }
-                // level schedules
-                auto schedule = [&](bool lower, std::vector<int>& rows, std::vector<long long>& levp) {
-                    lev.assign(nl, 0);
-                    int nlv = 0;
-                    if (lower) {
-                        for (int i = 0; i < nl; i++) {
-                            int l = 0;
-                            for (long long q = F.frp[i]; q < F.fdiag[i]; q++) l = std::max(l, lev[F.fci[q]] + 1);
-                            lev[i] = l;
-                            nlv = std::max(nlv, l + 1);
-                        }
-                    } else {
-                        for (int i = nl - 1; i >= 0; i--) {
-                            int l = 0;
-                            for (long long q = F.fdiag[i] + 1; q < F.frp[i + 1]; q++) l = std::max(l, lev[F.fci[q]] + 1);
-                            lev[i] = l;
-                            nlv = std::max(nlv, l + 1);
-                        }
-                    }
-                    levp.assign(nlv + 1, 0);
-                    for (int i = 0; i < nl; i++) levp[lev[i] + 1]++;
-                    for (int l = 0; l < nlv; l++) levp[l + 1] += levp[l];
-                    rows.assign(nl, 0);
-                    std::vector<long long> fill(levp.begin(), levp.end() - 1);
-                    for (int i = 0; i < nl; i++) rows[fill[lev[i]]++] = i;
-                };
-                schedule(true, F.Lrows, F.Llev);
-                schedule(false, F.Urows, F.Ulev);
-                // entry streams sorted by (level, row); levels split into pieces of <= PC_THREADS entries (one entry per
-                // thread per level in the kernel); U rows pre-divided by the pivot
-                DAS_CHECK(nl <= 65535, DAS_ERR_ARG, "preconditioner block larger than 65535 unknowns: reduce amd.pcBlockCells");
-                F.invd.resize(nl);
-                for (int i = 0; i < nl; i++) F.invd[i] = 1.0 / F.fv[F.fdiag[i]];
-                for (int t = 0; t < 2; t++) {
-                    const std::vector<long long>& lv = t == 0 ? F.Llev : F.Ulev;
-                    const std::vector<int>& rows = t == 0 ? F.Lrows : F.Urows;
-                    F.sval[t].reserve(F.fci.size() / 2 + 16);
-                    F.src[t].reserve(F.fci.size() / 2 + 16);
-                    for (size_t l = 0; l + 1 < lv.size(); l++) {
-                        F.slev[t].push_back((long long)F.sval[t].size());
-                        long long inLevel = 0;
-                        for (long long r = lv[l]; r < lv[l + 1]; r++) {
-                            const int i = rows[r];
-                            const long long q0 = t == 0 ? F.frp[i] : F.fdiag[i] + 1;
-                            const long long q1 = t == 0 ? F.fdiag[i] : F.frp[i + 1];
-                            const double scale = t == 0 ? 1.0 : F.invd[i];
-                            for (long long q = q0; q < q1; q++) {
-                                if (inLevel == PC_THREADS) { F.slev[t].push_back((long long)F.sval[t].size()); inLevel = 0; }
-                                F.sval[t].push_back(F.fv[q] * scale);
-                                F.src[t].push_back((unsigned)i | ((unsigned)F.fci[q] << 16));
-                                inLevel++;
-                            }
-                        }
-                    }
-                    F.slev[t].push_back((long long)F.sval[t].size());
-                }
+                factor_local(nl, lrp, lci, lv, lfill, F, where, lev, nullptr);
                 F.nnzLU = (long long)F.fci.size();
                 std::vector<long long>().swap(F.frp); std::vector<long long>().swap(F.fdiag); std::vector<int>().swap(F.fci);
                 std::vector<double>().swap(F.fv); std::vector<int>().swap(F.Lrows); std::vector<int>().swap(F.Urows);
@@ -1533,6 +1575,23 @@ int das_run_coloring(das_solver_t* s) {
     DAS_TRY
     DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
     ensure_coloring(s);
+    return DAS_OK;
+    DAS_CATCH
+}
+// host-only profiling aid: factorise one local CSR exactly like a preconditioner block and report the phase times
+int das_debug_factor_block(int nl, const long long* rp, const int* ci, const double* val, int lfill, double* tim4, long long* nnzLU,
+                           int* nLevelsL, int* nLevelsU) {
+    DAS_TRY
+    DAS_CHECK(nl > 0 && rp && ci && val && tim4, DAS_ERR_ARG, "null argument");
+    std::vector<long long> lrp(rp, rp + nl + 1), where;
+    std::vector<int> lci(ci, ci + rp[nl]), lev;
+    std::vector<double> lv(val, val + rp[nl]);
+    BlockFactor F;
+    for (int k = 0; k < 4; k++) tim4[k] = 0.0;
+    factor_local(nl, lrp, lci, lv, lfill, F, where, lev, tim4);
+    if (nnzLU) *nnzLU = (long long)F.fci.size();
+    if (nLevelsL) *nLevelsL = (int)F.Llev.size() - 1;
+    if (nLevelsU) *nLevelsU = (int)F.Ulev.size() - 1;
     return DAS_OK;
     DAS_CATCH
 }

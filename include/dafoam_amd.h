@@ -150,6 +150,10 @@ int das_run_coloring(das_solver_t* s);
 /* das_set_coloring <- DAJacCon::readJacConColoring (DAJacCon.C:1980-2019): colours read back from a dRdWColoring_n.bin
  *                      cache; validated against the freshly built connectivity ("Conflicting Colors Found!" otherwise). */
 int das_set_coloring(das_solver_t* s, const int* colors);
+/* host-only profiling aid (no GPU needed): factorises one block-local CSR (sorted columns) exactly like a preconditioner
+ * block - symbolic ILU(lfill), numeric, level schedules, entry streams - and returns the four phase times [s] */
+int das_debug_factor_block(int nl, const long long* rowptr, const int* col, const double* val, int lfill, double* tim4, long long* nnzLU,
+                           int* nLevelsL, int* nLevelsU);
 int das_get_n_colors(das_solver_t* s, int isPC);
 long long das_get_con_nnz(das_solver_t* s, int isPC);
 int das_get_con(das_solver_t* s, int isPC, long long* rowptr /*n+1*/, int* colidx /*nnz*/);
