@@ -1,6 +1,7 @@
-// MI355X device driver of the adjoint hot path: kernel launches, coloured Jacobian assembly, transposed-CSR
-// SpMV (dRdW^T psi), block-ILU(0) preconditioner and the on-device restarted GMRES, exported through the
-// C-ABI of include/dafoam_amd.h.  gfx950 only.
+// MI355X device driver of the adjoint hot path: kernel launches, coloured Jacobian assembly (dual numbers / FD),
+// transposed-CSR SpMV (dRdW^T psi), restricted-additive-Schwarz + ILU(k) preconditioner (one workgroup per block, block
+// vector in LDS), the on-device restarted GMRES, objective/boundary-input derivatives, exported through the C-ABI of
+// include/dafoam_amd.h.  gfx950 only.
 //
 // Reference orchestration being replaced (file:line):
 //   DASolver::calcdRdWT                         src/adjoint/DASolver/DASolver.C:948-1089

@@ -238,7 +238,7 @@ def bump_mapping(height: float = 0.1, skew: float = 0.15, Lx: float = 1.0, Ly: f
 
 class _InputGeometry:
     """Face/cell geometry used ONLY to build consistent synthetic input fields (phi from
-    U, wall distance).  The product's geometry lives in csrc/mesh_geom.cpp; the oracle's
+    U, wall distance).  The product's geometry lives in csrc/das_mesh.cpp; the oracle's
     in oracle/foam_mesh.py - neither is imported here."""
 
     def __init__(self, mesh: PolyMesh):
