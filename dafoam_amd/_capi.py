@@ -202,6 +202,7 @@ _SIGS = {
     "das_get_patch_value": (C.c_int, [_VP, C.c_int, C.c_char_p, c_double_p]),
     "das_calc_dbc_product": (C.c_int, [_VP, c_int_p, C.c_int, C.c_char_p, c_double_p, C.c_char_p, C.c_char_p, c_double_p, c_double_p]),
     "das_define_force_function": (C.c_int, [_VP, C.c_char_p, c_int_p, C.c_int, c_double_p, C.c_double]),
+    "das_define_face_function": (C.c_int, [_VP, C.c_char_p, C.c_char_p, c_int_p, c_int_p, C.c_int, c_double_p, c_double_p, C.c_double, C.c_double]),
     "das_calc_function": (C.c_int, [_VP, C.c_char_p, c_double_p]),
     "das_get_input_size": (C.c_int, [_VP, C.c_char_p, C.c_char_p]),
     "das_get_output_size": (C.c_int, [_VP, C.c_char_p, C.c_char_p]),

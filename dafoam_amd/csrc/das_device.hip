@@ -47,25 +47,35 @@ __global__ __launch_bounds__(256) void k_pres(DevMesh m, ResParams prm, const T*
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_pres<T, RHO>(c, m, prm, q, R);
 }
-// force objective: value (atomic sum) and coloured dual-number gradient scatter
+// face-integral objectives: value (atomic sums per group), forward-mode tangent, coloured dual-number gradient scatter
+struct FaceFnView {
+    const int* faces;
+    const unsigned char* group;  // 0 / 1: denominator / numerator set of ratio functions (all 0 otherwise)
+    const double* w;             // per-face weight (value pass: base weights; derivative passes: effective weights)
+    const double* dir;           // 3 per face (force / moment), may be null for the other kinds
+    int nf, kind;
+    double gammaFn, RFn;
+};
 template <bool RHO>
-__global__ __launch_bounds__(256) void k_force_value(DevMesh m, ResParams prm, const double* __restrict__ W, const double* nut, const double* gU,
-                                                     const int* __restrict__ faces, int nfaces, double d0, double d1, double d2, double scale, double* out) {
+__global__ __launch_bounds__(256) void k_fn_value(DevMesh m, ResParams prm, const double* __restrict__ W, const double* nut, const double* gU,
+                                                  FaceFnView fn, double* out2) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nfaces) return;
-    double dir[3] = {d0, d1, d2};
-    double v = body_force<double, RHO>(faces[k], m, prm, W, nut, gU, dir, scale);
-    atomicAdd(out, v);
+    if (k >= fn.nf) return;
+    double dir[3] = {0.0, 0.0, 0.0};
+    if (fn.dir) { dir[0] = fn.dir[3 * k]; dir[1] = fn.dir[3 * k + 1]; dir[2] = fn.dir[3 * k + 2]; }
+    double v = fn.w[k] * body_facefn<double, RHO>(fn.faces[k], m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
+    atomicAdd(&out2[fn.group[k]], v);
 }
-// tangent of the force for seeded boundary values (dF/d(BC value), one forward pass)
+// tangent of the objective for seeded boundary values (dF/d(BC value), one forward pass)
 template <bool RHO>
-__global__ __launch_bounds__(256) void k_force_tangent(DevMesh m, ResParams prm, const Dual<1>* __restrict__ W, const Dual<1>* nut, const Dual<1>* gU,
-                                                       const int* __restrict__ faces, int nfaces, double d0, double d1, double d2, double scale, double* out) {
+__global__ __launch_bounds__(256) void k_fn_tangent(DevMesh m, ResParams prm, const Dual<1>* __restrict__ W, const Dual<1>* nut, const Dual<1>* gU,
+                                                    FaceFnView fn, double seed, double* out) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nfaces) return;
-    double dir[3] = {d0, d1, d2};
-    Dual<1> v = body_force<Dual<1>, RHO>(faces[k], m, prm, W, nut, gU, dir, scale);
-    if (v.d[0] != 0.0) atomicAdd(out, v.d[0]);
+    if (k >= fn.nf) return;
+    double dir[3] = {0.0, 0.0, 0.0};
+    if (fn.dir) { dir[0] = fn.dir[3 * k]; dir[1] = fn.dir[3 * k + 1]; dir[2] = fn.dir[3 * k + 2]; }
+    Dual<1> v = body_facefn<Dual<1>, RHO>(fn.faces[k], m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
+    if (v.d[0] != 0.0) atomicAdd(out, seed * fn.w[k] * v.d[0]);
 }
 // out += sum_i psi_i * dR_i  (dR = tangent part of a dual residual)
 __global__ __launch_bounds__(256) void k_tangent_dot(long long n, const Dual<1>* __restrict__ R, const double* __restrict__ psi, double* out) {
@@ -80,24 +90,25 @@ __global__ __launch_bounds__(256) void k_tangent_dot(long long n, const Dual<1>*
     }
     if (threadIdx.x == 0) atomicAdd(out, sh[0]);
 }
-// the derivative of F_f w.r.t. the (unique) state of colour `col` in the stencil of face f (cell c and its face
+// the derivative of q_f w.r.t. the (unique) state of colour `col` in the stencil of face f (cell c and its face
 // neighbours: U, p, (T), nuTilda) is accumulated into dFdW
 template <bool RHO>
-__global__ __launch_bounds__(256) void k_force_grad(DevMesh m, ResParams prm, const Dual<1>* __restrict__ W, const Dual<1>* nut, const Dual<1>* gU,
-                                                    const int* __restrict__ faces, int nfaces, double d0, double d1, double d2, double scale,
-                                                    const int* __restrict__ colors, int col, double* dFdW) {
+__global__ __launch_bounds__(256) void k_fn_grad(DevMesh m, ResParams prm, const Dual<1>* __restrict__ W, const Dual<1>* nut, const Dual<1>* gU,
+                                                 FaceFnView fn, double seed, const int* __restrict__ colors, int col, double* dFdW) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nfaces) return;
-    double dir[3] = {d0, d1, d2};
-    const int f = faces[k];
-    Dual<1> v = body_force<Dual<1>, RHO>(f, m, prm, W, nut, gU, dir, scale);
+    if (k >= fn.nf) return;
+    double dir[3] = {0.0, 0.0, 0.0};
+    if (fn.dir) { dir[0] = fn.dir[3 * k]; dir[1] = fn.dir[3 * k + 1]; dir[2] = fn.dir[3 * k + 2]; }
+    const int f = fn.faces[k];
+    Dual<1> v = body_facefn<Dual<1>, RHO>(f, m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
     if (v.d[0] == 0.0) return;
+    const double g = seed * fn.w[k] * v.d[0];
     const long long N = m.nC;
     const int c = m.owner[f];
     const int nsc = RHO ? 3 : 2;  // scalar cell blocks after U
     auto try_cell = [&](int x) -> bool {
-        for (int q = 0; q < 3; q++) if (colors[3LL * x + q] == col) { atomicAdd(&dFdW[3LL * x + q], v.d[0]); return true; }
-        for (int b = 0; b < nsc; b++) if (colors[(3 + b) * N + x] == col) { atomicAdd(&dFdW[(3 + b) * N + x], v.d[0]); return true; }
+        for (int q = 0; q < 3; q++) if (colors[3LL * x + q] == col) { atomicAdd(&dFdW[3LL * x + q], g); return true; }
+        for (int b = 0; b < nsc; b++) if (colors[(3 + b) * N + x] == col) { atomicAdd(&dFdW[(3 + b) * N + x], g); return true; }
         return false;
     };
     if (try_cell(c)) return;
@@ -633,8 +644,22 @@ struct das_solver {
     DevBuf<Dual<1>> d_Wd, d_Rd;
     ConDev cd[2];
     std::unique_ptr<das_mat> op;  // matrix-free operator (dual-number assembled dRdW^T)
-    struct ForceFn { std::vector<int> faces; double dir[3]; double scale; DevBuf<int> d_faces; };
-    std::map<std::string, ForceFn> functions;
+    struct FaceFn {  // a face-integral objective (see body_facefn)
+        int kind = DAS_FN_FORCE;
+        bool ratio = false;  // F = S[1] / S[0] over the two face groups (totalTemperatureRatio), else F = S[0] + S[1]
+        double gammaFn = 1.4, RFn = 287.0;
+        std::vector<int> faces;
+        std::vector<unsigned char> group;
+        std::vector<double> w0, dir;  // base weights (nf), directions (3 nf, force/moment only)
+        DevBuf<int> d_faces;
+        DevBuf<unsigned char> d_group;
+        DevBuf<double> d_w0, d_weff, d_dir;
+        bool uploaded = false;
+        FaceFnView view(const double* w) const {
+            return FaceFnView{d_faces.p, d_group.p, w, dir.empty() ? nullptr : d_dir.p, (int)faces.size(), kind, gammaFn, RFn};
+        }
+    };
+    std::map<std::string, FaceFn> functions;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<unsigned char> owned;  // per state; empty = single-domain
@@ -1714,58 +1739,133 @@ int das_set_old_time_fields(das_solver_t* s, const double* phi_frozen, const dou
     DAS_CATCH
 }
 
-// ---- objective functions (reference "function" option dict, DAFunctionForce) ------------------------------------------
-int das_define_force_function(das_solver_t* s, const char* name, const int* patch_ids, int npatch, const double* direction, double scale) {
+// ---- objective functions (reference "function" option dict: DAFunctionForce, DAFunctionMoment, DAFunctionMassFlowRate,
+//      DAFunctionTotalPressure, DAFunctionTotalTemperatureRatio) ------------------------------------------------------
+int das_define_face_function(das_solver_t* s, const char* name, const char* type, const int* patch_ids, const int* patch_group, int npatch,
+                             const double* vecA, const double* vecB, double scale, double gammaFn) {
     DAS_TRY
-    DAS_CHECK(s && name && patch_ids && direction && npatch > 0, DAS_ERR_ARG, "bad argument");
-    DAS_CHECK(s->cp.solver == DAS_SOLVER_SIMPLEFOAM || DAS_IS_COMPRESSIBLE(s->cp.solver), DAS_ERR_ARG, "force needs a flow solver");
-    double mag = std::sqrt(direction[0] * direction[0] + direction[1] * direction[1] + direction[2] * direction[2]);
-    DAS_CHECK(std::fabs(mag - 1.0) <= 1.0e-8, DAS_ERR_ARG, std::string("the magnitude of the direction parameter in ") + name + " is not 1.0!");
-    das_solver::ForceFn& fn = s->functions[name];
-    fn.faces.clear();
-    for (int k = 0; k < npatch; k++) {
-        int p = patch_ids[k];
-        DAS_CHECK(p >= 0 && p < s->mesh.nPatch, DAS_ERR_ARG, "patch id out of range");
-        for (int q = 0; q < s->mesh.patch_size[p]; q++) fn.faces.push_back(s->mesh.patch_start[p] + q);
+    DAS_CHECK(s && name && type && patch_ids && npatch > 0, DAS_ERR_ARG, "bad argument");
+    DAS_CHECK(s->cp.solver == DAS_SOLVER_SIMPLEFOAM || DAS_IS_COMPRESSIBLE(s->cp.solver), DAS_ERR_ARG, "function needs a flow solver");
+    const std::string ty = type;
+    das_solver::FaceFn fn;
+    if (ty == "force" || ty == "moment") fn.kind = DAS_FN_FORCE;
+    else if (ty == "massFlowRate") fn.kind = DAS_FN_MASSFLOW;
+    else if (ty == "totalPressure") fn.kind = DAS_FN_TOTALPRESSURE;
+    else if (ty == "totalTemperatureRatio") { fn.kind = DAS_FN_TOTALTEMPERATURE; fn.ratio = true; }
+    else throw Error(DAS_ERR_ARG, "function type not implemented on the GPU path: " + ty);
+    if (fn.kind == DAS_FN_FORCE) {
+        DAS_CHECK(vecA, DAS_ERR_ARG, "force / moment need a direction / axis");
+        const double mag = std::sqrt(vecA[0] * vecA[0] + vecA[1] * vecA[1] + vecA[2] * vecA[2]);
+        // reference DAFunctionForce.C:60-66 / DAFunctionMoment.C: the direction (axis) has unit length
+        DAS_CHECK(std::fabs(mag - 1.0) <= 1.0e-8, DAS_ERR_ARG, std::string("the magnitude of the direction parameter in ") + name + " is not 1.0!");
+        DAS_CHECK(ty == "force" || vecB, DAS_ERR_ARG, "moment needs a center");
     }
-    for (int k = 0; k < 3; k++) fn.dir[k] = direction[k];
-    fn.scale = scale;
-    if (s->inited) fn.d_faces.upload(fn.faces);
+    if (fn.ratio) {
+        DAS_CHECK(DAS_IS_COMPRESSIBLE(s->cp.solver), DAS_ERR_ARG, "totalTemperatureRatio needs a compressible solver");
+        DAS_CHECK(patch_group, DAS_ERR_ARG, "totalTemperatureRatio needs the inlet (0) / outlet (1) group of every patch");
+        DAS_CHECK(gammaFn > 1.0, DAS_ERR_ARG, "totalTemperatureRatio needs gamma > 1");
+        fn.gammaFn = gammaFn;
+        fn.RFn = s->cp.Cp - s->cp.Cp / gammaFn;  // DAFunctionTotalTemperatureRatio.C:98
+    }
+    double area[2] = {0.0, 0.0};
+    for (int k = 0; k < npatch; k++) {
+        const int p = patch_ids[k];
+        DAS_CHECK(p >= 0 && p < s->mesh.nPatch, DAS_ERR_ARG, "patch id out of range");
+        const int grp = (fn.ratio && patch_group[k]) ? 1 : 0;
+        for (int q = 0; q < s->mesh.patch_size[p]; q++) {
+            const int f = s->mesh.patch_start[p] + q;
+            fn.faces.push_back(f);
+            fn.group.push_back((unsigned char)grp);
+            area[grp] += s->mesh.fg[f].magSf;
+        }
+    }
+    DAS_CHECK(!fn.ratio || (area[0] > 0 && area[1] > 0), DAS_ERR_ARG, "inlet/outletPatches names are not in patches");
+    const size_t nf = fn.faces.size();
+    fn.w0.resize(nf);
+    if (fn.kind == DAS_FN_FORCE) fn.dir.resize(3 * nf);
+    for (size_t k = 0; k < nf; k++) {
+        const FaceGeom& g = s->mesh.fg[fn.faces[k]];
+        if (fn.kind == DAS_FN_FORCE) {
+            if (ty == "force") for (int d = 0; d < 3; d++) fn.dir[3 * k + d] = vecA[d];
+            else {  // (r x F) . axis = F . (axis x r),  r = Cf - center
+                const double r[3] = {g.Cf[0] - vecB[0], g.Cf[1] - vecB[1], g.Cf[2] - vecB[2]};
+                fn.dir[3 * k] = vecA[1] * r[2] - vecA[2] * r[1];
+                fn.dir[3 * k + 1] = vecA[2] * r[0] - vecA[0] * r[2];
+                fn.dir[3 * k + 2] = vecA[0] * r[1] - vecA[1] * r[0];
+            }
+            fn.w0[k] = scale;
+        } else if (fn.kind == DAS_FN_MASSFLOW) fn.w0[k] = scale;
+        else if (fn.kind == DAS_FN_TOTALPRESSURE) fn.w0[k] = scale * g.magSf / area[0];  // area average, DAFunctionTotalPressure.C:77
+        else fn.w0[k] = g.magSf / area[fn.group[k]];                                       // TTIn / TTOut area averages
+    }
+    s->functions[name] = std::move(fn);
     return DAS_OK;
     DAS_CATCH
 }
-static das_solver::ForceFn& get_function(das_solver* s, const char* name) {
+int das_define_force_function(das_solver_t* s, const char* name, const int* patch_ids, int npatch, const double* direction, double scale) {
+    return das_define_face_function(s, name, "force", patch_ids, nullptr, npatch, direction, nullptr, scale, 0.0);
+}
+static das_solver::FaceFn& get_function(das_solver* s, const char* name) {
     auto it = s->functions.find(name ? name : "");
     DAS_CHECK(it != s->functions.end(), DAS_ERR_ARG, std::string("function not defined: ") + (name ? name : "(null)"));
-    if (it->second.d_faces.n != it->second.faces.size()) it->second.d_faces.upload(it->second.faces);
-    return it->second;
+    das_solver::FaceFn& fn = it->second;
+    if (!fn.uploaded) {
+        fn.d_faces.upload(fn.faces);
+        fn.d_group.upload(fn.group);
+        fn.d_w0.upload(fn.w0);
+        fn.d_weff.alloc(fn.w0.size());
+        if (!fn.dir.empty()) fn.d_dir.upload(fn.dir);
+        fn.uploaded = true;
+    }
+    return fn;
+}
+// group sums S[0], S[1] of w0_f q_f at the current states (k_grad + k_fn_value)
+static void function_sums(das_solver* s, das_solver::FaceFn& fn, double S[2]) {
+    const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
+    ResParams prm = s->wk.bind(s->cp.solver, s->dm.nC, s->dm.nF, make_params(s->cp, s->opt, 0));
+    const int B = 256, nf = (int)fn.faces.size();
+    DAS_HIP(hipMemsetAsync(s->d_tmp1.p, 0, 2 * sizeof(double), s->stream));
+    if (rho) {
+        hipLaunchKernelGGL((k_grad<double, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
+        hipLaunchKernelGGL((k_fn_value<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.view(fn.d_w0.p), s->d_tmp1.p);
+    } else {
+        hipLaunchKernelGGL((k_grad<double, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, (double*)nullptr);
+        hipLaunchKernelGGL((k_fn_value<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.view(fn.d_w0.p), s->d_tmp1.p);
+    }
+    DAS_HIP(hipGetLastError());
+    DAS_HIP(hipMemcpyAsync(S, s->d_tmp1.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    DAS_HIP(hipStreamSynchronize(s->stream));
+}
+// effective per-face weights of the derivative passes: the base weights, times the quotient rule for ratio functions
+static void function_effective_weights(das_solver* s, das_solver::FaceFn& fn) {
+    if (!fn.ratio) {
+        DAS_HIP(hipMemcpyAsync(fn.d_weff.p, fn.d_w0.p, fn.w0.size() * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+        return;
+    }
+    double S[2];
+    function_sums(s, fn, S);
+    const double c[2] = {-S[1] / (S[0] * S[0]), 1.0 / S[0]};  // F = S1/S0
+    std::vector<double> w(fn.w0.size());
+    for (size_t k = 0; k < w.size(); k++) w[k] = fn.w0[k] * c[fn.group[k]];
+    fn.d_weff.upload(w);
 }
 int das_calc_function(das_solver_t* s, const char* name, double* value) {
     DAS_TRY
     need_init(s);
     DAS_CHECK(value, DAS_ERR_ARG, "null output");
-    das_solver::ForceFn& fn = get_function(s, name);
-    const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
-    ResParams prm = s->wk.bind(s->cp.solver, s->dm.nC, s->dm.nF, make_params(s->cp, s->opt, 0));
-    const int B = 256, nf = (int)fn.faces.size();
-    DAS_HIP(hipMemsetAsync(s->d_tmp1.p, 0, sizeof(double), s->stream));
-    if (rho) {
-        hipLaunchKernelGGL((k_grad<double, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
-        hipLaunchKernelGGL((k_force_value<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale, s->d_tmp1.p);
-    } else {
-        hipLaunchKernelGGL((k_grad<double, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, (double*)nullptr);
-        hipLaunchKernelGGL((k_force_value<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale, s->d_tmp1.p);
-    }
-    DAS_HIP(hipMemcpyAsync(value, s->d_tmp1.p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    DAS_HIP(hipStreamSynchronize(s->stream));
+    das_solver::FaceFn& fn = get_function(s, name);
+    double S[2];
+    function_sums(s, fn, S);
+    *value = fn.ratio ? S[1] / S[0] : S[0] + S[1];
     return DAS_OK;
     DAS_CATCH
 }
 // product_j = seed * s_j dF/dW_j : coloured forward-mode gradient of the objective (one k_grad + one k_force per colour)
 static void function_gradient(das_solver* s, const char* name, double seed, double* product) {
     need_init(s);
-    das_solver::ForceFn& fn = get_function(s, name);
+    das_solver::FaceFn& fn = get_function(s, name);
     ensure_con_dev(s, 0);
+    function_effective_weights(s, fn);
     ResParams prm = s->wk1.bind(s->cp.solver, s->dm.nC, s->dm.nF, make_params(s->cp, s->opt, 0));
     const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
     const long long n = s->n;
@@ -1776,10 +1876,10 @@ static void function_gradient(das_solver* s, const char* name, double seed, doub
         hipLaunchKernelGGL(k_seed<1>, dim3(nblk(n, B)), dim3(B), 0, s->stream, n, s->d_W.p, s->d_colors.p, s->d_scale.p, col, s->d_Wd.p);
         if (rho) {
             hipLaunchKernelGGL((k_grad<Dual<1>, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
-            hipLaunchKernelGGL((k_force_grad<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale * seed, s->d_colors.p, col, s->d_tmp2.p);
+            hipLaunchKernelGGL((k_fn_grad<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seed, s->d_colors.p, col, s->d_tmp2.p);
         } else {
             hipLaunchKernelGGL((k_grad<Dual<1>, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, (Dual<1>*)nullptr);
-            hipLaunchKernelGGL((k_force_grad<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale * seed, s->d_colors.p, col, s->d_tmp2.p);
+            hipLaunchKernelGGL((k_fn_grad<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seed, s->d_colors.p, col, s->d_tmp2.p);
         }
     }
     DAS_HIP(hipGetLastError());
@@ -1873,15 +1973,17 @@ int das_calc_dbc_product(das_solver_t* s, const int* patches, int np, const char
         DAS_HIP(hipMemcpyAsync(s->d_tmp2.p, seeds, n * sizeof(double), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_tangent_dot, dim3(1024), dim3(256), 0, st, n, s->d_Rd.p, s->d_tmp2.p, s->d_tmp1.p);
     } else {
-        das_solver::ForceFn& fn = get_function(s, outputName);
+        das_solver::FaceFn& fn = get_function(s, outputName);
+        function_effective_weights(s, fn);
+        DAS_HIP(hipMemsetAsync(s->d_tmp1.p, 0, sizeof(double), st));  // function_sums used the scratch
         prm = s->wk1.bind(s->cp.solver, s->dm.nC, s->dm.nF, prm);
         const int nf = (int)fn.faces.size();
         if (rho) {
             hipLaunchKernelGGL((k_grad<Dual<1>, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
-            hipLaunchKernelGGL((k_force_tangent<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale * seeds[0], s->d_tmp1.p);
+            hipLaunchKernelGGL((k_fn_tangent<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seeds[0], s->d_tmp1.p);
         } else {
             hipLaunchKernelGGL((k_grad<Dual<1>, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, (Dual<1>*)nullptr);
-            hipLaunchKernelGGL((k_force_tangent<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.d_faces.p, nf, fn.dir[0], fn.dir[1], fn.dir[2], fn.scale * seeds[0], s->d_tmp1.p);
+            hipLaunchKernelGGL((k_fn_tangent<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seeds[0], s->d_tmp1.p);
         }
     }
     DAS_HIP(hipGetLastError());

@@ -777,6 +777,38 @@ DAS_HD T body_force(int f, const DevMesh& m, const ResParams& prm, const T* W, c
     return scale * acc;
 }
 
+// ================================================================================ face-integral objectives
+// One boundary face's contribution q_f of the reference's patch functions (the weights - scale, area fractions, the
+// quotient rule of ratio functions - are applied by the caller):
+//   kind 0  force / moment   (S_f p_b + S_f . devRhoReff_b) . d_f      DAFunctionForce.C:79-158, DAFunctionMoment.C:73-120
+//                            (moment: d_f = axis x (C_f - center))
+//   kind 1  massFlowRate     rho_b (U_b . S_f)                          DAFunctionMassFlowRate.C:52-80
+//   kind 2  totalPressure    p_b + 0.5 rho_b |U_b|^2                    DAFunctionTotalPressure.C:60-90
+//   kind 3  totalTemperature T_b (1 + 0.5 (gamma-1) Ma^2), Ma^2 = |U_b|^2 / (gamma R T_b), R = Cp - Cp/gamma
+//                                                                       DAFunctionTotalTemperatureRatio.C:88-125
+#define DAS_FN_FORCE 0
+#define DAS_FN_MASSFLOW 1
+#define DAS_FN_TOTALPRESSURE 2
+#define DAS_FN_TOTALTEMPERATURE 3
+template <class T, bool RHO>
+DAS_HD T body_facefn(int f, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, int kind, const double* dir,
+                     double gammaFn, double RFn) {
+    if (kind == DAS_FN_FORCE) return body_force<T, RHO>(f, m, prm, W, nut, gradU, dir, 1.0);
+    const long long N = m.nC;
+    const FaceGeom& g = m.fg[f];
+    const int c = m.owner[f];
+    T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
+    T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
+    T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
+    BFace<T> b;
+    eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, m.cg[c], prm, Uc, pc, Tc, nc, nut[c], val(W[prm.offPhi * N + f]), b);
+    T U2 = b.U.xb[0] * b.U.xb[0] + b.U.xb[1] * b.U.xb[1] + b.U.xb[2] * b.U.xb[2];
+    if (kind == DAS_FN_MASSFLOW) return b.rho_b * (b.U.xb[0] * g.Sf[0] + b.U.xb[1] * g.Sf[1] + b.U.xb[2] * g.Sf[2]);
+    if (kind == DAS_FN_TOTALPRESSURE) return b.p.xb + 0.5 * b.rho_b * U2;
+    // total temperature (compressible solvers only; the caller checks)
+    return b.Tt.xb + (0.5 * (gammaFn - 1.0) / (gammaFn * RFn)) * U2;
+}
+
 // ================================================================================ DAScalarTransportFoam
 template <class T>
 DAS_HD void body_gradT(int c, const DevMesh& m, const ResParams& prm, const T* W, const double* phiF, T* gradT) {

@@ -542,17 +542,36 @@ class pyDASolvers:
 
     # -- objective functions ------------------------------------------------------------------------
     def _define_functions(self, functions):
-        """"function" option dict (reference pyDAFoam.py DAOPTION.function): only type "force" with
-        directionMode "fixedDirection" is on this path."""
+        """"function" option dict (reference pyDAFoam.py DAOPTION.function): the patch-integral types force (directionMode
+        fixedDirection), moment, massFlowRate, totalPressure and totalTemperatureRatio are on this path."""
         names = [p.name for p in self._case.mesh.patches]
+        L = lib()
         for fname, fd in (functions or {}).items():
-            if fd.get("type") != "force":
-                raise NotImplementedError(f"function type {fd.get('type')} is outside the GPU hot path")
-            if fd.get("directionMode", "fixedDirection") != "fixedDirection":
+            ftype = fd.get("type")
+            if ftype not in ("force", "moment", "massFlowRate", "totalPressure", "totalTemperatureRatio"):
+                raise NotImplementedError(f"function type {ftype} is outside the GPU hot path")
+            if ftype == "force" and fd.get("directionMode", "fixedDirection") != "fixedDirection":
                 raise NotImplementedError("only directionMode fixedDirection is implemented")
             ids = np.array([names.index(p) for p in fd["patches"]], dtype=np.int32)
-            d = np.ascontiguousarray(fd["direction"], dtype=np.float64)
-            check(lib().das_define_force_function(self._h, fname.encode(), ids.ctypes.data_as(_capi.c_int_p), ids.size, dptr(d), float(fd.get("scale", 1.0))))
+            grp = None
+            gamma = 0.0
+            vecA = vecB = None
+            if ftype == "force":
+                vecA = np.ascontiguousarray(fd["direction"], dtype=np.float64)
+            elif ftype == "moment":
+                vecA = np.ascontiguousarray(fd["axis"], dtype=np.float64)
+                vecB = np.ascontiguousarray(fd["center"], dtype=np.float64)
+            elif ftype == "totalTemperatureRatio":
+                inl, out = fd["inletPatches"], fd["outletPatches"]
+                for p in fd["patches"]:
+                    if p not in inl and p not in out:
+                        raise _capi.DASError("inlet/outletPatches names are not in patches")
+                grp = np.array([1 if p in out else 0 for p in fd["patches"]], dtype=np.int32)
+                gamma = float(self._case.thermo.get("gamma", 1.4))
+            check(L.das_define_face_function(
+                self._h, fname.encode(), ftype.encode(), ids.ctypes.data_as(_capi.c_int_p),
+                grp.ctypes.data_as(_capi.c_int_p) if grp is not None else None, ids.size,
+                dptr(vecA) if vecA is not None else None, dptr(vecB) if vecB is not None else None, float(fd.get("scale", 1.0)), gamma))
 
     def calcFunction(self, functionName):
         v = C.c_double(0.0)

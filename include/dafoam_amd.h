@@ -210,6 +210,17 @@ int das_get_patch_value(das_solver_t* s, int patch_id, const char* field, double
 int das_calc_dbc_product(das_solver_t* s, const int* patch_ids, int npatch, const char* field, const double* tangent, const char* outputName,
                          const char* outputType, const double* seeds, double* product);
 int das_define_force_function(das_solver_t* s, const char* name, const int* patch_ids, int npatch, const double* direction, double scale);
+/* das_define_face_function <- the other patch-integral entries of the "function" option dict (pyDAFoam.py:100-200):
+ *   type "force"                 vecA = direction (unit)                                   DAFunctionForce.C:79-158
+ *        "moment"                vecA = axis (unit), vecB = center                         DAFunctionMoment.C:73-120
+ *        "massFlowRate"          sum rho_b (U_b . S_f) * scale                             DAFunctionMassFlowRate.C:52-80
+ *        "totalPressure"         area average of p_b + 0.5 rho_b |U_b|^2, * scale          DAFunctionTotalPressure.C:60-90
+ *        "totalTemperatureRatio" TT_out / TT_in (area averages); patch_group[k] = 0 inlet, 1 outlet; gammaFn = the
+ *                                thermophysicalProperties gamma, R = Cp - Cp/gamma         DAFunctionTotalTemperatureRatio.C:60-130
+ * patch_group may be NULL for the non-ratio types.  Values and derivatives go through das_calc_function /
+ * das_calc_jac_t_vec_product / das_calc_dbc_product like the force. */
+int das_define_face_function(das_solver_t* s, const char* name, const char* type, const int* patch_ids, const int* patch_group, int npatch,
+                             const double* vecA, const double* vecB, double scale, double gammaFn);
 int das_calc_function(das_solver_t* s, const char* name, double* value);
 
 /* das_calc_jac_t_vec_product <- calcJacTVecProduct(inputName,inputType,inputs,outputName,outputType,seeds,product)

@@ -200,6 +200,47 @@ def test_force_function_and_dFdW(solver):
         D.solver.calcFunction("nope")
 
 
+@pytest.mark.parametrize("solver", ["DASimpleFoam", "DATurboFoam"])
+def test_patch_functions_values_and_gradients(solver):
+    """moment, massFlowRate, totalPressure (and totalTemperatureRatio for the compressible solvers; the objectives of the
+    reference's DATurboFoam / MRF tests): values and state-scaled dFdW against the oracle's complex-step gradients,
+    including the quotient rule of the ratio function and the rotating-wall velocity of the MRF zone."""
+    from oracle import functions as Fn
+
+    turbo = solver == "DATurboFoam"
+    case = turbo_channel_case(6, 5, 4, wall_function=True, perturb=0.02) if turbo else channel_case(6, 5, 4, wall_function=True, perturb=0.02)
+    g = Geometry(case.mesh)
+    W = case.states
+    walls = ["bottom", "top"]
+    fn = {
+        "CMZ": {"type": "moment", "source": "patchToFace", "patches": walls, "axis": [0.0, 0.0, 1.0], "center": [0.5, 0.1, 0.0], "scale": 3.0},
+        "MFR": {"type": "massFlowRate", "source": "patchToFace", "patches": ["inlet"], "scale": -1.0},
+        "TP": {"type": "totalPressure", "source": "patchToFace", "patches": ["outlet"], "scale": 0.5},
+    }
+    ref = {
+        "CMZ": lambda Wp: Fn.moment(case, g, Wp, walls, [0, 0, 1], [0.5, 0.1, 0.0], 3.0),
+        "MFR": lambda Wp: Fn.mass_flow_rate(case, g, Wp, ["inlet"], -1.0),
+        "TP": lambda Wp: Fn.total_pressure(case, g, Wp, ["outlet"], 0.5),
+    }
+    if turbo:
+        fn["TTR"] = {"type": "totalTemperatureRatio", "source": "patchToFace", "patches": ["inlet", "outlet"], "inletPatches": ["inlet"],
+                     "outletPatches": ["outlet"], "scale": 1.0}
+        ref["TTR"] = lambda Wp: Fn.total_temperature_ratio(case, g, Wp, ["inlet"], ["outlet"], 1.4)
+    D = make(case, function=fn)
+    sc = J.state_scales(case, g, norm_states(case))
+    for name, f in ref.items():
+        Fo = f(W)
+        assert abs(D.solver.calcFunction(name) - Fo) <= 1e-12 * abs(Fo), name
+        dFo = Fn.gradient(f, W, sc)
+        dF = np.zeros(W.size)
+        D.solverAD.calcJacTVecProduct("states", "stateVar", W, name, "function", np.array([1.0]), dF)
+        assert np.abs(dF - dFo).max() <= 1e-10 * np.abs(dFo).max(), name
+    if not turbo:
+        with pytest.raises(Exception, match="compressible"):
+            make(case, function={"TTR": {"type": "totalTemperatureRatio", "patches": ["inlet", "outlet"], "inletPatches": ["inlet"],
+                                         "outletPatches": ["outlet"]}})
+
+
 def test_normalize_residuals_option():
     # DAMacroFunctions.H:28-51: residuals not listed are volume-integrated / not area-divided
     case = channel_case(5, 5, 4)
