@@ -230,7 +230,7 @@ def test_patch_functions_values_and_gradients(solver):
     sc = J.state_scales(case, g, norm_states(case))
     for name, f in ref.items():
         Fo = f(W)
-        assert abs(D.solver.calcFunction(name) - Fo) <= 1e-12 * abs(Fo), name
+        assert abs(D.solver.calcFunction(name) - Fo) <= 1e-10 * abs(Fo), name  # sums of p ~ 1e5 terms cancel in the moment
         dFo = Fn.gradient(f, W, sc)
         dF = np.zeros(W.size)
         D.solverAD.calcJacTVecProduct("states", "stateVar", W, name, "function", np.array([1.0]), dF)
