@@ -75,6 +75,8 @@ def sadd(idx, vals, n):
             return np.bincount(idx, vals.real, n) + 1j * np.bincount(idx, vals.imag, n)
         return np.bincount(idx, vals, n)
     out = np.zeros((n,) + vals.shape[1:], dtype=vals.dtype)
+    if vals.shape[0] == 0:  # e.g. a mesh without internal faces
+        return out
     flat = vals.reshape(vals.shape[0], -1)
     o2 = out.reshape(n, -1)
     for k in range(flat.shape[1]):

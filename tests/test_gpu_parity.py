@@ -241,6 +241,30 @@ def test_patch_functions_values_and_gradients(solver):
                                          "outletPatches": ["outlet"]}})
 
 
+@pytest.mark.parametrize("dims", [(1, 1, 1), (2, 1, 1), (3, 2, 1)])
+def test_degenerate_meshes_full_path(dims):
+    """A single cell / a row of cells through the whole GPU path (launch sizes, block partition, level schedules with a
+    handful of unknowns): residual, Jacobian and adjoint vector against the oracle."""
+    from dafoam_amd.pyDASolvers import Mat
+
+    case = channel_case(*dims, wall_function=True)
+    g = Geometry(case.mesh)
+    W = case.states
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-12, "printInfo": 0}, jacLowerBounds={"dRdW": 0.0, "dRdWPC": 0.0})
+    R = np.zeros(W.size)
+    D.solver.getResiduals(R)
+    Ro = residual(case, g, W)
+    assert np.abs(R - Ro).max() <= 1e-12 * np.abs(Ro).max()
+    sc, con, col, A = oracle_mats(case, g)
+    D.solver.runColoring()
+    M = Mat()
+    D.solver.calcdRdWT(0, M, mode=1)
+    assert np.abs((M.to_scipy() - A).tocsr().data).max() <= 1e-10 * np.abs(A.data).max()
+    rhs = np.ones(W.size) * sc
+    psi, fail = D.solveAdjoint(rhs)
+    assert fail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-8
+
+
 def test_normalize_residuals_option():
     # DAMacroFunctions.H:28-51: residuals not listed are volume-integrated / not area-divided
     case = channel_case(5, 5, 4)

@@ -238,6 +238,26 @@ def test_coloring_cache_roundtrip_and_validation(tmp_path):
     assert np.array_equal(col3, col) and np.array_equal(petsc_io.read_vec(str(f)), col.astype(np.float64))
 
 
+@pytest.mark.parametrize("dims", [(1, 1, 1), (2, 1, 1), (1, 3, 1), (2, 2, 2)])
+def test_degenerate_meshes(dims):
+    """Edge cases: a single cell (no internal face at all), one row / one column of cells.  Oracle, kernel bodies,
+    connectivity and colouring agree; with 8 or fewer cells every column conflicts with every other (n colours)."""
+    case = channel_case(*dims, wall_function=True)
+    g = Geometry(case.mesh)
+    W = case.states
+    Ro = residual(case, g, W)
+    Rv, _ = _emu_res(case, W)
+    assert np.abs(Rv - Ro).max() <= 1e-12 * np.abs(Ro).max()
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    s.runColoring()
+    con = J.connectivity(case, g)
+    assert (s.getConnectivity(0) != con).nnz == 0
+    col, nc = s.getColoring()
+    assert J.validate_coloring(con, col.astype(np.int64))
+    if case.mesh.n_cells <= 3:
+        assert nc == W.size
+
+
 def test_petsc_binary_io_roundtrip_and_layout(tmp_path):
     """PETSc binary Vec/Mat (big-endian, classids 1211214 / 1211216 - SURVEY.md Appendix D)."""
     import scipy.sparse as sp
