@@ -68,6 +68,7 @@ class das_case_t(C.Structure):
         ("patch_mrf_rotating", c_int_p),
         ("transonic", C.c_int),
         ("transonic_pc_option", C.c_int),
+        ("simple_has_T", C.c_int),
     ]
 
 
@@ -151,6 +152,7 @@ class CaseStruct:
             s.patch_mrf_rotating = _ip(k["patch_mrf_rotating"])
         s.transonic = 1 if getattr(case, "transonic", False) else 0
         s.transonic_pc_option = int(getattr(case, "transonic_pc_option", 1))
+        s.simple_has_T = 1 if (case.solver_name == "DASimpleFoam" and getattr(case, "has_T", False)) else 0
 
     def byref(self):
         return C.byref(self.struct)

@@ -8,7 +8,7 @@ struct CaseParams {
     int solver = DAS_SOLVER_SIMPLEFOAM;
     double nu = 1.5e-5, relax_U = 0.7, relax_nuTilda = 0.7, relax_T = 1.0, DT = 0.01, deltaT = 1.0;
     double Cp = 1005.0, molWeight = 28.96, mu = 1.8e-5, Pr = 0.7, Prt = 1.0;
-    int mrf = 0, transonic = 0, transonicPC = 1;
+    int mrf = 0, transonic = 0, transonicPC = 1, hasT = 0;
     double om[3] = {0, 0, 0}, org[3] = {0, 0, 0};
     std::vector<double> phi_frozen, T_old;
     void from_case(const das_case_t* c) {
@@ -23,6 +23,12 @@ struct CaseParams {
             mrf = c->mrf_active != 0;
             for (int k = 0; k < 3; k++) { om[k] = c->mrf_omega[k]; org[k] = c->mrf_origin[k]; }
             DAS_CHECK(!mrf || c->patch_mrf_rotating, DAS_ERR_ARG, "MRF needs the per-patch rotating flags");
+        }
+        hasT = (solver == DAS_SOLVER_SIMPLEFOAM) && c->simple_has_T != 0;
+        if (hasT) {
+            Pr = c->Pr; Prt = c->Prt;
+            DAS_CHECK(Pr > 0 && Prt > 0, DAS_ERR_ARG, "DASimpleFoam with a T field needs positive Pr, Prt");
+            DAS_CHECK(c->bc_T_code != nullptr, DAS_ERR_ARG, "DASimpleFoam with a T field needs the T patch table");
         }
         if (DAS_IS_COMPRESSIBLE(solver)) {
             transonic = (solver == DAS_SOLVER_TURBOFOAM) && c->transonic != 0;
@@ -51,11 +57,12 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.normN = opt.list_has("normalizeResiduals", "nuTildaRes");
     p.normPhi = opt.list_has("normalizeResiduals", "phiRes");
     p.normT = opt.list_has("normalizeResiduals", "TRes");
-    const bool rho = DAS_IS_COMPRESSIBLE(cp.solver);
+    const bool rho = DAS_IS_COMPRESSIBLE(cp.solver) || cp.hasT;  // layouts with a T block
     p.offP = 3;
     p.offT = rho ? 4 : 0;
     p.offN = rho ? 5 : 4;
     p.offPhi = rho ? 6 : 5;
+    p.hasT = cp.hasT;
     p.Cp = cp.Cp;
     p.Rgas = 8314.47 / cp.molWeight;  // Foam::constant::thermodynamic::RR / molWeight
     p.mu = cp.mu;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_fn_grad(DevMesh m, ResParams prm, const
     const double g = seed * fn.w[k] * v.d[0];
     const long long N = m.nC;
     const int c = m.owner[f];
-    const int nsc = RHO ? 3 : 2;  // scalar cell blocks after U
+    const int nsc = prm.offPhi - 3;  // scalar cell blocks after U (p, [T], nuTilda)
     auto try_cell = [&](int x) -> bool {
         for (int q = 0; q < 3; q++) if (colors[3LL * x + q] == col) { atomicAdd(&dFdW[3LL * x + q], g); return true; }
         for (int b = 0; b < nsc; b++) if (colors[(3 + b) * N + x] == col) { atomicAdd(&dFdW[(3 + b) * N + x], g); return true; }
@@ -138,7 +138,7 @@ struct ResWork {
             if (nut.n != (size_t)N) {
                 nut.alloc(N); gU.alloc(9 * N); gP.alloc(3 * N); gN.alloc(3 * N); rAU.alloc(N); HbyA.alloc(3 * N); q.alloc(F);
             }
-            if (DAS_IS_COMPRESSIBLE(solver) && gH.n != (size_t)(3 * N)) gH.alloc(3 * N);
+            if (gH.n != (size_t)(3 * N)) gH.alloc(3 * N);  // compressible he / the optional T field of DASimpleFoam
             if (solver == DAS_SOLVER_TURBOFOAM && TU.n != (size_t)(3 * N)) TU.alloc(3 * N);
         } else if (gT.n != (size_t)(3 * N)) gT.alloc(3 * N);
     }
@@ -159,9 +159,9 @@ static void eval_residual(const DevMesh& dm, const CaseParams& cp, const ResPara
     const ResParams prm = wk.bind(cp.solver, dm.nC, dm.nF, prm_in);
     const int B = 256;
     if (cp.solver == DAS_SOLVER_SIMPLEFOAM) {
-        hipLaunchKernelGGL((k_grad<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, (T*)nullptr);
+        hipLaunchKernelGGL((k_grad<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, wk.gH.p);
         hipLaunchKernelGGL((k_cell<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p,
-                           (const T*)nullptr, R, wk.rAU.p, wk.HbyA.p);
+                           (const T*)wk.gH.p, R, wk.rAU.p, wk.HbyA.p);
         hipLaunchKernelGGL((k_face<T, false>), dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
         hipLaunchKernelGGL((k_pres<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, wk.q.p, R);
     } else if (DAS_IS_COMPRESSIBLE(cp.solver)) {
@@ -706,8 +706,8 @@ static void compute_scales(das_solver* s) {
 static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
     if (s->colored && !preset) return;
     double t = wall_seconds();
-    s->st_full = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, false);
-    s->st_pc = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, true);
+    s->st_full = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, false, s->cp.hasT != 0);
+    s->st_pc = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, true, s->cp.hasT != 0);
     double t1 = wall_seconds();
     s->con_full.build(s->mesh, s->st_full);
     s->con_pc.build(s->mesh, s->st_pc);
@@ -1456,7 +1456,7 @@ das_solver_t* das_create(const das_case_t* c) {
         s->cp.from_case(c);
         s->mesh.build(c);
         s->opt.s["solverName"] = c->solver == DAS_SOLVER_SIMPLEFOAM ? "DASimpleFoam" : (c->solver == DAS_SOLVER_RHOSIMPLEFOAM ? "DARhoSimpleFoam" : (c->solver == DAS_SOLVER_TURBOFOAM ? "DATurboFoam" : "DAScalarTransportFoam"));
-        s->st_full = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, false);
+        s->st_full = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, false, s->cp.hasT != 0);
         s->n = s->st_full.n;
         s->h_W.assign(s->n, 0.0);
         compute_scales(s.get());
@@ -1829,7 +1829,7 @@ static void function_sums(das_solver* s, das_solver::FaceFn& fn, double S[2]) {
         hipLaunchKernelGGL((k_grad<double, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
         hipLaunchKernelGGL((k_fn_value<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.view(fn.d_w0.p), s->d_tmp1.p);
     } else {
-        hipLaunchKernelGGL((k_grad<double, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, (double*)nullptr);
+        hipLaunchKernelGGL((k_grad<double, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
         hipLaunchKernelGGL((k_fn_value<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.view(fn.d_w0.p), s->d_tmp1.p);
     }
     DAS_HIP(hipGetLastError());
@@ -1878,7 +1878,7 @@ static void function_gradient(das_solver* s, const char* name, double seed, doub
             hipLaunchKernelGGL((k_grad<Dual<1>, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
             hipLaunchKernelGGL((k_fn_grad<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seed, s->d_colors.p, col, s->d_tmp2.p);
         } else {
-            hipLaunchKernelGGL((k_grad<Dual<1>, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, (Dual<1>*)nullptr);
+            hipLaunchKernelGGL((k_grad<Dual<1>, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
             hipLaunchKernelGGL((k_fn_grad<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seed, s->d_colors.p, col, s->d_tmp2.p);
         }
     }
@@ -1982,7 +1982,7 @@ int das_calc_dbc_product(das_solver_t* s, const int* patches, int np, const char
             hipLaunchKernelGGL((k_grad<Dual<1>, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
             hipLaunchKernelGGL((k_fn_tangent<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seeds[0], s->d_tmp1.p);
         } else {
-            hipLaunchKernelGGL((k_grad<Dual<1>, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, (Dual<1>*)nullptr);
+            hipLaunchKernelGGL((k_grad<Dual<1>, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
             hipLaunchKernelGGL((k_fn_tangent<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seeds[0], s->d_tmp1.p);
         }
     }

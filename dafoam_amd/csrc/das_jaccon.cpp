@@ -21,7 +21,7 @@
 
 namespace das {
 
-Stencil make_stencil(int solver, int nC, int nF, const Options& opt, bool isPC) {
+Stencil make_stencil(int solver, int nC, int nF, const Options& opt, bool isPC, bool simpleHasT) {
     Stencil st;
     auto add_state = [&](const char* nm, StateKind k) {
         StateDef s;
@@ -39,7 +39,22 @@ Stencil make_stencil(int solver, int nC, int nF, const Options& opt, bool isPC) 
                 if (st.states[i].name == nm) m |= 1u << i;
         return m;
     };
-    if (solver == DAS_SOLVER_SIMPLEFOAM) {
+    if (solver == DAS_SOLVER_SIMPLEFOAM && simpleHasT) {
+        // DASimpleFoam with the optional T field (DAStateInfoSimpleFoam.C:118-131).  TRes lists U at level 0 in addition
+        // to the reference's table: alphat_b = nut_b/Prt of a wall-function face depends on the cell velocity.
+        add_state("U", KIND_VEC);
+        add_state("p", KIND_SCL);
+        add_state("T", KIND_SCL);
+        add_state("nuTilda", KIND_SCL);
+        add_state("phi", KIND_FACE);
+        st.levels.resize(5);
+        st.levels[0] = {bits({"U", "p", "nuTilda", "phi"}), bits({"U", "p", "nuTilda"}), bits({"U"})};  // URes
+        st.levels[1] = {bits({"U", "p", "nuTilda", "phi"}), bits({"U", "p", "nuTilda", "phi"}), bits({"U", "p", "nuTilda"}),
+                        bits({"U"})};                                                                // pRes
+        st.levels[2] = {bits({"U", "T", "nuTilda", "phi"}), bits({"T", "nuTilda"}), bits({"T"})};      // TRes
+        st.levels[3] = {bits({"U", "nuTilda", "phi"}), bits({"U", "nuTilda"}), bits({"nuTilda"})};    // nuTildaRes
+        st.levels[4] = {bits({"U", "p", "nuTilda", "phi"}), bits({"U", "p", "nuTilda"}), bits({"U"})};  // phiRes
+    } else if (solver == DAS_SOLVER_SIMPLEFOAM) {
         // order: volVector, volScalar, model, surfaceScalar (reference DAIndex.C:43-63)
         add_state("U", KIND_VEC);
         add_state("p", KIND_SCL);

@@ -23,7 +23,7 @@ struct Stencil {
     long long n = 0;
 };
 
-Stencil make_stencil(int solver, int nC, int nF, const Options& opt, bool isPC);
+Stencil make_stencil(int solver, int nC, int nF, const Options& opt, bool isPC, bool simpleHasT = false);
 
 // std::vector whose resize() leaves trivially-constructible elements uninitialised: the big index arrays are written
 // in full by parallel loops, and a serial zero-fill (page faults of GBs of fresh memory) used to cost more than the

@@ -51,6 +51,7 @@ struct ResParams {
     double Cp, Rgas, mu, Pr, Prt;
     // DATurboFoam switches and the MRF zone (angular velocity, origin)
     int turbo, transonic, transonicPC, mrf;
+    int hasT;  // DASimpleFoam with the optional passive T field (RHO = false kernels)
     double om[3], org[3];
     // DATurboFoam work array of the launch (typed by the kernel's scalar type): Teff.U per cell (3N)
     void* wTU;
@@ -202,6 +203,10 @@ DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc
     } else {
         o.rho_b = T(1.0);
         o.nu_b = T(prm.nu);
+        if (prm.hasT) {  // passive T of DASimpleFoam: "he" is T itself
+            bc_scalar<T>(bc.T_code, bc.T_val, bc.dT_val, g.nod, phib, Tc, o.Tt);
+            o.he = o.Tt;
+        }
     }
     if (bc.nut_code == DAS_NUT_LOWRE_WALL) o.nut_b = T(0.0);
     else if (bc.nut_code == DAS_NUT_SYMMETRY) o.nut_b = nut_c;
@@ -242,7 +247,8 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
     const CellGeom& cgc = m.cg[c];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
     T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
-    T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
+    const bool energy = RHO || prm.hasT;  // an energy-like scalar with a gradient (he, or the passive T)
+    T Tc = energy ? W[prm.offT * N + c] : T(0.0);
     T nu_c = RHO ? prm.mu * (prm.Rgas * Tc) / pc : T(prm.nu);
     T nut_c = nc * fv1_of<T>(nc / nu_c);
     nut[c] = nut_c;
@@ -266,6 +272,7 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
             pf = wc * pc + (1.0 - wc) * W[prm.offP * N + o];
             nf = wc * nc + (1.0 - wc) * W[prm.offN * N + o];
             if (RHO) hf = prm.Cp * (wc * Tc + (1.0 - wc) * W[prm.offT * N + o] - DAS_TREF);
+            else if (energy) hf = wc * Tc + (1.0 - wc) * W[prm.offT * N + o];
         } else {
             BFace<T> b;
             eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, cgc, prm, Uc, pc, Tc, nc, nut_c, val(W[prm.offPhi * N + f]), b);
@@ -273,7 +280,7 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
             for (int k = 0; k < 3; k++) Uf[k] = b.U.xb[k];
             pf = b.p.xb;
             nf = b.n.xb;
-            if (RHO) hf = b.he.xb;
+            if (energy) hf = b.he.xb;
         }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
@@ -282,7 +289,7 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
             for (int j = 0; j < 3; j++) gU[3 * i + j] += S * Uf[j];
             gP[i] += S * pf;
             gN[i] += S * nf;
-            if (RHO) gH[i] += S * hf;
+            if (energy) gH[i] += S * hf;
         }
     }
     double rV = 1.0 / cgc.V;
@@ -292,7 +299,7 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
     for (int k = 0; k < 3; k++) {
         gradP[3LL * c + k] = gP[k] * rV;
         gradN[3LL * c + k] = gN[k] * rV;
-        if (RHO) gradH[3LL * c + k] = gH[k] * rV;
+        if (energy) gradH[3LL * c + k] = gH[k] * rV;
     }
     if (RHO && prm.turbo) {  // viscous-work vector Teff.U of the cell (EEqn: - fvc::div(Teff.T() & U))
 #pragma unroll
@@ -329,7 +336,8 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     const CellGeom& cgc = m.cg[c];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
     T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
-    T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
+    const bool energy = RHO || prm.hasT;  // energy equation (RHO) or the passive T equation of DASimpleFoam
+    T Tc = energy ? W[prm.offT * N + c] : T(0.0);
     T rho_c = RHO ? pc / (prm.Rgas * Tc) : T(1.0);
     T nu_c = RHO ? prm.mu / rho_c : T(prm.nu);
     T nut_c = nut[c];
@@ -342,8 +350,9 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     dev2T_scaled<T>(gUc, muEff_c, tau_c);
     T Dn_c = rho_c * (nc + nu_c) * (1.0 / SA_SIGMA);
     // energy (RHO)
-    T he_c = RHO ? prm.Cp * (Tc - DAS_TREF) : T(0.0);
-    T aEff_c = RHO ? prm.mu / prm.Pr + rho_c * nut_c * (1.0 / prm.Prt) : T(0.0);
+    T he_c = RHO ? prm.Cp * (Tc - DAS_TREF) : Tc;
+    // alphaEff: compressible mu/Pr + rho nut/Prt ; DASimpleFoam T field nu/Pr + nut/Prt (DAResidualSimpleFoam.C:226)
+    T aEff_c = RHO ? prm.mu / prm.Pr + rho_c * nut_c * (1.0 / prm.Prt) : prm.nu / prm.Pr + nut_c * (1.0 / prm.Prt);
     T K_c = RHO ? 0.5 * (Uc[0] * Uc[0] + Uc[1] * Uc[1] + Uc[2] * Uc[2]) : T(0.0);
 
     const bool turbo = RHO && prm.turbo;
@@ -376,8 +385,8 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             T Uo[3] = {W[3LL * o], W[3LL * o + 1], W[3LL * o + 2]};
             T nuT_o = W[prm.offN * N + o];
             T rho_o(1.0), nu_o(prm.nu), T_o(0.0);
+            if (energy) T_o = W[prm.offT * N + o];
             if (RHO) {
-                T_o = W[prm.offT * N + o];
                 rho_o = W[prm.offP * N + o] / (prm.Rgas * T_o);
                 nu_o = prm.mu / rho_o;
             }
@@ -445,9 +454,10 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                     + g.corr[2] * (wc * gNc[2] + wo * gradN[3LL * o + 2]);
             sN += sg * (gn * cvn);
             // ---- energy: div(phi,he) upwind + fvc::div(phi,K) upwind - laplacian(alphaEff, he)
-            if (RHO) {
-                T he_o = prm.Cp * (T_o - DAS_TREF);
-                T aEff_o = prm.mu / prm.Pr + rho_o * nut_o * (1.0 / prm.Prt);
+            //      (DASimpleFoam T field: div(phi,T) bounded upwind - laplacian(alphaEff, T), no K)
+            if (energy) {
+                T he_o = RHO ? prm.Cp * (T_o - DAS_TREF) : T_o;
+                T aEff_o = RHO ? prm.mu / prm.Pr + rho_o * nut_o * (1.0 / prm.Prt) : prm.nu / prm.Pr + nut_o * (1.0 / prm.Prt);
                 T ga = (wc * aEff_c + wo * aEff_o) * g.magSf;
                 T cde = ga * g.nod;
                 dE += dcoef + cde;
@@ -455,11 +465,13 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 T cve = g.corr[0] * (wc * gradH[3LL * c] + wo * gradH[3LL * o]) + g.corr[1] * (wc * gradH[3LL * c + 1] + wo * gradH[3LL * o + 1])
                         + g.corr[2] * (wc * gradH[3LL * c + 2] + wo * gradH[3LL * o + 2]);
                 sE += sg * (ga * cve);
-                T K_o = 0.5 * (Uo[0] * Uo[0] + Uo[1] * Uo[1] + Uo[2] * Uo[2]);
-                // upwind face value of K: owner value if flux >= 0
-                bool ownerIsC = !nb;
-                T Kf = ((pv >= 0.0) == ownerIsC) ? K_c : K_o;
-                sE -= (sg * phi) * Kf;
+                if (RHO) {
+                    T K_o = 0.5 * (Uo[0] * Uo[0] + Uo[1] * Uo[1] + Uo[2] * Uo[2]);
+                    // upwind face value of K: owner value if flux >= 0
+                    bool ownerIsC = !nb;
+                    T Kf = ((pv >= 0.0) == ownerIsC) ? K_c : K_o;
+                    sE -= (sg * phi) * Kf;
+                }
                 if (turbo) {
                     // - fvc::div(Teff.T() & U) (Gauss linear) and + fvc::div(p (U - URel)), U - URel = Omega x r
                     T qf = g.Sf[0] * (wc * TU[3LL * c] + wo * TU[3LL * o]) + g.Sf[1] * (wc * TU[3LL * c + 1] + wo * TU[3LL * o + 1])
@@ -518,12 +530,12 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             T gn_b = b.rho_b * (b.n.xb + b.nu_b) * (g.magSf / SA_SIGMA);
             bdN += phi * b.n.vic - gn_b * b.n.gic;
             bsN += gn_b * b.n.gbc - phi * b.n.vbc;
-            if (RHO) {
-                T ga_b = (prm.mu / prm.Pr + b.rho_b * b.nut_b * (1.0 / prm.Prt)) * g.magSf;
+            if (energy) {
+                T ga_b = (RHO ? prm.mu / prm.Pr + b.rho_b * b.nut_b * (1.0 / prm.Prt) : prm.nu / prm.Pr + b.nut_b * (1.0 / prm.Prt)) * g.magSf;
                 bdE += phi * b.he.vic - ga_b * b.he.gic;
                 bsE += ga_b * b.he.gbc - phi * b.he.vbc;
                 T Kb = 0.5 * (b.U.xb[0] * b.U.xb[0] + b.U.xb[1] * b.U.xb[1] + b.U.xb[2] * b.U.xb[2]);
-                sE -= phi * Kb;
+                if (RHO) sE -= phi * Kb;
                 if (turbo) {
                     T qb[3];
                     teff_dot_u<T>(gUb, muEff_b, b.U.xb, qb);
@@ -569,7 +581,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
         T H = ((avgb - bdiag[k]) * Uc[k] - offU[k] + sk + bsrc[k]) * rV;
         HbyA[3LL * c + k] = rA * H;
     }
-    if (RHO) {
+    if (energy) {
         dE -= sumPhi;
         T tres = ((dE + bdE) * he_c + offE - sE - bsE) * rV;
         if (!prm.normT) tres = tres * cgc.V;

@@ -358,7 +358,7 @@ def extract_submesh(case, part, rank, G=GHOST_LAYERS):
     nl = cell_g.size
     W = case.states
     solver = case.solver_name
-    nsc = {"DASimpleFoam": 2, "DARhoSimpleFoam": 3, "DATurboFoam": 3}[solver]
+    nsc = {"DASimpleFoam": 3 if getattr(case, "has_T", False) else 2, "DARhoSimpleFoam": 3, "DATurboFoam": 3}[solver]
     blocks_g = [np.repeat(3 * cell_g, 3) + np.tile(np.arange(3), nl)] + [(3 + b) * N + cell_g for b in range(nsc)] + [(3 + nsc) * N + face_g]
     key = np.concatenate(blocks_g)
     sgn = np.concatenate([np.ones(key.size - face_g.size), face_sign])

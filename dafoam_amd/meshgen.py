@@ -93,6 +93,9 @@ class FoamCase:
     transonic_pc_option: int = 1
     # system/fvSolution SIMPLE.consistent (SIMPLEC form of the DASimpleFoam pressure equation, DAResidualSimpleFoam.C:187-194)
     simple_consistent: bool = False
+    # DASimpleFoam with the optional passive T field (0/T present; Pr, Prt from transportProperties -> thermo["Pr"/"Prt"]):
+    # states [U | p | T | nuTilda | phi]
+    has_T: bool = False
 
 
 def hex_block(
@@ -303,7 +306,7 @@ def n_states(case: FoamCase) -> int:
     if case.solver_name == "DAScalarTransportFoam":
         return m.n_cells
     if case.solver_name == "DASimpleFoam":
-        return 5 * m.n_cells + m.n_faces
+        return (6 if case.has_T else 5) * m.n_cells + m.n_faces
     if case.solver_name in ("DARhoSimpleFoam", "DATurboFoam"):
         return 6 * m.n_cells + m.n_faces
     raise ValueError(case.solver_name)
@@ -546,6 +549,28 @@ def rho_channel_case(nx=7, ny=7, nz=7, lengths=(1.0, 0.2, 0.1), U0=50.0, p0=1013
     p = p0 + rho0 * pk
     T = T0 * (1.0 + 0.01 * np.sin(np.pi * g.C[:, 0] / lengths[0]) * np.cos(np.pi * g.C[:, 1] / lengths[1]))
     case.states = np.concatenate([U.ravel(), p, T, nuT, rho0 * phiv])
+    return case
+
+
+def simple_T_channel_case(nx=7, ny=7, nz=7, T0=300.0, **kw) -> FoamCase:
+    """DASimpleFoam + SA with the optional passive T field (reference DAResidualSimpleFoam.C:215-235): the incompressible
+    channel plus a smooth temperature field; fixedValue T at the inlet, inletOutlet at the outlet, hot bottom wall."""
+    case = channel_case(nx, ny, nz, **kw)
+    N, F = case.mesh.n_cells, case.mesh.n_faces
+    g = _InputGeometry(case.mesh)
+    lengths = kw.get("lengths", (1.0, 0.2, 0.1))
+    bcs = case.bcs
+    bcs["inlet"]["T"] = (BC_FIXED_VALUE, T0)
+    bcs["outlet"]["T"] = (BC_INLET_OUTLET, T0)
+    bcs["bottom"]["T"] = (BC_FIXED_VALUE, T0 + 20.0)
+    bcs["top"]["T"] = (BC_ZERO_GRADIENT, 0.0)
+    for nm in ("front", "back"):
+        bcs[nm]["T"] = (BC_SYMMETRY, 0.0) if bcs[nm]["U"][0] == BC_SYMMETRY else (BC_ZERO_GRADIENT, 0.0)
+    W = case.states
+    T = T0 * (1.0 + 0.02 * np.sin(np.pi * g.C[:, 0] / lengths[0]) * np.cos(np.pi * g.C[:, 1] / lengths[1]))
+    case.states = np.concatenate([W[: 4 * N], T, W[4 * N :]])
+    case.has_T = True
+    case.relax = dict(case.relax, T=1.0)
     return case
 
 

@@ -257,7 +257,8 @@ class pyDASolvers:
         (volVector, volScalar, model) followed by the phi of the faces it owns (DAIndex.C:602-651)."""
         m = self._case.mesh
         N, F = m.n_cells, m.n_faces
-        layout = {"DASimpleFoam": (1, 2), "DARhoSimpleFoam": (1, 3), "DATurboFoam": (1, 3), "DAScalarTransportFoam": (0, 1)}[self._case.solver_name]
+        layout = {"DASimpleFoam": (1, 3 if getattr(self._case, "has_T", False) else 2), "DARhoSimpleFoam": (1, 3), "DATurboFoam": (1, 3),
+                  "DAScalarTransportFoam": (0, 1)}[self._case.solver_name]
         nvec, nscl = layout
         has_phi = self._case.solver_name != "DAScalarTransportFoam"
         owned = [[] for _ in range(N)]
@@ -325,7 +326,7 @@ class pyDASolvers:
     def getNLocalAdjointBoundaryStates(self):
         m = self._case.mesh
         nb = m.n_faces - m.n_internal_faces
-        return {"DASimpleFoam": 5, "DARhoSimpleFoam": 6, "DATurboFoam": 6}.get(self._case.solver_name, 1) * nb
+        return {"DASimpleFoam": 6 if getattr(self._case, "has_T", False) else 5, "DARhoSimpleFoam": 6, "DATurboFoam": 6}.get(self._case.solver_name, 1) * nb
 
     def getNLocalCells(self):
         return int(lib().das_get_n_local_cells(self._h))

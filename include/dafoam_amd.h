@@ -100,6 +100,9 @@ typedef struct das_case {
     /* DATurboFoam: system/fvSolution SIMPLE.transonic and the reference option transonicPCOption (-1/0: keep
      * div(phid,p) in the PC, 1: drop it, 2: additionally phiRes = phi) */
     int transonic, transonic_pc_option;
+    /* DASimpleFoam with the optional passive T field (reference DAResidualSimpleFoam.C:50-76,215-235; states
+     * [U | p | T | nuTilda | phi], DAStateInfoSimpleFoam.C:118-131); Pr / Prt above are then transportProperties' */
+    int simple_has_T;
 } das_case_t;
 
 const char* das_last_error(void);

@@ -40,6 +40,16 @@ STENCIL = {
         "phiRes": [["U", "p", "nuTilda", "phi"], ["U", "p", "nuTilda"], ["U"]],
         "nuTildaRes": [["U", "nuTilda", "phi"], ["U", "nuTilda"], ["nuTilda"]],
     },
+    # DASimpleFoam with the optional T field (DAStateInfoSimpleFoam.C:118-131).  TRes additionally lists U at level 0: the
+    # boundary alphat = nut_b/Prt of a wall-function face depends on the cell velocity (the reference's table omits it).
+    "DASimpleFoam+T": {
+        "states": [("U", "vec"), ("p", "scl"), ("T", "scl"), ("nuTilda", "scl"), ("phi", "face")],
+        "URes": [["U", "p", "nuTilda", "phi"], ["U", "p", "nuTilda"], ["U"]],
+        "pRes": [["U", "p", "nuTilda", "phi"], ["U", "p", "nuTilda", "phi"], ["U", "p", "nuTilda"], ["U"]],
+        "TRes": [["U", "T", "nuTilda", "phi"], ["T", "nuTilda"], ["T"]],
+        "phiRes": [["U", "p", "nuTilda", "phi"], ["U", "p", "nuTilda"], ["U"]],
+        "nuTildaRes": [["U", "nuTilda", "phi"], ["U", "nuTilda"], ["nuTilda"]],
+    },
     # DAStateInfoRhoSimpleFoam.C:40-47,79-116 + compressible SA (DASpalartAllmaras.C:364-383)
     "DARhoSimpleFoam": {
         "states": [("U", "vec"), ("p", "scl"), ("T", "scl"), ("nuTilda", "scl"), ("phi", "face")],
@@ -66,6 +76,10 @@ STENCIL = {
 MAX_RES_CON_LV_PC = {"pRes": 2, "phiRes": 1, "URes": 2, "TRes": 2, "nuTildaRes": 2}
 
 
+def stencil_name(case):
+    return "DASimpleFoam+T" if (case.solver_name == "DASimpleFoam" and getattr(case, "has_T", False)) else case.solver_name
+
+
 def state_layout(solver, N, F):
     """DAIndex 'state' ordering offsets (reference DAIndex.C:188-258)."""
     off = {}
@@ -82,9 +96,9 @@ def state_scales(case, g, normalize_states):
     """s_j of SURVEY Appendix C: normalizeStates[name] for cell states, |S_f| for phi
     (reference DAPartDeriv.C:210-315)."""
     N, F = g.nC, g.nF
-    off, size, n = state_layout(case.solver_name, N, F)
+    off, size, n = state_layout(stencil_name(case), N, F)
     s = np.ones(n)
-    for name, kind in STENCIL[case.solver_name]["states"]:
+    for name, kind in STENCIL[stencil_name(case)]["states"]:
         if name in normalize_states:
             if kind == "face":
                 s[off[name] : off[name] + size[name]] = g.magSf
@@ -95,7 +109,7 @@ def state_scales(case, g, normalize_states):
 
 def connectivity(case, g, isPC=False):
     """dRdWCon as scipy CSR (rows = residuals, cols = states), values 1."""
-    solver = case.solver_name
+    solver = stencil_name(case)
     N, F, nIF = g.nC, g.nF, g.nIF
     tbl = STENCIL[solver]
     C = g.cellCells.astype(np.int32)

@@ -247,12 +247,14 @@ def relax_diag(D0, sumOff, iC_b, bcell, alpha, nC):
 def unpack_simple(W, N, F):
     U = W[: 3 * N].reshape(N, 3)
     p = W[3 * N : 4 * N]
+    if W.size == 6 * N + F:  # with the optional T field: [U | p | T | nuTilda | phi] (DAStateInfoSimpleFoam.C:118-131)
+        return U, p, W[5 * N : 6 * N], W[6 * N : 6 * N + F]
     nuT = W[4 * N : 5 * N]
     phi = W[5 * N : 5 * N + F]
     return U, p, nuT, phi
 
 
-def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "nuTildaRes", "phiRes"),
+def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "nuTildaRes", "phiRes"),
                     use_constrain_hbya=True, return_parts=False):
     """R(W) for DASimpleFoam + Spalart-Allmaras in DAIndex 'state' ordering:
     [URes (3N, xyz interleaved) | pRes (N) | nuTildaRes (N) | phiRes (F, internal then boundary)]."""
@@ -460,6 +462,35 @@ def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "nuTildaR
     )
     # (relax() leaves M & psi unchanged)
 
+    # =================================================================== optional T field (DAResidualSimpleFoam.C:215-235)
+    # TEqn = div(phi,T) - laplacian(alphaEff,T), alphaEff = nu/Pr + alphat, alphat = nut/Prt; bounded Gauss upwind /
+    # Gauss linear corrected.  T is a passive scalar: no other residual depends on it.
+    TRes = None
+    if getattr(case, "has_T", False):
+        Tt = W[4 * N : 5 * N]
+        Pr, Prt = case.thermo["Pr"], case.thermo["Prt"]
+        btT = BCTable(case, g, ("T",))
+        Tb, TvIC, TvBC, TgIC, TgBC = bc_scalar(btT.code["T"], btT.val["T"], Tt[bcell], delta, phi_b)
+        gradT = ops.grad_scalar(Tt, Tb)
+        aEff = nu / Pr + nut / Prt
+        aEff_b = nu / Pr + nut_b / Prt
+        loT = -wu * phi_i
+        upT = loT + phi_i
+        dT = sadd(oi, -loT, N) + sadd(ni, -upT, N) - sumPhi
+        ga = ops.interp(aEff) * g.magSf[:nIF]
+        ga_b = aEff_b * g.bMagSf
+        cdT = ga * g.nonOrthDeltaCoeffs
+        upT, loT = upT - cdT, loT - cdT
+        dT = dT + sadd(oi, cdT, N) + sadd(ni, cdT, N)
+        fcT = ga * (g.nonOrthCorr * ops.interp(gradT)).sum(1)
+        sT = sadd(oi, fcT, N) - sadd(ni, fcT, N)
+        iCt = phi_b * TvIC - ga_b * TgIC
+        bCt = -phi_b * TvBC + ga_b * TgBC
+        offT = sadd(oi, upT * Tt[ni], N) + sadd(ni, loT * Tt[oi], N)
+        TRes = ((dT + sadd(bcell, iCt, N)) * Tt + offT - sT - sadd(bcell, bCt, N)) / V
+        if "TRes" not in normalize:
+            TRes = TRes * V
+
     # ---- normalisation macros (DAMacroFunctions.H:28-51)
     if "URes" not in normalize:
         URes = URes * V[:, None]
@@ -469,7 +500,7 @@ def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "nuTildaR
         nuTildaRes = nuTildaRes * V
     if "phiRes" in normalize:
         phiRes = phiRes / g.magSf
-    R = np.concatenate([URes.ravel(), pRes, nuTildaRes, phiRes])
+    R = np.concatenate([URes.ravel(), pRes, nuTildaRes, phiRes] if TRes is None else [URes.ravel(), pRes, TRes, nuTildaRes, phiRes])
     if return_parts:
         parts = dict(
             Ub=Ub, pb=pb, nuTildab=nb, nut=nut, nut_b=nut_b, gradU=gradU, gradP=gradP, gradN=gradN,

@@ -10,10 +10,10 @@ static void eval(const Mesh& mesh, const CaseParams& cp, const ResParams& prm, c
     DevMesh m = host_view(mesh);
     const long long N = m.nC;
     if (cp.solver == DAS_SOLVER_SIMPLEFOAM) {
-        std::vector<T> nut(N), gU(9 * N), gP(3 * N), gN(3 * N), rAU(N), HbyA(3 * N), q(m.nF);
-        for (int c = 0; c < m.nC; c++) body_grad<T, false>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), (T*)nullptr);
+        std::vector<T> nut(N), gU(9 * N), gP(3 * N), gN(3 * N), gH(3 * N), rAU(N), HbyA(3 * N), q(m.nF);
+        for (int c = 0; c < m.nC; c++) body_grad<T, false>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), gH.data());
         for (int c = 0; c < m.nC; c++)
-            body_cell<T, false>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), (const T*)nullptr, R.data(), rAU.data(), HbyA.data());
+            body_cell<T, false>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), gH.data(), R.data(), rAU.data(), HbyA.data());
         for (int f = 0; f < m.nF; f++) body_face<T, false>(f, m, prm, W.data(), nut.data(), gP.data(), rAU.data(), HbyA.data(), q.data(), R.data());
         for (int c = 0; c < m.nC; c++) body_pres<T, false>(c, m, prm, q.data(), R.data());
     } else if (DAS_IS_COMPRESSIBLE(cp.solver)) {

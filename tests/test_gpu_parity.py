@@ -8,7 +8,8 @@ import pytest
 import scipy.sparse.linalg as spla
 
 from common import NORM_STATES, blocks, norm_states, options, relerr
-from dafoam_amd.meshgen import bench_channel_case, channel_case, renumber_case, rho_channel_case, scalar_transport_case, turbo_channel_case
+from dafoam_amd.meshgen import (bench_channel_case, channel_case, renumber_case, rho_channel_case, scalar_transport_case, simple_T_channel_case,
+                                turbo_channel_case)
 from oracle import jacobian as J
 from oracle import linear as OL
 from oracle.foam_mesh import Geometry
@@ -132,7 +133,7 @@ def test_rhosimplefoam_residual_jacobian_adjoint(wall_function):
     assert fail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-6
 
 
-@pytest.mark.parametrize("variant", ["simple_mrf", "rho_mrf", "turbo", "turbo_transonic"])
+@pytest.mark.parametrize("variant", ["simple_mrf", "simple_T", "rho_mrf", "turbo", "turbo_transonic"])
 def test_turbofoam_and_mrf_residual_jacobian_adjoint(variant):
     """DATurboFoam (BASELINE configs[4] solver: SIMPLEC-consistent or transonic pEqn, "h" energy with viscous and MRF
     pressure work, MRF Coriolis / relative flux / rotating walls) and DARhoSimpleFoam with MRF: residual (PC and non-PC),
@@ -144,6 +145,8 @@ def test_turbofoam_and_mrf_residual_jacobian_adjoint(variant):
         case = channel_case(8, 6, 5, wall_function=True, lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.02)
         case.mrf = {"omega": (20.0, 0.0, 0.0), "origin": (0.0, -0.3, 0.0), "nonRotatingPatches": ["inlet", "outlet", "top"]}
         case.simple_consistent = True
+    elif variant == "simple_T":  # DASimpleFoam with the optional passive T field (DAResidualSimpleFoam.C:215-235)
+        case = simple_T_channel_case(8, 6, 5, wall_function=True, lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.02)
     else:
         kw = {"rho_mrf": dict(solver_name="DARhoSimpleFoam"), "turbo": {}, "turbo_transonic": dict(transonic=True)}[variant]
         case = turbo_channel_case(8, 6, 5, wall_function=True, lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.02, **kw)

@@ -11,7 +11,7 @@ import pytest
 from common import NORM_STATES, NORM_STATES_RHO, blocks, options, relerr
 from dafoam_amd import _capi
 from dafoam_amd._capi import CaseStruct, das_case_t, dptr
-from dafoam_amd.meshgen import channel_case, renumber_case, rho_channel_case, scalar_transport_case, turbo_channel_case
+from dafoam_amd.meshgen import channel_case, renumber_case, rho_channel_case, scalar_transport_case, simple_T_channel_case, turbo_channel_case
 from dafoam_amd.pyDASolvers import pyDASolvers
 from oracle import jacobian as J
 from oracle.foam_mesh import Geometry
@@ -324,6 +324,41 @@ def test_kernel_bodies_match_oracle_turbofoam_and_mrf(variant, isPC):
     _, Rd = _emu_res(case, W, isPC, v)
     for nm, sl in blocks(case, g):
         assert relerr(Rd[sl], cs[sl]) < 1e-10, nm
+
+
+@pytest.mark.parametrize("isPC", [0, 1])
+def test_simplefoam_with_T_field(isPC):
+    """DASimpleFoam with the optional passive T field (DAResidualSimpleFoam.C:215-235, states [U|p|T|nuTilda|phi]):
+    kernel bodies vs oracle (values, dual tangents), connectivity and colouring of the 5-block layout."""
+    from common import norm_states
+
+    case = simple_T_channel_case(6, 5, 4, wall_function=True, perturb=0.02)
+    g = Geometry(case.mesh)
+    W = case.states
+    assert W.size == 6 * g.nC + g.nF
+    Ro = residual(case, g, W, isPC=bool(isPC))
+    Rv, _ = _emu_res(case, W, isPC)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rv[sl], Ro[sl]) < 1e-12, nm
+    v = np.random.default_rng(3).standard_normal(W.size) * J.state_scales(case, g, norm_states(case))
+    cs = residual(case, g, W + 1j * 1e-30 * v, isPC=bool(isPC)).imag / 1e-30
+    _, Rd = _emu_res(case, W, isPC, v)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rd[sl], cs[sl]) < 1e-10, nm
+    # the other residuals do not see T (passive scalar)
+    W2 = W.copy()
+    W2[4 * g.nC : 5 * g.nC] *= 1.01
+    R2 = residual(case, g, W2, isPC=bool(isPC))
+    b = dict(blocks(case, g))
+    assert np.array_equal(R2[b["U"]], Ro[b["U"]]) and np.array_equal(R2[b["p"]], Ro[b["p"]]) and relerr(R2[b["T"]], Ro[b["T"]]) > 1e-6
+    if not isPC:
+        s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+        assert s.getNLocalAdjointStates() == W.size
+        s.runColoring()
+        for pc in (0, 1):
+            assert (s.getConnectivity(pc) != J.connectivity(case, g, isPC=bool(pc))).nnz == 0
+        col, _ = s.getColoring()
+        assert J.validate_coloring(J.connectivity(case, g), col.astype(np.int64))
 
 
 def test_simplefoam_mrf_and_simplec():
