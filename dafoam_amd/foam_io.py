@@ -313,3 +313,46 @@ def write_case(case_dir, case: FoamCase, time="0"):
     with open(os.path.join(tdir, "phi"), "w") as f:
         f.write(_HEADER.format(cls="surfaceScalarField", loc=time, obj="phi"))
         f.write(f"dimensions      [0 3 -1 0 0 0 0];\n\ninternalField   nonuniform List<scalar>\n{nIF}\n(\n" + "\n".join("%.17g" % v for v in W[5 * N : 5 * N + nIF]) + "\n)\n;\n")
+
+
+def write_adjoint_fields(case_dir, case: FoamCase, function, write_time, psi, state_blocks):
+    """DASolver::writeAdjointFields (reference DASolver.C:4055-4160): the adjoint vector as OpenFOAM fields
+    `adjoint_<function>_<state>` in <case_dir>/<write_time>/ (cell states: the state's patch types with zero-gradient
+    values, i.e. calculated from the cell values; phi: surfaceScalarField with its boundary values).
+    state_blocks: [(name, "vec"|"scl"|"face", offset, size)] in "state" ordering."""
+    mesh = case.mesh
+    N, nIF = mesh.n_cells, mesh.n_internal_faces
+    time = ("%g" % write_time) if not isinstance(write_time, str) else write_time
+    tdir = os.path.join(case_dir, time)
+    os.makedirs(tdir, exist_ok=True)
+    written = []
+    for name, kind, off, size in state_blocks:
+        var = f"adjoint_{function}_{name}"
+        blk = np.asarray(psi[off : off + size], dtype=np.float64)
+        with open(os.path.join(tdir, var), "w") as f:
+            if kind == "face":
+                f.write(_HEADER.format(cls="surfaceScalarField", loc=time, obj=var))
+                f.write("dimensions      [0 0 0 0 0 0 0];\n\n")
+                f.write(f"internalField   nonuniform List<scalar>\n{nIF}\n(\n" + "\n".join("%.17g" % v for v in blk[:nIF]) + "\n)\n;\n\n")
+                f.write("boundaryField\n{\n")
+                for pt in mesh.patches:
+                    vals = blk[pt.start : pt.start + pt.size]
+                    f.write(f"    {pt.name}\n    {{\n        type            calculated;\n        value           nonuniform List<scalar>\n{pt.size}\n(\n"
+                            + "\n".join("%.17g" % v for v in vals) + "\n)\n;\n    }\n")
+                f.write("}\n")
+            else:
+                vec = kind == "vec"
+                f.write(_HEADER.format(cls="volVectorField" if vec else "volScalarField", loc=time, obj=var))
+                f.write("dimensions      [0 0 0 0 0 0 0];\n\n")
+                if vec:
+                    rows = "\n".join("(%.17g %.17g %.17g)" % tuple(v) for v in blk.reshape(N, 3))
+                    f.write(f"internalField   nonuniform List<vector>\n{N}\n(\n{rows}\n)\n;\n\n")
+                else:
+                    f.write(f"internalField   nonuniform List<scalar>\n{N}\n(\n" + "\n".join("%.17g" % v for v in blk) + "\n)\n;\n\n")
+                f.write("boundaryField\n{\n")
+                for pt in mesh.patches:
+                    ptype = "symmetry" if pt.type == "symmetry" else "zeroGradient"
+                    f.write(f"    {pt.name}\n    {{\n        type            {ptype};\n    }}\n")
+                f.write("}\n")
+        written.append(os.path.join(tdir, var))
+    return written

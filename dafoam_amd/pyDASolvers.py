@@ -603,6 +603,58 @@ class pyDASolvers:
         return rc
 
     # -- timing ----------------------------------------------------------------------------------
+    def _state_blocks(self):
+        """[(name, kind, offset, size)] of the DAIndex "state" ordering (reference DAIndex.C:188-258)."""
+        m = self._case.mesh
+        N, F = m.n_cells, m.n_faces
+        names = {"DASimpleFoam": ["U", "p"] + (["T"] if getattr(self._case, "has_T", False) else []) + ["nuTilda", "phi"],
+                 "DARhoSimpleFoam": ["U", "p", "T", "nuTilda", "phi"], "DATurboFoam": ["U", "p", "T", "nuTilda", "phi"],
+                 "DAScalarTransportFoam": ["T"]}[self._case.solver_name]
+        out, off = [], 0
+        for nm in names:
+            kind = "vec" if nm == "U" else ("face" if nm == "phi" else "scl")
+            size = {"vec": 3 * N, "scl": N, "face": F}[kind]
+            out.append((nm, kind, off, size))
+            off += size
+        return out
+
+    def calcPrimalResidualStatistics(self, mode, writeRes=0):
+        """DASolver::calcPrimalResidualStatistics (reference DASolver.C:745-946): norm2 / mean / max of every residual
+        block at the current states; printed for mode "print", only computed for "calc".  Returns the numbers (the
+        reference keeps them internal): {resName: {"norm2", "mean", "max"}, "totalResNorm2": ...}."""
+        if mode not in ("print", "calc"):
+            raise _capi.DASError("mode not valid")
+        n = self.getNLocalAdjointStates()
+        R = np.zeros(n)
+        check(lib().das_get_residuals(self._h, dptr(R)))
+        stats, tot = {}, 0.0
+        if mode == "print":
+            print("Printing Primal Residual Statistics.")
+        for nm, kind, off, size in self._state_blocks():
+            blk = R[off : off + size]
+            if kind == "vec":
+                blk = blk.reshape(-1, 3)
+                st = {"norm2": np.sqrt((blk * blk).sum(0)), "mean": np.abs(blk).mean(0), "max": np.abs(blk).max(0)}
+            else:
+                st = {"norm2": float(np.sqrt((blk * blk).sum())), "mean": float(np.abs(blk).mean()), "max": float(np.abs(blk).max())}
+            tot += float((blk * blk).sum())
+            stats[nm + "Res"] = st
+            if mode == "print":
+                print(f"{nm} Residual Norm2: {st['norm2']}\n{nm} Residual Mean: {st['mean']}\n{nm} Residual Max: {st['max']}")
+        stats["totalResNorm2"] = float(np.sqrt(tot))
+        if mode == "print":
+            print(f"Total Residual Norm2: {stats['totalResNorm2']}")
+        return stats
+
+    def writeAdjointFields(self, function, writeTime, psi, caseDir="."):
+        """DASolver::writeAdjointFields (reference DASolver.C:4055-4160, pyDASolvers.pyx:470): psi as OpenFOAM fields
+        adjoint_<function>_<state> under <caseDir>/<writeTime>/ (the reference writes into its case directory)."""
+        from . import foam_io
+
+        assert len(psi) == self.getNLocalAdjointStates(), "invalid array size!"
+        psi_s = np.ascontiguousarray(self._to_state(np.asarray(psi, dtype=np.float64)))
+        return foam_io.write_adjoint_fields(caseDir, self._case, function, writeTime, psi_s, self._state_blocks())
+
     def getElapsedClockTime(self):
         return lib().das_get_elapsed_clock_time(self._h)
 

@@ -277,6 +277,13 @@ def test_normalize_residuals_option():
     D.solver.getResiduals(R)
     Ro = residual(case, g, case.states, normalize=("URes", "nuTildaRes"))
     assert relerr(R, Ro) < 1e-12
+    # calcPrimalResidualStatistics (reference DASolver.C:745-946): per-state norm2 / mean / max of the same residuals
+    st = D.solver.calcPrimalResidualStatistics("calc")
+    b = dict(blocks(case, g))
+    assert np.allclose(st["URes"]["norm2"], np.sqrt((Ro[b["U"]].reshape(-1, 3) ** 2).sum(0)), rtol=1e-11)
+    assert abs(st["pRes"]["max"] - np.abs(Ro[b["p"]]).max()) <= 1e-11 * np.abs(Ro[b["p"]]).max()
+    assert abs(st["phiRes"]["mean"] - np.abs(Ro[b["phi"]]).mean()) <= 1e-11 * np.abs(Ro[b["phi"]]).mean()
+    assert abs(st["totalResNorm2"] - np.linalg.norm(Ro)) <= 1e-11 * np.linalg.norm(Ro)
 
 
 @pytest.mark.parametrize("solver", ["DASimpleFoam", "DAScalarTransportFoam"])

@@ -258,6 +258,28 @@ def test_degenerate_meshes(dims):
         assert nc == W.size
 
 
+def test_write_adjoint_fields(tmp_path):
+    """writeAdjointFields (reference DASolver.C:4055-4160): psi as adjoint_<function>_<state> OpenFOAM fields, read back."""
+    from dafoam_amd import foam_io
+
+    case = channel_case(5, 4, 3, wall_function=True)
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    n = s.getNLocalAdjointStates()
+    N, F = case.mesh.n_cells, case.mesh.n_faces
+    psi = np.random.default_rng(0).standard_normal(n)
+    files = s.writeAdjointFields("CD", 100, psi, caseDir=str(tmp_path))
+    assert sorted(os.path.basename(f) for f in files) == ["adjoint_CD_U", "adjoint_CD_nuTilda", "adjoint_CD_p", "adjoint_CD_phi"]
+    U, _ = foam_io.read_field(str(tmp_path / "100" / "adjoint_CD_U"), N, 3)
+    p, _ = foam_io.read_field(str(tmp_path / "100" / "adjoint_CD_p"), N, 1)
+    assert np.array_equal(U.ravel(), psi[: 3 * N]) and np.array_equal(p, psi[3 * N : 4 * N])
+    txt = open(tmp_path / "100" / "adjoint_CD_phi").read()
+    assert "surfaceScalarField" in txt and f"\n{case.mesh.n_internal_faces}\n" in txt
+    with pytest.raises(AssertionError):
+        s.writeAdjointFields("CD", 100, psi[:-1], caseDir=str(tmp_path))
+    with pytest.raises(_capi.DASError, match="mode not valid"):
+        s.calcPrimalResidualStatistics("bogus")
+
+
 def test_petsc_binary_io_roundtrip_and_layout(tmp_path):
     """PETSc binary Vec/Mat (big-endian, classids 1211214 / 1211216 - SURVEY.md Appendix D)."""
     import scipy.sparse as sp
