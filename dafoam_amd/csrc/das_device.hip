@@ -721,7 +721,11 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
         }
         s->nColors = mx + 1;
     } else {
-        s->nColors = d2_coloring(s->con_full, s->colors);
+        {
+            std::vector<double> ctr(3 * (size_t)s->mesh.nC);
+            for (int c = 0; c < s->mesh.nC; c++) for (int d = 0; d < 3; d++) ctr[3 * (size_t)c + d] = s->mesh.cg[c].C[d];
+            s->nColors = d2_coloring(s->con_full, s->colors, ctr.data());
+        }
     }
     double t3 = wall_seconds();
     DAS_CHECK(validate_coloring(s->con_full, s->colors), DAS_ERR_INTERNAL, "Conflicting Colors Found!");

@@ -269,7 +269,7 @@ static bool is_subset(const int* a, long long na, const int* b, long long nb) {
     return i == na;
 }
 
-int d2_coloring(const JacCon& con, std::vector<int>& colors) {
+int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres) {
     const long long n = con.n;
     colors.assign(n, -1);
     // dominance pruning: a row that is a subset of the longest row anchored at the same cell adds no
@@ -326,9 +326,10 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors) {
     const int nth = std::max(1, omp_get_max_threads());
     // Columns are grouped by the cell they live in (anchor) and the cell range is cut into spatially contiguous
     // chunks, so concurrent threads only interact near chunk boundaries (few conflicts, near-serial colour count).
-    // Opt-in (DAS_PARALLEL_COLORING=1): ~3.5x faster for ~11 % more colours (451-457 vs 410 at 200k cells), but the
-    // colour labels depend on thread timing (the Jacobians do not: columns of one colour never share a row).  The
-    // default stays the deterministic serial first-fit; repeated runs use the dRdWColoring cache instead.
+    // DAS_PARALLEL_COLORING=1 selects this speculative variant: ~3.5x faster than serial for ~11 % more colours (451-457
+    // vs 410 at 200k cells), but the colour labels depend on thread timing (the Jacobians do not: columns of one colour
+    // never share a row).  =0 forces the serial first-fit.  Default: serial below 20k cells, the deterministic
+    // tile-parallel variant (further down) above.
     const char* pc_env = getenv("DAS_PARALLEL_COLORING");
     const bool par = nth > 1 && pc_env && pc_env[0] == '1';
     if (par) {
@@ -371,6 +372,95 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors) {
             std::vector<long long> forb(4096, -1);
             for (long long j : redo) color_column(j, forb, j);
         }
+    } else if (centres && nAnch >= 20000 && nth > 1 && !(pc_env && pc_env[0] == '0')) {
+        // Deterministic tile-parallel first-fit.  The anchor cells are cut into compact tiles (recursive coordinate
+        // bisection); two tiles are adjacent if some kept row holds columns of both, i.e. if their columns can conflict;
+        // the tile graph is coloured greedily into phases and the tiles of one phase are first-fit coloured
+        // concurrently.  A column only ever looks at columns of its own or of adjacent tiles, and adjacent tiles are
+        // never in the same phase - so there is no race and the result does not depend on the number of threads.
+        const long long tileCells = std::max<long long>(2048, (nAnch + 4095) / 4096);
+        std::vector<int> tileOf(nAnch, 0);
+        int nT = 0;
+        {
+            std::vector<int> idx(nAnch);
+            std::iota(idx.begin(), idx.end(), 0);
+            struct Rg { long long b, e; };
+            std::vector<Rg> stack{{0, nAnch}};
+            while (!stack.empty()) {
+                Rg r = stack.back();
+                stack.pop_back();
+                if (r.e - r.b <= tileCells) {
+                    for (long long q = r.b; q < r.e; q++) tileOf[idx[q]] = nT;
+                    nT++;
+                    continue;
+                }
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                for (long long q = r.b; q < r.e; q++)
+                    for (int d = 0; d < 3; d++) { double x = centres[3LL * idx[q] + d]; lo[d] = std::min(lo[d], x); hi[d] = std::max(hi[d], x); }
+                int ax = 0;
+                for (int d = 1; d < 3; d++) if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+                const long long mid = (r.b + r.e) / 2;
+                std::nth_element(idx.begin() + r.b, idx.begin() + mid, idx.begin() + r.e, [&](int a, int b2) {
+                    const double xa = centres[3LL * a + ax], xb = centres[3LL * b2 + ax];
+                    return xa < xb || (xa == xb && a < b2);
+                });
+                stack.push_back({mid, r.e});
+                stack.push_back({r.b, mid});
+            }
+        }
+        // tile adjacency from the kept rows (bit matrix, OR-merged over threads)
+        const size_t words = ((size_t)nT * nT + 63) / 64;
+        std::vector<unsigned long long> adjBits(words, 0ULL);
+#pragma omp parallel
+        {
+            std::vector<unsigned long long> mine(words, 0ULL);
+            std::vector<int> tiles;
+#pragma omp for schedule(dynamic, 1024)
+            for (long long q = 0; q < (long long)keep.size(); q++) {
+                const long long r = keep[q];
+                tiles.clear();
+                for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) {
+                    const int t = tileOf[con.anchor[con.col[k]]];
+                    if (std::find(tiles.begin(), tiles.end(), t) == tiles.end()) tiles.push_back(t);
+                }
+                for (size_t a = 0; a < tiles.size(); a++)
+                    for (size_t b2 = 0; b2 < tiles.size(); b2++) {
+                        const size_t bit = (size_t)tiles[a] * nT + tiles[b2];
+                        mine[bit >> 6] |= 1ULL << (bit & 63);
+                    }
+            }
+#pragma omp critical
+            for (size_t w = 0; w < words; w++) adjBits[w] |= mine[w];
+        }
+        auto adjacent = [&](int a, int b2) { const size_t bit = (size_t)a * nT + b2; return (adjBits[bit >> 6] >> (bit & 63)) & 1ULL; };
+        std::vector<int> phase(nT, -1);
+        int nPh = 0;
+        {
+            std::vector<int> used;
+            for (int t = 0; t < nT; t++) {
+                used.assign(nPh + 1, 0);
+                for (int u = 0; u < t; u++) if (adjacent(t, u)) used[phase[u]] = 1;
+                int p = 0;
+                while (used[p]) p++;
+                phase[t] = p;
+                nPh = std::max(nPh, p + 1);
+            }
+        }
+        std::vector<std::vector<long long>> tileCols(nT);
+        for (long long j = 0; j < n; j++) tileCols[tileOf[con.anchor[j]]].push_back(j);
+        std::vector<std::vector<int>> phaseTiles(nPh);
+        for (int t = 0; t < nT; t++) phaseTiles[phase[t]].push_back(t);
+        for (int ph = 0; ph < nPh; ph++) {
+            const std::vector<int>& tl = phaseTiles[ph];
+#pragma omp parallel
+            {
+                std::vector<long long> forb(4096, -1);
+#pragma omp for schedule(dynamic, 1)
+                for (long long ti = 0; ti < (long long)tl.size(); ti++)
+                    for (long long j : tileCols[tl[ti]]) color_column(j, forb, j);
+            }
+        }
+        if (getenv("DAS_DEBUG_TIMING")) fprintf(stderr, "[dafoam_amd]   colouring: %d tiles of <= %lld cells, %d phases\n", nT, tileCells, nPh);
     } else {
         // serial first-fit.  Consecutive columns with the same kept-row list (the xyz components of a cell's U) see the
         // same neighbourhood: its forbidden set is gathered once and extended by the colours just handed out - the

@@ -58,7 +58,8 @@ struct JacCon {
 
 // distance-2 (column) colouring of `con`: greedy first-fit over the non-dominated rows.
 // Returns number of colours.  Validity rule = reference DAColoring.C:931-1037.
-int d2_coloring(const JacCon& con, std::vector<int>& colors);
+// `centres` (3 per anchor cell, optional) enables the deterministic tile-parallel variant on large meshes.
+int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres = nullptr);
 bool validate_coloring(const JacCon& con, const std::vector<int>& colors);
 
 }  // namespace das
