@@ -272,6 +272,9 @@ static bool is_subset(const int* a, long long na, const int* b, long long nb) {
 int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres) {
     const long long n = con.n;
     colors.assign(n, -1);
+    const bool dbgT = getenv("DAS_DEBUG_TIMING") != nullptr;
+    double tq = wall_seconds();
+    auto lap = [&](const char* what) { if (dbgT) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]   colouring: %s %.2f s\n", what, t2 - tq); tq = t2; } };
     // dominance pruning: a row that is a subset of the longest row anchored at the same cell adds no
     // colouring constraint (for the reference's tables every row of a cell / owned face is a subset
     // of that cell's pRes row).  Generic: the subset test decides, no solver-specific assumption.
@@ -292,25 +295,46 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         if (d != r && is_subset(&con.col[con.rowptr[r]], len, &con.col[con.rowptr[d]], con.rowptr[d + 1] - con.rowptr[d])) continue;
         keep.push_back(r);
     }
-    // CSC over kept rows
+    lap("prune");
+    // CSC over kept rows: stable chunked counting (like JacCon::build_transpose_and_maps), int row ids, no zero-fill
     std::vector<long long> cptr(n + 1, 0);
-    for (long long r : keep)
-        for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) cptr[con.col[k] + 1]++;
-    for (long long j = 0; j < n; j++) cptr[j + 1] += cptr[j];
-    std::vector<long long> crow(cptr[n]);
+    uvector<int> crow;
     {
-        std::vector<long long> pos(cptr.begin(), cptr.end() - 1);
-        for (long long r : keep)
-            for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) crow[pos[con.col[k]]++] = r;
+        const long long nk = (long long)keep.size();
+        const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 16LL, nk}));
+        std::vector<long long> q0(T + 1);
+        for (int t = 0; t <= T; t++) q0[t] = nk * t / T;
+        std::vector<std::vector<int>> cnt(T);
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+        for (int t = 0; t < T; t++) {
+            cnt[t].assign(n, 0);
+            for (long long q = q0[t]; q < q0[t + 1]; q++)
+                for (long long k = con.rowptr[keep[q]]; k < con.rowptr[keep[q] + 1]; k++) cnt[t][con.col[k]]++;
+        }
+        for (long long j = 0; j < n; j++) {
+            long long tot = 0;
+            for (int t = 0; t < T; t++) tot += cnt[t][j];
+            cptr[j + 1] = cptr[j] + tot;
+        }
+#pragma omp parallel for schedule(static)
+        for (long long j = 0; j < n; j++) {
+            int acc = 0;
+            for (int t = 0; t < T; t++) { int c = cnt[t][j]; cnt[t][j] = acc; acc += c; }
+        }
+        crow.resize(cptr[n]);
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+        for (int t = 0; t < T; t++) {
+            std::vector<int>& pos = cnt[t];
+            for (long long q = q0[t]; q < q0[t + 1]; q++) {
+                const long long r = keep[q];
+                for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) { const int j = con.col[k]; crow[cptr[j] + pos[j]++] = (int)r; }
+            }
+        }
     }
-    // speculative parallel greedy (Gebremedhin-Manne), opt-in: chunks of columns are first-fit coloured concurrently
-    // against a shared (racy) colour array, then conflicts (two columns of one kept row with the same colour) are
-    // detected in parallel, the higher-index column of each conflict is un-coloured and the (few) leftovers are coloured
-    // serially.  (A deterministic variant in which chunks ignore each other was measured: with a 3-ring stencil almost
-    // every column of a 200k-cell mesh lies near a chunk boundary and the serial fix-up costs more than it saves.)
+    // first-fit colour of column j: the smallest colour not used by any column sharing a kept row with j
     auto color_column = [&](long long j, std::vector<long long>& forb, long long stamp) {
         for (long long q = cptr[j]; q < cptr[j + 1]; q++) {
-            long long r = crow[q];
+            const long long r = crow[q];
             for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) {
                 int c = colors[con.col[k]];
                 if (c >= 0) {
@@ -323,6 +347,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         while ((size_t)c < forb.size() && forb[c] == stamp) c++;
         colors[j] = c;
     };
+    lap("csc");
     const int nth = std::max(1, omp_get_max_threads());
     // Columns are grouped by the cell they live in (anchor) and the cell range is cut into spatially contiguous
     // chunks, so concurrent threads only interact near chunk boundaries (few conflicts, near-serial colour count).
@@ -483,6 +508,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
             j = g;
         }
     }
+    lap("greedy");
     int ncol = 0;
     for (long long j = 0; j < n; j++) ncol = std::max(ncol, colors[j] + 1);
     DAS_CHECK(ncol < 65535, DAS_ERR_INTERNAL, "more than 65534 colours");
