@@ -347,6 +347,29 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         while ((size_t)c < forb.size() && forb[c] == stamp) c++;
         colors[j] = c;
     };
+    // first-fit over an ascending column list.  Consecutive columns with the same kept-row list (the xyz components of a
+    // cell's U) see the same neighbourhood: its forbidden set is gathered once and extended by the colours just handed
+    // out - identical to colouring them one by one, at a third of the gathers.
+    auto sweep_grouped = [&](const std::vector<long long>& cols, std::vector<long long>& forb) {
+        size_t a = 0;
+        while (a < cols.size()) {
+            const long long j = cols[a];
+            color_column(j, forb, j);
+            const long long len = cptr[j + 1] - cptr[j];
+            size_t b = a + 1;
+            while (b < cols.size() && cols[b] == cols[b - 1] + 1 && cptr[cols[b] + 1] - cptr[cols[b]] == len
+                   && std::equal(crow.begin() + cptr[j], crow.begin() + cptr[j + 1], crow.begin() + cptr[cols[b]])) {
+                const int cprev = colors[cols[b - 1]];
+                if ((size_t)cprev >= forb.size()) forb.resize(2 * cprev + 2, -1);
+                forb[cprev] = j;  // stamp of the group
+                int c = 0;
+                while ((size_t)c < forb.size() && forb[c] == j) c++;
+                colors[cols[b]] = c;
+                b++;
+            }
+            a = b;
+        }
+    };
     lap("csc");
     const int nth = std::max(1, omp_get_max_threads());
     // Columns are grouped by the cell they live in (anchor) and the cell range is cut into spatially contiguous
@@ -482,31 +505,22 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
                 std::vector<long long> forb(4096, -1);
 #pragma omp for schedule(dynamic, 1)
                 for (long long ti = 0; ti < (long long)tl.size(); ti++)
-                    for (long long j : tileCols[tl[ti]]) color_column(j, forb, j);
+                    sweep_grouped(tileCols[tl[ti]], forb);
             }
         }
-        if (getenv("DAS_DEBUG_TIMING")) fprintf(stderr, "[dafoam_amd]   colouring: %d tiles of <= %lld cells, %d phases\n", nT, tileCells, nPh);
+        if (getenv("DAS_DEBUG_TIMING")) {
+            fprintf(stderr, "[dafoam_amd]   colouring: %d tiles of <= %lld cells, %d phases, tiles per phase:", nT, tileCells, nPh);
+            for (int ph = 0; ph < nPh; ph++) fprintf(stderr, " %d", (int)phaseTiles[ph].size());
+            fprintf(stderr, "\n");
+        }
     } else {
         // serial first-fit.  Consecutive columns with the same kept-row list (the xyz components of a cell's U) see the
         // same neighbourhood: its forbidden set is gathered once and extended by the colours just handed out - the
         // result is identical to colouring them one by one, at a third of the gathers.
         std::vector<long long> forb(4096, -1);
-        long long j = 0;
-        while (j < n) {
-            color_column(j, forb, j);
-            long long g = j + 1;
-            const long long len = cptr[j + 1] - cptr[j];
-            while (g < n && cptr[g + 1] - cptr[g] == len && std::equal(crow.begin() + cptr[j], crow.begin() + cptr[j + 1], crow.begin() + cptr[g])) {
-                const int cprev = colors[g - 1];
-                if ((size_t)cprev >= forb.size()) forb.resize(2 * cprev + 2, -1);
-                forb[cprev] = j;  // stamp of the group
-                int c = 0;
-                while ((size_t)c < forb.size() && forb[c] == j) c++;
-                colors[g] = c;
-                g++;
-            }
-            j = g;
-        }
+        std::vector<long long> all(n);
+        std::iota(all.begin(), all.end(), 0LL);
+        sweep_grouped(all, forb);
     }
     lap("greedy");
     int ncol = 0;
