@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdafoam_amd.so")
 
 SOLVER_IDS = {"DASimpleFoam": 0, "DAScalarTransportFoam": 1, "DARhoSimpleFoam": 2, "DATurboFoam": 3}
-PATCH_TYPES = {"patch": 0, "wall": 1, "symmetry": 2}
+PATCH_TYPES = {"patch": 0, "wall": 1, "symmetry": 2, "cyclic": 3}
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)
@@ -69,6 +69,7 @@ class das_case_t(C.Structure):
         ("transonic", C.c_int),
         ("transonic_pc_option", C.c_int),
         ("simple_has_T", C.c_int),
+        ("patch_neighbour", c_int_p),
     ]
 
 
@@ -152,6 +153,10 @@ class CaseStruct:
             s.patch_mrf_rotating = _ip(k["patch_mrf_rotating"])
         s.transonic = 1 if getattr(case, "transonic", False) else 0
         s.transonic_pc_option = int(getattr(case, "transonic_pc_option", 1))
+        if any(p.type == "cyclic" for p in m.patches):
+            pnames = [p.name for p in m.patches]
+            k["patch_neighbour"] = np.array([pnames.index(p.neighbour) if p.type == "cyclic" else -1 for p in m.patches], dtype=np.int32)
+            s.patch_neighbour = _ip(k["patch_neighbour"])
         s.simple_has_T = 1 if (case.solver_name == "DASimpleFoam" and getattr(case, "has_T", False)) else 0
 
     def byref(self):

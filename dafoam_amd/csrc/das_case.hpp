@@ -84,6 +84,7 @@ inline DevMesh host_view(const Mesh& m) {
     d.cf_ptr = m.cf_ptr.data(); d.cf_face = m.cf_face.data(); d.cf_other = m.cf_other.data();
     d.owner = m.owner.data(); d.neigh = m.neighbour.data();
     d.bpatch = m.bface_patch.data(); d.bc = m.bc.data();
+    d.cyc = m.cyc_face.data();
     return d;
 }
 

@@ -126,6 +126,7 @@ struct Mesh {
     std::vector<FaceGeom> fg;
     std::vector<CellGeom> cg;
     std::vector<int> bface_patch;  // nBF
+    std::vector<int> cyc_face;     // nBF: the paired face of a cyclic boundary face, -1 otherwise
     // cell -> faces CSR; entry = face id | (side<<31), side 1 = this cell is the face's neighbour
     std::vector<int> cf_ptr, cf_face, cf_other;
     // cell -> cells CSR (face neighbours, ascending)

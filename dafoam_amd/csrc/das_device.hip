@@ -632,7 +632,7 @@ struct das_solver {
     // device mesh
     DevBuf<FaceGeom> d_fg;
     DevBuf<CellGeom> d_cg;
-    DevBuf<int> d_cf_ptr, d_cf_face, d_cf_other, d_owner, d_neigh, d_bpatch;
+    DevBuf<int> d_cf_ptr, d_cf_face, d_cf_other, d_owner, d_neigh, d_bpatch, d_cyc;
     DevBuf<PatchBC> d_bc;
     DevBuf<double> d_phiF, d_Told;
     DevMesh dm;
@@ -1528,11 +1528,12 @@ int das_init_solver(das_solver_t* s, int device) {
     s->d_owner.upload(m.owner);
     if (m.nIF) s->d_neigh.upload(m.neighbour);
     s->d_bpatch.upload(m.bface_patch);
+    s->d_cyc.upload(m.cyc_face);
     s->d_bc.upload(m.bc);
     if (!s->cp.phi_frozen.empty()) s->d_phiF.upload(s->cp.phi_frozen);
     if (!s->cp.T_old.empty()) s->d_Told.upload(s->cp.T_old);
     s->dm = DevMesh{m.nC, m.nF, m.nIF, s->d_fg.p, s->d_cg.p, s->d_cf_ptr.p, s->d_cf_face.p, s->d_cf_other.p, s->d_owner.p, s->d_neigh.p,
-                    s->d_bpatch.p, s->d_bc.p};
+                    s->d_bpatch.p, s->d_bc.p, s->d_cyc.p};
     s->d_W.upload(s->h_W);
     s->d_R.alloc(s->n);
     s->d_tmp1.alloc(s->n);

@@ -219,8 +219,10 @@ void JacCon::build(const Mesh& m, const Stencil& st) {
                 rb.begin();
                 int anch;
                 if (s.kind == KIND_FACE) {
-                    bool bnd = e >= m.nIF;
-                    int cn = bnd ? m.owner[e] : m.neighbour[e];
+                    // a cyclic boundary face is coupled to two cells like an internal face
+                    const int cyc = e >= m.nIF ? m.cyc_face[e - m.nIF] : -1;
+                    bool bnd = e >= m.nIF && cyc < 0;
+                    int cn = bnd ? m.owner[e] : (cyc >= 0 ? m.owner[cyc] : m.neighbour[e]);
                     rb.add(ch.block, cn, bnd);
                     if (!bnd) rb.add(ch.block, m.owner[e], false);
                     anch = m.owner[e];

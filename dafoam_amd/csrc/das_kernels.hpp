@@ -38,6 +38,7 @@ struct DevMesh {
     const int* neigh;
     const int* bpatch;  // boundary face -> patch
     const PatchBC* bc;
+    const int* cyc;     // boundary face -> paired face of a cyclic pair, -1 otherwise
 };
 
 struct ResParams {
@@ -264,7 +265,7 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
         const FaceGeom& g = m.fg[f];
         T Uf[3], pf, nf, hf(0.0);
         double sg = nb ? -1.0 : 1.0;
-        if (f < m.nIF) {
+        if (m.cf_other[s] >= 0) {  // internal face, or a cyclic boundary face (the paired cell acts as the neighbour)
             int o = m.cf_other[s];
             double wc = nb ? 1.0 - g.w : g.w;
 #pragma unroll
@@ -373,7 +374,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
         const FaceGeom& g = m.fg[f];
         T phi = W[prm.offPhi * N + f];
         double sg = nb ? -1.0 : 1.0;
-        if (f < m.nIF) {
+        if (m.cf_other[s] >= 0) {  // internal face, or a cyclic boundary face (the paired cell acts as the neighbour)
             int o = m.cf_other[s];
             const CellGeom& cgo = m.cg[o];
             double pv = val(phi);
@@ -412,6 +413,10 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 const T* gUp = upIsC ? gUc : gUo;
                 const double* Cup = upIsC ? cgc.C : cgo.C;
                 double d[3] = {g.Cf[0] - Cup[0], g.Cf[1] - Cup[1], g.Cf[2] - Cup[2]};
+                if (f >= m.nIF && !upIsC) {  // cyclic: the neighbour's face-centre offset lives at the paired face
+                    const FaceGeom& g2 = m.fg[m.cyc[f - m.nIF]];
+                    d[0] = g2.Cf[0] - cgo.C[0]; d[1] = g2.Cf[1] - cgo.C[1]; d[2] = g2.Cf[2] - cgo.C[2];
+                }
                 T corr[3], mx[3];
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
@@ -623,8 +628,8 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
         // DAResidualTurboFoam.C:146-212.  "phiHbyA" below is what enters div(): phiHbyA (+ SIMPLEC correction), or the
         // convective flux phid_f p_upwind of fvm::div(phid,p) in the transonic form.
         T snGradP, rho_f;
-        if (f < m.nIF) {
-            int o = m.owner[f], n = m.neigh[f];
+        if (f < m.nIF || m.cyc[f - m.nIF] >= 0) {  // internal or cyclic face
+            int o = m.owner[f], n = f < m.nIF ? m.neigh[f] : m.owner[m.cyc[f - m.nIF]];
             const double wl = g.w, wn = 1.0 - g.w;
             T po = W[prm.offP * N + o], pn = W[prm.offP * N + n];
             T psio = 1.0 / (prm.Rgas * W[prm.offT * N + o]), psin = 1.0 / (prm.Rgas * W[prm.offT * N + n]);
@@ -686,8 +691,8 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
         R[prm.offPhi * N + f] = pr;
         return;
     }
-    if (f < m.nIF) {
-        int o = m.owner[f], n = m.neigh[f];
+    if (f < m.nIF || m.cyc[f - m.nIF] >= 0) {  // internal or cyclic face
+        int o = m.owner[f], n = f < m.nIF ? m.neigh[f] : m.owner[m.cyc[f - m.nIF]];
         const double wl = g.w, wn = 1.0 - g.w;
         phiHbyA = g.Sf[0] * (wl * HbyA[3LL * o] + wn * HbyA[3LL * n]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * HbyA[3LL * n + 1])
                   + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * HbyA[3LL * n + 2]);

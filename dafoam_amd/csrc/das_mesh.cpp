@@ -134,6 +134,17 @@ void Mesh::build(const das_case_t* c) {
         b.mrf_included = (c->mrf_active && c->patch_mrf_rotating) ? (c->patch_mrf_rotating[p] != 0) : 0;
     }
     DAS_CHECK(expect == nF, DAS_ERR_ARG, "patches do not cover all boundary faces");
+    // cyclic pairs (cyclicPolyPatch: neighbPatch, same size, face k <-> face k)
+    cyc_face.assign(nF - nIF, -1);
+    for (int p = 0; p < nPatch; p++) {
+        if (patch_type[p] != DAS_PATCH_CYCLIC) continue;
+        DAS_CHECK(c->patch_neighbour, DAS_ERR_ARG, "cyclic patch without patch_neighbour table");
+        const int q = c->patch_neighbour[p];
+        DAS_CHECK(q >= 0 && q < nPatch && q != p && patch_type[q] == DAS_PATCH_CYCLIC && c->patch_neighbour[q] == p, DAS_ERR_ARG,
+                  "cyclic patch: neighbour patch is not its cyclic partner");
+        DAS_CHECK(patch_size[q] == patch_size[p], DAS_ERR_ARG, "cyclic patch pair with different sizes");
+        for (int k = 0; k < patch_size[p]; k++) cyc_face[patch_start[p] - nIF + k] = patch_start[q] + k;
+    }
     compute_geometry(c->y_wall);
     build_addressing();
 }
@@ -226,6 +237,24 @@ void Mesh::compute_geometry(const double* y_wall) {
             g.w = sn / (so + sn);
             g.nod = 1.0 / std::max(nd, 0.05 * md);
             for (int k = 0; k < 3; k++) g.corr[k] = g.Sf[k] / g.magSf - d[k] * g.nod;
+        } else if (cyc_face[f - nIF] >= 0) {
+            // cyclicFvPatch::makeWeights / delta() for a translational pair: the neighbour cell is the owner of the
+            // paired face, seen at  Cf - (Cf' - C')  (its image across the pair)
+            const int f2 = cyc_face[f - nIF];
+            const FaceGeom& g2 = fg[f2];
+            const double* C2 = cg[owner[f2]].C;
+            double dOwn = 0, dNbr = 0, d[3], md = 0, nd = 0;
+            for (int k = 0; k < 3; k++) {
+                dOwn += g.Sf[k] / g.magSf * (g.Cf[k] - Co[k]);
+                dNbr += g2.Sf[k] / g2.magSf * (g2.Cf[k] - C2[k]);
+                d[k] = (g.Cf[k] - Co[k]) - (g2.Cf[k] - C2[k]);
+                md += d[k] * d[k];
+            }
+            for (int k = 0; k < 3; k++) nd += g.Sf[k] / g.magSf * d[k];
+            md = std::sqrt(md);
+            g.w = dNbr / (dOwn + dNbr);
+            g.nod = 1.0 / std::max(nd, 0.05 * md);
+            for (int k = 0; k < 3; k++) g.corr[k] = g.Sf[k] / g.magSf - d[k] * g.nod;
         } else {
             double md = 0;
             for (int k = 0; k < 3; k++) { double dk = g.Cf[k] - Co[k]; md += dk * dk; }
@@ -247,7 +276,8 @@ void Mesh::build_addressing() {
     for (int f = 0; f < nF; f++) {
         int o = owner[f];
         cf_face[pos[o]] = f;
-        cf_other[pos[o]] = f < nIF ? neighbour[f] : -1;
+        // a cyclic boundary face has a neighbour cell too: the owner of its paired face
+        cf_other[pos[o]] = f < nIF ? neighbour[f] : (cyc_face[f - nIF] >= 0 ? owner[cyc_face[f - nIF]] : -1);
         pos[o]++;
         if (f < nIF) {
             int n = neighbour[f];
@@ -263,11 +293,18 @@ void Mesh::build_addressing() {
         cc_ptr[c + 1] = cc_ptr[c] + k;
     }
     cc.assign(cc_ptr[nC], 0);
+    std::vector<int> tmp;
+    int w = 0;
     for (int c = 0; c < nC; c++) {
-        int k = cc_ptr[c];
-        for (int s = cf_ptr[c]; s < cf_ptr[c + 1]; s++) if (cf_other[s] >= 0) cc[k++] = cf_other[s];
-        std::sort(cc.begin() + cc_ptr[c], cc.begin() + cc_ptr[c + 1]);
+        tmp.clear();
+        for (int s = cf_ptr[c]; s < cf_ptr[c + 1]; s++) if (cf_other[s] >= 0 && cf_other[s] != c) tmp.push_back(cf_other[s]);
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());  // (a thin periodic layer reaches the same cell twice)
+        cc_ptr[c] = w;
+        for (int x : tmp) cc[w++] = x;
     }
+    cc_ptr[nC] = w;
+    cc.resize(w);
 }
 
 }  // namespace das

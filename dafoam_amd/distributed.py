@@ -286,6 +286,8 @@ def extract_submesh(case, part, rank, G=GHOST_LAYERS):
     from .meshgen import BC_ZERO_GRADIENT, NUT_CALCULATED, FoamCase, Patch, PolyMesh
 
     m = case.mesh
+    if any(p.type == "cyclic" for p in m.patches):
+        raise NotImplementedError("extract_submesh: cyclic patch pairs are not supported by the multi-GPU partitioner yet")
     N, F, nIF = m.n_cells, m.n_faces, m.n_internal_faces
     own, nei = m.owner.astype(np.int64), m.neighbour.astype(np.int64)
     A = sp.coo_matrix((np.ones(nIF, np.int8), (own[:nIF], nei)), shape=(N, N)).tocsr()

@@ -24,6 +24,7 @@ BC_FIXED_VALUE = 0
 BC_ZERO_GRADIENT = 1
 BC_INLET_OUTLET = 2
 BC_SYMMETRY = 3
+BC_CYCLIC = 4  # coupled (cyclic) patch: no patch-field coefficients, the paired cell acts as a neighbour
 # nut wall treatment codes
 NUT_CALCULATED = 0
 NUT_LOWRE_WALL = 1  # nut_w = 0 (nutLowReWallFunction, reference DAField.C:1155-1218)
@@ -34,9 +35,10 @@ NUT_SYMMETRY = 3
 @dataclass
 class Patch:
     name: str
-    type: str  # "patch" | "wall" | "symmetry"
+    type: str  # "patch" | "wall" | "symmetry" | "cyclic"
     start: int
     size: int
+    neighbour: Optional[str] = None  # cyclic: name of the paired patch (face k pairs with face k, translational)
 
 
 @dataclass
@@ -223,7 +225,7 @@ def hex_block(
     )
 
 
-def bump_mapping(height: float = 0.1, skew: float = 0.15, Lx: float = 1.0, Ly: float = 1.0):
+def bump_mapping(height: float = 0.1, skew: float = 0.15, Lx: float = 1.0, Ly: float = 1.0, z_periodic: bool = False):
     """Convergent-channel-like bump on the bottom wall plus a sinusoidal interior skew
     (gives non-orthogonal, non-uniform hexes like the reference's ConvergentChannel)."""
 
@@ -233,7 +235,8 @@ def bump_mapping(height: float = 0.1, skew: float = 0.15, Lx: float = 1.0, Ly: f
         bump = height * Ly * np.sin(np.pi * x) ** 2
         q[:, 1] = p[:, 1] + bump * (1.0 - y)
         q[:, 0] = p[:, 0] + skew * Lx / 8.0 * np.sin(np.pi * y) * np.sin(2 * np.pi * x)
-        q[:, 2] = z * (1.0 + 0.05 * np.sin(np.pi * x) * np.sin(np.pi * y))
+        if not z_periodic:  # (a z-translation-invariant block is needed for front/back cyclic pairs)
+            q[:, 2] = z * (1.0 + 0.05 * np.sin(np.pi * x) * np.sin(np.pi * y))
         return q
 
     return f
@@ -410,6 +413,100 @@ def channel_case(
     phi[:nIF] *= 1.0 + perturb * rng.standard_normal(nIF)
     case.states = np.concatenate([U.ravel(), p, nuT, phi])
     return case
+
+
+def periodic_channel_case(nx=6, ny=5, nz=5, lengths=(1.0, 0.2, 0.1), copies=1, wall_function=False, perturb=0.02, seed=0, **kw) -> FoamCase:
+    """DASimpleFoam + SA channel that is translationally periodic in z: front/back are a cyclic patch pair (copies = 1).
+    copies > 1 emits the same block repeated `copies` times in z with ORDINARY front/back patches and the periodic
+    state repeated - the non-periodic "unrolled" mesh the tests use to check the cyclic implementation with the
+    unchanged oracle (the middle copy sees its periodic images as real neighbours)."""
+    Lx, Ly, Lz = lengths
+    base = channel_case(nx, ny, nz, lengths=lengths, wall_function=wall_function, perturb=0.0, seed=seed, **kw)
+    mesh1 = hex_block(nx, ny, nz, lengths, bump_mapping(kw.get("bump", 0.1), kw.get("skew", 0.15), Lx, Ly, z_periodic=True),
+                      patch_types=("patch", "patch", "wall", "wall", "cyclic", "cyclic"), grading_y=kw.get("grading_y", 1.0))
+    for pt in mesh1.patches:
+        if pt.name == "front":
+            pt.neighbour = "back"
+        if pt.name == "back":
+            pt.neighbour = "front"
+    g = _InputGeometry(mesh1)
+    y = wall_distance(mesh1, g.C, g.Cf, g.Sf)
+    bcs = {k: dict(v) for k, v in base.bcs.items() if k not in ("front", "back")}
+    cyc = {"U": (BC_CYCLIC, (0.0, 0.0, 0.0)), "p": (BC_CYCLIC, 0.0), "nuTilda": (BC_CYCLIC, 0.0), "nut": (NUT_CALCULATED, 0.0)}
+    bcs["front"], bcs["back"] = dict(cyc), dict(cyc)
+    rng = np.random.default_rng(seed)
+    N, F, nIF = mesh1.n_cells, mesh1.n_faces, mesh1.n_internal_faces
+    U0, nuTilda0 = kw.get("U0", 10.0), kw.get("nuTilda0", 4.5e-5)
+    eta = np.clip(y / (0.5 * Ly), 0.0, 1.0)
+    prof = eta ** (1.0 / 7.0)
+    xh, zh = g.C[:, 0] / Lx, g.C[:, 2] / Lz
+    U = np.zeros((N, 3))
+    U[:, 0] = U0 * prof * (1.0 + 0.3 * np.sin(np.pi * xh) ** 2) * (1.0 + 0.05 * np.sin(2 * np.pi * zh))
+    U[:, 1] = 0.05 * U0 * prof * np.sin(2 * np.pi * xh + 0.3)
+    U[:, 2] = 0.04 * U0 * prof * (0.5 + np.cos(2 * np.pi * zh + 0.4) * np.sin(np.pi * xh))
+    U *= 1.0 + perturb * rng.standard_normal((N, 1))
+    p = 0.5 * U0 * U0 * 0.2 * (1.0 - xh) * (1.0 + 0.1 * np.sin(2 * np.pi * zh)) * (1.0 + perturb * rng.standard_normal(N))
+    nuT = nuTilda0 * (1.0 + 20.0 * eta * (1.0 - 0.5 * eta)) * (1.0 + perturb * rng.standard_normal(N))
+    own, nei = mesh1.owner, mesh1.neighbour
+    phi = np.zeros(F)
+    phi[:nIF] = np.einsum("ij,ij->i", g.w[:, None] * U[own[:nIF]] + (1 - g.w[:, None]) * U[nei], g.Sf[:nIF])
+    phi[:nIF] *= 1.0 + perturb * rng.standard_normal(nIF)
+    sl = {pt.name: slice(pt.start, pt.start + pt.size) for pt in mesh1.patches}
+    phi[sl["inlet"]] = U0 * g.Sf[sl["inlet"], 0]
+    phi[sl["outlet"]] = np.einsum("ij,ij->i", U[own[sl["outlet"]]], g.Sf[sl["outlet"]])
+    # periodic-consistent flux through the pair: phi_back(i,j) = -phi_front(i,j) (face k of front pairs with face k of back)
+    Ub = 0.5 * (U[own[sl["back"]]] + U[own[sl["front"]]])
+    phi[sl["back"]] = np.einsum("ij,ij->i", Ub, g.Sf[sl["back"]]) * (1.0 + perturb * rng.standard_normal(sl["back"].stop - sl["back"].start))
+    phi[sl["front"]] = -phi[sl["back"]]
+    case = FoamCase(mesh=mesh1, solver_name="DASimpleFoam", nu=base.nu, bcs=bcs, y_wall=y)
+    case.states = np.concatenate([U.ravel(), p, nuT, phi])
+    if copies == 1:
+        return case
+    # ---- unrolled copies: ordinary patches at the two ends, periodic repetition of geometry and state
+    meshC = hex_block(nx, ny, nz * copies, (Lx, Ly, Lz * copies), bump_mapping(kw.get("bump", 0.1), kw.get("skew", 0.15), Lx, Ly, z_periodic=True),
+                      patch_types=("patch", "patch", "wall", "wall", "patch", "patch"), grading_y=kw.get("grading_y", 1.0))
+    caseC_states = unroll_periodic_vector(mesh1, meshC, case.states, copies)
+    bcsC = {k: dict(v) for k, v in bcs.items()}
+    zg = {"U": (BC_ZERO_GRADIENT, (0.0, 0.0, 0.0)), "p": (BC_ZERO_GRADIENT, 0.0), "nuTilda": (BC_ZERO_GRADIENT, 0.0), "nut": (NUT_CALCULATED, 0.0)}
+    bcsC["front"], bcsC["back"] = dict(zg), dict(zg)
+    caseC = FoamCase(mesh=meshC, solver_name="DASimpleFoam", nu=base.nu, bcs=bcsC, y_wall=np.tile(y, copies))
+    caseC.states = caseC_states
+    return caseC
+
+
+def unroll_periodic_vector(mesh1: PolyMesh, meshC: PolyMesh, vec, copies):
+    """A state-like vector of the z-periodic block `mesh1` ([U|p|nuTilda|phi], front/back fluxes periodic-consistent:
+    phi_front = -phi_back) repeated onto the `copies`-fold unrolled block `meshC`."""
+    N, F, nIF = mesh1.n_cells, mesh1.n_faces, mesh1.n_internal_faces
+    NC, FC, nIFC = meshC.n_cells, meshC.n_faces, meshC.n_internal_faces
+    own, nei = mesh1.owner, mesh1.neighbour
+    sl = {pt.name: slice(pt.start, pt.start + pt.size) for pt in mesh1.patches}
+    phi = vec[-F:]
+    nsc = (vec.size - 3 * N - F) // N
+    cell1 = np.arange(NC) % N  # cell (i,j,k) of the unrolled block <-> (i,j,k mod nz): cid = i + nx (j + ny k)
+    copy_of = np.arange(NC) // N
+    pair = {(int(own[f]), int(nei[f])): f for f in range(nIF)}
+    back_of = {int(own[f]): f for f in range(sl["back"].start, sl["back"].stop)}
+    front_of = {int(own[f]): f for f in range(sl["front"].start, sl["front"].stop)}
+    phiC = np.zeros(FC, dtype=vec.dtype)
+    for f in range(nIFC):
+        a, b = int(meshC.owner[f]), int(meshC.neighbour[f])
+        if copy_of[a] == copy_of[b]:
+            phiC[f] = phi[pair[(int(cell1[a]), int(cell1[b]))]]
+        else:  # interface between two copies = the back face of the lower cell (same orientation +z)
+            phiC[f] = phi[back_of[int(cell1[a])]]
+    slC = {pt.name: slice(pt.start, pt.start + pt.size) for pt in meshC.patches}
+    for nm in ("inlet", "outlet", "bottom", "top"):
+        by_cell = {int(own[f]): f for f in range(sl[nm].start, sl[nm].stop)}
+        for f in range(slC[nm].start, slC[nm].stop):
+            phiC[f] = phi[by_cell[int(cell1[meshC.owner[f]])]]
+    for f in range(slC["front"].start, slC["front"].stop):
+        phiC[f] = phi[front_of[int(cell1[meshC.owner[f]])]]
+    for f in range(slC["back"].start, slC["back"].stop):
+        phiC[f] = phi[back_of[int(cell1[meshC.owner[f]])]]
+    Ublk = vec[: 3 * N].reshape(N, 3)
+    parts = [np.tile(Ublk, (copies, 1)).ravel()] + [np.tile(vec[(3 + b) * N : (4 + b) * N], copies) for b in range(nsc)] + [phiC]
+    return np.concatenate(parts)
 
 
 def renumber_case(case: FoamCase, seed=0) -> FoamCase:

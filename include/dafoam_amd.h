@@ -43,12 +43,14 @@ extern "C" {
 #define DAS_PATCH_PATCH 0
 #define DAS_PATCH_WALL 1
 #define DAS_PATCH_SYMMETRY 2
+#define DAS_PATCH_CYCLIC 3 /* coupled pair (translational): face k of the patch pairs with face k of patch_neighbour */
 
 /* boundary-condition codes per patch and field */
 #define DAS_BC_FIXED_VALUE 0
 #define DAS_BC_ZERO_GRADIENT 1
 #define DAS_BC_INLET_OUTLET 2
 #define DAS_BC_SYMMETRY 3
+#define DAS_BC_CYCLIC 4 /* placeholder code of coupled patches: no patch-field coefficients are evaluated */
 /* nut patch treatment (reference DAField.C:1155-1218, DAMisc/nutUSpaldingWallFunctionDF) */
 #define DAS_NUT_CALCULATED 0
 #define DAS_NUT_LOWRE_WALL 1
@@ -103,6 +105,9 @@ typedef struct das_case {
     /* DASimpleFoam with the optional passive T field (reference DAResidualSimpleFoam.C:50-76,215-235; states
      * [U | p | T | nuTilda | phi], DAStateInfoSimpleFoam.C:118-131); Pr / Prt above are then transportProperties' */
     int simple_has_T;
+    /* cyclic (coupled) patches, OpenFOAM cyclicFvPatch semantics for a TRANSLATIONAL pair: per patch the index of the
+     * paired patch (-1 for ordinary patches); may be NULL if no patch is cyclic */
+    const int* patch_neighbour;
 } das_case_t;
 
 const char* das_last_error(void);

@@ -8,10 +8,11 @@ import re
 import numpy as np
 import pytest
 
-from common import NORM_STATES, NORM_STATES_RHO, blocks, options, relerr
+from common import NORM_STATES, NORM_STATES_RHO, blocks, options, relerr, unrolled_maps
 from dafoam_amd import _capi
 from dafoam_amd._capi import CaseStruct, das_case_t, dptr
-from dafoam_amd.meshgen import channel_case, renumber_case, rho_channel_case, scalar_transport_case, simple_T_channel_case, turbo_channel_case
+from dafoam_amd.meshgen import (channel_case, periodic_channel_case, renumber_case, rho_channel_case, scalar_transport_case, simple_T_channel_case,
+                                turbo_channel_case, unroll_periodic_vector)
 from dafoam_amd.pyDASolvers import pyDASolvers
 from oracle import jacobian as J
 from oracle.foam_mesh import Geometry
@@ -381,6 +382,62 @@ def test_simplefoam_with_T_field(isPC):
             assert (s.getConnectivity(pc) != J.connectivity(case, g, isPC=bool(pc))).nnz == 0
         col, _ = s.getColoring()
         assert J.validate_coloring(J.connectivity(case, g), col.astype(np.int64))
+
+
+@pytest.mark.parametrize("wall_function", [False, True])
+@pytest.mark.parametrize("isPC", [0, 1])
+def test_cyclic_translational_vs_unrolled_oracle(wall_function, isPC):
+    """Cyclic (coupled) patch pair, OpenFOAM cyclicFvPatch semantics for a translational pair: the paired cell acts as
+    the neighbour of the boundary face (interpolation weights nbrDelta/(delta+nbrDelta), delta = own-centre -> image of
+    the neighbour centre, corrected non-orthogonal flux), both faces keep their own phi state and phiRes row.
+    Checked WITHOUT a cyclic oracle: the same periodic block unrolled three times is an ordinary mesh for the unchanged
+    oracle, whose middle copy sees the periodic images as real neighbours - values and (periodic-consistent) tangents
+    of every residual row incl. the cyclic faces' phiRes agree to round-off."""
+    c1 = periodic_channel_case(6, 5, 5, wall_function=wall_function)
+    c3 = periodic_channel_case(6, 5, 5, copies=3, wall_function=wall_function)
+    idx, sgn = unrolled_maps(c1, c3)
+    assert np.array_equal(c3.states[idx] * sgn, c1.states)
+    g1, g3 = Geometry(c1.mesh), Geometry(c3.mesh)
+    ref = residual(c3, g3, c3.states, isPC=bool(isPC))[idx] * sgn
+    Rv, _ = _emu_res(c1, c1.states, isPC)
+    for nm, sl in blocks(c1, g1):
+        assert relerr(Rv[sl], ref[sl]) < 1e-12, nm
+    v = np.random.default_rng(1).standard_normal(c1.states.size) * J.state_scales(c1, g1, NORM_STATES)
+    sl = {p.name: np.arange(p.start, p.start + p.size) for p in c1.mesh.patches}
+    off = c1.states.size - c1.mesh.n_faces
+    v[off + sl["front"]] = -v[off + sl["back"]]  # periodic-consistent direction: one flux per pair in the unrolled mesh
+    v3 = unroll_periodic_vector(c1.mesh, c3.mesh, v, 3)
+    cs = (residual(c3, g3, c3.states + 1e-30j * v3, isPC=bool(isPC)).imag / 1e-30)[idx] * sgn
+    _, Rd = _emu_res(c1, c1.states, isPC, v)
+    for nm, sl_ in blocks(c1, g1):
+        assert relerr(Rd[sl_], cs[sl_]) < 1e-11, nm
+
+
+def test_cyclic_connectivity_covers_every_dependency():
+    """dRdWCon with a cyclic pair: the level rings run through the pair (the paired cell is a face neighbour, cyclic
+    faces are coupled to two cells).  Every non-zero of the column-by-column forward-mode Jacobian of the kernel bodies
+    lies inside the pattern, the colouring is valid and the mesh without the pair has a strictly smaller pattern."""
+    c1 = periodic_channel_case(4, 3, 4, wall_function=True)
+    s = pyDASolvers(b"DASimpleFoam -python", options(c1), case=c1)
+    s.runColoring()
+    con = s.getConnectivity(0).tocsr()
+    n = c1.states.size
+    dense = np.zeros((n, n))
+    for j in range(n):
+        e = np.zeros(n)
+        e[j] = 1.0
+        _, Rd = _emu_res(c1, c1.states, 0, e)
+        dense[:, j] = Rd
+    pat = np.asarray(con.todense()) != 0
+    assert np.abs(np.where(pat, 0.0, dense)).max() == 0.0
+    col, nc = s.getColoring()
+    for r in range(n):
+        cs = col[con.indices[con.indptr[r] : con.indptr[r + 1]]]
+        assert np.unique(cs).size == cs.size
+    plain = channel_case(4, 3, 4, wall_function=True)
+    s2 = pyDASolvers(b"DASimpleFoam -python", options(plain), case=plain)
+    s2.runColoring()
+    assert s2.getConnectivity(0).nnz < con.nnz
 
 
 def test_simplefoam_mrf_and_simplec():
