@@ -70,6 +70,7 @@ class das_case_t(C.Structure):
         ("transonic_pc_option", C.c_int),
         ("simple_has_T", C.c_int),
         ("patch_neighbour", c_int_p),
+        ("patch_rotation", c_double_p),
     ]
 
 
@@ -157,6 +158,11 @@ class CaseStruct:
             pnames = [p.name for p in m.patches]
             k["patch_neighbour"] = np.array([pnames.index(p.neighbour) if p.type == "cyclic" else -1 for p in m.patches], dtype=np.int32)
             s.patch_neighbour = _ip(k["patch_neighbour"])
+            if any(getattr(p, "rotation", None) is not None for p in m.patches):
+                k["patch_rotation"] = np.ascontiguousarray(
+                    [np.asarray(p.rotation, dtype=np.float64).reshape(9) if getattr(p, "rotation", None) is not None else np.eye(3).reshape(9)
+                     for p in m.patches], dtype=np.float64)
+                s.patch_rotation = _dp(k["patch_rotation"])
         s.simple_has_T = 1 if (case.solver_name == "DASimpleFoam" and getattr(case, "has_T", False)) else 0
 
     def byref(self):

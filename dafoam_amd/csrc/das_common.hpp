@@ -113,6 +113,8 @@ struct PatchBC {  // per patch, small table
     double dU_val[3];
     double dp_val, dnuTilda_val, dT_val;
     int mrf_included;  // 1 = the patch rotates with the MRF zone (MRFZone includedFaces)
+    int rot;           // cyclic patch with a rotation: neighbour-side vectors are multiplied by Q (forwardT)
+    double Q[9];
 };
 
 // ---- host mesh (fvMesh equivalent) ------------------------------------------------------------

@@ -87,6 +87,33 @@ DAS_HD double mrf_face_flux(const ResParams& prm, const FaceGeom& g) {
 #define DAS_SMALL 1e-15
 #define DAS_ROOTVSMALL 1e-150
 
+// rotational cyclic pairs: neighbour-side vectors / gradient tensors seen in this side's frame (forwardT = Q)
+template <class T>
+DAS_HD void rot_vec(const double* Q, T* v) {
+    T a = Q[0] * v[0] + Q[1] * v[1] + Q[2] * v[2];
+    T b = Q[3] * v[0] + Q[4] * v[1] + Q[5] * v[2];
+    T c = Q[6] * v[0] + Q[7] * v[1] + Q[8] * v[2];
+    v[0] = a; v[1] = b; v[2] = c;
+}
+template <class T>
+DAS_HD void rot_ten(const double* Q, T* g) {  // g[3i+j] = d_i U_j  ->  Q g Q^T
+    T t[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[3 * i + j] = Q[3 * i] * g[j] + Q[3 * i + 1] * g[3 + j] + Q[3 * i + 2] * g[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) g[3 * i + j] = t[3 * i] * Q[3 * j] + t[3 * i + 1] * Q[3 * j + 1] + t[3 * i + 2] * Q[3 * j + 2];
+}
+// the rotation of the cyclic patch of boundary face f, or null (internal faces, translational pairs)
+DAS_HD const double* cyclic_rotation(const DevMesh& m, int f) {
+    if (f < m.nIF) return nullptr;
+    const PatchBC& pb = m.bc[m.bpatch[f - m.nIF]];
+    return pb.rot ? pb.Q : nullptr;
+}
+
 template <class T>
 DAS_HD T fv1_of(const T& chi) {
     T chi3 = chi * chi * chi;
@@ -268,8 +295,11 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
         if (m.cf_other[s] >= 0) {  // internal face, or a cyclic boundary face (the paired cell acts as the neighbour)
             int o = m.cf_other[s];
             double wc = nb ? 1.0 - g.w : g.w;
+            T Uo[3] = {W[3LL * o], W[3LL * o + 1], W[3LL * o + 2]};
+            const double* Qr = cyclic_rotation(m, f);
+            if (Qr) rot_vec<T>(Qr, Uo);
 #pragma unroll
-            for (int k = 0; k < 3; k++) Uf[k] = wc * Uc[k] + (1.0 - wc) * W[3LL * o + k];
+            for (int k = 0; k < 3; k++) Uf[k] = wc * Uc[k] + (1.0 - wc) * Uo[k];
             pf = wc * pc + (1.0 - wc) * W[prm.offP * N + o];
             nf = wc * nc + (1.0 - wc) * W[prm.offN * N + o];
             if (RHO) hf = prm.Cp * (wc * Tc + (1.0 - wc) * W[prm.offT * N + o] - DAS_TREF);
@@ -384,6 +414,8 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             else { dcoef = -((1.0 - wu) * phi); off = -(wu * phi); }
             sumPhi += sg * phi;
             T Uo[3] = {W[3LL * o], W[3LL * o + 1], W[3LL * o + 2]};
+            const double* Qr = cyclic_rotation(m, f);
+            if (Qr) rot_vec<T>(Qr, Uo);
             T nuT_o = W[prm.offN * N + o];
             T rho_o(1.0), nu_o(prm.nu), T_o(0.0);
             if (energy) T_o = W[prm.offT * N + o];
@@ -396,6 +428,8 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             T gUo[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) gUo[k] = gradU[9LL * o + k];
+            T gNo[3] = {gradN[3LL * o], gradN[3LL * o + 1], gradN[3LL * o + 2]};
+            if (Qr) { rot_ten<T>(Qr, gUo); rot_vec<T>(Qr, gNo); }
             const double wl = g.w;
             const double wc = nb ? 1.0 - wl : wl, wo = 1.0 - wc;
             // ---- momentum diffusion  -fvm::laplacian(rho nuEff,U)  (Gauss linear corrected)
@@ -416,6 +450,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 if (f >= m.nIF && !upIsC) {  // cyclic: the neighbour's face-centre offset lives at the paired face
                     const FaceGeom& g2 = m.fg[m.cyc[f - m.nIF]];
                     d[0] = g2.Cf[0] - cgo.C[0]; d[1] = g2.Cf[1] - cgo.C[1]; d[2] = g2.Cf[2] - cgo.C[2];
+                    if (Qr) rot_vec<double>(Qr, d);
                 }
                 T corr[3], mx[3];
 #pragma unroll
@@ -455,8 +490,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             T cdn = gn * g.nod;
             dN += dcoef + cdn;
             offN += (off - cdn) * nuT_o;
-            T cvn = g.corr[0] * (wc * gNc[0] + wo * gradN[3LL * o]) + g.corr[1] * (wc * gNc[1] + wo * gradN[3LL * o + 1])
-                    + g.corr[2] * (wc * gNc[2] + wo * gradN[3LL * o + 2]);
+            T cvn = g.corr[0] * (wc * gNc[0] + wo * gNo[0]) + g.corr[1] * (wc * gNc[1] + wo * gNo[1]) + g.corr[2] * (wc * gNc[2] + wo * gNo[2]);
             sN += sg * (gn * cvn);
             // ---- energy: div(phi,he) upwind + fvc::div(phi,K) upwind - laplacian(alphaEff, he)
             //      (DASimpleFoam T field: div(phi,T) bounded upwind - laplacian(alphaEff, T), no K)
@@ -467,8 +501,10 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 T cde = ga * g.nod;
                 dE += dcoef + cde;
                 offE += (off - cde) * he_o;
-                T cve = g.corr[0] * (wc * gradH[3LL * c] + wo * gradH[3LL * o]) + g.corr[1] * (wc * gradH[3LL * c + 1] + wo * gradH[3LL * o + 1])
-                        + g.corr[2] * (wc * gradH[3LL * c + 2] + wo * gradH[3LL * o + 2]);
+                T gHo[3] = {gradH[3LL * o], gradH[3LL * o + 1], gradH[3LL * o + 2]};
+                if (Qr) rot_vec<T>(Qr, gHo);
+                T cve = g.corr[0] * (wc * gradH[3LL * c] + wo * gHo[0]) + g.corr[1] * (wc * gradH[3LL * c + 1] + wo * gHo[1])
+                        + g.corr[2] * (wc * gradH[3LL * c + 2] + wo * gHo[2]);
                 sE += sg * (ga * cve);
                 if (RHO) {
                     T K_o = 0.5 * (Uo[0] * Uo[0] + Uo[1] * Uo[1] + Uo[2] * Uo[2]);
@@ -479,12 +515,15 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 }
                 if (turbo) {
                     // - fvc::div(Teff.T() & U) (Gauss linear) and + fvc::div(p (U - URel)), U - URel = Omega x r
-                    T qf = g.Sf[0] * (wc * TU[3LL * c] + wo * TU[3LL * o]) + g.Sf[1] * (wc * TU[3LL * c + 1] + wo * TU[3LL * o + 1])
-                           + g.Sf[2] * (wc * TU[3LL * c + 2] + wo * TU[3LL * o + 2]);
+                    T TUo[3] = {TU[3LL * o], TU[3LL * o + 1], TU[3LL * o + 2]};
+                    if (Qr) rot_vec<T>(Qr, TUo);
+                    T qf = g.Sf[0] * (wc * TU[3LL * c] + wo * TUo[0]) + g.Sf[1] * (wc * TU[3LL * c + 1] + wo * TUo[1])
+                           + g.Sf[2] * (wc * TU[3LL * c + 2] + wo * TUo[2]);
                     sE += sg * qf;
                     if (mrf) {
                         double vC_o[3];
                         mrf_velocity(prm, cgo.C, vC_o);
+                        if (Qr) rot_vec<double>(Qr, vC_o);
                         T p_o = W[prm.offP * N + o];
                         T wf = g.Sf[0] * (wc * (pc * vC_c[0]) + wo * (p_o * vC_o[0])) + g.Sf[1] * (wc * (pc * vC_c[1]) + wo * (p_o * vC_o[1]))
                                + g.Sf[2] * (wc * (pc * vC_c[2]) + wo * (p_o * vC_o[2]));
@@ -634,21 +673,25 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
             T po = W[prm.offP * N + o], pn = W[prm.offP * N + n];
             T psio = 1.0 / (prm.Rgas * W[prm.offT * N + o]), psin = 1.0 / (prm.Rgas * W[prm.offT * N + n]);
             T ro = po * psio, rn = pn * psin;
-            T cg = g.corr[0] * (wl * gradP[3LL * o] + wn * gradP[3LL * n]) + g.corr[1] * (wl * gradP[3LL * o + 1] + wn * gradP[3LL * n + 1])
-                   + g.corr[2] * (wl * gradP[3LL * o + 2] + wn * gradP[3LL * n + 2]);
+            T gPn[3] = {gradP[3LL * n], gradP[3LL * n + 1], gradP[3LL * n + 2]};
+            T Hn[3] = {HbyA[3LL * n], HbyA[3LL * n + 1], HbyA[3LL * n + 2]};
+            const double* Qr = cyclic_rotation(m, f);
+            if (Qr) { rot_vec<T>(Qr, gPn); rot_vec<T>(Qr, Hn); }
+            T cg = g.corr[0] * (wl * gradP[3LL * o] + wn * gPn[0]) + g.corr[1] * (wl * gradP[3LL * o + 1] + wn * gPn[1])
+                   + g.corr[2] * (wl * gradP[3LL * o + 2] + wn * gPn[2]);
             snGradP = g.nod * (pn - po) + cg;
             rho_f = wl * ro + wn * rn;
             if (!prm.transonic) {
-                phiHbyA = g.Sf[0] * (wl * (ro * HbyA[3LL * o]) + wn * (rn * HbyA[3LL * n]))
-                          + g.Sf[1] * (wl * (ro * HbyA[3LL * o + 1]) + wn * (rn * HbyA[3LL * n + 1]))
-                          + g.Sf[2] * (wl * (ro * HbyA[3LL * o + 2]) + wn * (rn * HbyA[3LL * n + 2])) - rho_f * rel;
+                phiHbyA = g.Sf[0] * (wl * (ro * HbyA[3LL * o]) + wn * (rn * Hn[0]))
+                          + g.Sf[1] * (wl * (ro * HbyA[3LL * o + 1]) + wn * (rn * Hn[1]))
+                          + g.Sf[2] * (wl * (ro * HbyA[3LL * o + 2]) + wn * (rn * Hn[2])) - rho_f * rel;
                 // SIMPLEC-consistent form (AtU = AU - H1): interpolate(rho/AtU - rho/AU) snGrad(p) |Sf| is added to phiHbyA
                 // and to the laplacian(rho/AtU, p) flux alike, so it cancels identically in pRes and phiRes (linear
                 // interpolation is linear); what remains is the rho/AU flux.  The oracle keeps both terms.
                 flux = (wl * (ro * rAU[o]) + wn * (rn * rAU[n])) * g.magSf * snGradP;
             } else {
-                T hs = g.Sf[0] * (wl * HbyA[3LL * o] + wn * HbyA[3LL * n]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * HbyA[3LL * n + 1])
-                       + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * HbyA[3LL * n + 2]);
+                T hs = g.Sf[0] * (wl * HbyA[3LL * o] + wn * Hn[0]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * Hn[1])
+                       + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * Hn[2]);
                 T phid = (wl * psio + wn * psin) * (hs - rel);
                 phiHbyA = phid * (val(phid) >= 0.0 ? po : pn);
                 flux = (wl * (ro * rAU[o]) + wn * (rn * rAU[n])) * g.magSf * snGradP;
@@ -694,8 +737,12 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
     if (f < m.nIF || m.cyc[f - m.nIF] >= 0) {  // internal or cyclic face
         int o = m.owner[f], n = f < m.nIF ? m.neigh[f] : m.owner[m.cyc[f - m.nIF]];
         const double wl = g.w, wn = 1.0 - g.w;
-        phiHbyA = g.Sf[0] * (wl * HbyA[3LL * o] + wn * HbyA[3LL * n]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * HbyA[3LL * n + 1])
-                  + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * HbyA[3LL * n + 2]);
+        T gPn[3] = {gradP[3LL * n], gradP[3LL * n + 1], gradP[3LL * n + 2]};
+        T Hn[3] = {HbyA[3LL * n], HbyA[3LL * n + 1], HbyA[3LL * n + 2]};
+        const double* Qr = cyclic_rotation(m, f);
+        if (Qr) { rot_vec<T>(Qr, gPn); rot_vec<T>(Qr, Hn); }
+        phiHbyA = g.Sf[0] * (wl * HbyA[3LL * o] + wn * Hn[0]) + g.Sf[1] * (wl * HbyA[3LL * o + 1] + wn * Hn[1])
+                  + g.Sf[2] * (wl * HbyA[3LL * o + 2] + wn * Hn[2]);
         T ro(1.0), rn(1.0);
         phiHbyA = phiHbyA - rel;  // MRF.makeRelative(phiHbyA) / makeRelative(interpolate(rho), phiHbyA)
         if (RHO) {
@@ -704,8 +751,8 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
             phiHbyA = (wl * ro + wn * rn) * phiHbyA;
         }
         T gp = (wl * (ro * rAU[o]) + wn * (rn * rAU[n])) * g.magSf;
-        T cg = g.corr[0] * (wl * gradP[3LL * o] + wn * gradP[3LL * n]) + g.corr[1] * (wl * gradP[3LL * o + 1] + wn * gradP[3LL * n + 1])
-               + g.corr[2] * (wl * gradP[3LL * o + 2] + wn * gradP[3LL * n + 2]);
+        T cg = g.corr[0] * (wl * gradP[3LL * o] + wn * gPn[0]) + g.corr[1] * (wl * gradP[3LL * o + 1] + wn * gPn[1])
+               + g.corr[2] * (wl * gradP[3LL * o + 2] + wn * gPn[2]);
         flux = gp * (g.nod * (W[prm.offP * N + n] - W[prm.offP * N + o]) + cg);
     } else {
         int c = m.owner[f];

@@ -132,6 +132,13 @@ void Mesh::build(const das_case_t* c) {
         b.dU_val[0] = b.dU_val[1] = b.dU_val[2] = 0.0;
         b.dp_val = b.dnuTilda_val = b.dT_val = 0.0;
         b.mrf_included = (c->mrf_active && c->patch_mrf_rotating) ? (c->patch_mrf_rotating[p] != 0) : 0;
+        b.rot = 0;
+        for (int k = 0; k < 9; k++) b.Q[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        if (patch_type[p] == DAS_PATCH_CYCLIC && c->patch_rotation) {
+            double dev = 0;
+            for (int k = 0; k < 9; k++) { b.Q[k] = c->patch_rotation[9 * p + k]; dev += std::fabs(b.Q[k] - ((k % 4 == 0) ? 1.0 : 0.0)); }
+            b.rot = dev > 1e-14;
+        }
     }
     DAS_CHECK(expect == nF, DAS_ERR_ARG, "patches do not cover all boundary faces");
     // cyclic pairs (cyclicPolyPatch: neighbPatch, same size, face k <-> face k)
@@ -239,15 +246,17 @@ void Mesh::compute_geometry(const double* y_wall) {
             for (int k = 0; k < 3; k++) g.corr[k] = g.Sf[k] / g.magSf - d[k] * g.nod;
         } else if (cyc_face[f - nIF] >= 0) {
             // cyclicFvPatch::makeWeights / delta() for a translational pair: the neighbour cell is the owner of the
-            // paired face, seen at  Cf - (Cf' - C')  (its image across the pair)
+            // paired face, seen at  Cf - Q (Cf' - C')  (its image across the pair)
             const int f2 = cyc_face[f - nIF];
             const FaceGeom& g2 = fg[f2];
             const double* C2 = cg[owner[f2]].C;
+            const double* Q = bc[bface_patch[f - nIF]].Q;  // forwardT: neighbour-side vectors -> this side
             double dOwn = 0, dNbr = 0, d[3], md = 0, nd = 0;
+            const double r2[3] = {g2.Cf[0] - C2[0], g2.Cf[1] - C2[1], g2.Cf[2] - C2[2]};
             for (int k = 0; k < 3; k++) {
                 dOwn += g.Sf[k] / g.magSf * (g.Cf[k] - Co[k]);
-                dNbr += g2.Sf[k] / g2.magSf * (g2.Cf[k] - C2[k]);
-                d[k] = (g.Cf[k] - Co[k]) - (g2.Cf[k] - C2[k]);
+                dNbr += g2.Sf[k] / g2.magSf * r2[k];
+                d[k] = (g.Cf[k] - Co[k]) - (Q[3 * k] * r2[0] + Q[3 * k + 1] * r2[1] + Q[3 * k + 2] * r2[2]);
                 md += d[k] * d[k];
             }
             for (int k = 0; k < 3; k++) nd += g.Sf[k] / g.magSf * d[k];

@@ -38,7 +38,8 @@ class Patch:
     type: str  # "patch" | "wall" | "symmetry" | "cyclic"
     start: int
     size: int
-    neighbour: Optional[str] = None  # cyclic: name of the paired patch (face k pairs with face k, translational)
+    neighbour: Optional[str] = None  # cyclic: name of the paired patch (face k pairs with face k)
+    rotation: Optional[np.ndarray] = None  # cyclic, rotational: 3x3 forwardT (neighbour-side vectors -> this side); None = translational
 
 
 @dataclass
@@ -415,68 +416,134 @@ def channel_case(
     return case
 
 
-def periodic_channel_case(nx=6, ny=5, nz=5, lengths=(1.0, 0.2, 0.1), copies=1, wall_function=False, perturb=0.02, seed=0, **kw) -> FoamCase:
-    """DASimpleFoam + SA channel that is translationally periodic in z: front/back are a cyclic patch pair (copies = 1).
-    copies > 1 emits the same block repeated `copies` times in z with ORDINARY front/back patches and the periodic
-    state repeated - the non-periodic "unrolled" mesh the tests use to check the cyclic implementation with the
-    unchanged oracle (the middle copy sees its periodic images as real neighbours)."""
+def _rot_x(a):
+    return np.array([[1.0, 0.0, 0.0], [0.0, np.cos(a), -np.sin(a)], [0.0, np.sin(a), np.cos(a)]])
+
+
+def periodic_channel_case(nx=6, ny=5, nz=5, lengths=(1.0, 0.2, 0.1), copies=1, wall_function=False, perturb=0.02, seed=0, sector=None,
+                          solver_name="DASimpleFoam", mrf_omega=None, transonic=False, **kw) -> FoamCase:
+    """SA channel that is periodic in its third direction: front/back are a cyclic patch pair (copies = 1).
+    sector=None: translational periodicity in z.  sector=(r0, dtheta): the block is bent into an annular sector about
+    the x axis (y -> radius r0 + y, z -> angle), i.e. ROTATIONAL periodicity - the cyclic pair carries the rotation
+    tensors forwardT = Rx(-+dtheta), vector fields are periodic in their cylindrical components.
+    solver_name: DASimpleFoam, or DARhoSimpleFoam / DATurboFoam (compressible states like rho_channel_case; mrf_omega =
+    angular velocity about the x axis with the hub (bottom) rotating, as in a compressor passage).
+    copies > 1 emits the same block repeated `copies` times in the periodic direction with ORDINARY front/back patches
+    and the periodic state repeated (rotated copy by copy) - the non-periodic "unrolled" mesh the tests use to check the
+    cyclic implementation with the unchanged oracle (the middle copy sees its periodic images as real neighbours; the
+    single periodic block coincides with the MIDDLE copy)."""
     Lx, Ly, Lz = lengths
-    base = channel_case(nx, ny, nz, lengths=lengths, wall_function=wall_function, perturb=0.0, seed=seed, **kw)
-    mesh1 = hex_block(nx, ny, nz, lengths, bump_mapping(kw.get("bump", 0.1), kw.get("skew", 0.15), Lx, Ly, z_periodic=True),
-                      patch_types=("patch", "patch", "wall", "wall", "cyclic", "cyclic"), grading_y=kw.get("grading_y", 1.0))
+    mid = 1  # the single periodic block sits where the middle of three unrolled copies sits
+    assert copies in (1, 3)
+    bump, skew, gy = kw.get("bump", 0.1), kw.get("skew", 0.15), kw.get("grading_y", 1.0)
+
+    def mapping(ncop, first):
+        base_map = bump_mapping(bump, skew, Lx, Ly, z_periodic=True)
+        if sector is None:
+            def f(p):
+                q = base_map(p)
+                q[:, 2] = q[:, 2] + first * Lz
+                return q
+            return f
+        r0, dth = sector
+
+        def f(p):
+            q = base_map(p)
+            th = (q[:, 2] / Lz + first) * dth
+            r = r0 + q[:, 1]
+            return np.stack([q[:, 0], r * np.cos(th), r * np.sin(th)], axis=1)
+        return f
+
+    types = ("patch", "patch", "wall", "wall", "cyclic", "cyclic")
+    mesh1 = hex_block(nx, ny, nz, lengths, mapping(1, mid), patch_types=types, grading_y=gy)
     for pt in mesh1.patches:
-        if pt.name == "front":
-            pt.neighbour = "back"
-        if pt.name == "back":
-            pt.neighbour = "front"
+        if pt.name in ("front", "back"):
+            pt.neighbour = "back" if pt.name == "front" else "front"
+            if sector is not None:  # neighbour-side vectors seen from this side: the neighbour image is rotated by -+dtheta
+                pt.rotation = _rot_x(-sector[1] if pt.name == "front" else sector[1])
     g = _InputGeometry(mesh1)
     y = wall_distance(mesh1, g.C, g.Cf, g.Sf)
+    base = channel_case(2, 2, 2, lengths=lengths, wall_function=wall_function, perturb=0.0)  # BC table template
     bcs = {k: dict(v) for k, v in base.bcs.items() if k not in ("front", "back")}
-    cyc = {"U": (BC_CYCLIC, (0.0, 0.0, 0.0)), "p": (BC_CYCLIC, 0.0), "nuTilda": (BC_CYCLIC, 0.0), "nut": (NUT_CALCULATED, 0.0)}
+    cyc = {"U": (BC_CYCLIC, (0.0, 0.0, 0.0)), "p": (BC_CYCLIC, 0.0), "nuTilda": (BC_CYCLIC, 0.0), "nut": (NUT_CALCULATED, 0.0), "T": (BC_CYCLIC, 0.0)}
     bcs["front"], bcs["back"] = dict(cyc), dict(cyc)
     rng = np.random.default_rng(seed)
     N, F, nIF = mesh1.n_cells, mesh1.n_faces, mesh1.n_internal_faces
-    U0, nuTilda0 = kw.get("U0", 10.0), kw.get("nuTilda0", 4.5e-5)
+    compressible = solver_name in ("DARhoSimpleFoam", "DATurboFoam")
+    U0 = kw.get("U0", 50.0 if compressible else 10.0)
+    nuTilda0 = kw.get("nuTilda0", 4.5e-5)
+    # box coordinates of the cell centres: (x, y = wall-normal / radial offset, zh = periodic coordinate in [0,1))
+    if sector is None:
+        yb, zh = g.C[:, 1], g.C[:, 2] / Lz - mid
+        e2 = np.tile([0.0, 1.0, 0.0], (N, 1))
+        e3 = np.tile([0.0, 0.0, 1.0], (N, 1))
+    else:
+        r0, dth = sector
+        rr, th = np.hypot(g.C[:, 1], g.C[:, 2]), np.arctan2(g.C[:, 2], g.C[:, 1])
+        yb, zh = rr - r0, th / dth - mid
+        e2 = np.stack([np.zeros(N), np.cos(th), np.sin(th)], axis=1)   # e_r
+        e3 = np.stack([np.zeros(N), -np.sin(th), np.cos(th)], axis=1)  # e_theta
     eta = np.clip(y / (0.5 * Ly), 0.0, 1.0)
     prof = eta ** (1.0 / 7.0)
-    xh, zh = g.C[:, 0] / Lx, g.C[:, 2] / Lz
-    U = np.zeros((N, 3))
-    U[:, 0] = U0 * prof * (1.0 + 0.3 * np.sin(np.pi * xh) ** 2) * (1.0 + 0.05 * np.sin(2 * np.pi * zh))
-    U[:, 1] = 0.05 * U0 * prof * np.sin(2 * np.pi * xh + 0.3)
-    U[:, 2] = 0.04 * U0 * prof * (0.5 + np.cos(2 * np.pi * zh + 0.4) * np.sin(np.pi * xh))
+    xh = g.C[:, 0] / Lx
+    u1 = U0 * prof * (1.0 + 0.3 * np.sin(np.pi * xh) ** 2) * (1.0 + 0.05 * np.sin(2 * np.pi * zh))
+    u2 = 0.05 * U0 * prof * np.sin(2 * np.pi * xh + 0.3)
+    u3 = 0.04 * U0 * prof * (0.5 + np.cos(2 * np.pi * zh + 0.4) * np.sin(np.pi * xh))
+    U = u1[:, None] * np.array([1.0, 0.0, 0.0]) + u2[:, None] * e2 + u3[:, None] * e3
     U *= 1.0 + perturb * rng.standard_normal((N, 1))
     p = 0.5 * U0 * U0 * 0.2 * (1.0 - xh) * (1.0 + 0.1 * np.sin(2 * np.pi * zh)) * (1.0 + perturb * rng.standard_normal(N))
     nuT = nuTilda0 * (1.0 + 20.0 * eta * (1.0 - 0.5 * eta)) * (1.0 + perturb * rng.standard_normal(N))
     own, nei = mesh1.owner, mesh1.neighbour
+    sl = {pt.name: slice(pt.start, pt.start + pt.size) for pt in mesh1.patches}
     phi = np.zeros(F)
     phi[:nIF] = np.einsum("ij,ij->i", g.w[:, None] * U[own[:nIF]] + (1 - g.w[:, None]) * U[nei], g.Sf[:nIF])
     phi[:nIF] *= 1.0 + perturb * rng.standard_normal(nIF)
-    sl = {pt.name: slice(pt.start, pt.start + pt.size) for pt in mesh1.patches}
     phi[sl["inlet"]] = U0 * g.Sf[sl["inlet"], 0]
     phi[sl["outlet"]] = np.einsum("ij,ij->i", U[own[sl["outlet"]]], g.Sf[sl["outlet"]])
     # periodic-consistent flux through the pair: phi_back(i,j) = -phi_front(i,j) (face k of front pairs with face k of back)
-    Ub = 0.5 * (U[own[sl["back"]]] + U[own[sl["front"]]])
-    phi[sl["back"]] = np.einsum("ij,ij->i", Ub, g.Sf[sl["back"]]) * (1.0 + perturb * rng.standard_normal(sl["back"].stop - sl["back"].start))
+    phi[sl["back"]] = np.einsum("ij,ij->i", U[own[sl["back"]]], g.Sf[sl["back"]]) * (1.0 + perturb * rng.standard_normal(sl["back"].stop - sl["back"].start))
     phi[sl["front"]] = -phi[sl["back"]]
-    case = FoamCase(mesh=mesh1, solver_name="DASimpleFoam", nu=base.nu, bcs=bcs, y_wall=y)
-    case.states = np.concatenate([U.ravel(), p, nuT, phi])
+    case = FoamCase(mesh=mesh1, solver_name=solver_name, nu=base.nu, bcs=bcs, y_wall=y)
+    if compressible:
+        p0, T0 = kw.get("p0", 101325.0), kw.get("T0", 300.0)
+        bcs["inlet"]["T"] = (BC_FIXED_VALUE, T0)
+        bcs["outlet"]["T"] = (BC_INLET_OUTLET, T0)
+        bcs["outlet"]["p"] = (BC_FIXED_VALUE, p0)
+        for nm in ("bottom", "top"):
+            bcs[nm]["T"] = (BC_ZERO_GRADIENT, 0.0)
+        case.relax = {"U": 0.7, "nuTilda": 0.7, "T": 0.9}
+        rho0 = p0 / (8314.47 / case.thermo["molWeight"] * T0)
+        T = T0 * (1.0 + 0.01 * np.sin(np.pi * xh) * np.cos(2 * np.pi * zh))
+        case.states = np.concatenate([U.ravel(), p0 + rho0 * p, T, nuT, rho0 * phi])
+        case.transonic = bool(transonic)
+        if mrf_omega is not None:
+            case.mrf = {"omega": (float(mrf_omega), 0.0, 0.0), "origin": (0.0, 0.0, 0.0), "nonRotatingPatches": ["inlet", "outlet", "top"]}
+    else:
+        case.states = np.concatenate([U.ravel(), p, nuT, phi])
+        if mrf_omega is not None:
+            case.mrf = {"omega": (float(mrf_omega), 0.0, 0.0), "origin": (0.0, 0.0, 0.0), "nonRotatingPatches": ["inlet", "outlet", "top"]}
     if copies == 1:
         return case
     # ---- unrolled copies: ordinary patches at the two ends, periodic repetition of geometry and state
-    meshC = hex_block(nx, ny, nz * copies, (Lx, Ly, Lz * copies), bump_mapping(kw.get("bump", 0.1), kw.get("skew", 0.15), Lx, Ly, z_periodic=True),
-                      patch_types=("patch", "patch", "wall", "wall", "patch", "patch"), grading_y=kw.get("grading_y", 1.0))
-    caseC_states = unroll_periodic_vector(mesh1, meshC, case.states, copies)
+    import copy as _copy
+
+    meshC = hex_block(nx, ny, nz * copies, (Lx, Ly, Lz * copies), mapping(copies, 0), patch_types=("patch", "patch", "wall", "wall", "patch", "patch"),
+                      grading_y=gy)
     bcsC = {k: dict(v) for k, v in bcs.items()}
-    zg = {"U": (BC_ZERO_GRADIENT, (0.0, 0.0, 0.0)), "p": (BC_ZERO_GRADIENT, 0.0), "nuTilda": (BC_ZERO_GRADIENT, 0.0), "nut": (NUT_CALCULATED, 0.0)}
+    zg = {"U": (BC_ZERO_GRADIENT, (0.0, 0.0, 0.0)), "p": (BC_ZERO_GRADIENT, 0.0), "nuTilda": (BC_ZERO_GRADIENT, 0.0), "nut": (NUT_CALCULATED, 0.0),
+          "T": (BC_ZERO_GRADIENT, 0.0)}
     bcsC["front"], bcsC["back"] = dict(zg), dict(zg)
-    caseC = FoamCase(mesh=meshC, solver_name="DASimpleFoam", nu=base.nu, bcs=bcsC, y_wall=np.tile(y, copies))
-    caseC.states = caseC_states
+    caseC = _copy.copy(case)
+    caseC.mesh, caseC.bcs, caseC.y_wall = meshC, bcsC, np.tile(y, copies)
+    caseC.states = unroll_periodic_vector(mesh1, meshC, case.states, copies, dtheta=None if sector is None else sector[1])
     return caseC
 
 
-def unroll_periodic_vector(mesh1: PolyMesh, meshC: PolyMesh, vec, copies):
-    """A state-like vector of the z-periodic block `mesh1` ([U|p|nuTilda|phi], front/back fluxes periodic-consistent:
-    phi_front = -phi_back) repeated onto the `copies`-fold unrolled block `meshC`."""
+def unroll_periodic_vector(mesh1: PolyMesh, meshC: PolyMesh, vec, copies, dtheta=None):
+    """A state-like vector of the periodic block `mesh1` ([U|p|(T)|nuTilda|phi], front/back fluxes periodic-consistent:
+    phi_front = -phi_back) repeated onto the `copies`-fold unrolled block `meshC` (mesh1 = its middle copy).  dtheta:
+    sector angle of a rotationally periodic block - the vector block U of copy m is rotated by (m - middle) dtheta
+    about the x axis."""
     N, F, nIF = mesh1.n_cells, mesh1.n_faces, mesh1.n_internal_faces
     NC, FC, nIFC = meshC.n_cells, meshC.n_faces, meshC.n_internal_faces
     own, nei = mesh1.owner, mesh1.neighbour
@@ -505,7 +572,11 @@ def unroll_periodic_vector(mesh1: PolyMesh, meshC: PolyMesh, vec, copies):
     for f in range(slC["back"].start, slC["back"].stop):
         phiC[f] = phi[back_of[int(cell1[meshC.owner[f]])]]
     Ublk = vec[: 3 * N].reshape(N, 3)
-    parts = [np.tile(Ublk, (copies, 1)).ravel()] + [np.tile(vec[(3 + b) * N : (4 + b) * N], copies) for b in range(nsc)] + [phiC]
+    if dtheta is not None:
+        Uall = np.concatenate([Ublk @ _rot_x((m - copies // 2) * dtheta).T for m in range(copies)])
+    else:
+        Uall = np.tile(Ublk, (copies, 1))
+    parts = [Uall.ravel()] + [np.tile(vec[(3 + b) * N : (4 + b) * N], copies) for b in range(nsc)] + [phiC]
     return np.concatenate(parts)
 
 

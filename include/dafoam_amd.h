@@ -43,7 +43,7 @@ extern "C" {
 #define DAS_PATCH_PATCH 0
 #define DAS_PATCH_WALL 1
 #define DAS_PATCH_SYMMETRY 2
-#define DAS_PATCH_CYCLIC 3 /* coupled pair (translational): face k of the patch pairs with face k of patch_neighbour */
+#define DAS_PATCH_CYCLIC 3 /* coupled pair (translational or rotational): face k of the patch pairs with face k of patch_neighbour */
 
 /* boundary-condition codes per patch and field */
 #define DAS_BC_FIXED_VALUE 0
@@ -105,9 +105,12 @@ typedef struct das_case {
     /* DASimpleFoam with the optional passive T field (reference DAResidualSimpleFoam.C:50-76,215-235; states
      * [U | p | T | nuTilda | phi], DAStateInfoSimpleFoam.C:118-131); Pr / Prt above are then transportProperties' */
     int simple_has_T;
-    /* cyclic (coupled) patches, OpenFOAM cyclicFvPatch semantics for a TRANSLATIONAL pair: per patch the index of the
-     * paired patch (-1 for ordinary patches); may be NULL if no patch is cyclic */
+    /* cyclic (coupled) patches, OpenFOAM cyclicFvPatch semantics: per patch the index of the paired patch (-1 for
+     * ordinary patches; may be NULL if no patch is cyclic) and, for rotational pairs, the tensor forwardT (row-major 3x3
+     * per patch) that carries neighbour-side vectors into this side's frame (cyclicPolyPatch::forwardT; identity /
+     * NULL for translational pairs; the partner patch holds the transpose) */
     const int* patch_neighbour;
+    const double* patch_rotation;
 } das_case_t;
 
 const char* das_last_error(void);

@@ -244,17 +244,20 @@ def test_patch_functions_values_and_gradients(solver):
                                          "outletPatches": ["outlet"]}})
 
 
-def test_cyclic_pair_residual_jacobian_adjoint():
-    """Translational cyclic (coupled) patch pair through the GPU path: residuals (PC / non-PC) against the unchanged
-    oracle on the three-fold unrolled twin of the periodic block, the assembled dual-number dRdWT against the
-    column-by-column forward-mode Jacobian of the host-emulated kernel bodies (test harness), and the adjoint vector
-    against a sparse direct solve."""
+@pytest.mark.parametrize("variant", ["translational", "turbo_sector"])
+def test_cyclic_pair_residual_jacobian_adjoint(variant):
+    """Cyclic (coupled) patch pairs through the GPU path - a translational pair (DASimpleFoam) and the compressor-passage
+    configuration (DATurboFoam, annular sector with a ROTATIONAL pair, MRF about the axis, rotating hub): residuals
+    (PC / non-PC) against the unchanged oracle on the three-fold unrolled twin of the periodic block, the assembled
+    dual-number dRdWT against the column-by-column forward-mode Jacobian of the host-emulated kernel bodies (test
+    harness), and the adjoint vector against a sparse direct solve."""
     import scipy.sparse as sp
     from dafoam_amd.pyDASolvers import Mat
     from test_host_cpu import _emu_res
 
-    c1 = periodic_channel_case(6, 5, 5, wall_function=True)
-    c3 = periodic_channel_case(6, 5, 5, copies=3, wall_function=True)
+    kw = {} if variant == "translational" else dict(sector=(0.5, 0.12), solver_name="DATurboFoam", mrf_omega=60.0)
+    c1 = periodic_channel_case(6, 5, 5, wall_function=True, **kw)
+    c3 = periodic_channel_case(6, 5, 5, copies=3, wall_function=True, **kw)
     idx, sgn = unrolled_maps(c1, c3)
     g1, g3 = Geometry(c1.mesh), Geometry(c3.mesh)
     W = c1.states
@@ -267,7 +270,7 @@ def test_cyclic_pair_residual_jacobian_adjoint():
         ref = residual(c3, g3, c3.states, isPC=bool(pc))[idx] * sgn
         for nm, sl in blocks(c1, g1):
             assert relerr(R[sl], ref[sl]) < 1e-11, (pc, nm)
-    sc = J.state_scales(c1, g1, NORM_STATES)
+    sc = J.state_scales(c1, g1, norm_states(c1))
     dense = np.zeros((n, n))  # dense[j, i] = s_j dR_i/dW_j
     for j in range(n):
         e = np.zeros(n)
