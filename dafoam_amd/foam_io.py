@@ -107,11 +107,39 @@ def read_boundary(path):
     for name, d in ent.items():
         t = d.get("type", "patch")
         t = {"symmetryPlane": "symmetry", "empty": "symmetry"}.get(t, t)
-        if t not in ("patch", "wall", "symmetry"):
-            raise NotImplementedError(f"patch type {t} of {name} is outside the hot path (processor/cyclic patches: see DESIGN.md)")
-        patches.append(Patch(name, t, int(d["startFace"]), int(d["nFaces"])))
+        if t not in ("patch", "wall", "symmetry", "cyclic"):
+            raise NotImplementedError(f"patch type {t} of {name} is outside the hot path (processor / AMI patches: see DESIGN.md)")
+        pt = Patch(name, t, int(d["startFace"]), int(d["nFaces"]))
+        if t == "cyclic":
+            pt.neighbour = d["neighbourPatch"].strip()
+            pt._transform = {k: d[k].strip() for k in ("transform", "rotationAxis", "rotationCentre", "separationVector") if k in d}
+        patches.append(pt)
     patches.sort(key=lambda p: p.start)
     return patches
+
+
+def _cyclic_rotations(mesh: PolyMesh):
+    """forwardT of rotational cyclic pairs (cyclicPolyPatch: rotationAxis / rotationCentre; the angle follows from the
+    first face pair): the rotation that carries neighbour-side vectors into this side's frame."""
+    by_name = {p.name: p for p in mesh.patches}
+    for pt in mesh.patches:
+        tr = getattr(pt, "_transform", None)
+        if pt.type != "cyclic" or not tr or tr.get("transform", "translational") != "rotational":
+            continue
+        axis = np.array(re.sub(r"[()]", " ", tr["rotationAxis"]).split(), dtype=np.float64)
+        axis /= np.linalg.norm(axis)
+        centre = np.array(re.sub(r"[()]", " ", tr.get("rotationCentre", "(0 0 0)")).split(), dtype=np.float64)
+        nb = by_name[pt.neighbour]
+
+        def fc(f):
+            v = mesh.face_pts[mesh.face_ptr[f] : mesh.face_ptr[f + 1]]
+            return mesh.points[v].mean(0) - centre
+
+        a, b = fc(pt.start), fc(nb.start)  # this side, neighbour side
+        a, b = a - axis * (a @ axis), b - axis * (b @ axis)
+        ang = np.arctan2(np.cross(b, a) @ axis, b @ a)  # rotating the neighbour side by `ang` about the axis lands on this side
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        pt.rotation = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
 
 
 def read_polymesh(case_dir):
@@ -121,6 +149,7 @@ def read_polymesh(case_dir):
                     neighbour=read_labels(os.path.join(pm, "neighbour")), patches=read_boundary(os.path.join(pm, "boundary")))
     nB = sum(p.size for p in mesh.patches)
     assert mesh.n_internal_faces + nB == mesh.n_faces, "boundary does not cover all boundary faces"
+    _cyclic_rotations(mesh)
     return mesh
 
 
@@ -144,8 +173,22 @@ def write_polymesh(case_dir, mesh: PolyMesh):
     with open(os.path.join(pm, "boundary"), "w") as f:
         f.write(_HEADER.format(cls="polyBoundaryMesh", loc="constant/polyMesh", obj="boundary"))
         f.write(f"{len(mesh.patches)}\n(\n")
+        by_name = {p.name: p for p in mesh.patches}
         for p in mesh.patches:
-            f.write(f"    {p.name}\n    {{\n        type            {p.type};\n        nFaces          {p.size};\n        startFace       {p.start};\n    }}\n")
+            extra = ""
+            if p.type == "cyclic":
+                extra = f"        neighbourPatch  {p.neighbour};\n"
+                if p.rotation is not None:  # axis-angle of forwardT
+                    Q = np.asarray(p.rotation, dtype=np.float64).reshape(3, 3)
+                    ax = np.array([Q[2, 1] - Q[1, 2], Q[0, 2] - Q[2, 0], Q[1, 0] - Q[0, 1]])
+                    ax = ax / np.linalg.norm(ax) if np.linalg.norm(ax) > 0 else np.array([1.0, 0.0, 0.0])
+                    extra += "        transform       rotational;\n        rotationAxis    (%.17g %.17g %.17g);\n        rotationCentre  (0 0 0);\n" % tuple(np.abs(ax))
+                else:
+                    def fc(f):
+                        return mesh.points[mesh.face_pts[mesh.face_ptr[f] : mesh.face_ptr[f + 1]]].mean(0)
+                    sep = fc(by_name[p.neighbour].start) - fc(p.start)
+                    extra += "        transform       translational;\n        separationVector (%.17g %.17g %.17g);\n" % tuple(sep)
+            f.write(f"    {p.name}\n    {{\n        type            {p.type};\n{extra}        nFaces          {p.size};\n        startFace       {p.start};\n    }}\n")
         f.write(")\n")
 
 

@@ -259,6 +259,25 @@ def test_degenerate_meshes(dims):
         assert nc == W.size
 
 
+@pytest.mark.parametrize("sector", [None, (0.5, 0.12)])
+def test_openfoam_boundary_cyclic_roundtrip(tmp_path, sector):
+    """constant/polyMesh/boundary with a cyclic pair (neighbourPatch, transform translational / rotational): written and
+    read back; the rotation tensor forwardT is recovered from rotationAxis / rotationCentre and the first face pair."""
+    from dafoam_amd import foam_io
+
+    c = periodic_channel_case(4, 3, 4, sector=sector)
+    foam_io.write_polymesh(str(tmp_path), c.mesh)
+    txt = open(tmp_path / "constant" / "polyMesh" / "boundary").read()
+    assert "neighbourPatch  back;" in txt and ("rotational" if sector else "separationVector") in txt
+    m = foam_io.read_polymesh(str(tmp_path))
+    for p0, p1 in zip(c.mesh.patches, m.patches):
+        assert (p0.name, p0.type, p0.neighbour, p0.start, p0.size) == (p1.name, p1.type, p1.neighbour, p1.start, p1.size)
+        if p0.rotation is None:
+            assert p1.rotation is None
+        else:
+            assert np.abs(p0.rotation - p1.rotation).max() < 1e-14
+
+
 def test_write_adjoint_fields(tmp_path):
     """writeAdjointFields (reference DASolver.C:4055-4160): psi as adjoint_<function>_<state> OpenFOAM fields, read back."""
     from dafoam_amd import foam_io
