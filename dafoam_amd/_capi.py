@@ -193,6 +193,8 @@ _SIGS = {
     "das_get_residuals": (C.c_int, [_VP, c_double_p]),
     "das_calc_residuals": (C.c_int, [_VP, C.c_int, c_double_p]),
     "das_run_coloring": (C.c_int, [_VP]),
+    "das_update_of_mesh": (C.c_int, [_VP, c_double_p]),
+    "das_get_of_mesh_points": (C.c_int, [_VP, c_double_p]),
     "das_set_coloring": (C.c_int, [_VP, c_int_p]),
     "das_debug_factor_block": (C.c_int, [C.c_int, c_ll_p, c_int_p, c_double_p, C.c_int, c_double_p, c_ll_p, c_int_p, c_int_p]),
     "das_get_n_colors": (C.c_int, [_VP, C.c_int]),

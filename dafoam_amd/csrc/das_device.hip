@@ -655,11 +655,16 @@ struct das_solver {
         DevBuf<unsigned char> d_group;
         DevBuf<double> d_w0, d_weff, d_dir;
         bool uploaded = false;
+        // definition (kept so that the geometry-dependent weights / directions can be rebuilt after updateOFMesh)
+        bool isMoment = false;
+        double vecA[3] = {0, 0, 0}, vecB[3] = {0, 0, 0}, scale = 1.0;
+        long long geomVersion = -1;
         FaceFnView view(const double* w) const {
             return FaceFnView{d_faces.p, d_group.p, w, dir.empty() ? nullptr : d_dir.p, (int)faces.size(), kind, gammaFn, RFn};
         }
     };
     std::map<std::string, FaceFn> functions;
+    long long geomVersion = 0;  // bumped by das_update_of_mesh
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<unsigned char> owned;  // per state; empty = single-domain
@@ -1550,6 +1555,34 @@ long long das_get_n_global_cells(das_solver_t* s) { return s ? s->mesh.nC : -1; 
 long long das_get_n_local_points(das_solver_t* s) { return s ? s->mesh.nP : -1; }
 long long das_get_n_local_faces(das_solver_t* s) { return s ? s->mesh.nF : -1; }
 
+// DASolver::updateOFMesh (reference pyDASolvers.pyx:297-300): new point coordinates -> fvMesh metrics recomputed, the
+// device copies refreshed.  Matrices assembled before the call keep describing the old mesh (the caller rebuilds them,
+// like the reference after setVolCoords); the frozen wall distance is kept (DASpalartAllmaras.C:94).
+int das_update_of_mesh(das_solver_t* s, const double* points) {
+    DAS_TRY
+    DAS_CHECK(s && points, DAS_ERR_ARG, "null argument");
+    Mesh& m = s->mesh;
+    std::vector<double> y(m.nC);
+    for (int c = 0; c < m.nC; c++) y[c] = m.cg[c].y;
+    m.points.assign(points, points + 3 * (size_t)m.nP);
+    m.compute_geometry(y.data());
+    s->geomVersion++;
+    if (s->inited) {
+        DAS_HIP(hipStreamSynchronize(s->stream));
+        s->d_fg.upload(m.fg);
+        s->d_cg.upload(m.cg);
+    }
+    compute_scales(s);
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_get_of_mesh_points(das_solver_t* s, double* points) {
+    DAS_TRY
+    DAS_CHECK(s && points, DAS_ERR_ARG, "null argument");
+    std::copy(s->mesh.points.begin(), s->mesh.points.end(), points);
+    return DAS_OK;
+    DAS_CATCH
+}
 int das_get_geometry(das_solver_t* s, double* Sf, double* Cf, double* C, double* V, double* w, double* nod, double* corr, double* bdc) {
     DAS_TRY
     DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
@@ -1744,6 +1777,33 @@ int das_set_old_time_fields(das_solver_t* s, const double* phi_frozen, const dou
     DAS_CATCH
 }
 
+// geometry-dependent part of a face function: per-face weights (scale, area fractions) and directions (moment arms)
+static void build_function_geometry(das_solver* s, das_solver::FaceFn& fn) {
+    const size_t nf = fn.faces.size();
+    double area[2] = {0.0, 0.0};
+    for (size_t k = 0; k < nf; k++) area[fn.group[k]] += s->mesh.fg[fn.faces[k]].magSf;
+    DAS_CHECK(!fn.ratio || (area[0] > 0 && area[1] > 0), DAS_ERR_ARG, "inlet/outletPatches names are not in patches");
+    fn.w0.resize(nf);
+    if (fn.kind == DAS_FN_FORCE) fn.dir.resize(3 * nf);
+    for (size_t k = 0; k < nf; k++) {
+        const FaceGeom& g = s->mesh.fg[fn.faces[k]];
+        if (fn.kind == DAS_FN_FORCE) {
+            if (!fn.isMoment) for (int d = 0; d < 3; d++) fn.dir[3 * k + d] = fn.vecA[d];
+            else {  // (r x F) . axis = F . (axis x r),  r = Cf - center
+                const double r[3] = {g.Cf[0] - fn.vecB[0], g.Cf[1] - fn.vecB[1], g.Cf[2] - fn.vecB[2]};
+                fn.dir[3 * k] = fn.vecA[1] * r[2] - fn.vecA[2] * r[1];
+                fn.dir[3 * k + 1] = fn.vecA[2] * r[0] - fn.vecA[0] * r[2];
+                fn.dir[3 * k + 2] = fn.vecA[0] * r[1] - fn.vecA[1] * r[0];
+            }
+            fn.w0[k] = fn.scale;
+        } else if (fn.kind == DAS_FN_MASSFLOW) fn.w0[k] = fn.scale;
+        else if (fn.kind == DAS_FN_TOTALPRESSURE) fn.w0[k] = fn.scale * g.magSf / area[0];  // area average, DAFunctionTotalPressure.C:77
+        else fn.w0[k] = g.magSf / area[fn.group[k]];                                          // TTIn / TTOut area averages
+    }
+    fn.geomVersion = s->geomVersion;
+    fn.uploaded = false;
+}
+
 // ---- objective functions (reference "function" option dict: DAFunctionForce, DAFunctionMoment, DAFunctionMassFlowRate,
 //      DAFunctionTotalPressure, DAFunctionTotalTemperatureRatio) ------------------------------------------------------
 int das_define_face_function(das_solver_t* s, const char* name, const char* type, const int* patch_ids, const int* patch_group, int npatch,
@@ -1772,37 +1832,20 @@ int das_define_face_function(das_solver_t* s, const char* name, const char* type
         fn.gammaFn = gammaFn;
         fn.RFn = s->cp.Cp - s->cp.Cp / gammaFn;  // DAFunctionTotalTemperatureRatio.C:98
     }
-    double area[2] = {0.0, 0.0};
     for (int k = 0; k < npatch; k++) {
         const int p = patch_ids[k];
         DAS_CHECK(p >= 0 && p < s->mesh.nPatch, DAS_ERR_ARG, "patch id out of range");
+        DAS_CHECK(s->mesh.patch_type[p] != DAS_PATCH_CYCLIC, DAS_ERR_ARG, "functions cannot be defined on cyclic patches");
         const int grp = (fn.ratio && patch_group[k]) ? 1 : 0;
         for (int q = 0; q < s->mesh.patch_size[p]; q++) {
-            const int f = s->mesh.patch_start[p] + q;
-            fn.faces.push_back(f);
+            fn.faces.push_back(s->mesh.patch_start[p] + q);
             fn.group.push_back((unsigned char)grp);
-            area[grp] += s->mesh.fg[f].magSf;
         }
     }
-    DAS_CHECK(!fn.ratio || (area[0] > 0 && area[1] > 0), DAS_ERR_ARG, "inlet/outletPatches names are not in patches");
-    const size_t nf = fn.faces.size();
-    fn.w0.resize(nf);
-    if (fn.kind == DAS_FN_FORCE) fn.dir.resize(3 * nf);
-    for (size_t k = 0; k < nf; k++) {
-        const FaceGeom& g = s->mesh.fg[fn.faces[k]];
-        if (fn.kind == DAS_FN_FORCE) {
-            if (ty == "force") for (int d = 0; d < 3; d++) fn.dir[3 * k + d] = vecA[d];
-            else {  // (r x F) . axis = F . (axis x r),  r = Cf - center
-                const double r[3] = {g.Cf[0] - vecB[0], g.Cf[1] - vecB[1], g.Cf[2] - vecB[2]};
-                fn.dir[3 * k] = vecA[1] * r[2] - vecA[2] * r[1];
-                fn.dir[3 * k + 1] = vecA[2] * r[0] - vecA[0] * r[2];
-                fn.dir[3 * k + 2] = vecA[0] * r[1] - vecA[1] * r[0];
-            }
-            fn.w0[k] = scale;
-        } else if (fn.kind == DAS_FN_MASSFLOW) fn.w0[k] = scale;
-        else if (fn.kind == DAS_FN_TOTALPRESSURE) fn.w0[k] = scale * g.magSf / area[0];  // area average, DAFunctionTotalPressure.C:77
-        else fn.w0[k] = g.magSf / area[fn.group[k]];                                       // TTIn / TTOut area averages
-    }
+    fn.isMoment = ty == "moment";
+    fn.scale = scale;
+    for (int d = 0; d < 3; d++) { fn.vecA[d] = vecA ? vecA[d] : 0.0; fn.vecB[d] = vecB ? vecB[d] : 0.0; }
+    build_function_geometry(s, fn);
     s->functions[name] = std::move(fn);
     return DAS_OK;
     DAS_CATCH
@@ -1814,6 +1857,7 @@ static das_solver::FaceFn& get_function(das_solver* s, const char* name) {
     auto it = s->functions.find(name ? name : "");
     DAS_CHECK(it != s->functions.end(), DAS_ERR_ARG, std::string("function not defined: ") + (name ? name : "(null)"));
     das_solver::FaceFn& fn = it->second;
+    if (fn.geomVersion != s->geomVersion) build_function_geometry(s, fn);
     if (!fn.uploaded) {
         fn.d_faces.upload(fn.faces);
         fn.d_group.upload(fn.group);

@@ -424,7 +424,43 @@ class pyDASolvers:
 
     def getOFMeshPoints(self, points):
         assert len(points) == self.getNLocalPoints() * 3, "invalid array size!"
-        points[:] = self._case.mesh.points.ravel()
+        check(lib().das_get_of_mesh_points(self._h, dptr(points)))
+
+    def updateOFMesh(self, vol_coords):
+        """pyDASolvers.pyx:297-300 (PYDAFOAM.setVolCoords, pyDAFoam.py:2111-2117): new point coordinates; the library
+        recomputes the fvMesh metrics (the wall distance stays frozen).  Jacobians assembled earlier describe the old
+        mesh and have to be rebuilt by the caller, as in the reference."""
+        assert len(vol_coords) == self.getNLocalPoints() * 3, "invalid array size!"
+        check(lib().das_update_of_mesh(self._h, dptr(np.ascontiguousarray(vol_coords, dtype=np.float64))))
+
+    def calcVolCoordDirectionalProduct(self, dX, outputName, outputType, seeds, eps=1e-6):
+        """seeds^T (dOutput/dX . dX) for ONE direction dX of the mesh points (e.g. the volume-mesh sensitivity of one
+        FFD design variable), by a central difference of the geometry: two metric updates + two residual (or objective)
+        evaluations on the device.  The reference returns the full product vector of calcJacTVecProduct(volCoord -> ...)
+        from one reverse sweep of its AD tape (DASolver.C:1690-1839); without a tape the per-design-variable form is the
+        one that maps to forward evaluations - the design variables of a shape optimisation are few.
+        eps is relative to max|dX| (step = eps * characteristic point spacing / max|dX| is the caller's choice: here the
+        points move by eps * dX)."""
+        n3 = self.getNLocalPoints() * 3
+        assert len(dX) == n3, "invalid array size!"
+        X0 = np.zeros(n3)
+        self.getOFMeshPoints(X0)
+        dX = np.asarray(dX, dtype=np.float64)
+        vals = []
+        try:
+            for sgn in (1.0, -1.0):
+                self.updateOFMesh(X0 + sgn * eps * dX)
+                if outputType == "residual":
+                    R = np.zeros(self.getNLocalAdjointStates())
+                    check(lib().das_get_residuals(self._h, dptr(R)))
+                    vals.append(float(np.dot(self._to_state(np.asarray(seeds, dtype=np.float64)), R)))
+                elif outputType == "function":
+                    vals.append(float(seeds[0]) * self.calcFunction(outputName))
+                else:
+                    raise _capi.DASError(f"outputType not supported on this path: {outputType}")
+        finally:
+            self.updateOFMesh(X0)
+        return (vals[0] - vals[1]) / (2.0 * eps)
 
     def geometry(self):
         """fvMesh metrics computed by the library (host side)."""

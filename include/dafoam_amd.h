@@ -138,6 +138,11 @@ long long das_get_n_global_cells(das_solver_t* s);
 long long das_get_n_local_points(das_solver_t* s);
 long long das_get_n_local_faces(das_solver_t* s);
 
+/* das_update_of_mesh <- updateOFMesh(vol_coords)  pyDASolvers.pyx:297-300 (PYDAFOAM.setVolCoords, pyDAFoam.py:2111-2117):
+ *   new point coordinates (3 * n_points); metrics are recomputed and re-uploaded, the wall distance stays frozen.
+ * das_get_of_mesh_points <- getOFMeshPoints  pyDASolvers.pyx:278 */
+int das_update_of_mesh(das_solver_t* s, const double* points);
+int das_get_of_mesh_points(das_solver_t* s, double* points);
 /* ---- host-side mesh geometry (fvMesh metrics; no GPU needed) - used by tests and input generators */
 int das_get_geometry(das_solver_t* s, double* Sf /*3F*/, double* Cf /*3F*/, double* C /*3N*/, double* V /*N*/,
                      double* weights /*Fi*/, double* nonOrthDeltaCoeffs /*Fi*/, double* nonOrthCorr /*3Fi*/,

@@ -555,6 +555,66 @@ def test_total_derivative_patch_velocity_vs_primal_fd():
         D2.solver.setSolverInput("w", "patchVar", 1, np.array([1.0]))
 
 
+def test_shape_total_derivative_vs_primal_fd():
+    """Shape sensitivity end to end (the purpose of the adjoint): design variable = height of the wall bump, i.e. a
+    displacement field dX of the mesh points.  dF/db = dF/dX.dX - psi^T dR/dX.dX with psi, both directional mesh
+    products (updateOFMesh + central difference of the metrics, calcVolCoordDirectionalProduct) and dFdW from the GPU,
+    against central differences of the oracle's CONVERGED primal on the deformed meshes (frozen wall distance, like the
+    reference's meshWaveFrozen).  The partial products are also checked against the oracle's geometry differences."""
+    import copy
+
+    from oracle.functions import force
+    from oracle.primal import solve_primal
+
+    dims, kw, b0 = (10, 8, 6), dict(lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.0), 0.1
+    base = converged_case(dims, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(base.mesh)
+    W = base.states
+    walls, d = ["bottom", "top"], [1.0, 0.0, 0.0]
+
+    def case_at(b):
+        c = channel_case(*dims, bump=b, **kw)
+        c.y_wall = base.y_wall
+        return c
+
+    h = 1e-4
+    dX = ((case_at(b0 + h).mesh.points - case_at(b0 - h).mesh.points) / (2 * h)).ravel()
+    D = make(base, adjEqnOption={"gmresRelTol": 1e-12, "gmresAbsTol": 1e-16, "gmresMaxIters": 400, "printInfo": 0},
+             function={"CD": {"type": "force", "source": "patchToFace", "patches": walls, "directionMode": "fixedDirection",
+                              "direction": d, "scale": 1.0}})
+    n = W.size
+    dFdW = np.zeros(n)
+    D.solverAD.calcJacTVecProduct("states", "stateVar", W, "CD", "function", np.ones(1), dFdW)
+    psi, fail = D.solveAdjoint(dFdW)
+    assert fail == 0
+    pF = D.solverAD.calcVolCoordDirectionalProduct(dX, "CD", "function", np.ones(1), eps=1e-6)
+    pR = D.solverAD.calcVolCoordDirectionalProduct(dX, "residual", "residual", psi, eps=1e-6)
+    # the mesh is back where it was
+    X = np.zeros(dX.size)
+    D.solverAD.getOFMeshPoints(X)
+    assert np.array_equal(X, base.mesh.points.ravel())
+    # partials against the oracle on the two displaced meshes
+    eps = 1e-6
+    ca, cb = copy.copy(base), copy.copy(base)
+    ca.mesh, cb.mesh = copy.copy(base.mesh), copy.copy(base.mesh)
+    ca.mesh.points = base.mesh.points + eps * dX.reshape(-1, 3)
+    cb.mesh.points = base.mesh.points - eps * dX.reshape(-1, 3)
+    ga, gb = Geometry(ca.mesh), Geometry(cb.mesh)
+    refR = psi @ ((residual(ca, ga, W) - residual(cb, gb, W)) / (2 * eps))
+    refF = (force(ca, ga, W, walls, d) - force(cb, gb, W, walls, d)) / (2 * eps)
+    assert abs(pR - refR) <= 1e-6 * abs(refR) and abs(pF - refF) <= 1e-6 * abs(refF)
+    total = pF - pR
+    hh = 3e-3
+    Fs = []
+    for sgn in (1, -1):
+        c3 = case_at(b0 + sgn * hh)
+        g3 = Geometry(c3.mesh)
+        W3, _ = solve_primal(c3, g3, W0=W, max_iters=3000, tol=1e-12)
+        Fs.append(force(c3, g3, W3, walls, d))
+    fd = (Fs[0] - Fs[1]) / (2 * hh)
+    assert abs(total - fd) <= 3e-4 * abs(fd), (total, fd)
+
+
 @pytest.mark.parametrize("kind", ["simple", "rho", "scalar"])
 def test_forward_mode_jac_vec_product(kind):
     """calcJacVecProduct (one dual-number residual pass) against the oracle's complex-step directional derivative, and

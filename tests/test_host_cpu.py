@@ -278,6 +278,28 @@ def test_openfoam_boundary_cyclic_roundtrip(tmp_path, sector):
             assert np.abs(p0.rotation - p1.rotation).max() < 1e-14
 
 
+def test_update_of_mesh_recomputes_metrics():
+    """updateOFMesh (reference pyDASolvers.pyx:297-300): the library's fvMesh metrics after moving the points equal the
+    oracle's geometry of the moved mesh; the wall distance stays frozen; getOFMeshPoints returns the new points."""
+    import copy
+
+    case = channel_case(6, 5, 4, wall_function=True)
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    moved = channel_case(6, 5, 4, wall_function=True, bump=0.13, skew=0.1)
+    X = np.ascontiguousarray(moved.mesh.points.ravel())
+    s.updateOFMesh(X)
+    back = np.zeros(X.size)
+    s.getOFMeshPoints(back)
+    assert np.array_equal(back, X)
+    geo = s.geometry()
+    g = Geometry(moved.mesh)
+    nIF = g.nIF
+    assert relerr(geo["Sf"].reshape(-1, 3), np.concatenate([g.Sf[:nIF], g.bSf])) < 1e-13 and relerr(geo["V"], g.V) < 1e-13
+    assert relerr(geo["w"], g.w) < 1e-13 and relerr(geo["nonOrthDeltaCoeffs"], g.nonOrthDeltaCoeffs) < 1e-13
+    with pytest.raises(AssertionError):
+        s.updateOFMesh(X[:-3])
+
+
 def test_write_adjoint_fields(tmp_path):
     """writeAdjointFields (reference DASolver.C:4055-4160): psi as adjoint_<function>_<state> OpenFOAM fields, read back."""
     from dafoam_amd import foam_io
