@@ -55,10 +55,14 @@ def main():
     dev_index = 0 if os.environ.get("DAS_BENCH_ONE_GPU") == "1" else local_rank
     torch.cuda.set_device(dev_index)
     if world > 1:
+        import datetime
+
+        # a bounded collective timeout: a peer that never arrives aborts the job instead of hanging the node
+        tmo = datetime.timedelta(seconds=int(os.environ.get("DAS_BENCH_COLLECTIVE_TIMEOUT", 900)))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
     # host-side setup (pattern build, ILU factorisation) is OpenMP-parallel: give every rank its share of the cores
     # (torch.distributed.run exports OMP_NUM_THREADS=1 when it is unset; the library reads it when it is loaded below)
