@@ -123,6 +123,9 @@ class PYDAFOAM(object):
         for name, value in options.items():
             self._initOption(name, value)
         self._case = case
+        # patch names of the case (the reference reads constant/polyMesh/boundary, pyDAFoam.py:1553-1563)
+        self.boundaries = {p.name: {"type": p.type, "nFaces": p.size, "startFace": p.start} for p in case.mesh.patches} if case is not None else {}
+        self._checkOptions()
         self._initSolver()
         self.dRdWTPC = None
         self.ksp = None
@@ -184,6 +187,20 @@ class PYDAFOAM(object):
         plain = {k: v[1] for k, v in self.options.items()}
         self.solver.updateDAOption(plain)
 
+    def _checkOptions(self):
+        """pyDAFoam.py:846-899: combinations of options that cannot work are rejected before the solver is built."""
+        if self.getOption("useAD")["mode"] not in ["reverse", "forward"]:
+            raise Error("useAD->mode only supports reverse, or forward!")
+        if self.getOption("discipline") not in ["aero", "thermal"]:
+            raise Error("discipline: %s not supported. Options are: aero or thermal" % self.getOption("discipline"))
+        for key, label in (("primalBC", "primalBC"), ("function", "function")):
+            for objKey, entry in self.getOption(key).items():
+                patches = entry.get("patches") if isinstance(entry, dict) else None
+                for patchName in patches or []:
+                    if patchName not in self.boundaries.keys():
+                        raise Error("%s-%s-patches-%s is not valid. Please use a patchName from the boundaries list: %s"
+                                    % (label, objKey, patchName, self.boundaries.keys()))
+
     # ---------------------------------------------------------------- solver init (pyDAFoam.py:1417-1452)
     def _initSolver(self):
         solverName = self.getOption("solverName")
@@ -207,6 +224,50 @@ class PYDAFOAM(object):
 
     def getNLocalAdjointStates(self):
         return self.solver.getNLocalAdjointStates()
+
+    def getNLocalPoints(self):
+        return self.solver.getNLocalPoints()
+
+    def setVolCoords(self, vol_coords):
+        """pyDAFoam.py:2111-2119"""
+        self.solver.updateOFMesh(vol_coords)
+        if self.solverAD is not self.solver:
+            self.solverAD.updateOFMesh(vol_coords)
+
+    def getResiduals(self):
+        """pyDAFoam.py:2121-2130"""
+        residuals = np.zeros(self.solver.getNLocalAdjointStates(), self.dtype)
+        self.solver.getResiduals(residuals)
+        return residuals
+
+    def evalFunctions(self, funcs):
+        """pyDAFoam.py:917-939: funcs[name] = value for every entry of the "function" option (steady solvers: the
+        time-operator value is the function value at the current states)."""
+        for funcName in list(self.getOption("function").keys()):
+            funcs[funcName] = self.solver.calcFunction(funcName)
+
+    def calcPrimalResidualStatistics(self, mode):
+        """pyDAFoam.py:901-905"""
+        return self.solverAD.calcPrimalResidualStatistics(mode)
+
+    def writeAdjointFields(self, function, writeTime, psi, caseDir="."):
+        """pyDAFoam.py:907-915"""
+        if self.getOption("writeAdjointFields"):
+            if len(self.getOption("function").keys()) > 1:
+                raise Error("writeAdjointFields supports only one function, while multiple are defined!")
+            return self.solver.writeAdjointFields(function, writeTime, psi, caseDir=caseDir)
+
+    def arrayVal2Vec(self, array1, vec):
+        """pyDAFoam.py:2132-2149"""
+        Istart, Iend = vec.getOwnershipRange()
+        assert Iend - Istart == len(array1), "array1 and vec must have the same size"
+        vec.array[Istart:Iend] = array1
+
+    def vecVal2Array(self, vec, array1):
+        """pyDAFoam.py:2151-2165"""
+        Istart, Iend = vec.getOwnershipRange()
+        assert Iend - Istart == len(array1), "array1 and vec must have the same size"
+        array1[:] = vec.array[Istart:Iend]
 
     def vec2Array(self, vec):
         Istart, Iend = vec.getOwnershipRange()

@@ -300,6 +300,20 @@ def test_update_of_mesh_recomputes_metrics():
         s.updateOFMesh(X[:-3])
 
 
+def test_pydafoam_check_options():
+    """PYDAFOAM._checkOptions (reference pyDAFoam.py:846-899): invalid option combinations are rejected with the
+    reference's messages before any solver object exists."""
+    from dafoam_amd.pyDAFoam import PYDAFOAM, Error
+
+    case = channel_case(4, 3, 3)
+    with pytest.raises(Error, match="function-CD-patches-wing is not valid"):
+        PYDAFOAM(options=options(case, function={"CD": {"type": "force", "patches": ["wing"], "direction": [1.0, 0.0, 0.0]}}), case=case)
+    with pytest.raises(Error, match="discipline: solid not supported"):
+        PYDAFOAM(options=options(case, discipline="solid"), case=case)
+    with pytest.raises(Error, match="useAD->mode only supports reverse, or forward"):
+        PYDAFOAM(options=options(case, useAD={"mode": "fd"}), case=case)
+
+
 def test_write_adjoint_fields(tmp_path):
     """writeAdjointFields (reference DASolver.C:4055-4160): psi as adjoint_<function>_<state> OpenFOAM fields, read back."""
     from dafoam_amd import foam_io
