@@ -238,8 +238,10 @@ class pyDASolvers:
         if isinstance(pyOptions, dict) and pyOptions.get("adjStateOrdering", "state") == "cell":
             self._perm = self._cell_ordering_permutation()
         self.updateDAOption(pyOptions)
-        self._define_functions(pyOptions.get("function") if isinstance(pyOptions, dict) else None)
         self._inputInfo = dict(pyOptions.get("inputInfo") or {}) if isinstance(pyOptions, dict) else {}
+        self._patchVelocity = [0.0, 0.0]  # DAGlobalVar::patchVelocity = [UMag, AoA(deg)], set by DAInputPatchVelocity::run
+        self._flowdir_fns = {}
+        self._define_functions(pyOptions.get("function") if isinstance(pyOptions, dict) else None)
         if case.states is not None:  # FoamCase.states is always in "state" ordering (input data)
             check(lib().das_update_of_fields(self._h, dptr(np.ascontiguousarray(case.states, dtype=np.float64))))
 
@@ -391,6 +393,12 @@ class pyDASolvers:
         field, val, _ = self._patch_input_tangents(inputName, inputType, inputs)
         ids = self._patch_ids(self._inputInfo[inputName])
         check(lib().das_set_patch_value(self._h, ids.ctypes.data_as(_capi.c_int_p), ids.size, field.encode(), dptr(np.ascontiguousarray(val))))
+        if inputType == "patchVelocity":
+            # DAGlobalVar::patchVelocity: the forces defined parallel / normal to the flow follow the new AoA
+            self._patchVelocity = [float(inputs[0]), float(inputs[1])]
+            for fname, meta in self._flowdir_fns.items():
+                if meta["pv"] == inputName:
+                    self._define_flowdir(fname)
 
     def getOutputSize(self, outputName, outputType):
         return check(lib().das_get_output_size(self._h, outputName.encode(), outputType.encode()))
@@ -550,6 +558,14 @@ class pyDASolvers:
                 check(lib().das_calc_dbc_product(self._h, ids.ctypes.data_as(_capi.c_int_p), ids.size, field.encode(), dptr(np.ascontiguousarray(t)),
                                                  outputName.encode(), outputType.encode(), dptr(np.ascontiguousarray(seeds_s, dtype=np.float64)), C.byref(out)))
                 product[i] = out.value
+            meta = self._flowdir_fns.get(outputName) if outputType == "function" else None
+            if meta is not None and inputType == "patchVelocity" and meta["pv"] == inputName:
+                # the force direction itself depends on the AoA: F is linear in it, so dF/dAoA|dir = F(d') with the
+                # unit vector of d' = dd/dAoA, times |d'| = pi/180
+                dprime = self._flow_direction(meta, deriv=True)
+                tmp = outputName + "__ddir"
+                self._define_flowdir(outputName, name=tmp, direction=dprime * (180.0 / np.pi))
+                product[1] += float(seeds[0]) * self.calcFunction(tmp) * (np.pi / 180.0)
             return
         tmp = np.zeros(len(product)) if self._perm is not None else product
         check(lib().das_calc_jac_t_vec_product(
@@ -587,9 +603,18 @@ class pyDASolvers:
             ftype = fd.get("type")
             if ftype not in ("force", "moment", "massFlowRate", "totalPressure", "totalTemperatureRatio"):
                 raise NotImplementedError(f"function type {ftype} is outside the GPU hot path")
-            if ftype == "force" and fd.get("directionMode", "fixedDirection") != "fixedDirection":
-                raise NotImplementedError("only directionMode fixedDirection is implemented")
             ids = np.array([names.index(p) for p in fd["patches"]], dtype=np.int32)
+            dmode = fd.get("directionMode", "fixedDirection") if ftype == "force" else None
+            if dmode in ("parallelToFlow", "normalToFlow"):
+                # the direction follows the angle of attack of a patchVelocity input (DAFunctionForce.C:45-61,92-113)
+                pv = fd["patchVelocityInputName"]
+                e = self._input_entry(pv, "patchVelocity")
+                ax = {"x": 0, "y": 1, "z": 2}
+                self._flowdir_fns[fname] = dict(mode=dmode, fi=ax[e["flowAxis"]], ni=ax[e["normalAxis"]], ids=ids, scale=float(fd.get("scale", 1.0)), pv=pv)
+                self._define_flowdir(fname)
+                continue
+            if ftype == "force" and dmode != "fixedDirection":
+                raise _capi.DASError(f"directionMode for {fname} not valid!Options: fixedDirection, parallelToFlow, normalToFlow.")
             grp = None
             gamma = 0.0
             vecA = vecB = None
@@ -609,6 +634,24 @@ class pyDASolvers:
                 self._h, fname.encode(), ftype.encode(), ids.ctypes.data_as(_capi.c_int_p),
                 grp.ctypes.data_as(_capi.c_int_p) if grp is not None else None, ids.size,
                 dptr(vecA) if vecA is not None else None, dptr(vecB) if vecB is not None else None, float(fd.get("scale", 1.0)), gamma))
+
+    def _flow_direction(self, meta, deriv=False):
+        """force direction of parallelToFlow / normalToFlow at the current AoA (deriv: d/dAoA[deg])"""
+        a = self._patchVelocity[1] * np.pi / 180.0
+        d = np.zeros(3)
+        ca, sa = (np.cos(a), np.sin(a)) if not deriv else (-np.sin(a) * np.pi / 180.0, np.cos(a) * np.pi / 180.0)
+        if meta["mode"] == "parallelToFlow":
+            d[meta["fi"]], d[meta["ni"]] = ca, sa
+        else:
+            d[meta["fi"]], d[meta["ni"]] = -sa, ca
+        return d
+
+    def _define_flowdir(self, fname, name=None, direction=None):
+        meta = self._flowdir_fns[fname]
+        d = np.ascontiguousarray(self._flow_direction(meta) if direction is None else direction, dtype=np.float64)
+        ids = meta["ids"]
+        check(lib().das_define_face_function(self._h, (name or fname).encode(), b"force", ids.ctypes.data_as(_capi.c_int_p), None, ids.size,
+                                             dptr(d), None, meta["scale"], 0.0))
 
     def calcFunction(self, functionName):
         v = C.c_double(0.0)

@@ -300,6 +300,31 @@ def test_update_of_mesh_recomputes_metrics():
         s.updateOFMesh(X[:-3])
 
 
+def test_flow_aligned_force_directions():
+    """directionMode parallelToFlow / normalToFlow (reference DAFunctionForce.C:45-61,92-113): direction and its AoA
+    derivative from the patchVelocity input; any other mode is rejected with the reference's message."""
+    case = channel_case(4, 3, 3)
+    o = options(case, function={"CD": {"type": "force", "patches": ["bottom"], "directionMode": "parallelToFlow", "patchVelocityInputName": "pv"},
+                                "CL": {"type": "force", "patches": ["bottom"], "directionMode": "normalToFlow", "patchVelocityInputName": "pv"}},
+                inputInfo={"pv": {"type": "patchVelocity", "patches": ["inlet"], "flowAxis": "x", "normalAxis": "z"}})
+    s = pyDASolvers(b"DASimpleFoam -python", o, case=case)
+    s._patchVelocity = [10.0, 30.0]
+    a = np.pi / 6
+    assert np.allclose(s._flow_direction(s._flowdir_fns["CD"]), [np.cos(a), 0.0, np.sin(a)])
+    assert np.allclose(s._flow_direction(s._flowdir_fns["CL"]), [-np.sin(a), 0.0, np.cos(a)])
+    h = 1e-6
+    for nm in ("CD", "CL"):
+        s._patchVelocity = [10.0, 30.0 + h]
+        dp = s._flow_direction(s._flowdir_fns[nm])
+        s._patchVelocity = [10.0, 30.0 - h]
+        dm = s._flow_direction(s._flowdir_fns[nm])
+        s._patchVelocity = [10.0, 30.0]
+        assert np.allclose(s._flow_direction(s._flowdir_fns[nm], deriv=True), (dp - dm) / (2 * h), atol=1e-9)
+    o["function"]["CD"]["directionMode"] = "sideways"
+    with pytest.raises(_capi.DASError, match="directionMode for CD not valid"):
+        pyDASolvers(b"DASimpleFoam -python", o, case=case)
+
+
 def test_pydafoam_check_options():
     """PYDAFOAM._checkOptions (reference pyDAFoam.py:846-899): invalid option combinations are rejected with the
     reference's messages before any solver object exists."""
