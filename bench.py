@@ -273,7 +273,7 @@ def cpu_baseline(D, pc, iters, n):
     t1 = time.perf_counter()
     Ac.matvec(rhs)
     t_spmv = time.perf_counter() - t1
-    return {
+    out = {
         "value": iters / dt,
         "unit": "iter/s",
         "cores": 1,
@@ -282,6 +282,23 @@ def cpu_baseline(D, pc, iters, n):
                   f"matrices copied back from HBM; one oracle SpMV = {t_spmv*1e3:.1f} ms; export+ILU prep {prep:.1f} s (untimed)",
         "spmv_GBps": (12.0 * Ah.nnz + 4.0 * (n + 1) + 16.0 * n) / t_spmv / 1e9,
     }
+    # multi-core leg (informative, never allowed to break the line): chunked mat-vec + block-Jacobi ILU(0), one block per
+    # thread - the reference's one-ASM-block-per-MPI-rank layout without the overlap
+    try:
+        if os.environ.get("DAS_BENCH_CPU_MT", "1") != "0":
+            threads = max(2, min(32, (os.cpu_count() or 2)))
+            t0 = time.time()
+            T = OL.ThreadedOperators(Ah, Ph, threads, fill=0)
+            prep_mt = time.time() - t0
+            t0 = time.perf_counter()
+            OL.gmres(T.matvec, rhs, T.pc_solve, restart=iters, fixed_iters=iters)
+            dt_mt = time.perf_counter() - t0
+            out["multicore"] = {"value": iters / dt_mt, "unit": "iter/s", "cores": T.threads, "kind": "port",
+                                "sample": f"{iters} GMRES iterations, {T.threads} threads: row-chunked oracle SpMV + block-Jacobi ILU(0) "
+                                          f"(one block per thread), serial CGS2; prep {prep_mt:.1f} s (untimed)"}
+    except Exception as e:  # noqa: BLE001
+        out["multicore"] = {"error": str(e)[:200]}
+    return out
 
 
 if __name__ == "__main__":

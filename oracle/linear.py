@@ -175,3 +175,33 @@ def gmres(matvec, rhs, pc_solve=None, x0=None, restart=1000, max_iters=1000, rel
     res = hist[-1]
     fail = int((res / res0 / rel_tol > tol_diff) and (res / abs_tol > tol_diff)) if res0 > 0 else 0
     return x, dict(iters=its, res0=res0, res=res, hist=np.array(hist), fail=fail)
+
+
+class ThreadedOperators:
+    """Multi-core variant of the CPU baseline (bench.py `cpu_baseline_mt`): the rows are cut into `threads` contiguous
+    chunks of equal nnz; the mat-vec runs one chunk per thread (the C kernels release the GIL), the preconditioner is
+    block-Jacobi ILU(fill) with one block per chunk - the reference's layout of one ASM sub-domain per MPI rank
+    (DALinearEqn.C:199-299) without the overlap."""
+
+    def __init__(self, A, P, threads, fill=0):
+        from concurrent.futures import ThreadPoolExecutor
+
+        A = sp.csr_matrix(A)
+        P = sp.csr_matrix(P)
+        self.n = A.shape[0]
+        threads = max(1, min(int(threads), self.n))
+        cuts = np.searchsorted(A.indptr, np.linspace(0, A.nnz, threads + 1))
+        cuts[0], cuts[-1] = 0, self.n
+        self.bounds = [(int(a), int(b)) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+        self.pool = ThreadPoolExecutor(max_workers=len(self.bounds))
+        self.rows = [CSR(A[a:b]) for a, b in self.bounds]
+        self.ilus = list(self.pool.map(lambda ab: ILU(P[ab[0]:ab[1]][:, ab[0]:ab[1]], fill=fill), self.bounds))
+        self.threads = len(self.bounds)
+
+    def matvec(self, x):
+        x = np.ascontiguousarray(x)
+        return np.concatenate(list(self.pool.map(lambda c: c.matvec(x), self.rows)))
+
+    def pc_solve(self, b):
+        b = np.ascontiguousarray(b)
+        return np.concatenate(list(self.pool.map(lambda t: t[0].solve(b[t[1][0]:t[1][1]]), zip(self.ilus, self.bounds))))
