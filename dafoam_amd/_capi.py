@@ -233,6 +233,10 @@ _SIGS = {
     "das_ksp_get_factor_nnz": (C.c_longlong, [_VP]),
     "das_ksp_get_n_ext": (C.c_longlong, [_VP]),
     "das_ksp_get_blocks": (C.c_int, [_VP, c_int_p, c_ll_p]),
+    "das_pc_structure_build": (C.c_int, [_VP, c_int_p, c_ll_p, c_int_p, c_int_p]),
+    "das_pc_structure_get": (C.c_int, [_VP, c_int_p, c_ll_p, c_int_p, c_int_p, c_int_p]),
+    "das_ksp_get_pc_structure_sizes": (C.c_int, [_VP, c_int_p, c_ll_p, c_int_p]),
+    "das_ksp_get_pc_structure": (C.c_int, [_VP, c_int_p, c_ll_p, c_int_p, c_int_p, c_int_p]),
     "das_ksp_get_info": (C.c_int, [_VP, c_int_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_get_history": (C.c_int, [_VP, c_double_p, C.c_int]),
     "das_ksp_run_fixed_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),

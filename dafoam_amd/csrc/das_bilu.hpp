@@ -1,0 +1,597 @@
+// Global node-block ILU(0) preconditioner with sync-free (data-flow) triangular sweeps - gfx950 only.
+//
+// What it replaces: the reference's PC stack ASM + ILU(pcFillLevel) (DALinearEqn.C:199-299).  With ONE sub-domain per
+// GPU (the reference's layout is one ASM sub-domain per MPI rank) the additive-Schwarz level disappears inside a rank
+// and the preconditioner is a single incomplete factorisation of dRdWTPC restricted to the owned unknowns.
+//
+// MI355X design:
+//   * NODES: the unknowns are grouped cell by cell (adjStateOrdering "cell", DAIndex.C:602-651) into dense nodes of
+//     BILU_NB = 8 slots (an interior hex cell of DASimpleFoam+SA - U, p, nuTilda and the phi of its three owned faces -
+//     is exactly one node; other cells are split / packed, empty slots are identity rows).  The factorisation is the
+//     block ILU(0) on the node graph: node I is coupled to every node whose cells lie within the stencil reach of the
+//     PC connectivity (reduceStateResConLevel, DASolver.C:576-705).  It contains every entry of the scalar ILU(0) plus
+//     the fill inside the 8x8 blocks; there are no per-entry indices (8 B per factor entry instead of 12) and the
+//     dependent chain of a triangular solve shrinks from ~8 (nx+2ny+3nz) scalar levels to nx+2ny+3nz node levels.
+//   * ORDER: nodes are renumbered by level set of the lower-triangular dependency graph (a topological order that keeps
+//     the relative order of all coupled nodes, so the factorisation equals the natural-order one up to summation
+//     order).  Consecutive nodes are independent.
+//   * FACTORISATION on the device: one launch per level, one wavefront per node row, 8x8 products through wave
+//     shuffles, block inverse by Gauss-Jordan with row pivoting and a non-zero pivot shift (PCFactorSetShiftType
+//     NONZERO analogue, DALinearEqn.C:270-272).
+//   * SWEEPS: one wavefront per node, no level barriers and no flags: the solution vector itself is the flag (all
+//     entries start as a NaN sentinel; a node polls the 8 values of each dependency with agent-scope (sc1) loads until
+//     they are written, then publishes its own 8 values with sc1 stores - "the data IS the flag",
+//     cdna_hip_programming.md Guideline 16 R2).  Work is handed out in processing order through a device-side ticket
+//     counter, so a waiting wave only ever waits for nodes that are already running: no dependence on dispatch order
+//     or residency.  Factor blocks are streamed exactly once per sweep, packed per 8-block pass so that every
+//     16-byte load instruction of a wave reads one contiguous segment.
+#pragma once
+#include <algorithm>
+#include <numeric>
+
+#include <omp.h>
+
+#include "das_common.hpp"
+#include "das_jaccon.hpp"
+
+namespace das {
+
+constexpr int BILU_NB = 8;
+constexpr int BILU_NB2 = 64;
+constexpr unsigned long long BILU_SENTINEL = 0xFFF7A5A5FFF7A5A5ull;  // a NaN no arithmetic produces
+#ifndef BILU_WG
+#define BILU_WG 512  // threads per workgroup of the sweeps (8 wavefronts)
+#endif
+#ifndef BILU_NPW
+#define BILU_NPW 4  // nodes per wavefront per ticket
+#endif
+#ifndef BILU_SPIN_LIMIT
+#define BILU_SPIN_LIMIT (1u << 22)
+#endif
+
+struct BiluView {
+    int nNodes;
+    const int* nodeUnk;          // nNodes*8: global state index of a slot or -1 (processing order)
+    const long long* ptr[2];     // [0] L rows by p, [1] U rows by q = nNodes-1-p
+    const int* col[2];           // node positions p of the dependencies
+    const double* val[2];
+    const float* valf[2];
+    const double* invD;          // 64 per node, row-major
+    double* y;                   // forward-sweep result (also the flags of the forward sweep)
+    double* z;                   // backward-sweep result
+    unsigned* ctrl;              // [0],[1] ticket counters, [2] abort flag
+};
+
+// ---------------------------------------------------------------------------------------------------
+// device kernels
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_bilu_reset(long long nslots, double* y, double* z, unsigned* ctrl) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nslots) {
+        reinterpret_cast<unsigned long long*>(y)[i] = BILU_SENTINEL;
+        reinterpret_cast<unsigned long long*>(z)[i] = BILU_SENTINEL;
+    }
+    if (i < 2) ctrl[i] = 0u;
+}
+
+__device__ __forceinline__ void bilu_store_sc1(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long bilu_load_sc1(const double* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class VT>
+__device__ __forceinline__ void bilu_load_pair(const VT* p, double& a, double& b);
+template <>
+__device__ __forceinline__ void bilu_load_pair<double>(const double* p, double& a, double& b) {
+    const double2 t = *reinterpret_cast<const double2*>(p);
+    a = t.x; b = t.y;
+}
+template <>
+__device__ __forceinline__ void bilu_load_pair<float>(const float* p, double& a, double& b) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    a = (double)t.x; b = (double)t.y;
+}
+
+// One triangular sweep.  UPPER = false: y_p = b_p - sum_{J<p} L_pJ y_J; UPPER = true: z_p = invD_p (y_p - sum_{J>p} U_pJ z_J),
+// out[state] = z.  Lane (g, r) = (lane / 8, lane % 8) owns row r of the g-th block of a pass of 8 blocks.
+template <class VT, bool UPPER>
+__global__ __launch_bounds__(BILU_WG) void k_bilu_sweep(BiluView P, const double* __restrict__ b, double* __restrict__ out) {
+    __shared__ unsigned sh_chunk[2];
+    constexpr int WAVES = BILU_WG / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 3, r = lane & 7;
+    const long long* __restrict__ ptr = P.ptr[UPPER ? 1 : 0];
+    const int* __restrict__ col = P.col[UPPER ? 1 : 0];
+    const VT* __restrict__ val = reinterpret_cast<const VT*>(sizeof(VT) == 4 ? (const void*)P.valf[UPPER ? 1 : 0] : (const void*)P.val[UPPER ? 1 : 0]);
+    double* xs = UPPER ? P.z : P.y;
+    for (unsigned it = 0;; it++) {
+        if (threadIdx.x == 0) sh_chunk[it & 1] = atomicAdd(&P.ctrl[UPPER ? 1 : 0], 1u);
+        __syncthreads();
+        const long long q0 = (long long)sh_chunk[it & 1] * (WAVES * BILU_NPW);
+        if (q0 >= P.nNodes) return;
+        for (int t = 0; t < BILU_NPW; t++) {
+            const long long q = q0 + (long long)t * WAVES + wave;
+            if (q >= P.nNodes) break;
+            const long long e0 = ptr[q];
+            const int nE = (int)(ptr[q + 1] - e0);
+            double acc = 0.0;
+            // software pipeline over the passes: the factor blocks of pass i+1 are requested before pass i spins on its
+            // dependencies (the block loads never depend on the solution)
+            double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int c = 0, cn = 0;
+            auto load_pass = [&](int a0, double (&vv)[8], int& cc) {
+                const int nb = min(8, nE - a0);
+                if (g < nb) {
+                    cc = col[e0 + a0 + g];
+                    const VT* base = val + (e0 + a0) * BILU_NB2;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) bilu_load_pair<VT>(base + ((qq * nb + g) * 8 + r) * 2, vv[2 * qq], vv[2 * qq + 1]);
+                }
+            };
+            if (nE > 0) load_pass(0, v, c);
+            for (int a0 = 0; a0 < nE; a0 += 8) {
+                const bool act = g < min(8, nE - a0);
+                if (a0 + 8 < nE) load_pass(a0 + 8, vn, cn);
+                const double* xp = xs + (long long)c * BILU_NB;
+                unsigned long long xb[8];
+                unsigned spins = 0;
+                for (;;) {
+                    bool ok = true;
+                    if (act) {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) { xb[k] = bilu_load_sc1(xp + k); ok = ok && (xb[k] != BILU_SENTINEL); }
+                    }
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 1023u) == 0u) {  // bounded spin: a stuck sweep sets the abort flag instead of hanging the GPU
+                        const unsigned ab = __hip_atomic_load(&P.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (ab != 0u || spins >= BILU_SPIN_LIMIT) {
+                            if (lane == 0) __hip_atomic_store(&P.ctrl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            return;
+                        }
+                    }
+                }
+                if (act) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc += v[k] * __longlong_as_double((long long)xb[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = vn[k];
+                c = cn;
+            }
+            acc += __shfl_xor(acc, 8, 64);
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            if (!UPPER) {
+                if (g == 0) {
+                    const int gi = P.nodeUnk[q * BILU_NB + r];
+                    bilu_store_sc1(&P.y[q * BILU_NB + r], (gi >= 0 ? b[gi] : 0.0) - acc);
+                }
+            } else {
+                const long long p = (long long)P.nNodes - 1 - q;
+                const double tr = P.y[p * BILU_NB + r] - acc;
+                double w = P.invD[p * BILU_NB2 + g * 8 + r] * tr;
+                w += __shfl_xor(w, 1, 64);
+                w += __shfl_xor(w, 2, 64);
+                w += __shfl_xor(w, 4, 64);
+                if (r == 0) {
+                    bilu_store_sc1(&P.z[p * BILU_NB + g], w);
+                    const int gi = P.nodeUnk[p * BILU_NB + g];
+                    if (gi >= 0) out[gi] = w;
+                }
+            }
+        }
+    }
+}
+
+// scalar CSR (rows = states, 16 lanes per row) -> dense node blocks (row-major 8x8 per block entry)
+__global__ __launch_bounds__(256) void k_bilu_scatter(long long n, const long long* __restrict__ rp, const int* __restrict__ ci,
+                                                      const double* __restrict__ v, const int* __restrict__ unkNode,
+                                                      const unsigned char* __restrict__ unkSlot, const long long* __restrict__ bptr,
+                                                      const int* __restrict__ bcol, double* __restrict__ bval, unsigned long long* dropped) {
+    const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l16 = threadIdx.x & 15;
+    if (row >= n) return;
+    const int I = unkNode[row];
+    if (I < 0) return;
+    const int r = unkSlot[row];
+    const long long b0 = bptr[I], b1 = bptr[I + 1];
+    for (long long k = rp[row] + l16; k < rp[row + 1]; k += 16) {
+        const int j = ci[k];
+        const int J = unkNode[j];
+        if (J < 0) continue;  // not owned by this rank (block-Jacobi across ranks)
+        long long lo = b0, hi = b1 - 1, e = -1;
+        while (lo <= hi) {
+            const long long mid = (lo + hi) >> 1;
+            const int cm = bcol[mid];
+            if (cm == J) { e = mid; break; }
+            if (cm < J) lo = mid + 1; else hi = mid - 1;
+        }
+        if (e < 0) { atomicAdd(dropped, 1ull); continue; }
+        bval[e * BILU_NB2 + r * 8 + unkSlot[j]] = v[k];
+    }
+}
+__global__ void k_bilu_pad_diag(int nNodes, const int* __restrict__ nodeUnk, const long long* __restrict__ bdiag, double* __restrict__ bval) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nNodes * BILU_NB) return;
+    if (nodeUnk[i] < 0) { const int k = (int)(i & 7); bval[bdiag[i >> 3] * BILU_NB2 + k * 8 + k] = 1.0; }
+}
+
+// 8x8 inverse of the block held one element per lane (lane = r*8+c): Gauss-Jordan with row pivoting; a pivot below
+// `tiny` is replaced by +-shift (non-zero shift).  Returns the inverse element of this lane; *nshift counts shifts.
+__device__ __forceinline__ double bilu_inverse8(double a, int lane, int* nshift) {
+    const int r = lane >> 3, c = lane & 7;
+    double b = (r == c) ? 1.0 : 0.0;
+    for (int k = 0; k < 8; k++) {
+        int pr = k;
+        double best = -1.0;
+        for (int rr = k; rr < 8; rr++) {
+            const double t = fabs(__shfl(a, rr * 8 + k, 64));
+            if (t > best) { best = t; pr = rr; }
+        }
+        // swap rows k and pr
+        const int src = (r == k) ? pr * 8 + c : (r == pr ? k * 8 + c : lane);
+        a = __shfl(a, src, 64);
+        b = __shfl(b, src, 64);
+        double pv = __shfl(a, k * 8 + k, 64);
+        if (!(fabs(pv) > 1e-300)) {  // MAT_SHIFT_NONZERO analogue: the pivot is replaced, the elimination continues
+            pv = (pv < 0.0 ? -1.0 : 1.0) * 1e-12;
+            if (lane == k * 9) a = pv;
+            if (lane == 0) (*nshift)++;
+        }
+        const double rk = __shfl(a, k * 8 + c, 64) / pv;
+        const double rkb = __shfl(b, k * 8 + c, 64) / pv;
+        const double f = __shfl(a, r * 8 + k, 64);
+        if (r == k) { a = rk; b = rkb; }
+        else { a -= f * rk; b -= f * rkb; }
+    }
+    return b;
+}
+
+// numeric block ILU(0) of the rows [node0, node1) of one level (all their dependencies belong to earlier launches);
+// one wavefront per row, lane = r*8+c holds element (r,c) of the current block
+__global__ __launch_bounds__(256) void k_bilu_factor(int node0, int node1, const long long* __restrict__ bptr, const long long* __restrict__ bdiag,
+                                                     const int* __restrict__ bcol, double* bval, double* invD, int* nshift) {
+    const int lane = threadIdx.x & 63;
+    const int p = node0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= node1) return;
+    const int r = lane >> 3, c = lane & 7;
+    const long long rb = bptr[p], rd = bdiag[p], re = bptr[p + 1];
+    for (long long e = rb; e < rd; e++) {
+        const int J = bcol[e];
+        const double a = bval[e * BILU_NB2 + lane];
+        double Lv = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) Lv += __shfl(a, r * 8 + k, 64) * invD[(long long)J * BILU_NB2 + k * 8 + c];
+        bval[e * BILU_NB2 + lane] = Lv;
+        double Lrow[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) Lrow[k] = __shfl(Lv, r * 8 + k, 64);
+        const long long je = bptr[J + 1];
+        long long from = e + 1;
+        for (long long f = bdiag[J] + 1; f < je; f++) {
+            const int M = bcol[f];
+            // both lists are ascending: continue the search behind the previous hit
+            long long lo = from, hi = re - 1, pos = -1;
+            while (lo <= hi) {
+                const long long mid = (lo + hi) >> 1;
+                const int cm = bcol[mid];
+                if (cm == M) { pos = mid; break; }
+                if (cm < M) lo = mid + 1; else hi = mid - 1;
+            }
+            if (pos < 0) { from = lo; continue; }
+            from = pos + 1;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) s += Lrow[k] * bval[f * BILU_NB2 + k * 8 + c];
+            bval[pos * BILU_NB2 + lane] -= s;
+        }
+    }
+    int ns = 0;
+    const double inv = bilu_inverse8(bval[rd * BILU_NB2 + lane], lane, &ns);
+    invD[(long long)p * BILU_NB2 + lane] = inv;
+    if (lane == 0 && ns) atomicAdd(nshift, ns);
+}
+
+// pack the factor into the two sweep streams: per row the blocks in passes of <= 8, inside a pass [qq][g][r][2]
+// (k = 2 qq + rr), so that the qq-th 16-byte load of all lanes of a wave reads one contiguous segment
+template <class VT>
+__global__ __launch_bounds__(256) void k_bilu_pack(int nNodes, const long long* __restrict__ bptr, const long long* __restrict__ bdiag,
+                                                   const int* __restrict__ bcol, const double* __restrict__ bval, const long long* __restrict__ Lptr,
+                                                   const long long* __restrict__ Uptr, int* __restrict__ Lcol, int* __restrict__ Ucol,
+                                                   VT* __restrict__ Lval, VT* __restrict__ Uval) {
+    const int lane = threadIdx.x & 63;
+    const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= nNodes) return;
+    const int r = lane >> 3, k = lane & 7;
+    for (int t = 0; t < 2; t++) {
+        const long long s0 = t == 0 ? bptr[p] : bdiag[p] + 1;
+        const long long s1 = t == 0 ? bdiag[p] : bptr[p + 1];
+        const int nE = (int)(s1 - s0);
+        const long long d0 = t == 0 ? Lptr[p] : Uptr[nNodes - 1 - p];
+        int* dcol = t == 0 ? Lcol : Ucol;
+        VT* dval = t == 0 ? Lval : Uval;
+        for (int a = 0; a < nE; a++) {
+            const int pass = a >> 3, g = a & 7;
+            const int nb = min(8, nE - 8 * pass);
+            dval[(d0 + 8 * pass) * BILU_NB2 + (((k >> 1) * nb + g) * 8 + r) * 2 + (k & 1)] = (VT)bval[(s0 + a) * BILU_NB2 + lane];
+            if (lane == 0) dcol[d0 + a] = bcol[s0 + a];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side object
+// ---------------------------------------------------------------------------------------------------
+struct NodeILU {
+    bool ready = false;
+    long long n = 0;
+    int nNodes = 0, nLevels = 0, nshift = 0, maxRow = 0;
+    long long nnzB = 0, nL = 0, nU = 0;
+    bool fp32 = false;
+    // host copies (tests / introspection)
+    std::vector<int> h_nodeUnk, h_bcol, h_lvlPtr, h_natural;  // h_natural[p] = natural (cell-order) index of the node at position p
+    std::vector<long long> h_bptr;
+    DevBuf<int> nodeUnk, Lcol, Ucol;
+    DevBuf<long long> Lptr, Uptr;
+    DevBuf<double> Lval, Uval, invD, y, z;
+    DevBuf<float> Lvalf, Uvalf;
+    DevBuf<unsigned> ctrl;
+    BiluView view;
+    double t_struct = 0, t_scatter = 0, t_factor = 0, t_pack = 0;
+    long long factor_bytes() const { return (nL + nU) * BILU_NB2 * (fp32 ? 4 : 8) + (long long)nNodes * BILU_NB2 * 8; }
+};
+
+// Structure: nodes, node pattern, level order.  `states` = DAIndex state blocks, `owned` (per state, may be empty) /
+// `cellOwned` restrict the preconditioner to this rank's unknowns, `reach` = stencil reach in cell rings.
+inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned,
+                                 const std::vector<char>& cellOwned, int reach, NodeILU& P, std::vector<int>& unkNode,
+                                 std::vector<unsigned char>& unkSlot, std::vector<long long>& bptr, std::vector<long long>& bdiag,
+                                 std::vector<int>& bcol, int nthr) {
+    const int nC = m.nC;
+    // ---- unknowns cell by cell, packed into nodes of 8 slots
+    std::vector<std::vector<int>> ownedFaces;
+    bool hasFace = false;
+    for (const StateDef& sd : states) if (sd.kind == KIND_FACE) hasFace = true;
+    std::vector<int> of_ptr(nC + 1, 0), of;
+    if (hasFace) {
+        for (int f = 0; f < m.nF; f++) of_ptr[m.owner[f] + 1]++;
+        for (int c = 0; c < nC; c++) of_ptr[c + 1] += of_ptr[c];
+        of.resize(m.nF);
+        std::vector<int> fill(of_ptr.begin(), of_ptr.end() - 1);
+        for (int f = 0; f < m.nF; f++) of[fill[m.owner[f]]++] = f;
+    }
+    std::vector<int> nodeUnk0;           // natural node order
+    std::vector<int> nodeCell_ptr{0}, nodeCell;  // node -> cells
+    std::vector<int> cellNode_ptr(nC + 1, 0), cellNode;
+    nodeUnk0.reserve((size_t)nC * 9);
+    std::vector<long long> tmp;
+    int fillSlots = BILU_NB;  // slots used in the current node (BILU_NB = closed)
+    auto is_owned = [&](long long g) { return owned.empty() || owned[g]; };
+    for (int c = 0; c < nC; c++) {
+        cellNode_ptr[c + 1] = cellNode_ptr[c];
+        if (!cellOwned[c]) continue;
+        tmp.clear();
+        for (const StateDef& sd : states) {
+            if (sd.kind == KIND_VEC) { for (int k = 0; k < 3; k++) if (is_owned(sd.offset + 3LL * c + k)) tmp.push_back(sd.offset + 3LL * c + k); }
+            else if (sd.kind == KIND_SCL) { if (is_owned(sd.offset + c)) tmp.push_back(sd.offset + c); }
+        }
+        for (const StateDef& sd : states)
+            if (sd.kind == KIND_FACE) for (int q = of_ptr[c]; q < of_ptr[c + 1]; q++) if (is_owned(sd.offset + of[q])) tmp.push_back(sd.offset + of[q]);
+        size_t done = 0;
+        const size_t mc = tmp.size();
+        if (mc == 0) continue;
+        // a cell that does not fit into the open node starts a new one (cells larger than a node are split)
+        if ((size_t)(BILU_NB - fillSlots) < std::min<size_t>(mc, BILU_NB)) fillSlots = BILU_NB;
+        while (done < mc) {
+            if (fillSlots == BILU_NB) {
+                nodeUnk0.insert(nodeUnk0.end(), BILU_NB, -1);
+                nodeCell_ptr.push_back(nodeCell_ptr.back());
+                fillSlots = 0;
+            }
+            const int node = (int)nodeCell_ptr.size() - 2;
+            if (nodeCell.empty() || nodeCell_ptr[node + 1] == nodeCell_ptr[node] || nodeCell.back() != c) { nodeCell.push_back(c); nodeCell_ptr[node + 1]++; }
+            if (cellNode.empty() || cellNode_ptr[c + 1] == cellNode_ptr[c] || cellNode.back() != node) { cellNode.push_back(node); cellNode_ptr[c + 1]++; }
+            while (done < mc && fillSlots < BILU_NB) nodeUnk0[(size_t)node * BILU_NB + fillSlots++] = (int)tmp[done++];
+        }
+    }
+    const int nN = (int)nodeCell_ptr.size() - 1;
+    DAS_CHECK(nN > 0, DAS_ERR_INTERNAL, "preconditioner: no owned unknowns");
+    // ---- node pattern: nodes of all cells within `reach` rings of the node's cells (symmetric by construction)
+    std::vector<long long> rptr(nN + 1, 0);
+    std::vector<std::vector<int>> rows(nN);
+#pragma omp parallel num_threads(nthr)
+    {
+        std::vector<int> cmark(nC, -1), nmark(nN, -1), cur, nxt;
+#pragma omp for schedule(dynamic, 256)
+        for (int I = 0; I < nN; I++) {
+            std::vector<int>& row = rows[I];
+            cur.clear();
+            for (int q = nodeCell_ptr[I]; q < nodeCell_ptr[I + 1]; q++) { const int c = nodeCell[q]; cmark[c] = I; cur.push_back(c); }
+            auto add_cell = [&](int c) {
+                for (int q = cellNode_ptr[c]; q < cellNode_ptr[c + 1]; q++) { const int J = cellNode[q]; if (nmark[J] != I) { nmark[J] = I; row.push_back(J); } }
+            };
+            for (int c : cur) add_cell(c);
+            for (int ring = 0; ring < reach; ring++) {
+                nxt.clear();
+                for (int c : cur)
+                    for (int q = m.cc_ptr[c]; q < m.cc_ptr[c + 1]; q++) {
+                        const int d = m.cc[q];
+                        if (cmark[d] != I) { cmark[d] = I; nxt.push_back(d); if (cellOwned[d]) add_cell(d); }
+                    }
+                cur.swap(nxt);
+            }
+            std::sort(row.begin(), row.end());
+        }
+    }
+    // ---- level sets of the lower-triangular dependency graph, level order = processing order
+    std::vector<int> level(nN, 0);
+    int nLv = 0;
+    for (int I = 0; I < nN; I++) {
+        int l = 0;
+        for (int J : rows[I]) { if (J >= I) break; l = std::max(l, level[J] + 1); }
+        level[I] = l;
+        nLv = std::max(nLv, l + 1);
+    }
+    std::vector<int> lvlPtr(nLv + 1, 0), pos(nN);
+    for (int I = 0; I < nN; I++) lvlPtr[level[I] + 1]++;
+    for (int l = 0; l < nLv; l++) lvlPtr[l + 1] += lvlPtr[l];
+    {
+        std::vector<int> fill(lvlPtr.begin(), lvlPtr.end() - 1);
+        for (int I = 0; I < nN; I++) pos[I] = fill[level[I]]++;
+    }
+    std::vector<int> inv(nN);
+    for (int I = 0; I < nN; I++) inv[pos[I]] = I;
+    // ---- permuted block CSR
+    bptr.assign(nN + 1, 0);
+    for (int p = 0; p < nN; p++) bptr[p + 1] = bptr[p] + (long long)rows[inv[p]].size();
+    bcol.resize((size_t)bptr[nN]);
+    bdiag.assign(nN, -1);
+    int maxRow = 0;
+#pragma omp parallel for schedule(static) reduction(max : maxRow) num_threads(nthr)
+    for (int p = 0; p < nN; p++) {
+        const std::vector<int>& row = rows[inv[p]];
+        int* dst = bcol.data() + bptr[p];
+        for (size_t k = 0; k < row.size(); k++) dst[k] = pos[row[k]];
+        std::sort(dst, dst + row.size());
+        bdiag[p] = bptr[p] + (std::lower_bound(dst, dst + row.size(), p) - dst);
+        maxRow = std::max(maxRow, (int)row.size());
+    }
+    P.h_nodeUnk.assign((size_t)nN * BILU_NB, -1);
+    unkNode.assign(n, -1);
+    unkSlot.assign(n, 0);
+    for (int p = 0; p < nN; p++)
+        for (int k = 0; k < BILU_NB; k++) {
+            const int gidx = nodeUnk0[(size_t)inv[p] * BILU_NB + k];
+            P.h_nodeUnk[(size_t)p * BILU_NB + k] = gidx;
+            if (gidx >= 0) { unkNode[gidx] = p; unkSlot[gidx] = (unsigned char)k; }
+        }
+    P.n = n; P.nNodes = nN; P.nLevels = nLv; P.nnzB = bptr[nN]; P.maxRow = maxRow;
+    P.h_bptr = bptr; P.h_bcol = bcol; P.h_lvlPtr = lvlPtr; P.h_natural = inv;
+}
+
+// Numeric setup on the device from the assembled PC matrix (device CSR, rows = states).
+inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned, int reach,
+                       bool fp32, long long An, const long long* d_rp, const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P,
+                       bool debug, int nthr) {
+    const double t0 = wall_seconds();
+    std::vector<char> cellOwned(m.nC, 1);
+    if (!owned.empty()) {
+        const StateDef& s0 = states[0];
+        const int stride = s0.kind == KIND_VEC ? 3 : 1;
+        for (int c = 0; c < m.nC; c++) cellOwned[c] = owned[s0.offset + (long long)stride * c] ? 1 : 0;
+    }
+    std::vector<int> unkNode, bcol;
+    std::vector<unsigned char> unkSlot;
+    std::vector<long long> bptr, bdiag;
+    bilu_build_structure(m, states, n, owned, cellOwned, reach, P, unkNode, unkSlot, bptr, bdiag, bcol, std::max(1, nthr));
+    const int nN = P.nNodes;
+    P.fp32 = fp32;
+    P.nodeUnk.upload(P.h_nodeUnk);
+    DevBuf<int> d_unkNode, d_bcol;
+    DevBuf<unsigned char> d_unkSlot;
+    DevBuf<long long> d_bptr, d_bdiag;
+    d_unkNode.upload(unkNode); d_unkSlot.upload(unkSlot); d_bptr.upload(bptr); d_bdiag.upload(bdiag); d_bcol.upload(bcol);
+    DevBuf<double> bval((size_t)P.nnzB * BILU_NB2);
+    DevBuf<unsigned long long> d_dropped(1);
+    DevBuf<int> d_nshift(1);
+    DAS_HIP(hipMemsetAsync(bval.p, 0, bval.n * sizeof(double), st));
+    DAS_HIP(hipMemsetAsync(d_dropped.p, 0, sizeof(unsigned long long), st));
+    DAS_HIP(hipMemsetAsync(d_nshift.p, 0, sizeof(int), st));
+    P.t_struct = wall_seconds() - t0;
+    double t1 = wall_seconds();
+    hipLaunchKernelGGL(k_bilu_scatter, dim3((unsigned)((An + 15) / 16)), dim3(256), 0, st, An, d_rp, d_ci, d_av, d_unkNode.p, d_unkSlot.p, d_bptr.p,
+                       d_bcol.p, bval.p, d_dropped.p);
+    hipLaunchKernelGGL(k_bilu_pad_diag, dim3((unsigned)(((long long)nN * BILU_NB + 255) / 256)), dim3(256), 0, st, nN, P.nodeUnk.p, d_bdiag.p, bval.p);
+    DAS_HIP(hipGetLastError());
+    unsigned long long dropped = 0;
+    DAS_HIP(hipMemcpyAsync(&dropped, d_dropped.p, sizeof(dropped), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
+    DAS_CHECK(dropped == 0, DAS_ERR_INTERNAL, "preconditioner: " + std::to_string(dropped) + " matrix entries fall outside the node pattern (stencil reach too small)");
+    P.t_scatter = wall_seconds() - t1;
+    t1 = wall_seconds();
+    // ---- numeric factorisation, one launch per level
+    P.invD.alloc((size_t)nN * BILU_NB2);
+    for (int l = 0; l < P.nLevels; l++) {
+        const int a = P.h_lvlPtr[l], bnd = P.h_lvlPtr[l + 1];
+        if (bnd > a)
+            hipLaunchKernelGGL(k_bilu_factor, dim3((unsigned)((bnd - a + 3) / 4)), dim3(256), 0, st, a, bnd, d_bptr.p, d_bdiag.p, d_bcol.p, bval.p, P.invD.p,
+                               d_nshift.p);
+    }
+    DAS_HIP(hipGetLastError());
+    DAS_HIP(hipMemcpyAsync(&P.nshift, d_nshift.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
+    P.t_factor = wall_seconds() - t1;
+    t1 = wall_seconds();
+    // ---- sweep streams
+    std::vector<long long> Lptr(nN + 1, 0), Uptr(nN + 1, 0);
+    for (int p = 0; p < nN; p++) Lptr[p + 1] = Lptr[p] + (bdiag[p] - bptr[p]);
+    for (int q = 0; q < nN; q++) { const int p = nN - 1 - q; Uptr[q + 1] = Uptr[q] + (bptr[p + 1] - bdiag[p] - 1); }
+    P.nL = Lptr[nN]; P.nU = Uptr[nN];
+    P.Lptr.upload(Lptr); P.Uptr.upload(Uptr);
+    P.Lcol.alloc(std::max<long long>(P.nL, 1)); P.Ucol.alloc(std::max<long long>(P.nU, 1));
+    if (fp32) {
+        P.Lvalf.alloc((size_t)std::max<long long>(P.nL, 1) * BILU_NB2); P.Uvalf.alloc((size_t)std::max<long long>(P.nU, 1) * BILU_NB2);
+        P.Lval.release(); P.Uval.release();
+        hipLaunchKernelGGL(k_bilu_pack<float>, dim3((unsigned)((nN + 3) / 4)), dim3(256), 0, st, nN, d_bptr.p, d_bdiag.p, d_bcol.p, bval.p, P.Lptr.p,
+                           P.Uptr.p, P.Lcol.p, P.Ucol.p, P.Lvalf.p, P.Uvalf.p);
+    } else {
+        P.Lval.alloc((size_t)std::max<long long>(P.nL, 1) * BILU_NB2); P.Uval.alloc((size_t)std::max<long long>(P.nU, 1) * BILU_NB2);
+        P.Lvalf.release(); P.Uvalf.release();
+        hipLaunchKernelGGL(k_bilu_pack<double>, dim3((unsigned)((nN + 3) / 4)), dim3(256), 0, st, nN, d_bptr.p, d_bdiag.p, d_bcol.p, bval.p, P.Lptr.p,
+                           P.Uptr.p, P.Lcol.p, P.Ucol.p, P.Lval.p, P.Uval.p);
+    }
+    DAS_HIP(hipGetLastError());
+    P.y.alloc((size_t)nN * BILU_NB); P.z.alloc((size_t)nN * BILU_NB);
+    P.ctrl.alloc(4);
+    DAS_HIP(hipMemsetAsync(P.ctrl.p, 0, 4 * sizeof(unsigned), st));
+    DAS_HIP(hipStreamSynchronize(st));
+    P.t_pack = wall_seconds() - t1;
+    P.view.nNodes = nN; P.view.nodeUnk = P.nodeUnk.p;
+    P.view.ptr[0] = P.Lptr.p; P.view.ptr[1] = P.Uptr.p; P.view.col[0] = P.Lcol.p; P.view.col[1] = P.Ucol.p;
+    P.view.val[0] = P.Lval.p; P.view.val[1] = P.Uval.p; P.view.valf[0] = P.Lvalf.p; P.view.valf[1] = P.Uvalf.p;
+    P.view.invD = P.invD.p; P.view.y = P.y.p; P.view.z = P.z.p; P.view.ctrl = P.ctrl.p;
+    P.ready = true;
+    if (debug)
+        fprintf(stderr, "[dafoam_amd] node-block ILU(0): %d nodes (%.3f slots/unknown), %lld blocks (%.1f per node, max %d), %d levels, %d shifted pivots, "
+                        "factor %.2f GB%s; structure %.2f s, scatter %.3f s, factorise %.3f s, pack %.3f s\n", nN, (double)nN * BILU_NB / (double)n, P.nnzB,
+                (double)P.nnzB / nN, P.maxRow, P.nLevels, P.nshift, P.factor_bytes() / 1e9, fp32 ? " (fp32)" : "", P.t_struct, P.t_scatter, P.t_factor,
+                P.t_pack);
+}
+
+inline int bilu_sweep_grid() {
+    static int grid = 0;
+    if (!grid) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        grid = std::max(1, cus) * 2;
+    }
+    return grid;
+}
+
+// out = (LU)^-1 b on the owned unknowns (entries of `out` outside the preconditioner's unknowns are not touched)
+inline void bilu_apply(NodeILU& P, const double* b, double* out, hipStream_t st) {
+    const long long nslots = (long long)P.nNodes * BILU_NB;
+    hipLaunchKernelGGL(k_bilu_reset, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, P.y.p, P.z.p, P.ctrl.p);
+    const int perTicket = (BILU_WG / 64) * BILU_NPW;
+    const int grid = (int)std::min<long long>(bilu_sweep_grid(), ((long long)P.nNodes + perTicket - 1) / perTicket + 1);
+    if (P.fp32) {
+        hipLaunchKernelGGL((k_bilu_sweep<float, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out);
+        hipLaunchKernelGGL((k_bilu_sweep<float, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out);
+    } else {
+        hipLaunchKernelGGL((k_bilu_sweep<double, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out);
+        hipLaunchKernelGGL((k_bilu_sweep<double, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out);
+    }
+}
+
+// abort flag of the sweeps (set when a bounded spin ran out): checked by the solver at its synchronisation points
+inline bool bilu_aborted(NodeILU& P, hipStream_t st) {
+    unsigned c[4] = {0, 0, 0, 0};
+    DAS_HIP(hipMemcpyAsync(c, P.ctrl.p, sizeof(c), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
+    return c[2] != 0u;
+}
+
+}  // namespace das

@@ -17,6 +17,7 @@
 
 #include "das_case.hpp"
 #include "das_jaccon.hpp"
+#include "das_bilu.hpp"
 
 #include <omp.h>
 
@@ -643,7 +644,9 @@ struct das_mat {
 
 struct das_ksp {
     das_mat* pcmat = nullptr;
-    BlockILU pc;
+    BlockILU pc;      // amd.pcType "ras": restricted additive Schwarz + scalar ILU(k) blocks in LDS
+    NodeILU bilu;     // amd.pcType "bilu" (default): global node-block ILU(0), sync-free sweeps (das_bilu.hpp)
+    bool useBilu = false;
     int restart = 0;
     DevBuf<double> V, w, z, r, xdev, bdev, partial, hdev;
     int iters = 0, nrefine = 0;
@@ -707,6 +710,7 @@ struct das_solver {
     das_allreduce_cb allreduce_cb = nullptr;
     void* comm_user = nullptr;
     KernelTimer timer;
+    NodeILU pcStruct;  // das_pc_structure_build (host-only introspection)
     double t0_wall = 0;
     std::clock_t t0_cpu = 0;
 };
@@ -1314,9 +1318,46 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
                 wall_seconds() - t_fact);
 }
 
+// reach (in cell rings, measured between the cells that own the unknowns) of the PC connectivity: level lv of a residual,
+// +1 if the level lists a face state (the face of a ring-lv cell may be owned by its neighbour), +1 for a face residual
+// (anchored at either adjacent cell, owned by one of them)
+static int pc_stencil_reach(das_solver* s) {
+    ensure_coloring(s);
+    int reach = 0;
+    for (size_t b = 0; b < s->st_pc.states.size(); b++)
+        for (size_t lv = 0; lv < s->st_pc.levels[b].size(); lv++) {
+            const unsigned mask = s->st_pc.levels[b][lv];
+            if (!mask) continue;
+            bool faceState = false;
+            for (size_t q = 0; q < s->st_pc.states.size(); q++) if ((mask >> q & 1u) && s->st_pc.states[q].kind == KIND_FACE) faceState = true;
+            reach = std::max<int>(reach, (int)lv + (faceState ? 1 : 0) + (s->st_pc.states[b].kind == KIND_FACE ? 1 : 0));
+        }
+    return reach;
+}
+
+// global node-block ILU(0) (das_bilu.hpp): one incomplete factorisation of dRdWTPC over this rank's unknowns
+static void setup_node_ilu(das_solver* s, das_ksp* k) {
+    const double t0 = wall_seconds();
+    const Mat& A = k->pcmat->m;
+    const int reach = pc_stencil_reach(s);
+    const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
+    bilu_setup(s->mesh, s->st_full.states, s->n, s->owned, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
+               k->bilu, s->opt.geti("debug") != 0, nthr);
+    k->useBilu = true;
+    k->pc.setup_seconds = wall_seconds() - t0;
+    k->pc.nBlocks = 1;
+    k->pc.fnnz = (k->bilu.nL + k->bilu.nU + k->bilu.nNodes) * (long long)BILU_NB2;
+    k->pc.next = (long long)k->bilu.nNodes * BILU_NB;
+}
+
 static void pc_apply(das_solver* s, das_ksp* k, const double* b, double* x) {
     hipEvent_t ev = nullptr;
     s->timer.begin("pc", s->stream, ev);
+    if (k->useBilu) {
+        bilu_apply(k->bilu, b, x, s->stream);
+        s->timer.end("pc", s->stream, ev);
+        return;
+    }
     const int mlv = k->pc.maxLevels;
     const size_t lvlBytes = (size_t)((mlv + 2 * PC_PF + 4) >> 1) * sizeof(double);
     if (k->pc.useLDS)
@@ -1467,6 +1508,7 @@ static int run_gmres(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x
         else done = beta <= target || its >= maxIts;
     }
     DAS_HIP(hipStreamSynchronize(st));
+    if (k->useBilu) DAS_CHECK(!bilu_aborted(k->bilu, st), DAS_ERR_INTERNAL, "preconditioner sweep timed out (bounded spin)");
     k->iters = its;
     k->res = k->hist.back();
     k->seconds = wall_seconds() - t0;
@@ -2153,7 +2195,10 @@ int das_create_ml_rksp_matrix_free(das_solver_t* s, das_mat_t* pc, das_ksp_t** k
     DAS_CHECK(pc && ksp, DAS_ERR_ARG, "null argument");
     std::unique_ptr<das_ksp> k(new das_ksp);
     k->pcmat = pc;
-    setup_block_ilu(s, k.get());
+    const std::string pcType = s->opt.gets("amd.pcType");
+    DAS_CHECK(pcType == "bilu" || pcType == "ras", DAS_ERR_ARG, "amd.pcType must be \"bilu\" or \"ras\"");
+    if (pcType == "bilu") setup_node_ilu(s, k.get());
+    else setup_block_ilu(s, k.get());
     *ksp = k.release();
     return DAS_OK;
     DAS_CATCH
@@ -2179,9 +2224,64 @@ int das_ksp_apply_pc(das_solver_t* s, das_ksp_t* ksp, const double* x, double* y
     DevBuf<double> dx(s->n), dy(s->n);
     dx.upload(x, s->n);
     DAS_HIP(hipDeviceSynchronize());
+    dy.zero();
     pc_apply(s, ksp, dx.p, dy.p);
     DAS_HIP(hipStreamSynchronize(s->stream));
+    if (ksp->useBilu) DAS_CHECK(!bilu_aborted(ksp->bilu, s->stream), DAS_ERR_INTERNAL, "preconditioner sweep timed out (bounded spin)");
     dy.download(y, s->n);
+    return DAS_OK;
+    DAS_CATCH
+}
+// node structure of the "bilu" preconditioner (host only, no GPU needed): sizes, then the arrays in processing order
+static void copy_pc_structure(const NodeILU& P, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural) {
+    if (natural) std::copy(P.h_natural.begin(), P.h_natural.end(), natural);
+    if (nodeUnk) std::copy(P.h_nodeUnk.begin(), P.h_nodeUnk.end(), nodeUnk);
+    if (bptr) std::copy(P.h_bptr.begin(), P.h_bptr.end(), bptr);
+    if (bcol) std::copy(P.h_bcol.begin(), P.h_bcol.end(), bcol);
+    if (lvlPtr) std::copy(P.h_lvlPtr.begin(), P.h_lvlPtr.end(), lvlPtr);
+}
+int das_pc_structure_build(das_solver_t* s, int* nNodes, long long* nBlocks, int* nLevels, int* reach) {
+    DAS_TRY
+    DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
+    const int rch = pc_stencil_reach(s);
+    std::vector<char> cellOwned(s->mesh.nC, 1);
+    if (!s->owned.empty()) {
+        const StateDef& s0 = s->st_full.states[0];
+        const int stride = s0.kind == KIND_VEC ? 3 : 1;
+        for (int c = 0; c < s->mesh.nC; c++) cellOwned[c] = s->owned[s0.offset + (long long)stride * c] ? 1 : 0;
+    }
+    std::vector<int> unkNode, bcol;
+    std::vector<unsigned char> unkSlot;
+    std::vector<long long> bptr, bdiag;
+    const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
+    bilu_build_structure(s->mesh, s->st_full.states, s->n, s->owned, cellOwned, rch, s->pcStruct, unkNode, unkSlot, bptr, bdiag, bcol, nthr);
+    if (nNodes) *nNodes = s->pcStruct.nNodes;
+    if (nBlocks) *nBlocks = s->pcStruct.nnzB;
+    if (nLevels) *nLevels = s->pcStruct.nLevels;
+    if (reach) *reach = rch;
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_pc_structure_get(das_solver_t* s, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural) {
+    DAS_TRY
+    DAS_CHECK(s && s->pcStruct.nNodes > 0, DAS_ERR_STATE, "das_pc_structure_build has not been called");
+    copy_pc_structure(s->pcStruct, nodeUnk, bptr, bcol, lvlPtr, natural);
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_ksp_get_pc_structure_sizes(das_ksp_t* ksp, int* nNodes, long long* nBlocks, int* nLevels) {
+    DAS_TRY
+    DAS_CHECK(ksp && ksp->useBilu, DAS_ERR_STATE, "the KSP does not hold a node-block ILU preconditioner (amd.pcType \"bilu\")");
+    if (nNodes) *nNodes = ksp->bilu.nNodes;
+    if (nBlocks) *nBlocks = ksp->bilu.nnzB;
+    if (nLevels) *nLevels = ksp->bilu.nLevels;
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_ksp_get_pc_structure(das_ksp_t* ksp, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural) {
+    DAS_TRY
+    DAS_CHECK(ksp && ksp->useBilu, DAS_ERR_STATE, "the KSP does not hold a node-block ILU preconditioner (amd.pcType \"bilu\")");
+    copy_pc_structure(ksp->bilu, nodeUnk, bptr, bcol, lvlPtr, natural);
     return DAS_OK;
     DAS_CATCH
 }
@@ -2191,6 +2291,7 @@ long long das_ksp_get_n_ext(das_ksp_t* ksp) { return ksp ? ksp->pc.next : -1; }
 int das_ksp_get_blocks(das_ksp_t* ksp, int* perm, long long* block_off) {
     DAS_TRY
     DAS_CHECK(ksp && perm && block_off, DAS_ERR_ARG, "null argument");
+    DAS_CHECK(!ksp->useBilu, DAS_ERR_STATE, "das_ksp_get_blocks describes the \"ras\" preconditioner; use das_ksp_get_pc_structure");
     std::copy(ksp->pc.h_core_perm.begin(), ksp->pc.h_core_perm.end(), perm);
     std::copy(ksp->pc.h_core_off.begin(), ksp->pc.h_core_off.end(), block_off);
     return DAS_OK;

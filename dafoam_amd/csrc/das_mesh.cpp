@@ -58,6 +58,7 @@ Options::Options() {
     d["jacLowerBounds.dRdW"] = 1.0e-30;
     d["jacLowerBounds.dRdWPC"] = 1.0e-30;
     // MI355X-specific knobs (not in the reference)
+    s["amd.pcType"] = "bilu";       // "bilu": global node-block ILU(0), sync-free sweeps (das_bilu.hpp); "ras": RAS + ILU(k) blocks in LDS
     i["amd.setupThreads"] = 32;     // host threads of the block-ILU setup (page-fault bound beyond that)
     i["amd.pcBlockCells"] = 1024;   // cells per additive-Schwarz block (one workgroup each)
     i["amd.jacMode"] = 1;           // operator assembly: 1 = dual numbers

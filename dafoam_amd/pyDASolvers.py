@@ -173,6 +173,21 @@ class KSP:
         check(L.das_ksp_get_blocks(self.handle, perm.ctypes.data_as(_capi.c_int_p), off.ctypes.data_as(_capi.c_ll_p)))
         return perm, off
 
+    def pcStructure(self):
+        """Node structure of the default ("bilu") preconditioner: dict(nodeUnk[nNodes, 8], bptr, bcol, lvlPtr, natural)."""
+        L = lib()
+        nN, nB, nLv = C.c_int(0), C.c_longlong(0), C.c_int(0)
+        check(L.das_ksp_get_pc_structure_sizes(self.handle, C.byref(nN), C.byref(nB), C.byref(nLv)))
+        nu = np.empty(nN.value * 8, np.int32)
+        bptr = np.empty(nN.value + 1, np.int64)
+        bcol = np.empty(nB.value, np.int32)
+        lvl = np.empty(nLv.value + 1, np.int32)
+        nat = np.empty(nN.value, np.int32)
+        ip = _capi.c_int_p
+        check(L.das_ksp_get_pc_structure(self.handle, nu.ctypes.data_as(ip), bptr.ctypes.data_as(_capi.c_ll_p), bcol.ctypes.data_as(ip),
+                                         lvl.ctypes.data_as(ip), nat.ctypes.data_as(ip)))
+        return dict(nodeUnk=nu.reshape(-1, 8), bptr=bptr, bcol=bcol, lvlPtr=lvl, natural=nat)
+
     def applyPC(self, solver, x):
         y = np.zeros_like(x)
         check(lib().das_ksp_apply_pc(solver._h, self.handle, dptr(np.ascontiguousarray(x)), dptr(y)))

@@ -266,6 +266,15 @@ int das_ksp_get_n_blocks(das_ksp_t* ksp);
 long long das_ksp_get_factor_nnz(das_ksp_t* ksp);
 long long das_ksp_get_n_ext(das_ksp_t* ksp);
 int das_ksp_get_blocks(das_ksp_t* ksp, int* perm, long long* block_off);
+/* node structure of the default preconditioner (amd.pcType "bilu": one node-block ILU(0) of jacPCMat per GPU, the
+ * reference's ASM+ILU stack DALinearEqn.C:199-299 with one sub-domain per rank): nodes of 8 unknown slots in processing
+ * (level) order, nodeUnk[8 nNodes] = state index or -1, block CSR bptr[nNodes+1]/bcol[nBlocks] over node positions,
+ * lvlPtr[nLevels+1], natural[nNodes] = index of the node in the natural (cell-by-cell) order.  das_pc_structure_* build it on the host without a GPU (tests), das_ksp_get_pc_structure* return
+ * the one a KSP was factorised on. */
+int das_pc_structure_build(das_solver_t* s, int* nNodes, long long* nBlocks, int* nLevels, int* reach);
+int das_pc_structure_get(das_solver_t* s, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural);
+int das_ksp_get_pc_structure_sizes(das_ksp_t* ksp, int* nNodes, long long* nBlocks, int* nLevels);
+int das_ksp_get_pc_structure(das_ksp_t* ksp, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural);
 int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, double* seconds);
 int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
 /* run exactly `iters` GMRES iterations on device-resident rhs/sol (bench.py "step"); no convergence exit */

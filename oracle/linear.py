@@ -205,3 +205,122 @@ class ThreadedOperators:
     def pc_solve(self, b):
         b = np.ascontiguousarray(b)
         return np.concatenate(list(self.pool.map(lambda t: t[0].solve(b[t[1][0]:t[1][1]]), zip(self.ilus, self.bounds))))
+
+
+class NodeBlockILU:
+    """Oracle of the product's default preconditioner (amd.pcType "bilu"): block ILU(0) of P on a given grouping of the
+    unknowns into nodes of <= 8 slots and a given node pattern - the reference's PC stack ASM + ILU
+    (DALinearEqn.C:199-299) with ONE sub-domain, restated as a dense-block incomplete factorisation.
+
+    node_unk[nNodes, 8] = unknown index or -1 (empty slot = identity row), bptr/bcol = block CSR over node positions.
+    Two independent formulations are provided and compared in tests/:
+      * `solve`        - dense 8x8 block IKJ factorisation in the GIVEN node order (numpy);
+      * `scalar_twin`  - the scalar ILU(0) (oracle C kernel) of P with the node pattern filled in explicitly, in any
+                         node order that keeps the relative order of coupled nodes (e.g. the natural one): the two are
+                         the same incomplete factorisation, because both drop exactly the updates outside the pattern.
+    """
+
+    def __init__(self, P, node_unk, bptr, bcol, shift=1e-12):
+        P = sp.csr_matrix(P)
+        self.n = P.shape[0]
+        nu = np.asarray(node_unk).reshape(-1, 8)
+        self.nu = nu
+        nN = nu.shape[0]
+        self.bptr = np.asarray(bptr, dtype=np.int64)
+        self.bcol = np.asarray(bcol, dtype=np.int64)
+        pos = np.full(self.n, -1, dtype=np.int64)
+        slot = np.zeros(self.n, dtype=np.int64)
+        for k in range(8):
+            m = nu[:, k] >= 0
+            pos[nu[m, k]] = np.nonzero(m)[0]
+            slot[nu[m, k]] = k
+        self.pos, self.slot = pos, slot
+        nB = self.bcol.size
+        val = np.zeros((nB, 8, 8))
+        # scatter the scalar entries (rows/cols outside the grouping are dropped: block-Jacobi across ranks)
+        C = P.tocoo()
+        keep = (pos[C.row] >= 0) & (pos[C.col] >= 0)
+        I, J = pos[C.row[keep]], pos[C.col[keep]]
+        key = I * nN + J
+        bkey = np.repeat(np.arange(nN), np.diff(self.bptr)) * nN + self.bcol
+        order = np.argsort(bkey)
+        e = order[np.searchsorted(bkey[order], key)]
+        if not np.all(bkey[e] == key):
+            raise ValueError("matrix entries outside the node pattern")
+        np.add.at(val, (e, slot[C.row[keep]], slot[C.col[keep]]), C.data[keep])
+        diag = np.empty(nN, dtype=np.int64)
+        for p in range(nN):
+            b0, b1 = self.bptr[p], self.bptr[p + 1]
+            diag[p] = b0 + np.searchsorted(self.bcol[b0:b1], p)
+            for k in range(8):
+                if nu[p, k] < 0:
+                    val[diag[p], k, k] = 1.0
+        invD = np.zeros((nN, 8, 8))
+        self.nshift = 0
+        for p in range(nN):
+            b0, b1 = self.bptr[p], self.bptr[p + 1]
+            cols = self.bcol[b0:b1]
+            for e in range(b0, diag[p]):
+                J = self.bcol[e]
+                L = val[e] @ invD[J]
+                val[e] = L
+                for f in range(diag[J] + 1, self.bptr[J + 1]):
+                    M = self.bcol[f]
+                    q = np.searchsorted(cols, M)
+                    if q < cols.size and cols[q] == M:
+                        val[b0 + q] -= L @ val[f]
+            D = val[diag[p]]
+            try:
+                invD[p] = np.linalg.inv(D)
+            except np.linalg.LinAlgError:
+                self.nshift += 1
+                invD[p] = np.linalg.inv(D + shift * np.eye(8))
+        self.val, self.diag, self.invD = val, diag, invD
+
+    def solve(self, b):
+        nu, nN = self.nu, self.nu.shape[0]
+        y = np.zeros((nN, 8))
+        m = nu >= 0
+        y[m] = np.asarray(b)[nu[m]]
+        for p in range(nN):
+            for e in range(self.bptr[p], self.diag[p]):
+                y[p] -= self.val[e] @ y[self.bcol[e]]
+        for p in range(nN - 1, -1, -1):
+            t = y[p].copy()
+            for e in range(self.diag[p] + 1, self.bptr[p + 1]):
+                t -= self.val[e] @ y[self.bcol[e]]
+            y[p] = self.invD[p] @ t
+        x = np.zeros(self.n)
+        x[nu[m]] = y[m]
+        return x
+
+    def scalar_twin(self, P, node_order=None):
+        """ILU(0) (scalar oracle kernel) of P on the explicitly filled node pattern; unknowns ordered node by node in
+        `node_order` (default: node positions sorted by their first unknown = the natural cell order)."""
+        nu, nN = self.nu, self.nu.shape[0]
+        if node_order is None:
+            first = np.where(nu >= 0, nu, np.iinfo(np.int64).max).min(axis=1)
+            node_order = np.argsort(first, kind="stable")
+        unk = np.concatenate([nu[p][nu[p] >= 0] for p in node_order])
+        n_loc = unk.size
+        loc = np.full(self.n, -1, dtype=np.int64)
+        loc[unk] = np.arange(n_loc)
+        Pl = sp.csr_matrix(P)[unk][:, unk].tocsr()
+        # pattern: all unknown pairs of coupled nodes
+        rows, cols = [], []
+        for p in range(nN):
+            up = loc[nu[p][nu[p] >= 0]]
+            for e in range(self.bptr[p], self.bptr[p + 1]):
+                uq = loc[nu[self.bcol[e]][nu[self.bcol[e]] >= 0]]
+                rr, cc = np.meshgrid(up, uq, indexing="ij")
+                rows.append(rr.ravel())
+                cols.append(cc.ravel())
+        E = sp.csr_matrix((np.full(sum(r.size for r in rows), 1e-300), (np.concatenate(rows), np.concatenate(cols))), shape=(n_loc, n_loc))
+        ilu = ILU((Pl + E).tocsr(), fill=0)
+
+        def solve(b):
+            x = np.zeros(self.n)
+            x[unk] = ilu.solve(np.asarray(b)[unk])
+            return x
+
+        return solve

@@ -15,7 +15,9 @@ ap.add_argument("--overlap", type=int, nargs="+", default=[1])
 ap.add_argument("--fill", type=int, nargs="+", default=[0])
 ap.add_argument("--lx", type=float, default=2.0)
 ap.add_argument("--fp32", type=int, nargs="+", default=[0])
-ap.add_argument("--threads", type=int, nargs="+", default=[64])
+ap.add_argument("--threads", type=int, nargs="+", default=[32])
+ap.add_argument("--pctype", nargs="+", default=["bilu"])
+ap.add_argument("--krylov-gb", type=float, default=32.0)
 a = ap.parse_args()
 import __graft_entry__ as ge
 ge.build()
@@ -35,14 +37,15 @@ N = case.mesh.n_cells
 rhs = np.zeros(n); rhs[0:3 * N:3] = 1.0 / N
 L = _capi.lib()
 import itertools
-for b, ov, fl, f32, nth in itertools.product(a.block, a.overlap, a.fill, a.fp32, a.threads):
-    D.solver.updateDAOption({"amd": {"pcBlockCells": b, "pcFactorFP32": f32, "setupThreads": nth}, "adjEqnOption": {"asmOverlap": ov, "pcFillLevel": fl}})
+for pct, b, ov, fl, f32, nth in itertools.product(a.pctype, a.block, a.overlap, a.fill, a.fp32, a.threads):
+    D.solver.updateDAOption({"amd": {"pcType": pct, "maxKrylovBytes": int(a.krylov_gb * 2**30), "pcBlockCells": b, "pcFactorFP32": f32, "setupThreads": nth}, "adjEqnOption": {"asmOverlap": ov, "pcFillLevel": fl}})
     ksp = KSP(); t = time.time(); D.solverAD.createMLRKSPMatrixFree(pc, ksp); t_ilu = time.time() - t
     x = Vec(n); r = Vec(n); r.array[:] = rhs
     L.das_timer_reset(D.solver._h); L.das_timer_enable(D.solver._h, 1)
     t = time.time(); fail = D.solverAD.solveLinearEqn(ksp, r, x); ts = time.time() - t
     info = ksp.info()
     h = ksp.history(); print("   hist", " ".join(f"{v/h[0]:.1e}" for v in h[::max(1,len(h)//12)]))
-    print(f"block {b} overlap {ov} fill {fl} fp32 {f32} threads {nth} nblocks {L.das_ksp_get_n_blocks(ksp.handle)}: ilu {t_ilu:.2f}s  iters {info['iters']} fail {fail} relres {info['res']/info['res0']:.2e} solve {ts:.3f}s "
+    print(f"pc {pct} block {b} overlap {ov} fill {fl} fp32 {f32} threads {nth} nblocks {L.das_ksp_get_n_blocks(ksp.handle)}: ilu {t_ilu:.2f}s  iters {info['iters']} fail {fail} relres {info['res']/info['res0']:.2e} solve {ts:.3f}s "
           f"-> {info['iters']/ts:.1f} it/s  spmv {L.das_timer_avg_ms(D.solver._h,b'spmv'):.3f} ms pc {L.das_timer_avg_ms(D.solver._h,b'pc'):.3f} ms")
     L.das_timer_enable(D.solver._h, 0)
+    ksp.destroy() if hasattr(ksp, 'destroy') else None
