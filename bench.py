@@ -1,14 +1,22 @@
 #!/usr/bin/env python
 """bench.py - adjoint hot-path benchmark (BASELINE.json metric: adjoint GMRES iterations/s + dRdWTPsi GB/s).
 
-One "step" = one right-preconditioned GMRES iteration of the adjoint solve (block-ILU(0) apply + dRdW^T.z SpMV +
-CGS2 orthogonalisation + norm) on the device-resident system assembled by coloured dual-number / FD perturbation
-of the HIP residual.  Inputs (matrices, rhs, Krylov basis) are resident in HBM when the timed region starts.
+Workload at N = 1: BASELINE configs[2] - DASimpleFoam + SA, 2 M-cell hex mesh (250x100x80 bump channel until the
+swept-wing generator exists), one GPU, full GMRES adjoint.  One "step" = one right-preconditioned GMRES iteration of
+the adjoint solve: node-block ILU(0) apply (two sync-free triangular sweeps) + dRdW^T.z SpMV + CGS (refine-if-needed)
+orthogonalisation against the j basis vectors + norm, on the device-resident system assembled by coloured dual-number /
+FD perturbation of the HIP residual.  Matrices, rhs and Krylov basis are resident in HBM when the timed region starts.
+
+Timed region: the solve is advanced W (= --warmup) iterations inside ONE Arnoldi cycle, then EXACTLY K (= --steps)
+iterations are timed, i.e. at basis sizes j in [W, W+K) (defaults 100 and 100: the orthogonalisation cost of a realistic
+solve, not of its first iterations).  Afterwards (N = 1) the same system is solved from scratch to gmresRelTol = 1e-6
+with the reference's defaults (gmresRestart 1000 capped by HBM, gmresMaxIters 1000): `config.solve` reports
+iterations, time_to_tolerance_s and the reference's fail flag (DALinearEqn.C:422-434).
 
   python bench.py --gpus 1 --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = transposed-CSR SpMV, HIP-event timed on the
-launch stream) and `cpu_baseline` (the oracle's C kernels on the host, bounded sample).
+Prints ONE JSON line (rank 0) with `roofline` (dRdW^T.psi SpMV, HIP-event timed on the launch stream), `roofline_pc`,
+`roofline_iteration` and `cpu_baseline` (the oracle's C kernels on the host cores, bounded sample).
 """
 import argparse
 import ctypes as C
@@ -23,22 +31,34 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+NORM = {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0}  # reference tests/runRegTests_AeroOpt.py:83
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--nx", type=int, default=int(os.environ.get("DAS_BENCH_NX", 100)))
-    ap.add_argument("--ny", type=int, default=int(os.environ.get("DAS_BENCH_NY", 50)))
-    ap.add_argument("--nz", type=int, default=int(os.environ.get("DAS_BENCH_NZ", 40)))
-    ap.add_argument("--cpu-sample-iters", type=int, default=int(os.environ.get("DAS_BENCH_CPU_ITERS", 6)))
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--nx", type=int, default=int(os.environ.get("DAS_BENCH_NX", 250)))
+    ap.add_argument("--ny", type=int, default=int(os.environ.get("DAS_BENCH_NY", 100)))
+    ap.add_argument("--nz", type=int, default=int(os.environ.get("DAS_BENCH_NZ", 80)))
+    ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("DAS_BENCH_CPU_SECONDS", 15.0)))
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--block", type=int, default=int(os.environ.get("DAS_BENCH_BLOCK", 1024)))
-    ap.add_argument("--overlap", type=int, default=int(os.environ.get("DAS_BENCH_OVERLAP", 1)))
-    ap.add_argument("--fill", type=int, default=int(os.environ.get("DAS_BENCH_FILL", 1)))
+    ap.add_argument("--no-solve", action="store_true", help="skip the solve-to-tolerance phase")
+    ap.add_argument("--pctype", default=os.environ.get("DAS_BENCH_PCTYPE", "bilu"))
+    ap.add_argument("--fp32-factor", type=int, default=int(os.environ.get("DAS_BENCH_PCFP32", 0)))
+    ap.add_argument("--krylov-gb", type=float, default=float(os.environ.get("DAS_BENCH_KRYLOV_GB", 140.0)))
     return ap.parse_args()
+
+
+def make_opts(a, dev_index, restart, maxit, rtol):
+    return {
+        "solverName": "DASimpleFoam",
+        "normalizeStates": dict(NORM),
+        "adjEqnOption": {"gmresRestart": int(restart), "gmresMaxIters": int(maxit), "gmresRelTol": rtol, "gmresAbsTol": 1e-300, "printInfo": 0},
+        "amd": {"pcType": a.pctype, "pcFactorFP32": a.fp32_factor, "maxKrylovBytes": int(a.krylov_gb * 2**30)},
+        "amdDevice": dev_index,
+    }
 
 
 def main():
@@ -63,10 +83,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), timeout=tmo)
         else:
             dist.init_process_group(backend, timeout=tmo)
-
-    # host-side setup (pattern build, ILU factorisation) is OpenMP-parallel: give every rank its share of the cores
-    # (torch.distributed.run exports OMP_NUM_THREADS=1 when it is unset; the library reads it when it is loaded below)
-    if world > 1:
+        # host-side setup is OpenMP-parallel: give every rank its share of the cores (torch.distributed.run exports
+        # OMP_NUM_THREADS=1 when it is unset; the library reads it when it is loaded below)
         os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // world))
 
     import __graft_entry__ as ge
@@ -83,20 +101,13 @@ def main():
     from dafoam_amd.pyDAFoam import PYDAFOAM
     from dafoam_amd.pyDASolvers import KSP, Mat
 
-    t_setup = time.time()
-    opts = {
-        "solverName": "DASimpleFoam",
-        "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0},
-        "adjEqnOption": {"gmresRestart": max(a.steps, a.warmup, 1), "gmresMaxIters": 100000, "gmresRelTol": 1e-30,
-                         "gmresAbsTol": 1e-300, "printInfo": 0, "asmOverlap": a.overlap, "pcFillLevel": a.fill},
-        "amd": {"pcBlockCells": a.block},
-        "amdDevice": dev_index,
-    }
     L = _capi.lib()
+    t_setup = time.time()
+    window_restart = max(a.steps + a.warmup, 1)
+    opts = make_opts(a, dev_index, window_restart, 10**9, 1e-30)
     sharded = None
     if world > 1:
-        # weak scaling: the global channel has nx*world cell columns, every rank owns nx of them (+3 ghost layers);
-        # halo reduction over RCCL p2p, dots over RCCL all-reduce (dafoam_amd/distributed.py)
+        # weak scaling: the global channel has nx*world cell columns, every rank owns nx of them (+3 ghost layers)
         from dafoam_amd.distributed import ShardedAdjoint
 
         sharded = ShardedAdjoint(a.nx * world, a.ny, a.nz, opts, device_index=dev_index)
@@ -108,6 +119,7 @@ def main():
         case = bench_channel_case(a.nx, a.ny, a.nz)
         ncell = case.mesh.n_cells
         D = PYDAFOAM(options=opts, case=case)
+    t_case = time.time() - t_setup
     h = D.solver._h
     n = D.getNLocalAdjointStates()
     t0 = time.time()
@@ -121,23 +133,25 @@ def main():
     ksp = KSP()
     t0 = time.time()
     D.solverAD.createMLRKSPMatrixFree(pc, ksp)
-    t_ilu = time.time() - t0
+    t_pc = time.time() - t0
     t0 = time.time()
     D.solverAD.initializedRdWTMatrixFree()
     t_op = time.time() - t0
-    # rhs on the device (torch owns the buffers; the C-ABI gets raw pointers)
-    rng = np.random.default_rng(1234 + rank)
-    rhs_h = rng.standard_normal(n)
+    # rhs on the device (torch owns the buffers; the C-ABI gets raw pointers): the volume-averaged x-velocity functional,
+    # dF/dW scaled like the reference scales its right-hand sides
+    N = case.mesh.n_cells
+    rhs_h = np.zeros(n)
+    rhs_h[0 : 3 * N : 3] = 1.0 / (N * world)
     if sharded is not None:
         rhs_h = np.where(sharded.owned, rhs_h, 0.0)
     rhs = torch.from_numpy(rhs_h).cuda()
     sol = torch.zeros(n, dtype=torch.float64, device="cuda")
     setup_s = time.time() - t_setup
 
-    def run(iters):
-        rc = L.das_ksp_run_fixed_device(h, ksp.handle, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()), int(iters))
+    def check(rc):
         if rc < 0:
             raise RuntimeError(L.das_last_error().decode())
+        return rc
 
     def barrier():
         torch.cuda.synchronize()
@@ -145,99 +159,145 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- timed window: iterations j in [W, W+K) of one Arnoldi cycle -------------------------------------------------
+    check(L.das_ksp_begin_device(h, ksp.handle, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()), 1))
     if a.warmup > 0:
-        run(a.warmup)
+        check(L.das_ksp_advance(h, ksp.handle, int(a.warmup)))
     L.das_timer_reset(h)
     L.das_timer_enable(h, 1)
     barrier()
     t0 = time.perf_counter()
-    run(a.steps)
+    check(L.das_ksp_advance(h, ksp.handle, int(a.steps)))
     barrier()
     dt = time.perf_counter() - t0
     L.das_timer_enable(h, 0)
+    check(L.das_ksp_end(h, ksp.handle))
     spmv_ms = L.das_timer_avg_ms(h, b"spmv")
     spmv_cnt = L.das_timer_count(h, b"spmv")
     pc_ms = L.das_timer_avg_ms(h, b"pc")
+    win_info = ksp.info()
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # operator size (for the algorithmic-bytes formula of SURVEY.md section 8d / BASELINE.md section 3)
+    # ---- algorithmic bytes (SURVEY.md section 8d / BASELINE.md section 3) ---------------------------------------------
     opmat_nnz = int(L.das_get_con_nnz(h, 0))
-    # the operator drops exact zeros (jacLowerBounds 1e-30): use its true nnz
-    op_nnz = int(L.das_op_nnz(h))
+    op_nnz = int(L.das_op_nnz(h))  # the operator drops exact zeros (jacLowerBounds 1e-30): its true nnz
     spmv_bytes = 12.0 * op_nnz + 4.0 * (n + 1) + 16.0 * n
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms and spmv_ms > 0 else None
-    pc_bytes = 12.0 * L.das_ksp_get_factor_nnz(ksp.handle) + 16.0 * L.das_ksp_get_n_ext(ksp.handle)
+    fac_entries = int(L.das_ksp_get_factor_nnz(ksp.handle))
+    n_ext = int(L.das_ksp_get_n_ext(ksp.handle))
+    if a.pctype == "bilu":
+        # dense 8x8 node blocks: 8 (4) B per factor entry, one int32 per block, + b, y, z, out vectors
+        pc_bytes = (4.0 if a.fp32_factor else 8.0) * fac_entries + 4.0 * fac_entries / 64.0 + 8.0 * (2 * n + 3 * n_ext)
+    else:
+        pc_bytes = 12.0 * fac_entries + 16.0 * n_ext
+    jmean = a.warmup + 0.5 * a.steps
+    iter_bytes = spmv_bytes + pc_bytes + 32.0 * jmean * n + 48.0 * n  # one CGS pass (dots + axpy)
+    ms_step = dt / a.steps * 1e3
+
+    # ---- solve to tolerance (N = 1): the reference's defaults ----------------------------------------------------------
+    solve = None
+    if world == 1 and not a.no_solve:
+        D.solver.updateDAOption({"adjEqnOption": {"gmresRestart": 1000, "gmresMaxIters": 1000, "gmresRelTol": 1e-6, "gmresAbsTol": 1e-14}})
+        sol.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        check(L.das_ksp_begin_device(h, ksp.handle, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()), 0))
+        while not check(L.das_ksp_advance(h, ksp.handle, 1000)):
+            pass
+        fail = check(L.das_ksp_end(h, ksp.handle))
+        torch.cuda.synchronize()
+        t_solve = time.perf_counter() - t0
+        inf = ksp.info()
+        hist = ksp.history()
+        solve = {"converged": fail == 0, "fail": int(fail), "iterations": inf["iters"], "time_to_tolerance_s": t_solve,
+                 "rel_residual": inf["res"] / inf["res0"] if inf["res0"] else None, "gmresRelTol": 1e-6,
+                 "restart_used": int(min(1000, a.krylov_gb * 2**30 // (8 * n) - 1)),
+                 "rel_residual_every_100": [float(v / hist[0]) for v in hist[::100]],
+                 "iterations_per_sec_whole_solve": inf["iters"] / t_solve}
 
     out = None
     if rank == 0:
         cpu = None
         if not a.no_cpu and world == 1:
-            cpu = cpu_baseline(D, pc, a.cpu_sample_iters, n)
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "spmv_traffic_bytes.json")
-        if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                cpu = cpu_baseline(a, dev_index, ncell)
+            except Exception as e:  # noqa: BLE001 - the baseline must never break the line
+                cpu = {"error": str(e)[:300]}
+        pc_desc = ("node-block ILU(0) of FD dRdWTPC over the whole rank (8-slot cell nodes, 8x8 fp%s blocks), factorised on the device, "
+                   "two sync-free sweeps per apply" % ("32" if a.fp32_factor else "64")) if a.pctype == "bilu" else \
+            "RAS(overlap 1)+ILU(1) of FD dRdWTPC, RCB blocks of <= 1024 cells, one workgroup per block"
         out = {
             "metric": "adjoint_gmres_iterations_per_sec",
-            # whole-job aggregate: every rank advances its 200k-cell shard through `steps` GMRES iterations of ONE global
-            # solve (weak scaling: N x more cells per iteration), so the job processes world * steps shard-iterations; at
-            # N = 1 this is the plain iterations/s of the solve.  config.global_solve_iterations_per_sec is steps / time.
+            # whole-job aggregate: every rank advances its shard through `steps` GMRES iterations of ONE global solve
+            # (weak scaling: N x more cells per iteration), so the job processes world * steps shard-iterations; at N = 1
+            # this is the plain iterations/s of the solve.  config.global_solve_iterations_per_sec is steps / time.
             "value": world * a.steps * 1.0 / dt,
             "unit": "iter/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"DASimpleFoam+SA adjoint, bump-channel hex mesh (state: prolonged converged coarse primal) {a.nx}x{a.ny}x{a.nz} = {ncell} cells per GPU "
-                            f"(stand-in for BASELINE configs[1] NACA0012 ~200k cells: same solver, 8 states/cell, reference stencil tables)",
+                "workload": f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell hex mesh per GPU ({a.nx}x{a.ny}x{a.nz} bump channel, wall-normal "
+                            f"grading; state: prolonged converged coarse primal), full GMRES adjoint, 8 states/cell, reference stencil tables; "
+                            f"timed iterations sit at Krylov basis sizes j in [{a.warmup}, {a.warmup + a.steps})",
                 "cells_per_gpu": ncell,
                 "global_cells": ncell * world,
                 "global_solve_iterations_per_sec": a.steps * 1.0 / dt,
-                "aggregation": "value = n_gpus x global_solve_iterations_per_sec: GMRES iterations/s per 200k-cell shard summed over the shards of one global solve",
+                "aggregation": "value = n_gpus x global_solve_iterations_per_sec (iterations/s per shard summed over the shards of one global solve)",
                 "states_per_gpu": n,
                 "dRdWT_nnz": op_nnz,
                 "dRdWT_structural_nnz": opmat_nnz,
                 "colors": int(ncolors),
-                "gmres_restart": max(a.steps, a.warmup, 1),
-                "pc": f"RAS(overlap {a.overlap} cell ring)+ILU({a.fill}) of FD dRdWTPC, RCB blocks of <= {a.block} cells, one workgroup per block",
+                "gmres_restart_window": window_restart,
+                "cgs_refinements_in_window_run": int(L.das_ksp_get_n_refine(ksp.handle)) if hasattr(L, "das_ksp_get_n_refine") else None,
+                "pc": pc_desc,
+                "pc_factor_entries": fac_entries,
                 "halo_ms": L.das_timer_avg_ms(h, b"halo") if world > 1 else None,
-                "setup_seconds": {"total": setup_s, "coloring_host": t_color, "dRdWTPC_fd": t_pcmat, "ilu_host": t_ilu, "dRdWT_dual": t_op},
+                "setup_seconds": {"total": setup_s, "mesh_and_state_host": t_case, "coloring_host": t_color, "dRdWTPC_fd_gpu": t_pcmat,
+                                  "pc_factorisation": t_pc, "dRdWT_dual_gpu": t_op},
                 "dRdWTPsi_GBps": achieved,
                 "spmv_ms": spmv_ms,
                 "pc_apply_ms": pc_ms,
+                "window_rel_residual": win_info["res"] / win_info["res0"] if win_info["res0"] else None,
+                "solve": solve,
             },
             "roofline": {
-                "kernel": "k_spmv (dRdW^T.psi, transposed CSR fp64/int32)",
+                "kernel": "k_spmv_wave (dRdW^T.psi, transposed CSR fp64/int32)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": traffic,
+                "traffic": None,  # PMC passes are separate runs: profiles/ holds them (profiles/README.md)
                 "launches_timed": int(spmv_cnt),
                 "algorithmic_bytes_per_launch": spmv_bytes,
             },
             "roofline_pc": {
-                "kernel": "k_ras_apply (RAS+ILU(k) level-scheduled triangular solves; largest share of an iteration)",
+                "kernel": "k_bilu_sweep x2 (forward + backward node-block sweeps)" if a.pctype == "bilu" else "k_ras_apply",
                 "bound": "hbm",
                 "achieved": pc_bytes / (pc_ms * 1e-3) / 1e9 if pc_ms and pc_ms > 0 else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": pc_bytes / (pc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pc_ms and pc_ms > 0 else None,
                 "algorithmic_bytes_per_launch": pc_bytes,
-                "note": "12 B per factor entry (fp64 value + 2x u16 index) + 16 B per extended unknown; measured to be bound by the per-level LDS dependency chain, not by bytes",
+            },
+            "roofline_iteration": {
+                "bound": "hbm",
+                "algorithmic_bytes_per_step": iter_bytes,
+                "formula": "B_spmv + B_pc + 32 j n + 48 n at the mean j of the window (one CGS pass)",
+                "achieved": iter_bytes / (ms_step * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": iter_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             "cpu_baseline": cpu,
         }
@@ -247,58 +307,62 @@ def main():
     return out
 
 
-def cpu_baseline(D, pc, iters, n):
-    """The oracle's C kernels (oracle/csrc/oracle_linalg.c: CSR SpMV, ILU(0) solve, CGS2) timed on ONE host core on
-    the same matrices (exported from HBM): `iters` GMRES iterations.  kind = "port" (CPU restatement, not DAFoam)."""
+def cpu_baseline(a, dev_index, ncell_gpu):
+    """CPU restatement (kind "port": the oracle's C kernels, NOT DAFoam) on the host cores, bounded sample: the same solver
+    on a 10x smaller mesh of the same family (100x50x40 = 200 k cells) - its matrices are assembled by the GPU path and
+    copied back - runs right-preconditioned GMRES with a row-chunked SpMV and block-Jacobi ILU(1) (one block per thread:
+    the reference's one-ASM-sub-domain-per-MPI-rank layout) for about `--cpu-seconds`; iterations/s is scaled to the
+    GPU mesh by the cell ratio (every per-iteration cost of this algorithm is linear in the cell count)."""
     from oracle import linear as OL
+    from dafoam_amd.meshgen import bench_channel_case
+    from dafoam_amd.pyDAFoam import PYDAFOAM
     from dafoam_amd.pyDASolvers import Mat
-    import ctypes as C
-    from dafoam_amd import _capi
 
     t0 = time.time()
-    # export the operator: re-assemble into a Mat handle to read it back
+    dims = (100, 50, 40)
+    case = bench_channel_case(*dims)
+    D = PYDAFOAM(options=make_opts(a, dev_index, 50, 50, 1e-30), case=case)
+    D.solver.runColoring()
+    P = Mat()
+    D.solver.calcdRdWT(1, P)
     A = Mat()
     D.solver.calcdRdWT(0, A, mode=1)
-    Ah = A.to_scipy()
-    Ph = pc.to_scipy()
+    Ah, Ph = A.to_scipy(), P.to_scipy()
     A.destroy()
-    ilu = OL.ILU(Ph, fill=0)
-    Ac = OL.CSR(Ah)
-    rng = np.random.default_rng(1234)
-    rhs = rng.standard_normal(n)
+    P.destroy()
+    n = Ah.shape[0]
+    N = case.mesh.n_cells
+    rhs = np.zeros(n)
+    rhs[0 : 3 * N : 3] = 1.0 / N
+    threads = max(1, min(64, (os.cpu_count() or 1)))
+    T = OL.ThreadedOperators(Ah, Ph, threads, fill=1)
     prep = time.time() - t0
-    t0 = time.perf_counter()
-    x, info = OL.gmres(Ac.matvec, rhs, ilu.solve, restart=iters, fixed_iters=iters)
-    dt = time.perf_counter() - t0
     t1 = time.perf_counter()
-    Ac.matvec(rhs)
+    T.matvec(rhs)
     t_spmv = time.perf_counter() - t1
-    out = {
-        "value": iters / dt,
+    # pilot of 3 iterations sizes the bounded sample
+    t1 = time.perf_counter()
+    OL.gmres(T.matvec, rhs, T.pc_solve, restart=3, fixed_iters=3)
+    per_it = (time.perf_counter() - t1) / 3
+    iters = int(max(5, min(200, a.cpu_seconds / max(per_it, 1e-6))))
+    t1 = time.perf_counter()
+    OL.gmres(T.matvec, rhs, T.pc_solve, restart=iters, fixed_iters=iters)
+    dt = time.perf_counter() - t1
+    ratio = N / float(ncell_gpu)
+    return {
+        "value": iters / dt * ratio,
         "unit": "iter/s",
-        "cores": 1,
+        "cores": T.threads,
         "kind": "port",
-        "sample": f"{iters} GMRES iterations (oracle C SpMV + ILU(0) + CGS2, gcc -O3 -march=native) on the same dRdWT/dRdWTPC "
-                  f"matrices copied back from HBM; one oracle SpMV = {t_spmv*1e3:.1f} ms; export+ILU prep {prep:.1f} s (untimed)",
+        "sample": f"{iters} GMRES iterations at basis sizes j < {iters} on a {dims[0]}x{dims[1]}x{dims[2]} = {N}-cell mesh of the same family (matrices assembled "
+                  f"on the GPU, copied back): oracle C kernels (gcc -O3 -march=native), {T.threads} threads, row-chunked SpMV + block-Jacobi ILU(1) "
+                  f"(one block per thread), serial CGS2; measured {iters / dt:.2f} iter/s at {N} cells, scaled by {ratio:.3f} to the {ncell_gpu}-cell GPU workload; "
+                  f"one SpMV {t_spmv * 1e3:.1f} ms; prep {prep:.1f} s (untimed)",
+        "measured_iter_per_sec_at_sample_size": iters / dt,
+        "sample_cells": N,
         "spmv_GBps": (12.0 * Ah.nnz + 4.0 * (n + 1) + 16.0 * n) / t_spmv / 1e9,
+        "host_cpus": os.cpu_count(),
     }
-    # multi-core leg (informative, never allowed to break the line): chunked mat-vec + block-Jacobi ILU(0), one block per
-    # thread - the reference's one-ASM-block-per-MPI-rank layout without the overlap
-    try:
-        if os.environ.get("DAS_BENCH_CPU_MT", "1") != "0":
-            threads = max(2, min(32, (os.cpu_count() or 2)))
-            t0 = time.time()
-            T = OL.ThreadedOperators(Ah, Ph, threads, fill=0)
-            prep_mt = time.time() - t0
-            t0 = time.perf_counter()
-            OL.gmres(T.matvec, rhs, T.pc_solve, restart=iters, fixed_iters=iters)
-            dt_mt = time.perf_counter() - t0
-            out["multicore"] = {"value": iters / dt_mt, "unit": "iter/s", "cores": T.threads, "kind": "port",
-                                "sample": f"{iters} GMRES iterations, {T.threads} threads: row-chunked oracle SpMV + block-Jacobi ILU(0) "
-                                          f"(one block per thread), serial CGS2; prep {prep_mt:.1f} s (untimed)"}
-    except Exception as e:  # noqa: BLE001
-        out["multicore"] = {"error": str(e)[:200]}
-    return out
 
 
 if __name__ == "__main__":

@@ -185,6 +185,7 @@ _SIGS = {
     "das_get_n_local_adjoint_states": (C.c_longlong, [_VP]),
     "das_get_n_local_cells": (C.c_longlong, [_VP]),
     "das_get_n_global_cells": (C.c_longlong, [_VP]),
+    "das_set_n_global_cells": (C.c_int, [_VP, C.c_longlong]),
     "das_get_n_local_points": (C.c_longlong, [_VP]),
     "das_get_n_local_faces": (C.c_longlong, [_VP]),
     "das_get_geometry": (C.c_int, [_VP] + [c_double_p] * 8),
@@ -206,6 +207,7 @@ _SIGS = {
     "das_mat_nnz": (C.c_longlong, [_VP]),
     "das_mat_export": (C.c_int, [_VP, c_ll_p, c_int_p, c_double_p]),
     "das_mat_mult": (C.c_int, [_VP, c_double_p, c_double_p]),
+    "das_mat_create_from_csr": (C.c_int, [C.c_longlong, c_ll_p, c_int_p, c_double_p, C.POINTER(_VP)]),
     "das_mat_destroy": (None, [_VP]),
     "das_initialize_drdwt_matrix_free": (C.c_int, [_VP]),
     "das_destroy_drdwt_matrix_free": (C.c_int, [_VP]),
@@ -239,9 +241,18 @@ _SIGS = {
     "das_ksp_get_pc_structure": (C.c_int, [_VP, c_int_p, c_ll_p, c_int_p, c_int_p, c_int_p]),
     "das_ksp_get_info": (C.c_int, [_VP, c_int_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_get_history": (C.c_int, [_VP, c_double_p, C.c_int]),
+    "das_ksp_get_n_refine": (C.c_int, [_VP]),
     "das_ksp_run_fixed_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),
+    "das_ksp_begin_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),
+    "das_ksp_advance": (C.c_int, [_VP, _VP, C.c_int]),
+    "das_ksp_end": (C.c_int, [_VP, _VP]),
     "das_ksp_destroy": (None, [_VP]),
     "das_set_owned_mask": (C.c_int, [_VP, C.POINTER(C.c_ubyte)]),
+    "das_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "das_comm_init_rccl": (C.c_int, [_VP, C.c_int, C.c_int, C.c_char_p]),
+    "das_comm_set_halo": (C.c_int, [_VP, C.c_int, c_int_p, c_ll_p, c_int_p, c_ll_p, c_int_p, C.c_longlong, c_int_p]),
+    "das_set_exchange_cb": (C.c_int, [_VP, _VP, _VP]),
+    "das_comm_is_native": (C.c_int, [_VP]),
     "das_set_comm": (C.c_int, [_VP, _VP, _VP, _VP]),
     "das_set_stream": (C.c_int, [_VP, _VP]),
     "das_get_elapsed_clock_time": (C.c_double, [_VP]),

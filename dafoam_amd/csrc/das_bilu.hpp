@@ -344,12 +344,51 @@ struct NodeILU {
     long long factor_bytes() const { return (nL + nU) * BILU_NB2 * (fp32 ? 4 : 8) + (long long)nNodes * BILU_NB2 * 8; }
 };
 
+// reverse Cuthill-McKee ordering of the owned cells on the face-neighbour graph (jacMatReOrdering "rcm": the reference
+// hands MATORDERINGRCM to the sub-domain ILU, DALinearEqn.C:238-290); start cells are pseudo-peripheral (two BFS sweeps)
+inline std::vector<int> bilu_rcm_cells(const Mesh& m, const std::vector<char>& cellOwned) {
+    const int nC = m.nC;
+    std::vector<int> order, deg(nC, 0), queue;
+    std::vector<char> seen(nC, 0);
+    order.reserve(nC);
+    for (int c = 0; c < nC; c++) for (int q = m.cc_ptr[c]; q < m.cc_ptr[c + 1]; q++) deg[c] += cellOwned[m.cc[q]] ? 1 : 0;
+    auto bfs = [&](int start, std::vector<int>& out, std::vector<char>& mark) {
+        const size_t first = out.size();
+        out.push_back(start);
+        mark[start] = 1;
+        std::vector<int> nb;
+        for (size_t head = first; head < out.size(); head++) {
+            const int c = out[head];
+            nb.clear();
+            for (int q = m.cc_ptr[c]; q < m.cc_ptr[c + 1]; q++) { const int d = m.cc[q]; if (cellOwned[d] && !mark[d]) { mark[d] = 1; nb.push_back(d); } }
+            std::sort(nb.begin(), nb.end(), [&](int a, int b) { return deg[a] < deg[b] || (deg[a] == deg[b] && a < b); });
+            out.insert(out.end(), nb.begin(), nb.end());
+        }
+    };
+    std::vector<char> tmpMark(nC, 0);
+    std::vector<int> tmp;
+    for (int c0 = 0; c0 < nC; c0++) {
+        if (!cellOwned[c0] || seen[c0]) continue;
+        // pseudo-peripheral start: the last cell of a BFS from c0, then the last cell of a BFS from there
+        int start = c0;
+        for (int sweep = 0; sweep < 2; sweep++) {
+            tmp.clear();
+            bfs(start, tmp, tmpMark);
+            start = tmp.back();
+            for (int c : tmp) tmpMark[c] = 0;
+        }
+        bfs(start, order, seen);
+    }
+    std::reverse(order.begin(), order.end());
+    return order;
+}
+
 // Structure: nodes, node pattern, level order.  `states` = DAIndex state blocks, `owned` (per state, may be empty) /
 // `cellOwned` restrict the preconditioner to this rank's unknowns, `reach` = stencil reach in cell rings.
 inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned,
                                  const std::vector<char>& cellOwned, int reach, NodeILU& P, std::vector<int>& unkNode,
                                  std::vector<unsigned char>& unkSlot, std::vector<long long>& bptr, std::vector<long long>& bdiag,
-                                 std::vector<int>& bcol, int nthr) {
+                                 std::vector<int>& bcol, int nthr, bool rcm = false) {
     const int nC = m.nC;
     // ---- unknowns cell by cell, packed into nodes of 8 slots
     std::vector<std::vector<int>> ownedFaces;
@@ -370,9 +409,12 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
     std::vector<long long> tmp;
     int fillSlots = BILU_NB;  // slots used in the current node (BILU_NB = closed)
     auto is_owned = [&](long long g) { return owned.empty() || owned[g]; };
-    for (int c = 0; c < nC; c++) {
-        cellNode_ptr[c + 1] = cellNode_ptr[c];
-        if (!cellOwned[c]) continue;
+    // cell order of the elimination: the mesh's own numbering, or RCM of the cell graph
+    std::vector<int> cellOrder;
+    if (rcm) cellOrder = bilu_rcm_cells(m, cellOwned);
+    else { cellOrder.reserve(nC); for (int c = 0; c < nC; c++) if (cellOwned[c]) cellOrder.push_back(c); }
+    std::vector<std::pair<int, int>> cellNodePairs;  // (cell, node), cells in visiting order
+    for (int c : cellOrder) {
         tmp.clear();
         for (const StateDef& sd : states) {
             if (sd.kind == KIND_VEC) { for (int k = 0; k < 3; k++) if (is_owned(sd.offset + 3LL * c + k)) tmp.push_back(sd.offset + 3LL * c + k); }
@@ -393,12 +435,19 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
             }
             const int node = (int)nodeCell_ptr.size() - 2;
             if (nodeCell.empty() || nodeCell_ptr[node + 1] == nodeCell_ptr[node] || nodeCell.back() != c) { nodeCell.push_back(c); nodeCell_ptr[node + 1]++; }
-            if (cellNode.empty() || cellNode_ptr[c + 1] == cellNode_ptr[c] || cellNode.back() != node) { cellNode.push_back(node); cellNode_ptr[c + 1]++; }
+            if (cellNodePairs.empty() || cellNodePairs.back() != std::make_pair(c, node)) cellNodePairs.push_back({c, node});
             while (done < mc && fillSlots < BILU_NB) nodeUnk0[(size_t)node * BILU_NB + fillSlots++] = (int)tmp[done++];
         }
     }
     const int nN = (int)nodeCell_ptr.size() - 1;
     DAS_CHECK(nN > 0, DAS_ERR_INTERNAL, "preconditioner: no owned unknowns");
+    for (const auto& pr : cellNodePairs) cellNode_ptr[pr.first + 1]++;
+    for (int c = 0; c < nC; c++) cellNode_ptr[c + 1] += cellNode_ptr[c];
+    cellNode.resize(cellNodePairs.size());
+    {
+        std::vector<int> fill(cellNode_ptr.begin(), cellNode_ptr.end() - 1);
+        for (const auto& pr : cellNodePairs) cellNode[fill[pr.first]++] = pr.second;
+    }
     // ---- node pattern: nodes of all cells within `reach` rings of the node's cells (symmetric by construction)
     std::vector<long long> rptr(nN + 1, 0);
     std::vector<std::vector<int>> rows(nN);
@@ -475,7 +524,7 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
 // Numeric setup on the device from the assembled PC matrix (device CSR, rows = states).
 inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned, int reach,
                        bool fp32, long long An, const long long* d_rp, const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P,
-                       bool debug, int nthr) {
+                       bool debug, int nthr, bool rcm) {
     const double t0 = wall_seconds();
     std::vector<char> cellOwned(m.nC, 1);
     if (!owned.empty()) {
@@ -486,7 +535,7 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     std::vector<int> unkNode, bcol;
     std::vector<unsigned char> unkSlot;
     std::vector<long long> bptr, bdiag;
-    bilu_build_structure(m, states, n, owned, cellOwned, reach, P, unkNode, unkSlot, bptr, bdiag, bcol, std::max(1, nthr));
+    bilu_build_structure(m, states, n, owned, cellOwned, reach, P, unkNode, unkSlot, bptr, bdiag, bcol, std::max(1, nthr), rcm);
     const int nN = P.nNodes;
     P.fp32 = fp32;
     P.nodeUnk.upload(P.h_nodeUnk);

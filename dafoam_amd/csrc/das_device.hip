@@ -18,6 +18,7 @@
 #include "das_case.hpp"
 #include "das_jaccon.hpp"
 #include "das_bilu.hpp"
+#include "das_comm.hpp"
 
 #include <omp.h>
 
@@ -648,7 +649,8 @@ struct das_ksp {
     NodeILU bilu;     // amd.pcType "bilu" (default): global node-block ILU(0), sync-free sweeps (das_bilu.hpp)
     bool useBilu = false;
     int restart = 0;
-    DevBuf<double> V, w, z, r, xdev, bdev, partial, hdev;
+    DevBuf<double> V, w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
+    std::unique_ptr<struct GmresRun> run;
     int iters = 0, nrefine = 0;
     double res0 = 0, res = 0, seconds = 0;
     std::vector<double> hist;
@@ -702,10 +704,12 @@ struct das_solver {
     };
     std::map<std::string, FaceFn> functions;
     long long geomVersion = 0;  // bumped by das_update_of_mesh
+    long long nGlobalCells = 0; // sharded runs (das_set_n_global_cells); 0 = single domain
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::vector<unsigned char> owned;  // per state; empty = single-domain
     DevBuf<unsigned char> d_owned;
+    HaloPlan halo;  // native halo reduction / all-reduce (das_comm.hpp); the two callbacks below are the legacy host transport
     das_halo_cb halo_cb = nullptr;
     das_allreduce_cb allreduce_cb = nullptr;
     void* comm_user = nullptr;
@@ -802,10 +806,17 @@ static ConDev& ensure_con_dev(das_solver* s, int isPC) {
 
 static void spmv(das_solver* s, const Mat& A, const double* x, double* y) {
     hipEvent_t ev = nullptr;
+    // sharded: ghost rows first (their contributions travel to the owner ranks while the owned rows are computed)
+    if (s->halo.active) s->halo.begin(A, x, s->stream);
     s->timer.begin("spmv", s->stream, ev);
     hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(A.n), dim3(256), 0, s->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y);
     s->timer.end("spmv", s->stream, ev);
-    if (s->halo_cb) {  // ghost-row contributions -> owner ranks (one neighbour exchange per product)
+    if (s->halo.active) {
+        hipEvent_t eh = nullptr;
+        s->timer.begin("halo", s->stream, eh);
+        s->halo.finish(y, s->stream);
+        s->timer.end("halo", s->stream, eh);
+    } else if (s->halo_cb) {  // legacy transport: the whole halo reduction in a host callback
         hipEvent_t eh = nullptr;
         s->timer.begin("halo", s->stream, eh);
         s->halo_cb(y, s->comm_user);
@@ -1335,6 +1346,14 @@ static int pc_stencil_reach(das_solver* s) {
     return reach;
 }
 
+// adjEqnOption.jacMatReOrdering (DALinearEqn.C:82-83,238-290): ordering of the unknowns inside the sub-domain ILU.
+// "natural" = the mesh's cell numbering, "rcm" = reverse Cuthill-McKee of the cell graph; the others are rejected.
+static bool pc_ordering_rcm(das_solver* s) {
+    const std::string& o = s->opt.gets("adjEqnOption.jacMatReOrdering");
+    DAS_CHECK(o == "natural" || o == "rcm", DAS_ERR_ARG, "adjEqnOption.jacMatReOrdering \"" + o + "\" is not implemented (natural | rcm)");
+    return o == "rcm";
+}
+
 // global node-block ILU(0) (das_bilu.hpp): one incomplete factorisation of dRdWTPC over this rank's unknowns
 static void setup_node_ilu(das_solver* s, das_ksp* k) {
     const double t0 = wall_seconds();
@@ -1342,7 +1361,7 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     const int reach = pc_stencil_reach(s);
     const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
     bilu_setup(s->mesh, s->st_full.states, s->n, s->owned, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
-               k->bilu, s->opt.geti("debug") != 0, nthr);
+               k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s));
     k->useBilu = true;
     k->pc.setup_seconds = wall_seconds() - t0;
     k->pc.nBlocks = 1;
@@ -1369,8 +1388,11 @@ static void pc_apply(das_solver* s, das_ksp* k, const double* b, double* x) {
 }
 
 // ---- restarted right-preconditioned GMRES on the device (reference DALinearEqn.C:28-339 settings) -----------------
-// Orthogonalisation: classical Gram-Schmidt, fused multi-dot (one pass over the basis), refined by a second pass
-// (CGS2; the reference uses KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160).  Givens rotations on the host.
+// Orthogonalisation: classical Gram-Schmidt, fused multi-dot (one pass over the basis), refined by a second pass if
+// needed (the reference uses KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160), or modified Gram-Schmidt when
+// adjEqnOption.useMGSO is set (DALinearEqn.C:162-167).  Givens rotations on the host.  The solve is a small state
+// machine (begin / step / end) so that a caller can advance it a given number of iterations (bench.py times a window of
+// iterations deep inside a cycle).
 static void gmres_ws(das_solver* s, das_ksp* k) {
     const long long n = s->n;
     long long restart = std::min<long long>(s->opt.geti("adjEqnOption.gmresRestart"), s->opt.geti("adjEqnOption.gmresMaxIters"));
@@ -1385,138 +1407,222 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
         k->z.zero();  // multi-GPU: ghost entries are never written by the PC and must stay zero
         int nb = nblk(n, MD_CHUNK);
         k->partial.alloc((size_t)(restart + 2) * nb);
-        k->hdev.alloc(restart + 2);
+        k->hdev.alloc(2 * (restart + 2));
     }
 }
 
-// h[0..m) = V^T w, h[m] = w.w  (device result in k->hdev, copied to host)
-static void multidot(das_solver* s, das_ksp* k, int m, const double* w, double* h_host) {
+// dev_out[0..m) = V^T w (V = m vectors of stride n starting at Vbase), dev_out[m] = w.w; summed over the ranks
+static void multidot_dev(das_solver* s, das_ksp* k, const double* Vbase, int m, const double* w, double* dev_out) {
     const long long n = s->n;
     int nb = nblk(n, MD_CHUNK);
-    hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, n, m, k->V.p, n, w, k->partial.p, nb);
-    hipLaunchKernelGGL(k_reduce, dim3(m + 1), dim3(256), 0, s->stream, nb, k->partial.p, k->hdev.p);
-    if (s->allreduce_cb) s->allreduce_cb(k->hdev.p, m + 1, s->comm_user);
+    hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, n, m, Vbase, n, w, k->partial.p, nb);
+    hipLaunchKernelGGL(k_reduce, dim3(m + 1), dim3(256), 0, s->stream, nb, k->partial.p, dev_out);
+    if (!(s->halo.active && s->halo.allreduce(dev_out, m + 1, s->stream)) && s->allreduce_cb) s->allreduce_cb(dev_out, m + 1, s->comm_user);
+}
+// h[0..m) = V^T w, h[m] = w.w  (device result in k->hdev, copied to host)
+static void multidot(das_solver* s, das_ksp* k, int m, const double* w, double* h_host) {
+    multidot_dev(s, k, k->V.p, m, w, k->hdev.p);
     DAS_HIP(hipMemcpyAsync(h_host, k->hdev.p, (m + 1) * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     DAS_HIP(hipStreamSynchronize(s->stream));
 }
 
-static int run_gmres(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x, int fixed_iters) {
+// z = M^{-1} v: the factorisation, wrapped in globalPCIters x localPCIters Richardson sweeps on jacPCMat when the
+// options ask for more than one (reference DALinearEqn.C:173-205, 237-260: KSPRICHARDSON around ASM and around the
+// sub-domain ILU; with one sub-domain per GPU both iterate the same stationary scheme, so l x g sweeps in total)
+static void pc_apply_full(das_solver* s, das_ksp* k, const double* v, double* z) {
+    const long long sweeps = std::max<long long>(1, s->opt.geti("adjEqnOption.globalPCIters")) * std::max<long long>(1, s->opt.geti("adjEqnOption.localPCIters"));
+    pc_apply(s, k, v, z);
+    if (sweeps <= 1) return;
+    const long long n = s->n;
+    if (k->rich_r.n != (size_t)n) { k->rich_r.alloc(n); k->rich_d.alloc(n); k->rich_d.zero(); }
+    const Mat& P = k->pcmat->m;
+    for (long long it = 1; it < sweeps; it++) {
+        hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(P.n), dim3(256), 0, s->stream, P.n, P.rowptr.p, P.col.p, P.val.p, z, k->rich_r.p);
+        hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, v, -1.0, k->rich_r.p);  // r = v - P z
+        pc_apply(s, k, k->rich_r.p, k->rich_d.p);
+        hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, k->rich_d.p, 1.0, z);
+    }
+}
+
+struct GmresRun {
+    bool open = false;        // inside an Arnoldi cycle
+    bool fixed = false;       // no convergence exit (bench)
+    int m = 0, j = 0;
+    long long its = 0, maxIts = 0;
+    double beta = 0, target = 0, rtol = 0, atol = 0, t0 = 0;
+    const double* d_rhs = nullptr;
+    double* d_x = nullptr;
+    std::vector<double> H, cs, sn, g, hh, h2, y;
+};
+
+static void gmres_true_residual(das_solver* s, das_ksp* k, GmresRun& G, bool haveGuess) {
+    const long long n = s->n;
+    hipStream_t st = s->stream;
+    if (haveGuess) {
+        spmv(s, s->op->m, G.d_x, k->r.p);
+        hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, st, n, 1.0, G.d_rhs, -1.0, k->r.p);
+    } else {
+        DAS_HIP(hipMemsetAsync(G.d_x, 0, n * sizeof(double), st));
+        DAS_HIP(hipMemcpyAsync(k->r.p, G.d_rhs, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    multidot(s, k, 0, k->r.p, G.hh.data());
+    G.beta = std::sqrt(G.hh[0]);
+}
+
+static void gmres_begin(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x, bool fixed) {
     need_init(s);
     DAS_CHECK(s->op, DAS_ERR_STATE, "initializedRdWTMatrixFree() must be called before solveLinearEqn()");
-    const Mat& A = s->op->m;
-    const long long n = s->n;
     gmres_ws(s, k);
-    const int B = 256;
-    hipStream_t st = s->stream;
+    if (!k->run) k->run.reset(new GmresRun);
+    GmresRun& G = *k->run;
     const int m = k->restart;
-    const long long maxIts = fixed_iters > 0 ? fixed_iters : s->opt.geti("adjEqnOption.gmresMaxIters");
-    const double rtol = s->opt.getd("adjEqnOption.gmresRelTol"), atol = s->opt.getd("adjEqnOption.gmresAbsTol");
-    const bool nonzeroGuess = s->opt.geti("adjEqnOption.useNonZeroInitGuess") != 0;
-    const bool alwaysRefine = s->opt.geti("amd.cgsAlwaysRefine") != 0;
+    G = GmresRun();
+    G.m = m; G.fixed = fixed; G.d_rhs = d_rhs; G.d_x = d_x;
+    G.maxIts = s->opt.geti("adjEqnOption.gmresMaxIters");
+    G.rtol = s->opt.getd("adjEqnOption.gmresRelTol"); G.atol = s->opt.getd("adjEqnOption.gmresAbsTol");
+    G.H.assign((size_t)(m + 1) * m, 0.0); G.cs.assign(m, 0.0); G.sn.assign(m, 0.0); G.g.assign(m + 1, 0.0);
+    G.hh.assign(m + 2, 0.0); G.h2.assign(m + 2, 0.0); G.y.assign(m, 0.0);
     k->nrefine = 0;
-    double t0 = wall_seconds();
-    std::vector<double> H((size_t)(m + 1) * m, 0.0), cs(m), sn(m), g(m + 1), hh(m + 2), h2(m + 2), y(m);
     k->hist.clear();
-    int its = 0;
-    // r = b - A x0
-    if (nonzeroGuess) {
-        spmv(s, A, d_x, k->r.p);
-        hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, d_rhs, -1.0, k->r.p);
+    G.t0 = wall_seconds();
+    gmres_true_residual(s, k, G, s->opt.geti("adjEqnOption.useNonZeroInitGuess") != 0);
+    k->res0 = G.beta;
+    k->hist.push_back(G.beta);
+    G.target = std::max(G.rtol * G.beta, G.atol);
+}
+static void gmres_cycle_start(das_solver* s, das_ksp* k) {
+    GmresRun& G = *k->run;
+    const long long n = s->n;
+    hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, k->r.p, k->V.p);
+    std::fill(G.g.begin(), G.g.end(), 0.0);
+    G.g[0] = G.beta;
+    G.j = 0;
+    G.open = true;
+}
+// one Arnoldi step; returns the recurrence residual norm
+static double gmres_iter(das_solver* s, das_ksp* k) {
+    GmresRun& G = *k->run;
+    const long long n = s->n;
+    const int B = 256, m = G.m, j = G.j;
+    hipStream_t st = s->stream;
+    const Mat& A = s->op->m;
+    const bool alwaysRefine = s->opt.geti("amd.cgsAlwaysRefine") != 0;
+    const bool mgs = s->opt.geti("adjEqnOption.useMGSO") != 0;
+    std::vector<double>&H = G.H, &hh = G.hh, &h2 = G.h2, &cs = G.cs, &sn = G.sn, &g = G.g;
+    double* vj = k->V.p + (long long)j * n;
+    pc_apply_full(s, k, vj, k->z.p);
+    spmv(s, A, k->z.p, k->w.p);
+    double hn;
+    std::fill(h2.begin(), h2.end(), 0.0);
+    if (mgs) {
+        // modified Gram-Schmidt: j+1 dependent (dot, axpy) pairs, coefficients stay on the device until the end
+        double* hcol = k->hdev.p + (m + 2);
+        for (int i = 0; i <= j; i++) {
+            multidot_dev(s, k, k->V.p + (long long)i * n, 1, k->w.p, k->hdev.p);
+            DAS_HIP(hipMemcpyAsync(hcol + i, k->hdev.p, sizeof(double), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, 1, k->V.p + (long long)i * n, n, k->hdev.p, k->w.p);
+        }
+        multidot_dev(s, k, k->V.p, 0, k->w.p, k->hdev.p);
+        DAS_HIP(hipMemcpyAsync(hcol + j + 1, k->hdev.p, sizeof(double), hipMemcpyDeviceToDevice, st));
+        DAS_HIP(hipMemcpyAsync(hh.data(), hcol, (j + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+        DAS_HIP(hipStreamSynchronize(st));
+        hn = std::sqrt(std::max(hh[j + 1], 0.0));
     } else {
-        DAS_HIP(hipMemsetAsync(d_x, 0, n * sizeof(double), st));
-        DAS_HIP(hipMemcpyAsync(k->r.p, d_rhs, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-    }
-    multidot(s, k, 0, k->r.p, hh.data());
-    double beta = std::sqrt(hh[0]);
-    k->res0 = beta;
-    k->hist.push_back(beta);
-    double target = std::max(rtol * beta, atol);
-    bool done = (fixed_iters <= 0) && beta <= target;
-    while (!done) {
-        int mm = (int)std::min<long long>(m, maxIts - its);
-        if (mm <= 0) break;
-        if (beta == 0.0) break;
-        hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / beta, k->r.p, k->V.p);
-        std::fill(g.begin(), g.end(), 0.0);
-        g[0] = beta;
-        int j = 0;
-        while (j < mm) {
-            double* vj = k->V.p + (long long)j * n;
-            pc_apply(s, k, vj, k->z.p);
-            spmv(s, A, k->z.p, k->w.p);
-            // classical Gram-Schmidt, one fused pass: h = V^T w and w.w; refinement only if needed (reference:
-            // KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160): refine when the projected vector keeps less than half
-            // of its squared norm, i.e. ||w - V h||^2 (= w.w - h.h) < h.h
-            multidot(s, k, j + 1, k->w.p, hh.data());
+        // classical Gram-Schmidt, one fused pass: h = V^T w and w.w; refinement only if needed (reference:
+        // KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160): refine when the projected vector keeps less than half
+        // of its squared norm, i.e. ||w - V h||^2 (= w.w - h.h) < h.h
+        multidot(s, k, j + 1, k->w.p, hh.data());
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
+        double hsq = 0.0;
+        for (int i = 0; i <= j; i++) hsq += hh[i] * hh[i];
+        const double ww = hh[j + 1];
+        const double est = ww - hsq;
+        if (alwaysRefine || !(est > hsq) || !(est > 0.0)) {
+            multidot(s, k, j + 1, k->w.p, h2.data());
             hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
-            double hsq = 0.0;
-            for (int i = 0; i <= j; i++) hsq += hh[i] * hh[i];
-            const double ww = hh[j + 1];
-            double est = ww - hsq;
-            double hn;
-            std::fill(h2.begin(), h2.end(), 0.0);
-            if (alwaysRefine || !(est > hsq) || !(est > 0.0)) {
-                multidot(s, k, j + 1, k->w.p, h2.data());
-                hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
-                double hn2;
-                multidot(s, k, 0, k->w.p, &hn2);
-                hn = std::sqrt(std::max(hn2, 0.0));
-                k->nrefine++;
-            } else {
-                hn = std::sqrt(est);
-            }
-            for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = hh[i] + h2[i];
-            H[(size_t)(j + 1) * m + j] = hn;
-            if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, k->w.p, k->V.p + (long long)(j + 1) * n);
-            for (int i = 0; i < j; i++) {
-                double a = H[(size_t)i * m + j], b2 = H[(size_t)(i + 1) * m + j];
-                H[(size_t)i * m + j] = cs[i] * a + sn[i] * b2;
-                H[(size_t)(i + 1) * m + j] = -sn[i] * a + cs[i] * b2;
-            }
-            double a = H[(size_t)j * m + j], b2 = H[(size_t)(j + 1) * m + j];
-            double d = std::hypot(a, b2);
-            cs[j] = d > 0 ? a / d : 1.0;
-            sn[j] = d > 0 ? b2 / d : 0.0;
-            H[(size_t)j * m + j] = d;
-            H[(size_t)(j + 1) * m + j] = 0.0;
-            g[j + 1] = -sn[j] * g[j];
-            g[j] = cs[j] * g[j];
-            its++;
-            j++;
-            double res = std::fabs(g[j]);
-            k->hist.push_back(res);
-            if (fixed_iters <= 0 && (res <= target || its >= maxIts)) break;
-            if (hn == 0.0) break;
+            double hn2;
+            multidot(s, k, 0, k->w.p, &hn2);
+            hn = std::sqrt(std::max(hn2, 0.0));
+            k->nrefine++;
+        } else {
+            hn = std::sqrt(est);
         }
-        // back substitution, x += M^{-1} (V y)
-        for (int i = j - 1; i >= 0; i--) {
-            double sacc = g[i];
-            for (int q = i + 1; q < j; q++) sacc -= H[(size_t)i * m + q] * y[q];
-            y[i] = sacc / H[(size_t)i * m + i];
-        }
-        DAS_HIP(hipMemcpyAsync(k->hdev.p, y.data(), j * sizeof(double), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, j, k->V.p, n, k->hdev.p, k->w.p);
-        pc_apply(s, k, k->w.p, k->z.p);
-        hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, k->z.p, 1.0, d_x);
-        // true residual
-        spmv(s, A, d_x, k->r.p);
-        hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, d_rhs, -1.0, k->r.p);
-        multidot(s, k, 0, k->r.p, hh.data());
-        beta = std::sqrt(hh[0]);
-        k->hist.back() = beta;
-        if (fixed_iters > 0) done = its >= fixed_iters;
-        else done = beta <= target || its >= maxIts;
     }
-    DAS_HIP(hipStreamSynchronize(st));
-    if (k->useBilu) DAS_CHECK(!bilu_aborted(k->bilu, st), DAS_ERR_INTERNAL, "preconditioner sweep timed out (bounded spin)");
-    k->iters = its;
+    for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = hh[i] + h2[i];
+    H[(size_t)(j + 1) * m + j] = hn;
+    if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, k->w.p, k->V.p + (long long)(j + 1) * n);
+    for (int i = 0; i < j; i++) {
+        double a = H[(size_t)i * m + j], b2 = H[(size_t)(i + 1) * m + j];
+        H[(size_t)i * m + j] = cs[i] * a + sn[i] * b2;
+        H[(size_t)(i + 1) * m + j] = -sn[i] * a + cs[i] * b2;
+    }
+    double a = H[(size_t)j * m + j], b2 = H[(size_t)(j + 1) * m + j];
+    double d = std::hypot(a, b2);
+    cs[j] = d > 0 ? a / d : 1.0;
+    sn[j] = d > 0 ? b2 / d : 0.0;
+    H[(size_t)j * m + j] = d;
+    H[(size_t)(j + 1) * m + j] = 0.0;
+    g[j + 1] = -sn[j] * g[j];
+    g[j] = cs[j] * g[j];
+    G.its++;
+    G.j++;
+    const double res = std::fabs(g[G.j]);
+    k->hist.push_back(res);
+    if (hn == 0.0) G.j = -G.j;  // happy breakdown: close the cycle (sign marks it)
+    return res;
+}
+// back substitution, x += M^{-1} (V y), true residual
+static void gmres_cycle_end(das_solver* s, das_ksp* k) {
+    GmresRun& G = *k->run;
+    const long long n = s->n;
+    const int B = 256, m = G.m, j = std::abs(G.j);
+    hipStream_t st = s->stream;
+    for (int i = j - 1; i >= 0; i--) {
+        double sacc = G.g[i];
+        for (int q = i + 1; q < j; q++) sacc -= G.H[(size_t)i * m + q] * G.y[q];
+        G.y[i] = sacc / G.H[(size_t)i * m + i];
+    }
+    DAS_HIP(hipMemcpyAsync(k->hdev.p, G.y.data(), j * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, j, k->V.p, n, k->hdev.p, k->w.p);
+    pc_apply_full(s, k, k->w.p, k->z.p);
+    hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, k->z.p, 1.0, G.d_x);
+    gmres_true_residual(s, k, G, true);
+    k->hist.back() = G.beta;
+    G.open = false;
+}
+// advance by up to `nsteps` iterations (cycles are opened / closed as needed); returns true when the solve is over
+static bool gmres_advance(das_solver* s, das_ksp* k, long long nsteps) {
+    GmresRun& G = *k->run;
+    for (long long t = 0; t < nsteps; t++) {
+        if (!G.fixed && !G.open && (G.beta <= G.target || G.its >= G.maxIts)) return true;
+        if (G.beta == 0.0) return true;
+        if (!G.open) gmres_cycle_start(s, k);
+        const double res = gmres_iter(s, k);
+        const bool stop = !G.fixed && (res <= G.target || G.its >= G.maxIts);
+        if (G.j < 0 || G.j >= G.m || stop) gmres_cycle_end(s, k);
+    }
+    return !G.fixed && !G.open && (G.beta <= G.target || G.its >= G.maxIts);
+}
+static int gmres_end(das_solver* s, das_ksp* k) {
+    GmresRun& G = *k->run;
+    if (G.open) gmres_cycle_end(s, k);
+    DAS_HIP(hipStreamSynchronize(s->stream));
+    if (k->useBilu) DAS_CHECK(!bilu_aborted(k->bilu, s->stream), DAS_ERR_INTERNAL, "preconditioner sweep timed out (bounded spin)");
+    k->iters = (int)G.its;
     k->res = k->hist.back();
-    k->seconds = wall_seconds() - t0;
+    k->seconds = wall_seconds() - G.t0;
     // reference failure rule (DALinearEqn.C:422-434)
-    double absRatio = k->res / atol;
-    double relRatio = k->res0 > 0 ? k->res / k->res0 / rtol : 0.0;
+    double absRatio = k->res / G.atol;
+    double relRatio = k->res0 > 0 ? k->res / k->res0 / G.rtol : 0.0;
     double diff = s->opt.getd("adjEqnOption.gmresTolDiff");
     return (relRatio > diff && absRatio > diff) ? 1 : 0;
+}
+
+static int run_gmres(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x, int fixed_iters) {
+    gmres_begin(s, k, d_rhs, d_x, fixed_iters > 0);
+    if (fixed_iters > 0) gmres_advance(s, k, fixed_iters);
+    else while (!gmres_advance(s, k, 1 << 20)) {}
+    return gmres_end(s, k);
 }
 
 // =====================================================================================================
@@ -1627,7 +1733,15 @@ int das_init_solver(das_solver_t* s, int device) {
 
 long long das_get_n_local_adjoint_states(das_solver_t* s) { return s ? s->n : -1; }
 long long das_get_n_local_cells(das_solver_t* s) { return s ? s->mesh.nC : -1; }
-long long das_get_n_global_cells(das_solver_t* s) { return s ? s->mesh.nC : -1; }
+long long das_get_n_global_cells(das_solver_t* s) { return s ? (s->nGlobalCells > 0 ? s->nGlobalCells : (long long)s->mesh.nC) : -1; }
+// sharded runs: the cell count of the whole (undecomposed) mesh, set by the partitioner
+int das_set_n_global_cells(das_solver_t* s, long long nGlobal) {
+    DAS_TRY
+    DAS_CHECK(s && nGlobal > 0, DAS_ERR_ARG, "bad argument");
+    s->nGlobalCells = nGlobal;
+    return DAS_OK;
+    DAS_CATCH
+}
 long long das_get_n_local_points(das_solver_t* s) { return s ? s->mesh.nP : -1; }
 long long das_get_n_local_faces(das_solver_t* s) { return s ? s->mesh.nF : -1; }
 
@@ -1800,6 +1914,22 @@ int das_mat_mult(das_mat_t* m, const double* x, double* y) {
     hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(m->m.n), dim3(256), 0, 0, m->m.n, m->m.rowptr.p, m->m.col.p, m->m.val.p, dx.p, dy.p);
     DAS_HIP(hipDeviceSynchronize());
     dy.download(y, m->m.n);
+    return DAS_OK;
+    DAS_CATCH
+}
+// a matrix read from a file (reference: PETSc.Mat().load of dRdWTPC.bin when adjEqnOption.readPCMat is set,
+// mphys_dafoam.py:469-471,520-522) -> device CSR handle
+int das_mat_create_from_csr(long long n, const long long* rowptr, const int* colidx, const double* vals, das_mat_t** out) {
+    DAS_TRY
+    DAS_CHECK(n > 0 && rowptr && colidx && vals && out, DAS_ERR_ARG, "bad argument");
+    DAS_CHECK(das_device_count() > 0, DAS_ERR_NO_DEVICE, "no HIP device visible");
+    std::unique_ptr<das_mat> m(new das_mat);
+    m->m.n = n;
+    m->m.nnz = rowptr[n];
+    m->m.rowptr.upload(rowptr, n + 1);
+    m->m.col.upload(colidx, m->m.nnz);
+    m->m.val.upload(vals, m->m.nnz);
+    *out = m.release();
     return DAS_OK;
     DAS_CATCH
 }
@@ -2254,7 +2384,7 @@ int das_pc_structure_build(das_solver_t* s, int* nNodes, long long* nBlocks, int
     std::vector<unsigned char> unkSlot;
     std::vector<long long> bptr, bdiag;
     const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
-    bilu_build_structure(s->mesh, s->st_full.states, s->n, s->owned, cellOwned, rch, s->pcStruct, unkNode, unkSlot, bptr, bdiag, bcol, nthr);
+    bilu_build_structure(s->mesh, s->st_full.states, s->n, s->owned, cellOwned, rch, s->pcStruct, unkNode, unkSlot, bptr, bdiag, bcol, nthr, pc_ordering_rcm(s));
     if (nNodes) *nNodes = s->pcStruct.nNodes;
     if (nBlocks) *nBlocks = s->pcStruct.nnzB;
     if (nLevels) *nLevels = s->pcStruct.nLevels;
@@ -2307,6 +2437,7 @@ int das_ksp_get_info(das_ksp_t* k, int* iters, double* res0, double* res, double
     return DAS_OK;
     DAS_CATCH
 }
+int das_ksp_get_n_refine(das_ksp_t* k) { return k ? k->nrefine : -1; }
 int das_ksp_get_history(das_ksp_t* k, double* hist, int cap) {
     DAS_TRY
     DAS_CHECK(k && hist, DAS_ERR_ARG, "null argument");
@@ -2319,6 +2450,27 @@ int das_ksp_run_fixed_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rh
     DAS_TRY
     DAS_CHECK(ksp && d_rhs && d_sol && iters > 0, DAS_ERR_ARG, "bad argument");
     return run_gmres(s, ksp, d_rhs, d_sol, iters);
+    DAS_CATCH
+}
+// the same solve as a state machine on device-resident rhs/sol: begin, advance by n iterations (returns 1 once the solve
+// is over: converged or gmresMaxIters reached; never in `fixed` mode), end (closes the cycle, returns the fail code)
+int das_ksp_begin_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rhs, double* d_sol, int fixed) {
+    DAS_TRY
+    DAS_CHECK(ksp && d_rhs && d_sol, DAS_ERR_ARG, "bad argument");
+    gmres_begin(s, ksp, d_rhs, d_sol, fixed != 0);
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_ksp_advance(das_solver_t* s, das_ksp_t* ksp, int iters) {
+    DAS_TRY
+    DAS_CHECK(ksp && ksp->run && iters > 0, DAS_ERR_STATE, "das_ksp_begin_device has not been called");
+    return gmres_advance(s, ksp, iters) ? 1 : 0;
+    DAS_CATCH
+}
+int das_ksp_end(das_solver_t* s, das_ksp_t* ksp) {
+    DAS_TRY
+    DAS_CHECK(ksp && ksp->run, DAS_ERR_STATE, "das_ksp_begin_device has not been called");
+    return gmres_end(s, ksp);
     DAS_CATCH
 }
 void das_ksp_destroy(das_ksp_t* k) { delete k; }
@@ -2341,6 +2493,68 @@ int das_set_comm(das_solver_t* s, das_halo_cb halo, das_allreduce_cb allreduce, 
     return DAS_OK;
     DAS_CATCH
 }
+// ---- native communication (das_comm.hpp) ---------------------------------------------------------------------------
+// rank 0 creates the RCCL unique id (128 bytes); the host side distributes it (bootstrap only)
+int das_comm_unique_id(char* out128) {
+    DAS_TRY
+    DAS_CHECK(out128, DAS_ERR_ARG, "null argument");
+    rccl().load();
+    ncclUniqueId id;
+    DAS_NCCL(rccl().GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId size");
+    std::memcpy(out128, &id, sizeof(id));
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_comm_init_rccl(das_solver_t* s, int rank, int world, const char* id128) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(id128 && world >= 1 && rank >= 0 && rank < world, DAS_ERR_ARG, "bad argument");
+    rccl().load();
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    DAS_HIP(hipSetDevice(s->device));
+    DAS_NCCL(rccl().CommInitRank(&s->halo.comm, world, id, rank));
+    s->halo.rank = rank;
+    s->halo.world = world;
+    s->halo.ensure_streams();
+    return DAS_OK;
+    DAS_CATCH
+}
+// host-staged transport of the same plan (gloo tests on single-GPU boxes): cb(d_send, d_recv) moves the packed segments
+int das_set_exchange_cb(das_solver_t* s, das_exchange_cb cb, void* user) {
+    DAS_TRY
+    DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
+    s->halo.exchange_cb = cb;
+    s->halo.cb_user = user;
+    return DAS_OK;
+    DAS_CATCH
+}
+// the halo plan: per peer the extended rows I hold for it (send, evaluated first) and my owned rows it holds as ghosts
+// (recv, in the peer's send order); ghostIdx = all local ghost rows (zeroed after the reduction)
+int das_comm_set_halo(das_solver_t* s, int npeers, const int* peers, const long long* sendOff, const int* sendIdx, const long long* recvOff,
+                      const int* recvIdx, long long nGhost, const int* ghostIdx) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(npeers >= 0 && (npeers == 0 || (peers && sendOff && recvOff)), DAS_ERR_ARG, "bad argument");
+    HaloPlan& H = s->halo;
+    H.peers.assign(peers, peers + npeers);
+    H.sendOff.assign(1, 0);
+    H.recvOff.assign(1, 0);
+    if (npeers) { H.sendOff.assign(sendOff, sendOff + npeers + 1); H.recvOff.assign(recvOff, recvOff + npeers + 1); }
+    H.nSend = H.sendOff.back(); H.nRecv = H.recvOff.back(); H.nGhost = nGhost;
+    for (long long k = 0; k < H.nSend; k++) DAS_CHECK(sendIdx[k] >= 0 && sendIdx[k] < s->n, DAS_ERR_ARG, "send index out of range");
+    for (long long k = 0; k < H.nRecv; k++) DAS_CHECK(recvIdx[k] >= 0 && recvIdx[k] < s->n, DAS_ERR_ARG, "recv index out of range");
+    if (H.nSend) { H.sendIdx.upload(sendIdx, H.nSend); H.sendBuf.alloc(H.nSend); }
+    if (H.nRecv) { H.recvIdx.upload(recvIdx, H.nRecv); H.recvBuf.alloc(H.nRecv); }
+    if (nGhost) H.ghostIdx.upload(ghostIdx, nGhost);
+    H.ensure_streams();
+    H.active = true;
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_comm_is_native(das_solver_t* s) { return (s && s->halo.comm) ? 1 : 0; }
+
 int das_set_stream(das_solver_t* s, void* hip_stream) {
     DAS_TRY
     need_init(s);

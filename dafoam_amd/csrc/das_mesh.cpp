@@ -38,7 +38,7 @@ Options::Options() {
     i["adjEqnOption.globalPCIters"] = 0;
     i["adjEqnOption.asmOverlap"] = 1;
     i["adjEqnOption.localPCIters"] = 1;
-    s["adjEqnOption.jacMatReOrdering"] = "rcm";
+    s["adjEqnOption.jacMatReOrdering"] = "rcm";  // of the cell graph (natural | rcm are implemented)
     i["adjEqnOption.pcFillLevel"] = 1;
     i["adjEqnOption.gmresMaxIters"] = 1000;
     i["adjEqnOption.gmresRestart"] = 1000;

@@ -143,6 +143,82 @@ class HaloExchange:
         return w
 
 
+def install_comm(obj, native=None):
+    """Install the communication of one shard (obj: .h, .L, .key, .owner_rank, .rank, .world, .dev, .n, .halo):
+
+      * backend nccl (RCCL, one GPU per rank): the halo plan goes to the C++ library, which issues grouped
+        ncclSend/ncclRecv on its own communication stream overlapped with the owned-row product and an in-stream
+        ncclAllReduce for the dots - nothing of torch.distributed runs inside the iteration loop (das_comm.hpp);
+      * backend gloo (CPU tests / several ranks on one GPU): the SAME plan (pack, overlap order, unpack in C++) with a
+        host-staged exchange callback, and the all-reduce callback.
+    """
+    import torch
+    import torch.distributed as dist
+
+    from . import _capi
+
+    L, h, halo = obj.L, obj.h, obj.halo
+    if native is None:
+        native = dist.get_backend() == "nccl"
+    peers = list(halo.peers)
+    send = [halo.send_idx[q].cpu().numpy() if q in halo.send_idx else np.zeros(0, np.int64) for q in peers]
+    recv = [halo.recv_idx[q].cpu().numpy() if q in halo.recv_idx else np.zeros(0, np.int64) for q in peers]
+    sendOff = np.concatenate([[0], np.cumsum([a.size for a in send])]).astype(np.int64)
+    recvOff = np.concatenate([[0], np.cumsum([a.size for a in recv])]).astype(np.int64)
+    sendIdx = (np.concatenate(send) if peers else np.zeros(0)).astype(np.int32)
+    recvIdx = (np.concatenate(recv) if peers else np.zeros(0)).astype(np.int32)
+    ghostIdx = halo.ghost_idx.cpu().numpy().astype(np.int32)
+    peers_a = np.asarray(peers, dtype=np.int32)
+    ip, lp = _capi.c_int_p, _capi.c_ll_p
+    if native:
+        ident = [None]
+        if obj.rank == 0:
+            buf = C.create_string_buffer(128)
+            _capi.check(L.das_comm_unique_id(buf))
+            ident[0] = buf.raw
+        dist.broadcast_object_list(ident, src=0)
+        _capi.check(L.das_comm_init_rccl(h, obj.rank, obj.world, ident[0]))
+    _capi.check(L.das_comm_set_halo(h, len(peers), peers_a.ctypes.data_as(ip), sendOff.ctypes.data_as(lp), sendIdx.ctypes.data_as(ip),
+                                    recvOff.ctypes.data_as(lp), recvIdx.ctypes.data_as(ip), int(ghostIdx.size), ghostIdx.ctypes.data_as(ip)))
+    obj._comm_native = bool(native)
+    if native:
+        obj._cb = ()
+        return
+    nS, nR = int(sendOff[-1]), int(recvOff[-1])
+    stage = dist.get_backend() == "gloo"
+
+    def exch_cb(ps, pr, _user):
+        torch.cuda.current_stream(obj.dev).synchronize()
+        sb = torch.as_tensor(_DevPtr(ps, nS), device=obj.dev) if nS else torch.empty(0, dtype=torch.float64, device=obj.dev)
+        rb = torch.as_tensor(_DevPtr(pr, nR), device=obj.dev) if nR else None
+        src = sb.cpu() if stage else sb
+        dst = torch.empty(nR, dtype=torch.float64, device="cpu" if stage else obj.dev)
+        ops = []
+        for i, q in enumerate(peers):
+            if sendOff[i + 1] > sendOff[i]:
+                ops.append(dist.P2POp(dist.isend, src[sendOff[i]:sendOff[i + 1]], q))
+            if recvOff[i + 1] > recvOff[i]:
+                ops.append(dist.P2POp(dist.irecv, dst[recvOff[i]:recvOff[i + 1]], q))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        if nR:
+            rb.copy_(dst)
+
+    def ared_cb(ptr, m, _user):
+        t = torch.as_tensor(_DevPtr(ptr, m), device=obj.dev)
+        if stage:
+            c = t.cpu()
+            dist.all_reduce(c)
+            t.copy_(c)
+        else:
+            dist.all_reduce(t)
+
+    obj._cb = (_EXCH_CB(exch_cb), _ARED_CB(ared_cb))  # keep alive
+    _capi.check(L.das_set_exchange_cb(h, C.cast(obj._cb[0], C.c_void_p), None))
+    _capi.check(L.das_set_comm(h, None, C.cast(obj._cb[1], C.c_void_p), None))
+
+
 class _DevPtr:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
@@ -150,6 +226,7 @@ class _DevPtr:
 
 _HALO_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 _ARED_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+_EXCH_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 class ShardedAdjoint:
@@ -198,24 +275,9 @@ class ShardedAdjoint:
         self.dev = torch.device("cuda", device_index)
         self.halo = HaloExchange(self.key, self.owner_rank, self.rank, self.world, device=self.dev)
         _capi.check(L.das_set_stream(h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
-        n = self.n = self.key.size
-        stage = dist.get_backend() == "gloo"
-
-        def halo_cb(ptr, _user):
-            w = torch.as_tensor(_DevPtr(ptr, n), device=self.dev)
-            self.halo.reduce_(w)
-
-        def ared_cb(ptr, m, _user):
-            t = torch.as_tensor(_DevPtr(ptr, m), device=self.dev)
-            if stage:
-                c = t.cpu()
-                dist.all_reduce(c)
-                t.copy_(c)
-            else:
-                dist.all_reduce(t)
-
-        self._cb = (_HALO_CB(halo_cb), _ARED_CB(ared_cb))  # keep alive
-        _capi.check(L.das_set_comm(h, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
+        self.n = self.key.size
+        _capi.check(L.das_set_n_global_cells(h, int(NX) * int(NY) * int(NZ)))
+        install_comm(self)
         self.n_owned = int(self.owned.sum())
 
     # ------------------------------------------------------------------ solve_linear sequence on the shard
@@ -399,21 +461,7 @@ class ShardedAdjointGeneral(ShardedAdjoint):
         self.dev = torch.device("cuda", device_index)
         self.halo = HaloExchange(self.key, self.owner_rank, self.rank, self.world, device=self.dev)
         _capi.check(L.das_set_stream(h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
-        n = self.n = self.key.size
-        stage = dist.get_backend() == "gloo"
-
-        def halo_cb(ptr, _user):
-            self.halo.reduce_(torch.as_tensor(_DevPtr(ptr, n), device=self.dev))
-
-        def ared_cb(ptr, m_, _user):
-            t = torch.as_tensor(_DevPtr(ptr, m_), device=self.dev)
-            if stage:
-                c = t.cpu()
-                dist.all_reduce(c)
-                t.copy_(c)
-            else:
-                dist.all_reduce(t)
-
-        self._cb = (_HALO_CB(halo_cb), _ARED_CB(ared_cb))
-        _capi.check(L.das_set_comm(h, C.cast(self._cb[0], C.c_void_p), C.cast(self._cb[1], C.c_void_p), None))
+        self.n = self.key.size
+        _capi.check(L.das_set_n_global_cells(h, int(global_case.mesh.n_cells)))
+        install_comm(self)
         self.n_owned = int(self.owned.sum())

@@ -18,21 +18,19 @@ from .pyDASolvers import KSP, Mat, Vec, pyDASolvers
 
 
 class Error(Exception):
-    """Format the error message in a box (reference pyDAFoam.py Error class)."""
+    """Error type of the pyDAFoam mirror (same name and role as the reference's pyDAFoam.Error): the message is
+    printed inside a ruled box, 80 columns wide, before the exception propagates."""
+
+    WIDTH = 80
 
     def __init__(self, message):
-        msg = "\n+" + "-" * 78 + "+" + "\n" + "| pyDAFoam Error: "
-        i = 19
-        for word in message.split():
-            if len(word) + i + 1 > 78:
-                msg += " " * (78 - i) + "|\n| " + word + " "
-                i = 1 + len(word) + 1
-            else:
-                msg += word + " "
-                i += len(word) + 1
-        msg += " " * (78 - i) + "|\n" + "+" + "-" * 78 + "+" + "\n"
-        print(msg)
-        Exception.__init__(self, message)
+        import textwrap
+
+        inner = self.WIDTH - 4
+        lines = textwrap.wrap("pyDAFoam Error: " + str(message), width=inner) or [""]
+        rule = "+" + "-" * (self.WIDTH - 2) + "+"
+        print("\n".join([""] + [rule] + ["| " + ln.ljust(inner) + " |" for ln in lines] + [rule, ""]))
+        super().__init__(message)
 
 
 class DAOPTION(object):
@@ -281,19 +279,30 @@ class PYDAFOAM(object):
         return vec
 
     # ---------------------------------------------------------------- adjoint (mphys_dafoam.py:433-574 sequence)
-    def solveAdjoint(self, dFdWArray):
+    def solveAdjoint(self, dFdWArray, psi0=None):
         """psi with D_s (dR/dW)^T psi = dFdW (dFdW already state-scaled like the output of
-        calcJacTVecProduct(stateVar -> function), DASolver.C:1820).  Returns (psi, fail)."""
+        calcJacTVecProduct(stateVar -> function), DASolver.C:1820).  Returns (psi, fail).  Follows
+        DAFoamSolver.solve_linear (dafoam/mphys/mphys_dafoam.py:433-574): colouring once, dRdWTPC + KSP rebuilt every
+        adjPCLag solves (or read from dRdWTPC.bin under adjEqnOption.readPCMat, :469-471), matrix-free operator per
+        solve, optional non-zero initial guess `psi0` and dynamically adjusted tolerance (dynAdjustTol, :540-544,576-611)."""
         dFdW = self.array2Vec(np.ascontiguousarray(dFdWArray, dtype=np.float64))
         if self.getOption("adjUseColoring") and self.runColoring:
             self.solver.runColoring(cacheDir=self.getOption("amdColoringDir") or None)
             self.runColoring = False
         adjPCLag = self.getOption("adjPCLag")
         writeJac = self.getOption("writeJacobians")
+        adjOpt = self.getOption("adjEqnOption")
         if self.nSolveAdjoints % adjPCLag == 0 or self.dRdWTPC is None:
-            self.dRdWTPC = Mat().create()
-            self.solver.calcdRdWT(1, self.dRdWTPC)
-            if "dRdWTPC" in writeJac or "all" in writeJac:  # DASolver.C:1080-1085 (matName dRdWTPC when isPC=1)
+            if adjOpt.get("readPCMat"):
+                from .petsc_io import read_mat
+
+                self.dRdWTPC = Mat.from_scipy(read_mat("dRdWTPC.bin"))
+            else:
+                self.dRdWTPC = Mat().create()
+                self.solver.calcdRdWT(1, self.dRdWTPC)
+            # DASolver.C:1080-1085: calcdRdWT writes the matrix it has just built under the "dRdWT" key (matName
+            # dRdWTPC when isPC = 1); the explicit "dRdWTPC" key is kept as an alias
+            if any(k in writeJac for k in ("dRdWT", "dRdWTPC", "all")):
                 from .petsc_io import write_mat
 
                 write_mat("dRdWTPC.bin", self.dRdWTPC.to_scipy())
@@ -313,7 +322,21 @@ class PYDAFOAM(object):
             write_vec("dRdWColoring_1.bin", self.solver.getColoring()[0].astype(float))
         psi = Vec(len(dFdWArray))
         psi.set(0)
+        if adjOpt.get("useNonZeroInitGuess") and psi0 is not None:
+            psi.array[:] = np.asarray(psi0, dtype=np.float64)
+        if adjOpt.get("dynAdjustTol"):
+            self._updateKSPTolerances(psi, dFdW, self.ksp)
         fail = self.solverAD.solveLinearEqn(self.ksp, dFdW, psi)
         self.solverAD.destroydRdWTMatrixFree()
         self.nSolveAdjoints += 1
         return self.vec2Array(psi), fail
+
+    def _updateKSPTolerances(self, psi, dFdW, ksp):
+        """dynAdjustTol (reference DAFoamSolver._updateKSPTolerances, mphys_dafoam.py:576-611): converge gmresRelTol
+        orders below the CURRENT residual of the initial guess: atol = max(||A psi0 - dFdW|| * rtol0, atol0), rtol = 0."""
+        n = dFdW.array.size
+        r = np.zeros(n)
+        self.solverAD.calcJacTVecProduct("states", "stateVar", self.getStates(), "residuals", "residual", np.ascontiguousarray(psi.array), r)
+        rNorm = float(np.linalg.norm(r - dFdW.array))
+        opt = self.getOption("adjEqnOption")
+        ksp.setTolerances(rtol=0.0, atol=max(rNorm * opt["gmresRelTol"], opt["gmresAbsTol"]), divtol=None, max_it=None)

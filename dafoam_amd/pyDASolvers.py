@@ -115,6 +115,20 @@ class Mat:
         check(L.das_mat_export(self.handle, rp.ctypes.data_as(_capi.c_ll_p), ci.ctypes.data_as(_capi.c_int_p), dptr(v)))
         return sp.csr_matrix((v, ci, rp), shape=(n, n))
 
+    @staticmethod
+    def from_scipy(A):
+        """Device handle of a host CSR matrix (e.g. a dRdWTPC.bin read with petsc_io.read_mat: adjEqnOption.readPCMat)."""
+        import scipy.sparse as sp
+
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        rp, ci, v = A.indptr.astype(np.int64), A.indices.astype(np.int32), np.ascontiguousarray(A.data, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib().das_mat_create_from_csr(A.shape[0], rp.ctypes.data_as(_capi.c_ll_p), ci.ctypes.data_as(_capi.c_int_p), dptr(v), C.byref(h)))
+        m = Mat()
+        m._set(h)
+        return m
+
     def mult(self, x: Vec, y: Vec):
         check(lib().das_mat_mult(self.handle, dptr(x.array), dptr(y.array)))
 

@@ -135,6 +135,7 @@ int das_init_solver(das_solver_t* s, int device);
 long long das_get_n_local_adjoint_states(das_solver_t* s);
 long long das_get_n_local_cells(das_solver_t* s);
 long long das_get_n_global_cells(das_solver_t* s);
+int das_set_n_global_cells(das_solver_t* s, long long nGlobal); /* sharded runs: set by the partitioner */
 long long das_get_n_local_points(das_solver_t* s);
 long long das_get_n_local_faces(das_solver_t* s);
 
@@ -186,6 +187,9 @@ long long das_mat_nnz(das_mat_t* m);
 int das_mat_export(das_mat_t* m, long long* rowptr, int* colidx, double* vals);
 /* y = A x on host buffers (testing) */
 int das_mat_mult(das_mat_t* m, const double* x, double* y);
+/* device CSR handle from host arrays (reference: PETSc.Mat().load of dRdWTPC.bin under adjEqnOption.readPCMat,
+ * dafoam/mphys/mphys_dafoam.py:469-471) */
+int das_mat_create_from_csr(long long n, const long long* rowptr, const int* colidx, const double* vals, das_mat_t** out);
 void das_mat_destroy(das_mat_t* m);
 
 /* das_initialize_drdwt_matrix_free <- initializedRdWTMatrixFree()  pyDASolvers.pyx:253 (DASolver.C:1321-1351):
@@ -277,8 +281,16 @@ int das_ksp_get_pc_structure_sizes(das_ksp_t* ksp, int* nNodes, long long* nBloc
 int das_ksp_get_pc_structure(das_ksp_t* ksp, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural);
 int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, double* seconds);
 int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
+/* number of Gram-Schmidt refinement passes of the last solve (KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160) */
+int das_ksp_get_n_refine(das_ksp_t* ksp);
 /* run exactly `iters` GMRES iterations on device-resident rhs/sol (bench.py "step"); no convergence exit */
 int das_ksp_run_fixed_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rhs, double* d_sol, int iters);
+/* the same solve advanced in pieces on device-resident rhs/sol (bench.py times a window of iterations deep inside an
+ * Arnoldi cycle): begin -> advance(n) ... -> end.  advance returns 1 once the solve is over (never in `fixed` mode),
+ * end closes the open cycle (x += M^-1 V y, true residual) and returns the solveLinearEqn fail code. */
+int das_ksp_begin_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rhs, double* d_sol, int fixed);
+int das_ksp_advance(das_solver_t* s, das_ksp_t* ksp, int iters);
+int das_ksp_end(das_solver_t* s, das_ksp_t* ksp);
 void das_ksp_destroy(das_ksp_t* k);
 
 /* ---- multi-GPU sharding (one process per GPU; reference: MPI domain decomposition, one OpenFOAM sub-domain per rank) ----
@@ -294,6 +306,22 @@ typedef void (*das_halo_cb)(double* d_vec, void* user);
 typedef void (*das_allreduce_cb)(double* d_buf, int n, void* user);
 int das_set_owned_mask(das_solver_t* s, const unsigned char* owned /* n states */);
 int das_set_comm(das_solver_t* s, das_halo_cb halo, das_allreduce_cb allreduce, void* user);
+/* Native transport (no host code in the iteration loop): RCCL point-to-point halo reduction overlapped with the owned-row
+ * product + in-stream ncclAllReduce of the Gram-Schmidt dots.  Reference: PETSc VecScatter of the MPIAIJ off-diagonal
+ * block in MatMult and MPI_Allreduce in VecMDot (KSPGMRES, DALinearEqn.C:341-437).
+ *   das_comm_unique_id   rank 0: 128-byte RCCL id, distributed by the host side (bootstrap only)
+ *   das_comm_init_rccl   every rank: communicator on the solver's device
+ *   das_comm_set_halo    the halo plan: peers[npeers]; sendIdx[sendOff[i]..sendOff[i+1]) = extended rows held for peer i
+ *                        (evaluated first, sent); recvIdx[...] = my owned rows peer i holds as ghosts, in its send order;
+ *                        ghostIdx[nGhost] = all local ghost rows (zeroed after the reduction)
+ *   das_set_exchange_cb  host-staged transport of the same plan (gloo tests on single-GPU boxes) */
+typedef void (*das_exchange_cb)(double* d_send, double* d_recv, void* user);
+int das_comm_unique_id(char* out128);
+int das_comm_init_rccl(das_solver_t* s, int rank, int world, const char* id128);
+int das_comm_set_halo(das_solver_t* s, int npeers, const int* peers, const long long* sendOff, const int* sendIdx, const long long* recvOff,
+                      const int* recvIdx, long long nGhost, const int* ghostIdx);
+int das_set_exchange_cb(das_solver_t* s, das_exchange_cb cb, void* user);
+int das_comm_is_native(das_solver_t* s);
 int das_set_stream(das_solver_t* s, void* hip_stream);
 
 /* ---- timing (getElapsedClockTime/getElapsedCpuTime pyDASolvers.pyx:332-336) and kernel timers */

@@ -17,6 +17,7 @@ OPTS = {"solverName": "DASimpleFoam", "normalizeStates": dict(NORM_STATES),
         "amd": {"pcBlockCells": 256}}
 
 
+
 def _rhs_from_keys(key):
     # smooth objective-like right-hand side: weight on the U_x states only (kind 0, component 0), function of the cell id
     kind = key >> 40
@@ -43,18 +44,23 @@ def _converged_global():
     return case
 
 
-def _worker(rank, world, port, q, gstate):
+def _worker(rank, world, port, q, gstate, backend="gloo"):
     import torch
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = rank if backend == "nccl" else 0  # nccl = RCCL: one GPU per rank; gloo: both ranks share GPU 0 (host staging)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.cuda.set_device(0)
         from dafoam_amd.distributed import ShardedAdjoint
 
-        S = ShardedAdjoint(NX, NY, NZ, OPTS, device_index=0, global_state=gstate, case_kw=CASE_KW)
+        S = ShardedAdjoint(NX, NY, NZ, OPTS, device_index=dev, global_state=gstate, case_kw=CASE_KW)
+        assert S._comm_native == (backend == "nccl")
         S.setup()
         rhs = _rhs_from_keys(S.key)
         psi, fail = S.solve(rhs)
@@ -123,8 +129,15 @@ def test_two_rank_general_partition_unstructured():
     assert not np.isnan(psi_s).any() and relerr(psi_s, psi_g) <= 1e-6
 
 
-def test_two_rank_sharded_adjoint_matches_single_domain():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_sharded_adjoint_matches_single_domain(backend):
+    """gloo: both ranks on GPU 0, host-staged exchange callback around the C++ pack / unpack kernels; nccl: the production
+    transport (RCCL point-to-point + in-stream all-reduce issued from C++, das_comm.hpp) - needs two GPUs."""
+    import torch
     import torch.multiprocessing as mp
+
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the native RCCL transport needs one GPU per rank (this box has %d)" % torch.cuda.device_count())
 
     from dafoam_amd.distributed import SlabPartition, state_table
     from dafoam_amd.pyDAFoam import PYDAFOAM
@@ -134,7 +147,7 @@ def test_two_rank_sharded_adjoint_matches_single_domain():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, (gkey, gcase.states, gcase.y_wall))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, (gkey, gcase.states, gcase.y_wall), backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
