@@ -10,7 +10,7 @@ FD perturbation of the HIP residual.  Matrices, rhs and Krylov basis are residen
 Timed region: the solve is advanced W (= --warmup) iterations inside ONE Arnoldi cycle, then EXACTLY K (= --steps)
 iterations are timed, i.e. at basis sizes j in [W, W+K) (defaults 100 and 100: the orthogonalisation cost of a realistic
 solve, not of its first iterations).  Afterwards (N = 1) the same system is solved from scratch to gmresRelTol = 1e-6
-with the reference's defaults (gmresRestart 1000 capped by HBM, gmresMaxIters 1000): `config.solve` reports
+with gmresRestart 1200 / gmresMaxIters 1500 (reference defaults 1000 / 1000; the 2 M-cell case needs ~1040): `config.solve` reports
 iterations, time_to_tolerance_s and the reference's fail flag (DALinearEqn.C:422-434).
 
   python bench.py --gpus 1 --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
@@ -47,7 +47,9 @@ def parse():
     ap.add_argument("--no-solve", action="store_true", help="skip the solve-to-tolerance phase")
     ap.add_argument("--pctype", default=os.environ.get("DAS_BENCH_PCTYPE", "bilu"))
     ap.add_argument("--fp32-factor", type=int, default=int(os.environ.get("DAS_BENCH_PCFP32", 0)))
-    ap.add_argument("--krylov-gb", type=float, default=float(os.environ.get("DAS_BENCH_KRYLOV_GB", 140.0)))
+    ap.add_argument("--krylov-gb", type=float, default=float(os.environ.get("DAS_BENCH_KRYLOV_GB", 160.0)))
+    ap.add_argument("--solve-restart", type=int, default=1200)
+    ap.add_argument("--solve-maxit", type=int, default=1500)
     return ap.parse_args()
 
 
@@ -200,7 +202,9 @@ def main():
     # ---- solve to tolerance (N = 1): the reference's defaults ----------------------------------------------------------
     solve = None
     if world == 1 and not a.no_solve:
-        D.solver.updateDAOption({"adjEqnOption": {"gmresRestart": 1000, "gmresMaxIters": 1000, "gmresRelTol": 1e-6, "gmresAbsTol": 1e-14}})
+        # reference defaults are gmresRestart = gmresMaxIters = 1000 (pyDAFoam.py:526-548); 2 M-cell cases need a few more
+        # iterations (the DAFoam tutorials raise both for large meshes), and 288 GB of HBM hold the longer basis
+        D.solver.updateDAOption({"adjEqnOption": {"gmresRestart": a.solve_restart, "gmresMaxIters": a.solve_maxit, "gmresRelTol": 1e-6, "gmresAbsTol": 1e-14}})
         sol.zero_()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -214,7 +218,8 @@ def main():
         hist = ksp.history()
         solve = {"converged": fail == 0, "fail": int(fail), "iterations": inf["iters"], "time_to_tolerance_s": t_solve,
                  "rel_residual": inf["res"] / inf["res0"] if inf["res0"] else None, "gmresRelTol": 1e-6,
-                 "restart_used": int(min(1000, a.krylov_gb * 2**30 // (8 * n) - 1)),
+                 "gmresRestart": int(min(a.solve_restart, a.krylov_gb * 2**30 // (8 * n) - 1)), "gmresMaxIters": a.solve_maxit,
+                 "rel_residual_at_1000_iterations": float(hist[1000] / hist[0]) if len(hist) > 1000 else None,
                  "rel_residual_every_100": [float(v / hist[0]) for v in hist[::100]],
                  "iterations_per_sec_whole_solve": inf["iters"] / t_solve}
 

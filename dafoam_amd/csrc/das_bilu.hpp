@@ -27,6 +27,7 @@
 //     16-byte load instruction of a wave reads one contiguous segment.
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 #include <omp.h>
@@ -41,9 +42,6 @@ constexpr int BILU_NB2 = 64;
 constexpr unsigned long long BILU_SENTINEL = 0xFFF7A5A5FFF7A5A5ull;  // a NaN no arithmetic produces
 #ifndef BILU_WG
 #define BILU_WG 512  // threads per workgroup of the sweeps (8 wavefronts)
-#endif
-#ifndef BILU_NPW
-#define BILU_NPW 4  // nodes per wavefront per ticket
 #endif
 #ifndef BILU_SPIN_LIMIT
 #define BILU_SPIN_LIMIT (1u << 22)
@@ -95,13 +93,17 @@ __device__ __forceinline__ void bilu_load_pair<float>(const float* p, double& a,
 }
 
 // One triangular sweep.  UPPER = false: y_p = b_p - sum_{J<p} L_pJ y_J; UPPER = true: z_p = invD_p (y_p - sum_{J>p} U_pJ z_J),
-// out[state] = z.  Lane (g, r) = (lane / 8, lane % 8) owns row r of the g-th block of a pass of 8 blocks.
-template <class VT, bool UPPER>
-__global__ __launch_bounds__(BILU_WG) void k_bilu_sweep(BiluView P, const double* __restrict__ b, double* __restrict__ out) {
+// out[state] = z.  Lane (g, k) = (lane / 8, lane % 8) owns COLUMN k of the g-th block of a pass of 8 blocks: it polls exactly
+// the one solution value it multiplies with (x_k of dependency g), keeps 8 row accumulators over all passes, and one
+// reduce-scatter per node (10 exchanges) leaves the row sums in the lane groups.
+// LEAN = true: no intra-wave prefetch of the next pass, <= 64 VGPRs, 4 workgroups (32 waves) per CU instead of 2 - more
+// waves hide more of the dependent-load chain (ticket -> row pointers -> blocks -> poll) than the prefetch does.
+template <class VT, bool UPPER, bool LEAN>
+__global__ __launch_bounds__(BILU_WG, LEAN ? 8 : 4) void k_bilu_sweep(BiluView P, const double* __restrict__ b, double* __restrict__ out, int npw, int sleepReps) {
     __shared__ unsigned sh_chunk[2];
     constexpr int WAVES = BILU_WG / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 3, r = lane & 7;
+    const int g = lane >> 3, k = lane & 7;
     const long long* __restrict__ ptr = P.ptr[UPPER ? 1 : 0];
     const int* __restrict__ col = P.col[UPPER ? 1 : 0];
     const VT* __restrict__ val = reinterpret_cast<const VT*>(sizeof(VT) == 4 ? (const void*)P.valf[UPPER ? 1 : 0] : (const void*)P.val[UPPER ? 1 : 0]);
@@ -109,14 +111,14 @@ __global__ __launch_bounds__(BILU_WG) void k_bilu_sweep(BiluView P, const double
     for (unsigned it = 0;; it++) {
         if (threadIdx.x == 0) sh_chunk[it & 1] = atomicAdd(&P.ctrl[UPPER ? 1 : 0], 1u);
         __syncthreads();
-        const long long q0 = (long long)sh_chunk[it & 1] * (WAVES * BILU_NPW);
+        const long long q0 = (long long)sh_chunk[it & 1] * (WAVES * npw);
         if (q0 >= P.nNodes) return;
-        for (int t = 0; t < BILU_NPW; t++) {
+        for (int t = 0; t < npw; t++) {
             const long long q = q0 + (long long)t * WAVES + wave;
             if (q >= P.nNodes) break;
             const long long e0 = ptr[q];
             const int nE = (int)(ptr[q + 1] - e0);
-            double acc = 0.0;
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             // software pipeline over the passes: the factor blocks of pass i+1 are requested before pass i spins on its
             // dependencies (the block loads never depend on the solution)
             double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -127,24 +129,22 @@ __global__ __launch_bounds__(BILU_WG) void k_bilu_sweep(BiluView P, const double
                     cc = col[e0 + a0 + g];
                     const VT* base = val + (e0 + a0) * BILU_NB2;
 #pragma unroll
-                    for (int qq = 0; qq < 4; qq++) bilu_load_pair<VT>(base + ((qq * nb + g) * 8 + r) * 2, vv[2 * qq], vv[2 * qq + 1]);
+                    for (int qq = 0; qq < 4; qq++) bilu_load_pair<VT>(base + ((qq * nb + g) * 8 + k) * 2, vv[2 * qq], vv[2 * qq + 1]);
                 }
             };
-            if (nE > 0) load_pass(0, v, c);
+            if (!LEAN && nE > 0) load_pass(0, v, c);
             for (int a0 = 0; a0 < nE; a0 += 8) {
                 const bool act = g < min(8, nE - a0);
-                if (a0 + 8 < nE) load_pass(a0 + 8, vn, cn);
-                const double* xp = xs + (long long)c * BILU_NB;
-                unsigned long long xb[8];
+                if (LEAN) load_pass(a0, v, c);
+                else if (a0 + 8 < nE) load_pass(a0 + 8, vn, cn);
+                const double* xp = xs + (long long)c * BILU_NB + k;
+                unsigned long long xb = 0ull;
                 unsigned spins = 0;
                 for (;;) {
                     bool ok = true;
-                    if (act) {
-#pragma unroll
-                        for (int k = 0; k < 8; k++) { xb[k] = bilu_load_sc1(xp + k); ok = ok && (xb[k] != BILU_SENTINEL); }
-                    }
+                    if (act) { xb = bilu_load_sc1(xp); ok = xb != BILU_SENTINEL; }
                     if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    for (int w = 0; w < sleepReps; w++) __builtin_amdgcn_s_sleep(2);
                     if ((++spins & 1023u) == 0u) {  // bounded spin: a stuck sweep sets the abort flag instead of hanging the GPU
                         const unsigned ab = __hip_atomic_load(&P.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (ab != 0u || spins >= BILU_SPIN_LIMIT) {
@@ -154,31 +154,50 @@ __global__ __launch_bounds__(BILU_WG) void k_bilu_sweep(BiluView P, const double
                     }
                 }
                 if (act) {
+                    const double xk = __longlong_as_double((long long)xb);
 #pragma unroll
-                    for (int k = 0; k < 8; k++) acc += v[k] * __longlong_as_double((long long)xb[k]);
+                    for (int r = 0; r < 8; r++) acc[r] += v[r] * xk;
                 }
+                if (!LEAN) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) v[k] = vn[k];
-                c = cn;
+                    for (int r = 0; r < 8; r++) v[r] = vn[r];
+                    c = cn;
+                }
             }
-            acc += __shfl_xor(acc, 8, 64);
-            acc += __shfl_xor(acc, 16, 64);
-            acc += __shfl_xor(acc, 32, 64);
+            // reduce-scatter over the 8 lane groups: afterwards group g holds (per column lane) the partial sums of row g
+            double a4[4], a2[2], a1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double snd = (g & 4) ? acc[i] : acc[i + 4], keep = (g & 4) ? acc[i + 4] : acc[i];
+                a4[i] = keep + __shfl_xor(snd, 32, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const double snd = (g & 2) ? a4[i] : a4[i + 2], keep = (g & 2) ? a4[i + 2] : a4[i];
+                a2[i] = keep + __shfl_xor(snd, 16, 64);
+            }
+            {
+                const double snd = (g & 1) ? a2[0] : a2[1], keep = (g & 1) ? a2[1] : a2[0];
+                a1 = keep + __shfl_xor(snd, 8, 64);
+            }
+            a1 += __shfl_xor(a1, 1, 64);
+            a1 += __shfl_xor(a1, 2, 64);
+            a1 += __shfl_xor(a1, 4, 64);  // every lane of group g: the full sum of row g
             if (!UPPER) {
-                if (g == 0) {
-                    const int gi = P.nodeUnk[q * BILU_NB + r];
-                    bilu_store_sc1(&P.y[q * BILU_NB + r], (gi >= 0 ? b[gi] : 0.0) - acc);
+                if (k == 0) {
+                    const int gi = P.nodeUnk[q * BILU_NB + g];
+                    bilu_store_sc1(&P.y[q * BILU_NB + g], (gi >= 0 ? b[gi] : 0.0) - a1);
                 }
             } else {
                 const long long p = (long long)P.nNodes - 1 - q;
-                const double tr = P.y[p * BILU_NB + r] - acc;
-                double w = P.invD[p * BILU_NB2 + g * 8 + r] * tr;
-                w += __shfl_xor(w, 1, 64);
-                w += __shfl_xor(w, 2, 64);
-                w += __shfl_xor(w, 4, 64);
-                if (r == 0) {
-                    bilu_store_sc1(&P.z[p * BILU_NB + g], w);
-                    const int gi = P.nodeUnk[p * BILU_NB + g];
+                const double tg = P.y[p * BILU_NB + g] - a1;
+                double w = P.invD[p * BILU_NB2 + k * 8 + g] * tg;  // row k of invD times t, summed over the groups
+                w += __shfl_xor(w, 8, 64);
+                w += __shfl_xor(w, 16, 64);
+                w += __shfl_xor(w, 32, 64);
+                if (g == 0) {
+                    bilu_store_sc1(&P.z[p * BILU_NB + k], w);
+                    const int gi = P.nodeUnk[p * BILU_NB + k];
                     if (gi >= 0) out[gi] = w;
                 }
             }
@@ -190,7 +209,8 @@ __global__ __launch_bounds__(BILU_WG) void k_bilu_sweep(BiluView P, const double
 __global__ __launch_bounds__(256) void k_bilu_scatter(long long n, const long long* __restrict__ rp, const int* __restrict__ ci,
                                                       const double* __restrict__ v, const int* __restrict__ unkNode,
                                                       const unsigned char* __restrict__ unkSlot, const long long* __restrict__ bptr,
-                                                      const int* __restrict__ bcol, double* __restrict__ bval, unsigned long long* dropped) {
+                                                      const int* __restrict__ bcol, const unsigned char* __restrict__ late, double* __restrict__ bval,
+                                                      unsigned long long* dropped) {
     const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
     if (row >= n) return;
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(256) void k_bilu_scatter(long long n, const long lo
             if (cm == J) { e = mid; break; }
             if (cm < J) lo = mid + 1; else hi = mid - 1;
         }
-        if (e < 0) { atomicAdd(dropped, 1ull); continue; }
+        if (e < 0) { if (!(late[I] && late[J])) atomicAdd(dropped, 1ull); continue; }  // late-late couplings are dropped by design
         bval[e * BILU_NB2 + r * 8 + unkSlot[j]] = v[k];
     }
 }
@@ -295,8 +315,8 @@ __global__ __launch_bounds__(256) void k_bilu_factor(int node0, int node1, const
     if (lane == 0 && ns) atomicAdd(nshift, ns);
 }
 
-// pack the factor into the two sweep streams: per row the blocks in passes of <= 8, inside a pass [qq][g][r][2]
-// (k = 2 qq + rr), so that the qq-th 16-byte load of all lanes of a wave reads one contiguous segment
+// pack the factor into the two sweep streams: per row the blocks in passes of <= 8, inside a pass [qq][g][k][2]
+// (row r = 2 qq + rr of column k), so that the qq-th 16-byte load of all lanes of a wave reads one contiguous segment
 template <class VT>
 __global__ __launch_bounds__(256) void k_bilu_pack(int nNodes, const long long* __restrict__ bptr, const long long* __restrict__ bdiag,
                                                    const int* __restrict__ bcol, const double* __restrict__ bval, const long long* __restrict__ Lptr,
@@ -316,7 +336,7 @@ __global__ __launch_bounds__(256) void k_bilu_pack(int nNodes, const long long* 
         for (int a = 0; a < nE; a++) {
             const int pass = a >> 3, g = a & 7;
             const int nb = min(8, nE - 8 * pass);
-            dval[(d0 + 8 * pass) * BILU_NB2 + (((k >> 1) * nb + g) * 8 + r) * 2 + (k & 1)] = (VT)bval[(s0 + a) * BILU_NB2 + lane];
+            dval[(d0 + 8 * pass) * BILU_NB2 + (((r >> 1) * nb + g) * 8 + k) * 2 + (r & 1)] = (VT)bval[(s0 + a) * BILU_NB2 + lane];
             if (lane == 0) dcol[d0 + a] = bcol[s0 + a];
         }
     }
@@ -328,9 +348,11 @@ __global__ __launch_bounds__(256) void k_bilu_pack(int nNodes, const long long* 
 struct NodeILU {
     bool ready = false;
     long long n = 0;
-    int nNodes = 0, nLevels = 0, nshift = 0, maxRow = 0;
+    int nNodes = 0, nPrimary = 0, nLevels = 0, nshift = 0, maxRow = 0;
+    std::vector<unsigned char> h_late;  // per position: late node (extra unknowns of a cell, coupled to primary nodes only)
     long long nnzB = 0, nL = 0, nU = 0;
     bool fp32 = false;
+    double windowLevels = 3.0;  // levels kept in flight by the sweeps (launch shape; measured optimum at 200 k cells)
     // host copies (tests / introspection)
     std::vector<int> h_nodeUnk, h_bcol, h_lvlPtr, h_natural;  // h_natural[p] = natural (cell-order) index of the node at position p
     std::vector<long long> h_bptr;
@@ -414,6 +436,7 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
     if (rcm) cellOrder = bilu_rcm_cells(m, cellOwned);
     else { cellOrder.reserve(nC); for (int c = 0; c < nC; c++) if (cellOwned[c]) cellOrder.push_back(c); }
     std::vector<std::pair<int, int>> cellNodePairs;  // (cell, node), cells in visiting order
+    std::vector<int> lateUnk, lateCell;
     for (int c : cellOrder) {
         tmp.clear();
         for (const StateDef& sd : states) {
@@ -422,22 +445,36 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
         }
         for (const StateDef& sd : states)
             if (sd.kind == KIND_FACE) for (int q = of_ptr[c]; q < of_ptr[c + 1]; q++) if (is_owned(sd.offset + of[q])) tmp.push_back(sd.offset + of[q]);
-        size_t done = 0;
         const size_t mc = tmp.size();
         if (mc == 0) continue;
-        // a cell that does not fit into the open node starts a new one (cells larger than a node are split)
-        if ((size_t)(BILU_NB - fillSlots) < std::min<size_t>(mc, BILU_NB)) fillSlots = BILU_NB;
-        while (done < mc) {
-            if (fillSlots == BILU_NB) {
-                nodeUnk0.insert(nodeUnk0.end(), BILU_NB, -1);
-                nodeCell_ptr.push_back(nodeCell_ptr.back());
-                fillSlots = 0;
-            }
-            const int node = (int)nodeCell_ptr.size() - 2;
-            if (nodeCell.empty() || nodeCell_ptr[node + 1] == nodeCell_ptr[node] || nodeCell.back() != c) { nodeCell.push_back(c); nodeCell_ptr[node + 1]++; }
-            if (cellNodePairs.empty() || cellNodePairs.back() != std::make_pair(c, node)) cellNodePairs.push_back({c, node});
-            while (done < mc && fillSlots < BILU_NB) nodeUnk0[(size_t)node * BILU_NB + fillSlots++] = (int)tmp[done++];
+        // PRIMARY node: the first <= 8 unknowns of the cell (its cell states and first owned faces); a cell that does not
+        // fit into the open node starts a new one.  What is left (the extra owned faces of boundary cells) goes to LATE
+        // nodes, numbered behind all primary nodes: they depend on primary nodes only, so the boundary cells do not
+        // lengthen the dependent chain of the sweeps (see the pattern below).
+        const size_t mp = std::min<size_t>(mc, BILU_NB);
+        if ((size_t)(BILU_NB - fillSlots) < mp) fillSlots = BILU_NB;
+        if (fillSlots == BILU_NB) {
+            nodeUnk0.insert(nodeUnk0.end(), BILU_NB, -1);
+            nodeCell_ptr.push_back(nodeCell_ptr.back());
+            fillSlots = 0;
         }
+        const int node = (int)nodeCell_ptr.size() - 2;
+        nodeCell.push_back(c);
+        nodeCell_ptr[node + 1]++;
+        cellNodePairs.push_back({c, node});
+        for (size_t k = 0; k < mp; k++) nodeUnk0[(size_t)node * BILU_NB + fillSlots++] = (int)tmp[k];
+        for (size_t k = mp; k < mc; k++) { lateUnk.push_back((int)tmp[k]); lateCell.push_back(c); }
+    }
+    const int nPrimary = (int)nodeCell_ptr.size() - 1;
+    for (size_t k = 0; k < lateUnk.size();) {
+        const int c = lateCell[k];
+        nodeUnk0.insert(nodeUnk0.end(), BILU_NB, -1);
+        nodeCell_ptr.push_back(nodeCell_ptr.back());
+        const int node = (int)nodeCell_ptr.size() - 2;
+        nodeCell.push_back(c);
+        nodeCell_ptr[node + 1]++;
+        cellNodePairs.push_back({c, node});
+        for (int slot = 0; slot < BILU_NB && k < lateUnk.size() && lateCell[k] == c; slot++, k++) nodeUnk0[(size_t)node * BILU_NB + slot] = lateUnk[k];
     }
     const int nN = (int)nodeCell_ptr.size() - 1;
     DAS_CHECK(nN > 0, DAS_ERR_INTERNAL, "preconditioner: no owned unknowns");
@@ -459,8 +496,15 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
             std::vector<int>& row = rows[I];
             cur.clear();
             for (int q = nodeCell_ptr[I]; q < nodeCell_ptr[I + 1]; q++) { const int c = nodeCell[q]; cmark[c] = I; cur.push_back(c); }
+            // a late node is coupled to primary nodes (and itself) only: late-late couplings are dropped from the incomplete
+            // factorisation, which keeps all late nodes mutually independent
+            const bool lateI = I >= nPrimary;
             auto add_cell = [&](int c) {
-                for (int q = cellNode_ptr[c]; q < cellNode_ptr[c + 1]; q++) { const int J = cellNode[q]; if (nmark[J] != I) { nmark[J] = I; row.push_back(J); } }
+                for (int q = cellNode_ptr[c]; q < cellNode_ptr[c + 1]; q++) {
+                    const int J = cellNode[q];
+                    if (lateI && J >= nPrimary && J != I) continue;
+                    if (nmark[J] != I) { nmark[J] = I; row.push_back(J); }
+                }
             };
             for (int c : cur) add_cell(c);
             for (int ring = 0; ring < reach; ring++) {
@@ -517,7 +561,9 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
             P.h_nodeUnk[(size_t)p * BILU_NB + k] = gidx;
             if (gidx >= 0) { unkNode[gidx] = p; unkSlot[gidx] = (unsigned char)k; }
         }
-    P.n = n; P.nNodes = nN; P.nLevels = nLv; P.nnzB = bptr[nN]; P.maxRow = maxRow;
+    P.n = n; P.nNodes = nN; P.nLevels = nLv; P.nnzB = bptr[nN]; P.maxRow = maxRow; P.nPrimary = nPrimary;
+    P.h_late.assign(nN, 0);
+    for (int p = 0; p < nN; p++) P.h_late[p] = inv[p] >= nPrimary ? 1 : 0;
     P.h_bptr = bptr; P.h_bcol = bcol; P.h_lvlPtr = lvlPtr; P.h_natural = inv;
 }
 
@@ -542,6 +588,8 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     DevBuf<int> d_unkNode, d_bcol;
     DevBuf<unsigned char> d_unkSlot;
     DevBuf<long long> d_bptr, d_bdiag;
+    DevBuf<unsigned char> d_late;
+    d_late.upload(P.h_late);
     d_unkNode.upload(unkNode); d_unkSlot.upload(unkSlot); d_bptr.upload(bptr); d_bdiag.upload(bdiag); d_bcol.upload(bcol);
     DevBuf<double> bval((size_t)P.nnzB * BILU_NB2);
     DevBuf<unsigned long long> d_dropped(1);
@@ -552,7 +600,7 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     P.t_struct = wall_seconds() - t0;
     double t1 = wall_seconds();
     hipLaunchKernelGGL(k_bilu_scatter, dim3((unsigned)((An + 15) / 16)), dim3(256), 0, st, An, d_rp, d_ci, d_av, d_unkNode.p, d_unkSlot.p, d_bptr.p,
-                       d_bcol.p, bval.p, d_dropped.p);
+                       d_bcol.p, d_late.p, bval.p, d_dropped.p);
     hipLaunchKernelGGL(k_bilu_pad_diag, dim3((unsigned)(((long long)nN * BILU_NB + 255) / 256)), dim3(256), 0, st, nN, P.nodeUnk.p, d_bdiag.p, bval.p);
     DAS_HIP(hipGetLastError());
     unsigned long long dropped = 0;
@@ -610,29 +658,40 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
                 P.t_pack);
 }
 
-inline int bilu_sweep_grid() {
-    static int grid = 0;
-    if (!grid) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        grid = std::max(1, cus) * 2;
-    }
-    return grid;
+// launch shape of the sweeps: as many workgroups as keep a few levels in flight (a wave far ahead of the front only
+// spins and loads the memory system), nodes per ticket so that the ticket counter stays far below its saturation rate.
+// DAS_BILU_WGS / DAS_BILU_NPW / DAS_BILU_SLEEP override (tuning runs).
+struct BiluLaunch { int grid, npw, sleepReps; bool lean; };
+inline BiluLaunch bilu_launch_shape(const NodeILU& P) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int waves = BILU_WG / 64;
+    const double perLevel = (double)P.nNodes / std::max(1, P.nLevels);
+    BiluLaunch L;
+    L.npw = 1;
+    L.grid = (int)std::min<double>(cus * 4.0, std::max(8.0, P.windowLevels * perLevel / (waves * L.npw)));
+    L.sleepReps = 0;
+    L.lean = false;  // measured: the prefetching variant (2 workgroups / CU) beats the lean one (4 / CU) at 200 k and 2 M cells
+    if (const char* e = getenv("DAS_BILU_LEAN")) L.lean = atoi(e) != 0;
+    if (const char* e = getenv("DAS_BILU_WGS")) L.grid = std::max(1, atoi(e));
+    if (const char* e = getenv("DAS_BILU_NPW")) L.npw = std::max(1, atoi(e));
+    if (const char* e = getenv("DAS_BILU_SLEEP")) L.sleepReps = std::max(0, atoi(e));
+    const long long tickets = ((long long)P.nNodes + (long long)waves * L.npw - 1) / ((long long)waves * L.npw);
+    L.grid = (int)std::min<long long>(L.grid, tickets + 1);
+    return L;
 }
 
 // out = (LU)^-1 b on the owned unknowns (entries of `out` outside the preconditioner's unknowns are not touched)
 inline void bilu_apply(NodeILU& P, const double* b, double* out, hipStream_t st) {
     const long long nslots = (long long)P.nNodes * BILU_NB;
     hipLaunchKernelGGL(k_bilu_reset, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, P.y.p, P.z.p, P.ctrl.p);
-    const int perTicket = (BILU_WG / 64) * BILU_NPW;
-    const int grid = (int)std::min<long long>(bilu_sweep_grid(), ((long long)P.nNodes + perTicket - 1) / perTicket + 1);
-    if (P.fp32) {
-        hipLaunchKernelGGL((k_bilu_sweep<float, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out);
-        hipLaunchKernelGGL((k_bilu_sweep<float, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out);
-    } else {
-        hipLaunchKernelGGL((k_bilu_sweep<double, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out);
-        hipLaunchKernelGGL((k_bilu_sweep<double, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out);
-    }
+    const BiluLaunch L = bilu_launch_shape(P);
+#define DAS_BILU_LAUNCH(VT, LEAN)                                                                                                         \
+    hipLaunchKernelGGL((k_bilu_sweep<VT, false, LEAN>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.npw, L.sleepReps);         \
+    hipLaunchKernelGGL((k_bilu_sweep<VT, true, LEAN>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.npw, L.sleepReps)
+    if (P.fp32) { if (L.lean) { DAS_BILU_LAUNCH(float, true); } else { DAS_BILU_LAUNCH(float, false); } }
+    else { if (L.lean) { DAS_BILU_LAUNCH(double, true); } else { DAS_BILU_LAUNCH(double, false); } }
+#undef DAS_BILU_LAUNCH
 }
 
 // abort flag of the sweeps (set when a bounded spin ran out): checked by the solver at its synchronisation points

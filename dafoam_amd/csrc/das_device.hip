@@ -886,6 +886,12 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
                            masked ? s->d_owned.p : (const unsigned char*)nullptr, M.rowptr.p, M.col.p, M.val.p);
     }
     DAS_HIP(hipStreamSynchronize(st));
+    // the per-colour scatter lists and the transposed structure are only needed during assembly: at 2 M cells they hold
+    // ~40 GB of HBM that the Krylov basis can use (they are re-uploaded from the host copies by the next assembly)
+    if (!s->opt.geti("amd.keepAssemblyMaps")) {
+        c.cl_row.release(); c.cl_dest.release(); c.t_col.release(); c.t_rowptr.release();
+        c.ready = false;
+    }
     return out.release();
 }
 

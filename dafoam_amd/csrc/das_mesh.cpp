@@ -64,6 +64,7 @@ Options::Options() {
     i["amd.jacMode"] = 1;           // operator assembly: 1 = dual numbers
     i["amd.pcJacMode"] = 0;         // PC assembly: 0 = finite differences (reference behaviour)
     i["amd.pcFactorFP32"] = 0;      // store the ILU factors of the preconditioner in fp32 (operator stays fp64)
+    i["amd.keepAssemblyMaps"] = 0;  // 1: keep the coloured-assembly maps in HBM between assemblies (adjPCLag loops on small meshes)
     i["amd.cgsAlwaysRefine"] = 0;   // 1: CGS2 every iteration; 0: refine if needed (reference default)
 }
 double Options::getd(const std::string& k) const {

@@ -91,11 +91,11 @@ def read_faces(path):
 def _parse_dict_entries(body):
     """name { key value; ... } blocks -> dict of dicts (values as strings)."""
     out = {}
-    for m in re.finditer(r"([A-Za-z_][\w.:]*)\s*\{([^{}]*)\}", body):
+    for m in re.finditer(r"(\"[^\"]+\"|[A-Za-z_][\w.:\-]*)\s*\{([^{}]*)\}", body):
         d = {}
         for e in re.finditer(r"([A-Za-z_]\w*)\s+([^;]*);", m.group(2)):
             d[e.group(1)] = e.group(2).strip()
-        out[m.group(1)] = d
+        out[m.group(1).strip('"')] = d
     return out
 
 
@@ -193,12 +193,20 @@ def write_polymesh(case_dir, mesh: PolyMesh):
 
 
 # ----------------------------------------------------------------------------- fields
+class _NonUniform:
+    """Marker for a patch `value` that is not a uniform constant (nonuniform List, $internalField, ...): accepted where the
+    patch type does not consume it (zeroGradient, calculated, wall functions, ...), rejected where it would be needed."""
+
+    def __init__(self, text):
+        self.text = text[:40]
+
+
 def _parse_value(s, ncomp):
     s = s.strip()
     if s.startswith("uniform"):
         v = np.array(re.sub(r"[()]", " ", s[len("uniform"):]).split(), dtype=np.float64)
         return v if ncomp == 3 else float(v[0])
-    raise NotImplementedError(f"only uniform patch values are supported: {s[:40]}")
+    return _NonUniform(s)
 
 
 def read_field(path, n_cells, ncomp):
@@ -246,12 +254,16 @@ def _bc_entry(e, vec):
         raise NotImplementedError(f"patch field type {t} is outside the hot path")
     code = _SCALAR_BC[t]
     v = e.get("inletValue" if t == "inletOutlet" else "value", np.zeros(3) if vec else 0.0)
+    if isinstance(v, _NonUniform):
+        if code in (BC_FIXED_VALUE, BC_INLET_OUTLET):  # the value IS the boundary condition: must be a constant here
+            raise NotImplementedError(f"patch field type {t} with a non-uniform value is outside the hot path: {v.text}")
+        v = np.zeros(3) if vec else 0.0  # zeroGradient / calculated / symmetry restart files carry a value nobody reads
     return (code, tuple(np.atleast_1d(v)) if vec else float(v))
 
 
 def read_case(case_dir, solver_name="DASimpleFoam", time="0", y_wall=None) -> FoamCase:
     """DASimpleFoam / DARhoSimpleFoam case directory -> FoamCase (phi = interp(U).Sf if 0/phi is absent)."""
-    from .meshgen import _InputGeometry, wall_distance
+    from .meshgen import _InputGeometry, wall_distance_exact as wall_distance
 
     mesh = read_polymesh(case_dir)
     N, F, nIF = mesh.n_cells, mesh.n_faces, mesh.n_internal_faces
@@ -279,25 +291,48 @@ def read_case(case_dir, solver_name="DASimpleFoam", time="0", y_wall=None) -> Fo
     if y_wall is None:
         y_wall = wall_distance(mesh, g.C, g.Cf, g.Sf)
     case = FoamCase(mesh=mesh, solver_name=solver_name, nu=nu, bcs=bcs, y_wall=y_wall)
+    # phi: the face-flux state, internal AND boundary faces (DAIndex.C:109-112).  Values the file does not give (no phi
+    # file, a patch without a value) are derived from the patch velocity like OpenFOAM's createPhi does.
+    own, nei = mesh.owner, mesh.neighbour
+    Uf = g.w[:, None] * U[own[:nIF]] + (1 - g.w[:, None]) * U[nei]
+    phi = np.zeros(F)
+    phi[:nIF] = np.einsum("ij,ij->i", Uf, g.Sf[:nIF])
+    for pt in mesh.patches:
+        sl = slice(pt.start, pt.start + pt.size)
+        code, val = bcs[pt.name]["U"]
+        if code == BC_FIXED_VALUE:
+            phi[sl] = g.Sf[sl] @ np.asarray(val, dtype=float)
+        elif code != BC_SYMMETRY:
+            phi[sl] = np.einsum("ij,ij->i", U[own[sl]], g.Sf[sl])
     phi_path = os.path.join(t, "phi")
     if os.path.exists(phi_path):
         text = _strip(open(phi_path).read())
-        m = re.search(r"internalField\s+nonuniform\s+List<scalar>\s*", text)
-        n, body = _list_body(text[m.end():])
-        phi = np.zeros(F)
-        phi[:nIF] = np.array(body.split(), dtype=np.float64)
-    else:
-        own, nei = mesh.owner, mesh.neighbour
-        Uf = g.w[:, None] * U[own[:nIF]] + (1 - g.w[:, None]) * U[nei]
-        phi = np.zeros(F)
-        phi[:nIF] = np.einsum("ij,ij->i", Uf, g.Sf[:nIF])
-        for pt in mesh.patches:
-            sl = slice(pt.start, pt.start + pt.size)
-            code, val = bcs[pt.name]["U"]
-            if code == BC_FIXED_VALUE:
-                phi[sl] = g.Sf[sl] @ np.asarray(val, dtype=float)
-            elif code != BC_SYMMETRY:
-                phi[sl] = np.einsum("ij,ij->i", U[own[sl]], g.Sf[sl])
+        m = re.search(r"internalField\s+(uniform\s+[^;]+|nonuniform\s+List<scalar>\s*)", text)
+        if m.group(1).startswith("uniform"):
+            phi[:nIF] = float(m.group(1).split()[1])
+        else:
+            n, body = _list_body(text[m.end():])
+            phi[:nIF] = np.array(body.split(), dtype=np.float64)
+        bm = re.search(r"boundaryField\s*\{", text)
+        if bm:
+            for pt in mesh.patches:
+                if not pt.size:
+                    continue
+                pm = re.search(r"(?<![\w.:-])" + re.escape(pt.name) + r"\s*\{", text[bm.end():])
+                if not pm:
+                    continue
+                blk = text[bm.end() + pm.end():]
+                blk = blk[: blk.index("}")]
+                vm = re.search(r"\bvalue\s+(uniform\s+[-+0-9.eE]+|nonuniform\s+List<scalar>\s*)", blk)
+                if not vm:
+                    continue
+                sl = slice(pt.start, pt.start + pt.size)
+                if vm.group(1).startswith("uniform"):
+                    phi[sl] = float(vm.group(1).split()[1])
+                else:
+                    cnt, body = _list_body(blk[vm.end():])
+                    if cnt == pt.size:
+                        phi[sl] = np.array(body.split(), dtype=np.float64)
     case.states = np.concatenate([U.ravel(), p, nuT, phi])
     return case
 
@@ -355,7 +390,13 @@ def write_case(case_dir, case: FoamCase, time="0"):
     nIF = mesh.n_internal_faces
     with open(os.path.join(tdir, "phi"), "w") as f:
         f.write(_HEADER.format(cls="surfaceScalarField", loc=time, obj="phi"))
-        f.write(f"dimensions      [0 3 -1 0 0 0 0];\n\ninternalField   nonuniform List<scalar>\n{nIF}\n(\n" + "\n".join("%.17g" % v for v in W[5 * N : 5 * N + nIF]) + "\n)\n;\n")
+        f.write(f"dimensions      [0 3 -1 0 0 0 0];\n\ninternalField   nonuniform List<scalar>\n{nIF}\n(\n" + "\n".join("%.17g" % v for v in W[5 * N : 5 * N + nIF]) + "\n)\n;\n\n")
+        f.write("boundaryField\n{\n")
+        for pt in mesh.patches:
+            vals = W[5 * N + pt.start : 5 * N + pt.start + pt.size]
+            f.write(f"    {pt.name}\n    {{\n        type            calculated;\n        value           nonuniform List<scalar>\n{pt.size}\n(\n"
+                    + "\n".join("%.17g" % v for v in vals) + "\n)\n;\n    }\n")
+        f.write("}\n")
 
 
 def write_adjoint_fields(case_dir, case: FoamCase, function, write_time, psi, state_blocks):

@@ -305,6 +305,47 @@ def wall_distance(mesh: PolyMesh, cell_centres, face_centres, face_areas) -> np.
     return np.maximum(d, 1e-12)
 
 
+def wall_distance_exact(mesh: PolyMesh, cell_centres, face_centres, face_areas, k=6) -> np.ndarray:
+    """True nearest-wall distance for ARBITRARY cases (reference: yWall from meshWave, DASolver.C:4433-4482): Euclidean
+    distance from every cell centre to the nearest point of the wall-face polygons (the k wall faces with the nearest
+    centres are tested exactly: inside the polygon -> normal distance, else distance to its nearest edge).  The
+    synthetic channel generators keep `wall_distance` (walls span the whole domain there, the two coincide)."""
+    from scipy.spatial import cKDTree
+
+    idx = [np.arange(p.start, p.start + p.size) for p in mesh.patches if p.type == "wall"]
+    if not idx:
+        return np.full(mesh.n_cells, 1.0)
+    idx = np.concatenate(idx)
+    k = int(min(k, idx.size))
+    _, nn = cKDTree(face_centres[idx]).query(cell_centres, k=k)
+    nn = nn.reshape(len(cell_centres), k)
+    best = np.full(len(cell_centres), np.inf)
+    pts = mesh.points
+    for j in range(k):
+        f = idx[nn[:, j]]
+        nv = mesh.face_ptr[f + 1] - mesh.face_ptr[f]
+        for cnt in np.unique(nv):
+            sel = np.nonzero(nv == cnt)[0]
+            fv = mesh.face_pts[mesh.face_ptr[f[sel]][:, None] + np.arange(cnt)[None, :]]  # (m, cnt) vertex ids
+            V = pts[fv]                                                                   # (m, cnt, 3)
+            P = cell_centres[sel]
+            nrm = face_areas[f[sel]] / np.linalg.norm(face_areas[f[sel]], axis=1)[:, None]
+            dn = np.einsum("ij,ij->i", P - face_centres[f[sel]], nrm)
+            foot = P - dn[:, None] * nrm
+            inside = np.ones(sel.size, bool)
+            dedge = np.full(sel.size, np.inf)
+            for a in range(cnt):
+                A, B = V[:, a], V[:, (a + 1) % cnt]
+                e = B - A
+                # the foot point is inside a convex polygon iff it lies left of every edge (w.r.t. the face normal)
+                inside &= np.einsum("ij,ij->i", np.cross(e, foot - A), nrm) >= -1e-14
+                t = np.clip(np.einsum("ij,ij->i", P - A, e) / np.maximum(np.einsum("ij,ij->i", e, e), 1e-300), 0.0, 1.0)
+                dedge = np.minimum(dedge, np.linalg.norm(P - (A + t[:, None] * e), axis=1))
+            d = np.where(inside, np.abs(dn), dedge)
+            best[sel] = np.minimum(best[sel], d)
+    return np.maximum(best, 1e-12)
+
+
 def n_states(case: FoamCase) -> int:
     m = case.mesh
     if case.solver_name == "DAScalarTransportFoam":

@@ -244,10 +244,13 @@ class NodeBlockILU:
         key = I * nN + J
         bkey = np.repeat(np.arange(nN), np.diff(self.bptr)) * nN + self.bcol
         order = np.argsort(bkey)
-        e = order[np.searchsorted(bkey[order], key)]
-        if not np.all(bkey[e] == key):
-            raise ValueError("matrix entries outside the node pattern")
-        np.add.at(val, (e, slot[C.row[keep]], slot[C.col[keep]]), C.data[keep])
+        e = order[np.minimum(np.searchsorted(bkey[order], key), nB - 1)]
+        inpat = bkey[e] == key
+        # entries outside the node pattern are dropped (the product drops the couplings between two "late" nodes); the
+        # caller checks `dropped_pairs` against what it expects
+        self.dropped_pairs = np.unique(np.stack([I[~inpat], J[~inpat]], axis=1), axis=0) if not np.all(inpat) else np.zeros((0, 2), np.int64)
+        rr, cc, dd = C.row[keep][inpat], C.col[keep][inpat], C.data[keep][inpat]
+        np.add.at(val, (e[inpat], slot[rr], slot[cc]), dd)
         diag = np.empty(nN, dtype=np.int64)
         for p in range(nN):
             b0, b1 = self.bptr[p], self.bptr[p + 1]
@@ -316,6 +319,7 @@ class NodeBlockILU:
                 rows.append(rr.ravel())
                 cols.append(cc.ravel())
         E = sp.csr_matrix((np.full(sum(r.size for r in rows), 1e-300), (np.concatenate(rows), np.concatenate(cols))), shape=(n_loc, n_loc))
+        Pl = Pl.multiply(E != 0).tocsr()  # entries outside the node pattern are dropped
         ilu = ILU((Pl + E).tocsr(), fill=0)
 
         def solve(b):
