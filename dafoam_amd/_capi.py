@@ -71,6 +71,9 @@ class das_case_t(C.Structure):
         ("simple_has_T", C.c_int),
         ("patch_neighbour", c_int_p),
         ("patch_rotation", c_double_p),
+        ("transport_sutherland", C.c_int),
+        ("sutherland_As", C.c_double),
+        ("sutherland_Ts", C.c_double),
     ]
 
 
@@ -144,6 +147,8 @@ class CaseStruct:
         s.deltaT = case.deltaT
         th = getattr(case, "thermo", None) or {}
         s.Cp, s.molWeight, s.mu, s.Pr, s.Prt = (th.get("Cp", 1005.0), th.get("molWeight", 28.96), th.get("mu", 1.8e-5), th.get("Pr", 0.7), th.get("Prt", 1.0))
+        s.transport_sutherland = 1 if th.get("transport", "const") == "sutherland" else 0
+        s.sutherland_As, s.sutherland_Ts = th.get("As", 1.4792e-06), th.get("Ts", 116.0)
         mrf = getattr(case, "mrf", None)
         s.mrf_active = 1 if mrf else 0
         if mrf:
@@ -230,6 +235,7 @@ _SIGS = {
     "das_drdwt_mult_device": (C.c_int, [_VP, _VP, _VP]),
     "das_create_ml_rksp_matrix_free": (C.c_int, [_VP, _VP, C.POINTER(_VP)]),
     "das_solve_linear_eqn": (C.c_int, [_VP, _VP, c_double_p, c_double_p]),
+    "das_solve_linear_eqn_block": (C.c_int, [_VP, _VP, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_apply_pc": (C.c_int, [_VP, _VP, c_double_p, c_double_p]),
     "das_ksp_get_n_blocks": (C.c_int, [_VP]),
     "das_ksp_get_factor_nnz": (C.c_longlong, [_VP]),

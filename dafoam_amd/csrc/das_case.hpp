@@ -8,7 +8,8 @@ struct CaseParams {
     int solver = DAS_SOLVER_SIMPLEFOAM;
     double nu = 1.5e-5, relax_U = 0.7, relax_nuTilda = 0.7, relax_T = 1.0, DT = 0.01, deltaT = 1.0;
     double Cp = 1005.0, molWeight = 28.96, mu = 1.8e-5, Pr = 0.7, Prt = 1.0;
-    int mrf = 0, transonic = 0, transonicPC = 1, hasT = 0;
+    int mrf = 0, transonic = 0, transonicPC = 1, hasT = 0, sutherland = 0;
+    double As = 1.4792e-06, Ts = 116.0;
     double om[3] = {0, 0, 0}, org[3] = {0, 0, 0};
     std::vector<double> phi_frozen, T_old;
     void from_case(const das_case_t* c) {
@@ -35,6 +36,11 @@ struct CaseParams {
             transonicPC = c->transonic_pc_option;
             Cp = c->Cp; molWeight = c->molWeight; mu = c->mu; Pr = c->Pr; Prt = c->Prt;
             DAS_CHECK(Cp > 0 && molWeight > 0 && mu > 0 && Pr > 0 && Prt > 0, DAS_ERR_ARG, "DARhoSimpleFoam/DATurboFoam need positive Cp, molWeight, mu, Pr, Prt");
+            sutherland = c->transport_sutherland != 0;
+            if (sutherland) {
+                As = c->sutherland_As; Ts = c->sutherland_Ts;
+                DAS_CHECK(As > 0 && Ts >= 0, DAS_ERR_ARG, "sutherland transport needs As > 0, Ts >= 0");
+            }
         }
         if (c->phi_frozen) phi_frozen.assign(c->phi_frozen, c->phi_frozen + c->n_faces);
         if (c->T_old) T_old.assign(c->T_old, c->T_old + c->n_cells);
@@ -68,6 +74,13 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.mu = cp.mu;
     p.Pr = cp.Pr;
     p.Prt = cp.Prt;
+    p.sutherland = cp.sutherland;
+    p.As = cp.As;
+    p.Ts = cp.Ts;
+    {
+        const double Cv = p.Cp - p.Rgas;  // modified Eucken: alpha = mu Cv (1.32 + 1.77 R / Cv) / Cp
+        p.alphaFac = cp.sutherland ? Cv * (1.32 + 1.77 * p.Rgas / Cv) / p.Cp : 1.0 / cp.Pr;
+    }
     p.turbo = cp.solver == DAS_SOLVER_TURBOFOAM;
     p.transonic = cp.transonic;
     p.transonicPC = cp.transonicPC;

@@ -19,6 +19,7 @@
 #include "das_jaccon.hpp"
 #include "das_bilu.hpp"
 #include "das_comm.hpp"
+#include "das_block.hpp"
 
 #include <omp.h>
 
@@ -215,19 +216,25 @@ __global__ void k_perturb(long long n, const double* __restrict__ W, const int* 
     if (j >= n) return;
     Wp[j] = W[j] + (colors[j] == c ? delta * scale[j] : 0.0);
 }
-// setPartDerivMat (reference DAPartDeriv.C:109-208): the derivative of residual row[q] w.r.t. its (unique) column of the
-// current colour goes to entry dest[q] of the transposed Jacobian; q runs over the colour's entry list only
-__global__ void k_scatter_dual(long long cnt, const Dual<1>* __restrict__ R, const int* __restrict__ row, const unsigned* __restrict__ dest,
-                               double* vals) {
-    long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < cnt) vals[dest[q]] = R[row[q]].d[0];
+// setPartDerivMat (reference DAPartDeriv.C:109-208): after the residual pass of one colour, every column j of that colour
+// fills its own transposed row - the residuals listed there depend on j, and j is their unique column of this colour.
+// 16 lanes per column; no scatter map, no search.
+__global__ __launch_bounds__(256) void k_scatter_dual(long long cnt, const Dual<1>* __restrict__ R, const int* __restrict__ cols,
+                                                      const long long* __restrict__ trp, const int* __restrict__ tcol, double* __restrict__ vals) {
+    const long long q = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (q >= cnt) return;
+    const int j = cols[q];
+    for (long long k = trp[j] + (threadIdx.x & 15); k < trp[j + 1]; k += 16) vals[k] = R[tcol[k]].d[0];
 }
-__global__ void k_scatter_fd(long long cnt, const double* __restrict__ R, const double* __restrict__ R0, double rdelta,
-                             const int* __restrict__ row, const unsigned* __restrict__ dest, double* vals) {
-    long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < cnt) {
-        const int i = row[q];
-        vals[dest[q]] = (R[i] - R0[i]) * rdelta;
+__global__ __launch_bounds__(256) void k_scatter_fd(long long cnt, const double* __restrict__ R, const double* __restrict__ R0, double rdelta,
+                                                    const int* __restrict__ cols, const long long* __restrict__ trp, const int* __restrict__ tcol,
+                                                    double* __restrict__ vals) {
+    const long long q = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (q >= cnt) return;
+    const int j = cols[q];
+    for (long long k = trp[j] + (threadIdx.x & 15); k < trp[j + 1]; k += 16) {
+        const int i = tcol[k];
+        vals[k] = (R[i] - R0[i]) * rdelta;
     }
 }
 // jacLowerBound filter (reference DAPartDeriv.C:192): keep |v| > bound or diagonal
@@ -611,8 +618,7 @@ struct KernelTimer {
 struct ConDev {  // device copy of a JacCon (assembly maps + transposed structure)
     bool ready = false;
     DevBuf<long long> t_rowptr;
-    DevBuf<int> cl_row;
-    DevBuf<unsigned> cl_dest;
+    DevBuf<int> cl_cols;
     DevBuf<int> t_col;
 };
 
@@ -651,6 +657,8 @@ struct das_ksp {
     int restart = 0;
     DevBuf<double> V, w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
     std::unique_ptr<struct GmresRun> run;
+    std::unique_ptr<struct BlockWork> block;
+    std::vector<double> block_res0, block_res;
     int iters = 0, nrefine = 0;
     double res0 = 0, res = 0, seconds = 0;
     std::vector<double> hist;
@@ -794,8 +802,7 @@ static ConDev& ensure_con_dev(das_solver* s, int isPC) {
     ConDev& c = s->cd[isPC ? 1 : 0];
     if (!c.ready) {
         const JacCon& j = isPC ? s->con_pc : s->con_full;
-        c.cl_row.upload(j.cl_row.data(), j.cl_row.size());
-        c.cl_dest.upload(j.cl_dest.data(), j.cl_dest.size());
+        c.cl_cols.upload(j.cl_cols);
         c.t_rowptr.upload(j.t_rowptr);
         c.t_col.upload(j.t_col.data(), j.t_col.size());
         s->d_colors.upload(s->colors);
@@ -842,7 +849,7 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
             eval_residual<Dual<1>>(s->dm, s->cp, prm, s->d_Wd.p, s->d_Rd.p, s->wk1, s->d_phiF.p, s->d_Told.p, st);
             const long long q0 = jc.cl_ptr[col], cnt = jc.cl_ptr[col + 1] - q0;
             if (cnt > 0)
-                hipLaunchKernelGGL(k_scatter_dual, dim3(nblk(cnt, B)), dim3(B), 0, st, cnt, s->d_Rd.p, c.cl_row.p + q0, c.cl_dest.p + q0, vals.p);
+                hipLaunchKernelGGL(k_scatter_dual, dim3(nblk(cnt, 16)), dim3(B), 0, st, cnt, s->d_Rd.p, c.cl_cols.p + q0, c.t_rowptr.p, c.t_col.p, vals.p);
         }
     } else {
         const double delta = s->opt.getd("adjPartDerivFDStep.State");
@@ -853,8 +860,8 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
             eval_residual<double>(s->dm, s->cp, prm, s->d_Wp.p, s->d_R.p, s->wk, s->d_phiF.p, s->d_Told.p, st);
             const long long q0 = jc.cl_ptr[col], cnt = jc.cl_ptr[col + 1] - q0;
             if (cnt > 0)
-                hipLaunchKernelGGL(k_scatter_fd, dim3(nblk(cnt, B)), dim3(B), 0, st, cnt, s->d_R.p, s->d_R0.p, 1.0 / delta, c.cl_row.p + q0,
-                                   c.cl_dest.p + q0, vals.p);
+                hipLaunchKernelGGL(k_scatter_fd, dim3(nblk(cnt, 16)), dim3(B), 0, st, cnt, s->d_R.p, s->d_R0.p, 1.0 / delta, c.cl_cols.p + q0,
+                                   c.t_rowptr.p, c.t_col.p, vals.p);
         }
     }
     DAS_HIP(hipGetLastError());
@@ -889,7 +896,7 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
     // the per-colour scatter lists and the transposed structure are only needed during assembly: at 2 M cells they hold
     // ~40 GB of HBM that the Krylov basis can use (they are re-uploaded from the host copies by the next assembly)
     if (!s->opt.geti("amd.keepAssemblyMaps")) {
-        c.cl_row.release(); c.cl_dest.release(); c.t_col.release(); c.t_rowptr.release();
+        c.cl_cols.release(); c.t_col.release(); c.t_rowptr.release();
         c.ready = false;
     }
     return out.release();
@@ -1631,6 +1638,231 @@ static int run_gmres(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x
     return gmres_end(s, k);
 }
 
+// ---- block (multi right-hand-side) GMRES: s adjoints through one Krylov solve (das_block.hpp) ----------------------------
+// Right-preconditioned block GMRES with block size s = number of right-hand sides: block Arnoldi with block classical
+// Gram-Schmidt applied twice, CholQR2 for the new basis block, the block-Hessenberg least squares by Givens rotations on
+// the host, unpreconditioned residual norms per right-hand side, restart when the basis memory is exhausted.  The
+// convergence rule is the reference's per system (DALinearEqn.C:320-324, 422-434): every column has to meet
+// max(rtol ||b_r||, atol).  dRdW^T is streamed once per iteration for all s vectors (SpMM), V^T W and W -= V H run on
+// the matrix cores as tall-skinny fp64 GEMMs; the preconditioner is applied column by column.
+struct BlockWork {
+    DevBuf<double> V, W, Z, R, Xr, partial, Cdev, Tdev;
+    int s = 0, m = 0;
+};
+static constexpr int TSG_CHUNKS = 256;  // row chunks of the TN product (one wave each)
+
+// C_host (K x sv, row-major) = V^T W  (V: K vectors, W: sv vectors, both column-major with leading dimension n)
+static void block_tn(das_solver* s, BlockWork& bw, const double* V, int K, const double* W, int sv, double* C_host) {
+    const long long n = s->n;
+    long long rpc = (n + TSG_CHUNKS - 1) / TSG_CHUNKS;
+    rpc = (rpc + 3) / 4 * 4;
+    const int gy = (K + 16 * TSG_TILES - 1) / (16 * TSG_TILES);
+    const int Kpad = gy * 16 * TSG_TILES;
+    const size_t need = (size_t)TSG_CHUNKS * Kpad * 16;
+    if (bw.partial.n < need) bw.partial.alloc(need);
+    if (bw.Cdev.n < (size_t)K * sv) bw.Cdev.alloc((size_t)K * sv + 1024);
+    hipLaunchKernelGGL(k_tsgemm_tn, dim3(TSG_CHUNKS / TSG_WAVES, gy), dim3(64 * TSG_WAVES), 0, s->stream, n, K, sv, V, n, W, n, rpc, Kpad, bw.partial.p);
+    hipLaunchKernelGGL(k_tsgemm_reduce, dim3(nblk((long long)K * sv, 256)), dim3(256), 0, s->stream, K, sv, Kpad, (long long)TSG_CHUNKS, bw.partial.p,
+                       bw.Cdev.p);
+    DAS_HIP(hipMemcpyAsync(C_host, bw.Cdev.p, (size_t)K * sv * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    DAS_HIP(hipStreamSynchronize(s->stream));
+}
+// W -= V C  (C = K x sv on the host)
+static void block_nn_sub(das_solver* s, BlockWork& bw, const double* V, int K, const double* C_host, double* W, int sv) {
+    if (bw.Cdev.n < (size_t)K * sv) bw.Cdev.alloc((size_t)K * sv + 1024);
+    DAS_HIP(hipMemcpyAsync(bw.Cdev.p, C_host, (size_t)K * sv * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_tsgemm_nn_sub, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, K, sv, V, s->n, bw.Cdev.p, W, s->n);
+}
+// W = Q S with Q^T Q = I (CholQR applied twice); S (sv x sv upper triangular, row-major) returned on the host
+static void block_cholqr2(das_solver* s, BlockWork& bw, double* W, int sv, std::vector<double>& S) {
+    std::vector<double> G((size_t)sv * sv), L((size_t)sv * sv), T((size_t)sv * sv), S1((size_t)sv * sv, 0.0), S2((size_t)sv * sv, 0.0);
+    if (bw.Tdev.n < 64) bw.Tdev.alloc(64);
+    for (int pass = 0; pass < 2; pass++) {
+        block_tn(s, bw, W, sv, W, sv, G.data());
+        // Cholesky G = L L^T (a non-positive pivot = a column that lost all its new content: replaced by a tiny one)
+        std::fill(L.begin(), L.end(), 0.0);
+        double gmax = 0.0;
+        for (int i = 0; i < sv; i++) gmax = std::max(gmax, G[(size_t)i * sv + i]);
+        for (int j = 0; j < sv; j++) {
+            double d = G[(size_t)j * sv + j];
+            for (int q = 0; q < j; q++) d -= L[(size_t)j * sv + q] * L[(size_t)j * sv + q];
+            if (!(d > 1e-28 * gmax)) d = std::max(1e-28 * gmax, 1e-300);
+            L[(size_t)j * sv + j] = std::sqrt(d);
+            for (int i = j + 1; i < sv; i++) {
+                double a = G[(size_t)i * sv + j];
+                for (int q = 0; q < j; q++) a -= L[(size_t)i * sv + q] * L[(size_t)j * sv + q];
+                L[(size_t)i * sv + j] = a / L[(size_t)j * sv + j];
+            }
+        }
+        // T = L^-T (upper triangular): Q = W T
+        std::fill(T.begin(), T.end(), 0.0);
+        for (int c = 0; c < sv; c++) {  // solve L^T t_c = e_c  (upper triangular system, backward)
+            for (int i = sv - 1; i >= 0; i--) {
+                double a = (i == c) ? 1.0 : 0.0;
+                for (int q = i + 1; q < sv; q++) a -= L[(size_t)q * sv + i] * T[(size_t)q * sv + c];
+                T[(size_t)i * sv + c] = a / L[(size_t)i * sv + i];
+            }
+        }
+        DAS_HIP(hipMemcpyAsync(bw.Tdev.p, T.data(), (size_t)sv * sv * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        hipLaunchKernelGGL(k_block_right_mult, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, sv, W, s->n, bw.Tdev.p);
+        std::vector<double>& Sp = pass == 0 ? S1 : S2;
+        for (int i = 0; i < sv; i++) for (int j = i; j < sv; j++) Sp[(size_t)i * sv + j] = L[(size_t)j * sv + i];  // L^T
+    }
+    S.assign((size_t)sv * sv, 0.0);  // W = Q2 S2 S1
+    for (int i = 0; i < sv; i++) for (int j = i; j < sv; j++) { double a = 0.0; for (int q = i; q <= j; q++) a += S2[(size_t)i * sv + q] * S1[(size_t)q * sv + j]; S[(size_t)i * sv + j] = a; }
+}
+template <int S>
+static void block_spmm_t(das_solver* s, BlockWork& bw, const Mat& A, const double* X, double* Y, int sv) {
+    hipLaunchKernelGGL(k_block_to_rows<S>, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, sv, X, s->n, bw.Xr.p);
+    hipEvent_t ev = nullptr;
+    s->timer.begin("spmm", s->stream, ev);
+    hipLaunchKernelGGL(k_spmm_wave<S>, dim3(nblk(A.n, 16)), dim3(256), 0, s->stream, A.n, sv, A.rowptr.p, A.col.p, A.val.p, bw.Xr.p, Y, s->n);
+    s->timer.end("spmm", s->stream, ev);
+}
+static void block_spmm(das_solver* s, BlockWork& bw, const Mat& A, const double* X, double* Y, int sv) {
+    if (sv <= 2) block_spmm_t<2>(s, bw, A, X, Y, sv);
+    else if (sv <= 4) block_spmm_t<4>(s, bw, A, X, Y, sv);
+    else block_spmm_t<8>(s, bw, A, X, Y, sv);
+}
+
+static int run_block_gmres(das_solver* s, das_ksp* k, int sv, const double* d_B, double* d_X) {
+    need_init(s);
+    DAS_CHECK(s->op, DAS_ERR_STATE, "initializedRdWTMatrixFree() must be called before solveLinearEqn()");
+    DAS_CHECK(sv >= 1 && sv <= 8, DAS_ERR_ARG, "block solve: 1 to 8 right-hand sides");
+    DAS_CHECK(!s->halo.active && !s->halo_cb, DAS_ERR_ARG, "the block solve is single-rank (shard the right-hand sides across solves instead)");
+    const Mat& A = s->op->m;
+    const long long n = s->n;
+    hipStream_t st = s->stream;
+    long long budget = (long long)(32.0 * 1024 * 1024 * 1024);
+    auto itb = s->opt.i.find("amd.maxKrylovBytes");
+    if (itb != s->opt.i.end()) budget = itb->second;
+    const long long maxIts = s->opt.geti("adjEqnOption.gmresMaxIters");
+    long long m = std::min<long long>(s->opt.geti("adjEqnOption.gmresRestart"), maxIts);
+    m = std::max<long long>(1, std::min<long long>(m, std::min<long long>(budget / (8 * n * sv) - 1, 4000 / sv)));
+    if (!k->block) k->block.reset(new BlockWork);
+    BlockWork& bw = *k->block;
+    if (bw.s != sv || bw.m != (int)m || bw.V.n != (size_t)((m + 1) * sv) * n) {
+        bw.s = sv; bw.m = (int)m;
+        bw.V.alloc((size_t)((m + 1) * sv) * n);
+        bw.W.alloc((size_t)sv * n); bw.Z.alloc((size_t)sv * n); bw.R.alloc((size_t)sv * n); bw.Xr.alloc((size_t)8 * n);
+        bw.Z.zero();
+    }
+    const double rtol = s->opt.getd("adjEqnOption.gmresRelTol"), atol = s->opt.getd("adjEqnOption.gmresAbsTol");
+    const double t0 = wall_seconds();
+    const int B = 256;
+    const int ms = (int)m * sv;
+    std::vector<double> H((size_t)(ms + sv) * ms, 0.0);   // row-major, (m+1)s x ms
+    std::vector<double> G((size_t)(ms + sv) * sv, 0.0);   // rotated right-hand sides
+    std::vector<double> rc((size_t)ms * sv), rs((size_t)ms * sv);  // rotation (col q, step u)
+    std::vector<double> S, Hc, Hc2, Y((size_t)ms * sv), res0(sv), res(sv), target(sv), hcol;
+    auto col_norms = [&](const double* Rblk, std::vector<double>& out) {
+        std::vector<double> Gm((size_t)sv * sv);
+        block_tn(s, bw, Rblk, sv, Rblk, sv, Gm.data());
+        for (int r = 0; r < sv; r++) out[r] = std::sqrt(std::max(Gm[(size_t)r * sv + r], 0.0));
+    };
+    DAS_HIP(hipMemsetAsync(d_X, 0, (size_t)sv * n * sizeof(double), st));
+    DAS_HIP(hipMemcpyAsync(bw.R.p, d_B, (size_t)sv * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    col_norms(bw.R.p, res0);
+    for (int r = 0; r < sv; r++) { target[r] = std::max(rtol * res0[r], atol); res[r] = res0[r]; }
+    k->hist.clear();
+    k->hist.push_back(*std::max_element(res0.begin(), res0.end()));
+    long long its = 0;
+    auto all_done = [&]() { for (int r = 0; r < sv; r++) if (res[r] > target[r]) return false; return true; };
+    while (!all_done() && its < maxIts) {
+        // ---- new cycle: R = V_0 S0
+        DAS_HIP(hipMemcpyAsync(bw.V.p, bw.R.p, (size_t)sv * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        block_cholqr2(s, bw, bw.V.p, sv, S);
+        std::fill(H.begin(), H.end(), 0.0);
+        std::fill(G.begin(), G.end(), 0.0);
+        for (int i = 0; i < sv; i++) for (int r = 0; r < sv; r++) G[(size_t)i * sv + r] = S[(size_t)i * sv + r];
+        int j = 0;
+        for (; j < m && its < maxIts; j++) {
+            double* Vj = bw.V.p + (size_t)j * sv * n;
+            for (int r = 0; r < sv; r++) pc_apply_full(s, k, Vj + (size_t)r * n, bw.Z.p + (size_t)r * n);
+            block_spmm(s, bw, A, bw.Z.p, bw.W.p, sv);
+            const int K = (j + 1) * sv;
+            Hc.assign((size_t)K * sv, 0.0); Hc2.assign((size_t)K * sv, 0.0);
+            block_tn(s, bw, bw.V.p, K, bw.W.p, sv, Hc.data());
+            block_nn_sub(s, bw, bw.V.p, K, Hc.data(), bw.W.p, sv);
+            block_tn(s, bw, bw.V.p, K, bw.W.p, sv, Hc2.data());      // second Gram-Schmidt pass (block CGS2)
+            block_nn_sub(s, bw, bw.V.p, K, Hc2.data(), bw.W.p, sv);
+            double* Vn = bw.V.p + (size_t)(j + 1) * sv * n;
+            DAS_HIP(hipMemcpyAsync(Vn, bw.W.p, (size_t)sv * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+            block_cholqr2(s, bw, Vn, sv, S);
+            // ---- block Hessenberg column j: rows 0..K-1 from the projections, rows K..K+s-1 = S (upper triangular)
+            for (int c = 0; c < sv; c++) {
+                const int q = j * sv + c;
+                hcol.assign((size_t)K + sv, 0.0);
+                for (int i = 0; i < K; i++) hcol[i] = Hc[(size_t)i * sv + c] + Hc2[(size_t)i * sv + c];
+                for (int i = 0; i <= c; i++) hcol[K + i] = S[(size_t)i * sv + c];
+                for (int qq = 0; qq < q; qq++)          // earlier rotations, in the order they were generated
+                    for (int u = sv - 1; u >= 0; u--) {
+                        const int a = qq + u, b2 = qq + u + 1;
+                        if (b2 >= K + sv) continue;
+                        const double cc = rc[(size_t)qq * sv + u], ss = rs[(size_t)qq * sv + u];
+                        const double x = hcol[a], y = hcol[b2];
+                        hcol[a] = cc * x + ss * y; hcol[b2] = -ss * x + cc * y;
+                    }
+                for (int u = sv - 1; u >= 0; u--) {     // eliminate the s sub-diagonal entries of this column
+                    const int a = q + u, b2 = q + u + 1;
+                    const double x = hcol[a], y = hcol[b2];
+                    const double d = std::hypot(x, y);
+                    const double cc = d > 0 ? x / d : 1.0, ss = d > 0 ? y / d : 0.0;
+                    rc[(size_t)q * sv + u] = cc; rs[(size_t)q * sv + u] = ss;
+                    hcol[a] = d; hcol[b2] = 0.0;
+                    for (int r = 0; r < sv; r++) {
+                        const double gx = G[(size_t)a * sv + r], gy = G[(size_t)b2 * sv + r];
+                        G[(size_t)a * sv + r] = cc * gx + ss * gy; G[(size_t)b2 * sv + r] = -ss * gx + cc * gy;
+                    }
+                }
+                for (int i = 0; i <= q; i++) H[(size_t)i * ms + q] = hcol[i];
+            }
+            its++;
+            for (int r = 0; r < sv; r++) {
+                double a = 0.0;
+                for (int i = K; i < K + sv; i++) a += G[(size_t)i * sv + r] * G[(size_t)i * sv + r];
+                res[r] = std::sqrt(a);
+            }
+            k->hist.push_back(*std::max_element(res.begin(), res.end()));
+            if (all_done()) { j++; break; }
+        }
+        // ---- x += M^-1 (V Y),  R Y = G  (upper triangular, K x K)
+        const int K = j * sv;
+        for (int r = 0; r < sv; r++)
+            for (int i = K - 1; i >= 0; i--) {
+                double a = G[(size_t)i * sv + r];
+                for (int q = i + 1; q < K; q++) a -= H[(size_t)i * ms + q] * Y[(size_t)q * sv + r];
+                Y[(size_t)i * sv + r] = a / H[(size_t)i * ms + i];
+            }
+        if (bw.Cdev.n < (size_t)K * sv) bw.Cdev.alloc((size_t)K * sv + 1024);
+        DAS_HIP(hipMemcpyAsync(bw.Cdev.p, Y.data(), (size_t)K * sv * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_block_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, K, sv, bw.V.p, n, bw.Cdev.p, bw.W.p, n);
+        for (int r = 0; r < sv; r++) {
+            pc_apply_full(s, k, bw.W.p + (size_t)r * n, bw.Z.p + (size_t)r * n);
+            hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, bw.Z.p + (size_t)r * n, 1.0, d_X + (size_t)r * n);
+        }
+        // true residuals
+        block_spmm(s, bw, A, d_X, bw.R.p, sv);
+        hipLaunchKernelGGL(k_axpby, dim3(nblk((long long)sv * n, B)), dim3(B), 0, st, (long long)sv * n, 1.0, d_B, -1.0, bw.R.p);
+        col_norms(bw.R.p, res);
+        k->hist.back() = *std::max_element(res.begin(), res.end());
+    }
+    DAS_HIP(hipStreamSynchronize(st));
+    if (k->useBilu) DAS_CHECK(!bilu_aborted(k->bilu, st), DAS_ERR_INTERNAL, "preconditioner sweep timed out (bounded spin)");
+    k->iters = (int)its;
+    k->seconds = wall_seconds() - t0;
+    k->block_res0 = res0; k->block_res = res;
+    k->res0 = *std::max_element(res0.begin(), res0.end());
+    k->res = *std::max_element(res.begin(), res.end());
+    const double diff = s->opt.getd("adjEqnOption.gmresTolDiff");
+    int failed = 0;
+    for (int r = 0; r < sv; r++) {
+        const double relRatio = res0[r] > 0 ? res[r] / res0[r] / rtol : 0.0;
+        if (relRatio > diff && res[r] / atol > diff) failed = 1;  // reference failure rule per system (DALinearEqn.C:422-434)
+    }
+    return failed;
+}
+
 // =====================================================================================================
 // C-ABI
 // =====================================================================================================
@@ -2350,6 +2582,22 @@ int das_solve_linear_eqn(das_solver_t* s, das_ksp_t* ksp, const double* rhs, dou
     ksp->xdev.download(sol, s->n);
     if (s->opt.geti("adjEqnOption.printInfo"))
         fprintf(stderr, "Main iteration %d KSP Residual norm %14.12e %.2f s\n", ksp->iters, ksp->res, ksp->seconds);
+    return rc;
+    DAS_CATCH
+}
+// block solve: nrhs right-hand sides (host, column-major n x nrhs) through ONE block GMRES; res0/res (optional) return
+// the initial / final residual norm of every system
+int das_solve_linear_eqn_block(das_solver_t* s, das_ksp_t* ksp, int nrhs, const double* rhs, double* sol, double* res0, double* res) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(ksp && rhs && sol && nrhs >= 1, DAS_ERR_ARG, "bad argument");
+    DevBuf<double> dB((size_t)nrhs * s->n), dX((size_t)nrhs * s->n);
+    dB.upload(rhs, (size_t)nrhs * s->n);
+    int rc = run_block_gmres(s, ksp, nrhs, dB.p, dX.p);
+    dX.download(sol, (size_t)nrhs * s->n);
+    for (int r = 0; r < nrhs; r++) { if (res0) res0[r] = ksp->block_res0[r]; if (res) res[r] = ksp->block_res[r]; }
+    if (s->opt.geti("adjEqnOption.printInfo"))
+        fprintf(stderr, "Block solve (%d systems): iteration %d max KSP Residual norm %14.12e %.2f s\n", nrhs, ksp->iters, ksp->res, ksp->seconds);
     return rc;
     DAS_CATCH
 }

@@ -546,7 +546,6 @@ bool validate_coloring(const JacCon& con, const std::vector<int>& colors) {
 }
 
 void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
-    DAS_CHECK(nnz < 4294967295LL, DAS_ERR_ARG, "pattern nnz exceeds uint32 assembly map");
     // Stable parallel counting transpose: the rows are cut into T contiguous chunks; pass 1 counts the entries of every
     // column per chunk, a prefix over (column, chunk) gives each chunk its start inside every transposed row, pass 2
     // lets every chunk fill its rows in ascending order.  Transposed rows come out sorted by residual index and the
@@ -578,7 +577,6 @@ void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
     }
     lap("prefix");
     t_col.resize(nnz);
-    uvector<unsigned> dest(nnz);
     lap("alloc");
 #pragma omp parallel for schedule(static, 1) num_threads(T)
     for (int t = 0; t < T; t++) {
@@ -586,41 +584,23 @@ void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
         for (long long r = r0[t]; r < r0[t + 1]; r++)
             for (long long k = rowptr[r]; k < rowptr[r + 1]; k++) {
                 const int j = col[k];
-                const long long d = t_rowptr[j] + pos[j]++;
-                t_col[d] = (int)r;
-                dest[k] = (unsigned)d;
+                t_col[t_rowptr[j] + pos[j]++] = (int)r;
             }
     }
     cnt.clear();
     lap("fill");
-    // group the pattern entries by the colour of their column: stable chunked counting sort (same chunks as above)
+    // the columns sorted by colour (stable counting sort)
     int ncol = 0;
     for (long long jj = 0; jj < n; jj++) ncol = std::max(ncol, colors[jj] + 1);
-    std::vector<std::vector<long long>> hist(T, std::vector<long long>(ncol, 0));
-#pragma omp parallel for schedule(static, 1) num_threads(T)
-    for (int t = 0; t < T; t++)
-        for (long long k = rowptr[r0[t]]; k < rowptr[r0[t + 1]]; k++) hist[t][colors[col[k]]]++;
     cl_ptr.assign(ncol + 1, 0);
-    for (int c = 0; c < ncol; c++) {
-        long long acc = cl_ptr[c];
-        for (int t = 0; t < T; t++) { long long h = hist[t][c]; hist[t][c] = acc; acc += h; }
-        cl_ptr[c + 1] = acc;
+    for (long long jj = 0; jj < n; jj++) cl_ptr[colors[jj] + 1]++;
+    for (int c = 0; c < ncol; c++) cl_ptr[c + 1] += cl_ptr[c];
+    cl_cols.resize(n);
+    {
+        std::vector<long long> pos(cl_ptr.begin(), cl_ptr.end() - 1);
+        for (long long jj = 0; jj < n; jj++) cl_cols[pos[colors[jj]]++] = (int)jj;
     }
-    lap("hist");
-    cl_row.resize(nnz);
-    cl_dest.resize(nnz);
-    lap("alloc2");
-#pragma omp parallel for schedule(static, 1) num_threads(T)
-    for (int t = 0; t < T; t++) {
-        std::vector<long long>& pos = hist[t];
-        for (long long r = r0[t]; r < r0[t + 1]; r++)
-            for (long long k = rowptr[r]; k < rowptr[r + 1]; k++) {
-                const long long q = pos[colors[col[k]]]++;
-                cl_row[q] = (int)r;
-                cl_dest[q] = dest[k];
-            }
-    }
-    lap("group");
+    lap("colour lists");
 }
 
 }  // namespace das

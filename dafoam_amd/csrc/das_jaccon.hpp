@@ -45,13 +45,12 @@ struct JacCon {
     // transposed structure (rows = states j, cols = residual i), CSR
     std::vector<long long> t_rowptr;
     uvector<int> t_col;
-    // assembly map, grouped by COLOUR: the pattern entries whose column has colour c are cl_ptr[c]..cl_ptr[c+1]; entry q
-    // takes the derivative of residual cl_row[q] (its coloured column is unique) to position cl_dest[q] of the
-    // transposed value array (setPartDerivMat, reference DAPartDeriv.C:109-208).  One scatter launch per colour then
-    // touches exactly the rows that colour reaches - no search.
+    // coloured assembly: the columns (states) sorted by colour, cl_ptr[c]..cl_ptr[c+1] = the columns of colour c.  After the
+    // residual pass of colour c, transposed row j of such a column IS the list of residuals that depend on it, and for each of
+    // them j is the unique column of colour c: vals[t_rowptr[j] + q] = dR_{t_col[..]}/dW_j (setPartDerivMat, reference
+    // DAPartDeriv.C:109-208) - no per-entry scatter map, no search.
     std::vector<long long> cl_ptr;
-    uvector<int> cl_row;
-    uvector<unsigned> cl_dest;
+    std::vector<int> cl_cols;
     void build(const Mesh& m, const Stencil& st);
     void build_transpose_and_maps(const std::vector<int>& colors);
 };

@@ -50,6 +50,9 @@ struct ResParams {
     int offP, offT, offN, offPhi;
     // perfect-gas / hConst / const-transport thermo (reference DAResidual.C:179-293)
     double Cp, Rgas, mu, Pr, Prt;
+    // transport: const (mu, alpha = mu / Pr) or sutherland (mu(T), alpha = mu * alphaFac), DAResidual.C:264-293
+    int sutherland;
+    double As, Ts, alphaFac;
     // DATurboFoam switches and the MRF zone (angular velocity, origin)
     int turbo, transonic, transonicPC, mrf;
     int hasT;  // DASimpleFoam with the optional passive T field (RHO = false kernels)
@@ -58,6 +61,13 @@ struct ResParams {
     void* wTU;
 };
 #define DAS_TREF 298.15
+
+// laminar viscosity of the compressible solvers: constant, or Sutherland's law mu = As sqrt(T) / (1 + Ts / T)
+template <class T>
+DAS_HD T mu_of(const ResParams& prm, const T& Tk) {
+    if (!prm.sutherland) return T(prm.mu);
+    return prm.As * dsqrt(Tk) / (1.0 + prm.Ts / Tk);
+}
 
 // Omega x (x - origin)
 DAS_HD void mrf_velocity(const ResParams& prm, const double* x, double* v) {
@@ -200,7 +210,7 @@ struct BFace {
     VectorBC<T> U;
     ScalarBC<T> p, n;
     ScalarBC<T> Tt, he;  // compressible only
-    T rho_b, nu_b;       // compressible only (incompressible: rho_b = 1, nu_b = nu)
+    T rho_b, nu_b, mu_b;  // compressible only (incompressible: rho_b = 1, nu_b = nu)
     T nut_b;
     double nrm[3];
 };
@@ -227,7 +237,8 @@ DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc
         T hec = prm.Cp * (Tc - DAS_TREF);
         bc_scalar<T>(bc.T_code, prm.Cp * (bc.T_val - DAS_TREF), prm.Cp * bc.dT_val, g.nod, phib, hec, o.he);
         o.rho_b = o.p.xb / (prm.Rgas * o.Tt.xb);
-        o.nu_b = prm.mu / o.rho_b;
+        o.mu_b = mu_of<T>(prm, o.Tt.xb);
+        o.nu_b = o.mu_b / o.rho_b;
     } else {
         o.rho_b = T(1.0);
         o.nu_b = T(prm.nu);
@@ -277,7 +288,7 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
     T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
     const bool energy = RHO || prm.hasT;  // an energy-like scalar with a gradient (he, or the passive T)
     T Tc = energy ? W[prm.offT * N + c] : T(0.0);
-    T nu_c = RHO ? prm.mu * (prm.Rgas * Tc) / pc : T(prm.nu);
+    T nu_c = RHO ? mu_of<T>(prm, Tc) * (prm.Rgas * Tc) / pc : T(prm.nu);
     T nut_c = nc * fv1_of<T>(nc / nu_c);
     nut[c] = nut_c;
     T gU[9], gP[3], gN[3], gH[3];
@@ -370,7 +381,8 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     const bool energy = RHO || prm.hasT;  // energy equation (RHO) or the passive T equation of DASimpleFoam
     T Tc = energy ? W[prm.offT * N + c] : T(0.0);
     T rho_c = RHO ? pc / (prm.Rgas * Tc) : T(1.0);
-    T nu_c = RHO ? prm.mu / rho_c : T(prm.nu);
+    T mu_c = RHO ? mu_of<T>(prm, Tc) : T(0.0);
+    T nu_c = RHO ? mu_c / rho_c : T(prm.nu);
     T nut_c = nut[c];
     T muEff_c = rho_c * (nu_c + nut_c);
     T gUc[9];
@@ -383,7 +395,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     // energy (RHO)
     T he_c = RHO ? prm.Cp * (Tc - DAS_TREF) : Tc;
     // alphaEff: compressible mu/Pr + rho nut/Prt ; DASimpleFoam T field nu/Pr + nut/Prt (DAResidualSimpleFoam.C:226)
-    T aEff_c = RHO ? prm.mu / prm.Pr + rho_c * nut_c * (1.0 / prm.Prt) : prm.nu / prm.Pr + nut_c * (1.0 / prm.Prt);
+    T aEff_c = RHO ? mu_c * prm.alphaFac + rho_c * nut_c * (1.0 / prm.Prt) : prm.nu / prm.Pr + nut_c * (1.0 / prm.Prt);
     T K_c = RHO ? 0.5 * (Uc[0] * Uc[0] + Uc[1] * Uc[1] + Uc[2] * Uc[2]) : T(0.0);
 
     const bool turbo = RHO && prm.turbo;
@@ -421,7 +433,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             if (energy) T_o = W[prm.offT * N + o];
             if (RHO) {
                 rho_o = W[prm.offP * N + o] / (prm.Rgas * T_o);
-                nu_o = prm.mu / rho_o;
+                nu_o = mu_of<T>(prm, T_o) / rho_o;
             }
             T nut_o = nut[o];
             T muEff_o = rho_o * (nu_o + nut_o);
@@ -496,7 +508,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             //      (DASimpleFoam T field: div(phi,T) bounded upwind - laplacian(alphaEff, T), no K)
             if (energy) {
                 T he_o = RHO ? prm.Cp * (T_o - DAS_TREF) : T_o;
-                T aEff_o = RHO ? prm.mu / prm.Pr + rho_o * nut_o * (1.0 / prm.Prt) : prm.nu / prm.Pr + nut_o * (1.0 / prm.Prt);
+                T aEff_o = RHO ? (rho_o * nu_o) * prm.alphaFac + rho_o * nut_o * (1.0 / prm.Prt) : prm.nu / prm.Pr + nut_o * (1.0 / prm.Prt);
                 T ga = (wc * aEff_c + wo * aEff_o) * g.magSf;
                 T cde = ga * g.nod;
                 dE += dcoef + cde;
@@ -575,7 +587,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             bdN += phi * b.n.vic - gn_b * b.n.gic;
             bsN += gn_b * b.n.gbc - phi * b.n.vbc;
             if (energy) {
-                T ga_b = (RHO ? prm.mu / prm.Pr + b.rho_b * b.nut_b * (1.0 / prm.Prt) : prm.nu / prm.Pr + b.nut_b * (1.0 / prm.Prt)) * g.magSf;
+                T ga_b = (RHO ? b.mu_b * prm.alphaFac + b.rho_b * b.nut_b * (1.0 / prm.Prt) : prm.nu / prm.Pr + b.nut_b * (1.0 / prm.Prt)) * g.magSf;
                 bdE += phi * b.he.vic - ga_b * b.he.gic;
                 bsE += ga_b * b.he.gbc - phi * b.he.vbc;
                 T Kb = 0.5 * (b.U.xb[0] * b.U.xb[0] + b.U.xb[1] * b.U.xb[1] + b.U.xb[2] * b.U.xb[2]);

@@ -285,7 +285,7 @@ class PYDAFOAM(object):
         DAFoamSolver.solve_linear (dafoam/mphys/mphys_dafoam.py:433-574): colouring once, dRdWTPC + KSP rebuilt every
         adjPCLag solves (or read from dRdWTPC.bin under adjEqnOption.readPCMat, :469-471), matrix-free operator per
         solve, optional non-zero initial guess `psi0` and dynamically adjusted tolerance (dynAdjustTol, :540-544,576-611)."""
-        dFdW = self.array2Vec(np.ascontiguousarray(dFdWArray, dtype=np.float64))
+        dFdW = self.array2Vec(np.ascontiguousarray(dFdWArray, dtype=np.float64)) if np.ndim(dFdWArray) == 1 else None
         if self.getOption("adjUseColoring") and self.runColoring:
             self.solver.runColoring(cacheDir=self.getOption("amdColoringDir") or None)
             self.runColoring = False
@@ -320,6 +320,14 @@ class PYDAFOAM(object):
             from .petsc_io import write_vec
 
             write_vec("dRdWColoring_1.bin", self.solver.getColoring()[0].astype(float))
+        if np.ndim(dFdWArray) == 2:
+            # several objective functions at once: one block GMRES instead of the reference's loop over the functions
+            # (mphys_dafoam.py:478-481); columns = functions
+            psiB = np.zeros_like(np.asarray(dFdWArray, dtype=np.float64))
+            fail, _, _ = self.solverAD.solveLinearEqnBlock(self.ksp, dFdWArray, psiB)
+            self.solverAD.destroydRdWTMatrixFree()
+            self.nSolveAdjoints += 1
+            return psiB, fail
         psi = Vec(len(dFdWArray))
         psi.set(0)
         if adjOpt.get("useNonZeroInitGuess") and psi0 is not None:

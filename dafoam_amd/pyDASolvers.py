@@ -710,6 +710,28 @@ class pyDASolvers:
         self._from_state(sol, solVec.array)
         return rc
 
+    def solveLinearEqnBlock(self, myKSP: KSP, rhs, sol):
+        """Several adjoint systems with the same operator through ONE block GMRES (the reference loops solveLinearEqn over
+        the objective functions, mphys_dafoam.py:478-481).  rhs, sol: (n, s) arrays, s <= 8; returns (fail, res0[s], res[s])."""
+        L = lib()
+        for k, v in myKSP._tols.items():
+            (L.das_set_option_int if isinstance(v, int) else L.das_set_option_double)(self._h, k.encode(), v)
+        rhs = np.asarray(rhs, dtype=np.float64)
+        n, s = rhs.shape
+        if self._perm is not None:
+            rhs = np.stack([self._to_state(rhs[:, r]) for r in range(s)], axis=1)
+        B = np.asfortranarray(rhs)
+        X = np.zeros((n, s), order="F")
+        r0, r1 = np.zeros(s), np.zeros(s)
+        rc = check(L.das_solve_linear_eqn_block(self._h, myKSP.handle, int(s), B.ctypes.data_as(_capi.c_double_p), X.ctypes.data_as(_capi.c_double_p),
+                                                dptr(r0), dptr(r1)))
+        for r in range(s):
+            if self._perm is None:
+                sol[:, r] = X[:, r]
+            else:
+                self._from_state(np.ascontiguousarray(X[:, r]), sol[:, r])
+        return rc, r0, r1
+
     # -- timing ----------------------------------------------------------------------------------
     def _state_blocks(self):
         """[(name, kind, offset, size)] of the DAIndex "state" ordering (reference DAIndex.C:188-258)."""

@@ -111,6 +111,10 @@ typedef struct das_case {
      * NULL for translational pairs; the partner patch holds the transpose) */
     const int* patch_neighbour;
     const double* patch_rotation;
+    /* thermophysicalProperties transport "sutherland" (reference DAResidual::updateThermoVars, DAResidual.C:264-293):
+     * mu = As sqrt(T) / (1 + Ts / T), alpha = mu Cv (1.32 + 1.77 R / Cv) / Cp; 0 = "const" transport (mu, Pr above) */
+    int transport_sutherland;
+    double sutherland_As, sutherland_Ts;
 } das_case_t;
 
 const char* das_last_error(void);
@@ -262,6 +266,11 @@ int das_drdwt_mult_device(das_solver_t* s, const double* d_x, double* d_y);
  *     returns 0 converged / 1 failed by the reference's gmresTolDiff rule (:422-434), <0 on error. */
 int das_create_ml_rksp_matrix_free(das_solver_t* s, das_mat_t* pc, das_ksp_t** ksp);
 int das_solve_linear_eqn(das_solver_t* s, das_ksp_t* ksp, const double* rhs, double* sol);
+/* das_solve_linear_eqn_block: nrhs (1..8) adjoint systems with the same operator through ONE block GMRES (the reference
+ *     loops solveLinearEqn over the objective functions, mphys_dafoam.py:478-481): dRdW^T is streamed once per iteration
+ *     for all systems, the block orthogonalisation runs as tall-skinny fp64 MFMA GEMMs.  rhs / sol: column-major n x nrhs;
+ *     res0 / res (optional, nrhs each): initial / final residual norms.  Returns 1 if any system fails the reference rule. */
+int das_solve_linear_eqn_block(das_solver_t* s, das_ksp_t* ksp, int nrhs, const double* rhs, double* sol, double* res0, double* res);
 /* preconditioner introspection (tests): y = M^{-1} x on host buffers; block layout of the additive-Schwarz PC:
  * perm[n] = global state index at each permuted position, block_off[nBlocks+1] offsets into perm */
 int das_ksp_apply_pc(das_solver_t* s, das_ksp_t* ksp, const double* x, double* y);

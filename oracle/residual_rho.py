@@ -100,8 +100,18 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
     rho_b = pb / (R * Tb)
     he = Cp * (T - TREF)
     heb, hvIC, hvBC, hgIC, hgBC = bc_scalar(bt.code["T"], Cp * (bt.val["T"] - TREF), he[bcell], delta, phi_b)
-    nu = mu / rho
-    nu_b = mu / rho_b
+    if th.get("transport", "const") == "sutherland":  # DAResidual::updateThermoVars, DAResidual.C:264-293
+        As, Ts = th.get("As", 1.4792e-06), th.get("Ts", 116.0)
+        Cv = Cp - R
+        mu_c = As * np.sqrt(T + 0.0) / (1.0 + Ts / T)
+        mu_bf = As * np.sqrt(Tb + 0.0) / (1.0 + Ts / Tb)
+        alpha_c = mu_c * Cv * (1.32 + 1.77 * R / Cv) / Cp
+        alpha_bf = mu_bf * Cv * (1.32 + 1.77 * R / Cv) / Cp
+    else:
+        mu_c, mu_bf = mu, mu
+        alpha_c, alpha_bf = mu / Pr, mu / Pr
+    nu = mu_c / rho
+    nu_b = mu_bf / rho_b
     # ---- correctNut / correctAlphat
     nut = nuT * fv1_of(nuT / nu)
     nut_b = nb * fv1_of(nb / nu_b)
@@ -118,8 +128,8 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
         nut_b = tmp
     muEff = rho * (nu + nut)  # rho*nuEff
     muEff_b = rho_b * (nu_b + nut_b)
-    alphaEff = mu / Pr + rho * nut / Prt
-    alphaEff_b = mu / Pr + rho_b * nut_b / Prt
+    alphaEff = alpha_c + rho * nut / Prt
+    alphaEff_b = alpha_bf + rho_b * nut_b / Prt
 
     gradU = ops.grad_vector(U, Ub)
     gradP = ops.grad_scalar(p, pb)

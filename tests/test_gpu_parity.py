@@ -548,6 +548,55 @@ def test_node_block_ilu_apply_matches_oracle(dims, fp32, solver):
     assert np.array_equal(y, ksp.applyPC(D.solver, x))
 
 
+@pytest.mark.parametrize("nrhs", [2, 3, 8])
+def test_block_gmres_multi_rhs_matches_direct_solve(nrhs):
+    """Block (multi right-hand-side) GMRES - SpMM + tall-skinny fp64 MFMA Gram-Schmidt (das_block.hpp): every column of the
+    block solution against a sparse direct solve of the oracle Jacobian (<= 1e-6, the north-star tolerance), and against
+    the single-system GMRES of the same library."""
+    case = converged_case((10, 8, 6), lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    sc, con, col, A = oracle_mats(case, g)
+    n = case.states.size
+    rng = np.random.default_rng(3)
+    rhs = np.zeros((n, nrhs))
+    rhs[0 : 3 * g.nC : 3, 0] = g.V                      # drag-like functional
+    rhs[1 : 3 * g.nC : 3, 1] = g.V                      # lift-like functional
+    for r in range(2, nrhs):
+        rhs[:, r] = rng.standard_normal(n) * (r + 1.0)
+    rhs *= sc[:, None]
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "gmresAbsTol": 1e-16, "gmresMaxIters": 400, "gmresRestart": 400, "printInfo": 0})
+    psi, fail = D.solveAdjoint(rhs)
+    assert fail == 0 and psi.shape == (n, nrhs)
+    lu = spla.splu(A.tocsc())
+    for r in range(nrhs):
+        assert relerr(psi[:, r], lu.solve(rhs[:, r])) <= 1e-6, r
+    psi0, fail0 = D.solveAdjoint(np.ascontiguousarray(rhs[:, 0]))
+    assert fail0 == 0 and relerr(psi[:, 0], psi0) <= 1e-6
+
+
+def test_sutherland_transport_residual_and_jacobian():
+    """thermophysicalProperties transport "sutherland" (DAResidual.C:264-293) through the GPU path: residual and
+    dual-number dRdWT against the oracle."""
+    from dafoam_amd.pyDASolvers import Mat
+
+    case = rho_channel_case(7, 6, 5, perturb=0.02)
+    case.thermo = dict(case.thermo, transport="sutherland", As=1.4792e-06, Ts=116.0)
+    g = Geometry(case.mesh)
+    D = make(case, jacLowerBounds={"dRdW": 0.0, "dRdWPC": 0.0})
+    R = np.zeros(case.states.size)
+    D.solver.getResiduals(R)
+    Ro = residual(case, g, case.states)
+    for nm, sl in blocks(case, g):
+        assert relerr(R[sl], Ro[sl]) < 1e-11, nm
+    const = rho_channel_case(7, 6, 5, perturb=0.02)
+    assert relerr(residual(const, g, const.states), Ro) > 1e-6  # the law is active
+    sc, con, col, A = oracle_mats(case, g)
+    D.solver.runColoring()
+    M = Mat()
+    D.solver.calcdRdWT(0, M, mode=1)
+    assert np.abs((M.to_scipy() - A).tocsr().data).max() <= 1e-10 * np.abs(A.data).max()
+
+
 def test_parity_tool_oracle_dump_vs_gpu_engine(tmp_path):
     """tests/parity_from_dafoam_dump.py end to end: dumps written by the ORACLE in the reference's on-disk formats (OpenFOAM
     ASCII case at a converged primal, PETSc-binary dRdWT / dRdWTPC / colouring, adjoint_* fields) compared with the GPU

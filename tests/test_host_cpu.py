@@ -388,11 +388,15 @@ def test_petsc_binary_io_roundtrip_and_layout(tmp_path):
         pio.read_mat(pv)
 
 
+@pytest.mark.parametrize("transport", ["const", "sutherland"])
 @pytest.mark.parametrize("wall_function", [False, True])
 @pytest.mark.parametrize("isPC", [0, 1])
-def test_kernel_bodies_match_oracle_rhosimplefoam(wall_function, isPC):
-    """DARhoSimpleFoam (compressible) kernel bodies vs oracle/residual_rho.py: values and dual tangents."""
+def test_kernel_bodies_match_oracle_rhosimplefoam(wall_function, isPC, transport):
+    """DARhoSimpleFoam (compressible) kernel bodies vs oracle/residual_rho.py: values and dual tangents; const transport
+    and Sutherland's law with the modified-Eucken alpha (DAResidual::updateThermoVars, DAResidual.C:264-293)."""
     case = rho_channel_case(7, 6, 5, wall_function=wall_function, perturb=0.02)
+    if transport == "sutherland":
+        case.thermo = dict(case.thermo, transport="sutherland", As=1.4792e-06, Ts=116.0)
     g = Geometry(case.mesh)
     W = case.states
     Ro = residual(case, g, W, isPC=bool(isPC))
