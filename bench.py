@@ -10,7 +10,7 @@ FD perturbation of the HIP residual.  Matrices, rhs and Krylov basis are residen
 Timed region: the solve is advanced W (= --warmup) iterations inside ONE Arnoldi cycle, then EXACTLY K (= --steps)
 iterations are timed, i.e. at basis sizes j in [W, W+K) (defaults 100 and 100: the orthogonalisation cost of a realistic
 solve, not of its first iterations).  Afterwards (N = 1) the same system is solved from scratch to gmresRelTol = 1e-6
-with gmresRestart 1200 / gmresMaxIters 1500 (reference defaults 1000 / 1000; the 2 M-cell case needs ~1040): `config.solve` reports
+with the reference's defaults (gmresRestart = gmresMaxIters = 1000): `config.solve` reports
 iterations, time_to_tolerance_s and the reference's fail flag (DALinearEqn.C:422-434).
 
   python bench.py --gpus 1 --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
@@ -48,8 +48,10 @@ def parse():
     ap.add_argument("--pctype", default=os.environ.get("DAS_BENCH_PCTYPE", "bilu"))
     ap.add_argument("--fp32-factor", type=int, default=int(os.environ.get("DAS_BENCH_PCFP32", 0)))
     ap.add_argument("--krylov-gb", type=float, default=float(os.environ.get("DAS_BENCH_KRYLOV_GB", 160.0)))
-    ap.add_argument("--solve-restart", type=int, default=1200)
-    ap.add_argument("--solve-maxit", type=int, default=1500)
+    ap.add_argument("--solve-restart", type=int, default=1000)
+    ap.add_argument("--solve-maxit", type=int, default=1000)
+    ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
+    ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE", "additive"))
     return ap.parse_args()
 
 
@@ -58,7 +60,8 @@ def make_opts(a, dev_index, restart, maxit, rtol):
         "solverName": "DASimpleFoam",
         "normalizeStates": dict(NORM),
         "adjEqnOption": {"gmresRestart": int(restart), "gmresMaxIters": int(maxit), "gmresRelTol": rtol, "gmresAbsTol": 1e-300, "printInfo": 0},
-        "amd": {"pcType": a.pctype, "pcFactorFP32": a.fp32_factor, "maxKrylovBytes": int(a.krylov_gb * 2**30)},
+        "amd": {"pcType": a.pctype, "pcFactorFP32": a.fp32_factor, "maxKrylovBytes": int(a.krylov_gb * 2**30),
+                "pcCoarseAggregates": a.coarse_agg, "pcCoarseMode": a.coarse_mode},
         "amdDevice": dev_index,
     }
 
@@ -202,8 +205,7 @@ def main():
     # ---- solve to tolerance (N = 1): the reference's defaults ----------------------------------------------------------
     solve = None
     if world == 1 and not a.no_solve:
-        # reference defaults are gmresRestart = gmresMaxIters = 1000 (pyDAFoam.py:526-548); 2 M-cell cases need a few more
-        # iterations (the DAFoam tutorials raise both for large meshes), and 288 GB of HBM hold the longer basis
+        # the reference's defaults: gmresRestart = gmresMaxIters = 1000 (pyDAFoam.py:526-548)
         D.solver.updateDAOption({"adjEqnOption": {"gmresRestart": a.solve_restart, "gmresMaxIters": a.solve_maxit, "gmresRelTol": 1e-6, "gmresAbsTol": 1e-14}})
         sol.zero_()
         torch.cuda.synchronize()
@@ -232,7 +234,7 @@ def main():
             except Exception as e:  # noqa: BLE001 - the baseline must never break the line
                 cpu = {"error": str(e)[:300]}
         pc_desc = ("node-block ILU(0) of FD dRdWTPC over the whole rank (8-slot cell nodes, 8x8 fp%s blocks), factorised on the device, "
-                   "two sync-free sweeps per apply" % ("32" if a.fp32_factor else "64")) if a.pctype == "bilu" else \
+                   "two sync-free sweeps per apply; + piecewise-constant pressure coarse space (%s)" % ("32" if a.fp32_factor else "64", a.coarse_mode)) if a.pctype == "bilu" else \
             "RAS(overlap 1)+ILU(1) of FD dRdWTPC, RCB blocks of <= 1024 cells, one workgroup per block"
         out = {
             "metric": "adjoint_gmres_iterations_per_sec",
@@ -266,9 +268,14 @@ def main():
                 "cgs_refinements_in_window_run": int(L.das_ksp_get_n_refine(ksp.handle)) if hasattr(L, "das_ksp_get_n_refine") else None,
                 "pc": pc_desc,
                 "pc_factor_entries": fac_entries,
+                "pc_coarse_aggregates": int(L.das_ksp_get_coarse(ksp.handle, None)),
+                "pc_coarse_mode": a.coarse_mode,
+                "coarse_ms": L.das_timer_avg_ms(h, b"coarse"),
                 "halo_ms": L.das_timer_avg_ms(h, b"halo") if world > 1 else None,
-                "setup_seconds": {"total": setup_s, "mesh_and_state_host": t_case, "coloring_host": t_color, "dRdWTPC_fd_gpu": t_pcmat,
-                                  "pc_factorisation": t_pc, "dRdWT_dual_gpu": t_op},
+                # adjoint setup (what the reference does between the primal and the Krylov solve) vs. building the synthetic input
+                "setup_seconds": {"total": t_color + t_pcmat + t_pc + t_op, "coloring_and_connectivity": t_color, "dRdWTPC_fd_gpu": t_pcmat,
+                                  "pc_factorisation_and_coarse_space": t_pc, "dRdWT_dual_gpu": t_op,
+                                  "synthetic_mesh_and_state_generation_python": t_case},
                 "dRdWTPsi_GBps": achieved,
                 "spmv_ms": spmv_ms,
                 "pc_apply_ms": pc_ms,

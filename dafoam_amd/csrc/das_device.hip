@@ -20,6 +20,7 @@
 #include "das_bilu.hpp"
 #include "das_comm.hpp"
 #include "das_block.hpp"
+#include "das_color.hpp"
 
 #include <omp.h>
 
@@ -388,6 +389,98 @@ __global__ void k_mul(long long n, const double* __restrict__ s, double* __restr
     if (k < n) y[k] *= s[k];
 }
 
+// ---- two-level correction: piecewise-constant coarse space on one scalar cell field (the pressure) ---------------------
+// The incomplete factorisation alone leaves the smooth pressure modes to the Krylov method: the iteration count of the
+// adjoint solve grows linearly with the number of cells along the domain (measured ~4.2 x nx for the bench channels).  A
+// Nicolaides-type coarse space - one unknown per aggregate of cells, acting on the p / pRes entries only - removes that
+// growth: M^-1 = ILU^-1 + Z E^-1 Z^T (additive) or ILU^-1 (I - A Z E^-1 Z^T) + Z E^-1 Z^T (deflated, A-DEF1), with
+// E = Z^T P Z assembled from jacPCMat on the device and inverted on the host (nAgg <= 2048).
+__global__ void k_coarse_assemble(long long N, long long off, const long long* __restrict__ rp, const int* __restrict__ ci,
+                                  const double* __restrict__ v, const int* __restrict__ agg, int nagg, double* __restrict__ E) {
+    // 16 lanes per matrix row of the field block: E[agg(row)][agg(col)] += a_ij for columns inside the field block
+    const long long c = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (c >= N) return;
+    const int I = agg[c];
+    if (I < 0) return;
+    const long long row = off + c;
+    for (long long k = rp[row] + (threadIdx.x & 15); k < rp[row + 1]; k += 16) {
+        const long long j = (long long)ci[k] - off;
+        if (j < 0 || j >= N) continue;
+        const int J = agg[j];
+        if (J >= 0) atomicAdd(&E[(long long)I * nagg + J], v[k]);
+    }
+}
+// dense inverse of the coarse operator by Gauss-Jordan with partial pivoting on the device (n <= 2048): per pivot column
+// one single-workgroup kernel (pivot search, row swap, row scaling) and one elimination kernel (one workgroup per row)
+__global__ __launch_bounds__(256) void k_gj_pivot(int n, int k, double* __restrict__ E, double* __restrict__ Inv, int* __restrict__ singular) {
+    __shared__ double bv[256];
+    __shared__ int bi[256];
+    double best = -1.0;
+    int br = k;
+    for (int r = k + threadIdx.x; r < n; r += 256) { const double a = fabs(E[(long long)r * n + k]); if (a > best) { best = a; br = r; } }
+    bv[threadIdx.x] = best; bi[threadIdx.x] = br;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o && (bv[threadIdx.x + o] > bv[threadIdx.x] || (bv[threadIdx.x + o] == bv[threadIdx.x] && bi[threadIdx.x + o] < bi[threadIdx.x]))) {
+            bv[threadIdx.x] = bv[threadIdx.x + o]; bi[threadIdx.x] = bi[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    const int pr = bi[0];
+    if (!(bv[0] > 0.0)) { if (threadIdx.x == 0) *singular = 1; return; }
+    const double ip = 1.0 / E[(long long)pr * n + k];
+    __syncthreads();
+    for (int q = threadIdx.x; q < n; q += 256) {
+        const double ek = E[(long long)k * n + q], ep = E[(long long)pr * n + q];
+        const double ik = Inv[(long long)k * n + q], ipr = Inv[(long long)pr * n + q];
+        if (pr != k) { E[(long long)pr * n + q] = ek; Inv[(long long)pr * n + q] = ik; }
+        E[(long long)k * n + q] = ep * ip;
+        Inv[(long long)k * n + q] = ipr * ip;
+    }
+}
+__global__ __launch_bounds__(256) void k_gj_elim(int n, int k, double* __restrict__ E, double* __restrict__ Inv) {
+    const int r = blockIdx.x;
+    if (r == k) return;
+    __shared__ double fs;
+    if (threadIdx.x == 0) fs = E[(long long)r * n + k];
+    __syncthreads();
+    const double f = fs;
+    if (f == 0.0) return;
+    for (int q = threadIdx.x; q < n; q += 256) {
+        E[(long long)r * n + q] -= f * E[(long long)k * n + q];
+        Inv[(long long)r * n + q] -= f * Inv[(long long)k * n + q];
+    }
+}
+// t[I] = sum of r over the field entries of aggregate I (cells sorted by aggregate: deterministic, one workgroup each)
+__global__ __launch_bounds__(256) void k_coarse_restrict(const long long* __restrict__ aptr, const int* __restrict__ cells, long long off,
+                                                         const double* __restrict__ r, double* __restrict__ t) {
+    __shared__ double red[4];
+    const int I = blockIdx.x;
+    double acc = 0.0;
+    for (long long q = aptr[I] + threadIdx.x; q < aptr[I + 1]; q += 256) acc += r[off + cells[q]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) t[I] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void k_coarse_solve(int nagg, const double* __restrict__ Einv, const double* __restrict__ t, double* __restrict__ u) {
+    const int I = blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= nagg) return;
+    double acc = 0.0;
+    for (int J = 0; J < nagg; J++) acc += Einv[(long long)I * nagg + J] * t[J];
+    u[I] = acc;
+}
+// y[field entry of cell c] (+)= u[agg(c)]; `set`: y is zero elsewhere (the deflation vector), else accumulate
+__global__ void k_coarse_prolong(long long N, long long n, long long off, const int* __restrict__ agg, const double* __restrict__ u,
+                                 double* __restrict__ y, int set) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long c = i - off;
+    const double add = (c >= 0 && c < N && agg[c] >= 0) ? u[agg[c]] : 0.0;
+    y[i] = set ? add : y[i] + add;
+}
+
 // ---- RAS/ILU(k) apply: one workgroup per (overlapping) additive-Schwarz block -------------------------------------
 // Restricted additive Schwarz: the block solves on its extended (core + overlap) unknowns and writes back only the
 // core part (PETSc's default PC_ASM_RESTRICT, reference DALinearEqn.C:199-216).
@@ -654,6 +747,15 @@ struct das_ksp {
     BlockILU pc;      // amd.pcType "ras": restricted additive Schwarz + scalar ILU(k) blocks in LDS
     NodeILU bilu;     // amd.pcType "bilu" (default): global node-block ILU(0), sync-free sweeps (das_bilu.hpp)
     bool useBilu = false;
+    struct CoarsePC {
+        bool active = false, deflated = false;
+        int nagg = 0;
+        long long off = 0, N = 0;
+        DevBuf<int> agg, cells;
+        DevBuf<long long> aptr;
+        DevBuf<double> Einv, t, u, c, rr;
+        std::vector<int> h_agg;
+    } coarse;
     int restart = 0;
     DevBuf<double> V, w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
     std::unique_ptr<struct GmresRun> run;
@@ -779,7 +881,17 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
         {
             std::vector<double> ctr(3 * (size_t)s->mesh.nC);
             for (int c = 0; c < s->mesh.nC; c++) for (int d = 0; d < 3; d++) ctr[3 * (size_t)c + d] = s->mesh.cg[c].C[d];
-            s->nColors = d2_coloring(s->con_full, s->colors, ctr.data());
+            // on a GPU box the serial first-fit runs as a data-flow kernel (das_color.hpp); without a device (CPU tests) or with
+            // amd.coloringOnDevice = 0 the host variants of das_jaccon.cpp run
+            ColorDeviceFn fn = nullptr;
+            if (s->inited && s->opt.geti("amd.coloringOnDevice"))
+                fn = [s](long long nn, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
+                         const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors) {
+                    const bool ok = color_firstfit_device(nn, keep, cptr, crow, rowptr, col, colors, s->stream);
+                    if (!ok) fprintf(stderr, "[dafoam_amd] device colouring gave up (more than 4096 colours or a timeout): host first-fit instead\n");
+                    return ok;
+                };
+            s->nColors = d2_coloring(s->con_full, s->colors, ctr.data(), fn);
         }
     }
     double t3 = wall_seconds();
@@ -1382,6 +1494,93 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     k->pc.next = (long long)k->bilu.nNodes * BILU_NB;
 }
 
+// coarse space of the two-level preconditioner (amd.pcCoarseAggregates: 0 = off, -1 = automatic): RCB aggregates of the owned
+// cells, E = Z^T P Z on the entries of the scalar cell field amd.pcCoarseField ("p") of jacPCMat
+static void setup_coarse(das_solver* s, das_ksp* k) {
+    das_ksp::CoarsePC& C = k->coarse;
+    C.active = false;
+    long long want = s->opt.geti("amd.pcCoarseAggregates");
+    if (want == 0) return;
+    const std::string field = s->opt.gets("amd.pcCoarseField");
+    const StateDef* sd = nullptr;
+    for (const StateDef& q : s->st_full.states) if (q.name == field && q.kind == KIND_SCL) sd = &q;
+    if (!sd) return;  // no such field in this solver (e.g. DAScalarTransportFoam has no p)
+    const Mesh& m = s->mesh;
+    const long long N = m.nC;
+    std::vector<int> owned;
+    owned.reserve(N);
+    for (long long c = 0; c < N; c++) if (s->owned.empty() || s->owned[sd->offset + c]) owned.push_back((int)c);
+    if (owned.size() < 64) return;
+    if (want < 0) want = std::min<long long>(1024, std::max<long long>(16, (long long)owned.size() / 2048));
+    const int nagg = (int)std::min<long long>(want, std::min<long long>(2048, (long long)owned.size() / 4));
+    if (nagg < 2) return;
+    // recursive coordinate bisection into nagg parts of (almost) equal size
+    std::vector<int> agg(N, -1);
+    {
+        struct Rg { long long b, e; int a0, na; };
+        std::vector<Rg> stack{{0, (long long)owned.size(), 0, nagg}};
+        while (!stack.empty()) {
+            Rg r = stack.back();
+            stack.pop_back();
+            if (r.na == 1) { for (long long q = r.b; q < r.e; q++) agg[owned[q]] = r.a0; continue; }
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (long long q = r.b; q < r.e; q++)
+                for (int d = 0; d < 3; d++) { const double x = m.cg[owned[q]].C[d]; lo[d] = std::min(lo[d], x); hi[d] = std::max(hi[d], x); }
+            int ax = 0;
+            for (int d = 1; d < 3; d++) if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+            const int nl = r.na / 2;
+            const long long mid = r.b + (r.e - r.b) * nl / r.na;
+            std::nth_element(owned.begin() + r.b, owned.begin() + mid, owned.begin() + r.e, [&](int a, int b2) {
+                const double xa = m.cg[a].C[ax], xb = m.cg[b2].C[ax];
+                return xa < xb || (xa == xb && a < b2);
+            });
+            stack.push_back({mid, r.e, r.a0 + nl, r.na - nl});
+            stack.push_back({r.b, mid, r.a0, nl});
+        }
+    }
+    std::vector<long long> aptr(nagg + 1, 0);
+    for (long long c = 0; c < N; c++) if (agg[c] >= 0) aptr[agg[c] + 1]++;
+    for (int a = 0; a < nagg; a++) aptr[a + 1] += aptr[a];
+    std::vector<int> cells(aptr[nagg]);
+    {
+        std::vector<long long> pos(aptr.begin(), aptr.end() - 1);
+        for (long long c = 0; c < N; c++) if (agg[c] >= 0) cells[pos[agg[c]]++] = (int)c;
+    }
+    C.nagg = nagg; C.off = sd->offset; C.N = N; C.h_agg = agg;
+    C.agg.upload(agg); C.cells.upload(cells); C.aptr.upload(aptr);
+    DevBuf<double> E((size_t)nagg * nagg);
+    E.zero();
+    const Mat& P = k->pcmat->m;
+    hipLaunchKernelGGL(k_coarse_assemble, dim3(nblk(N, 16)), dim3(256), 0, s->stream, N, C.off, P.rowptr.p, P.col.p, P.val.p, C.agg.p, nagg, E.p);
+    // E^-1 on the device (Gauss-Jordan, partial pivoting)
+    {
+        std::vector<double> I0((size_t)nagg * nagg, 0.0);
+        for (int i = 0; i < nagg; i++) I0[(size_t)i * nagg + i] = 1.0;
+        C.Einv.upload(I0);
+        DevBuf<int> sing(1);
+        DAS_HIP(hipMemsetAsync(sing.p, 0, sizeof(int), s->stream));
+        for (int kk = 0; kk < nagg; kk++) {
+            hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s->stream, nagg, kk, E.p, C.Einv.p, sing.p);
+            hipLaunchKernelGGL(k_gj_elim, dim3(nagg), dim3(256), 0, s->stream, nagg, kk, E.p, C.Einv.p);
+        }
+        int hs = 0;
+        DAS_HIP(hipMemcpyAsync(&hs, sing.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        DAS_HIP(hipStreamSynchronize(s->stream));
+        if (hs) return;  // singular coarse operator: no coarse correction
+    }
+    C.t.alloc(nagg); C.u.alloc(nagg);
+    C.deflated = s->opt.gets("amd.pcCoarseMode") == "deflated";
+    if (C.deflated) { C.c.alloc(s->n); C.rr.alloc(s->n); }
+    C.active = true;
+    if (s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] coarse space: %d aggregates on field %s (%s)\n", nagg, field.c_str(), C.deflated ? "deflated" : "additive");
+}
+// u = E^-1 Z^T r
+static void coarse_solve(das_solver* s, das_ksp* k, const double* r) {
+    das_ksp::CoarsePC& C = k->coarse;
+    hipLaunchKernelGGL(k_coarse_restrict, dim3(C.nagg), dim3(256), 0, s->stream, C.aptr.p, C.cells.p, C.off, r, C.t.p);
+    hipLaunchKernelGGL(k_coarse_solve, dim3(nblk(C.nagg, 64)), dim3(64), 0, s->stream, C.nagg, C.Einv.p, C.t.p, C.u.p);
+}
+
 static void pc_apply(das_solver* s, das_ksp* k, const double* b, double* x) {
     hipEvent_t ev = nullptr;
     s->timer.begin("pc", s->stream, ev);
@@ -1444,9 +1643,29 @@ static void multidot(das_solver* s, das_ksp* k, int m, const double* w, double* 
 // sub-domain ILU; with one sub-domain per GPU both iterate the same stationary scheme, so l x g sweeps in total)
 static void pc_apply_full(das_solver* s, das_ksp* k, const double* v, double* z) {
     const long long sweeps = std::max<long long>(1, s->opt.geti("adjEqnOption.globalPCIters")) * std::max<long long>(1, s->opt.geti("adjEqnOption.localPCIters"));
-    pc_apply(s, k, v, z);
-    if (sweeps <= 1) return;
     const long long n = s->n;
+    das_ksp::CoarsePC& C = k->coarse;
+    if (C.active) {
+        hipEvent_t ev = nullptr;
+        s->timer.begin("coarse", s->stream, ev);
+        coarse_solve(s, k, v);
+        if (C.deflated && s->op) {
+            // A-DEF1: z = ILU^-1 (v - A c) + c,  c = Z E^-1 Z^T v
+            hipLaunchKernelGGL(k_coarse_prolong, dim3(nblk(n, 256)), dim3(256), 0, s->stream, C.N, n, C.off, C.agg.p, C.u.p, C.c.p, 1);
+            s->timer.end("coarse", s->stream, ev);
+            spmv(s, s->op->m, C.c.p, C.rr.p);
+            hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, v, -1.0, C.rr.p);
+            pc_apply(s, k, C.rr.p, z);
+            hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, C.c.p, 1.0, z);
+        } else {
+            s->timer.end("coarse", s->stream, ev);
+            pc_apply(s, k, v, z);
+            hipLaunchKernelGGL(k_coarse_prolong, dim3(nblk(n, 256)), dim3(256), 0, s->stream, C.N, n, C.off, C.agg.p, C.u.p, z, 0);
+        }
+    } else {
+        pc_apply(s, k, v, z);
+    }
+    if (sweeps <= 1) return;
     if (k->rich_r.n != (size_t)n) { k->rich_r.alloc(n); k->rich_d.alloc(n); k->rich_d.zero(); }
     const Mat& P = k->pcmat->m;
     for (long long it = 1; it < sweeps; it++) {
@@ -2567,6 +2786,7 @@ int das_create_ml_rksp_matrix_free(das_solver_t* s, das_mat_t* pc, das_ksp_t** k
     DAS_CHECK(pcType == "bilu" || pcType == "ras", DAS_ERR_ARG, "amd.pcType must be \"bilu\" or \"ras\"");
     if (pcType == "bilu") setup_node_ilu(s, k.get());
     else setup_block_ilu(s, k.get());
+    setup_coarse(s, k.get());
     *ksp = k.release();
     return DAS_OK;
     DAS_CATCH
@@ -2609,7 +2829,7 @@ int das_ksp_apply_pc(das_solver_t* s, das_ksp_t* ksp, const double* x, double* y
     dx.upload(x, s->n);
     DAS_HIP(hipDeviceSynchronize());
     dy.zero();
-    pc_apply(s, ksp, dx.p, dy.p);
+    pc_apply_full(s, ksp, dx.p, dy.p);
     DAS_HIP(hipStreamSynchronize(s->stream));
     if (ksp->useBilu) DAS_CHECK(!bilu_aborted(ksp->bilu, s->stream), DAS_ERR_INTERNAL, "preconditioner sweep timed out (bounded spin)");
     dy.download(y, s->n);
@@ -2692,6 +2912,12 @@ int das_ksp_get_info(das_ksp_t* k, int* iters, double* res0, double* res, double
     DAS_CATCH
 }
 int das_ksp_get_n_refine(das_ksp_t* k) { return k ? k->nrefine : -1; }
+// coarse space of the two-level preconditioner: number of aggregates (0 = none); aggOfCell[nCells] (optional) = aggregate or -1
+int das_ksp_get_coarse(das_ksp_t* k, int* aggOfCell) {
+    if (!k || !k->coarse.active) return 0;
+    if (aggOfCell) std::copy(k->coarse.h_agg.begin(), k->coarse.h_agg.end(), aggOfCell);
+    return k->coarse.nagg;
+}
 int das_ksp_get_history(das_ksp_t* k, double* hist, int cap) {
     DAS_TRY
     DAS_CHECK(k && hist, DAS_ERR_ARG, "null argument");

@@ -271,7 +271,7 @@ static bool is_subset(const int* a, long long na, const int* b, long long nb) {
     return i == na;
 }
 
-int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres) {
+int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres, const ColorDeviceFn& device_fn) {
     const long long n = con.n;
     colors.assign(n, -1);
     const bool dbgT = getenv("DAS_DEBUG_TIMING") != nullptr;
@@ -373,6 +373,12 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         }
     };
     lap("csc");
+    if (device_fn && device_fn(n, keep, cptr, crow, con.rowptr, con.col, colors)) {
+        lap("device first-fit");
+        int ncd = 0;
+        for (long long j = 0; j < n; j++) ncd = std::max(ncd, colors[j] + 1);
+        return ncd;
+    }
     const int nth = std::max(1, omp_get_max_threads());
     // Columns are grouped by the cell they live in (anchor) and the cell range is cut into spatially contiguous
     // chunks, so concurrent threads only interact near chunk boundaries (few conflicts, near-serial colour count).

@@ -1,5 +1,6 @@
 // Jacobian connectivity (dRdWCon), colouring and assembly maps - host graph work, one-off per mesh.
 #pragma once
+#include <functional>
 #include <memory>
 #include <type_traits>
 #include <utility>
@@ -58,7 +59,11 @@ struct JacCon {
 // distance-2 (column) colouring of `con`: greedy first-fit over the non-dominated rows.
 // Returns number of colours.  Validity rule = reference DAColoring.C:931-1037.
 // `centres` (3 per anchor cell, optional) enables the deterministic tile-parallel variant on large meshes.
-int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres = nullptr);
+// `device_fn` (optional): called with the kept rows and the CSC over them; if it returns true it has written `colors`
+// (the device first-fit of das_color.hpp), otherwise the host variants run.
+using ColorDeviceFn = std::function<bool(long long n, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
+                                         const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors)>;
+int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres = nullptr, const ColorDeviceFn& device_fn = nullptr);
 bool validate_coloring(const JacCon& con, const std::vector<int>& colors);
 
 }  // namespace das

@@ -59,6 +59,10 @@ Options::Options() {
     d["jacLowerBounds.dRdWPC"] = 1.0e-30;
     // MI355X-specific knobs (not in the reference)
     s["amd.pcType"] = "bilu";       // "bilu": global node-block ILU(0), sync-free sweeps (das_bilu.hpp); "ras": RAS + ILU(k) blocks in LDS
+    i["amd.pcCoarseAggregates"] = -1;  // two-level PC: piecewise-constant coarse space on the pressure (-1 auto, 0 off, n aggregates)
+    s["amd.pcCoarseField"] = "p";
+    s["amd.pcCoarseMode"] = "additive";  // additive | deflated (A-DEF1: one extra operator product per apply)
+    i["amd.coloringOnDevice"] = 1;   // serial first-fit colouring as a data-flow kernel (das_color.hpp); 0: host variants
     i["amd.setupThreads"] = 32;     // host threads of the block-ILU setup (page-fault bound beyond that)
     i["amd.pcBlockCells"] = 1024;   // cells per additive-Schwarz block (one workgroup each)
     i["amd.jacMode"] = 1;           // operator assembly: 1 = dual numbers

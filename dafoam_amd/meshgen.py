@@ -834,3 +834,149 @@ def scalar_transport_case(nx=18, ny=17, nz=16, lengths=(1.0, 0.5, 0.5), DT=0.01,
     case.T_old = T_old
     case.states = T.copy()
     return case
+
+
+# =================================================================================================================
+# NACA0012 O-grid (BASELINE configs[1]: DASimpleFoam + SA, ~200 k cells, wall-normal stretching)
+# =================================================================================================================
+def naca0012_xy(t):
+    """Closed NACA0012 contour, chord 1: t in [0,1) runs from the trailing edge along the LOWER side to the leading edge and
+    back along the upper side (closed-trailing-edge coefficient -0.1036, cosine spacing)."""
+    t = np.asarray(t, dtype=float)
+    s = np.where(t < 0.5, 1.0 - 2.0 * t, 2.0 * t - 1.0)          # 1 -> 0 -> 1 along the contour
+    x = 0.5 * (1.0 - np.cos(np.pi * s))                            # cosine clustering at both ends
+    yt = 0.6 * (0.2969 * np.sqrt(np.maximum(x, 0.0)) - 0.1260 * x - 0.3516 * x**2 + 0.2843 * x**3 - 0.1036 * x**4)
+    return x, np.where(t < 0.5, -yt, yt)
+
+
+def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first_cell=2.0e-5, U0=10.0, aoa_deg=2.0, nu=1.5e-5, nuTilda0=4.5e-5,
+                  wall_function=False, seed=0, perturb=0.02) -> FoamCase:
+    """DASimpleFoam + SA around a NACA0012 (chord 1) on a single-block O-grid of n_around x n_normal x nz hexahedra, extruded
+    `span` in z with symmetry front/back (the reference's 2-D airfoil cases use one cell and `empty`/symmetry sides,
+    tests/runRegTests_AeroOpt.py).  Wall-normal geometric stretching from `first_cell` (y+ ~ 1 at Re 6.7e5) to the far
+    field at `radius` chords.  The branch cut behind the trailing edge is an ORDINARY set of internal faces (points merged),
+    so the mesh needs no coupled patches.  Patches: airfoil (wall), farfield (patch: U / nuTilda inletOutlet about the
+    free stream at `aoa_deg`, p fixedValue), front / back (symmetry).  States: a smooth synthetic boundary-layer-like flow
+    (seeded perturbation) - the adjoint operator's conditioning does not depend on primal convergence."""
+    nx, ny = int(n_around), int(n_normal)
+    # wall-normal distribution: geometric growth with ratio r from the first cell height to the outer radius
+    lo, hi = 1.0 + 1e-9, 2.0
+    f = lambda r: first_cell * (r**ny - 1.0) / (r - 1.0) - radius  # noqa: E731
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if f(mid) < 0 else (lo, mid)
+    r = 0.5 * (lo + hi)
+    d = first_cell * (r ** np.arange(ny + 1) - 1.0) / (r - 1.0)      # distance from the wall, d[0] = 0, d[ny] = radius
+    sblend = d / d[-1]
+    t = np.arange(nx) / nx
+    xa, ya = naca0012_xy(t)
+    ang = -2.0 * np.pi * t                                           # outer circle, same sense as the contour (lower side first)
+    xo, yo = 0.5 + radius * np.cos(ang), radius * np.sin(ang)
+    # normal offset near the wall blended into the circle far away: smooth, non-overlapping for a thin symmetric section
+    tx, ty = np.gradient(xa, edge_order=2), np.gradient(ya, edge_order=2)
+    tx[0], ty[0] = xa[1] - xa[-1], ya[1] - ya[-1]
+    nrm = np.stack([ty, -tx], axis=1)
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1), 1e-300)[:, None]
+    # the contour runs clockwise (lower side first): the outward normal is (ty, -tx) up to sign - fix it with the circle
+    sign = np.sign(np.einsum("ij,ij->i", nrm, np.stack([xo - xa, yo - ya], axis=1)))
+    nrm *= sign[:, None]
+    pts2 = np.zeros((ny + 1, nx, 2))
+    for j in range(ny + 1):
+        wgt = sblend[j] ** 0.5                                       # how much of the ray follows the circle
+        px = (1.0 - wgt) * (xa + d[j] * nrm[:, 0]) + wgt * (xa + (xo - xa) * sblend[j])
+        py = (1.0 - wgt) * (ya + d[j] * nrm[:, 1]) + wgt * (ya + (yo - ya) * sblend[j])
+        pts2[j, :, 0], pts2[j, :, 1] = px, py
+    zs = np.linspace(0.0, span, nz + 1)
+    # point ids: (i, j, k) with i periodic
+    def pid(i, j, k):
+        return (np.asarray(i) % nx) + nx * (np.asarray(j) + (ny + 1) * np.asarray(k))
+
+    def cid(i, j, k):
+        return (np.asarray(i) % nx) + nx * (np.asarray(j) + ny * np.asarray(k))
+
+    points = np.zeros((nx * (ny + 1) * (nz + 1), 3))
+    for k in range(nz + 1):
+        base = nx * (ny + 1) * k
+        points[base : base + nx * (ny + 1), 0] = pts2[:, :, 0].ravel()
+        points[base : base + nx * (ny + 1), 1] = pts2[:, :, 1].ravel()
+        points[base : base + nx * (ny + 1), 2] = zs[k]
+    I, Jc, K = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    I, Jc, K = I.ravel(), Jc.ravel(), K.ravel()
+    c = cid(I, Jc, K)
+    # internal faces: +i (periodic), +j, +k, each as (cell a, cell b, quad with normal a -> b)
+    qi = np.stack([pid(I + 1, Jc, K), pid(I + 1, Jc + 1, K), pid(I + 1, Jc + 1, K + 1), pid(I + 1, Jc, K + 1)], axis=1)
+    fa, fb, fq = [c], [cid(I + 1, Jc, K)], [qi]
+    mj = Jc < ny - 1
+    fa.append(c[mj]); fb.append(cid(I[mj], Jc[mj] + 1, K[mj]))
+    fq.append(np.stack([pid(I[mj], Jc[mj] + 1, K[mj]), pid(I[mj], Jc[mj] + 1, K[mj] + 1), pid(I[mj] + 1, Jc[mj] + 1, K[mj] + 1), pid(I[mj] + 1, Jc[mj] + 1, K[mj])], axis=1))
+    mk = K < nz - 1
+    fa.append(c[mk]); fb.append(cid(I[mk], Jc[mk], K[mk] + 1))
+    fq.append(np.stack([pid(I[mk], Jc[mk], K[mk] + 1), pid(I[mk] + 1, Jc[mk], K[mk] + 1), pid(I[mk] + 1, Jc[mk] + 1, K[mk] + 1), pid(I[mk], Jc[mk] + 1, K[mk] + 1)], axis=1))
+    fa, fb, fq = np.concatenate(fa), np.concatenate(fb), np.concatenate(fq)
+    # the (i, j, k) -> (x, y, z) map built above is left-handed or right-handed depending on the contour sense: orient by
+    # the geometry (normal must point from cell a to cell b)
+    flip = fa > fb                                                   # owner must be the lower cell id (the branch cut)
+    own = np.where(flip, fb, fa)
+    nei = np.where(flip, fa, fb)
+    o = np.lexsort((nei, own))
+    own, nei, fq, flip = own[o], nei[o], fq[o], flip[o]
+    fq = np.where(flip[:, None], fq[:, ::-1], fq)
+    faces, owners, patches = [fq], [own], []
+    start = own.size
+
+    def add_patch(name, ptype, quads, cells):
+        nonlocal start
+        oo = np.argsort(cells, kind="stable")
+        faces.append(quads[oo]); owners.append(cells[oo])
+        patches.append(Patch(name, ptype, start, cells.size))
+        start += cells.size
+
+    II, KK = np.meshgrid(np.arange(nx), np.arange(nz), indexing="ij")
+    II, KK = II.ravel(), KK.ravel()
+    add_patch("airfoil", "wall", np.stack([pid(II, 0, KK), pid(II + 1, 0, KK), pid(II + 1, 0, KK + 1), pid(II, 0, KK + 1)], axis=1), cid(II, 0, KK))
+    add_patch("farfield", "patch", np.stack([pid(II, ny, KK), pid(II, ny, KK + 1), pid(II + 1, ny, KK + 1), pid(II + 1, ny, KK)], axis=1), cid(II, ny - 1, KK))
+    II, JJ = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    II, JJ = II.ravel(), JJ.ravel()
+    add_patch("front", "symmetry", np.stack([pid(II, JJ, 0), pid(II, JJ + 1, 0), pid(II + 1, JJ + 1, 0), pid(II + 1, JJ, 0)], axis=1), cid(II, JJ, 0))
+    add_patch("back", "symmetry", np.stack([pid(II, JJ, nz), pid(II + 1, JJ, nz), pid(II + 1, JJ + 1, nz), pid(II, JJ + 1, nz)], axis=1), cid(II, JJ, nz - 1))
+    allq = np.concatenate(faces).astype(np.int32)
+    mesh = PolyMesh(points=points, face_ptr=(4 * np.arange(allq.shape[0] + 1)).astype(np.int32), face_pts=np.ascontiguousarray(allq.ravel()),
+                    owner=np.concatenate(owners).astype(np.int32), neighbour=nei.astype(np.int32), patches=patches)
+    g = _InputGeometry(mesh)
+    # orientation check: the internal-face normals must point owner -> neighbour and the boundary normals outwards; the
+    # (xi, eta, z) triad may be left-handed for this contour sense, in which case every quad is reversed
+    nIF = mesh.n_internal_faces
+    if np.einsum("ij,ij->i", g.Sf[:nIF], g.C[mesh.neighbour] - g.C[mesh.owner[:nIF]]).sum() < 0:
+        mesh.face_pts = np.ascontiguousarray(allq[:, ::-1].ravel())
+        g = _InputGeometry(mesh)
+    assert np.all(g.V > 0) and np.all(np.einsum("ij,ij->i", g.Sf[:nIF], g.C[mesh.neighbour] - g.C[mesh.owner[:nIF]]) > 0)
+    y = wall_distance_exact(mesh, g.C, g.Cf, g.Sf)
+    a = np.deg2rad(aoa_deg)
+    Uinf = np.array([U0 * np.cos(a), U0 * np.sin(a), 0.0])
+    wall_nut = NUT_SPALDING_WALL if wall_function else NUT_LOWRE_WALL
+    sym = {"U": (BC_SYMMETRY, (0.0, 0.0, 0.0)), "p": (BC_SYMMETRY, 0.0), "nuTilda": (BC_SYMMETRY, 0.0), "nut": (NUT_SYMMETRY, 0.0)}
+    bcs = {
+        "airfoil": {"U": (BC_FIXED_VALUE, (0.0, 0.0, 0.0)), "p": (BC_ZERO_GRADIENT, 0.0), "nuTilda": (BC_FIXED_VALUE, 0.0), "nut": (wall_nut, 0.0)},
+        "farfield": {"U": (BC_INLET_OUTLET, tuple(Uinf)), "p": (BC_FIXED_VALUE, 0.0), "nuTilda": (BC_INLET_OUTLET, nuTilda0), "nut": (NUT_CALCULATED, 0.0)},
+        "front": dict(sym), "back": dict(sym),
+    }
+    rng = np.random.default_rng(seed)
+    N, F = mesh.n_cells, mesh.n_faces
+    delta = 0.02                                                     # boundary-layer-like thickness of the synthetic profile
+    prof = 1.0 - np.exp(-y / delta)
+    rr = np.hypot(g.C[:, 0] - 0.25, g.C[:, 1]) + 0.1
+    th = np.arctan2(g.C[:, 1], g.C[:, 0] - 0.25)
+    # free stream + a doublet-like displacement that decays with the distance, damped to zero at the wall
+    Ux = Uinf[0] * (1.0 - 0.05 * np.cos(2.0 * th) / (rr * rr) * 0.04)
+    Uy = Uinf[1] - Uinf[0] * 0.05 * np.sin(2.0 * th) / (rr * rr) * 0.04
+    U = np.stack([Ux * prof, Uy * prof, np.zeros(N)], axis=1) * (1.0 + perturb * rng.standard_normal((N, 1)))
+    p = 0.5 * U0 * U0 * 0.2 * np.cos(th) / (1.0 + rr) * (1.0 + perturb * rng.standard_normal(N))
+    nuT = nuTilda0 * (1.0 + 30.0 * prof * np.exp(-y / (10.0 * delta))) * (1.0 + perturb * rng.standard_normal(N))
+    ownF, neiF = mesh.owner, mesh.neighbour
+    phi = np.zeros(F)
+    phi[:nIF] = np.einsum("ij,ij->i", g.w[:, None] * U[ownF[:nIF]] + (1 - g.w[:, None]) * U[neiF], g.Sf[:nIF]) * (1.0 + perturb * rng.standard_normal(nIF))
+    sl = {pt.name: slice(pt.start, pt.start + pt.size) for pt in mesh.patches}
+    phi[sl["farfield"]] = np.einsum("ij,ij->i", U[ownF[sl["farfield"]]], g.Sf[sl["farfield"]])
+    case = FoamCase(mesh=mesh, solver_name="DASimpleFoam", nu=nu, bcs=bcs, y_wall=y)
+    case.states = np.concatenate([U.ravel(), p, nuT, phi])
+    return case

@@ -202,6 +202,12 @@ class KSP:
                                          lvl.ctypes.data_as(ip), nat.ctypes.data_as(ip)))
         return dict(nodeUnk=nu.reshape(-1, 8), bptr=bptr, bcol=bcol, lvlPtr=lvl, natural=nat)
 
+    def coarse(self, n_cells):
+        """(nAgg, aggOfCell) of the two-level preconditioner's pressure coarse space (nAgg = 0: none)."""
+        agg = np.full(n_cells, -1, np.int32)
+        nagg = lib().das_ksp_get_coarse(self.handle, agg.ctypes.data_as(_capi.c_int_p))
+        return nagg, agg
+
     def applyPC(self, solver, x):
         y = np.zeros_like(x)
         check(lib().das_ksp_apply_pc(solver._h, self.handle, dptr(np.ascontiguousarray(x)), dptr(y)))

@@ -292,6 +292,9 @@ int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, doub
 int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
 /* number of Gram-Schmidt refinement passes of the last solve (KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160) */
 int das_ksp_get_n_refine(das_ksp_t* ksp);
+/* two-level preconditioner (amd.pcCoarseAggregates / pcCoarseField / pcCoarseMode): number of aggregates of the
+ * piecewise-constant pressure coarse space (0 = none) and, optionally, the aggregate of every cell (-1 = not owned) */
+int das_ksp_get_coarse(das_ksp_t* ksp, int* aggOfCell);
 /* run exactly `iters` GMRES iterations on device-resident rhs/sol (bench.py "step"); no convergence exit */
 int das_ksp_run_fixed_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rhs, double* d_sol, int iters);
 /* the same solve advanced in pieces on device-resident rhs/sol (bench.py times a window of iterations deep inside an

@@ -704,6 +704,34 @@ def test_wall_distance_exact_finite_plate():
     assert np.any(yproj[far] < 0.5 * y[far])  # the projected distance underestimates beside the plate, the exact one does not
 
 
+def test_naca0012_ogrid_generator():
+    """BASELINE configs[1] mesh family: single-block O-grid around a closed NACA0012 with geometric wall-normal stretching
+    and a merged branch cut (ordinary internal faces).  Closed cells, positive volumes, OpenFOAM face ordering, true wall
+    distance; the kernel bodies (host emulation) match the oracle residual on it."""
+    from dafoam_amd.meshgen import naca0012_case
+
+    case = naca0012_case(48, 14, 1, first_cell=2e-3, radius=8.0, wall_function=True)
+    m = case.mesh
+    g = Geometry(m)
+    N, nIF = m.n_cells, m.n_internal_faces
+    assert N == 48 * 14 and [p.name for p in m.patches] == ["airfoil", "farfield", "front", "back"]
+    acc = np.zeros((N, 3))
+    np.add.at(acc, m.owner, g.Sf)
+    np.subtract.at(acc, m.neighbour, g.Sf[:nIF])
+    assert np.abs(acc).max() < 1e-12 * np.abs(g.Sf).max() and g.V.min() > 0
+    assert np.all(m.owner[:nIF] < m.neighbour) and np.array_equal(np.lexsort((m.neighbour, m.owner[:nIF])), np.arange(nIF))
+    wall = next(p for p in m.patches if p.name == "airfoil")
+    first = np.abs(np.einsum("ij,ij->i", g.C[m.owner[wall.start:wall.start + wall.size]] - g.Cf[wall.start:wall.start + wall.size],
+                             g.Sf[wall.start:wall.start + wall.size] / np.linalg.norm(g.Sf[wall.start:wall.start + wall.size], axis=1)[:, None]))
+    assert np.allclose(case.y_wall[m.owner[wall.start:wall.start + wall.size]], first, rtol=0.05)  # wall cells: y = half the first cell height
+    assert case.y_wall.max() > 5.0  # far-field cells see the Euclidean distance to the airfoil, not a tangent-plane projection
+    W = case.states
+    Ro = residual(case, g, W)
+    Rv, _ = _emu_res(case, W, 0)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rv[sl], Ro[sl]) < 1e-10, nm
+
+
 def test_parity_tool_roundtrip_oracle(tmp_path):
     """tests/parity_from_dafoam_dump.py: this repo's own dumps in the reference's on-disk formats (OpenFOAM ASCII case,
     PETSc-binary dRdWT / dRdWTPC / colouring, adjoint_* fields) read back and compared - every block within tolerance."""

@@ -18,14 +18,17 @@ ap.add_argument("--fp32", type=int, nargs="+", default=[0])
 ap.add_argument("--threads", type=int, nargs="+", default=[32])
 ap.add_argument("--pctype", nargs="+", default=["bilu"])
 ap.add_argument("--krylov-gb", type=float, default=32.0)
+ap.add_argument("--case", default="channel", choices=["channel", "naca"], help="naca: --n = cells around, wall-normal, spanwise (BASELINE configs[1]: 800 250 1)")
+ap.add_argument("--coarse-agg", type=int, nargs="+", default=[-1])
+ap.add_argument("--coarse-mode", nargs="+", default=["additive"])
 a = ap.parse_args()
 import __graft_entry__ as ge
 ge.build()
-from dafoam_amd.meshgen import channel_case, bench_channel_case
+from dafoam_amd.meshgen import channel_case, bench_channel_case, naca0012_case
 from dafoam_amd.pyDAFoam import PYDAFOAM
 from dafoam_amd.pyDASolvers import KSP, Mat, Vec
 from dafoam_amd import _capi
-case = bench_channel_case(*a.n, wall_function=a.wf)
+case = naca0012_case(*a.n, wall_function=a.wf) if a.case == "naca" else bench_channel_case(*a.n, wall_function=a.wf)
 opts = {"solverName": "DASimpleFoam", "debug": True, "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0},
         "adjEqnOption": {"gmresRestart": a.restart, "gmresMaxIters": a.maxit, "gmresRelTol": a.rtol, "printInfo": 0}}
 D = PYDAFOAM(options=opts, case=case)
@@ -37,15 +40,16 @@ N = case.mesh.n_cells
 rhs = np.zeros(n); rhs[0:3 * N:3] = 1.0 / N
 L = _capi.lib()
 import itertools
-for pct, b, ov, fl, f32, nth in itertools.product(a.pctype, a.block, a.overlap, a.fill, a.fp32, a.threads):
-    D.solver.updateDAOption({"amd": {"pcType": pct, "maxKrylovBytes": int(a.krylov_gb * 2**30), "pcBlockCells": b, "pcFactorFP32": f32, "setupThreads": nth}, "adjEqnOption": {"asmOverlap": ov, "pcFillLevel": fl}})
+for pct, b, ov, fl, f32, nth, cagg, cmode in itertools.product(a.pctype, a.block, a.overlap, a.fill, a.fp32, a.threads, a.coarse_agg, a.coarse_mode):
+    D.solver.updateDAOption({"amd": {"pcType": pct, "pcCoarseAggregates": cagg, "pcCoarseMode": cmode, "maxKrylovBytes": int(a.krylov_gb * 2**30), "pcBlockCells": b, "pcFactorFP32": f32, "setupThreads": nth}, "adjEqnOption": {"asmOverlap": ov, "pcFillLevel": fl}})
     ksp = KSP(); t = time.time(); D.solverAD.createMLRKSPMatrixFree(pc, ksp); t_ilu = time.time() - t
     x = Vec(n); r = Vec(n); r.array[:] = rhs
     L.das_timer_reset(D.solver._h); L.das_timer_enable(D.solver._h, 1)
     t = time.time(); fail = D.solverAD.solveLinearEqn(ksp, r, x); ts = time.time() - t
     info = ksp.info()
     h = ksp.history(); print("   hist", " ".join(f"{v/h[0]:.1e}" for v in h[::max(1,len(h)//12)]))
-    print(f"pc {pct} block {b} overlap {ov} fill {fl} fp32 {f32} threads {nth} nblocks {L.das_ksp_get_n_blocks(ksp.handle)}: ilu {t_ilu:.2f}s  iters {info['iters']} fail {fail} relres {info['res']/info['res0']:.2e} solve {ts:.3f}s "
+    nag, cms = L.das_ksp_get_coarse(ksp.handle, None), L.das_timer_avg_ms(D.solver._h, b"coarse")
+    print(f"pc {pct} coarse {cagg}/{cmode} ({nag} aggregates, {cms:.3f} ms) block {b} overlap {ov} fill {fl} fp32 {f32} threads {nth} nblocks {L.das_ksp_get_n_blocks(ksp.handle)}: ilu {t_ilu:.2f}s  iters {info['iters']} fail {fail} relres {info['res']/info['res0']:.2e} solve {ts:.3f}s "
           f"-> {info['iters']/ts:.1f} it/s  spmv {L.das_timer_avg_ms(D.solver._h,b'spmv'):.3f} ms pc {L.das_timer_avg_ms(D.solver._h,b'pc'):.3f} ms")
     L.das_timer_enable(D.solver._h, 0)
     ksp.destroy() if hasattr(ksp, 'destroy') else None
