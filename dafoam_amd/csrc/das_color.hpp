@@ -10,6 +10,8 @@
 // preconditioner sweeps (das_bilu.hpp).  Result: exactly the colours of the serial first-fit (410 instead of ~500 at
 // 200 k cells, i.e. ~20 % fewer residual passes per Jacobian), in a fraction of the host time.
 #pragma once
+#include <cstdlib>
+
 #include "das_common.hpp"
 
 namespace das {
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(256) void k_color_firstfit(ColorView P) {
                 int cx = c[u];
                 unsigned spins = 0;
                 while (cx < 0) {
+                    __builtin_amdgcn_s_sleep(4);  // a waiting lane must not flood the memory system (polling-cost)
                     cx = __hip_atomic_load(&P.colors[jn[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (cx < 0 && (++spins & 1023u) == 0u) {
                         if (__hip_atomic_load(&P.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 24)) {
@@ -108,6 +111,9 @@ __global__ __launch_bounds__(256) void k_color_firstfit(ColorView P) {
 inline bool color_firstfit_device(long long n, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
                                   const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors, hipStream_t st) {
     const long long nKeep = (long long)keep.size();
+    const bool dbg = getenv("DAS_DEBUG_TIMING") != nullptr;
+    double tq = wall_seconds();
+    auto lap = [&](const char* what) { if (dbg) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]     device colouring: %s %.2f s\n", what, t2 - tq); tq = t2; } };
     // compact pattern of the kept rows
     std::vector<long long> krp(nKeep + 1, 0);
     for (long long q = 0; q < nKeep; q++) krp[q + 1] = krp[q] + (rowptr[keep[q] + 1] - rowptr[keep[q]]);
@@ -126,14 +132,17 @@ inline bool color_firstfit_device(long long n, const std::vector<long long>& kee
     for (long long q = 0; q < (long long)crow.size(); q++) crowK[q] = posOfRow[crow[q]];
     // groups: maximal runs of consecutive columns with identical kept-row lists (the xyz components of a cell's U)
     std::vector<long long> gstart;
-    gstart.reserve(n);
-    for (long long j = 0; j < n;) {
-        gstart.push_back(j);
-        const long long len = cptr[j + 1] - cptr[j];
-        long long b = j + 1;
-        while (b < n && cptr[b + 1] - cptr[b] == len && std::equal(crow.begin() + cptr[j], crow.begin() + cptr[j + 1], crow.begin() + cptr[b])) b++;
-        j = b;
+    {
+        std::vector<unsigned char> isStart(n, 1);
+#pragma omp parallel for schedule(static)
+        for (long long j = 1; j < n; j++) {
+            const long long len = cptr[j + 1] - cptr[j];
+            isStart[j] = !(cptr[j] - cptr[j - 1] == len && std::equal(crow.begin() + cptr[j], crow.begin() + cptr[j + 1], crow.begin() + cptr[j - 1]));
+        }
+        gstart.reserve(n);
+        for (long long j = 0; j < n; j++) if (isStart[j]) gstart.push_back(j);
     }
+    lap("host preparation");
     const long long nGroups = (long long)gstart.size();
     gstart.push_back(n);
     DevBuf<long long> d_gstart, d_cptr, d_krp;
@@ -143,15 +152,23 @@ inline bool color_firstfit_device(long long n, const std::vector<long long>& kee
     d_crow.upload(crowK.data(), crowK.size()); d_kcol.upload(kcol.data(), kcol.size());
     DAS_HIP(hipMemsetAsync(d_colors.p, 0xff, n * sizeof(int), st));
     DAS_HIP(hipMemsetAsync(d_ctrl.p, 0, 2 * sizeof(unsigned), st));
+    DAS_HIP(hipStreamSynchronize(st));
+    lap("upload");
     ColorView V{nGroups, d_gstart.p, d_cptr.p, d_crow.p, d_krp.p, d_kcol.p, d_colors.p, d_ctrl.p};
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int grid = (int)std::min<long long>((long long)cus * 8, nGroups + 1);
+    // workgroups in flight = the window of consecutive column groups being coloured.  Neighbouring groups conflict, so the
+    // parallelism inside the window comes from the rows / planes of cells it spans: measured, the kernel time falls like
+    // 1 / window up to the residency limit (200 k cells: 5.8 s with 64 workgroups, 0.8 s with 1024; profiles/README.md)
+    long long wgs = (long long)cus * 8;
+    if (const char* e = getenv("DAS_COLOR_WGS")) wgs = std::max(1, atoi(e));
+    const int grid = (int)std::min<long long>(wgs, nGroups + 1);
     hipLaunchKernelGGL(k_color_firstfit, dim3(grid), dim3(256), 0, st, V);
     DAS_HIP(hipGetLastError());
     unsigned ctrl[2] = {0, 0};
     DAS_HIP(hipMemcpyAsync(ctrl, d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, st));
     DAS_HIP(hipStreamSynchronize(st));
+    lap("kernel");
     if (ctrl[1] != 0u) return false;
     colors.resize(n);
     d_colors.download(colors.data(), n);
