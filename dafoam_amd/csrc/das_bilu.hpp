@@ -210,19 +210,22 @@ __global__ __launch_bounds__(256) void k_bilu_scatter(long long n, const long lo
                                                       const double* __restrict__ v, const int* __restrict__ unkNode,
                                                       const unsigned char* __restrict__ unkSlot, const long long* __restrict__ bptr,
                                                       const int* __restrict__ bcol, const unsigned char* __restrict__ late, double* __restrict__ bval,
-                                                      unsigned long long* dropped) {
+                                                      unsigned long long* dropped, int transpose, double diagScale) {
     const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
     if (row >= n) return;
-    const int I = unkNode[row];
-    if (I < 0) return;
-    const int r = unkSlot[row];
-    const long long b0 = bptr[I], b1 = bptr[I + 1];
+    const int I0 = unkNode[row];
+    if (I0 < 0) return;
+    const int r0 = unkSlot[row];
     for (long long k = rp[row] + l16; k < rp[row + 1]; k += 16) {
         const int j = ci[k];
-        const int J = unkNode[j];
-        if (J < 0) continue;  // not owned by this rank (block-Jacobi across ranks)
-        long long lo = b0, hi = b1 - 1, e = -1;
+        const int J0 = unkNode[j];
+        if (J0 < 0) continue;  // not owned by this rank (block-Jacobi across ranks)
+        // transpose: the factorisation of the TRANSPOSED matrix (the forward system dR/dW of the Newton primal): entry (i,j)
+        // goes to block (J,I), element (c,r); the node pattern is symmetric
+        const int I = transpose ? J0 : I0, J = transpose ? I0 : J0;
+        const int r = transpose ? unkSlot[j] : r0, c = transpose ? r0 : unkSlot[j];
+        long long lo = bptr[I], hi = bptr[I + 1] - 1, e = -1;
         while (lo <= hi) {
             const long long mid = (lo + hi) >> 1;
             const int cm = bcol[mid];
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void k_bilu_scatter(long long n, const long lo
             if (cm < J) lo = mid + 1; else hi = mid - 1;
         }
         if (e < 0) { if (!(late[I] && late[J])) atomicAdd(dropped, 1ull); continue; }  // late-late couplings are dropped by design
-        bval[e * BILU_NB2 + r * 8 + unkSlot[j]] = v[k];
+        bval[e * BILU_NB2 + r * 8 + c] = (j == row) ? v[k] * diagScale : v[k];  // diagScale = 1 + 1/tau: pseudo-transient shift
     }
 }
 __global__ void k_bilu_pad_diag(int nNodes, const int* __restrict__ nodeUnk, const long long* __restrict__ bdiag, double* __restrict__ bval) {
@@ -570,7 +573,7 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
 // Numeric setup on the device from the assembled PC matrix (device CSR, rows = states).
 inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned, int reach,
                        bool fp32, long long An, const long long* d_rp, const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P,
-                       bool debug, int nthr, bool rcm) {
+                       bool debug, int nthr, bool rcm, bool transpose = false, double diagScale = 1.0) {
     const double t0 = wall_seconds();
     std::vector<char> cellOwned(m.nC, 1);
     if (!owned.empty()) {
@@ -600,7 +603,7 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     P.t_struct = wall_seconds() - t0;
     double t1 = wall_seconds();
     hipLaunchKernelGGL(k_bilu_scatter, dim3((unsigned)((An + 15) / 16)), dim3(256), 0, st, An, d_rp, d_ci, d_av, d_unkNode.p, d_unkSlot.p, d_bptr.p,
-                       d_bcol.p, d_late.p, bval.p, d_dropped.p);
+                       d_bcol.p, d_late.p, bval.p, d_dropped.p, transpose ? 1 : 0, diagScale);
     hipLaunchKernelGGL(k_bilu_pad_diag, dim3((unsigned)(((long long)nN * BILU_NB + 255) / 256)), dim3(256), 0, st, nN, P.nodeUnk.p, d_bdiag.p, bval.p);
     DAS_HIP(hipGetLastError());
     unsigned long long dropped = 0;

@@ -389,6 +389,28 @@ __global__ void k_mul(long long n, const double* __restrict__ s, double* __restr
     if (k < n) y[k] *= s[k];
 }
 
+// ---- Newton primal helpers ------------------------------------------------------------------------------------------------
+__global__ void k_extract_diag(long long n, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v, double* __restrict__ d) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0.0;
+    for (long long k = rp[i]; k < rp[i + 1]; k++) if (ci[k] == i) { a = v[k]; break; }
+    d[i] = a;
+}
+__global__ void k_add_diag_prod(long long n, double a, const double* __restrict__ d, const double* __restrict__ x, double* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += a * d[i] * x[i];
+}
+// Wn = W + omega * s o dw, with the SA working variable kept non-negative
+__global__ void k_newton_update(long long n, long long n0, long long n1, double omega, const double* __restrict__ W, const double* __restrict__ scale,
+                                const double* __restrict__ dw, double* __restrict__ Wn) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double w = W[i] + omega * scale[i] * dw[i];
+    if (i >= n0 && i < n1 && w < 1e-14) w = 1e-14;
+    Wn[i] = w;
+}
+
 // ---- two-level correction: piecewise-constant coarse space on one scalar cell field (the pressure) ---------------------
 // The incomplete factorisation alone leaves the smooth pressure modes to the Krylov method: the iteration count of the
 // adjoint solve grows linearly with the number of cells along the domain (measured ~4.2 x nx for the bench channels).  A
@@ -396,7 +418,8 @@ __global__ void k_mul(long long n, const double* __restrict__ s, double* __restr
 // growth: M^-1 = ILU^-1 + Z E^-1 Z^T (additive) or ILU^-1 (I - A Z E^-1 Z^T) + Z E^-1 Z^T (deflated, A-DEF1), with
 // E = Z^T P Z assembled from jacPCMat on the device and inverted on the host (nAgg <= 2048).
 __global__ void k_coarse_assemble(long long N, long long off, const long long* __restrict__ rp, const int* __restrict__ ci,
-                                  const double* __restrict__ v, const int* __restrict__ agg, int nagg, double* __restrict__ E) {
+                                  const double* __restrict__ v, const int* __restrict__ agg, int nagg, double* __restrict__ E, int transpose,
+                                  double diagScale) {
     // 16 lanes per matrix row of the field block: E[agg(row)][agg(col)] += a_ij for columns inside the field block
     const long long c = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     if (c >= N) return;
@@ -407,7 +430,7 @@ __global__ void k_coarse_assemble(long long N, long long off, const long long* _
         const long long j = (long long)ci[k] - off;
         if (j < 0 || j >= N) continue;
         const int J = agg[j];
-        if (J >= 0) atomicAdd(&E[(long long)I * nagg + J], v[k]);
+        if (J >= 0) atomicAdd(transpose ? &E[(long long)J * nagg + I] : &E[(long long)I * nagg + J], (j == c) ? v[k] * diagScale : v[k]);
     }
 }
 // dense inverse of the coarse operator by Gauss-Jordan with partial pivoting on the device (n <= 2048): per pivot column
@@ -747,6 +770,8 @@ struct das_ksp {
     BlockILU pc;      // amd.pcType "ras": restricted additive Schwarz + scalar ILU(k) blocks in LDS
     NodeILU bilu;     // amd.pcType "bilu" (default): global node-block ILU(0), sync-free sweeps (das_bilu.hpp)
     bool useBilu = false;
+    bool pcTranspose = false;   // factorise jacPCMat^T (forward system of the Newton primal)
+    double pcDiagScale = 1.0;   // 1 + 1/tau on the diagonal (pseudo-transient shift)
     struct CoarsePC {
         bool active = false, deflated = false;
         int nagg = 0;
@@ -821,6 +846,11 @@ struct das_solver {
     bool own_stream = false;
     std::vector<unsigned char> owned;  // per state; empty = single-domain
     DevBuf<unsigned char> d_owned;
+    struct FwdOp {  // Newton primal: the Krylov operator is (dR/dW S + D / tau) applied matrix-free by one dual-number residual pass
+        bool on = false;
+        double invTau = 0.0;
+        DevBuf<double> diag;  // D = diag(dR/dW S), taken from jacPCMat
+    } fwd;
     HaloPlan halo;  // native halo reduction / all-reduce (das_comm.hpp); the two callbacks below are the legacy host transport
     das_halo_cb halo_cb = nullptr;
     das_allreduce_cb allreduce_cb = nullptr;
@@ -1488,7 +1518,7 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     const int reach = pc_stencil_reach(s);
     const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
     bilu_setup(s->mesh, s->st_full.states, s->n, s->owned, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
-               k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s));
+               k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s), k->pcTranspose, k->pcDiagScale);
     k->useBilu = true;
     k->pc.setup_seconds = wall_seconds() - t0;
     k->pc.nBlocks = 1;
@@ -1553,7 +1583,8 @@ static void setup_coarse(das_solver* s, das_ksp* k) {
     DevBuf<double> E((size_t)nagg * nagg);
     E.zero();
     const Mat& P = k->pcmat->m;
-    hipLaunchKernelGGL(k_coarse_assemble, dim3(nblk(N, 16)), dim3(256), 0, s->stream, N, C.off, P.rowptr.p, P.col.p, P.val.p, C.agg.p, nagg, E.p);
+    hipLaunchKernelGGL(k_coarse_assemble, dim3(nblk(N, 16)), dim3(256), 0, s->stream, N, C.off, P.rowptr.p, P.col.p, P.val.p, C.agg.p, nagg, E.p, k->pcTranspose ? 1 : 0,
+                       k->pcDiagScale);
     // E^-1 on the device (Gauss-Jordan, partial pivoting)
     {
         std::vector<double> I0((size_t)nagg * nagg, 0.0);
@@ -1640,6 +1671,8 @@ static void multidot(das_solver* s, das_ksp* k, int m, const double* w, double* 
     DAS_HIP(hipStreamSynchronize(s->stream));
 }
 
+static void apply_operator(das_solver* s, const double* x, double* y);
+
 // z = M^{-1} v: the factorisation, wrapped in globalPCIters x localPCIters Richardson sweeps on jacPCMat when the
 // options ask for more than one (reference DALinearEqn.C:173-205, 237-260: KSPRICHARDSON around ASM and around the
 // sub-domain ILU; with one sub-domain per GPU both iterate the same stationary scheme, so l x g sweeps in total)
@@ -1651,11 +1684,11 @@ static void pc_apply_full(das_solver* s, das_ksp* k, const double* v, double* z)
         hipEvent_t ev = nullptr;
         s->timer.begin("coarse", s->stream, ev);
         coarse_solve(s, k, v);
-        if (C.deflated && s->op) {
+        if (C.deflated && (s->op || s->fwd.on)) {
             // A-DEF1: z = ILU^-1 (v - A c) + c,  c = Z E^-1 Z^T v
             hipLaunchKernelGGL(k_coarse_prolong, dim3(nblk(n, 256)), dim3(256), 0, s->stream, C.N, n, C.off, C.agg.p, C.u.p, C.c.p, 1);
             s->timer.end("coarse", s->stream, ev);
-            spmv(s, s->op->m, C.c.p, C.rr.p);
+            apply_operator(s, C.c.p, C.rr.p);
             hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, v, -1.0, C.rr.p);
             pc_apply(s, k, C.rr.p, z);
             hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, C.c.p, 1.0, z);
@@ -1678,6 +1711,23 @@ static void pc_apply_full(das_solver* s, das_ksp* k, const double* v, double* z)
     }
 }
 
+// y = (Krylov operator) x: the assembled dRdW^T (adjoint), or - Newton primal - (dR/dW S + D/tau) x by ONE forward-mode pass
+static void apply_operator(das_solver* s, const double* x, double* y) {
+    if (!s->fwd.on) { spmv(s, s->op->m, x, y); return; }
+    const long long n = s->n;
+    const int B = 256;
+    hipStream_t st = s->stream;
+    hipEvent_t ev = nullptr;
+    s->timer.begin("jvp", st, ev);
+    ResParams prm = make_params(s->cp, s->opt, 0);
+    if (s->d_Wd.n != (size_t)n) { s->d_Wd.alloc(n); s->d_Rd.alloc(n); }
+    hipLaunchKernelGGL(k_seed_dir, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_W.p, s->d_scale.p, x, s->d_Wd.p);
+    eval_residual<Dual<1>>(s->dm, s->cp, prm, s->d_Wd.p, s->d_Rd.p, s->wk1, s->d_phiF.p, s->d_Told.p, st);
+    hipLaunchKernelGGL(k_tangent_out, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_Rd.p, y);
+    if (s->fwd.invTau != 0.0) hipLaunchKernelGGL(k_add_diag_prod, dim3(nblk(n, B)), dim3(B), 0, st, n, s->fwd.invTau, s->fwd.diag.p, x, y);
+    s->timer.end("jvp", st, ev);
+}
+
 struct GmresRun {
     bool open = false;        // inside an Arnoldi cycle
     bool fixed = false;       // no convergence exit (bench)
@@ -1693,7 +1743,7 @@ static void gmres_true_residual(das_solver* s, das_ksp* k, GmresRun& G, bool hav
     const long long n = s->n;
     hipStream_t st = s->stream;
     if (haveGuess) {
-        spmv(s, s->op->m, G.d_x, k->r.p);
+        apply_operator(s, G.d_x, k->r.p);
         hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, st, n, 1.0, G.d_rhs, -1.0, k->r.p);
     } else {
         DAS_HIP(hipMemsetAsync(G.d_x, 0, n * sizeof(double), st));
@@ -1705,7 +1755,7 @@ static void gmres_true_residual(das_solver* s, das_ksp* k, GmresRun& G, bool hav
 
 static void gmres_begin(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x, bool fixed) {
     need_init(s);
-    DAS_CHECK(s->op, DAS_ERR_STATE, "initializedRdWTMatrixFree() must be called before solveLinearEqn()");
+    DAS_CHECK(s->op || s->fwd.on, DAS_ERR_STATE, "initializedRdWTMatrixFree() must be called before solveLinearEqn()");
     gmres_ws(s, k);
     if (!k->run) k->run.reset(new GmresRun);
     GmresRun& G = *k->run;
@@ -1739,13 +1789,12 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
     const long long n = s->n;
     const int B = 256, m = G.m, j = G.j;
     hipStream_t st = s->stream;
-    const Mat& A = s->op->m;
     const bool alwaysRefine = s->opt.geti("amd.cgsAlwaysRefine") != 0;
     const bool mgs = s->opt.geti("adjEqnOption.useMGSO") != 0;
     std::vector<double>&H = G.H, &hh = G.hh, &h2 = G.h2, &cs = G.cs, &sn = G.sn, &g = G.g;
     double* vj = k->V.p + (long long)j * n;
     pc_apply_full(s, k, vj, k->z.p);
-    spmv(s, A, k->z.p, k->w.p);
+    apply_operator(s, k->z.p, k->w.p);
     double hn;
     std::fill(h2.begin(), h2.end(), 0.0);
     if (mgs) {
@@ -2084,6 +2133,115 @@ static int run_block_gmres(das_solver* s, das_ksp* k, int sv, const double* d_B,
     return failed;
 }
 
+// ---- Newton-Krylov primal (survey row f4: the step before the adjoint, reference DASimpleFoam.C:123-185 solvePrimal) -----------
+// The reference iterates SIMPLE (UEqn -> pEqn -> turbulence) until the residuals of DAResidualSimpleFoam fall below
+// primalMinResTol.  Its fixed point is R(W) = 0 for exactly the residual this library evaluates, so the MI355X primal solves
+// R(W) = 0 with the machinery of the adjoint: pseudo-transient Newton, every step (dR/dW S + D/tau) dw = -R by GMRES with
+//   * the operator applied matrix-free by ONE forward-mode (dual-number) residual pass (no assembled Jacobian),
+//   * the preconditioner = node-block ILU(0) of jacPCMat^T (coloured FD, diagonal scaled by 1 + 1/tau) + the pressure coarse
+//     space - the adjoint's preconditioner with transposed blocks, rebuilt every `pcLag` steps,
+//   * tau from switched evolution relaxation (tau = tau0 ||R0|| / ||R||), a backtracking update that keeps nuTilda >= 0.
+// Verified against the oracle's SIMPLE fixed point (tests): same W* to 1e-6.
+struct NewtonInfo { int steps = 0, linIters = 0, pcBuilds = 0; double res0 = 0, res = 0, seconds = 0; std::vector<double> hist; };
+
+static double device_norm2(das_solver* s, das_ksp* k, const double* x) {
+    double h = 0.0;
+    multidot_dev(s, k, x, 0, x, k->hdev.p);
+    DAS_HIP(hipMemcpyAsync(&h, k->hdev.p, sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    DAS_HIP(hipStreamSynchronize(s->stream));
+    return std::sqrt(std::max(h, 0.0));
+}
+
+static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double absTol, NewtonInfo& info) {
+    need_init(s);
+    DAS_CHECK(s->cp.solver == DAS_SOLVER_SIMPLEFOAM || DAS_IS_COMPRESSIBLE(s->cp.solver), DAS_ERR_ARG, "the Newton primal needs a flow solver");
+    DAS_CHECK(!s->halo.active && !s->halo_cb, DAS_ERR_ARG, "the Newton primal is single-rank");
+    const long long n = s->n;
+    const int B = 256;
+    hipStream_t st = s->stream;
+    const double t0 = wall_seconds();
+    const double tau0 = s->opt.getd("amd.primalTau0"), linTol = s->opt.getd("amd.primalLinearTol");
+    const int pcLag = (int)std::max<long long>(1, s->opt.geti("amd.primalPCLag"));
+    const double serExp = s->opt.getd("amd.primalSERExponent");
+    const long long linIters = s->opt.geti("amd.primalLinearIters");
+    ensure_coloring(s);
+    // Krylov options of the inner solves (restored afterwards)
+    const Options saved = s->opt;
+    s->opt.i["adjEqnOption.gmresMaxIters"] = linIters;
+    s->opt.i["adjEqnOption.gmresRestart"] = linIters;
+    s->opt.d["adjEqnOption.gmresRelTol"] = linTol;
+    s->opt.d["adjEqnOption.gmresAbsTol"] = 1e-300;
+    s->opt.i["adjEqnOption.useNonZeroInitGuess"] = 0;
+    struct Restore { das_solver* s; Options o; ~Restore() { s->opt = o; s->fwd.on = false; } } restore{s, saved};
+    const StateDef* sdN = nullptr;
+    for (const StateDef& q : s->st_full.states) if (q.name == "nuTilda") sdN = &q;
+    const long long n0 = sdN ? sdN->offset : 0, n1 = sdN ? sdN->offset + sdN->size : 0;
+    ResParams prm = make_params(s->cp, s->opt, 0);
+    DevBuf<double> Rc(n), Rn(n), Wn(n), rhs(n), dw(n);  // Rc: residual at the current states (s->d_R is scratch of the FD assembly)
+    std::unique_ptr<das_ksp> k;
+    std::unique_ptr<das_mat> P;
+    auto residual_at = [&](const double* W, double* R) { eval_residual<double>(s->dm, s->cp, prm, W, R, s->wk, s->d_phiF.p, s->d_Told.p, st); };
+    // a scratch KSP just for norms before the first preconditioner exists
+    std::unique_ptr<das_ksp> scratch(new das_ksp);
+    scratch->partial.alloc((size_t)2 * nblk(n, MD_CHUNK));
+    scratch->hdev.alloc(8);
+    residual_at(s->d_W.p, Rc.p);
+    double rn = device_norm2(s, scratch.get(), Rc.p);
+    info = NewtonInfo();
+    info.res0 = rn;
+    info.hist.push_back(rn);
+    double tau = tau0;
+    int sincePC = pcLag;
+    for (int step = 0; step < maxSteps && rn > std::max(relTol * info.res0, absTol); step++) {
+        if (!(rn == rn)) break;
+        if (sincePC >= pcLag) {
+            // jacPCMat at the current states (coloured FD), transposed node-block ILU with the pseudo-transient diagonal
+            P.reset(assemble(s, 1, 0));
+            k.reset(new das_ksp);
+            k->pcmat = P.get();
+            k->pcTranspose = true;
+            k->pcDiagScale = 1.0 + 1.0 / tau;
+            setup_node_ilu(s, k.get());
+            setup_coarse(s, k.get());
+            if (s->fwd.diag.n != (size_t)n) s->fwd.diag.alloc(n);
+            hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n, B)), dim3(B), 0, st, n, P->m.rowptr.p, P->m.col.p, P->m.val.p, s->fwd.diag.p);
+            sincePC = 0;
+            info.pcBuilds++;
+        }
+        sincePC++;
+        s->fwd.on = true;
+        s->fwd.invTau = 1.0 / tau;
+        hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, -1.0, Rc.p, rhs.p);
+        run_gmres(s, k.get(), rhs.p, dw.p, 0);
+        s->fwd.on = false;
+        info.linIters += k->iters;
+        // backtracking: accept the first step that does not blow the residual up
+        double omega = 1.0, rnew = rn;
+        for (int ls = 0; ls < 8; ls++) {
+            hipLaunchKernelGGL(k_newton_update, dim3(nblk(n, B)), dim3(B), 0, st, n, n0, n1, omega, s->d_W.p, s->d_scale.p, dw.p, Wn.p);
+            residual_at(Wn.p, Rn.p);
+            rnew = device_norm2(s, k.get(), Rn.p);
+            if (rnew == rnew && rnew < 1.5 * rn) break;
+            omega *= 0.5;
+        }
+        DAS_HIP(hipMemcpyAsync(s->d_W.p, Wn.p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        DAS_HIP(hipMemcpyAsync(Rc.p, Rn.p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        // a preconditioner built for a much smaller tau is rebuilt early
+        const double tauNew = std::min(1e12, tau0 * std::pow(info.res0 / std::max(rnew, 1e-300), serExp));
+        if (tauNew > 4.0 * tau || tauNew < 0.25 * tau) sincePC = pcLag;
+        tau = tauNew;
+        rn = rnew;
+        info.steps = step + 1;
+        info.hist.push_back(rn);
+        if (s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] Newton primal step %d: |R| %.3e (omega %.3f, %d GMRES iterations, tau %.2e)\n", step + 1, rn, omega, k->iters, tau);
+    }
+    DAS_HIP(hipStreamSynchronize(st));
+    s->h_W = s->d_W.to_host();
+    info.res = rn;
+    info.seconds = wall_seconds() - t0;
+    return (rn <= std::max(relTol * info.res0, absTol)) ? 0 : 1;
+}
+
 // =====================================================================================================
 // C-ABI
 // =====================================================================================================
@@ -2284,6 +2442,17 @@ int das_calc_residuals(das_solver_t* s, int isPC, double* residuals) {
 }
 int das_get_residuals(das_solver_t* s, double* residuals) { return das_calc_residuals(s, 0, residuals); }
 
+// solvePrimal (reference pyDASolvers.pyx solvePrimal -> DASimpleFoam::solvePrimal, DASimpleFoam.C:123-185): converge
+// R(W) = 0 from the current states; returns 0 converged / 1 not converged; info4 = {steps, GMRES iterations, |R0|, |R|}
+int das_solve_primal(das_solver_t* s, int maxSteps, double relTol, double absTol, double* info4, double* hist, int histCap) {
+    DAS_TRY
+    NewtonInfo inf;
+    const int rc = run_newton_primal(s, maxSteps, relTol, absTol, inf);
+    if (info4) { info4[0] = inf.steps; info4[1] = inf.linIters; info4[2] = inf.res0; info4[3] = inf.res; }
+    if (hist) for (int i = 0; i < histCap && i < (int)inf.hist.size(); i++) hist[i] = inf.hist[i];
+    return rc;
+    DAS_CATCH
+}
 int das_run_coloring(das_solver_t* s) {
     DAS_TRY
     DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");

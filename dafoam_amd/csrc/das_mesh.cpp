@@ -63,6 +63,11 @@ Options::Options() {
     s["amd.pcCoarseField"] = "p";
     s["amd.pcCoarseMode"] = "additive";  // additive | deflated (A-DEF1: one extra operator product per apply)
     i["amd.coloringOnDevice"] = 1;   // serial first-fit colouring as a data-flow kernel (das_color.hpp); 0: host variants
+    d["amd.primalTau0"] = 1.0;          // Newton primal: initial pseudo-time factor (diagonal scaled by 1 + 1/tau), SER growth
+    d["amd.primalSERExponent"] = 1.5;   // tau = tau0 (|R0| / |R|)^exponent (measured: 1.0 -> 52+ steps, 1.5 -> 20-29, 2.0 -> 17-21 on the bench channels)
+    d["amd.primalLinearTol"] = 1.0e-3;  // relative tolerance of the inner GMRES solves
+    i["amd.primalLinearIters"] = 300;
+    i["amd.primalPCLag"] = 3;           // Newton steps per preconditioner rebuild
     i["amd.setupThreads"] = 32;     // host threads of the block-ILU setup (page-fault bound beyond that)
     i["amd.pcBlockCells"] = 1024;   // cells per additive-Schwarz block (one workgroup each)
     i["amd.jacMode"] = 1;           // operator assembly: 1 = dual numbers

@@ -278,6 +278,23 @@ class PYDAFOAM(object):
         vec.array[:] = array1
         return vec
 
+    # ---------------------------------------------------------------- primal (pyDAFoam.py __call__ / solvePrimal)
+    def solvePrimal(self, maxSteps=80):
+        """Converge the flow residuals from the current states (reference PYDAFOAM.solvePrimal -> DASimpleFoam::solvePrimal,
+        DASimpleFoam.C:123-185).  The tolerance is the reference's option primalMinResTol, taken relative to the initial
+        residual norm.  Sets self.primalFail (0 converged / 1 not, like the reference) and returns it."""
+        tol = float(self.getOption("primalMinResTol"))
+        fail, self.primalInfo = self.solver.solvePrimal(maxSteps=maxSteps, relTol=tol)
+        self.primalFail = int(fail)
+        W = self.getStates()
+        if self.solverAD is not self.solver:
+            self.solverAD.updateOFFields(W)
+        return self.primalFail
+
+    def __call__(self):
+        """One analysis, like the reference's DASolver(): the primal, then the functions are available through evalFunctions."""
+        return self.solvePrimal()
+
     # ---------------------------------------------------------------- adjoint (mphys_dafoam.py:433-574 sequence)
     def solveAdjoint(self, dFdWArray, psi0=None):
         """psi with D_s (dR/dW)^T psi = dFdW (dFdW already state-scaled like the output of

@@ -716,6 +716,16 @@ class pyDASolvers:
         self._from_state(sol, solVec.array)
         return rc
 
+    def solvePrimal(self, maxSteps=80, relTol=1e-8, absTol=0.0):
+        """solvePrimal (reference pyDASolvers.pyx solvePrimal -> DASimpleFoam::solvePrimal, DASimpleFoam.C:123-185): converge
+        the residuals from the current states.  Returns (fail, info) with info = dict(steps, linearIterations, res0, res,
+        history); the converged states are read back with getOFFields / getStates."""
+        info4 = np.zeros(4)
+        hist = np.zeros(int(maxSteps) + 2)
+        rc = check(lib().das_solve_primal(self._h, int(maxSteps), float(relTol), float(absTol), dptr(info4), dptr(hist), hist.size))
+        nst = int(info4[0])
+        return rc, dict(steps=nst, linearIterations=int(info4[1]), res0=float(info4[2]), res=float(info4[3]), history=hist[: nst + 1].copy())
+
     def solveLinearEqnBlock(self, myKSP: KSP, rhs, sol):
         """Several adjoint systems with the same operator through ONE block GMRES (the reference loops solveLinearEqn over
         the objective functions, mphys_dafoam.py:478-481).  rhs, sol: (n, s) arrays, s <= 8; returns (fail, res0[s], res[s])."""
@@ -798,5 +808,3 @@ class pyDASolvers:
         return lib().das_get_elapsed_cpu_time(self._h)
 
     # -- not on the hot path -----------------------------------------------------------------------
-    def solvePrimal(self):
-        raise NotImplementedError("primal solve is upstream of the adjoint hot path (SURVEY.md section 8f)")

@@ -167,6 +167,12 @@ int das_calc_residuals(das_solver_t* s, int isPC, double* residuals);
  * das_run_coloring <- runColoring()  pyDASolvers.pyx:161  (DASolver.C:708-743, DAJacCon, DAColoring)
  * Host graph work; needs no GPU.  The getters expose dRdWCon and the colour vector (the reference
  * writes them as dRdWCon.bin / dRdWColoring_<np>.bin, DAJacCon.C:1886-1975,2580-2586). */
+/* das_solve_primal <- solvePrimal()  pyDASolvers.pyx (DASimpleFoam::solvePrimal, DASimpleFoam.C:123-185): converge the
+ * residuals of the current states.  The reference iterates SIMPLE; its fixed point is R(W) = 0, which is solved here by a
+ * pseudo-transient Newton-Krylov method built from the adjoint's own kernels (forward-mode operator, transposed node-block
+ * ILU + coarse space; options amd.primalTau0 / primalLinearTol / primalLinearIters / primalPCLag).  Returns 0 converged
+ * (|R| <= max(relTol |R0|, absTol)) / 1 not converged; info4 = {Newton steps, GMRES iterations, |R0|, |R|}. */
+int das_solve_primal(das_solver_t* s, int maxSteps, double relTol, double absTol, double* info4, double* hist, int histCap);
 int das_run_coloring(das_solver_t* s);
 /* das_set_coloring <- DAJacCon::readJacConColoring (DAJacCon.C:1980-2019): colours read back from a dRdWColoring_n.bin
  *                      cache; validated against the freshly built connectivity ("Conflicting Colors Found!" otherwise). */

@@ -870,6 +870,35 @@ def test_naca0012_ogrid_residual_jacobian_adjoint():
     assert fail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-6
 
 
+def test_newton_krylov_primal_reaches_the_simple_fixed_point():
+    """solvePrimal on the GPU (survey row f4): pseudo-transient Newton-Krylov on R(W) = 0 built from the adjoint's kernels
+    (forward-mode operator, transposed node-block ILU + coarse space) against the ORACLE's SIMPLE loop (reference
+    DASimpleFoam.C:123-185 restated in oracle/primal.py): same fixed point, residual dropped by ten orders; the adjoint
+    linearised about the GPU primal equals the adjoint about the oracle primal."""
+    from oracle.primal import solve_primal
+
+    case = channel_case(10, 8, 6, perturb=0.0, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    Wo, hist = solve_primal(case, g, max_iters=800, tol=1e-11)
+    sc = J.state_scales(case, g, norm_states(case))
+    D = make(case, primalMinResTol=1e-10, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0})
+    fail = D()
+    info = D.primalInfo
+    assert fail == 0 and info["res"] <= 1e-10 * info["res0"] and info["steps"] <= 60, info
+    W = D.getStates()
+    assert relerr(W / sc, Wo / sc) <= 1e-6
+    R = np.zeros(W.size)
+    D.solver.getResiduals(R)
+    assert np.linalg.norm(residual(case, g, W)) <= 1e-8 * np.linalg.norm(residual(case, g, case.states))
+    rhs = np.zeros(W.size)
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= sc
+    psi, afail = D.solveAdjoint(rhs)
+    case.states = Wo
+    sc2, con, col, A = oracle_mats(case, g)
+    assert afail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-5
+
+
 def test_device_coloring_is_the_serial_first_fit():
     """The data-flow colouring kernel (das_color.hpp) reproduces the SERIAL first-fit colours exactly (below 20 k cells the
     host path is that serial sweep), validates like the reference demands (DAColoring::validateColoring, checked inside
