@@ -899,6 +899,21 @@ def test_newton_krylov_primal_reaches_the_simple_fixed_point():
     assert afail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-5
 
 
+def test_newton_krylov_primal_compressible():
+    """The same Newton-Krylov primal on DARhoSimpleFoam + SA: the fixed point of the oracle's compressible SIMPLE loop."""
+    from oracle.primal import solve_primal
+
+    case = rho_channel_case(8, 6, 5, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    Wo, hist = solve_primal(case, g, max_iters=800, tol=1e-11)
+    sc = J.state_scales(case, g, norm_states(case))
+    D = make(case, primalMinResTol=1e-9)
+    fail = D.solvePrimal(maxSteps=80)
+    info = D.primalInfo
+    assert fail == 0 and info["res"] <= 1e-9 * info["res0"], info
+    assert relerr(D.getStates() / sc, Wo / sc) <= 1e-6
+
+
 def test_device_coloring_is_the_serial_first_fit():
     """The data-flow colouring kernel (das_color.hpp) reproduces the SERIAL first-fit colours exactly (below 20 k cells the
     host path is that serial sweep), validates like the reference demands (DAColoring::validateColoring, checked inside
