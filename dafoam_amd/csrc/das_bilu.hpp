@@ -133,6 +133,19 @@ __global__ __launch_bounds__(BILU_WG, LEAN ? 8 : 4) void k_bilu_sweep(BiluView P
                 }
             };
             if (!LEAN && nE > 0) load_pass(0, v, c);
+            // what the end of the node needs besides the row sums does not depend on the solution: requested here, so that the
+            // (dependent) loads are not on the chain dependency ready -> row sums -> publish
+            const long long p = UPPER ? (long long)P.nNodes - 1 - q : q;
+            int gi;
+            double rhs, dinv = 0.0;
+            if (!UPPER) {
+                gi = P.nodeUnk[p * BILU_NB + g];
+                rhs = gi >= 0 ? b[gi] : 0.0;
+            } else {
+                gi = P.nodeUnk[p * BILU_NB + k];
+                rhs = P.y[p * BILU_NB + g];
+                dinv = P.invD[p * BILU_NB2 + k * 8 + g];
+            }
             for (int a0 = 0; a0 < nE; a0 += 8) {
                 const bool act = g < min(8, nE - a0);
                 if (LEAN) load_pass(a0, v, c);
@@ -184,20 +197,14 @@ __global__ __launch_bounds__(BILU_WG, LEAN ? 8 : 4) void k_bilu_sweep(BiluView P
             a1 += __shfl_xor(a1, 2, 64);
             a1 += __shfl_xor(a1, 4, 64);  // every lane of group g: the full sum of row g
             if (!UPPER) {
-                if (k == 0) {
-                    const int gi = P.nodeUnk[q * BILU_NB + g];
-                    bilu_store_sc1(&P.y[q * BILU_NB + g], (gi >= 0 ? b[gi] : 0.0) - a1);
-                }
+                if (k == 0) bilu_store_sc1(&P.y[p * BILU_NB + g], rhs - a1);
             } else {
-                const long long p = (long long)P.nNodes - 1 - q;
-                const double tg = P.y[p * BILU_NB + g] - a1;
-                double w = P.invD[p * BILU_NB2 + k * 8 + g] * tg;  // row k of invD times t, summed over the groups
+                double w = dinv * (rhs - a1);  // row k of invD times t, summed over the groups
                 w += __shfl_xor(w, 8, 64);
                 w += __shfl_xor(w, 16, 64);
                 w += __shfl_xor(w, 32, 64);
                 if (g == 0) {
                     bilu_store_sc1(&P.z[p * BILU_NB + k], w);
-                    const int gi = P.nodeUnk[p * BILU_NB + k];
                     if (gi >= 0) out[gi] = w;
                 }
             }

@@ -561,6 +561,22 @@ class pyDASolvers:
         check(lib().das_get_con(self._h, int(isPC), rp.ctypes.data_as(_capi.c_ll_p), ci.ctypes.data_as(_capi.c_int_p)))
         return sp.csr_matrix((np.ones(nnz, np.int8), ci, rp), shape=(n, n))
 
+    def pcStructure(self):
+        """Node structure the default ("bilu") preconditioner would be factorised on, built on the host (no GPU needed):
+        dict(nodeUnk[nNodes, 8], bptr, bcol, lvlPtr, natural, reach)."""
+        L = lib()
+        nN, nB, nLv, reach = C.c_int(0), C.c_longlong(0), C.c_int(0), C.c_int(0)
+        check(L.das_pc_structure_build(self._h, C.byref(nN), C.byref(nB), C.byref(nLv), C.byref(reach)))
+        nu = np.empty(nN.value * 8, np.int32)
+        bptr = np.empty(nN.value + 1, np.int64)
+        bcol = np.empty(nB.value, np.int32)
+        lvl = np.empty(nLv.value + 1, np.int32)
+        nat = np.empty(nN.value, np.int32)
+        ip = _capi.c_int_p
+        check(L.das_pc_structure_get(self._h, nu.ctypes.data_as(ip), bptr.ctypes.data_as(_capi.c_ll_p), bcol.ctypes.data_as(ip),
+                                     lvl.ctypes.data_as(ip), nat.ctypes.data_as(ip)))
+        return dict(nodeUnk=nu.reshape(-1, 8), bptr=bptr, bcol=bcol, lvlPtr=lvl, natural=nat, reach=reach.value)
+
     def calcdRdWT(self, isPC, dRdWT: Mat, mode=None):
         """pyDASolvers.pyx:237.  mode None: the reference's behaviour for the PC (coloured FD) and exact
         dual-number assembly for isPC=0."""

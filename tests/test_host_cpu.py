@@ -741,3 +741,32 @@ def test_parity_tool_roundtrip_oracle(tmp_path):
     ok, rows = P.compare(case_dir, str(tmp_path), engine="oracle", tol=1e-8, verbose=False)
     assert ok, [r for r in rows if not r[2]]
     assert any(r[0].startswith("psi[") for r in rows) and any("colouring" in r[0] for r in rows)
+
+
+def test_pc_node_structure_levels_and_pattern():
+    """Host side of the node-block ILU (das_bilu.hpp): every unknown sits in one slot, the node pattern holds every entry of
+    the PC connectivity except late-late couplings, and the processing (level) order keeps all coupled nodes in their natural
+    relative order - the condition under which the ticketed sweeps cannot deadlock and the factorisation equals the
+    natural-order one."""
+    case = channel_case(12, 10, 8, grading_y=1.5)
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    s.runColoring()
+    S = s.pcStructure()
+    nu, bptr, bcol, nat = S["nodeUnk"], S["bptr"], S["bcol"], S["natural"]
+    n, nN = case.states.size, nu.shape[0]
+    lev = np.repeat(np.arange(S["lvlPtr"].size - 1), np.diff(S["lvlPtr"]))
+    assert np.array_equal(np.sort(nu[nu >= 0]), np.arange(n))
+    assert np.array_equal(np.sort(nat), np.arange(nN)) and lev.size == nN
+    rows = np.repeat(np.arange(nN), np.diff(bptr))
+    lower, upper = bcol < rows, bcol > rows
+    assert np.all(lev[bcol[lower]] < lev[rows[lower]]) and np.all(nat[bcol[lower]] < nat[rows[lower]])
+    assert np.all(lev[bcol[upper]] > lev[rows[upper]]) and np.all(nat[bcol[upper]] > nat[rows[upper]])
+    # pattern coverage: the PC connectivity, mapped to nodes
+    node_of = np.empty(n, np.int64)
+    node_of[nu[nu >= 0]] = np.nonzero(nu >= 0)[0]
+    con = s.getConnectivity(1).tocoo()
+    have = set(zip(rows.tolist(), bcol.tolist()))
+    nPrimary = int(np.sum(np.any((nu >= 0) & (nu < n - case.mesh.n_faces), axis=1)))
+    late = nat >= nPrimary
+    missing = [(a, b) for a, b in set(zip(node_of[con.row].tolist(), node_of[con.col].tolist())) if (a, b) not in have]
+    assert all(late[a] and late[b] for a, b in missing)
