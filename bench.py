@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--cpu-solve", action="store_true", help="cpu_baseline additionally solves the 200 k-cell sample to 1e-6 on the host cores and reports time-to-tolerance and |psi_gpu - psi_cpu| (minutes)")
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
     ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE", "additive"))
+    ap.add_argument("--orth", default=os.environ.get("DAS_BENCH_ORTH", "dcgs2"), help="dcgs2 (delayed re-orthogonalisation, 2 basis reads / iteration) | cgs (reference: refine if needed)")
     return ap.parse_args()
 
 
@@ -63,7 +64,7 @@ def make_opts(a, dev_index, restart, maxit, rtol):
         "normalizeStates": dict(NORM),
         "adjEqnOption": {"gmresRestart": int(restart), "gmresMaxIters": int(maxit), "gmresRelTol": rtol, "gmresAbsTol": 1e-300, "printInfo": 0},
         "amd": {"pcType": a.pctype, "pcFactorFP32": a.fp32_factor, "maxKrylovBytes": int(a.krylov_gb * 2**30),
-                "pcCoarseAggregates": a.coarse_agg, "pcCoarseMode": a.coarse_mode},
+                "pcCoarseAggregates": a.coarse_agg, "pcCoarseMode": a.coarse_mode, "gmresOrthogonalization": a.orth},
         "amdDevice": dev_index,
     }
 
@@ -208,7 +209,10 @@ def main():
     else:
         pc_bytes = 12.0 * fac_entries + 16.0 * n_ext
     jmean = a.warmup + 0.5 * a.steps
-    iter_bytes = spmv_bytes + pc_bytes + 32.0 * jmean * n + 48.0 * n  # one CGS pass (dots + axpy)
+    iter_bytes = spmv_bytes + pc_bytes + 32.0 * jmean * n + 48.0 * n  # BASELINE.md section 3 (CGS with refinement: 4 basis reads)
+    # what this implementation has to move: the delayed re-orthogonalisation reads the basis twice per iteration
+    orth = a.orth
+    moved_bytes = spmv_bytes + pc_bytes + (16.0 if orth == "dcgs2" else 32.0) * jmean * n + 48.0 * n
     ms_step = dt / a.steps * 1e3
 
     # ---- solve to tolerance (N = 1): the reference's defaults ----------------------------------------------------------
@@ -315,11 +319,14 @@ def main():
             "roofline_iteration": {
                 "bound": "hbm",
                 "algorithmic_bytes_per_step": iter_bytes,
-                "formula": "B_spmv + B_pc + 32 j n + 48 n at the mean j of the window (one CGS pass)",
+                "formula": "B_spmv + B_pc + 32 j n + 48 n at the mean j of the window (BASELINE.md section 3: Gram-Schmidt with refinement, 4 basis reads)",
                 "achieved": iter_bytes / (ms_step * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": iter_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "orthogonalization": orth,
+                "bytes_moved_model_per_step": moved_bytes,
+                "frac_of_bytes_moved_model": moved_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             "cpu_baseline": cpu,
         }

@@ -369,6 +369,94 @@ __global__ __launch_bounds__(256) void k_multiaxpy(long long n, int m, const dou
     for (int i = 0; i < m; i++) s -= h[i] * V[(long long)i * ldv + k];
     w[k] = s;
 }
+// Two right-hand sides against K basis vectors in ONE pass over the basis (the fused inner products of the delayed
+// re-orthogonalisation, gmres_iter_dcgs2): partial[(r K + i) nbw + slot] = this wave's part of V_i . (r == 0 ? u : v).
+// A thread keeps MD2_ROWS rows of u and v in registers; four basis vectors at a time give 8 sums per lane, which one
+// reduce-scatter over the wave (10 exchanges for 8 sums instead of 48) leaves in the 8 lane groups.
+#define MD2_ROWS 8
+#define MD2_CHUNK (256 * MD2_ROWS)
+template <bool FULL>
+__device__ __forceinline__ void multidot2_body(long long n, int K, const double* __restrict__ V, long long ldv, const double* __restrict__ u,
+                                               const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
+    const int lane = threadIdx.x & 63, g = lane >> 3;
+    const long long base = (long long)blockIdx.x * MD2_CHUNK + threadIdx.x;
+    const long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    double ur[MD2_ROWS], vr[MD2_ROWS];
+#pragma unroll
+    for (int t = 0; t < MD2_ROWS; t++) {
+        const long long k = FULL ? base + 256 * t : min(base + 256 * t, n - 1);  // clamped loads, masked below: no branches
+        const double m = (FULL || base + 256 * t < n) ? 1.0 : 0.0;
+        ur[t] = m * u[k];
+        vr[t] = m * v[k];
+    }
+    for (int i0 = 0; i0 < K; i0 += 4) {
+        double acc[8], x[4][MD2_ROWS];
+        // all 4 x MD2_ROWS loads are issued before the first use (written as two loops: the scheduler otherwise trades the
+        // loads in flight for registers and waits after every load)
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            const double* vi = V + (long long)min(i0 + ii, K - 1) * ldv;
+#pragma unroll
+            for (int t = 0; t < MD2_ROWS; t++) x[ii][t] = vi[FULL ? base + 256 * t : min(base + 256 * t, n - 1)];  // ur, vr are zero beyond n
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int t = 0; t < MD2_ROWS; t++) {
+                a += x[ii][t] * ur[t];
+                b += x[ii][t] * vr[t];
+            }
+            acc[2 * ii] = a;
+            acc[2 * ii + 1] = b;
+        }
+        double a4[4], a2[2], a1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double snd = (g & 4) ? acc[i] : acc[i + 4], keep = (g & 4) ? acc[i + 4] : acc[i];
+            a4[i] = keep + __shfl_xor(snd, 32, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const double snd = (g & 2) ? a4[i] : a4[i + 2], keep = (g & 2) ? a4[i + 2] : a4[i];
+            a2[i] = keep + __shfl_xor(snd, 16, 64);
+        }
+        {
+            const double snd = (g & 1) ? a2[0] : a2[1], keep = (g & 1) ? a2[1] : a2[0];
+            a1 = keep + __shfl_xor(snd, 8, 64);
+        }
+        a1 += __shfl_xor(a1, 1, 64);
+        a1 += __shfl_xor(a1, 2, 64);
+        a1 += __shfl_xor(a1, 4, 64);  // lane group g: the wave's sum number g = 2 ii + r
+        const int i = i0 + (g >> 1);
+        if ((lane & 7) == 0 && i < K) partial[((long long)(g & 1) * K + i) * nbw + slot] = a1;
+    }
+}
+__global__ __launch_bounds__(256) void k_multidot2(long long n, int K, const double* __restrict__ V, long long ldv, const double* __restrict__ u,
+                                                   const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
+    if ((long long)(blockIdx.x + 1) * MD2_CHUNK <= n) multidot2_body<true>(n, K, V, ldv, u, v, partial, nbw);
+    else multidot2_body<false>(n, K, V, ldv, u, v, partial, nbw);
+}
+// The fused update of the delayed re-orthogonalisation, one pass over the basis: with Q = the j final vectors, u = slot j
+// (projected once), v = the operator applied to u:   q_j = (u - Q s) / alpha  -> slot j,
+//                                                     u' = (v - gamma u - Q c) / alpha -> slot j + 1
+__global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, double* __restrict__ V, long long ldv, const double* __restrict__ sc,
+                                                      double gamma, double ralpha, const double* __restrict__ v) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double* s = sc;
+    const double* c = sc + j;
+    double as = 0.0, ac = 0.0;
+#pragma unroll 8
+    for (int i = 0; i < j; i++) {
+        const double q = V[(long long)i * ldv + k];
+        as += s[i] * q;
+        ac += c[i] * q;
+    }
+    const double u = V[(long long)j * ldv + k];
+    V[(long long)j * ldv + k] = (u - as) * ralpha;
+    V[(long long)(j + 1) * ldv + k] = (v[k] - gamma * u - ac) * ralpha;
+}
 // y = sum_i c_i V_i
 __global__ __launch_bounds__(256) void k_lincomb(long long n, int m, const double* __restrict__ V, long long ldv, const double* __restrict__ c,
                                                  double* __restrict__ y) {
@@ -1646,15 +1734,15 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
     long long budget = (long long)(32.0 * 1024 * 1024 * 1024);
     auto it = s->opt.i.find("amd.maxKrylovBytes");
     if (it != s->opt.i.end()) budget = it->second;
-    restart = std::max<long long>(1, std::min<long long>(restart, budget / (8 * n) - 1));
-    if (k->restart != restart || k->V.n != (size_t)((restart + 1) * n)) {
+    restart = std::max<long long>(1, std::min<long long>(restart, budget / (8 * n) - 2));
+    if (k->restart != restart || k->V.n != (size_t)((restart + 2) * n)) {
         k->restart = (int)restart;
-        k->V.alloc((restart + 1) * n);
+        k->V.alloc((restart + 2) * n);  // m + 1 basis vectors and the pending vector of the delayed re-orthogonalisation
         k->w.alloc(n); k->z.alloc(n); k->r.alloc(n); k->xdev.alloc(n); k->bdev.alloc(n);
         k->z.zero();  // multi-GPU: ghost entries are never written by the PC and must stay zero
         int nb = nblk(n, MD_CHUNK);
-        k->partial.alloc((size_t)(restart + 2) * nb);
-        k->hdev.alloc(2 * (restart + 2));
+        k->partial.alloc(std::max<size_t>((size_t)(restart + 2) * nb, (size_t)2 * (restart + 2) * 4 * (size_t)nblk(n, MD2_CHUNK)));
+        k->hdev.alloc(4 * (restart + 3));
     }
 }
 
@@ -1739,6 +1827,10 @@ struct GmresRun {
     const double* d_rhs = nullptr;
     double* d_x = nullptr;
     std::vector<double> H, cs, sn, g, hh, h2, y;
+    // delayed re-orthogonalisation (gmres_iter_dcgs2)
+    bool dcgs2 = false;
+    int pend = 0;                 // slot of the pending (once projected, not normalised) vector = number of final basis vectors
+    std::vector<double> Hraw, h1; // unrotated Hessenberg matrix; first-projection coefficients of the pending vector
 };
 
 static void gmres_true_residual(das_solver* s, das_ksp* k, GmresRun& G, bool haveGuess) {
@@ -1767,7 +1859,11 @@ static void gmres_begin(das_solver* s, das_ksp* k, const double* d_rhs, double* 
     G.maxIts = s->opt.geti("adjEqnOption.gmresMaxIters");
     G.rtol = s->opt.getd("adjEqnOption.gmresRelTol"); G.atol = s->opt.getd("adjEqnOption.gmresAbsTol");
     G.H.assign((size_t)(m + 1) * m, 0.0); G.cs.assign(m, 0.0); G.sn.assign(m, 0.0); G.g.assign(m + 1, 0.0);
-    G.hh.assign(m + 2, 0.0); G.h2.assign(m + 2, 0.0); G.y.assign(m, 0.0);
+    G.hh.assign(2 * (m + 2), 0.0); G.h2.assign(2 * (m + 2), 0.0); G.y.assign(m, 0.0);
+    const std::string& orth = s->opt.gets("amd.gmresOrthogonalization");
+    DAS_CHECK(orth == "dcgs2" || orth == "cgs", DAS_ERR_ARG, "amd.gmresOrthogonalization \"" + orth + "\" is not one of dcgs2 | cgs");
+    G.dcgs2 = orth == "dcgs2" && s->opt.geti("adjEqnOption.useMGSO") == 0;
+    if (G.dcgs2) { G.Hraw.assign((size_t)(m + 1) * m, 0.0); G.h1.assign(m + 2, 0.0); }
     k->nrefine = 0;
     k->hist.clear();
     G.t0 = wall_seconds();
@@ -1783,11 +1879,14 @@ static void gmres_cycle_start(das_solver* s, das_ksp* k) {
     std::fill(G.g.begin(), G.g.end(), 0.0);
     G.g[0] = G.beta;
     G.j = 0;
+    G.pend = 0;
     G.open = true;
 }
 // one Arnoldi step; returns the recurrence residual norm
+static double gmres_iter_dcgs2(das_solver* s, das_ksp* k);
 static double gmres_iter(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
+    if (G.dcgs2) return gmres_iter_dcgs2(s, k);
     const long long n = s->n;
     const int B = 256, m = G.m, j = G.j;
     hipStream_t st = s->stream;
@@ -1854,6 +1953,100 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
     const double res = std::fabs(g[G.j]);
     k->hist.push_back(res);
     if (hn == 0.0) G.j = -G.j;  // happy breakdown: close the cycle (sign marks it)
+    return res;
+}
+// Givens update of Hessenberg column `col` (entries H[0..col+1][col] already set); returns the recurrence residual norm
+static double gmres_rotate_column(GmresRun& G, int col) {
+    const int m = G.m;
+    std::vector<double>&H = G.H, &cs = G.cs, &sn = G.sn, &g = G.g;
+    for (int i = 0; i < col; i++) {
+        const double a = H[(size_t)i * m + col], b2 = H[(size_t)(i + 1) * m + col];
+        H[(size_t)i * m + col] = cs[i] * a + sn[i] * b2;
+        H[(size_t)(i + 1) * m + col] = -sn[i] * a + cs[i] * b2;
+    }
+    const double a = H[(size_t)col * m + col], b2 = H[(size_t)(col + 1) * m + col];
+    const double d = std::hypot(a, b2);
+    cs[col] = d > 0 ? a / d : 1.0;
+    sn[col] = d > 0 ? b2 / d : 0.0;
+    H[(size_t)col * m + col] = d;
+    H[(size_t)(col + 1) * m + col] = 0.0;
+    g[col + 1] = -sn[col] * g[col];
+    g[col] = cs[col] * g[col];
+    return std::fabs(g[col + 1]);
+}
+// One step of GMRES with classical Gram-Schmidt and DELAYED re-orthogonalisation (DCGS2; Bielich, Langou, Thomas,
+// Swirydowicz, Yamazaki, Boman, "Low-synch Gram-Schmidt with delayed reorthogonalization for Krylov solvers", 2022).
+// The reference's CGS with refinement (DALinearEqn.C:160) reads the basis four times per iteration here (it refines at
+// nearly every step: the right-preconditioned operator is close to the identity on the current vector, so the first
+// projection removes most of the norm).  DCGS2 produces the same basis with TWO reads: the second projection of the newest
+// vector and the first projection of the next Krylov vector share their inner products and their update.
+//
+// State: Q = [q_0 .. q_{j-1}] final; u (slot j) = B q_{j-1} - Q h1, projected once, not normalised (B = A M^-1).
+//   v = B u
+//   [s; uu] = [Q u]^T u,  [t; uv] = [Q u]^T v                       one pass over the basis (k_multidot2)
+//   alpha^2 = uu - s.s ;  column j-1 of H = [h1 + s ; alpha]         (B q_{j-1} = Q (h1 + s) + alpha q_j)
+//   q_j = (u - Q s) / alpha
+//   B q_j = (v - B Q s) / alpha = (v - Q (H_jj s) - q_j alpha s_{j-1}) / alpha     (Arnoldi relation for B Q)
+//   gamma = q_j.(B q_j) + s_{j-1} = (uv - s.t) / alpha^2
+//   u' = B q_j - [Q q_j] h1' = (v - gamma u - Q (t - gamma s)) / alpha,  h1' = [(t - H_jj s) / alpha ; gamma - s_{j-1}]
+//   q_j and u' come out of one more pass over the basis (k_dcgs2_update).
+// The Hessenberg column (and with it the residual norm) of a step is known one step later; a solve that stops after k
+// columns has applied the operator k + 1 times.
+static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
+    GmresRun& G = *k->run;
+    const long long n = s->n;
+    const int m = G.m, j = G.pend;
+    hipStream_t st = s->stream;
+    double* u = k->V.p + (long long)j * n;
+    pc_apply_full(s, k, u, k->z.p);
+    apply_operator(s, k->z.p, k->w.p);
+    const int K = j + 1;
+    const long long nbw = 4LL * nblk(n, MD2_CHUNK);
+    hipLaunchKernelGGL(k_multidot2, dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, k->V.p, n, u, k->w.p, k->partial.p, nbw);
+    hipLaunchKernelGGL(k_reduce, dim3(2 * K), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
+    if (!(s->halo.active && s->halo.allreduce(k->hdev.p, 2 * K, st)) && s->allreduce_cb) s->allreduce_cb(k->hdev.p, 2 * K, s->comm_user);
+    std::vector<double>& o = G.hh;
+    DAS_HIP(hipMemcpyAsync(o.data(), k->hdev.p, 2 * K * sizeof(double), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
+    const double* sv = o.data();
+    const double* tv = o.data() + K;
+    const double uu = sv[j], uv = tv[j];
+    double ss = 0.0, stt = 0.0;
+    for (int i = 0; i < j; i++) { ss += sv[i] * sv[i]; stt += sv[i] * tv[i]; }
+    const double al2 = uu - ss;
+    const bool breakdown = !(al2 > 0.0);
+    const double al = breakdown ? 0.0 : std::sqrt(al2);
+    double res = k->hist.back();
+    if (j == 0) {
+        G.g[0] = G.beta * al;  // slot 0 holds r / beta, alpha = 1 up to rounding
+    } else {
+        const int col = j - 1;
+        for (int i = 0; i < j; i++) G.Hraw[(size_t)i * m + col] = G.H[(size_t)i * m + col] = G.h1[i] + sv[i];
+        G.Hraw[(size_t)j * m + col] = G.H[(size_t)j * m + col] = al;
+        res = gmres_rotate_column(G, col);
+        G.its++;
+        G.j = j;
+        k->hist.push_back(res);
+        if (breakdown) { G.j = -G.j; return res; }  // happy breakdown: close the cycle (sign marks it)
+        const bool stop = !G.fixed && (res <= G.target || G.its >= G.maxIts);
+        if (stop || G.j >= m) return res;            // the cycle is closed by the caller: no further basis vector needed
+    }
+    DAS_CHECK(!breakdown, DAS_ERR_INTERNAL, "GMRES: the initial residual vanished inside the Arnoldi process");
+    const double gam = (uv - stt) / al2;
+    // coefficients of the fused update: s, then c = t - gamma s
+    std::vector<double>& co = G.h2;
+    for (int i = 0; i < j; i++) { co[i] = sv[i]; co[j + i] = tv[i] - gam * sv[i]; }
+    double* dco = k->hdev.p + 2 * (m + 3);
+    if (j > 0) DAS_HIP(hipMemcpyAsync(dco, co.data(), 2 * j * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_dcgs2_update, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, k->V.p, n, dco, gam, 1.0 / al, k->w.p);
+    // first-projection coefficients of the new pending vector: (t - H_jj s) / alpha, gamma - s_{j-1}
+    for (int i = 0; i < j; i++) {
+        double a = tv[i];
+        for (int q = std::max(0, i - 1); q < j; q++) a -= G.Hraw[(size_t)i * m + q] * sv[q];
+        G.h1[i] = a / al;
+    }
+    G.h1[j] = gam - (j > 0 ? sv[j - 1] : 0.0);
+    G.pend = j + 1;
     return res;
 }
 // back substitution, x += M^{-1} (V y), true residual

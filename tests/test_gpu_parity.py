@@ -1021,6 +1021,32 @@ def test_gmres_failure_rule_and_restart():
     assert fail2 == 0 and relerr(psi2, spla.spsolve(A.tocsc(), rhs)) <= 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("restart", [1000, 25])
+def test_delayed_reorthogonalisation_matches_reference_gram_schmidt(restart):
+    """amd.gmresOrthogonalization "dcgs2" (default: second projection of a step fused with the first of the next one, two
+    basis reads per iteration) against "cgs" (the reference's KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160) and against
+    modified Gram-Schmidt: the same Krylov iterates - equal iteration counts, equal residual histories, equal psi."""
+    case = converged_case((10, 8, 6), lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    rhs = np.zeros(case.states.size)
+    rhs[0 : 3 * g.nC : 3] = g.V
+    out = {}
+    for name, amd, adj in (("dcgs2", {"gmresOrthogonalization": "dcgs2"}, {}), ("cgs", {"gmresOrthogonalization": "cgs"}, {}),
+                           ("mgs", {}, {"useMGSO": 1})):
+        D = make(case, amd=dict(amd, pcCoarseAggregates=0), adjEqnOption=dict(adj, gmresRelTol=1e-10, gmresRestart=restart, gmresMaxIters=3000, printInfo=0))
+        psi, fail = D.solveAdjoint(rhs)
+        assert fail == 0
+        out[name] = (psi, D.ksp.history(), D.ksp.info()["iters"])
+    for other in ("cgs", "mgs"):
+        assert out["dcgs2"][2] == out[other][2]
+        h1, h2 = out["dcgs2"][1], out[other][1]
+        assert np.all(np.abs(h1 - h2) <= 1e-5 * h2 + 1e-12 * h2[0])  # (the last entries sit at the rounding level of the true residual)
+        assert relerr(out["dcgs2"][0], out[other][0]) < 1e-8
+    with pytest.raises(Exception, match="gmresOrthogonalization"):
+        make(case, amd={"gmresOrthogonalization": "householder"}).solveAdjoint(rhs)
+
+
 def test_size_independent_properties_larger_mesh():
     """At a size where the oracle Jacobian would take minutes: linearity of dRdW^T.psi, FD-vs-dual agreement of
     J^T psi via the dot-product identity with a GPU residual difference, and GMRES residual reduction."""
