@@ -58,6 +58,19 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(op_nnz, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json), if they were taken on this
+    workload (same operator nnz); None otherwise - counters cannot be collected inside a timed run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            for w in json.load(f)["workloads"]:
+                if int(w["dRdWT_nnz"]) == int(op_nnz) and kernel in w:
+                    return float(w[kernel])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def make_opts(a, dev_index, restart, maxit, rtol):
     return {
         "solverName": "DASimpleFoam",
@@ -303,7 +316,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": None,  # PMC passes are separate runs: profiles/ holds them (profiles/README.md)
+                "traffic": pmc_traffic(op_nnz, "k_spmv_wave"),  # separate rocprofv3 --pmc passes, committed under profiles/
                 "launches_timed": int(spmv_cnt),
                 "algorithmic_bytes_per_launch": spmv_bytes,
             },
@@ -315,6 +328,7 @@ def main():
                 "unit": "GB/s",
                 "frac": pc_bytes / (pc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pc_ms and pc_ms > 0 else None,
                 "algorithmic_bytes_per_launch": pc_bytes,
+                "traffic": (pmc_traffic(op_nnz, "k_bilu_sweep_forward") or 0.0) + (pmc_traffic(op_nnz, "k_bilu_sweep_backward") or 0.0) or None,
             },
             "roofline_iteration": {
                 "bound": "hbm",

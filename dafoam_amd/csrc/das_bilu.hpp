@@ -96,10 +96,10 @@ __device__ __forceinline__ void bilu_load_pair<float>(const float* p, double& a,
 // out[state] = z.  Lane (g, k) = (lane / 8, lane % 8) owns COLUMN k of the g-th block of a pass of 8 blocks: it polls exactly
 // the one solution value it multiplies with (x_k of dependency g), keeps 8 row accumulators over all passes, and one
 // reduce-scatter per node (10 exchanges) leaves the row sums in the lane groups.
-// LEAN = true: no intra-wave prefetch of the next pass, <= 64 VGPRs, 4 workgroups (32 waves) per CU instead of 2 - more
-// waves hide more of the dependent-load chain (ticket -> row pointers -> blocks -> poll) than the prefetch does.
-template <class VT, bool UPPER, bool LEAN>
-__global__ __launch_bounds__(BILU_WG, LEAN ? 8 : 4) void k_bilu_sweep(BiluView P, const double* __restrict__ b, double* __restrict__ out, int npw, int sleepReps) {
+// (Measured and dropped: a lean variant without the prefetch of the next pass - <= 64 VGPRs, 4 workgroups per CU - and
+// several nodes per wave per ticket: both slower at 200 k and at 2 M cells.)
+template <class VT, bool UPPER>
+__global__ __launch_bounds__(BILU_WG, 4) void k_bilu_sweep(BiluView P, const double* __restrict__ b, double* __restrict__ out, int sleepReps) {
     __shared__ unsigned sh_chunk[2];
     constexpr int WAVES = BILU_WG / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -111,11 +111,11 @@ __global__ __launch_bounds__(BILU_WG, LEAN ? 8 : 4) void k_bilu_sweep(BiluView P
     for (unsigned it = 0;; it++) {
         if (threadIdx.x == 0) sh_chunk[it & 1] = atomicAdd(&P.ctrl[UPPER ? 1 : 0], 1u);
         __syncthreads();
-        const long long q0 = (long long)sh_chunk[it & 1] * (WAVES * npw);
+        const long long q0 = (long long)sh_chunk[it & 1] * WAVES;
         if (q0 >= P.nNodes) return;
-        for (int t = 0; t < npw; t++) {
-            const long long q = q0 + (long long)t * WAVES + wave;
-            if (q >= P.nNodes) break;
+        {
+            const long long q = q0 + wave;
+            if (q >= P.nNodes) continue;
             const long long e0 = ptr[q];
             const int nE = (int)(ptr[q + 1] - e0);
             double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BILU_WG, LEAN ? 8 : 4) void k_bilu_sweep(BiluView P
                     for (int qq = 0; qq < 4; qq++) bilu_load_pair<VT>(base + ((qq * nb + g) * 8 + k) * 2, vv[2 * qq], vv[2 * qq + 1]);
                 }
             };
-            if (!LEAN && nE > 0) load_pass(0, v, c);
+            if (nE > 0) load_pass(0, v, c);
             // what the end of the node needs besides the row sums does not depend on the solution: requested here, so that the
             // (dependent) loads are not on the chain dependency ready -> row sums -> publish
             const long long p = UPPER ? (long long)P.nNodes - 1 - q : q;
@@ -148,8 +148,7 @@ __global__ __launch_bounds__(BILU_WG, LEAN ? 8 : 4) void k_bilu_sweep(BiluView P
             }
             for (int a0 = 0; a0 < nE; a0 += 8) {
                 const bool act = g < min(8, nE - a0);
-                if (LEAN) load_pass(a0, v, c);
-                else if (a0 + 8 < nE) load_pass(a0 + 8, vn, cn);
+                if (a0 + 8 < nE) load_pass(a0 + 8, vn, cn);
                 const double* xp = xs + (long long)c * BILU_NB + k;
                 unsigned long long xb = 0ull;
                 unsigned spins = 0;
@@ -171,11 +170,9 @@ __global__ __launch_bounds__(BILU_WG, LEAN ? 8 : 4) void k_bilu_sweep(BiluView P
 #pragma unroll
                     for (int r = 0; r < 8; r++) acc[r] += v[r] * xk;
                 }
-                if (!LEAN) {
 #pragma unroll
-                    for (int r = 0; r < 8; r++) v[r] = vn[r];
-                    c = cn;
-                }
+                for (int r = 0; r < 8; r++) v[r] = vn[r];
+                c = cn;
             }
             // reduce-scatter over the 8 lane groups: afterwards group g holds (per column lane) the partial sums of row g
             double a4[4], a2[2], a1;
@@ -669,24 +666,19 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
 }
 
 // launch shape of the sweeps: as many workgroups as keep a few levels in flight (a wave far ahead of the front only
-// spins and loads the memory system), nodes per ticket so that the ticket counter stays far below its saturation rate.
-// DAS_BILU_WGS / DAS_BILU_NPW / DAS_BILU_SLEEP override (tuning runs).
-struct BiluLaunch { int grid, npw, sleepReps; bool lean; };
+// spins and loads the memory system).  DAS_BILU_WGS / DAS_BILU_SLEEP override (tuning runs).
+struct BiluLaunch { int grid, sleepReps; };
 inline BiluLaunch bilu_launch_shape(const NodeILU& P) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int waves = BILU_WG / 64;
     const double perLevel = (double)P.nNodes / std::max(1, P.nLevels);
     BiluLaunch L;
-    L.npw = 1;
-    L.grid = (int)std::min<double>(cus * 4.0, std::max(8.0, P.windowLevels * perLevel / (waves * L.npw)));
+    L.grid = (int)std::min<double>(cus * 4.0, std::max(8.0, P.windowLevels * perLevel / waves));
     L.sleepReps = 0;
-    L.lean = false;  // measured: the prefetching variant (2 workgroups / CU) beats the lean one (4 / CU) at 200 k and 2 M cells
-    if (const char* e = getenv("DAS_BILU_LEAN")) L.lean = atoi(e) != 0;
     if (const char* e = getenv("DAS_BILU_WGS")) L.grid = std::max(1, atoi(e));
-    if (const char* e = getenv("DAS_BILU_NPW")) L.npw = std::max(1, atoi(e));
     if (const char* e = getenv("DAS_BILU_SLEEP")) L.sleepReps = std::max(0, atoi(e));
-    const long long tickets = ((long long)P.nNodes + (long long)waves * L.npw - 1) / ((long long)waves * L.npw);
+    const long long tickets = ((long long)P.nNodes + waves - 1) / waves;
     L.grid = (int)std::min<long long>(L.grid, tickets + 1);
     return L;
 }
@@ -696,12 +688,13 @@ inline void bilu_apply(NodeILU& P, const double* b, double* out, hipStream_t st)
     const long long nslots = (long long)P.nNodes * BILU_NB;
     hipLaunchKernelGGL(k_bilu_reset, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, P.y.p, P.z.p, P.ctrl.p);
     const BiluLaunch L = bilu_launch_shape(P);
-#define DAS_BILU_LAUNCH(VT, LEAN)                                                                                                         \
-    hipLaunchKernelGGL((k_bilu_sweep<VT, false, LEAN>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.npw, L.sleepReps);         \
-    hipLaunchKernelGGL((k_bilu_sweep<VT, true, LEAN>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.npw, L.sleepReps)
-    if (P.fp32) { if (L.lean) { DAS_BILU_LAUNCH(float, true); } else { DAS_BILU_LAUNCH(float, false); } }
-    else { if (L.lean) { DAS_BILU_LAUNCH(double, true); } else { DAS_BILU_LAUNCH(double, false); } }
-#undef DAS_BILU_LAUNCH
+    if (P.fp32) {
+        hipLaunchKernelGGL((k_bilu_sweep<float, false>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.sleepReps);
+        hipLaunchKernelGGL((k_bilu_sweep<float, true>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.sleepReps);
+    } else {
+        hipLaunchKernelGGL((k_bilu_sweep<double, false>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.sleepReps);
+        hipLaunchKernelGGL((k_bilu_sweep<double, true>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.sleepReps);
+    }
 }
 
 // abort flag of the sweeps (set when a bounded spin ran out): checked by the solver at its synchronisation points

@@ -1,4 +1,4 @@
-"""Dev tool (GPU): launch-shape sweep of the node-block ILU sweeps (workgroups in flight, nodes per ticket, poll back-off)
+"""Dev tool (GPU): launch-shape sweep of the node-block ILU sweeps (workgroups in flight, poll back-off)
 on the bench channel, then a full adjoint solve with the best shape.  Prints the PC apply time per configuration."""
 import argparse, itertools, os, sys, time
 import numpy as np
@@ -6,10 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, nargs=3, default=[100, 50, 40])
-ap.add_argument("--wgs", type=int, nargs="+", default=[16, 32, 64, 128, 256, 512, 1024])
-ap.add_argument("--npw", type=int, nargs="+", default=[1, 2, 4])
+ap.add_argument("--wgs", type=int, nargs="+", default=[64, 128, 256, 512, 1024])
 ap.add_argument("--sleep", type=int, nargs="+", default=[0])
-ap.add_argument("--lean", type=int, nargs="+", default=[1, 0])
 ap.add_argument("--fp32", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--solve", type=int, default=1)
@@ -40,19 +38,19 @@ def timed(reps):
         y = ksp.applyPC(D.solver, x)
     ms = L.das_timer_avg_ms(h, b"pc"); L.das_timer_enable(h, 0)
     return ms, y
-KNOBS = ("DAS_BILU_WGS", "DAS_BILU_NPW", "DAS_BILU_SLEEP", "DAS_BILU_LEAN")
+KNOBS = ("DAS_BILU_WGS", "DAS_BILU_SLEEP")
 for k in KNOBS:
     os.environ.pop(k, None)
 ms0, y0 = timed(a.reps)
 print(f"default launch shape: {ms0:.3f} ms", flush=True)
 best = (ms0, None)
-for lean, npw, sl, w in itertools.product(a.lean, a.npw, a.sleep, a.wgs):
-    os.environ["DAS_BILU_WGS"] = str(w); os.environ["DAS_BILU_NPW"] = str(npw); os.environ["DAS_BILU_SLEEP"] = str(sl); os.environ["DAS_BILU_LEAN"] = str(lean)
+for sl, w in itertools.product(a.sleep, a.wgs):
+    os.environ["DAS_BILU_WGS"] = str(w); os.environ["DAS_BILU_SLEEP"] = str(sl)
     ms, y = timed(2 if ms0 > 20 else a.reps)
     ok = np.array_equal(y, y0) or np.linalg.norm(y - y0) <= 1e-10 * np.linalg.norm(y0)
-    print(f"lean {lean} wgs {w:5d} npw {npw} sleep {sl}: {ms:8.3f} ms {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"wgs {w:5d} sleep {sl}: {ms:8.3f} ms {'ok' if ok else 'MISMATCH'}", flush=True)
     if ms < best[0]:
-        best = (ms, (w, npw, sl, lean))
+        best = (ms, (w, sl))
 print("best", best, flush=True)
 for k in KNOBS:
     os.environ.pop(k, None)
