@@ -13,7 +13,7 @@ import numpy as np
 from .meshgen import FoamCase
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdafoam_amd.so")
+LIB_PATH = os.environ.get("DAFOAM_AMD_LIB") or os.path.join(_HERE, "lib", "libdafoam_amd.so")  # (override: tuning builds)
 
 SOLVER_IDS = {"DASimpleFoam": 0, "DAScalarTransportFoam": 1, "DARhoSimpleFoam": 2, "DATurboFoam": 3}
 PATCH_TYPES = {"patch": 0, "wall": 1, "symmetry": 2, "cyclic": 3}

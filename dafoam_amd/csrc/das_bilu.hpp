@@ -43,6 +43,15 @@ constexpr unsigned long long BILU_SENTINEL = 0xFFF7A5A5FFF7A5A5ull;  // a NaN no
 #ifndef BILU_WG
 #define BILU_WG 512  // threads per workgroup of the sweeps (8 wavefronts)
 #endif
+#ifndef BILU_OCC
+#define BILU_OCC 4   // wavefronts per SIMD the sweeps are compiled for (register budget 512 / BILU_OCC)
+#endif
+#ifndef BILU_XCD_TICKETS
+#define BILU_XCD_TICKETS 1  // one ticket counter per XCD (see k_bilu_sweep); 0: one device-wide counter
+#endif
+constexpr int BILU_CTRL_STRIDE = 32;                       // unsigneds per 128-byte line
+constexpr int BILU_CTRL_ABORT = 16 * BILU_CTRL_STRIDE;     // lines 0-7: forward-sweep counters, 8-15: backward, 16: abort flag
+constexpr int BILU_CTRL_SIZE = 17 * BILU_CTRL_STRIDE;
 #ifndef BILU_SPIN_LIMIT
 #define BILU_SPIN_LIMIT (1u << 22)
 #endif
@@ -57,7 +66,7 @@ struct BiluView {
     const double* invD;          // 64 per node, row-major
     double* y;                   // forward-sweep result (also the flags of the forward sweep)
     double* z;                   // backward-sweep result
-    unsigned* ctrl;              // [0],[1] ticket counters, [2] abort flag
+    unsigned* ctrl;              // ticket counters and abort flag, one 128-byte line each (BILU_CTRL_* below)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -69,7 +78,7 @@ __global__ void k_bilu_reset(long long nslots, double* y, double* z, unsigned* c
         reinterpret_cast<unsigned long long*>(y)[i] = BILU_SENTINEL;
         reinterpret_cast<unsigned long long*>(z)[i] = BILU_SENTINEL;
     }
-    if (i < 2) ctrl[i] = 0u;
+    if (i < 16) ctrl[i * BILU_CTRL_STRIDE] = 0u;
 }
 
 __device__ __forceinline__ void bilu_store_sc1(double* p, double v) {
@@ -99,7 +108,7 @@ __device__ __forceinline__ void bilu_load_pair<float>(const float* p, double& a,
 // (Measured and dropped: a lean variant without the prefetch of the next pass - <= 64 VGPRs, 4 workgroups per CU - and
 // several nodes per wave per ticket: both slower at 200 k and at 2 M cells.)
 template <class VT, bool UPPER>
-__global__ __launch_bounds__(BILU_WG, 4) void k_bilu_sweep(BiluView P, const double* __restrict__ b, double* __restrict__ out, int sleepReps) {
+__global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep(BiluView P, const double* __restrict__ b, double* __restrict__ out, int sleepReps) {
     __shared__ unsigned sh_chunk[2];
     constexpr int WAVES = BILU_WG / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,8 +117,23 @@ __global__ __launch_bounds__(BILU_WG, 4) void k_bilu_sweep(BiluView P, const dou
     const int* __restrict__ col = P.col[UPPER ? 1 : 0];
     const VT* __restrict__ val = reinterpret_cast<const VT*>(sizeof(VT) == 4 ? (const void*)P.valf[UPPER ? 1 : 0] : (const void*)P.val[UPPER ? 1 : 0]);
     double* xs = UPPER ? P.z : P.y;
+#if BILU_XCD_TICKETS
+    // Tickets per XCD: a device-wide counter is one address all 8 XCDs increment - an agent-scope atomic executes at the
+    // memory side, ~13 ns apiece, and 290 k tickets per sweep at 2 M cells made the counter the pace of the whole sweep.  Here
+    // XCD x (XCC_ID hardware register) draws local tickets i from its own counter - an atomic that never leaves its L2 - and
+    // solves global ticket 8 i + x.  Still deadlock-free: the lowest unfinished ticket belongs to some XCD, whose resident
+    // workgroups draw their tickets in increasing order and wait only for lower ones.
+    const unsigned xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID[3:0]
+    unsigned* ctr = &P.ctrl[((UPPER ? 8 : 0) + xcd) * BILU_CTRL_STRIDE];
+#else
+    unsigned* ctr = &P.ctrl[(UPPER ? 8 : 0) * BILU_CTRL_STRIDE];
+#endif
     for (unsigned it = 0;; it++) {
-        if (threadIdx.x == 0) sh_chunk[it & 1] = atomicAdd(&P.ctrl[UPPER ? 1 : 0], 1u);
+#if BILU_XCD_TICKETS
+        if (threadIdx.x == 0) sh_chunk[it & 1] = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * 8u + xcd;
+#else
+        if (threadIdx.x == 0) sh_chunk[it & 1] = atomicAdd(ctr, 1u);
+#endif
         __syncthreads();
         const long long q0 = (long long)sh_chunk[it & 1] * WAVES;
         if (q0 >= P.nNodes) return;
@@ -158,9 +182,9 @@ __global__ __launch_bounds__(BILU_WG, 4) void k_bilu_sweep(BiluView P, const dou
                     if (__all(ok)) break;
                     for (int w = 0; w < sleepReps; w++) __builtin_amdgcn_s_sleep(2);
                     if ((++spins & 1023u) == 0u) {  // bounded spin: a stuck sweep sets the abort flag instead of hanging the GPU
-                        const unsigned ab = __hip_atomic_load(&P.ctrl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned ab = __hip_atomic_load(&P.ctrl[BILU_CTRL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (ab != 0u || spins >= BILU_SPIN_LIMIT) {
-                            if (lane == 0) __hip_atomic_store(&P.ctrl[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (lane == 0) __hip_atomic_store(&P.ctrl[BILU_CTRL_ABORT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             return;
                         }
                     }
@@ -649,8 +673,8 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     }
     DAS_HIP(hipGetLastError());
     P.y.alloc((size_t)nN * BILU_NB); P.z.alloc((size_t)nN * BILU_NB);
-    P.ctrl.alloc(4);
-    DAS_HIP(hipMemsetAsync(P.ctrl.p, 0, 4 * sizeof(unsigned), st));
+    P.ctrl.alloc(BILU_CTRL_SIZE);
+    DAS_HIP(hipMemsetAsync(P.ctrl.p, 0, BILU_CTRL_SIZE * sizeof(unsigned), st));
     DAS_HIP(hipStreamSynchronize(st));
     P.t_pack = wall_seconds() - t1;
     P.view.nNodes = nN; P.view.nodeUnk = P.nodeUnk.p;
@@ -674,7 +698,7 @@ inline BiluLaunch bilu_launch_shape(const NodeILU& P) {
     const int waves = BILU_WG / 64;
     const double perLevel = (double)P.nNodes / std::max(1, P.nLevels);
     BiluLaunch L;
-    L.grid = (int)std::min<double>(cus * 4.0, std::max(8.0, P.windowLevels * perLevel / waves));
+    L.grid = (int)std::min<double>(cus * 2.0 * (BILU_OCC * 4 / waves), std::max(8.0, P.windowLevels * perLevel / waves));  // <= 2 x resident
     L.sleepReps = 0;
     if (const char* e = getenv("DAS_BILU_WGS")) L.grid = std::max(1, atoi(e));
     if (const char* e = getenv("DAS_BILU_SLEEP")) L.sleepReps = std::max(0, atoi(e));
@@ -699,10 +723,10 @@ inline void bilu_apply(NodeILU& P, const double* b, double* out, hipStream_t st)
 
 // abort flag of the sweeps (set when a bounded spin ran out): checked by the solver at its synchronisation points
 inline bool bilu_aborted(NodeILU& P, hipStream_t st) {
-    unsigned c[4] = {0, 0, 0, 0};
-    DAS_HIP(hipMemcpyAsync(c, P.ctrl.p, sizeof(c), hipMemcpyDeviceToHost, st));
+    unsigned c = 0u;
+    DAS_HIP(hipMemcpyAsync(&c, P.ctrl.p + BILU_CTRL_ABORT, sizeof(c), hipMemcpyDeviceToHost, st));
     DAS_HIP(hipStreamSynchronize(st));
-    return c[2] != 0u;
+    return c != 0u;
 }
 
 }  // namespace das
