@@ -280,10 +280,13 @@ void Mesh::compute_geometry(const double* y_wall) {
             g.nod = 1.0 / std::max(nd, 0.05 * md);
             for (int k = 0; k < 3; k++) g.corr[k] = g.Sf[k] / g.magSf - d[k] * g.nod;
         } else {
-            double md = 0;
-            for (int k = 0; k < 3; k++) { double dk = g.Cf[k] - Co[k]; md += dk * dk; }
+            // non-coupled patch: fvPatch::delta() is the PATCH-NORMAL part of Cf - Cn (OpenFOAM v1712+, fvPatch.C "Use patch-normal
+            // delta for all non-coupled BCs"), so deltaCoeffs = nonOrthDeltaCoeffs = 1 / |nf . (Cf - Cn)|; identical to 1/|Cf - Cn|
+            // on orthogonal wall cells, different on sheared ones (bump, airfoil)
+            double nd = 0;
+            for (int k = 0; k < 3; k++) nd += g.Sf[k] / g.magSf * (g.Cf[k] - Co[k]);
             g.w = 1.0;
-            g.nod = 1.0 / std::sqrt(md);  // fvPatch::deltaCoeffs() = 1/|Cf - Cn|
+            g.nod = 1.0 / std::fabs(nd);
             g.corr[0] = g.corr[1] = g.corr[2] = 0.0;
         }
     }

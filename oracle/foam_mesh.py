@@ -14,7 +14,7 @@ OpenFOAM's published algorithms:
   * primitiveMesh::makeCellCentresAndVols (pyramid decomposition about the mean
     of face centres),
   * surfaceInterpolation::makeWeights / makeDeltaCoeffs / makeNonOrthDeltaCoeffs /
-    makeNonOrthCorrectionVectors (ESI conventions: fvPatch::delta() = Cf - Cn).
+    makeNonOrthCorrectionVectors (ESI conventions; fvPatch::delta() of a non-coupled patch = nf (nf . (Cf - Cn))).
 """
 from __future__ import annotations
 
@@ -103,8 +103,10 @@ class Geometry:
         self.nonOrthDeltaCoeffs = 1.0 / np.maximum(nd, 0.05 * magd)
         self.nonOrthCorr = self.nf[:nIF] - d * self.nonOrthDeltaCoeffs[:, None]
         # ---- boundary faces ----
+        # fvPatch::delta() of a non-coupled patch is the patch-normal part of Cf - Cn (OpenFOAM v1712+: "Use patch-normal delta for
+        # all non-coupled BCs"): deltaCoeffs = 1 / |nf . (Cf - Cn)|
         db = Cf[nIF:] - self.C[self.bcell]
-        self.bDeltaCoeffs = 1.0 / np.sqrt((db * db).sum(1))
+        self.bDeltaCoeffs = 1.0 / np.abs((self.nf[nIF:] * db).sum(1))
         self.bSf = Sf[nIF:]
         self.bMagSf = self.magSf[nIF:]
         self.bnf = self.nf[nIF:]
