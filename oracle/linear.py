@@ -177,6 +177,67 @@ def gmres(matvec, rhs, pc_solve=None, x0=None, restart=1000, max_iters=1000, rel
     return x, dict(iters=its, res0=res0, res=res, hist=np.array(hist), fail=fail)
 
 
+def gmres_dcgs2(matvec, rhs, pc_solve=None, restart=1000, max_iters=1000, rel_tol=1e-6, abs_tol=1e-14, tol_diff=1e2):
+    """Restatement of the GPU engine's default orthogonalisation (csrc/das_device.hip gmres_iter_dcgs2): right-preconditioned
+    GMRES with classical Gram-Schmidt and DELAYED re-orthogonalisation (Bielich et al. 2022) - per step ONE product
+    [Q u]^T [u v] and ONE update that finishes q_j and produces the once-projected next vector.  Same interface and the
+    same iterates as `gmres` (CGS2); the Hessenberg column of a step is known one step later."""
+    n = rhs.size
+    M = pc_solve if pc_solve is not None else (lambda v: v)
+    x = np.zeros(n)
+    r = rhs.copy()
+    beta = np.linalg.norm(r)
+    res0 = beta
+    hist = [beta]
+    its = 0
+    target = max(rel_tol * res0, abs_tol)
+    done = beta <= target
+    while not done:
+        m = min(restart, max_iters - its)
+        if m <= 0:
+            break
+        Q = np.zeros((m + 2, n))
+        H = np.zeros((m + 1, m))
+        Q[0] = r / beta          # pending vector u, not yet normalised "finally"
+        h1 = np.zeros(0)
+        ncol = 0
+        y = np.zeros(0)
+        for j in range(m + 1):   # step j makes q_j final and completes Hessenberg column j - 1
+            u = Q[j].copy()
+            v = matvec(M(u))
+            QU = Q[: j + 1]
+            su, tv = QU @ u, QU @ v            # the one fused pass: [Q u]^T u, [Q u]^T v
+            s, uu, t, uv = su[:j], su[j], tv[:j], tv[j]
+            al2 = uu - s @ s
+            al = np.sqrt(al2)
+            if j == 0:
+                g0 = beta * al
+            else:
+                H[:j, j - 1] = h1 + s
+                H[j, j - 1] = al
+                ncol = j
+                its += 1
+                e = np.zeros(j + 1)
+                e[0] = g0
+                y, *_ = np.linalg.lstsq(H[: j + 1, :j], e, rcond=None)
+                res = np.linalg.norm(H[: j + 1, :j] @ y - e)
+                hist.append(res)
+                if res <= target or its >= max_iters or j == m:
+                    break
+            gam = (uv - s @ t) / al2
+            Q[j] = (u - s @ Q[:j]) / al        # the one fused update
+            Q[j + 1] = (v - gam * u - (t - gam * s) @ Q[:j]) / al
+            h1 = np.concatenate([(t - H[:j, :j] @ s) / al, [gam - (s[j - 1] if j > 0 else 0.0)]])
+        x = x + M(Q[:ncol].T @ y)
+        r = rhs - matvec(x)
+        beta = np.linalg.norm(r)
+        hist[-1] = beta
+        done = beta <= target or its >= max_iters
+    res = hist[-1]
+    fail = int((res / res0 / rel_tol > tol_diff) and (res / abs_tol > tol_diff)) if res0 > 0 else 0
+    return x, dict(iters=its, res0=res0, res=res, hist=np.array(hist), fail=fail)
+
+
 class ThreadedOperators:
     """Multi-core variant of the CPU baseline (bench.py `cpu_baseline_mt`): the rows are cut into `threads` contiguous
     chunks of equal nnz; the mat-vec runs one chunk per thread (the C kernels release the GIL), the preconditioner is

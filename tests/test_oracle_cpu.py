@@ -132,6 +132,27 @@ def test_oracle_adjoint_small_channel():
     assert abs(ps @ Jv - (A @ ps) @ v) < 1e-10 * abs(ps @ Jv)
 
 
+def test_delayed_reorthogonalisation_restatement_matches_cgs2():
+    """oracle.linear.gmres_dcgs2 - the restatement of the GPU engine's default orthogonalisation (gmres_iter_dcgs2, DCGS2) -
+    gives the iterates of CGS2-GMRES: equal iteration counts, residual histories and solutions, also across restarts."""
+    import scipy.sparse as sp
+
+    nx = 30
+    I, T = sp.identity(nx), sp.diags([-1.0, 2.0, -1.0], [-1, 0, 1], (nx, nx))
+    Cv = sp.diags([-1.0, 1.0], [-1, 1], (nx, nx))
+    A = (sp.kron(I, T) + sp.kron(T, I) + 1.9 * sp.kron(I, Cv) + 0.7 * sp.kron(Cv, I)).tocsr()
+    b = np.random.default_rng(2).standard_normal(nx * nx)
+    pc = OL.ILU(A, fill=0).solve
+    for restart in (400, 12):
+        x1, i1 = OL.gmres(lambda v: A @ v, b, pc, rel_tol=1e-10, restart=restart, max_iters=2000)
+        x2, i2 = OL.gmres_dcgs2(lambda v: A @ v, b, pc, rel_tol=1e-10, restart=restart, max_iters=2000)
+        assert i1["iters"] == i2["iters"] and i1["fail"] == i2["fail"] == 0
+        assert np.all(np.abs(i1["hist"] - i2["hist"]) <= 1e-6 * i1["hist"] + 1e-13 * i1["hist"][0])
+        assert relerr(x2, x1) < 1e-9
+    x, info = OL.gmres_dcgs2(lambda v: A @ v, b, None, rel_tol=1e-14, max_iters=2, restart=2)
+    assert info["fail"] == 1 and info["iters"] == 2
+
+
 def test_golden_fixture_regression():
     """tests/golden/oracle_channel_443.npz is produced by tests/golden/make_golden.py from the oracle (the
     reference cannot be run here); it freezes the oracle against silent edits."""
