@@ -266,6 +266,7 @@ _SIGS = {
     "das_get_elapsed_clock_time": (C.c_double, [_VP]),
     "das_get_elapsed_cpu_time": (C.c_double, [_VP]),
     "das_timer_avg_ms": (C.c_double, [_VP, C.c_char_p]),
+    "das_debug_orth_bench": (C.c_int, [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "das_timer_count": (C.c_longlong, [_VP, C.c_char_p]),
     "das_timer_reset": (None, [_VP]),
     "das_timer_enable": (None, [_VP, C.c_int]),

@@ -371,39 +371,41 @@ __global__ __launch_bounds__(256) void k_multiaxpy(long long n, int m, const dou
 }
 // Two right-hand sides against K basis vectors in ONE pass over the basis (the fused inner products of the delayed
 // re-orthogonalisation, gmres_iter_dcgs2): partial[(r K + i) nbw + slot] = this wave's part of V_i . (r == 0 ? u : v).
-// A thread keeps MD2_ROWS rows of u and v in registers; four basis vectors at a time give 8 sums per lane, which one
+// A thread keeps MD2_ROWS rows of u and v in registers (16: 5.9 TB/s, 8: 5.6, 4: 4.7 on synthetic vectors, tools/orth_bench.py); four basis vectors at a time give 8 sums per lane, which one
 // reduce-scatter over the wave (10 exchanges for 8 sums instead of 48) leaves in the 8 lane groups.
-#define MD2_ROWS 8
+#ifndef MD2_ROWS
+#define MD2_ROWS 16
+#endif
 #define MD2_CHUNK (256 * MD2_ROWS)
-template <bool FULL>
+template <int ROWS, bool FULL>
 __device__ __forceinline__ void multidot2_body(long long n, int K, const double* __restrict__ V, long long ldv, const double* __restrict__ u,
                                                const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
     const int lane = threadIdx.x & 63, g = lane >> 3;
-    const long long base = (long long)blockIdx.x * MD2_CHUNK + threadIdx.x;
+    const long long base = (long long)blockIdx.x * (256 * ROWS) + threadIdx.x;
     const long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    double ur[MD2_ROWS], vr[MD2_ROWS];
+    double ur[ROWS], vr[ROWS];
 #pragma unroll
-    for (int t = 0; t < MD2_ROWS; t++) {
+    for (int t = 0; t < ROWS; t++) {
         const long long k = FULL ? base + 256 * t : min(base + 256 * t, n - 1);  // clamped loads, masked below: no branches
         const double m = (FULL || base + 256 * t < n) ? 1.0 : 0.0;
         ur[t] = m * u[k];
         vr[t] = m * v[k];
     }
     for (int i0 = 0; i0 < K; i0 += 4) {
-        double acc[8], x[4][MD2_ROWS];
-        // all 4 x MD2_ROWS loads are issued before the first use (written as two loops: the scheduler otherwise trades the
+        double acc[8], x[4][ROWS];
+        // all 4 x ROWS loads are issued before the first use (written as two loops: the scheduler otherwise trades the
         // loads in flight for registers and waits after every load)
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             const double* vi = V + (long long)min(i0 + ii, K - 1) * ldv;
 #pragma unroll
-            for (int t = 0; t < MD2_ROWS; t++) x[ii][t] = vi[FULL ? base + 256 * t : min(base + 256 * t, n - 1)];  // ur, vr are zero beyond n
+            for (int t = 0; t < ROWS; t++) x[ii][t] = vi[FULL ? base + 256 * t : min(base + 256 * t, n - 1)];  // ur, vr are zero beyond n
         }
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             double a = 0.0, b = 0.0;
 #pragma unroll
-            for (int t = 0; t < MD2_ROWS; t++) {
+            for (int t = 0; t < ROWS; t++) {
                 a += x[ii][t] * ur[t];
                 b += x[ii][t] * vr[t];
             }
@@ -432,30 +434,54 @@ __device__ __forceinline__ void multidot2_body(long long n, int K, const double*
         if ((lane & 7) == 0 && i < K) partial[((long long)(g & 1) * K + i) * nbw + slot] = a1;
     }
 }
+template <int ROWS>
 __global__ __launch_bounds__(256) void k_multidot2(long long n, int K, const double* __restrict__ V, long long ldv, const double* __restrict__ u,
                                                    const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
-    if ((long long)(blockIdx.x + 1) * MD2_CHUNK <= n) multidot2_body<true>(n, K, V, ldv, u, v, partial, nbw);
-    else multidot2_body<false>(n, K, V, ldv, u, v, partial, nbw);
+    if ((long long)(blockIdx.x + 1) * (256 * ROWS) <= n) multidot2_body<ROWS, true>(n, K, V, ldv, u, v, partial, nbw);
+    else multidot2_body<ROWS, false>(n, K, V, ldv, u, v, partial, nbw);
 }
 // The fused update of the delayed re-orthogonalisation, one pass over the basis: with Q = the j final vectors, u = slot j
 // (projected once), v = the operator applied to u:   q_j = (u - Q s) / alpha  -> slot j,
 //                                                     u' = (v - gamma u - Q c) / alpha -> slot j + 1
+#ifndef DCGS2_UNROLL
+#define DCGS2_UNROLL 4
+#endif
+#ifndef DCGS2_RPT
+#define DCGS2_RPT 2
+#endif
+template <int UNROLL, int RPT>
 __global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, double* __restrict__ V, long long ldv, const double* __restrict__ sc,
                                                       double gamma, double ralpha, const double* __restrict__ v) {
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+    const long long k0 = ((long long)blockIdx.x * RPT) * blockDim.x + threadIdx.x;  // rows k0 + r * blockDim.x
     const double* s = sc;
     const double* c = sc + j;
-    double as = 0.0, ac = 0.0;
-#pragma unroll 8
-    for (int i = 0; i < j; i++) {
-        const double q = V[(long long)i * ldv + k];
-        as += s[i] * q;
-        ac += c[i] * q;
+    double as[RPT], ac[RPT];
+    long long kk[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; r++) { as[r] = 0.0; ac[r] = 0.0; kk[r] = min(k0 + (long long)r * blockDim.x, n - 1); }
+    int i = 0;
+    for (; i + UNROLL <= j; i += UNROLL) {
+        double q[UNROLL][RPT];
+#pragma unroll
+        for (int t = 0; t < UNROLL; t++)
+#pragma unroll
+            for (int r = 0; r < RPT; r++) q[t][r] = V[(long long)(i + t) * ldv + kk[r]];
+#pragma unroll
+        for (int t = 0; t < UNROLL; t++)
+#pragma unroll
+            for (int r = 0; r < RPT; r++) { as[r] += s[i + t] * q[t][r]; ac[r] += c[i + t] * q[t][r]; }
     }
-    const double u = V[(long long)j * ldv + k];
-    V[(long long)j * ldv + k] = (u - as) * ralpha;
-    V[(long long)(j + 1) * ldv + k] = (v[k] - gamma * u - ac) * ralpha;
+    for (; i < j; i++)
+#pragma unroll
+        for (int r = 0; r < RPT; r++) { const double q = V[(long long)i * ldv + kk[r]]; as[r] += s[i] * q; ac[r] += c[i] * q; }
+#pragma unroll
+    for (int r = 0; r < RPT; r++) {
+        const long long k = k0 + (long long)r * blockDim.x;
+        if (k >= n) continue;
+        const double u = V[(long long)j * ldv + k];
+        V[(long long)j * ldv + k] = (u - as[r]) * ralpha;
+        V[(long long)(j + 1) * ldv + k] = (v[k] - gamma * u - ac[r]) * ralpha;
+    }
 }
 // y = sum_i c_i V_i
 __global__ __launch_bounds__(256) void k_lincomb(long long n, int m, const double* __restrict__ V, long long ldv, const double* __restrict__ c,
@@ -2002,7 +2028,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     apply_operator(s, k->z.p, k->w.p);
     const int K = j + 1;
     const long long nbw = 4LL * nblk(n, MD2_CHUNK);
-    hipLaunchKernelGGL(k_multidot2, dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, k->V.p, n, u, k->w.p, k->partial.p, nbw);
+    hipLaunchKernelGGL(k_multidot2<MD2_ROWS>, dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, k->V.p, n, u, k->w.p, k->partial.p, nbw);
     hipLaunchKernelGGL(k_reduce, dim3(2 * K), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
     if (!(s->halo.active && s->halo.allreduce(k->hdev.p, 2 * K, st)) && s->allreduce_cb) s->allreduce_cb(k->hdev.p, 2 * K, s->comm_user);
     std::vector<double>& o = G.hh;
@@ -2038,7 +2064,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     for (int i = 0; i < j; i++) { co[i] = sv[i]; co[j + i] = tv[i] - gam * sv[i]; }
     double* dco = k->hdev.p + 2 * (m + 3);
     if (j > 0) DAS_HIP(hipMemcpyAsync(dco, co.data(), 2 * j * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_dcgs2_update, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, k->V.p, n, dco, gam, 1.0 / al, k->w.p);
+    hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, k->V.p, n, dco, gam, 1.0 / al, k->w.p);
     // first-projection coefficients of the new pending vector: (t - H_jj s) / alpha, gamma - s_{j-1}
     for (int i = 0; i < j; i++) {
         double a = tv[i];
@@ -2440,6 +2466,16 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
 // =====================================================================================================
 // C-ABI
 // =====================================================================================================
+// launch helpers of the tuning hook das_debug_orth_bench (templates cannot sit inside the extern "C" block)
+template <int ROWS>
+static void orth_bench_dots(long long n, int K, const double* V, const double* w, double* partial) {
+    hipLaunchKernelGGL(k_multidot2<ROWS>, dim3(nblk(n, 256 * ROWS)), dim3(256), 0, 0, n, K, V, n, V + (long long)(K - 1) * n, w, partial, 4LL * nblk(n, 256 * ROWS));
+}
+template <int UNROLL, int RPT>
+static void orth_bench_update(long long n, int j, double* V, const double* sc, const double* w) {
+    hipLaunchKernelGGL((k_dcgs2_update<UNROLL, RPT>), dim3(nblk(n, 256 * RPT)), dim3(256), 0, 0, n, j, V, n, sc, 0.5, 1.0, w);
+}
+
 extern "C" {
 
 const char* das_last_error(void) { return g_err.c_str(); }
@@ -3414,6 +3450,39 @@ int das_set_stream(das_solver_t* s, void* hip_stream) {
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     s->stream = (hipStream_t)hip_stream;
     s->own_stream = false;
+    return DAS_OK;
+    DAS_CATCH
+}
+
+// Tuning hook (tools/orth_bench.py): times the two kernels of the delayed re-orthogonalisation on synthetic vectors of length n
+// against K basis vectors, for the compiled variants (rows per thread of the inner products; unroll / rows per thread of
+// the update).  No solver handle: it only needs the device.
+int das_debug_orth_bench(long long n, int K, int reps, int rows, int unroll, int rpt, double* ms_dots, double* ms_update) {
+    DAS_TRY
+    DAS_CHECK(n > 0 && K > 1 && reps > 0 && ms_dots && ms_update, DAS_ERR_ARG, "das_debug_orth_bench: bad arguments");
+    DevBuf<double> V((size_t)(K + 2) * n), w(n), partial((size_t)2 * K * 4 * nblk(n, 256 * 4)), sc(2 * (size_t)K);
+    V.zero(); w.zero(); sc.zero();
+    hipEvent_t e0, e1;
+    DAS_HIP(hipEventCreate(&e0)); DAS_HIP(hipEventCreate(&e1));
+    auto timed = [&](auto&& launch) {
+        launch();  // warm-up
+        DAS_HIP(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; r++) launch();
+        DAS_HIP(hipEventRecord(e1, 0));
+        DAS_HIP(hipEventSynchronize(e1));
+        DAS_HIP(hipGetLastError());
+        float ms = 0.f;
+        DAS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return (double)ms / reps;
+    };
+    *ms_dots = -1.0; *ms_update = -1.0;
+    if (rows == 4) *ms_dots = timed([&] { orth_bench_dots<4>(n, K, V.p, w.p, partial.p); });
+    else if (rows == 8) *ms_dots = timed([&] { orth_bench_dots<8>(n, K, V.p, w.p, partial.p); });
+    else if (rows == 16) *ms_dots = timed([&] { orth_bench_dots<16>(n, K, V.p, w.p, partial.p); });
+#define DAS_UPD(U, R) if (unroll == U && rpt == R) *ms_update = timed([&] { orth_bench_update<U, R>(n, K - 1, V.p, sc.p, w.p); })
+    DAS_UPD(4, 1); DAS_UPD(8, 1); DAS_UPD(16, 1); DAS_UPD(4, 2); DAS_UPD(8, 2); DAS_UPD(4, 4); DAS_UPD(8, 4);
+#undef DAS_UPD
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     return DAS_OK;
     DAS_CATCH
 }

@@ -348,6 +348,10 @@ double das_get_elapsed_cpu_time(das_solver_t* s);
 /* average duration [ms] of the named kernel family measured with HIP events on the launch stream since
  * the last reset: "spmv", "pc", "residual" ; returns <0 if never launched */
 double das_timer_avg_ms(das_solver_t* s, const char* name);
+/* tuning hook (tools/orth_bench.py): average ms of the two kernels of the delayed re-orthogonalisation (inner products with
+ * `rows` rows per thread; update with `unroll` basis vectors in flight and `rpt` rows per thread) on synthetic vectors of
+ * length n against K basis vectors; -1 for a variant that is not compiled in */
+int das_debug_orth_bench(long long n, int K, int reps, int rows, int unroll, int rpt, double* ms_dots, double* ms_update);
 long long das_timer_count(das_solver_t* s, const char* name);
 void das_timer_reset(das_solver_t* s);
 void das_timer_enable(das_solver_t* s, int on);
