@@ -2039,7 +2039,24 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     const double uu = sv[j], uv = tv[j];
     double ss = 0.0, stt = 0.0;
     for (int i = 0; i < j; i++) { ss += sv[i] * sv[i]; stt += sv[i] * tv[i]; }
-    const double al2 = uu - ss;
+    double al2 = uu - ss, num = uv - stt;  // |u - Q s|^2 and (u - Q s).v by Pythagoras - accurate while s is small against u
+    bool explicitProj = false;
+    if (j > 0 && !(ss <= 1e-2 * uu)) {
+        // the first projection left a large component in span(Q): u is (nearly) rounding noise - the Krylov space is exhausted or
+        // orthogonality was lost - and uu - s.s cancels.  Rare; pay one extra pass: c = u - Q s explicitly, then c.c and c.v
+        double* dsc = k->hdev.p + 2 * (m + 3);
+        DAS_HIP(hipMemcpyAsync(dsc, sv, j * sizeof(double), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, k->V.p, n, dsc, u);
+        hipLaunchKernelGGL(k_multidot2<MD2_ROWS>, dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, 1, u, n, u, k->w.p, k->partial.p, nbw);
+        hipLaunchKernelGGL(k_reduce, dim3(2), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
+        if (!(s->halo.active && s->halo.allreduce(k->hdev.p, 2, st)) && s->allreduce_cb) s->allreduce_cb(k->hdev.p, 2, s->comm_user);
+        double cc[2] = {0.0, 0.0};
+        DAS_HIP(hipMemcpyAsync(cc, k->hdev.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+        DAS_HIP(hipStreamSynchronize(st));
+        al2 = cc[0]; num = cc[1];
+        explicitProj = true;
+        k->nrefine++;
+    }
     const bool breakdown = !(al2 > 0.0);
     const double al = breakdown ? 0.0 : std::sqrt(al2);
     double res = k->hist.back();
@@ -2053,15 +2070,18 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
         G.its++;
         G.j = j;
         k->hist.push_back(res);
-        if (breakdown) { G.j = -G.j; return res; }  // happy breakdown: close the cycle (sign marks it)
+        // happy breakdown, or the explicit projection above (Krylov space exhausted / orthogonality lost: the lagged recurrence
+        // below would divide by a noise-level alpha): close the cycle (sign marks it), restart from the true residual
+        if (breakdown || explicitProj) { G.j = -G.j; return res; }
         const bool stop = !G.fixed && (res <= G.target || G.its >= G.maxIts);
         if (stop || G.j >= m) return res;            // the cycle is closed by the caller: no further basis vector needed
     }
     DAS_CHECK(!breakdown, DAS_ERR_INTERNAL, "GMRES: the initial residual vanished inside the Arnoldi process");
-    const double gam = (uv - stt) / al2;
-    // coefficients of the fused update: s, then c = t - gamma s
+    const double gam = num / al2;
+    // coefficients of the fused update: s, then c = t - gamma s  (u already holds u - Q s after an explicit projection:
+    // then q_j = u / alpha and u' = (v - gamma u - Q t) / alpha)
     std::vector<double>& co = G.h2;
-    for (int i = 0; i < j; i++) { co[i] = sv[i]; co[j + i] = tv[i] - gam * sv[i]; }
+    for (int i = 0; i < j; i++) { co[i] = explicitProj ? 0.0 : sv[i]; co[j + i] = explicitProj ? tv[i] : tv[i] - gam * sv[i]; }
     double* dco = k->hdev.p + 2 * (m + 3);
     if (j > 0) DAS_HIP(hipMemcpyAsync(dco, co.data(), 2 * j * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, k->V.p, n, dco, gam, 1.0 / al, k->w.p);

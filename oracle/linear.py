@@ -208,7 +208,11 @@ def gmres_dcgs2(matvec, rhs, pc_solve=None, restart=1000, max_iters=1000, rel_to
             QU = Q[: j + 1]
             su, tv = QU @ u, QU @ v            # the one fused pass: [Q u]^T u, [Q u]^T v
             s, uu, t, uv = su[:j], su[j], tv[:j], tv[j]
-            al2 = uu - s @ s
+            al2, num = uu - s @ s, uv - s @ t
+            explicit = j > 0 and not (s @ s <= 1e-2 * uu)
+            if explicit:  # u is (nearly) noise in span(Q): Pythagoras cancels - project explicitly (same rule as the GPU engine)
+                u = u - s @ Q[:j]
+                al2, num = u @ u, u @ v
             al = np.sqrt(al2)
             if j == 0:
                 g0 = beta * al
@@ -222,11 +226,16 @@ def gmres_dcgs2(matvec, rhs, pc_solve=None, restart=1000, max_iters=1000, rel_to
                 y, *_ = np.linalg.lstsq(H[: j + 1, :j], e, rcond=None)
                 res = np.linalg.norm(H[: j + 1, :j] @ y - e)
                 hist.append(res)
-                if res <= target or its >= max_iters or j == m:
-                    break
-            gam = (uv - s @ t) / al2
-            Q[j] = (u - s @ Q[:j]) / al        # the one fused update
-            Q[j + 1] = (v - gam * u - (t - gam * s) @ Q[:j]) / al
+                if res <= target or its >= max_iters or j == m or explicit:
+                    break  # (explicit: the Krylov space is exhausted / orthogonality lost - the lagged recurrence would divide by a
+                           #  noise-level alpha; close the cycle and restart from the true residual)
+            gam = num / al2
+            if explicit:
+                Q[j] = u / al
+                Q[j + 1] = (v - gam * u - t @ Q[:j]) / al
+            else:
+                Q[j] = (u - s @ Q[:j]) / al        # the one fused update
+                Q[j + 1] = (v - gam * u - (t - gam * s) @ Q[:j]) / al
             h1 = np.concatenate([(t - H[:j, :j] @ s) / al, [gam - (s[j - 1] if j > 0 else 0.0)]])
         x = x + M(Q[:ncol].T @ y)
         r = rhs - matvec(x)

@@ -151,6 +151,13 @@ def test_delayed_reorthogonalisation_restatement_matches_cgs2():
         assert relerr(x2, x1) < 1e-9
     x, info = OL.gmres_dcgs2(lambda v: A @ v, b, None, rel_tol=1e-14, max_iters=2, restart=2)
     assert info["fail"] == 1 and info["iters"] == 2
+    # past the exhaustion of the Krylov space (more iterations than unknowns, unreachable tolerance) the pending vector is
+    # rounding noise: the explicit projection + restart rule keeps the solution at the attainable accuracy
+    n = 12
+    B = np.diag(np.arange(1.0, n + 1)) + 0.3 * np.random.default_rng(5).standard_normal((n, n))
+    c = np.random.default_rng(6).standard_normal(n)
+    x, info = OL.gmres_dcgs2(lambda v: B @ v, c, None, rel_tol=1e-30, abs_tol=1e-300, restart=1000, max_iters=60)
+    assert info["iters"] == 60 and relerr(x, np.linalg.solve(B, c)) < 1e-12
 
 
 def test_golden_fixture_regression():
