@@ -296,7 +296,8 @@ int das_ksp_get_pc_structure_sizes(das_ksp_t* ksp, int* nNodes, long long* nBloc
 int das_ksp_get_pc_structure(das_ksp_t* ksp, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural);
 int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, double* seconds);
 int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
-/* number of Gram-Schmidt refinement passes of the last solve (KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160) */
+/* number of Gram-Schmidt refinement passes of the last solve (KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160); with
+ * amd.gmresOrthogonalization "dcgs2": the number of explicit projections (exhausted Krylov space / lost orthogonality) */
 int das_ksp_get_n_refine(das_ksp_t* ksp);
 /* two-level preconditioner (amd.pcCoarseAggregates / pcCoarseField / pcCoarseMode): number of aggregates of the
  * piecewise-constant pressure coarse space (0 = none) and, optionally, the aggregate of every cell (-1 = not owned) */
