@@ -182,7 +182,19 @@ def write_polymesh(case_dir, mesh: PolyMesh):
                     Q = np.asarray(p.rotation, dtype=np.float64).reshape(3, 3)
                     ax = np.array([Q[2, 1] - Q[1, 2], Q[0, 2] - Q[2, 0], Q[1, 0] - Q[0, 1]])
                     ax = ax / np.linalg.norm(ax) if np.linalg.norm(ax) > 0 else np.array([1.0, 0.0, 0.0])
-                    extra += "        transform       rotational;\n        rotationAxis    (%.17g %.17g %.17g);\n        rotationCentre  (0 0 0);\n" % tuple(np.abs(ax))
+                    if ax[np.argmax(np.abs(ax) > 1e-12)] < 0:
+                        ax = -ax  # one sign for both patches of the pair (the reader takes the angle's sign from the face pair)
+
+                    def fcr(f):
+                        return mesh.points[mesh.face_pts[mesh.face_ptr[f] : mesh.face_ptr[f + 1]]].mean(0)
+
+                    # a point on the axis: a - c = Q (b - c) for the first face pair (a this side, b the neighbour side);
+                    # I - Q is singular along the axis, the least-squares solution is the axis point nearest the origin
+                    a, b = fcr(p.start), fcr(by_name[p.neighbour].start)
+                    cen = np.linalg.lstsq(np.eye(3) - Q, a - Q @ b, rcond=None)[0]
+                    cen[np.abs(cen) < 1e-14 * max(1.0, np.abs(mesh.points).max())] = 0.0
+                    extra += ("        transform       rotational;\n        rotationAxis    (%.17g %.17g %.17g);\n        rotationCentre  (%.17g %.17g %.17g);\n"
+                              % (tuple(ax) + tuple(cen)))
                 else:
                     def fc(f):
                         return mesh.points[mesh.face_pts[mesh.face_ptr[f] : mesh.face_ptr[f + 1]]].mean(0)

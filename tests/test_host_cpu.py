@@ -278,6 +278,32 @@ def test_openfoam_boundary_cyclic_roundtrip(tmp_path, sector):
             assert np.abs(p0.rotation - p1.rotation).max() < 1e-14
 
 
+def test_openfoam_rotational_cyclic_off_origin_mixed_sign_axis(tmp_path):
+    """A rotational cyclic pair whose axis has mixed-sign components and does not pass through the origin (a rigidly moved
+    sector): rotationAxis / rotationCentre written by write_polymesh reproduce forwardT on reading."""
+    from dafoam_amd import foam_io
+
+    c = periodic_channel_case(4, 3, 4, sector=(0.5, 0.12))
+    a = np.array([0.2, -0.1, 1.0]); a /= np.linalg.norm(a)
+    th = 2.2
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R0 = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+    c.mesh.points = c.mesh.points @ R0.T + np.array([0.3, -1.1, 2.0])
+    for p in c.mesh.patches:
+        if p.rotation is not None:
+            p.rotation = R0 @ np.asarray(p.rotation).reshape(3, 3) @ R0.T
+    foam_io.write_polymesh(str(tmp_path), c.mesh)
+    txt = open(tmp_path / "constant" / "polyMesh" / "boundary").read()
+    axis = np.array(re.search(r"rotationAxis\s+\(([^)]*)\)", txt).group(1).split(), dtype=float)
+    assert (axis < -1e-6).any() and (axis > 1e-6).any()                      # the sign pattern survives
+    centre = np.array(re.search(r"rotationCentre\s+\(([^)]*)\)", txt).group(1).split(), dtype=float)
+    assert np.linalg.norm(centre) > 0.1
+    m = foam_io.read_polymesh(str(tmp_path))
+    for p0, p1 in zip(c.mesh.patches, m.patches):
+        if p0.rotation is not None:
+            assert np.abs(np.asarray(p0.rotation).reshape(3, 3) - p1.rotation).max() < 1e-12
+
+
 def test_update_of_mesh_recomputes_metrics():
     """updateOFMesh (reference pyDASolvers.pyx:297-300): the library's fvMesh metrics after moving the points equal the
     oracle's geometry of the moved mesh; the wall distance stays frozen; getOFMeshPoints returns the new points."""
