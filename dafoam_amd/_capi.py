@@ -261,6 +261,7 @@ _SIGS = {
     "das_comm_set_halo": (C.c_int, [_VP, C.c_int, c_int_p, c_ll_p, c_int_p, c_ll_p, c_int_p, C.c_longlong, c_int_p]),
     "das_set_exchange_cb": (C.c_int, [_VP, _VP, _VP]),
     "das_comm_is_native": (C.c_int, [_VP]),
+    "das_comm_reset": (C.c_int, [_VP]),
     "das_set_comm": (C.c_int, [_VP, _VP, _VP, _VP]),
     "das_set_stream": (C.c_int, [_VP, _VP]),
     "das_get_elapsed_clock_time": (C.c_double, [_VP]),

@@ -3463,6 +3463,14 @@ int das_comm_set_halo(das_solver_t* s, int npeers, const int* peers, const long 
     DAS_CATCH
 }
 int das_comm_is_native(das_solver_t* s) { return (s && s->halo.comm) ? 1 : 0; }
+// drop a native communicator again (the ranks agreed to use the callback transport instead)
+int das_comm_reset(das_solver_t* s) {
+    DAS_TRY
+    DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
+    if (s->halo.comm) { (void)rccl().CommDestroy(s->halo.comm); s->halo.comm = nullptr; }
+    return DAS_OK;
+    DAS_CATCH
+}
 
 int das_set_stream(das_solver_t* s, void* hip_stream) {
     DAS_TRY

@@ -18,6 +18,8 @@ The partition implemented here is a slab decomposition along x of the structured
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
@@ -170,14 +172,28 @@ def install_comm(obj, native=None):
     ghostIdx = halo.ghost_idx.cpu().numpy().astype(np.int32)
     peers_a = np.asarray(peers, dtype=np.int32)
     ip, lp = _capi.c_int_p, _capi.c_ll_p
+    if os.environ.get("DAFOAM_AMD_COMM", "") == "torch":
+        native = False  # force the callback transport (torch.distributed issues the same RCCL calls)
     if native:
+        # every rank must end up on the same transport: a failure of the native set-up anywhere (RCCL not loadable, communicator
+        # not created) is agreed on through the torch backend and all ranks fall back to the callback transport together
         ident = [None]
         if obj.rank == 0:
             buf = C.create_string_buffer(128)
-            _capi.check(L.das_comm_unique_id(buf))
-            ident[0] = buf.raw
+            if L.das_comm_unique_id(buf) == 0:
+                ident[0] = buf.raw
         dist.broadcast_object_list(ident, src=0)
-        _capi.check(L.das_comm_init_rccl(h, obj.rank, obj.world, ident[0]))
+        ok = 0
+        if ident[0] is not None:
+            ok = 1 if L.das_comm_init_rccl(h, obj.rank, obj.world, ident[0]) == 0 else 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=obj.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if obj.rank == 0:
+                print("[dafoam_amd] native RCCL transport unavailable (%s); using the torch.distributed callback transport"
+                      % L.das_last_error().decode(), file=sys.stderr, flush=True)
+            _capi.check(L.das_comm_reset(h))
+            native = False
     _capi.check(L.das_comm_set_halo(h, len(peers), peers_a.ctypes.data_as(ip), sendOff.ctypes.data_as(lp), sendIdx.ctypes.data_as(ip),
                                     recvOff.ctypes.data_as(lp), recvIdx.ctypes.data_as(ip), int(ghostIdx.size), ghostIdx.ctypes.data_as(ip)))
     obj._comm_native = bool(native)

@@ -341,6 +341,8 @@ int das_comm_set_halo(das_solver_t* s, int npeers, const int* peers, const long 
                       const int* recvIdx, long long nGhost, const int* ghostIdx);
 int das_set_exchange_cb(das_solver_t* s, das_exchange_cb cb, void* user);
 int das_comm_is_native(das_solver_t* s);
+/* drop the native communicator again (all ranks fall back to the callback transport together) */
+int das_comm_reset(das_solver_t* s);
 int das_set_stream(das_solver_t* s, void* hip_stream);
 
 /* ---- timing (getElapsedClockTime/getElapsedCpuTime pyDASolvers.pyx:332-336) and kernel timers */
