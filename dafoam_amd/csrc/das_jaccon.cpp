@@ -184,7 +184,7 @@ void JacCon::build(const Mesh& m, const Stencil& st) {
     struct Item { int block; int ent; long long row0; };
     // chunks of entities per block, processed in parallel, concatenated in order
     const int nthreads = std::max(1, omp_get_max_threads());
-    struct Chunk { int block; int e0, e1; long long row0; std::vector<int> col; std::vector<int> rowlen; };
+    struct Chunk { int block; int e0, e1; long long row0; uvector<int> col; std::vector<int> rowlen; };
     std::vector<Chunk> chunks;
     {
         long long r = 0;
@@ -254,7 +254,7 @@ void JacCon::build(const Mesh& m, const Stencil& st) {
             std::copy(ch.col.begin(), ch.col.end(), col.begin() + choff[ci]);
             long long o = choff[ci];
             for (size_t k = 0; k < ch.rowlen.size(); k++) { rowptr[ch.row0 + (long long)k] = o; o += ch.rowlen[k]; }
-            std::vector<int>().swap(ch.col);
+            uvector<int>().swap(ch.col);
         }
     }
     rowptr[n] = total;
@@ -306,10 +306,11 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 16LL, nk}));
         std::vector<long long> q0(T + 1);
         for (int t = 0; t <= T; t++) q0[t] = nk * t / T;
-        std::vector<std::vector<int>> cnt(T);
+        std::vector<uvector<int>> cnt(T);
 #pragma omp parallel for schedule(static, 1) num_threads(T)
         for (int t = 0; t < T; t++) {
-            cnt[t].assign(n, 0);
+            cnt[t].resize(n);
+            std::fill(cnt[t].begin(), cnt[t].end(), 0);
             for (long long q = q0[t]; q < q0[t + 1]; q++)
                 for (long long k = con.rowptr[keep[q]]; k < con.rowptr[keep[q] + 1]; k++) cnt[t][con.col[k]]++;
         }
@@ -326,7 +327,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         crow.resize(cptr[n]);
 #pragma omp parallel for schedule(static, 1) num_threads(T)
         for (int t = 0; t < T; t++) {
-            std::vector<int>& pos = cnt[t];
+            uvector<int>& pos = cnt[t];
             for (long long q = q0[t]; q < q0[t + 1]; q++) {
                 const long long r = keep[q];
                 for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) { const int j = con.col[k]; crow[cptr[j] + pos[j]++] = (int)r; }
@@ -562,10 +563,11 @@ void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
     const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 16LL, n}));
     std::vector<long long> r0(T + 1);
     for (int t = 0; t <= T; t++) r0[t] = n * t / T;
-    std::vector<std::vector<int>> cnt(T);
+    std::vector<uvector<int>> cnt(T);
 #pragma omp parallel for schedule(static, 1) num_threads(T)
     for (int t = 0; t < T; t++) {
-        cnt[t].assign(n, 0);
+        cnt[t].resize(n);
+        std::fill(cnt[t].begin(), cnt[t].end(), 0);
         for (long long k = rowptr[r0[t]]; k < rowptr[r0[t + 1]]; k++) cnt[t][col[k]]++;
     }
     lap("count");
@@ -586,7 +588,7 @@ void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
     lap("alloc");
 #pragma omp parallel for schedule(static, 1) num_threads(T)
     for (int t = 0; t < T; t++) {
-        std::vector<int>& pos = cnt[t];
+        uvector<int>& pos = cnt[t];
         for (long long r = r0[t]; r < r0[t + 1]; r++)
             for (long long k = rowptr[r]; k < rowptr[r + 1]; k++) {
                 const int j = col[k];
