@@ -796,3 +796,43 @@ def test_pc_node_structure_levels_and_pattern():
     late = nat >= nPrimary
     missing = [(a, b) for a, b in set(zip(node_of[con.row].tolist(), node_of[con.col].tolist())) if (a, b) not in have]
     assert all(late[a] and late[b] for a, b in missing)
+
+
+def test_amd_option_defaults_and_profile_helpers(tmp_path):
+    """The MI355X-specific option table (mirror and library agree on the defaults that select the measured code paths), and
+    the two host helpers around the PMC evidence: tools/pmc_summary.py and bench.pmc_traffic."""
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+
+    from dafoam_amd.pyDAFoam import DAOPTION
+
+    d = DAOPTION()
+    assert d.amd["gmresOrthogonalization"] == "dcgs2" and d.amd["pcType"] == "bilu" and d.amd["pcCoarseMode"] == "additive"
+    case = channel_case(4, 4, 3)
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    buf = C.create_string_buffer(64)
+    if hasattr(_capi.lib(), "das_get_option_string"):
+        _capi.check(_capi.lib().das_get_option_string(s._h, b"amd.gmresOrthogonalization", buf, 64))
+        assert buf.value == b"dcgs2"
+    # pmc_summary: two passes (one counter each), KB units, bytes = 2 x FETCH + WRITE
+    for ctr, vals in (("FETCH_SIZE", (1000.0, 3000.0)), ("WRITE_SIZE", (100.0, 300.0))):
+        dd = tmp_path / ctr / "host" / "1"
+        dd.mkdir(parents=True)
+        with open(dd / "pmc_counter_collection.csv", "w") as f:
+            f.write('"Correlation_Id","Kernel_Name","Counter_Name","Counter_Value"\n')
+            for i, v in enumerate(vals):
+                f.write(f'{i},"k_a","{ctr}",{v}\n')
+            f.write(f'9,"k_b","{ctr}",5.0\n')
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), str(tmp_path / "FETCH_SIZE"), str(tmp_path / "WRITE_SIZE")])
+    summ = json.loads(out)
+    assert summ["k_a"]["FETCH_SIZE_KB_avg"] == 2000.0 and summ["k_a"]["launches_WRITE_SIZE"] == 2
+    assert summ["k_a"]["hbm_bytes_per_launch_corrected"] == (2 * 2000.0 + 200.0) * 1024.0
+    # bench.pmc_traffic: the committed passes are reported only for the workload they were taken on
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t = bench.pmc_traffic(2091189176, "k_spmv_wave")
+    assert t is not None and 2.5e10 < t < 4.5e10
+    assert bench.pmc_traffic(12345, "k_spmv_wave") is None and bench.pmc_traffic(2091189176, "no_such_kernel") is None
