@@ -303,7 +303,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
     uvector<int> crow;
     {
         const long long nk = (long long)keep.size();
-        const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 16LL, nk}));
+        const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 32LL, nk}));
         std::vector<long long> q0(T + 1);
         for (int t = 0; t <= T; t++) q0[t] = nk * t / T;
         std::vector<uvector<int>> cnt(T);
@@ -560,7 +560,7 @@ void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
     const bool dbg = getenv("DAS_DEBUG_TIMING") != nullptr;
     double tt = wall_seconds();
     auto lap = [&](const char* what) { if (dbg) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]   maps: %s %.2f s\n", what, t2 - tt); tt = t2; } };
-    const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 16LL, n}));
+    const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 32LL, n}));
     std::vector<long long> r0(T + 1);
     for (int t = 0; t <= T; t++) r0[t] = n * t / T;
     std::vector<uvector<int>> cnt(T);
