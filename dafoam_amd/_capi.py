@@ -249,6 +249,7 @@ _SIGS = {
     "das_ksp_get_info": (C.c_int, [_VP, c_int_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_get_history": (C.c_int, [_VP, c_double_p, C.c_int]),
     "das_ksp_get_n_refine": (C.c_int, [_VP]),
+    "das_ksp_get_status": (C.c_int, [_VP, c_int_p, c_int_p, c_int_p, c_int_p]),
     "das_ksp_get_coarse": (C.c_int, [_VP, c_int_p]),
     "das_ksp_run_fixed_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),
     "das_ksp_begin_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),
@@ -256,6 +257,7 @@ _SIGS = {
     "das_ksp_end": (C.c_int, [_VP, _VP]),
     "das_ksp_destroy": (None, [_VP]),
     "das_set_owned_mask": (C.c_int, [_VP, C.POINTER(C.c_ubyte)]),
+    "das_comm_load_rccl": (C.c_int, []),
     "das_comm_unique_id": (C.c_int, [C.c_char_p]),
     "das_comm_init_rccl": (C.c_int, [_VP, C.c_int, C.c_int, C.c_char_p]),
     "das_comm_set_halo": (C.c_int, [_VP, C.c_int, c_int_p, c_ll_p, c_int_p, c_ll_p, c_int_p, C.c_longlong, c_int_p]),

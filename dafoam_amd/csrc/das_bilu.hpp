@@ -47,7 +47,7 @@ constexpr unsigned long long BILU_SENTINEL = 0xFFF7A5A5FFF7A5A5ull;  // a NaN no
 #define BILU_OCC 4   // wavefronts per SIMD the sweeps are compiled for (register budget 512 / BILU_OCC)
 #endif
 #ifndef BILU_XCD_TICKETS
-#define BILU_XCD_TICKETS 1  // one ticket counter per XCD (see k_bilu_sweep); 0: one device-wide counter
+#define BILU_XCD_TICKETS 1  // allow one ticket counter per XCD (see k_bilu_sweep) where the host finds it safe; 0: always one device-wide counter
 #endif
 constexpr int BILU_CTRL_STRIDE = 32;                       // unsigneds per 128-byte line
 constexpr int BILU_CTRL_ABORT = 16 * BILU_CTRL_STRIDE;     // lines 0-7: forward-sweep counters, 8-15: backward, 16: abort flag
@@ -108,7 +108,8 @@ __device__ __forceinline__ void bilu_load_pair<float>(const float* p, double& a,
 // (Measured and dropped: a lean variant without the prefetch of the next pass - <= 64 VGPRs, 4 workgroups per CU - and
 // several nodes per wave per ticket: both slower at 200 k and at 2 M cells.)
 template <class VT, bool UPPER>
-__global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep(BiluView P, const double* __restrict__ b, double* __restrict__ out, int sleepReps) {
+__global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep(BiluView P, const double* __restrict__ b, double* __restrict__ out, int sleepReps,
+                                                                   int perXcd) {
     __shared__ unsigned sh_chunk[2];
     constexpr int WAVES = BILU_WG / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -117,23 +118,23 @@ __global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep(BiluView P, co
     const int* __restrict__ col = P.col[UPPER ? 1 : 0];
     const VT* __restrict__ val = reinterpret_cast<const VT*>(sizeof(VT) == 4 ? (const void*)P.valf[UPPER ? 1 : 0] : (const void*)P.val[UPPER ? 1 : 0]);
     double* xs = UPPER ? P.z : P.y;
-#if BILU_XCD_TICKETS
-    // Tickets per XCD: a device-wide counter is one address all 8 XCDs increment - an agent-scope atomic executes at the
-    // memory side, ~13 ns apiece, and 290 k tickets per sweep at 2 M cells made the counter the pace of the whole sweep.  Here
-    // XCD x (XCC_ID hardware register) draws local tickets i from its own counter - an atomic that never leaves its L2 - and
-    // solves global ticket 8 i + x.  Still deadlock-free: the lowest unfinished ticket belongs to some XCD, whose resident
-    // workgroups draw their tickets in increasing order and wait only for lower ones.
-    const unsigned xcd = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;  // HW_REG_XCC_ID[3:0]
+    // Tickets per XCD (perXcd != 0): a device-wide counter is one address all 8 XCDs increment - an agent-scope atomic executes
+    // at the memory side, ~13 ns apiece, and 290 k tickets per sweep at 2 M cells made the counter the pace of the whole sweep.
+    // Here XCD x (XCC_ID hardware register) draws local tickets i from its own counter and solves global ticket 8 i + x.  The
+    // counter of an XCD is only ever touched by workgroups of that XCD, and gfx9 executes global atomics in the (per-XCD) L2:
+    // a workgroup-scope atomic is therefore coherent among exactly the workgroups that use it and never leaves that L2.
+    // Still deadlock-free: the lowest unfinished ticket belongs to some XCD, whose workgroups draw their tickets in
+    // increasing order and wait only for lower ones.  COMPLETE only if every one of the 8 XCDs runs at least one workgroup
+    // of the launch: the host enables the mode only after bilu_xcd_probe() has seen XCC ids 0..7 on this device AND for
+    // grids of >= 8 workgroups per XCD (workgroups are dealt round-robin to the XCDs); every other launch - small meshes,
+    // partitioned (CPX/DPX/QPX) devices, other parts - takes the device-wide counter (the 2-workgroup
+    // launches of the 1- and 2-cell test meshes used to land on two arbitrary XCDs and solve nothing when neither was XCD 0).
+    const unsigned xcd = perXcd ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0u;  // HW_REG_XCC_ID[3:0]
     unsigned* ctr = &P.ctrl[((UPPER ? 8 : 0) + xcd) * BILU_CTRL_STRIDE];
-#else
-    unsigned* ctr = &P.ctrl[(UPPER ? 8 : 0) * BILU_CTRL_STRIDE];
-#endif
     for (unsigned it = 0;; it++) {
-#if BILU_XCD_TICKETS
-        if (threadIdx.x == 0) sh_chunk[it & 1] = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * 8u + xcd;
-#else
-        if (threadIdx.x == 0) sh_chunk[it & 1] = atomicAdd(ctr, 1u);
-#endif
+        if (threadIdx.x == 0)
+            sh_chunk[it & 1] = perXcd ? __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * 8u + xcd
+                                      : __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const long long q0 = (long long)sh_chunk[it & 1] * WAVES;
         if (q0 >= P.nNodes) return;
@@ -384,6 +385,7 @@ struct NodeILU {
     long long nnzB = 0, nL = 0, nU = 0;
     bool fp32 = false;
     double windowLevels = 3.0;  // levels kept in flight by the sweeps (launch shape; measured optimum at 200 k cells)
+    int launchGrid = 0, launchSleep = 0, launchPerXcd = 0;  // launch shape of the sweeps, fixed by bilu_setup (bilu_launch_shape)
     // host copies (tests / introspection)
     std::vector<int> h_nodeUnk, h_bcol, h_lvlPtr, h_natural;  // h_natural[p] = natural (cell-order) index of the node at position p
     std::vector<long long> h_bptr;
@@ -598,6 +600,9 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
     P.h_bptr = bptr; P.h_bcol = bcol; P.h_lvlPtr = lvlPtr; P.h_natural = inv;
 }
 
+struct NodeILU;
+inline void bilu_launch_shape(NodeILU& P, hipStream_t st);
+
 // Numeric setup on the device from the assembled PC matrix (device CSR, rows = states).
 inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned, int reach,
                        bool fp32, long long An, const long long* d_rp, const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P,
@@ -681,6 +686,7 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     P.view.ptr[0] = P.Lptr.p; P.view.ptr[1] = P.Uptr.p; P.view.col[0] = P.Lcol.p; P.view.col[1] = P.Ucol.p;
     P.view.val[0] = P.Lval.p; P.view.val[1] = P.Uval.p; P.view.valf[0] = P.Lvalf.p; P.view.valf[1] = P.Uvalf.p;
     P.view.invD = P.invD.p; P.view.y = P.y.p; P.view.z = P.z.p; P.view.ctrl = P.ctrl.p;
+    bilu_launch_shape(P, st);
     P.ready = true;
     if (debug)
         fprintf(stderr, "[dafoam_amd] node-block ILU(0): %d nodes (%.3f slots/unknown), %lld blocks (%.1f per node, max %d), %d levels, %d shifted pivots, "
@@ -689,35 +695,56 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
                 P.t_pack);
 }
 
+// Which XCC ids do the workgroups of a launch on this device see?  One tiny launch per process (cached): 256 workgroups OR
+// 1 << XCC_ID into a mask.  Returns the number of XCDs if the ids are exactly 0..7 (an unpartitioned MI300X / MI355X), else 0
+// (partition modes, other parts): the per-XCD ticket scheme of k_bilu_sweep is then never used.
+__global__ void k_bilu_xcd_probe(unsigned* mask) {
+    if (threadIdx.x == 0) atomicOr(mask, 1u << (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u));
+}
+inline int bilu_xcd_probe(hipStream_t st) {
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    DevBuf<unsigned> mask(1);
+    DAS_HIP(hipMemsetAsync(mask.p, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_bilu_xcd_probe, dim3(256), dim3(64), 0, st, mask.p);
+    unsigned h = 0u;
+    DAS_HIP(hipMemcpyAsync(&h, mask.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
+    cached = (h == 0xFFu) ? 8 : 0;
+    return cached;
+}
+
 // launch shape of the sweeps: as many workgroups as keep a few levels in flight (a wave far ahead of the front only
-// spins and loads the memory system).  DAS_BILU_WGS / DAS_BILU_SLEEP override (tuning runs).
-struct BiluLaunch { int grid, sleepReps; };
-inline BiluLaunch bilu_launch_shape(const NodeILU& P) {
+// spins and loads the memory system).  DAS_BILU_WGS / DAS_BILU_SLEEP / DAS_BILU_XCD override (tuning runs).  Computed once
+// per factorisation (bilu_setup) and cached in the NodeILU.
+inline void bilu_launch_shape(NodeILU& P, hipStream_t st) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int waves = BILU_WG / 64;
     const double perLevel = (double)P.nNodes / std::max(1, P.nLevels);
-    BiluLaunch L;
-    L.grid = (int)std::min<double>(cus * 2.0 * (BILU_OCC * 4 / waves), std::max(8.0, P.windowLevels * perLevel / waves));  // <= 2 x resident
-    L.sleepReps = 0;
-    if (const char* e = getenv("DAS_BILU_WGS")) L.grid = std::max(1, atoi(e));
-    if (const char* e = getenv("DAS_BILU_SLEEP")) L.sleepReps = std::max(0, atoi(e));
+    int grid = (int)std::min<double>(cus * 2.0 * (BILU_OCC * 4 / waves), std::max(8.0, P.windowLevels * perLevel / waves));  // <= 2 x resident
+    int sleepReps = 0;
+    if (const char* e = getenv("DAS_BILU_WGS")) grid = std::max(1, atoi(e));
+    if (const char* e = getenv("DAS_BILU_SLEEP")) sleepReps = std::max(0, atoi(e));
     const long long tickets = ((long long)P.nNodes + waves - 1) / waves;
-    L.grid = (int)std::min<long long>(L.grid, tickets + 1);
-    return L;
+    grid = (int)std::min<long long>(grid, tickets + 1);
+    // per-XCD ticket counters only where every XCD is certain to run workgroups of the launch (see k_bilu_sweep)
+    int perXcd = (BILU_XCD_TICKETS && grid >= 64 && bilu_xcd_probe(st) == 8) ? 1 : 0;
+    if (const char* e = getenv("DAS_BILU_XCD")) perXcd = (atoi(e) != 0 && grid >= 64 && bilu_xcd_probe(st) == 8) ? 1 : 0;
+    P.launchGrid = grid; P.launchSleep = sleepReps; P.launchPerXcd = perXcd;
 }
 
 // out = (LU)^-1 b on the owned unknowns (entries of `out` outside the preconditioner's unknowns are not touched)
 inline void bilu_apply(NodeILU& P, const double* b, double* out, hipStream_t st) {
     const long long nslots = (long long)P.nNodes * BILU_NB;
     hipLaunchKernelGGL(k_bilu_reset, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, P.y.p, P.z.p, P.ctrl.p);
-    const BiluLaunch L = bilu_launch_shape(P);
+    const int grid = P.launchGrid, sl = P.launchSleep, px = P.launchPerXcd;
     if (P.fp32) {
-        hipLaunchKernelGGL((k_bilu_sweep<float, false>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.sleepReps);
-        hipLaunchKernelGGL((k_bilu_sweep<float, true>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.sleepReps);
+        hipLaunchKernelGGL((k_bilu_sweep<float, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
+        hipLaunchKernelGGL((k_bilu_sweep<float, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
     } else {
-        hipLaunchKernelGGL((k_bilu_sweep<double, false>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.sleepReps);
-        hipLaunchKernelGGL((k_bilu_sweep<double, true>), dim3(L.grid), dim3(BILU_WG), 0, st, P.view, b, out, L.sleepReps);
+        hipLaunchKernelGGL((k_bilu_sweep<double, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
+        hipLaunchKernelGGL((k_bilu_sweep<double, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
     }
 }
 
@@ -728,5 +755,8 @@ inline bool bilu_aborted(NodeILU& P, hipStream_t st) {
     DAS_HIP(hipStreamSynchronize(st));
     return c != 0u;
 }
+
+// a new solve starts with a clear abort flag (a sweep that timed out once must not disable the preconditioner for good)
+inline void bilu_clear_abort(NodeILU& P, hipStream_t st) { DAS_HIP(hipMemsetAsync(P.ctrl.p + BILU_CTRL_ABORT, 0, sizeof(unsigned), st)); }
 
 }  // namespace das

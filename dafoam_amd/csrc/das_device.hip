@@ -902,7 +902,7 @@ struct das_ksp {
     std::unique_ptr<struct GmresRun> run;
     std::unique_ptr<struct BlockWork> block;
     std::vector<double> block_res0, block_res;
-    int iters = 0, nrefine = 0;
+    int iters = 0, nrefine = 0, reason = 0, nBreakdown = 0;
     double res0 = 0, res = 0, seconds = 0;
     std::vector<double> hist;
 };
@@ -957,6 +957,10 @@ struct das_solver {
     };
     std::map<std::string, FaceFn> functions;
     long long geomVersion = 0;  // bumped by das_update_of_mesh
+    // everything else the Jacobian depends on besides the states and the geometry: patch values, old-time fields, options
+    // (normalizeStates, residual / discretisation switches).  Every setter bumps the epoch; a cached operator is only
+    // reused by calcJacTVecProduct when its epoch is current
+    long long opEpoch = 0, op_epoch = -1;
     long long nGlobalCells = 0; // sharded runs (das_set_n_global_cells); 0 = single domain
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -1857,7 +1861,20 @@ struct GmresRun {
     bool dcgs2 = false;
     int pend = 0;                 // slot of the pending (once projected, not normalised) vector = number of final basis vectors
     std::vector<double> Hraw, h1; // unrotated Hessenberg matrix; first-projection coefficients of the pending vector
+    // breakdown / stagnation control (gmres_advance): a cycle closed by a Krylov breakdown, by lost orthogonality or by a
+    // recurrence residual the recomputed true residual does not confirm must make progress; two such cycles in a row that
+    // do not halve the true residual end the solve (PETSc, which the reference runs - DALinearEqn.C:341-437 - leaves the
+    // iteration at a breakdown as well: KSP_CONVERGED_HAPPY_BREAKDOWN / KSP_DIVERGED_BREAKDOWN)
+    bool earlyClose = false;      // the open cycle was closed before the basis was full and before maxIts
+    bool safeOrth = false;        // after lost orthogonality: the following cycles use the two-pass scheme ("cgs")
+    bool stalled = false;
+    int nonImproving = 0, nBreakdown = 0;
+    double betaStart = 0;         // true residual norm at the start of the open cycle
 };
+// a new basis vector whose norm is below this fraction of the norm of the operator image it was projected from is
+// rounding noise (the rounding errors of the projection itself are ~1e-16 of that norm, at any problem size: they are
+// componentwise): the Krylov space is exhausted - happy breakdown
+static constexpr double GMRES_BREAKDOWN_TOL = 1e-13;
 
 static void gmres_true_residual(das_solver* s, das_ksp* k, GmresRun& G, bool haveGuess) {
     const long long n = s->n;
@@ -1877,6 +1894,7 @@ static void gmres_begin(das_solver* s, das_ksp* k, const double* d_rhs, double* 
     need_init(s);
     DAS_CHECK(s->op || s->fwd.on, DAS_ERR_STATE, "initializedRdWTMatrixFree() must be called before solveLinearEqn()");
     gmres_ws(s, k);
+    if (k->useBilu) bilu_clear_abort(k->bilu, s->stream);
     if (!k->run) k->run.reset(new GmresRun);
     GmresRun& G = *k->run;
     const int m = k->restart;
@@ -1907,12 +1925,14 @@ static void gmres_cycle_start(das_solver* s, das_ksp* k) {
     G.j = 0;
     G.pend = 0;
     G.open = true;
+    G.earlyClose = false;
+    G.betaStart = G.beta;
 }
 // one Arnoldi step; returns the recurrence residual norm
 static double gmres_iter_dcgs2(das_solver* s, das_ksp* k);
 static double gmres_iter(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
-    if (G.dcgs2) return gmres_iter_dcgs2(s, k);
+    if (G.dcgs2 && !G.safeOrth) return gmres_iter_dcgs2(s, k);
     const long long n = s->n;
     const int B = 256, m = G.m, j = G.j;
     hipStream_t st = s->stream;
@@ -1958,6 +1978,7 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
             hn = std::sqrt(est);
         }
     }
+    if (!mgs && !(hn > GMRES_BREAKDOWN_TOL * std::sqrt(std::max(hh[j + 1], 0.0)))) { hn = 0.0; G.nBreakdown++; }  // happy breakdown (hh[j+1] = |A M^-1 v_j|^2)
     for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = hh[i] + h2[i];
     H[(size_t)(j + 1) * m + j] = hn;
     if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, k->w.p, k->V.p + (long long)(j + 1) * n);
@@ -1978,7 +1999,7 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
     G.j++;
     const double res = std::fabs(g[G.j]);
     k->hist.push_back(res);
-    if (hn == 0.0) G.j = -G.j;  // happy breakdown: close the cycle (sign marks it)
+    if (hn == 0.0) { G.j = -G.j; G.earlyClose = true; }  // happy breakdown: close the cycle (sign marks it)
     return res;
 }
 // Givens update of Hessenberg column `col` (entries H[0..col+1][col] already set); returns the recurrence residual norm
@@ -2040,6 +2061,9 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     double ss = 0.0, stt = 0.0;
     for (int i = 0; i < j; i++) { ss += sv[i] * sv[i]; stt += sv[i] * tv[i]; }
     double al2 = uu - ss, num = uv - stt;  // |u - Q s|^2 and (u - Q s).v by Pythagoras - accurate while s is small against u
+    // |B q_{j-1}|^2 = |h1|^2 + u.u: the scale the pending vector is measured against (breakdown rule)
+    double normBq2 = uu;
+    for (int i = 0; i < j; i++) normBq2 += G.h1[i] * G.h1[i];
     bool explicitProj = false;
     if (j > 0 && !(ss <= 1e-2 * uu)) {
         // the first projection left a large component in span(Q): u is (nearly) rounding noise - the Krylov space is exhausted or
@@ -2057,31 +2081,38 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
         explicitProj = true;
         k->nrefine++;
     }
-    const bool breakdown = !(al2 > 0.0);
+    // happy breakdown: what is left of B q_{j-1} after the projections is rounding noise (GMRES_BREAKDOWN_TOL).  The column
+    // is completed with a ZERO sub-diagonal - the recurrence residual drops to zero - and the cycle is closed; whether the
+    // solve is over is decided on the recomputed true residual (gmres_advance)
+    const bool breakdown = !(al2 > GMRES_BREAKDOWN_TOL * GMRES_BREAKDOWN_TOL * normBq2);
     const double al = breakdown ? 0.0 : std::sqrt(al2);
     double res = k->hist.back();
     if (j == 0) {
+        DAS_CHECK(!breakdown, DAS_ERR_INTERNAL, "GMRES: the start vector of an Arnoldi cycle is not finite (preconditioner or operator returned NaN)");
         G.g[0] = G.beta * al;  // slot 0 holds r / beta, alpha = 1 up to rounding
     } else {
         const int col = j - 1;
-        for (int i = 0; i < j; i++) G.Hraw[(size_t)i * m + col] = G.H[(size_t)i * m + col] = G.h1[i] + sv[i];
+        for (int i = 0; i < j; i++) G.Hraw[(size_t)i * m + col] = G.H[(size_t)i * m + col] = G.h1[i] + (breakdown ? 0.0 : sv[i]);
         G.Hraw[(size_t)j * m + col] = G.H[(size_t)j * m + col] = al;
         res = gmres_rotate_column(G, col);
         G.its++;
         G.j = j;
         k->hist.push_back(res);
-        // happy breakdown, or the explicit projection above (Krylov space exhausted / orthogonality lost: the lagged recurrence
-        // below would divide by a noise-level alpha): close the cycle (sign marks it), restart from the true residual
-        if (breakdown || explicitProj) { G.j = -G.j; return res; }
+        // happy breakdown, or the explicit projection above (orthogonality lost: the lagged recurrence below would divide by
+        // a small alpha and multiply the rounding errors of s): close the cycle (sign marks it), restart from the true
+        // residual; the cycles after lost orthogonality run the two-pass scheme
+        if (breakdown || explicitProj) {
+            if (breakdown) G.nBreakdown++; else G.safeOrth = true;
+            G.j = -G.j; G.earlyClose = true;
+            return res;
+        }
         const bool stop = !G.fixed && (res <= G.target || G.its >= G.maxIts);
         if (stop || G.j >= m) return res;            // the cycle is closed by the caller: no further basis vector needed
     }
-    DAS_CHECK(!breakdown, DAS_ERR_INTERNAL, "GMRES: the initial residual vanished inside the Arnoldi process");
     const double gam = num / al2;
-    // coefficients of the fused update: s, then c = t - gamma s  (u already holds u - Q s after an explicit projection:
-    // then q_j = u / alpha and u' = (v - gamma u - Q t) / alpha)
+    // coefficients of the fused update: s, then c = t - gamma s
     std::vector<double>& co = G.h2;
-    for (int i = 0; i < j; i++) { co[i] = explicitProj ? 0.0 : sv[i]; co[j + i] = explicitProj ? tv[i] : tv[i] - gam * sv[i]; }
+    for (int i = 0; i < j; i++) { co[i] = sv[i]; co[j + i] = tv[i] - gam * sv[i]; }
     double* dco = k->hdev.p + 2 * (m + 3);
     if (j > 0) DAS_HIP(hipMemcpyAsync(dco, co.data(), 2 * j * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, k->V.p, n, dco, gam, 1.0 / al, k->w.p);
@@ -2115,17 +2146,29 @@ static void gmres_cycle_end(das_solver* s, das_ksp* k) {
     G.open = false;
 }
 // advance by up to `nsteps` iterations (cycles are opened / closed as needed); returns true when the solve is over
+static bool gmres_over(const GmresRun& G) { return !G.fixed && !G.open && (G.beta <= G.target || G.its >= G.maxIts || G.stalled); }
 static bool gmres_advance(das_solver* s, das_ksp* k, long long nsteps) {
     GmresRun& G = *k->run;
     for (long long t = 0; t < nsteps; t++) {
-        if (!G.fixed && !G.open && (G.beta <= G.target || G.its >= G.maxIts)) return true;
+        if (gmres_over(G)) return true;
         if (G.beta == 0.0) return true;
         if (!G.open) gmres_cycle_start(s, k);
         const double res = gmres_iter(s, k);
         const bool stop = !G.fixed && (res <= G.target || G.its >= G.maxIts);
-        if (G.j < 0 || G.j >= G.m || stop) gmres_cycle_end(s, k);
+        if (G.j < 0 || G.j >= G.m || stop) {
+            // a cycle that ends on a breakdown / lost orthogonality, or on a recurrence residual below the target, should
+            // leave a TRUE residual below the target.  If it does not, the next cycle works on the rounding level of this
+            // system; it may still gain (iterative refinement), but two such cycles in a row that do not halve the true
+            // residual mean the attainable accuracy is reached: stop instead of spending gmresMaxIters on one-step cycles
+            const bool judged = G.earlyClose || (res <= G.target && G.its < G.maxIts);
+            gmres_cycle_end(s, k);
+            if (!G.fixed && judged && G.beta > G.target) {
+                if (G.beta < 0.5 * G.betaStart) G.nonImproving = 0;
+                else if (++G.nonImproving >= 2) G.stalled = true;
+            }
+        }
     }
-    return !G.fixed && !G.open && (G.beta <= G.target || G.its >= G.maxIts);
+    return gmres_over(G);
 }
 static int gmres_end(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
@@ -2133,7 +2176,9 @@ static int gmres_end(das_solver* s, das_ksp* k) {
     DAS_HIP(hipStreamSynchronize(s->stream));
     if (k->useBilu) DAS_CHECK(!bilu_aborted(k->bilu, s->stream), DAS_ERR_INTERNAL, "preconditioner sweep timed out (bounded spin)");
     k->iters = (int)G.its;
+    k->nBreakdown = G.nBreakdown;
     k->res = k->hist.back();
+    k->reason = G.beta <= G.target ? 0 : (G.stalled ? 2 : 1);
     k->seconds = wall_seconds() - G.t0;
     // reference failure rule (DALinearEqn.C:422-434)
     double absRatio = k->res / G.atol;
@@ -2533,6 +2578,7 @@ void das_destroy(das_solver_t* s) {
 int das_set_option_double(das_solver_t* s, const char* key, double v) {
     DAS_TRY
     DAS_CHECK(s && key, DAS_ERR_ARG, "null argument");
+    { auto it = s->opt.d.find(key); if (it == s->opt.d.end() || it->second != v || s->opt.i.count(key)) s->opEpoch++; }
     s->opt.d[key] = v;
     s->opt.i.erase(key);
     if (std::string(key).rfind("normalizeStates.", 0) == 0) compute_scales(s);
@@ -2544,6 +2590,7 @@ int das_set_option_int(das_solver_t* s, const char* key, long long v) {
     DAS_CHECK(s && key, DAS_ERR_ARG, "null argument");
     std::string k(key);
     if (s->opt.d.count(k) && !s->opt.i.count(k)) return das_set_option_double(s, key, (double)v);
+    { auto it = s->opt.i.find(k); if (it == s->opt.i.end() || it->second != v) s->opEpoch++; }
     s->opt.i[k] = v;
     if (k.rfind("maxResConLv4JacPCMat.", 0) == 0) s->colored = false;
     return DAS_OK;
@@ -2554,6 +2601,7 @@ int das_set_option_str(das_solver_t* s, const char* key, const char* v) {
     DAS_CHECK(s && key && v, DAS_ERR_ARG, "null argument");
     std::string k(key);
     if (k == "adjStateOrdering") DAS_CHECK(std::string(v) == "state", DAS_ERR_ARG, "adjStateOrdering: only \"state\" is implemented");
+    { auto it = s->opt.s.find(k); if (it == s->opt.s.end() || it->second != v) s->opEpoch++; }
     s->opt.s[k] = v;
     return DAS_OK;
     DAS_CATCH
@@ -2820,6 +2868,7 @@ int das_initialize_drdwt_matrix_free(das_solver_t* s) {
     s->op.reset(assemble(s, 0, (int)s->opt.geti("amd.jacMode")));
     s->op_states = s->h_W;
     s->op_geom = s->geomVersion;
+    s->op_epoch = s->opEpoch;
     return DAS_OK;
     DAS_CATCH
 }
@@ -2860,6 +2909,7 @@ int das_set_old_time_fields(das_solver_t* s, const double* phi_frozen, const dou
     if (phi_frozen) s->cp.phi_frozen.assign(phi_frozen, phi_frozen + s->mesh.nF);
     if (T_old) s->cp.T_old.assign(T_old, T_old + s->mesh.nC);
     if (s->inited) { s->d_phiF.upload(s->cp.phi_frozen); s->d_Told.upload(s->cp.T_old); }
+    s->opEpoch++;
     return DAS_OK;
     DAS_CATCH
 }
@@ -3057,6 +3107,7 @@ int das_set_patch_value(das_solver_t* s, const int* patches, int np, const char*
     }
     DAS_HIP(hipStreamSynchronize(s->stream));
     s->d_bc.upload(s->mesh.bc);
+    s->opEpoch++;
     return DAS_OK;
     DAS_CATCH
 }
@@ -3162,7 +3213,7 @@ int das_calc_jac_t_vec_product(das_solver_t* s, const char* inputName, const cha
     // DAInputStateVar::run assigns the inputs to the states (reference DASolver.C:1690-1839)
     // the operator initializedRdWTMatrixFree built is reused when it was assembled at these very states (the reference
     // replays its tape; re-assembling all colours for one product would cost ~nColors residual passes)
-    const bool reuse = s->op && s->op_geom == s->geomVersion && s->op_states.size() == (size_t)s->n && (int)s->opt.geti("amd.jacMode") == 1
+    const bool reuse = s->op && s->op_geom == s->geomVersion && s->op_epoch == s->opEpoch && s->op_states.size() == (size_t)s->n && (int)s->opt.geti("amd.jacMode") == 1
                        && std::memcmp(s->op_states.data(), inputs, s->n * sizeof(double)) == 0;
     s->h_W.assign(inputs, inputs + s->n);
     s->d_W.upload(s->h_W);
@@ -3341,6 +3392,16 @@ int das_ksp_get_info(das_ksp_t* k, int* iters, double* res0, double* res, double
     DAS_CATCH
 }
 int das_ksp_get_n_refine(das_ksp_t* k) { return k ? k->nrefine : -1; }
+int das_ksp_get_status(das_ksp_t* k, int* reason, int* nBreakdown, int* nSweepGrid, int* sweepPerXcd) {
+    DAS_TRY
+    DAS_CHECK(k, DAS_ERR_ARG, "null ksp handle");
+    if (reason) *reason = k->reason;
+    if (nBreakdown) *nBreakdown = k->nBreakdown;
+    if (nSweepGrid) *nSweepGrid = k->useBilu ? k->bilu.launchGrid : 0;
+    if (sweepPerXcd) *sweepPerXcd = k->useBilu ? k->bilu.launchPerXcd : 0;
+    return DAS_OK;
+    DAS_CATCH
+}
 // coarse space of the two-level preconditioner: number of aggregates (0 = none); aggOfCell[nCells] (optional) = aggregate or -1
 int das_ksp_get_coarse(das_ksp_t* k, int* aggOfCell) {
     if (!k || !k->coarse.active) return 0;
@@ -3404,6 +3465,14 @@ int das_set_comm(das_solver_t* s, das_halo_cb halo, das_allreduce_cb allreduce, 
 }
 // ---- native communication (das_comm.hpp) ---------------------------------------------------------------------------
 // rank 0 creates the RCCL unique id (128 bytes); the host side distributes it (bootstrap only)
+// step 1 of the native set-up, LOCAL (no collective inside): bind RCCL.  The ranks agree on the result before any of them
+// enters the collective ncclCommInitRank - a rank that cannot load the library must not leave the others blocked there
+int das_comm_load_rccl(void) {
+    DAS_TRY
+    rccl().load();
+    return DAS_OK;
+    DAS_CATCH
+}
 int das_comm_unique_id(char* out128) {
     DAS_TRY
     DAS_CHECK(out128, DAS_ERR_ARG, "null argument");
@@ -3423,6 +3492,7 @@ int das_comm_init_rccl(das_solver_t* s, int rank, int world, const char* id128) 
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     DAS_HIP(hipSetDevice(s->device));
+    if (s->halo.comm) { (void)rccl().CommDestroy(s->halo.comm); s->halo.comm = nullptr; }  // re-install: no leaked communicator
     DAS_NCCL(rccl().CommInitRank(&s->halo.comm, world, id, rank));
     s->halo.rank = rank;
     s->halo.world = world;

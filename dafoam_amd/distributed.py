@@ -175,20 +175,26 @@ def install_comm(obj, native=None):
     if os.environ.get("DAFOAM_AMD_COMM", "") == "torch":
         native = False  # force the callback transport (torch.distributed issues the same RCCL calls)
     if native:
-        # every rank must end up on the same transport: a failure of the native set-up anywhere (RCCL not loadable, communicator
-        # not created) is agreed on through the torch backend and all ranks fall back to the callback transport together
+        # every rank must end up on the same transport, and ncclCommInitRank is collective: a rank that fails BEFORE it would
+        # leave the others blocked inside.  Two agreed steps: (1) local - bind RCCL, rank 0 draws the unique id; all ranks
+        # MIN-reduce the outcome through the torch backend; (2) only if every rank succeeded: the collective communicator
+        # creation, agreed on the same way.  Any failure: all ranks fall back to the callback transport together.
+        def agreed(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=obj.dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
         ident = [None]
-        if obj.rank == 0:
+        ok = L.das_comm_load_rccl() == 0
+        if ok and obj.rank == 0:
             buf = C.create_string_buffer(128)
-            if L.das_comm_unique_id(buf) == 0:
-                ident[0] = buf.raw
-        dist.broadcast_object_list(ident, src=0)
-        ok = 0
-        if ident[0] is not None:
-            ok = 1 if L.das_comm_init_rccl(h, obj.rank, obj.world, ident[0]) == 0 else 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=obj.dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+            ok = L.das_comm_unique_id(buf) == 0
+            ident[0] = buf.raw if ok else None
+        ok = agreed(ok)
+        if ok:
+            dist.broadcast_object_list(ident, src=0)
+            ok = agreed(L.das_comm_init_rccl(h, obj.rank, obj.world, ident[0]) == 0)
+        if not ok:
             if obj.rank == 0:
                 print("[dafoam_amd] native RCCL transport unavailable (%s); using the torch.distributed callback transport"
                       % L.das_last_error().decode(), file=sys.stderr, flush=True)

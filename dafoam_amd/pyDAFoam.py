@@ -34,29 +34,54 @@ class Error(Exception):
 
 
 class DAOPTION(object):
-    """Defaults of every option the adjoint hot path reads; names, nesting and values are the reference's
-    (dafoam/pyDAFoam.py:59-661, line numbers in comments)."""
+    """The reference's option surface: every DAOPTION attribute of dafoam/pyDAFoam.py:59-661 with its name, nesting and
+    default value (line numbers in the comments; tests/test_reference_pins.py parses the reference file with `ast` and
+    compares).  Options of subsystems outside the adjoint hot path (mesh quality checks, FFD output, regression models,
+    ...) are accepted and carried so that existing runScripts construct unchanged; the hot path reads the ones marked *."""
 
     def __init__(self):
-        self.solverName = "DASimpleFoam"  # :77
-        self.primalMinResTol = 1.0e-8  # :116-121
-        self.primalBC = {}  # :150
-        self.normalizeStates = {}  # :334
-        self.function = {}
-        self.inputInfo = {}
-        self.outputInfo = {}
-        self.discipline = "aero"  # :386
-        self.adjPartDerivFDStep = {"State": 1.0e-6}  # :390-392
-        self.transonicPCOption = -1  # :396
-        self.adjPCLag = 10000  # :417
-        self.useAD = {"mode": "reverse", "dvName": "None", "seedIndex": -9999}  # :426
-        self.useConstrainHbyA = True  # :433
-        self.debug = False  # :506
-        self.writeJacobians = ["None"]  # :510
-        self.printInterval = 100  # :514
-        self.adjUseColoring = True  # :521
-        self.adjEqnSolMethod = "Krylov"
-        self.adjEqnOption = {  # :526-548
+        self.solverName = "DASimpleFoam"  # * :76
+        self.primalMinResTol = 1.0e-8  # * :80
+        self.primalFuncStdTol = {"stdTol": -1.0, "slopeTol": -1.0, "funcNames": ["CD"], "nStepsFrac": 0.2}  # :91
+        self.primalBC = {}  # * :104
+        self.primalInitCondition = {}  # :114
+        self.normalizeStates = {}  # * :121
+        self.function = {}  # * :238
+        self.inputInfo = {}  # * :262
+        self.outputInfo = {}  # * :270
+        self.designSurfaces = ["ALL_OPENFOAM_WALL_PATCHES"]  # :274
+        self.fvSource = {}  # :325
+        self.prepareCaseOnly = False  # :331
+        self.adjEqnSolMethod = "Krylov"  # * :334
+        self.dynamicMesh = {"active": False, "mode": "rotation", "center": [0.25, 0.0, 0.0], "axis": "z", "omega": 0.1, "s": 2.0, "t0": 0.35}  # :338
+        bounds = {"U": (-1000.0, 1000.0), "p": (20000.0, 500000.0), "p_rgh": (20000.0, 500000.0), "e": (-220000.0, 55000.0), "T": (100.0, 1000.0),
+                  "h": (-200000.0, 200000.0), "D": (-1e16, 1e16), "rho": (0.2, 5.0)}
+        bounds.update({v: (1e-16, 1e16) for v in ("nuTilda", "k", "omega", "epsilon", "ReThetat", "gammaInt")})
+        self.primalVarBounds = {}  # :353
+        for v, (lo, hi) in bounds.items():
+            self.primalVarBounds[v + "Max"] = hi
+            self.primalVarBounds[v + "Min"] = lo
+        self.discipline = "aero"  # * :386
+        self.adjPartDerivFDStep = {"State": 1.0e-6}  # * :390
+        self.transonicPCOption = -1  # * :396
+        self.unsteadyAdjoint = {"mode": "None", "PCMatPrecomputeInterval": 100, "PCMatUpdateInterval": 1, "reduceIO": True,
+                                "additionalOutput": ["None"], "additionalOldTime": ["None"], "readZeroFields": True}  # :401
+        self.adjPCLag = 10000  # * :417
+        self.useAD = {"mode": "reverse", "dvName": "None", "seedIndex": -9999}  # * :426
+        self.useConstrainHbyA = True  # * :433
+        self.forceMeshWaveFrozen = True  # * :437 (the wall distance is always frozen here)
+        self.useDdtCorr = False  # :441
+        self.regressionModel = {"active": False}  # :450
+        self.useMeanStates = False  # :486
+        self.solveLinearFunctionName = "None"  # :494
+        self.printDAOptions = True  # :497
+        self.debug = False  # * :500
+        self.writeJacobians = ["None"]  # * :506
+        self.printInterval = 100  # :510
+        self.printIntervalUnsteady = 1  # :513
+        self.primalMinResTolDiff = 1.0e2  # * :517
+        self.adjUseColoring = True  # * :521
+        self.adjEqnOption = {  # * :526-548
             "globalPCIters": 0,
             "asmOverlap": 1,
             "localPCIters": 1,
@@ -79,15 +104,16 @@ class DAOPTION(object):
             "KSPCalcSingularVal": 0,
             "readPCMat": 0,
         }
-        self.normalizeResiduals = [  # :551-563
+        self.normalizeResiduals = [  # * :551-563
             "URes", "pRes", "p_rghRes", "nuTildaRes", "phiRes", "TRes", "DRes", "kRes", "omegaRes", "epsilonRes", "alpha.waterRes",
         ]
-        self.maxResConLv4JacPCMat = {  # :568-582
+        self.maxResConLv4JacPCMat = {  # * :568-582
             "pRes": 2, "phiRes": 1, "URes": 2, "TRes": 2, "nuTildaRes": 2, "kRes": 2, "epsilonRes": 2, "omegaRes": 2,
             "p_rghRes": 2, "DRes": 2, "gammaIntRes": 2, "ReThetatRes": 2, "alpha.waterRes": 2,
         }
-        self.jacLowerBounds = {"dRdW": 1.0e-30, "dRdWPC": 1.0e-30}  # :586-589
-        self.decomposeParDict = {  # :597-604
+        self.jacLowerBounds = {"dRdW": 1.0e-30, "dRdWPC": 1.0e-30}  # * :586-589
+        self.maxTractionBCIters = 100  # :592
+        self.decomposeParDict = {  # * :597-604 (preservePatches drives the multi-GPU partitioner)
             "method": "scotch",
             "simpleCoeffs": {"n": [2, 2, 1], "delta": 0.001},
             "kahipCoeffs": {"config": "fast", "imbalance": 0.01},
@@ -95,10 +121,17 @@ class DAOPTION(object):
             "singleProcessorFaceSets": ["None"],
             "args": ["None"],
         }
-        self.adjStateOrdering = "state"  # :608
-        self.writeAdjointFields = False
-        self.maxCorrectBCCalls = 2  # :628
-        self.writeMinorIterations = False
+        self.adjStateOrdering = "state"  # * :608
+        self.checkMeshThreshold = {"maxAspectRatio": 1000.0, "maxNonOrth": 70.0, "maxSkewness": 4.0, "maxIncorrectlyOrientedFaces": 0}  # :611
+        self.writeDeformedFFDs = False  # :619
+        self.writeDeformedConstraints = False  # :622
+        self.writeAdjointFields = False  # * :625
+        self.maxCorrectBCCalls = 2  # * :628
+        self.writeMinorIterations = False  # :635
+        self.primalMinIters = 1  # :639
+        self.tensorflow = {"active": False}  # :642
+        self.wallDistanceMethod = "default"  # :650
+        self.unsteadyCompOutput = {}  # :661
         # MI355X-specific additions (not in the reference)
         self.amd = {"pcType": "bilu", "pcCoarseAggregates": -1, "pcCoarseField": "p", "pcCoarseMode": "additive", "pcBlockCells": 1024, "jacMode": 1, "pcJacMode": 0, "pcFactorFP32": 0, "cgsAlwaysRefine": 0, "gmresOrthogonalization": "dcgs2", "setupThreads": 32}
         self.amdDevice = 0
@@ -281,11 +314,24 @@ class PYDAFOAM(object):
     # ---------------------------------------------------------------- primal (pyDAFoam.py __call__ / solvePrimal)
     def solvePrimal(self, maxSteps=80):
         """Converge the flow residuals from the current states (reference PYDAFOAM.solvePrimal -> DASimpleFoam::solvePrimal,
-        DASimpleFoam.C:123-185).  The tolerance is the reference's option primalMinResTol, taken relative to the initial
-        residual norm.  Sets self.primalFail (0 converged / 1 not, like the reference) and returns it."""
+        DASimpleFoam.C:123-185).  primalMinResTol is an ABSOLUTE bound on a normalised residual, as in the reference
+        (`primalMaxRes < primalMinResTol`, DASolver.C:188: primalMaxRes is the largest of OpenFOAM's normalised initial
+        residuals, O(1) for a start from scratch): here the residual 2-norm divided by the norm at the states the FIRST
+        primal of this object started from, so that a warm-started call inside an optimisation loop converges to the same
+        level instead of 1e-8 below an already converged start.  The failure flag follows
+        DASolver::checkPrimalFailure (DASolver.C:2722-2760): fail when primalMaxRes / primalMinResTol > primalMinResTolDiff."""
         tol = float(self.getOption("primalMinResTol"))
-        fail, self.primalInfo = self.solver.solvePrimal(maxSteps=maxSteps, relTol=tol)
-        self.primalFail = int(fail)
+        ref = getattr(self, "_primalResRef", None)
+        if ref is None:
+            R = np.zeros(self.getNLocalAdjointStates())
+            self.solver.getResiduals(R)
+            ref = float(np.linalg.norm(R))
+            self._primalResRef = ref if ref > 0.0 else 1.0
+            ref = self._primalResRef
+        _, self.primalInfo = self.solver.solvePrimal(maxSteps=maxSteps, relTol=0.0, absTol=tol * ref)
+        self.primalMaxRes = self.primalInfo["res"] / ref
+        self.primalInfo["primalMaxRes"] = self.primalMaxRes
+        self.primalFail = int(self.primalMaxRes / tol > float(self.getOption("primalMinResTolDiff")))
         W = self.getStates()
         if self.solverAD is not self.solver:
             self.solverAD.updateOFFields(W)

@@ -178,6 +178,14 @@ class KSP:
         check(lib().das_ksp_get_info(self.handle, C.byref(it), C.byref(r0), C.byref(r), C.byref(sec)))
         return dict(iters=it.value, res0=r0.value, res=r.value, seconds=sec.value)
 
+    def status(self):
+        """How the last solve ended: dict(reason 0 tolerance | 1 gmresMaxIters | 2 breakdown / stagnation, nBreakdown, nRefine,
+        sweepGrid, sweepPerXcd)."""
+        a = [C.c_int(0) for _ in range(4)]
+        check(lib().das_ksp_get_status(self.handle, *[C.byref(x) for x in a]))
+        return dict(reason=a[0].value, nBreakdown=a[1].value, nRefine=lib().das_ksp_get_n_refine(self.handle), sweepGrid=a[2].value,
+                    sweepPerXcd=a[3].value)
+
     def blocks(self):
         L = lib()
         nb = check(L.das_ksp_get_n_blocks(self.handle))

@@ -299,6 +299,11 @@ int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
 /* number of Gram-Schmidt refinement passes of the last solve (KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160); with
  * amd.gmresOrthogonalization "dcgs2": the number of explicit projections (exhausted Krylov space / lost orthogonality) */
 int das_ksp_get_n_refine(das_ksp_t* ksp);
+/* how the last solve ended: reason 0 = tolerance met (KSP_CONVERGED_RTOL/ATOL), 1 = gmresMaxIters reached (KSP_DIVERGED_ITS),
+ * 2 = stopped on stagnation after a Krylov breakdown / at the attainable accuracy (PETSc: KSP_CONVERGED_HAPPY_BREAKDOWN /
+ * KSP_DIVERGED_BREAKDOWN; the reference's failure flag is still the tolerance rule of DALinearEqn.C:422-434);
+ * nBreakdown = happy breakdowns detected, nSweepGrid / sweepPerXcd = launch shape of the preconditioner sweeps */
+int das_ksp_get_status(das_ksp_t* ksp, int* reason, int* nBreakdown, int* nSweepGrid, int* sweepPerXcd);
 /* two-level preconditioner (amd.pcCoarseAggregates / pcCoarseField / pcCoarseMode): number of aggregates of the
  * piecewise-constant pressure coarse space (0 = none) and, optionally, the aggregate of every cell (-1 = not owned) */
 int das_ksp_get_coarse(das_ksp_t* ksp, int* aggOfCell);
@@ -325,6 +330,10 @@ typedef void (*das_halo_cb)(double* d_vec, void* user);
 typedef void (*das_allreduce_cb)(double* d_buf, int n, void* user);
 int das_set_owned_mask(das_solver_t* s, const unsigned char* owned /* n states */);
 int das_set_comm(das_solver_t* s, das_halo_cb halo, das_allreduce_cb allreduce, void* user);
+/* Native transport set-up, step 1 (local, not collective): dlopen the RCCL PyTorch already loaded and bind its symbols.
+ * All ranks exchange the return code (torch.distributed MIN all-reduce) BEFORE any of them calls the collective
+ * das_comm_init_rccl: a rank without RCCL must not leave its peers blocked in ncclCommInitRank. */
+int das_comm_load_rccl(void);
 /* Native transport (no host code in the iteration loop): RCCL point-to-point halo reduction overlapped with the owned-row
  * product + in-stream ncclAllReduce of the Gram-Schmidt dots.  Reference: PETSc VecScatter of the MPIAIJ off-diagonal
  * block in MatMult and MPI_Allreduce in VecMDot (KSPGMRES, DALinearEqn.C:341-437).

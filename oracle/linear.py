@@ -177,13 +177,25 @@ def gmres(matvec, rhs, pc_solve=None, x0=None, restart=1000, max_iters=1000, rel
     return x, dict(iters=its, res0=res0, res=res, hist=np.array(hist), fail=fail)
 
 
-def gmres_dcgs2(matvec, rhs, pc_solve=None, restart=1000, max_iters=1000, rel_tol=1e-6, abs_tol=1e-14, tol_diff=1e2):
-    """Restatement of the GPU engine's default orthogonalisation (csrc/das_device.hip gmres_iter_dcgs2): right-preconditioned
-    GMRES with classical Gram-Schmidt and DELAYED re-orthogonalisation (Bielich et al. 2022) - per step ONE product
-    [Q u]^T [u v] and ONE update that finishes q_j and produces the once-projected next vector.  Same interface and the
-    same iterates as `gmres` (CGS2); the Hessenberg column of a step is known one step later."""
+BREAKDOWN_TOL = 1e-13  # csrc/das_device.hip GMRES_BREAKDOWN_TOL
+
+
+def gmres_dcgs2(matvec, rhs, pc_solve=None, restart=1000, max_iters=1000, rel_tol=1e-6, abs_tol=1e-14, tol_diff=1e2, noise=0.0, rng=None):
+    """Restatement of the GPU engine's default orthogonalisation (csrc/das_device.hip gmres_iter_dcgs2 + gmres_advance):
+    right-preconditioned GMRES with classical Gram-Schmidt and DELAYED re-orthogonalisation (Bielich et al. 2022) - per step
+    ONE product [Q u]^T [u v] and ONE update that finishes q_j and produces the once-projected next vector.  Same interface
+    and the same iterates as `gmres` (CGS2); the Hessenberg column of a step is known one step later.
+
+    Breakdown rule (as in the engine): what is left of B q_{j-1} after the projections is compared with |B q_{j-1}|
+    (= sqrt(|h1|^2 + u.u)); below BREAKDOWN_TOL it is rounding noise: the column is closed with a zero sub-diagonal (happy
+    breakdown) and the cycle ends.  A cycle that ended early (breakdown, lost orthogonality) or on a recurrence residual
+    below the target must leave a true residual below the target; two such cycles in a row that do not halve it end the
+    solve (info["reason"] = 2).  `noise` > 0 perturbs every inner product and operator image relatively (test hook: the
+    run-to-run rounding differences of a parallel machine)."""
     n = rhs.size
     M = pc_solve if pc_solve is not None else (lambda v: v)
+    rng = rng if rng is not None else np.random.default_rng(0)
+    jit = (lambda a: a * (1.0 + noise * rng.standard_normal(np.shape(a)))) if noise > 0 else (lambda a: a)
     x = np.zeros(n)
     r = rhs.copy()
     beta = np.linalg.norm(r)
@@ -192,59 +204,80 @@ def gmres_dcgs2(matvec, rhs, pc_solve=None, restart=1000, max_iters=1000, rel_to
     its = 0
     target = max(rel_tol * res0, abs_tol)
     done = beta <= target
+    non_improving, n_breakdown, stalled, safe = 0, 0, False, False
     while not done:
         m = min(restart, max_iters - its)
         if m <= 0:
             break
-        Q = np.zeros((m + 2, n))
-        H = np.zeros((m + 1, m))
-        Q[0] = r / beta          # pending vector u, not yet normalised "finally"
-        h1 = np.zeros(0)
-        ncol = 0
-        y = np.zeros(0)
-        for j in range(m + 1):   # step j makes q_j final and completes Hessenberg column j - 1
-            u = Q[j].copy()
-            v = matvec(M(u))
-            QU = Q[: j + 1]
-            su, tv = QU @ u, QU @ v            # the one fused pass: [Q u]^T u, [Q u]^T v
-            s, uu, t, uv = su[:j], su[j], tv[:j], tv[j]
-            al2, num = uu - s @ s, uv - s @ t
-            explicit = j > 0 and not (s @ s <= 1e-2 * uu)
-            if explicit:  # u is (nearly) noise in span(Q): Pythagoras cancels - project explicitly (same rule as the GPU engine)
-                u = u - s @ Q[:j]
-                al2, num = u @ u, u @ v
-            al = np.sqrt(al2)
-            if j == 0:
-                g0 = beta * al
-            else:
-                H[:j, j - 1] = h1 + s
-                H[j, j - 1] = al
-                ncol = j
-                its += 1
-                e = np.zeros(j + 1)
-                e[0] = g0
-                y, *_ = np.linalg.lstsq(H[: j + 1, :j], e, rcond=None)
-                res = np.linalg.norm(H[: j + 1, :j] @ y - e)
-                hist.append(res)
-                if res <= target or its >= max_iters or j == m or explicit:
-                    break  # (explicit: the Krylov space is exhausted / orthogonality lost - the lagged recurrence would divide by a
-                           #  noise-level alpha; close the cycle and restart from the true residual)
-            gam = num / al2
-            if explicit:
-                Q[j] = u / al
-                Q[j + 1] = (v - gam * u - t @ Q[:j]) / al
-            else:
+        beta_start = beta
+        early = False
+        if safe:  # after lost orthogonality the engine runs the two-pass scheme for the following cycles
+            x1, i1 = gmres(lambda v: jit(matvec(v)), r, pc_solve, restart=m, max_iters=m, rel_tol=target / beta, abs_tol=0.0)
+            x = x + x1
+            its += i1["iters"]
+            hist.extend(list(i1["hist"][1:]))
+            res = hist[-1]
+        else:
+            Q = np.zeros((m + 2, n))
+            H = np.zeros((m + 1, m))
+            Q[0] = r / beta          # pending vector u, not yet normalised "finally"
+            h1 = np.zeros(0)
+            ncol = 0
+            y = np.zeros(0)
+            res = beta
+            for j in range(m + 1):   # step j makes q_j final and completes Hessenberg column j - 1
+                u = Q[j].copy()
+                v = jit(matvec(M(u)))
+                QU = Q[: j + 1]
+                su, tv = jit(QU @ u), jit(QU @ v)  # the one fused pass: [Q u]^T u, [Q u]^T v
+                s, uu, t, uv = su[:j], su[j], tv[:j], tv[j]
+                al2, num = uu - s @ s, uv - s @ t
+                norm_bq2 = uu + h1 @ h1
+                explicit = j > 0 and not (s @ s <= 1e-2 * uu)
+                if explicit:  # u is (nearly) noise in span(Q): Pythagoras cancels - project explicitly (same rule as the GPU engine)
+                    u = u - s @ Q[:j]
+                    al2, num = u @ u, u @ v
+                breakdown = not (al2 > BREAKDOWN_TOL ** 2 * norm_bq2)
+                al = 0.0 if breakdown else np.sqrt(al2)
+                if j == 0:
+                    g0 = beta * al
+                else:
+                    H[:j, j - 1] = h1 + (0.0 if breakdown else s)
+                    H[j, j - 1] = al
+                    ncol = j
+                    its += 1
+                    e = np.zeros(j + 1)
+                    e[0] = g0
+                    y, *_ = np.linalg.lstsq(H[: j + 1, :j], e, rcond=None)
+                    res = np.linalg.norm(H[: j + 1, :j] @ y - e)
+                    hist.append(res)
+                    if breakdown or explicit:
+                        early = True
+                        n_breakdown += int(breakdown)
+                        safe = safe or not breakdown
+                        break
+                    if res <= target or its >= max_iters or j == m:
+                        break
+                gam = num / al2
                 Q[j] = (u - s @ Q[:j]) / al        # the one fused update
                 Q[j + 1] = (v - gam * u - (t - gam * s) @ Q[:j]) / al
-            h1 = np.concatenate([(t - H[:j, :j] @ s) / al, [gam - (s[j - 1] if j > 0 else 0.0)]])
-        x = x + M(Q[:ncol].T @ y)
+                h1 = np.concatenate([(t - H[:j, :j] @ s) / al, [gam - (s[j - 1] if j > 0 else 0.0)]])
+            x = x + M(Q[:ncol].T @ y)
         r = rhs - matvec(x)
         beta = np.linalg.norm(r)
         hist[-1] = beta
-        done = beta <= target or its >= max_iters
+        judged = early or (res <= target and its < max_iters)
+        if judged and beta > target:
+            if beta < 0.5 * beta_start:
+                non_improving = 0
+            else:
+                non_improving += 1
+                stalled = non_improving >= 2
+        done = beta <= target or its >= max_iters or stalled
     res = hist[-1]
     fail = int((res / res0 / rel_tol > tol_diff) and (res / abs_tol > tol_diff)) if res0 > 0 else 0
-    return x, dict(iters=its, res0=res0, res=res, hist=np.array(hist), fail=fail)
+    return x, dict(iters=its, res0=res0, res=res, hist=np.array(hist), fail=fail, reason=0 if res <= target else (2 if stalled else 1),
+                   n_breakdown=n_breakdown)
 
 
 class ThreadedOperators:

@@ -300,30 +300,6 @@ def test_cyclic_pair_residual_jacobian_adjoint(variant):
         assert abs(psi @ dR - rhs @ v) <= 1e-6 * max(abs(rhs @ v), np.linalg.norm(psi) * np.linalg.norm(dR) * 1e-3)
 
 
-@pytest.mark.parametrize("dims", [(1, 1, 1), (2, 1, 1), (3, 2, 1)])
-def test_degenerate_meshes_full_path(dims):
-    """A single cell / a row of cells through the whole GPU path (launch sizes, block partition, level schedules with a
-    handful of unknowns): residual, Jacobian and adjoint vector against the oracle."""
-    from dafoam_amd.pyDASolvers import Mat
-
-    case = channel_case(*dims, wall_function=True)
-    g = Geometry(case.mesh)
-    W = case.states
-    D = make(case, adjEqnOption={"gmresRelTol": 1e-12, "printInfo": 0}, jacLowerBounds={"dRdW": 0.0, "dRdWPC": 0.0})
-    R = np.zeros(W.size)
-    D.solver.getResiduals(R)
-    Ro = residual(case, g, W)
-    assert np.abs(R - Ro).max() <= 1e-12 * np.abs(Ro).max()
-    sc, con, col, A = oracle_mats(case, g)
-    D.solver.runColoring()
-    M = Mat()
-    D.solver.calcdRdWT(0, M, mode=1)
-    assert np.abs((M.to_scipy() - A).tocsr().data).max() <= 1e-10 * np.abs(A.data).max()
-    rhs = np.ones(W.size) * sc
-    psi, fail = D.solveAdjoint(rhs)
-    assert fail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-8
-
-
 def test_normalize_residuals_option():
     # DAMacroFunctions.H:28-51: residuals not listed are volume-integrated / not area-divided
     case = channel_case(5, 5, 4)
@@ -1005,20 +981,6 @@ def test_unsteady_terms_scalar_transport():
     R = np.zeros(n)
     D.solver.getResiduals(R)
     assert relerr(R, residual(c2, g, case.states)) < 1e-13
-
-
-def test_gmres_failure_rule_and_restart():
-    case = channel_case(6, 6, 5)
-    g = Geometry(case.mesh)
-    rhs = np.zeros(case.states.size)
-    rhs[0 : 3 * g.nC : 3] = g.V
-    D = make(case, adjEqnOption={"gmresRelTol": 1e-12, "gmresMaxIters": 3, "printInfo": 0})
-    psi, fail = D.solveAdjoint(rhs)
-    assert fail == 1 and D.ksp.info()["iters"] == 3  # DALinearEqn.C:422-434
-    D2 = make(case, adjEqnOption={"gmresRelTol": 1e-8, "gmresRestart": 20, "gmresMaxIters": 2000, "printInfo": 0})
-    psi2, fail2 = D2.solveAdjoint(rhs)
-    sc, con, col, A = oracle_mats(case, g)
-    assert fail2 == 0 and relerr(psi2, spla.spsolve(A.tocsc(), rhs)) <= 1e-5
 
 
 @pytest.mark.gpu
