@@ -185,13 +185,17 @@ DAS_HD void bc_vector(int code, const double* value, const double* dvalue, doubl
     }
 }
 
-// nutUSpaldingWallFunction (reference ...DF.C:42-150); laminar seed (:117-118), maxIter 10, tol 1e-14
+// nutUSpaldingWallFunctionDF (reference ...DF.C:42-150): Newton iteration to the root - maxIter 1000, tolerance 1e-14 are the
+// reference's defaults (...DF.C:180-181, ...DF.H:32-37; the stock OpenFOAM field stops after 10) - from the laminar seed
+// (:117-118; at the root the seed drops out).  The dual part rides along: at the root one Newton step of the dual number IS
+// the implicit-function derivative.
+#define DAS_SPALDING_MAXITER 1000
 template <class T>
 DAS_HD T spalding_nut(const T& magUp, const T& magGradU, double y, const T& nu) {
     const double kappa = 0.41, E = 9.8;
     T ut = dsqrt(nu * magGradU);
     if (!(val(ut) > DAS_ROOTVSMALL)) return T(0.0);
-    for (int it = 0; it < 10; it++) {
+    for (int it = 0; it < DAS_SPALDING_MAXITER; it++) {
         T kUu = dmin(kappa * magUp / ut, 50.0);
         T fkUu = dexp(kUu) - 1.0 - kUu * (1.0 + 0.5 * kUu);
         T f = -(ut * (y / nu)) + magUp / ut + (1.0 / E) * (fkUu - (1.0 / 6.0) * kUu * kUu * kUu);

@@ -50,8 +50,9 @@ ROOTVSMALL = 1e-150
 # Spalart-Allmaras constants, reference DASpalartAllmaras.C:47-80
 SA = dict(sigmaNut=0.66666, kappa=0.41, Cb1=0.1355, Cb2=0.622, Cw2=0.3, Cw3=2.0, Cv1=7.1, Cs=0.3)
 SA["Cw1"] = SA["Cb1"] / SA["kappa"] ** 2 + (1.0 + SA["Cb2"]) / SA["sigmaNut"]
-# nutUSpaldingWallFunction defaults (OpenFOAM nutWallFunction: kappa 0.41, E 9.8; maxIter 10)
-WF = dict(kappa=0.41, E=9.8, maxIter=10, tol=1e-14)
+# nutUSpaldingWallFunctionDF (reference ...DF.C:180-181,203-204: maxIter 1000, tolerance 1e-14 - "as accurate as possible
+# boundary values", ...DF.H:32-37; the stock OpenFOAM patch field has maxIter 10); nutWallFunction: kappa 0.41, E 9.8
+WF = dict(kappa=0.41, E=9.8, maxIter=1000, tol=1e-14)
 
 
 # ----------------------------------------------------------------------------- helpers
@@ -160,8 +161,9 @@ def fv1_of(chi):
 def spalding_nut(magUp, magGradU, y, nu):
     """nutUSpaldingWallFunction calcNut/calcUTau (reference ...DF.C:42-150): Newton solve of
     Spalding's law for u_tau per wall face; nut_w = max(0, u_tau^2/(|dU/dn|+ROOTVSMALL) - nu).
-    Start value: laminar seed sqrt(nu*|dU/dn|) (the reference's 'exact restart' variant,
-    :117-118) so that nut_w is a pure function of the state."""
+    Start value: laminar seed sqrt(nu*|dU/dn|) (the reference's 'exact restart' variant, :117-118; the reference seeds with
+    the stored nut_w of the previous call) - with the reference's iteration limit of 1000 and tolerance 1e-14 the iteration
+    runs to the root, so nut_w is a pure function of the state and the seed drops out."""
     kappa, E = WF["kappa"], WF["E"]
     ut = np.sqrt(nu * magGradU)
     active = np.real(ut) > ROOTVSMALL
@@ -176,6 +178,8 @@ def spalding_nut(magUp, magGradU, y, nu):
         err = np.abs(np.real((ut - utn) / ut))
         ut = np.where(done, ut, utn)
         done = done | (np.real(ut) <= ROOTVSMALL) | (err <= WF["tol"])
+        if np.all(done):
+            break
     ut = np.where(active, _max(ut, 0 * ut), 0 * ut)
     return _max(ut * ut / (magGradU + ROOTVSMALL) - nu, 0 * ut)
 

@@ -71,8 +71,8 @@ def test_degenerate_meshes_full_path(dims):
 
 @pytest.mark.parametrize("orth", ["dcgs2", "cgs"])
 def test_unreachable_tolerance_stops_on_stagnation(orth):
-    """gmresRelTol far below the attainable accuracy on a 59-unknown system: the Krylov space is exhausted (happy breakdown),
-    the recomputed true residual sits at rounding level and cannot reach the target.  The solve must neither hang in
+    """gmresRelTol far below the attainable accuracy on a 59-unknown system: the recurrence residual keeps falling (or the
+    Krylov space is exhausted - happy breakdown), the recomputed true residual sits at rounding level and cannot reach the target.  The solve must neither hang in
     one-step cycles up to gmresMaxIters nor blow up: it stops on stagnation (status reason 2) with psi at direct-solve
     accuracy, and the reference's failure rule (DALinearEqn.C:422-434) is applied to what was reached.  The restatement
     oracle.linear.gmres_dcgs2 follows the same rule."""
@@ -86,7 +86,7 @@ def test_unreachable_tolerance_stops_on_stagnation(orth):
     psi, fail = D.solveAdjoint(rhs)
     info, st = D.ksp.info(), D.ksp.status()
     assert relerr(psi, ref) <= 1e-9
-    assert st["reason"] == 2 and st["nBreakdown"] >= 1 and info["iters"] <= 6 * rhs.size, (info, st)
+    assert st["reason"] == 2 and info["iters"] <= 6 * rhs.size, (info, st)
     assert fail == 1 and info["res"] <= 1e-11 * info["res0"]
     # ... and with a reachable tolerance the same system converges with the flag clear
     D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0}, amd={"gmresOrthogonalization": orth})
