@@ -21,6 +21,7 @@
 #include "das_comm.hpp"
 #include "das_block.hpp"
 #include "das_color.hpp"
+#include "das_opmat.hpp"
 
 #include <omp.h>
 
@@ -806,6 +807,7 @@ struct Mat {
     DevBuf<long long> rowptr;
     DevBuf<int> col;
     DevBuf<double> val;
+    VecPack vp;  // packed vector rows of the Krylov operator (das_opmat.hpp); empty for every other matrix
 };
 
 struct KernelTimer {
@@ -1080,7 +1082,17 @@ static void spmv(das_solver* s, const Mat& A, const double* x, double* y) {
     // sharded: ghost rows first (their contributions travel to the owner ranks while the owned rows are computed)
     if (s->halo.active) s->halo.begin(A, x, s->stream);
     s->timer.begin("spmv", s->stream, ev);
-    hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(A.n), dim3(256), 0, s->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y);
+    if (A.vp.ready) {
+        // vector rows as group rows (one column list, three value planes), the scalar rows from the CSR arrays
+        const long long r1 = A.vp.row0 + 3 * A.vp.nGroups;
+        hipLaunchKernelGGL(k_spmv_vec3, dim3((unsigned)((A.vp.nGroups + 15) / 16)), dim3(256), 0, s->stream, A.vp.nGroups, A.vp.row0, A.vp.cptr.p,
+                           A.vp.data.p, x, y);
+        if (A.vp.row0 > 0) hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(A.vp.row0), dim3(256), 0, s->stream, A.vp.row0, A.rowptr.p, A.col.p, A.val.p, x, y);
+        if (A.n > r1)
+            hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(A.n - r1), dim3(256), 0, s->stream, A.n - r1, A.rowptr.p + r1, A.col.p, A.val.p, x, y + r1);
+    } else {
+        hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(A.n), dim3(256), 0, s->stream, A.n, A.rowptr.p, A.col.p, A.val.p, x, y);
+    }
     s->timer.end("spmv", s->stream, ev);
     if (s->halo.active) {
         hipEvent_t eh = nullptr;
@@ -2866,6 +2878,18 @@ int das_initialize_drdwt_matrix_free(das_solver_t* s) {
     DAS_TRY
     need_init(s);
     s->op.reset(assemble(s, 0, (int)s->opt.geti("amd.jacMode")));
+    // the Krylov operator: vector-state rows repacked as group rows (das_opmat.hpp); amd.opPackVector 0 keeps the plain CSR
+    {
+        auto it = s->opt.i.find("amd.opPackVector");
+        const StateDef& s0 = s->st_full.states[0];
+        if ((it == s->opt.i.end() || it->second != 0) && s0.kind == KIND_VEC) {
+            Mat& M = s->op->m;
+            const bool ok = vecpack_build(M.vp, s0.size / 3, s0.offset, M.rowptr.p, M.col.p, M.val.p, s->stream);
+            if (s->opt.geti("debug"))
+                fprintf(stderr, "[dafoam_amd] operator vector rows %s: %lld group rows, %lld chunks, %.2f GB\n",
+                        ok ? "packed" : "NOT packed (rows of a cell differ)", M.vp.nGroups, M.vp.nChunks, M.vp.bytes() / 1e9);
+        }
+    }
     s->op_states = s->h_W;
     s->op_geom = s->geomVersion;
     s->op_epoch = s->opEpoch;

@@ -397,6 +397,39 @@ def test_jac_t_vec_product_and_dot_product_identity():
         D.solverAD.calcJacTVecProduct("x", "volCoord", case.states, "r", "residual", psi, prod)
 
 
+@pytest.mark.parametrize("kind", ["simple", "rho", "renumbered", "compacted"])
+def test_packed_vector_rows_operator_equals_csr(kind):
+    """The Krylov operator stores the U rows as group rows (one column list, three value planes; csrc/das_opmat.hpp): dRdW^T psi
+    through the packed kernels == the plain CSR kernel (amd.opPackVector 0) == the oracle's matrix.  'compacted': a
+    jacLowerBounds filter that removes entries component-wise breaks the shared lists - the operator must fall back."""
+    case = {"simple": lambda: channel_case(9, 7, 6, wall_function=True), "rho": lambda: rho_channel_case(7, 6, 5),
+            "renumbered": lambda: renumber_case(channel_case(8, 7, 5), seed=3), "compacted": lambda: channel_case(7, 6, 5)}[kind]()
+    g = Geometry(case.mesh)
+    extra = {"jacLowerBounds": {"dRdW": 1e-3, "dRdWPC": 1e-30}} if kind == "compacted" else {}
+    sc = J.state_scales(case, g, norm_states(case))
+    con = J.connectivity(case, g)
+    col, _ = J.greedy_coloring(con)
+    A = J.jacobian_colored(case, g, case.states, con, col, sc, mode="cs", lower_bound=0)
+    rng = np.random.default_rng(11)
+    out = {}
+    for pack in (1, 0):
+        D = make(case, amd={"opPackVector": pack}, **extra)
+        D.solver.runColoring()
+        D.solverAD.initializedRdWTMatrixFree()
+        prods = []
+        for _ in range(3):
+            psi = rng.standard_normal(A.shape[0])
+            prod = np.zeros_like(psi)
+            D.solverAD.calcJacTVecProduct("states", "stateVar", case.states, "residuals", "residual", psi, prod)
+            prods.append((psi, prod))
+        out[pack] = prods
+        rng = np.random.default_rng(11)
+    for (psi, p1), (_, p0) in zip(out[1], out[0]):
+        assert relerr(p1, p0) < 1e-14
+        if kind != "compacted":  # entries of the compressible operator span ten orders of magnitude: row-wise bound |A||psi|
+            assert np.all(np.abs(p1 - A @ psi) <= 1e-9 * (abs(A) @ np.abs(psi)) + 1e-9 * np.abs(A.data).max())
+
+
 @pytest.mark.parametrize("wall_function", [False, True])
 def test_adjoint_vector_parity_simplefoam(wall_function):
     case = converged_case((10, 8, 6), wall_function=wall_function, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
@@ -816,6 +849,43 @@ def test_size_independent_properties_bench_size():
     D.solverAD.calcJacTVecProduct("s", "stateVar", W, "r", "residual", psi, chk)
     true_res = np.linalg.norm(chk - rhs)
     assert abs(true_res - info["res"]) <= 1e-6 * info["res0"], (true_res, info)
+
+
+def test_config1_naca0012_200k_cells_drdwtpsi_against_the_oracle_at_size():
+    """BASELINE configs[1] AS STATED: DASimpleFoam + SA on a NACA0012 O-grid of 800 x 250 x 1 = 200 k cells (1.8 M states),
+    `dRdWTPsi vs CPU to 1e-6` - at size, against the ORACLE (not against the GPU itself): the residual, and for random a, v
+        a . (dR/dW (s o v))_oracle  ==  ((dR/dW)^T a)_GPU . v
+    with the left side from ONE complex-step evaluation of the oracle's vectorised numpy residual (no oracle Jacobian is
+    affordable at this size) and the right side from the coloured, assembled, packed operator of the GPU path; tolerance 1e-6
+    (north star), achieved ~1e-10.  The GPU's own forward-mode product is compared with the oracle's vector entry by entry."""
+    from dafoam_amd.meshgen import naca0012_case
+
+    case = naca0012_case(800, 250, 1)
+    assert case.mesh.n_cells == 200000
+    g = Geometry(case.mesh)
+    W = case.states
+    n = W.size
+    D = make(case)
+    R = np.zeros(n)
+    D.solver.getResiduals(R)
+    Ro = residual(case, g, W)
+    for nm, sl in blocks(case, g):
+        assert relerr(R[sl], Ro[sl]) < 1e-10, nm
+    sc = J.state_scales(case, g, NORM_STATES)
+    D.solver.runColoring()
+    D.solverAD.initializedRdWTMatrixFree()
+    for seed in (0, 1):
+        rng = np.random.default_rng(seed)
+        a, v = rng.standard_normal(n), rng.standard_normal(n)
+        Jv_o = residual(case, g, W + 1j * 1e-30 * (sc * v)).imag / 1e-30
+        pa = np.zeros(n)
+        D.solverAD.calcJacTVecProduct("s", "stateVar", W, "r", "residual", a, pa)
+        lhs, rhs_ = a @ Jv_o, pa @ v
+        assert abs(lhs - rhs_) <= 1e-6 * np.linalg.norm(a) * np.linalg.norm(Jv_o) / np.sqrt(n), (lhs, rhs_)
+        assert abs(lhs - rhs_) <= 1e-9 * abs(lhs), (lhs, rhs_)
+        Jv = np.zeros(n)
+        D.solver.calcJacVecProduct(v, Jv)
+        assert relerr(Jv, Jv_o) < 1e-9
 
 
 def test_naca0012_ogrid_residual_jacobian_adjoint():
