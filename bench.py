@@ -212,8 +212,11 @@ def main():
     # ---- algorithmic bytes (SURVEY.md section 8d / BASELINE.md section 3) ---------------------------------------------
     opmat_nnz = int(L.das_get_con_nnz(h, 0))
     op_nnz = int(L.das_op_nnz(h))  # the operator drops exact zeros (jacLowerBounds 1e-30): its true nnz
-    spmv_bytes = 12.0 * op_nnz + 4.0 * (n + 1) + 16.0 * n
+    spmv_bytes = 12.0 * op_nnz + 4.0 * (n + 1) + 16.0 * n  # SURVEY.md 8(d) / BASELINE.md: the CSR formula, kept as THE algorithmic figure
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms and spmv_ms > 0 else None
+    # what the operator's storage format really streams (vector rows packed: one column list + three value planes per group row)
+    fmt_bytes = float(L.das_op_format_bytes(h)) + 16.0 * n
+    fmt_GBps = fmt_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms and spmv_ms > 0 else None
     fac_entries = int(L.das_ksp_get_factor_nnz(ksp.handle))
     n_ext = int(L.das_ksp_get_n_ext(ksp.handle))
     if a.pctype == "bilu":
@@ -264,10 +267,9 @@ def main():
             "RAS(overlap 1)+ILU(1) of FD dRdWTPC, RCB blocks of <= 1024 cells, one workgroup per block"
         out = {
             "metric": "adjoint_gmres_iterations_per_sec",
-            # whole-job aggregate: every rank advances its shard through `steps` GMRES iterations of ONE global solve
-            # (weak scaling: N x more cells per iteration), so the job processes world * steps shard-iterations; at N = 1
-            # this is the plain iterations/s of the solve.  config.global_solve_iterations_per_sec is steps / time.
-            "value": world * a.steps * 1.0 / dt,
+            # iterations/s of the ONE global adjoint solve all N ranks advance together (weak scaling: N x more cells per
+            # iteration, so flat is ideal); config.cell_iterations_per_sec = global cells x iterations/s is the whole-job work rate
+            "value": a.steps * 1.0 / dt,
             "unit": "iter/s",
             "n_gpus": world,
             "steps": a.steps,
@@ -285,7 +287,8 @@ def main():
                 "cells_per_gpu": ncell,
                 "global_cells": ncell * world,
                 "global_solve_iterations_per_sec": a.steps * 1.0 / dt,
-                "aggregation": "value = n_gpus x global_solve_iterations_per_sec (iterations/s per shard summed over the shards of one global solve)",
+                "cell_iterations_per_sec": ncell * world * a.steps * 1.0 / dt,
+                "aggregation": "value = iterations/s of the one global solve (weak scaling: flat = ideal); cell_iterations_per_sec = global cells x value",
                 "states_per_gpu": n,
                 "dRdWT_nnz": op_nnz,
                 "dRdWT_structural_nnz": opmat_nnz,
@@ -303,6 +306,7 @@ def main():
                                   "pc_factorisation_and_coarse_space": t_pc, "dRdWT_dual_gpu": t_op,
                                   "synthetic_mesh_and_state_generation_python": t_case},
                 "dRdWTPsi_GBps": achieved,
+                "dRdWTPsi_GBps_of_format_bytes": fmt_GBps,
                 "spmv_ms": spmv_ms,
                 "pc_apply_ms": pc_ms,
                 "window_rel_residual": win_info["res"] / win_info["res0"] if win_info["res0"] else None,
@@ -310,15 +314,18 @@ def main():
                 "primal_newton_krylov": primal,
             },
             "roofline": {
-                "kernel": "k_spmv_wave (dRdW^T.psi, transposed CSR fp64/int32)",
+                "kernel": "k_spmv_vec3 + k_spmv_wave (dRdW^T.psi: U rows as packed group rows, scalar rows as CSR; fp64 values, int32 columns)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                "traffic": pmc_traffic(op_nnz, "k_spmv_wave"),  # separate rocprofv3 --pmc passes, committed under profiles/
+                "traffic": pmc_traffic(op_nnz, "spmv"),  # separate rocprofv3 --pmc passes, committed under profiles/
                 "launches_timed": int(spmv_cnt),
                 "algorithmic_bytes_per_launch": spmv_bytes,
+                "algorithmic_formula": "12 nnz + 4 (n+1) + 16 n (SURVEY.md 8d: CSR fp64 + int32)",
+                "format_bytes_per_launch": fmt_bytes,
+                "frac_of_format_bytes": (fmt_GBps / HBM_PEAK_GBS) if fmt_GBps else None,
             },
             "roofline_pc": {
                 "kernel": "k_bilu_sweep x2 (forward + backward node-block sweeps)" if a.pctype == "bilu" else "k_ras_apply",
@@ -332,15 +339,16 @@ def main():
             },
             "roofline_iteration": {
                 "bound": "hbm",
-                "algorithmic_bytes_per_step": iter_bytes,
-                "formula": "B_spmv + B_pc + 32 j n + 48 n at the mean j of the window (BASELINE.md section 3: Gram-Schmidt with refinement, 4 basis reads)",
-                "achieved": iter_bytes / (ms_step * 1e-3) / 1e9,
+                "algorithmic_bytes_per_step": moved_bytes,
+                "formula": "B_spmv + B_pc + 16 j n + 48 n at the mean j of the window: what this implementation moves (delayed re-orthogonalisation = 2 basis reads per iteration)"
+                           if orth == "dcgs2" else "B_spmv + B_pc + 32 j n + 48 n (CGS with refinement: 4 basis reads)",
+                "achieved": moved_bytes / (ms_step * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": iter_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "frac": moved_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "orthogonalization": orth,
-                "bytes_moved_model_per_step": moved_bytes,
-                "frac_of_bytes_moved_model": moved_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "baseline_md_model_bytes_per_step": iter_bytes,
+                "frac_of_baseline_md_model": iter_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
             "cpu_baseline": cpu,
         }

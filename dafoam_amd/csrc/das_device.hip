@@ -307,7 +307,21 @@ __global__ __launch_bounds__(256) void k_spmv_wave(long long n, const long long*
 #pragma unroll
         for (int u = 0; u < SPMV_UNROLL; u++) acc[u] += vv[u] * x[cc[u]];
     }
-    for (; k < e; k += SPMV_LANES) acc[0] += v[k] * x[ci[k]];
+    // tail (and the whole of a short row - the phi rows hold ~31 entries): the same SPMV_UNROLL loads in flight, clamped to the
+    // last entry of the row and masked, instead of a serial loop with one load per round trip
+    if (k - lane < e) {
+        double vv[SPMV_UNROLL];
+        int cc[SPMV_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SPMV_UNROLL; u++) {
+            const long long kk = k + u * SPMV_LANES;
+            const long long kc = kk < e ? kk : e - 1;
+            vv[u] = kk < e ? v[kc] : 0.0;
+            cc[u] = ci[kc];
+        }
+#pragma unroll
+        for (int u = 0; u < SPMV_UNROLL; u++) acc[u] += vv[u] * x[cc[u]];
+    }
     double sacc = acc[0];
 #pragma unroll
     for (int u = 1; u < SPMV_UNROLL; u++) sacc += acc[u];
@@ -1649,6 +1663,10 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     const Mat& A = k->pcmat->m;
     const int reach = pc_stencil_reach(s);
     const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
+    {
+        auto it = s->opt.i.find("amd.pcSweepDesign");  // 1: ticket per workgroup, 2: ticket per wave, software-pipelined (das_bilu.hpp)
+        k->bilu.sweepDesign = (it != s->opt.i.end() && it->second == 2) ? 2 : 1;
+    }
     bilu_setup(s->mesh, s->st_full.states, s->n, s->owned, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
                k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s), k->pcTranspose, k->pcDiagScale);
     k->useBilu = true;
@@ -3098,6 +3116,13 @@ static void function_gradient(das_solver* s, const char* name, double seed, doub
 }
 
 long long das_op_nnz(das_solver_t* s) { return (s && s->op) ? s->op->m.nnz : -1; }
+// bytes of matrix data one dRdW^T.psi product streams in the operator's storage format (packed vector rows + CSR scalar rows)
+long long das_op_format_bytes(das_solver_t* s) {
+    if (!s || !s->op) return -1;
+    const Mat& M = s->op->m;
+    if (!M.vp.ready) return 12LL * M.nnz + 8LL * (M.n + 1);
+    return M.vp.bytes() + 12LL * (M.nnz - M.vp.csrEntries) + 8LL * (M.n - 3 * M.vp.nGroups + 1);
+}
 
 // ---- boundary-value inputs (reference DAInputPatchVelocity.C:33-135, DAInputPatchVar.C) ---------------------------
 static int bc_field_id(const char* field) {

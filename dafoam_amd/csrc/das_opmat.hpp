@@ -23,10 +23,11 @@ constexpr int VP_CHUNK_BYTES = 64 + 3 * 16 * 8;  // 448
 struct VecPack {
     bool ready = false;
     long long nGroups = 0, nChunks = 0, row0 = 0;  // vector rows are row0 + 3 g + d
+    long long csrEntries = 0;                      // entries of the CSR rows this pack replaces
     DevBuf<long long> cptr;                        // nGroups + 1 chunk offsets
     DevBuf<unsigned char> data;                    // nChunks * VP_CHUNK_BYTES
     long long bytes() const { return nChunks * (long long)VP_CHUNK_BYTES + (nGroups + 1) * 8; }
-    void release() { cptr.release(); data.release(); ready = false; nGroups = nChunks = 0; }
+    void release() { cptr.release(); data.release(); ready = false; nGroups = nChunks = csrEntries = 0; }
 };
 
 // chunks per group row, and: do the three rows share one column list?  (16 lanes per group)
@@ -96,11 +97,22 @@ __global__ __launch_bounds__(256) void k_spmv_vec3(long long nG, long long row0,
             a0 += v0[u] * xx; a1 += v1[u] * xx; a2 += v2[u] * xx;
         }
     }
-    for (; ch < c1; ch++) {
-        const unsigned char* base = data + ch * VP_CHUNK_BYTES;
-        const double xx = x[reinterpret_cast<const int*>(base)[lane]];
-        const double* vv = reinterpret_cast<const double*>(base + 64);
-        a0 += vv[lane] * xx; a1 += vv[16 + lane] * xx; a2 += vv[32 + lane] * xx;
+    if (ch < c1) {  // tail: the remaining 1..VP_UNROLL-1 chunks requested together (clamped to the last chunk, masked)
+        int cc[VP_UNROLL];
+        double v0[VP_UNROLL], v1[VP_UNROLL], v2[VP_UNROLL];
+#pragma unroll
+        for (int u = 0; u < VP_UNROLL - 1; u++) {
+            const bool in = ch + u < c1;
+            const unsigned char* base = data + (in ? ch + u : c1 - 1) * VP_CHUNK_BYTES;
+            cc[u] = reinterpret_cast<const int*>(base)[lane];
+            const double* vv = reinterpret_cast<const double*>(base + 64);
+            v0[u] = in ? vv[lane] : 0.0; v1[u] = in ? vv[16 + lane] : 0.0; v2[u] = in ? vv[32 + lane] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < VP_UNROLL - 1; u++) {
+            const double xx = x[cc[u]];
+            a0 += v0[u] * xx; a1 += v1[u] * xx; a2 += v2[u] * xx;
+        }
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) {
@@ -128,6 +140,12 @@ inline bool vecpack_build(VecPack& P, long long nG, long long row0, const long l
     std::vector<long long> cp(nG + 1, 0);
     for (long long g = 0; g < nG; g++) cp[g + 1] = cp[g] + h[g];
     P.nGroups = nG; P.row0 = row0; P.nChunks = cp[nG];
+    {
+        long long e[2] = {0, 0};
+        DAS_HIP(hipMemcpy(&e[0], d_rp + row0, sizeof(long long), hipMemcpyDeviceToHost));
+        DAS_HIP(hipMemcpy(&e[1], d_rp + row0 + 3 * nG, sizeof(long long), hipMemcpyDeviceToHost));
+        P.csrEntries = e[1] - e[0];
+    }
     P.cptr.upload(cp);
     P.data.alloc((size_t)std::max<long long>(1, P.nChunks) * VP_CHUNK_BYTES);
     hipLaunchKernelGGL(k_vecpack_fill, dim3((unsigned)((nG + 15) / 16)), dim3(256), 0, st, nG, row0, d_rp, d_ci, d_v, P.cptr.p, P.data.p);

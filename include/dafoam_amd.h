@@ -210,6 +210,9 @@ int das_initialize_drdwt_matrix_free(das_solver_t* s);
 int das_destroy_drdwt_matrix_free(das_solver_t* s);
 /* nnz of the assembled matrix-free operator (after the jacLowerBounds filter), -1 if not initialised */
 long long das_op_nnz(das_solver_t* s);
+/* bytes of matrix data one dRdW^T.psi product streams in the operator's storage format: vector-state rows packed as group
+ * rows (one int32 column list + three fp64 value planes per 16 entries, csrc/das_opmat.hpp), scalar rows as CSR (12 B/entry) */
+long long das_op_format_bytes(das_solver_t* s);
 
 /* ---- unsteady adjoint terms (DAScalarTransportFoam, BASELINE configs[0]) ---------------------------------------------
  * das_calc_drdwold_t_psi <- calcdRdWOldTPsiAD(oldTimeLevel, psi, dRdWOldTPsi)  pyDASolvers.pyx:240 (DASolver.C:1910-1969):
