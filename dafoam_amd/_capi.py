@@ -252,6 +252,7 @@ _SIGS = {
     "das_ksp_get_n_refine": (C.c_int, [_VP]),
     "das_ksp_get_status": (C.c_int, [_VP, c_int_p, c_int_p, c_int_p, c_int_p]),
     "das_ksp_get_coarse": (C.c_int, [_VP, c_int_p]),
+    "das_ksp_set_global_coarse": (C.c_int, [_VP, _VP, C.c_int, C.c_int, c_int_p]),
     "das_ksp_run_fixed_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),
     "das_ksp_begin_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),
     "das_ksp_advance": (C.c_int, [_VP, _VP, C.c_int]),

@@ -234,145 +234,13 @@ __global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep(BiluView P, co
     }
 }
 
-// ---- sweep, second design: one ticket per WAVE, drawn two nodes ahead; row extent and first pass of the next node requested
-// while the current node is in flight.  Measured on the first design (k_bilu_sweep) at 2 M cells: fp32 factors (half the bytes)
-// run in the same time - the sweeps are not bandwidth-bound but latency x occupancy bound: a node costs a chain of dependent
-// round trips (ticket -> row extent -> column / blocks -> dependency poll -> next pass ...), ~5 us, and 4096 resident waves
-// deliver 2.3 M nodes in ~3 ms.  Here the chain of a node is only poll -> reduce -> publish: the ticket of node k+2, the row
-// extent of node k+1 and the first pass of node k+1 travel while node k waits for its dependencies.  No workgroup barrier, no
-// LDS: the eight waves of a workgroup are independent.  Processing order and deadlock freedom as before: tickets are drawn in
-// increasing order; a wave that holds a ticket ahead of time works on a LOWER one, so the lowest unfinished node is always in
-// progress.  (The per-workgroup look-ahead rejected in round 2 coupled eight waves by a barrier per node.)
-template <class VT, bool UPPER>
-__global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep_w(BiluView P, const double* __restrict__ b, double* __restrict__ out, int sleepReps,
-                                                                     int perXcd) {
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 3, k = lane & 7;
-    const long long* __restrict__ ptr = P.ptr[UPPER ? 1 : 0];
-    const int* __restrict__ col = P.col[UPPER ? 1 : 0];
-    const VT* __restrict__ val = reinterpret_cast<const VT*>(sizeof(VT) == 4 ? (const void*)P.valf[UPPER ? 1 : 0] : (const void*)P.val[UPPER ? 1 : 0]);
-    double* xs = UPPER ? P.z : P.y;
-    const unsigned xcd = perXcd ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0u;
-    unsigned* ctr = &P.ctrl[((UPPER ? 8 : 0) + xcd) * BILU_CTRL_STRIDE];
-    const long long nN = P.nNodes;
-    auto draw = [&]() -> long long {
-        unsigned t = 0u;
-        if (lane == 0)
-            t = perXcd ? __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                       : __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = __builtin_amdgcn_readfirstlane(t);
-        return perXcd ? (long long)t * 8 + xcd : (long long)t;
-    };
-    auto load_pass = [&](long long e0, int nE, int a0, double (&vv)[8], int& cc) {
-        const int nb = min(8, nE - a0);
-        if (g < nb) {
-            cc = col[e0 + a0 + g];
-            const VT* base = val + (e0 + a0) * BILU_NB2;
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) bilu_load_pair<VT>(base + ((qq * nb + g) * 8 + k) * 2, vv[2 * qq], vv[2 * qq + 1]);
-        }
-    };
-    // pipeline state: node q (current), q1 (next: row extent requested / known), q2 (ticket drawn)
-    long long q = draw();
-    if (q >= nN) return;
-    long long q1 = draw();
-    long long e0 = ptr[q];
-    int nE = (int)(ptr[q + 1] - e0);
-    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int c = 0;
-    if (nE > 0) load_pass(e0, nE, 0, v, c);
-    for (;;) {
-        // requests for the nodes behind the current one (none of them depends on the solution)
-        const long long q2 = draw();
-        const bool has1 = q1 < nN;
-        const long long e1b = has1 ? ptr[q1] : 0, e1e = has1 ? ptr[q1 + 1] : 0;
-        const long long p = UPPER ? nN - 1 - q : q;
-        int gi;
-        double rhs, dinv = 0.0;
-        if (!UPPER) {
-            gi = P.nodeUnk[p * BILU_NB + g];
-            rhs = gi >= 0 ? b[gi] : 0.0;
-        } else {
-            gi = P.nodeUnk[p * BILU_NB + k];
-            rhs = P.y[p * BILU_NB + g];
-            dinv = P.invD[p * BILU_NB2 + k * 8 + g];
-        }
-        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        double vn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int cn = 0, c1 = 0;
-        const int nE1 = (int)(e1e - e1b);
-        bool sent1 = false;
-        for (int a0 = 0; a0 < nE || !sent1; a0 += 8) {
-            const bool last = a0 + 8 >= nE;
-            if (!last) load_pass(e0, nE, a0 + 8, vn, cn);
-            else if (!sent1) { if (has1 && nE1 > 0) load_pass(e1b, nE1, 0, v1, c1); sent1 = true; }  // first pass of the NEXT node
-            if (a0 >= nE) break;  // a node without dependencies only forwards the requests
-            const bool act = g < min(8, nE - a0);
-            const double* xp = xs + (long long)c * BILU_NB + k;
-            unsigned long long xb = 0ull;
-            unsigned spins = 0;
-            for (;;) {
-                bool ok = true;
-                if (act) { xb = bilu_load_sc1(xp); ok = xb != BILU_SENTINEL; }
-                if (__all(ok)) break;
-                for (int w = 0; w < sleepReps; w++) __builtin_amdgcn_s_sleep(2);
-                if ((++spins & 1023u) == 0u) {
-                    const unsigned ab = __hip_atomic_load(&P.ctrl[BILU_CTRL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (ab != 0u || spins >= BILU_SPIN_LIMIT) {
-                        if (lane == 0) __hip_atomic_store(&P.ctrl[BILU_CTRL_ABORT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        return;
-                    }
-                }
-            }
-            if (act) {
-                const double xk = __longlong_as_double((long long)xb);
-#pragma unroll
-                for (int r = 0; r < 8; r++) acc[r] += v[r] * xk;
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) v[r] = vn[r];
-            c = cn;
-        }
-        double a4[4], a2[2], a1;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const double snd = (g & 4) ? acc[i] : acc[i + 4], keep = (g & 4) ? acc[i + 4] : acc[i];
-            a4[i] = keep + __shfl_xor(snd, 32, 64);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const double snd = (g & 2) ? a4[i] : a4[i + 2], keep = (g & 2) ? a4[i + 2] : a4[i];
-            a2[i] = keep + __shfl_xor(snd, 16, 64);
-        }
-        {
-            const double snd = (g & 1) ? a2[0] : a2[1], keep = (g & 1) ? a2[1] : a2[0];
-            a1 = keep + __shfl_xor(snd, 8, 64);
-        }
-        a1 += __shfl_xor(a1, 1, 64);
-        a1 += __shfl_xor(a1, 2, 64);
-        a1 += __shfl_xor(a1, 4, 64);
-        if (!UPPER) {
-            if (k == 0) bilu_store_sc1(&P.y[p * BILU_NB + g], rhs - a1);
-        } else {
-            double w = dinv * (rhs - a1);
-            w += __shfl_xor(w, 8, 64);
-            w += __shfl_xor(w, 16, 64);
-            w += __shfl_xor(w, 32, 64);
-            if (g == 0) {
-                bilu_store_sc1(&P.z[p * BILU_NB + k], w);
-                if (gi >= 0) out[gi] = w;
-            }
-        }
-        // advance the pipeline
-        if (!has1) return;
-        q = q1; q1 = q2;
-        e0 = e1b; nE = nE1;
-#pragma unroll
-        for (int r = 0; r < 8; r++) v[r] = v1[r];
-        c = c1;
-    }
-}
-
+// (Round 3, measured and dropped - profiles/r03f_*: a second design with one ticket per WAVE drawn two nodes ahead and the row
+// extent / first pass of the next node requested while the current one waits for its dependencies, no workgroup barrier.
+// Parity-clean, but slower everywhere: 1.40 -> 1.97 ms at 200 k cells, 4.56 -> 7.15 ms on the 200 k-cell NACA0012 O-grid,
+// 6.36 -> 10.3 ms at 2 M cells.  Eight times the tickets means eight times the atomics on the same eight addresses, and a
+// contended L2 atomic retires every ~17 ns: 290 k tickets per XCD and sweep at 2 M cells = 5 ms.  Together with the fp32
+// result (half the factor bytes, same time) this fixes the picture of the sweeps: neither bandwidth nor the per-node load
+// chain bounds them, the ticket rate and the dependent hops do; 8 nodes per ticket is the measured optimum.)
 // scalar CSR (rows = states, 16 lanes per row) -> dense node blocks (row-major 8x8 per block entry)
 __global__ __launch_bounds__(256) void k_bilu_scatter(long long n, const long long* __restrict__ rp, const int* __restrict__ ci,
                                                       const double* __restrict__ v, const int* __restrict__ unkNode,
@@ -525,7 +393,6 @@ struct NodeILU {
     bool fp32 = false;
     double windowLevels = 3.0;  // levels kept in flight by the sweeps (launch shape; measured optimum at 200 k cells)
     int launchGrid = 0, launchSleep = 0, launchPerXcd = 0;  // launch shape of the sweeps, fixed by bilu_setup (bilu_launch_shape)
-    int sweepDesign = 1;                                    // 1: ticket per workgroup (k_bilu_sweep), 2: per wave, pipelined (k_bilu_sweep_w)
     // host copies (tests / introspection)
     std::vector<int> h_nodeUnk, h_bcol, h_lvlPtr, h_natural;  // h_natural[p] = natural (cell-order) index of the node at position p
     std::vector<long long> h_bptr;
@@ -871,15 +738,6 @@ inline void bilu_launch_shape(NodeILU& P, hipStream_t st) {
     // per-XCD ticket counters only where every XCD is certain to run workgroups of the launch (see k_bilu_sweep)
     int perXcd = (BILU_XCD_TICKETS && grid >= 64 && bilu_xcd_probe(st) == 8) ? 1 : 0;
     if (const char* e = getenv("DAS_BILU_XCD")) perXcd = (atoi(e) != 0 && grid >= 64 && bilu_xcd_probe(st) == 8) ? 1 : 0;
-    if (const char* e = getenv("DAS_BILU_SWEEP")) P.sweepDesign = atoi(e) == 2 ? 2 : 1;
-    if (P.sweepDesign == 2) {
-        // per-wave tickets: all resident waves draw; the grid is what fits the device (no workgroup is ever idle-queued)
-        grid = std::min(grid, cus * (BILU_OCC * 4 / waves));
-        if (const char* e = getenv("DAS_BILU_WGS")) grid = std::max(1, atoi(e));
-        grid = (int)std::min<long long>(grid, (long long)(P.nNodes + waves - 1) / waves + 1);
-        perXcd = (BILU_XCD_TICKETS && grid >= 64 && bilu_xcd_probe(st) == 8) ? 1 : 0;
-        if (const char* e = getenv("DAS_BILU_XCD")) perXcd = (atoi(e) != 0 && grid >= 64 && bilu_xcd_probe(st) == 8) ? 1 : 0;
-    }
     P.launchGrid = grid; P.launchSleep = sleepReps; P.launchPerXcd = perXcd;
 }
 
@@ -888,16 +746,6 @@ inline void bilu_apply(NodeILU& P, const double* b, double* out, hipStream_t st)
     const long long nslots = (long long)P.nNodes * BILU_NB;
     hipLaunchKernelGGL(k_bilu_reset, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, P.y.p, P.z.p, P.ctrl.p);
     const int grid = P.launchGrid, sl = P.launchSleep, px = P.launchPerXcd;
-    if (P.sweepDesign == 2) {
-        if (P.fp32) {
-            hipLaunchKernelGGL((k_bilu_sweep_w<float, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
-            hipLaunchKernelGGL((k_bilu_sweep_w<float, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
-        } else {
-            hipLaunchKernelGGL((k_bilu_sweep_w<double, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
-            hipLaunchKernelGGL((k_bilu_sweep_w<double, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
-        }
-        return;
-    }
     if (P.fp32) {
         hipLaunchKernelGGL((k_bilu_sweep<float, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
         hipLaunchKernelGGL((k_bilu_sweep<float, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);

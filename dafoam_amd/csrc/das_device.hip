@@ -548,21 +548,32 @@ __global__ void k_newton_update(long long n, long long n0, long long n1, double 
 // Nicolaides-type coarse space - one unknown per aggregate of cells, acting on the p / pRes entries only - removes that
 // growth: M^-1 = ILU^-1 + Z E^-1 Z^T (additive) or ILU^-1 (I - A Z E^-1 Z^T) + Z E^-1 Z^T (deflated, A-DEF1), with
 // E = Z^T P Z assembled from jacPCMat on the device and inverted on the host (nAgg <= 2048).
-__global__ void k_coarse_assemble(long long N, long long off, const long long* __restrict__ rp, const int* __restrict__ ci,
-                                  const double* __restrict__ v, const int* __restrict__ agg, int nagg, double* __restrict__ E, int transpose,
-                                  double diagScale) {
-    // 16 lanes per matrix row of the field block: E[agg(row)][agg(col)] += a_ij for columns inside the field block
-    const long long c = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (c >= N) return;
-    const int I = agg[c];
-    if (I < 0) return;
-    const long long row = off + c;
-    for (long long k = rp[row] + (threadIdx.x & 15); k < rp[row + 1]; k += 16) {
-        const long long j = (long long)ci[k] - off;
-        if (j < 0 || j >= N) continue;
-        const int J = agg[j];
-        if (J >= 0) atomicAdd(transpose ? &E[(long long)J * nagg + I] : &E[(long long)I * nagg + J], (j == c) ? v[k] * diagScale : v[k]);
+// E[I][J] = sum of the field-block entries a_ij with i in aggregate I, j in aggregate J - DETERMINISTIC (the
+// atomicAdd version summed in arrival order, so E - and with it every iterate - differed in the last bits from run to run):
+// one workgroup per row aggregate I walks the rows of its cells in list order; thread t owns the target columns J = t (mod 256)
+// and is the only one that ever adds to them (LDS row of nagg doubles), so every E[I][J] is summed in the same order every time.
+// aggRow: aggregate of a ROW cell (owned and - multi-GPU, global coarse space - ghost cells), aggCol: aggregate of a COLUMN
+// cell (owned residuals only: the matrix holds no other columns); cellsAll / aptrAll: the row cells sorted by aggregate.
+__global__ __launch_bounds__(256) void k_coarse_assemble(int nagg, const long long* __restrict__ aptrAll, const int* __restrict__ cellsAll, long long N,
+                                                         long long off, const long long* __restrict__ rp, const int* __restrict__ ci,
+                                                         const double* __restrict__ v, const int* __restrict__ aggCol, double* __restrict__ E,
+                                                         int transpose, double diagScale) {
+    __shared__ double accs[2048];
+    const int I = blockIdx.x, t = threadIdx.x;
+    const long long q0 = aptrAll[I], q1 = aptrAll[I + 1];
+    if (q0 == q1) return;  // no row cell of this aggregate on this rank: the row of E stays zero here
+    for (int J = t; J < nagg; J += 256) accs[J] = 0.0;
+    for (long long q = q0; q < q1; q++) {
+        const long long c = cellsAll[q];
+        const long long row = off + c;
+        for (long long k = rp[row]; k < rp[row + 1]; k++) {
+            const long long j = (long long)ci[k] - off;
+            if (j < 0 || j >= N) continue;
+            const int J = aggCol[j];
+            if (J >= 0 && (J & 255) == t) accs[J] += (j == c) ? v[k] * diagScale : v[k];
+        }
     }
+    for (int J = t; J < nagg; J += 256) E[transpose ? (long long)J * nagg + I : (long long)I * nagg + J] = accs[J];
 }
 // dense inverse of the coarse operator by Gauss-Jordan with partial pivoting on the device (n <= 2048): per pivot column
 // one single-workgroup kernel (pivot search, row swap, row scaling) and one elimination kernel (one workgroup per row)
@@ -607,7 +618,7 @@ __global__ __launch_bounds__(256) void k_gj_elim(int n, int k, double* __restric
 }
 // t[I] = sum of r over the field entries of aggregate I (cells sorted by aggregate: deterministic, one workgroup each)
 __global__ __launch_bounds__(256) void k_coarse_restrict(const long long* __restrict__ aptr, const int* __restrict__ cells, long long off,
-                                                         const double* __restrict__ r, double* __restrict__ t) {
+                                                         const double* __restrict__ r, double* __restrict__ t) {  // t: first OWN aggregate
     __shared__ double red[4];
     const int I = blockIdx.x;
     double acc = 0.0;
@@ -906,12 +917,16 @@ struct das_ksp {
     double pcDiagScale = 1.0;   // 1 + 1/tau on the diagonal (pseudo-transient shift)
     struct CoarsePC {
         bool active = false, deflated = false;
-        int nagg = 0;
+        bool global = false;        // multi-GPU: ONE coarse space over all ranks (das_ksp_set_global_coarse), else per rank
+        int nagg = 0;               // aggregates of this rank's owned cells
+        int naggG = 0, aggOff = 0;  // size of the coarse operator and the first own aggregate in it (single rank: nagg, 0)
         long long off = 0, N = 0;
-        DevBuf<int> agg, cells;
-        DevBuf<long long> aptr;
+        DevBuf<int> agg;            // per cell: aggregate in the coarse operator for OWNED cells, -1 otherwise (prolongation, columns of E)
+        DevBuf<int> aggRow;         // per cell: aggregate for owned AND ghost cells (rows of E); single rank: same as agg
+        DevBuf<int> cells, cellsAll;
+        DevBuf<long long> aptr, aptrAll;  // own aggregates (restriction) / all aggregates with local row cells (assembly)
         DevBuf<double> Einv, t, u, c, rr;
-        std::vector<int> h_agg;
+        std::vector<int> h_agg;     // local aggregate of every cell (-1: not owned), as handed out by das_ksp_get_coarse
     } coarse;
     int restart = 0;
     DevBuf<double> V, w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
@@ -1663,10 +1678,6 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     const Mat& A = k->pcmat->m;
     const int reach = pc_stencil_reach(s);
     const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
-    {
-        auto it = s->opt.i.find("amd.pcSweepDesign");  // 1: ticket per workgroup, 2: ticket per wave, software-pipelined (das_bilu.hpp)
-        k->bilu.sweepDesign = (it != s->opt.i.end() && it->second == 2) ? 2 : 1;
-    }
     bilu_setup(s->mesh, s->st_full.states, s->n, s->owned, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
                k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s), k->pcTranspose, k->pcDiagScale);
     k->useBilu = true;
@@ -1674,6 +1685,57 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     k->pc.nBlocks = 1;
     k->pc.fnnz = (k->bilu.nL + k->bilu.nU + k->bilu.nNodes) * (long long)BILU_NB2;
     k->pc.next = (long long)k->bilu.nNodes * BILU_NB;
+}
+
+// E = Z^T P Z and its dense inverse for a coarse space of naggG aggregates of which [aggOff, aggOff + C.nagg) are this rank's;
+// aggRowG[cell] = aggregate of every local cell that belongs to one (owned cells: aggOff + local id; multi-GPU ghost cells: the
+// owner rank's numbering; -1: none).  With naggG > C.nagg the contributions of all ranks are summed (all-reduce) and every
+// rank inverts the same matrix.
+static void coarse_build_operator(das_solver* s, das_ksp* k, int naggG, int aggOff, const std::vector<int>& aggRowG) {
+    das_ksp::CoarsePC& C = k->coarse;
+    C.active = false;
+    DAS_CHECK(naggG >= C.nagg && naggG <= 2048, DAS_ERR_ARG, "coarse space: at most 2048 aggregates in total (dense inverse)");
+    const long long N = C.N;
+    std::vector<int> aggOwn(N, -1);
+    for (long long c = 0; c < N; c++) if (C.h_agg[c] >= 0) aggOwn[c] = aggOff + C.h_agg[c];
+    std::vector<long long> aptrAll(naggG + 1, 0);
+    for (long long c = 0; c < N; c++) if (aggRowG[c] >= 0) aptrAll[aggRowG[c] + 1]++;
+    for (int a = 0; a < naggG; a++) aptrAll[a + 1] += aptrAll[a];
+    std::vector<int> cellsAll(aptrAll[naggG]);
+    {
+        std::vector<long long> pos(aptrAll.begin(), aptrAll.end() - 1);
+        for (long long c = 0; c < N; c++) if (aggRowG[c] >= 0) cellsAll[pos[aggRowG[c]]++] = (int)c;
+    }
+    C.naggG = naggG; C.aggOff = aggOff; C.global = naggG > C.nagg;
+    C.agg.upload(aggOwn); C.aggRow.upload(aggRowG); C.cellsAll.upload(cellsAll); C.aptrAll.upload(aptrAll);
+    DevBuf<double> E((size_t)naggG * naggG);
+    E.zero();
+    const Mat& P = k->pcmat->m;
+    // rows: cells of every aggregate present on this rank (transposed storage: rows = states); columns: owned residual cells
+    hipLaunchKernelGGL(k_coarse_assemble, dim3(naggG), dim3(256), 0, s->stream, naggG, C.aptrAll.p, C.cellsAll.p, N, C.off, P.rowptr.p, P.col.p, P.val.p,
+                       k->pcTranspose ? C.aggRow.p : C.agg.p, E.p, k->pcTranspose ? 1 : 0, k->pcDiagScale);
+    if (C.global) {
+        DAS_CHECK(!k->pcTranspose, DAS_ERR_ARG, "global coarse space: adjoint preconditioner only");
+        if (!(s->halo.active && s->halo.allreduce(E.p, naggG * naggG, s->stream)) && s->allreduce_cb) s->allreduce_cb(E.p, naggG * naggG, s->comm_user);
+    }
+    // E^-1 on the device (Gauss-Jordan, partial pivoting)
+    {
+        std::vector<double> I0((size_t)naggG * naggG, 0.0);
+        for (int i = 0; i < naggG; i++) I0[(size_t)i * naggG + i] = 1.0;
+        C.Einv.upload(I0);
+        DevBuf<int> sing(1);
+        DAS_HIP(hipMemsetAsync(sing.p, 0, sizeof(int), s->stream));
+        for (int kk = 0; kk < naggG; kk++) {
+            hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s->stream, naggG, kk, E.p, C.Einv.p, sing.p);
+            hipLaunchKernelGGL(k_gj_elim, dim3(naggG), dim3(256), 0, s->stream, naggG, kk, E.p, C.Einv.p);
+        }
+        int hs = 0;
+        DAS_HIP(hipMemcpyAsync(&hs, sing.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        DAS_HIP(hipStreamSynchronize(s->stream));
+        if (hs) return;  // singular coarse operator: no coarse correction
+    }
+    C.t.alloc(naggG); C.u.alloc(naggG);
+    C.active = true;
 }
 
 // coarse space of the two-level preconditioner (amd.pcCoarseAggregates: 0 = off, -1 = automatic): RCB aggregates of the owned
@@ -1729,39 +1791,20 @@ static void setup_coarse(das_solver* s, das_ksp* k) {
         for (long long c = 0; c < N; c++) if (agg[c] >= 0) cells[pos[agg[c]]++] = (int)c;
     }
     C.nagg = nagg; C.off = sd->offset; C.N = N; C.h_agg = agg;
-    C.agg.upload(agg); C.cells.upload(cells); C.aptr.upload(aptr);
-    DevBuf<double> E((size_t)nagg * nagg);
-    E.zero();
-    const Mat& P = k->pcmat->m;
-    hipLaunchKernelGGL(k_coarse_assemble, dim3(nblk(N, 16)), dim3(256), 0, s->stream, N, C.off, P.rowptr.p, P.col.p, P.val.p, C.agg.p, nagg, E.p, k->pcTranspose ? 1 : 0,
-                       k->pcDiagScale);
-    // E^-1 on the device (Gauss-Jordan, partial pivoting)
-    {
-        std::vector<double> I0((size_t)nagg * nagg, 0.0);
-        for (int i = 0; i < nagg; i++) I0[(size_t)i * nagg + i] = 1.0;
-        C.Einv.upload(I0);
-        DevBuf<int> sing(1);
-        DAS_HIP(hipMemsetAsync(sing.p, 0, sizeof(int), s->stream));
-        for (int kk = 0; kk < nagg; kk++) {
-            hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(256), 0, s->stream, nagg, kk, E.p, C.Einv.p, sing.p);
-            hipLaunchKernelGGL(k_gj_elim, dim3(nagg), dim3(256), 0, s->stream, nagg, kk, E.p, C.Einv.p);
-        }
-        int hs = 0;
-        DAS_HIP(hipMemcpyAsync(&hs, sing.p, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-        DAS_HIP(hipStreamSynchronize(s->stream));
-        if (hs) return;  // singular coarse operator: no coarse correction
-    }
-    C.t.alloc(nagg); C.u.alloc(nagg);
+    C.cells.upload(cells); C.aptr.upload(aptr);
     C.deflated = s->opt.gets("amd.pcCoarseMode") == "deflated";
     if (C.deflated) { C.c.alloc(s->n); C.rr.alloc(s->n); }
-    C.active = true;
-    if (s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] coarse space: %d aggregates on field %s (%s)\n", nagg, field.c_str(), C.deflated ? "deflated" : "additive");
+    // per-rank coarse operator (replaced by das_ksp_set_global_coarse when the ranks agree on one global coarse space)
+    coarse_build_operator(s, k, nagg, 0, agg);
+    if (C.active && s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] coarse space: %d aggregates on field %s (%s)\n", nagg, field.c_str(), C.deflated ? "deflated" : "additive");
 }
-// u = E^-1 Z^T r
+// u = E^-1 Z^T r  (global coarse space: the restricted residual of every rank lands in its own slots, one small all-reduce)
 static void coarse_solve(das_solver* s, das_ksp* k, const double* r) {
     das_ksp::CoarsePC& C = k->coarse;
-    hipLaunchKernelGGL(k_coarse_restrict, dim3(C.nagg), dim3(256), 0, s->stream, C.aptr.p, C.cells.p, C.off, r, C.t.p);
-    hipLaunchKernelGGL(k_coarse_solve, dim3(nblk(C.nagg, 64)), dim3(64), 0, s->stream, C.nagg, C.Einv.p, C.t.p, C.u.p);
+    if (C.global) DAS_HIP(hipMemsetAsync(C.t.p, 0, (size_t)C.naggG * sizeof(double), s->stream));
+    if (C.nagg > 0) hipLaunchKernelGGL(k_coarse_restrict, dim3(C.nagg), dim3(256), 0, s->stream, C.aptr.p, C.cells.p, C.off, r, C.t.p + C.aggOff);
+    if (C.global && !(s->halo.active && s->halo.allreduce(C.t.p, C.naggG, s->stream)) && s->allreduce_cb) s->allreduce_cb(C.t.p, C.naggG, s->comm_user);
+    hipLaunchKernelGGL(k_coarse_solve, dim3(nblk(C.naggG, 64)), dim3(64), 0, s->stream, C.naggG, C.Einv.p, C.t.p, C.u.p);
 }
 
 static void pc_apply(das_solver* s, das_ksp* k, const double* b, double* x) {
@@ -3456,6 +3499,26 @@ int das_ksp_get_coarse(das_ksp_t* k, int* aggOfCell) {
     if (!k || !k->coarse.active) return 0;
     if (aggOfCell) std::copy(k->coarse.h_agg.begin(), k->coarse.h_agg.end(), aggOfCell);
     return k->coarse.nagg;
+}
+// multi-GPU: replace the per-rank coarse spaces by ONE coarse space over all ranks.  Every rank passes the size of the global
+// coarse operator, the position of its own aggregates in it and, per local cell (owned AND ghost), the global aggregate (-1:
+// none).  Collective: E = Z^T P Z is summed over the ranks (all-reduce through the installed communication) and inverted by
+// every rank; afterwards a preconditioner apply costs one all-reduce of naggGlobal doubles.
+int das_ksp_set_global_coarse(das_solver_t* s, das_ksp_t* k, int naggGlobal, int aggOffset, const int* aggRowGlobal) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(k && aggRowGlobal, DAS_ERR_ARG, "null argument");
+    das_ksp::CoarsePC& C = k->coarse;
+    DAS_CHECK(C.N > 0 && !C.h_agg.empty(), DAS_ERR_STATE, "the preconditioner of this KSP has no coarse space (amd.pcCoarseAggregates)");
+    DAS_CHECK(aggOffset >= 0 && aggOffset + C.nagg <= naggGlobal, DAS_ERR_ARG, "aggregate offset out of range");
+    std::vector<int> rows(aggRowGlobal, aggRowGlobal + C.N);
+    for (long long c = 0; c < C.N; c++) {
+        DAS_CHECK(rows[c] >= -1 && rows[c] < naggGlobal, DAS_ERR_ARG, "global aggregate id out of range");
+        if (C.h_agg[c] >= 0) DAS_CHECK(rows[c] == aggOffset + C.h_agg[c], DAS_ERR_ARG, "owned cells must carry offset + local aggregate");
+    }
+    coarse_build_operator(s, k, naggGlobal, aggOffset, rows);
+    return C.active ? DAS_OK : 1;  // 1: singular coarse operator, no coarse correction (all ranks see the same matrix)
+    DAS_CATCH
 }
 int das_ksp_get_history(das_ksp_t* k, double* hist, int cap) {
     DAS_TRY

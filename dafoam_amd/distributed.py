@@ -241,6 +241,32 @@ def install_comm(obj, native=None):
     _capi.check(L.das_set_comm(h, None, C.cast(obj._cb[1], C.c_void_p), None))
 
 
+def _forward_exchange(halo, w):
+    """The reverse direction of HaloExchange.reduce_: every owner sends the values of its owned states to the ranks that hold
+    them as ghosts (set-up time only: aggregate ids of the global coarse space)."""
+    import torch
+    import torch.distributed as dist
+
+    ops, recv_bufs, keep = [], {}, []
+    for q in halo.peers:
+        if q in halo.recv_idx:  # my owned states that q holds as ghosts
+            sb = w.index_select(0, halo.recv_idx[q])
+            if halo.stage:
+                sb = sb.cpu()
+            keep.append(sb)
+            ops.append(dist.P2POp(dist.isend, sb, q))
+        if q in halo.send_idx:  # ghost states I hold that q owns
+            rb = torch.empty(halo.send_idx[q].numel(), dtype=w.dtype, device="cpu" if halo.stage else w.device)
+            recv_bufs[q] = rb
+            ops.append(dist.P2POp(dist.irecv, rb, q))
+    if ops:
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+    for q, rb in recv_bufs.items():
+        w.index_copy_(0, halo.send_idx[q], rb.to(w.device))
+    return w
+
+
 class _DevPtr:
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
@@ -312,7 +338,41 @@ class ShardedAdjoint:
         D.solver.calcdRdWT(1, self.pc)
         self.ksp = KSP()
         D.solverAD.createMLRKSPMatrixFree(self.pc, self.ksp)
+        self.global_coarse = self.install_global_coarse()
         D.solverAD.initializedRdWTMatrixFree()
+
+    def install_global_coarse(self):
+        """ONE pressure coarse space over all ranks (das_ksp_set_global_coarse) instead of one per rank: the aggregates stay
+        the per-rank RCB aggregates, numbered rank after rank; the ghost cells learn the aggregate of their owner through one
+        owner -> ghost exchange of the p rows; E = Z^T P Z is summed over the ranks inside the library.  Returns the number of
+        global aggregates (0: per-rank coarse spaces kept - amd.pcCoarseGlobal 0, no coarse space on some rank, or more than
+        2048 aggregates in total)."""
+        import torch
+        import torch.distributed as dist
+
+        amd = self.D.getOption("amd") if hasattr(self.D, "getOption") else {}
+        if int(amd.get("pcCoarseGlobal", 1)) == 0 or amd.get("pcType", "bilu") != "bilu":
+            return 0
+        N = self.case.mesh.n_cells
+        nloc, agg = self.ksp.coarse(N)
+        stage = dist.get_backend() == "gloo"
+        cnt = torch.zeros(self.world, dtype=torch.int64, device="cpu" if stage else self.dev)
+        cnt[self.rank] = int(nloc)
+        dist.all_reduce(cnt)
+        cnt = cnt.cpu().numpy()
+        if cnt.min() <= 0 or cnt.sum() > 2048:
+            return 0
+        off = int(cnt[: self.rank].sum())
+        w = torch.full((self.n,), -1.0, dtype=torch.float64, device=self.dev)
+        p0 = 3 * N  # the p block follows the velocity block in every solver with a pressure (DAIndex "state" ordering)
+        gl = np.where(agg >= 0, agg + off, -1).astype(np.float64)
+        w[p0 : p0 + N] = torch.from_numpy(gl).to(self.dev)
+        _forward_exchange(self.halo, w)
+        rows = np.ascontiguousarray(w[p0 : p0 + N].cpu().numpy().round().astype(np.int32))
+        from . import _capi
+
+        rc = _capi.check(self.L.das_ksp_set_global_coarse(self.h, self.ksp.handle, int(cnt.sum()), off, rows.ctypes.data_as(_capi.c_int_p)))
+        return int(cnt.sum()) if rc == 0 else 0
 
     def solve(self, rhs_ext):
         """rhs_ext: extended-length vector (ghost entries ignored).  Returns (psi_ext with zero ghosts, fail)."""
@@ -357,6 +417,40 @@ def rcb_partition(centres, nparts):
     return part
 
 
+def preserve_patches(case, part, patch_names):
+    """decomposeParDict.preservePatches (reference pyDAFoam.py:597-604, tests/runRegTests_DATurboFoamTransonic.py:67): both
+    cells of every face pair of the named cyclic patches end up on ONE rank.  The cells connected through the pairs are merged
+    into groups (union-find over the pair graph) and every group goes to the rank that owns most of its cells."""
+    part = np.asarray(part).copy()
+    m = case.mesh
+    pname = {p.name: p for p in m.patches}
+    parent = np.arange(m.n_cells)
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    own = m.owner.astype(np.int64)
+    for nm in patch_names:
+        if nm in ("None", "none", ""):
+            continue
+        p = pname[nm]
+        if p.type != "cyclic":
+            continue
+        q = pname[p.neighbour]
+        for k in range(p.size):
+            a, b = find(int(own[p.start + k])), find(int(own[q.start + k]))
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+    roots = np.array([find(c) for c in range(m.n_cells)])
+    for r in np.unique(roots[roots != np.arange(m.n_cells)]):
+        members = np.nonzero(roots == r)[0]
+        part[members] = np.bincount(part[members]).argmax()
+    return part
+
+
 def extract_submesh(case, part, rank, G=GHOST_LAYERS):
     """Extended sub-mesh of `rank`: owned cells (part == rank) + G rings of ghost cells, as a FoamCase in OpenFOAM
     ordering.  Faces whose other cell lies outside the extended set become a trailing zero-gradient patch "ghostcut".
@@ -370,12 +464,25 @@ def extract_submesh(case, part, rank, G=GHOST_LAYERS):
     from .meshgen import BC_ZERO_GRADIENT, NUT_CALCULATED, FoamCase, Patch, PolyMesh
 
     m = case.mesh
-    if any(p.type == "cyclic" for p in m.patches):
-        raise NotImplementedError("extract_submesh: cyclic patch pairs are not supported by the multi-GPU partitioner yet")
     N, F, nIF = m.n_cells, m.n_faces, m.n_internal_faces
     own, nei = m.owner.astype(np.int64), m.neighbour.astype(np.int64)
-    A = sp.coo_matrix((np.ones(nIF, np.int8), (own[:nIF], nei)), shape=(N, N)).tocsr()
-    A = (A + A.T).tocsr()
+    # cell adjacency: internal faces AND coupled (cyclic) patch pairs - the paired cell is a face neighbour for every stencil
+    # (csrc/das_mesh.cpp cyc_face), so the ghost rings run through the pair and both faces of a pair whose two cells are in the
+    # extended set stay a cyclic pair of the sub-mesh.  A pair may be split between ranks (the partner is then a ghost cell);
+    # the reference instead keeps pairs on one processor (decomposeParDict preservePatches, pyDAFoam.py:597-604: OpenFOAM's
+    # processor-cyclic patches) - preserve_patches() below reproduces that for partitions that ask for it.
+    pname = {p.name: p for p in m.patches}
+    partner = np.full(F, -1, dtype=np.int64)  # cyclic face -> its paired face
+    for p in m.patches:
+        if p.type == "cyclic":
+            q = pname[p.neighbour]
+            assert q.size == p.size, "cyclic patches of a pair must have equal sizes"
+            partner[p.start : p.start + p.size] = q.start + np.arange(p.size)
+    cyc = np.nonzero(partner >= 0)[0]
+    rows = np.concatenate([own[:nIF], own[cyc]])
+    cols = np.concatenate([nei, own[partner[cyc]]])
+    A = sp.coo_matrix((np.ones(rows.size, np.int8), (rows, cols)), shape=(N, N)).tocsr()
+    A = ((A + A.T) > 0).astype(np.int8).tocsr()
     ext = part == rank
     for _ in range(G):
         ext = ext | (A @ ext.astype(np.int8) > 0)
@@ -394,20 +501,27 @@ def extract_submesh(case, part, rank, G=GHOST_LAYERS):
     owners_l = [loc[own[f_int]]]
     patches = []
     start = f_int.size
+    cut_b = []  # coupled faces whose partner cell is outside the extended set: cut like an internal face
     for p in m.patches:
         fs = np.arange(p.start, p.start + p.size)
-        fs = fs[o_in[fs]]
-        patches.append(Patch(p.name, p.type, start, fs.size))
+        keep = o_in[fs]
+        if p.type == "cyclic":
+            both = keep & o_in[partner[fs]]
+            cut_b.append(fs[keep & ~both])
+            keep = both  # the same positions k survive in the partner patch: face k still pairs with face k
+        fs = fs[keep]
+        patches.append(Patch(p.name, p.type, start, fs.size, neighbour=p.neighbour, rotation=p.rotation))
         faces_g.append(fs)
         signs.append(np.ones(fs.size))
         owners_l.append(loc[own[fs]])
         start += fs.size
+    cut_b = np.concatenate(cut_b) if cut_b else np.zeros(0, np.int64)
     # cut faces: internal global faces with exactly one cell inside the extended set
     cut_o = np.nonzero(o_in[:nIF] & ~n_in[:nIF])[0]  # inside cell is the global owner -> orientation kept
     cut_n = np.nonzero(~o_in[:nIF] & n_in[:nIF])[0]  # inside cell is the global neighbour -> flip
-    fcut = np.concatenate([cut_o, cut_n])
-    scut = np.concatenate([np.ones(cut_o.size), -np.ones(cut_n.size)])
-    ocut = np.concatenate([loc[own[cut_o]], loc[nei[cut_n]]])
+    fcut = np.concatenate([cut_o, cut_n, cut_b])
+    scut = np.concatenate([np.ones(cut_o.size), -np.ones(cut_n.size), np.ones(cut_b.size)])
+    ocut = np.concatenate([loc[own[cut_o]], loc[nei[cut_n]], loc[own[cut_b]]])
     oc = np.lexsort((fcut, ocut))
     patches.append(Patch("ghostcut", "patch", start, fcut.size))
     faces_g.append(fcut[oc])
@@ -458,10 +572,39 @@ def extract_submesh(case, part, rank, G=GHOST_LAYERS):
 
 
 class ShardedAdjointGeneral(ShardedAdjoint):
-    """Sharded adjoint for an ARBITRARY global case and cell partition vector (every rank holds the global case, e.g.
-    read with dafoam_amd.foam_io.read_case, extracts its extended sub-mesh and proceeds like ShardedAdjoint)."""
+    """Sharded adjoint for an ARBITRARY global case and cell partition vector.  Two ways in:
+      * ShardedAdjointGeneral(global_case, part, options): every rank holds the global case (e.g. read with
+        dafoam_amd.foam_io.read_case) and extracts its own extended sub-mesh;
+      * ShardedAdjointGeneral.scattered(global_case | None, part | None, options): only the SOURCE rank holds the global case; it
+        extracts the extended sub-mesh of every rank and scatters them (the reference's decomposePar step, pyDAFoam.py:597-604,
+        done in memory) - the other ranks never see more than their own cells plus three ghost rings.
+    Then it proceeds like ShardedAdjoint."""
 
     def __init__(self, global_case, part, options, device_index=0):
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        assert int(np.asarray(part).max()) + 1 <= world
+        case, info = extract_submesh(global_case, np.asarray(part), rank)
+        self._init_from_sub(case, info, int(global_case.mesh.n_cells), options, device_index)
+
+    @classmethod
+    def scattered(cls, global_case, part, options, device_index=0, src=0):
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        subs = None
+        if rank == src:
+            assert int(np.asarray(part).max()) + 1 <= world
+            subs = [extract_submesh(global_case, np.asarray(part), r) + (int(global_case.mesh.n_cells),) for r in range(world)]
+        out = [None]
+        dist.scatter_object_list(out, subs, src=src)
+        case, info, nglobal = out[0]
+        obj = cls.__new__(cls)
+        obj._init_from_sub(case, info, nglobal, options, device_index)
+        return obj
+
+    def _init_from_sub(self, case, info, n_global_cells, options, device_index):
         import torch
         import torch.distributed as dist
 
@@ -469,8 +612,6 @@ class ShardedAdjointGeneral(ShardedAdjoint):
         from .pyDAFoam import PYDAFOAM
 
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        assert int(part.max()) + 1 <= self.world
-        case, info = extract_submesh(global_case, np.asarray(part), self.rank)
         self.case, self.info = case, info
         self.key, self.owner_rank, self.owned = info["key"], info["owner_rank"], info["owned"]
         opts = dict(options)
@@ -484,6 +625,6 @@ class ShardedAdjointGeneral(ShardedAdjoint):
         self.halo = HaloExchange(self.key, self.owner_rank, self.rank, self.world, device=self.dev)
         _capi.check(L.das_set_stream(h, C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
         self.n = self.key.size
-        _capi.check(L.das_set_n_global_cells(h, int(global_case.mesh.n_cells)))
+        _capi.check(L.das_set_n_global_cells(h, int(n_global_cells)))
         install_comm(self)
         self.n_owned = int(self.owned.sum())

@@ -310,6 +310,12 @@ int das_ksp_get_status(das_ksp_t* ksp, int* reason, int* nBreakdown, int* nSweep
 /* two-level preconditioner (amd.pcCoarseAggregates / pcCoarseField / pcCoarseMode): number of aggregates of the
  * piecewise-constant pressure coarse space (0 = none) and, optionally, the aggregate of every cell (-1 = not owned) */
 int das_ksp_get_coarse(das_ksp_t* ksp, int* aggOfCell);
+/* multi-GPU: ONE coarse space over all ranks instead of one per rank (the reference's ASM level couples the sub-domains through
+ * its overlap, DALinearEqn.C:199-216; a per-rank coarse space lets the iteration count grow with the number of GPUs).
+ * Collective over the installed communication.  naggGlobal <= 2048: size of the global coarse operator; aggOffset: position of
+ * this rank's aggregates; aggRowGlobal[nLocalCells]: global aggregate of every local cell, owned (= aggOffset + local id) and
+ * ghost (the owner rank's numbering), -1 = none.  Returns 0, or 1 if the coarse operator is singular (no correction). */
+int das_ksp_set_global_coarse(das_solver_t* s, das_ksp_t* ksp, int naggGlobal, int aggOffset, const int* aggRowGlobal);
 /* run exactly `iters` GMRES iterations on device-resident rhs/sol (bench.py "step"); no convergence exit */
 int das_ksp_run_fixed_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rhs, double* d_sol, int iters);
 /* the same solve advanced in pieces on device-resident rhs/sol (bench.py times a window of iterations deep inside an

@@ -166,3 +166,140 @@ def test_two_rank_sharded_adjoint_matches_single_domain(backend):
         psi_s[[look[k] for k in keys.tolist()]] = psi
     assert not np.isnan(psi_s).any()
     assert relerr(psi_s, psi_g) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------- four ranks (round 3)
+def _spawn(target, world, args, timeout=900):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda t: t[0])
+
+
+def _worker_slab4(rank, world, port, q, gstate, nx, global_coarse):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dafoam_amd.distributed import ShardedAdjoint
+
+        opts = dict(OPTS, amd=dict(OPTS["amd"], pcCoarseGlobal=int(global_coarse), pcCoarseAggregates=8))
+        S = ShardedAdjoint(nx, NY, NZ, opts, device_index=0, global_state=gstate, case_kw=CASE_KW)
+        S.setup()
+        psi, fail = S.solve(_rhs_from_keys(S.key))
+        info = S.ksp.info()
+        q.put((rank, S.key[S.owned], psi[S.owned], fail, info["iters"], info["res"] / info["res0"], S.global_coarse))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_rank_global_coarse_space():
+    """Four ranks (one GPU, gloo staging), slab partition: ONE pressure coarse space over all ranks (das_ksp_set_global_coarse:
+    aggregate ids of the ghost cells by an owner -> ghost exchange, E = Z^T P Z all-reduced, one all-reduce of nAgg doubles
+    per preconditioner apply) against the per-rank coarse spaces (block-diagonal E, round 2) and the single-domain solve:
+    the same psi (<= 1e-6), and the global coarse space does not need more iterations than the per-rank one."""
+    from dafoam_amd.distributed import SlabPartition, state_table
+    from dafoam_amd.meshgen import channel_case
+    from dafoam_amd.pyDAFoam import PYDAFOAM
+    from oracle.foam_mesh import Geometry
+    from oracle.primal import solve_primal
+
+    nx = 32
+    gcase = channel_case(nx, NY, NZ, perturb=0.0, **CASE_KW)
+    W, hist = solve_primal(gcase, Geometry(gcase.mesh), max_iters=800, tol=1e-11)
+    gcase.states = W
+    gkey, _, _ = state_table(SlabPartition(nx, NY, NZ, 0, 1), gcase.mesh)
+    gstate = (gkey, gcase.states, gcase.y_wall)
+    D = PYDAFOAM(options=dict(OPTS, amd=dict(OPTS["amd"], pcCoarseAggregates=32)), case=gcase)
+    psi_g, fail_g = D.solveAdjoint(_rhs_from_keys(gkey))
+    assert fail_g == 0
+    look = dict(zip(gkey.tolist(), range(gkey.size)))
+    its = {}
+    for glob in (1, 0):
+        res = _spawn(_worker_slab4, 4, (gstate, nx, glob))
+        psi_s = np.full(gkey.size, np.nan)
+        for rank, keys, psi, fail, iters, relres, ng in res:
+            assert fail == 0 and relres < 1e-8, (glob, rank, fail, iters, relres)
+            assert ng == (32 if glob else 0)
+            psi_s[[look[k] for k in keys.tolist()]] = psi
+        assert not np.isnan(psi_s).any() and relerr(psi_s, psi_g) <= 1e-6, glob
+        its[glob] = res[0][4]
+    assert its[1] <= its[0] + 3, (its, D.ksp.info()["iters"])
+
+
+def _worker_general4(rank, world, port, q, gcase, part):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from common import options
+        from dafoam_amd.distributed import ShardedAdjointGeneral
+
+        opts = options(gcase, adjEqnOption={"gmresRelTol": 1e-10, "gmresMaxIters": 1500, "gmresRestart": 500, "printInfo": 0})
+        # only rank 0 hands over the global case: the sub-meshes are extracted there and scattered
+        S = ShardedAdjointGeneral.scattered(gcase if rank == 0 else None, part if rank == 0 else None, opts, device_index=0)
+        assert S.case.mesh.n_cells < gcase.mesh.n_cells
+        S.setup()
+        N = gcase.mesh.n_cells
+        rhs = np.zeros(S.n)
+        ux = (S.key < 3 * N) & (S.key % 3 == 0)
+        rhs[ux] = 1.0 + 0.5 * np.sin(1e-2 * (S.key[ux] // 3))
+        psi, fail = S.solve(rhs)
+        info = S.ksp.info()
+        q.put((rank, S.key[S.owned], psi[S.owned] * S.info["state_sign"][S.owned], fail, info["iters"], info["res"] / info["res0"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["rho", "turbo_cyclic"])
+def test_four_rank_general_partition_compressible_and_cyclic(kind):
+    """BASELINE configs[3] / configs[4] in miniature: DARhoSimpleFoam on four ranks, and DATurboFoam on an annular sector with a
+    rotational cyclic pair + MRF whose pairs are SPLIT between ranks (the partner cell is a ghost cell; the ghost rings run
+    through the pair) - arbitrary cell partition through extract_submesh, psi against the single-domain solve."""
+    from common import options
+    from dafoam_amd.meshgen import periodic_channel_case, rho_channel_case
+    from dafoam_amd.pyDAFoam import PYDAFOAM
+
+    if kind == "rho":
+        from oracle.foam_mesh import Geometry
+        from oracle.primal import solve_primal
+
+        gcase = rho_channel_case(16, 8, 6, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+        W, hist = solve_primal(gcase, Geometry(gcase.mesh), max_iters=800, tol=1e-11)
+        gcase.states = W
+        nx, ny, nz = 16, 8, 6
+    else:
+        nx, ny, nz = 12, 6, 8
+        gcase = periodic_channel_case(nx, ny, nz, wall_function=True, sector=(0.5, 0.12), solver_name="DATurboFoam", mrf_omega=60.0)
+    cidx = np.arange(gcase.mesh.n_cells)
+    ci, ck = cidx % nx, cidx // (nx * ny)
+    part = ((ci >= nx // 2).astype(np.int32) + 2 * (ck >= nz // 2).astype(np.int32)).astype(np.int32)
+    res = _spawn(_worker_general4, 4, (gcase, part))
+    n, N = gcase.states.size, gcase.mesh.n_cells
+    rhs = np.zeros(n)
+    rhs[0 : 3 * N : 3] = 1.0 + 0.5 * np.sin(1e-2 * np.arange(N))
+    D = PYDAFOAM(options=options(gcase, adjEqnOption={"gmresRelTol": 1e-10, "gmresMaxIters": 1500, "gmresRestart": 500, "printInfo": 0}), case=gcase)
+    psi_g, fail_g = D.solveAdjoint(rhs)
+    assert fail_g == 0, D.ksp.info()
+    psi_s = np.full(n, np.nan)
+    for rank, keys, psi, fail, iters, relres in res:
+        assert fail == 0 and relres < 1e-9, (rank, fail, iters, relres)
+        psi_s[keys] = psi
+    assert not np.isnan(psi_s).any() and relerr(psi_s, psi_g) <= 1e-6

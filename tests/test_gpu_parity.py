@@ -516,10 +516,9 @@ def test_ras_ilu_apply_matches_oracle(dims, block, overlap, fill, fp32):
     assert relerr(y, y_o) < (1e-2 if fp32 else 1e-9)  # fp32 factor storage: preconditioner-only approximation
 
 
-@pytest.mark.parametrize("design", [1, 2])
 @pytest.mark.parametrize("dims,fp32,solver", [((6, 6, 5), 0, "simple"), ((9, 8, 7), 0, "simple"), ((24, 20, 16), 0, "simple"), ((9, 8, 7), 1, "simple"),
                                                ((8, 6, 5), 0, "rho"), ((18, 17, 16), 0, "scalar")])
-def test_node_block_ilu_apply_matches_oracle(dims, fp32, solver, design):
+def test_node_block_ilu_apply_matches_oracle(dims, fp32, solver):
     """The default preconditioner (amd.pcType "bilu": ONE node-block ILU(0) of dRdWTPC per GPU - the reference's ASM+ILU
     stack, DALinearEqn.C:199-299, with one sub-domain per rank - factorised on the device level by level and applied by
     sync-free sweeps) against the oracle: the SCALAR ILU(0) kernel (oracle/csrc/oracle_linalg.c) on the explicitly filled
@@ -528,8 +527,7 @@ def test_node_block_ilu_apply_matches_oracle(dims, fp32, solver, design):
 
     case = {"simple": lambda: channel_case(*dims, grading_y=2.0), "rho": lambda: rho_channel_case(*dims, perturb=0.02),
             "scalar": lambda: scalar_transport_case(*dims)}[solver]()
-    # design 1: ticket per workgroup; design 2: ticket per wave, row extent / first pass of the next node requested ahead
-    D = make(case, amd={"pcFactorFP32": fp32, "pcCoarseAggregates": 0, "pcSweepDesign": design}, adjEqnOption={"printInfo": 0})
+    D = make(case, amd={"pcFactorFP32": fp32, "pcCoarseAggregates": 0}, adjEqnOption={"printInfo": 0})
     D.solver.runColoring()
     pc = Mat()
     D.solver.calcdRdWT(1, pc)

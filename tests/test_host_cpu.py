@@ -833,6 +833,49 @@ def test_amd_option_defaults_and_profile_helpers(tmp_path):
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    t = bench.pmc_traffic(2091189176, "k_spmv_wave")
-    assert t is not None and 2.5e10 < t < 4.5e10
-    assert bench.pmc_traffic(12345, "k_spmv_wave") is None and bench.pmc_traffic(2091189176, "no_such_kernel") is None
+    t = bench.pmc_traffic(2091189176, "spmv")  # round 3: k_spmv_vec3 (packed U rows) + k_spmv_wave (scalar rows) per product
+    assert t is not None and 2.2e10 < t < 3.2e10
+    assert bench.pmc_traffic(12345, "spmv") is None and bench.pmc_traffic(2091189176, "no_such_kernel") is None
+
+
+@pytest.mark.parametrize("variant", ["translational", "turbo_sector"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_cyclic_aware_partition_extended_submesh_residuals(variant, world):
+    """Multi-GPU partitioner with coupled cyclic pairs (BASELINE configs[4]: DATurboFoam, cyclic + MRF, 8 ranks): the ghost
+    rings of extract_submesh run THROUGH the pairs, pairs whose two cells are in the extended set stay cyclic pairs of the
+    sub-mesh (a pair may be split between ranks - the partner is then a ghost cell), the others are cut.  For every rank of
+    an RCB partition the residual rows of the OWNED cells / faces evaluated on the extended sub-mesh (host-emulated kernel
+    bodies, which carry the cyclic implementation) equal the rows of the undecomposed periodic case; the owned states
+    partition the global vector.  With decomposeParDict.preservePatches (reference pyDAFoam.py:597-604) every pair lies on
+    one rank."""
+    from dafoam_amd.distributed import extract_submesh, preserve_patches, rcb_partition
+
+    kw = {} if variant == "translational" else dict(sector=(0.5, 0.12), solver_name="DATurboFoam", mrf_omega=60.0)
+    gcase = periodic_channel_case(8, 5, 6, wall_function=True, **kw)
+    gg = Geometry(gcase.mesh)
+    Rg, _ = _emu_res(gcase, gcase.states, 0)
+    nx, ny, nz = 8, 5, 6
+    cidx = np.arange(gcase.mesh.n_cells)
+    ci, ck = cidx % nx, cidx // (nx * ny)
+    sl = {p.name: np.arange(p.start, p.start + p.size) for p in gcase.mesh.patches}
+    fo, bo = gcase.mesh.owner[sl["front"]], gcase.mesh.owner[sl["back"]]
+    for mode in ("rcb", "split_pairs", "preserve"):
+        if mode == "rcb":
+            part = rcb_partition(gg.C, world)
+        else:  # cut across the periodic direction: every pair is split between two ranks
+            part = ((ck >= nz // 2).astype(np.int32) + (2 * (ci >= nx // 2).astype(np.int32) if world == 4 else 0)).astype(np.int32)
+            assert np.all(part[fo] != part[bo])
+            if mode == "preserve":
+                part = preserve_patches(gcase, part, ["front", "back"])
+                assert np.array_equal(part[fo], part[bo])
+        seen = np.zeros(gcase.states.size, dtype=int)
+        for rank in range(world):
+            case, info = extract_submesh(gcase, part, rank)
+            owned, key = info["owned"], info["key"]
+            pf, pb = [p for p in case.mesh.patches if p.name in ("front", "back")]
+            assert pf.size == pb.size and pf.type == pb.type == "cyclic"
+            R, _ = _emu_res(case, case.states, 0)
+            ref = Rg[key] * info["state_sign"]
+            assert np.abs(R[owned] - ref[owned]).max() <= 1e-11 * np.abs(Rg).max(), (variant, world, mode, rank)
+            seen[key[owned]] += 1
+        assert np.all(seen == 1)
