@@ -175,4 +175,213 @@ inline bool color_firstfit_device(long long n, const std::vector<long long>& kee
     return true;
 }
 
+// =====================================================================================================================
+// Speculative distance-2 colouring over NET BITMAPS (round 3; amd.coloringAlgorithm "speculative", the default on a device).
+//
+// The data-flow first-fit above is exact (the serial colours) but it is work-bound: every column gathers the colours of its
+// whole distance-2 neighbourhood WITH multiplicity - ~63 kept rows x ~275 columns = 17 k gathers per column, 2e11 at 2 M cells,
+// 9.8 s.  Here every kept row ("net": one per cell, its pRes row) carries a bitmap of the colours its columns use (W 64-bit
+// words); a column reads its forbidden set as the OR of the bitmaps of its ~63 nets - 63 coalesced 64-byte lines instead of
+// 17 k scattered words - and the rounds are the classic speculate / detect / retry scheme (Gebremedhin-Manne; net-based
+// detection as in Tas, Kaya, Saule 2017), made deterministic by index priority:
+//   assign    every uncoloured column picks the first colour not in its forbidden set, starting the search at a hashed
+//             offset inside [0, S) (S ~ 1.2 x the longest net: spreads the simultaneous picks), beyond S only if [0, S) is full
+//   conflict  every net looks at its columns: of two that hold the same colour the committed one, else the lower index, wins
+//   commit    winners become final, losers go back to "uncoloured";  netbits: the bitmaps are rebuilt from the final colours
+// Every round commits at least the lowest-index contender of every colour class, so it terminates; measured rounds /
+// colours / time: profiles/README.md.  The result depends on nothing but the pattern (no race decides anything).
+// Reference contract: any valid colouring (DAColoring::validateColoring, DAColoring.C:931-1037); validity is checked by the
+// same net kernel at the end.
+struct SpecView {
+    long long n, nNets;
+    const long long* cptr;  // n+1: nets of a column
+    const int* crow;
+    const long long* krp;   // nNets+1: columns of a net
+    const int* kcol;
+    int W;                  // bitmap words per net
+    unsigned long long* F;  // nNets * W
+    int* colors;            // final colours, -1 = none
+    int* tent;              // tentative colour of this round, -1 = none
+    unsigned char* lose;
+    unsigned* ctrl;         // [0] columns still uncoloured after commit, [1] overflow (no free colour in 64 W), [2] invalid (check)
+};
+__device__ __forceinline__ unsigned spec_hash(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// 8 lanes per column (one bitmap word each when W == 8; W > 8: strided)
+__global__ __launch_bounds__(256) void k_spec_assign(SpecView P, int S, unsigned round) {
+    const long long j = (long long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int l8 = threadIdx.x & 7;
+    if (j >= P.n) return;
+    if (P.colors[j] >= 0) return;
+    const int W = P.W;
+    unsigned h = spec_hash((unsigned)j * 2654435761u + round * 40503u);
+    const int start = (int)(h % (unsigned)S);
+    // forbidden words owned by this lane: w = l8, l8 + 8, ...
+    int best = 1 << 30, bestWrap = 1 << 30;  // first free colour >= start (in [0,S) first, then anywhere), first free colour < start
+    for (int w = l8; w < W; w += 8) {
+        unsigned long long f = 0ull;
+        for (long long q = P.cptr[j]; q < P.cptr[j + 1]; q++) f |= P.F[(long long)P.crow[q] * W + w];
+        unsigned long long freeb = ~f;
+        const int base = w * 64;
+        // candidates at or after start
+        unsigned long long hi = freeb;
+        if (base + 64 <= start) hi = 0ull;
+        else if (base < start) hi &= ~0ull << (start - base);
+        if (hi) best = min(best, base + __builtin_ctzll(hi));
+        unsigned long long lo = freeb;
+        if (base >= start) lo = 0ull;
+        else if (base + 64 > start) lo &= (1ull << (start - base)) - 1ull;
+        if (lo) bestWrap = min(bestWrap, base + __builtin_ctzll(lo));
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        best = min(best, __shfl_xor(best, o, 8));
+        bestWrap = min(bestWrap, __shfl_xor(bestWrap, o, 8));
+    }
+    // inside [0, S): first free at/after start, else wrapped; if [0, S) is full: the first free colour beyond S
+    int c = (best < S) ? best : (bestWrap < (1 << 30) ? bestWrap : best);
+    if (l8 == 0) {
+        if (c >= 64 * W) { P.ctrl[1] = 1u; c = -1; }
+        P.tent[j] = c;
+    }
+}
+// one wave per net: of the columns that hold the same colour only one survives (final ones first, then the lowest index)
+__global__ __launch_bounds__(256) void k_spec_conflict(SpecView P, int check) {
+    extern __shared__ int sh_min[];  // 4 waves x 64 W entries
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + wave;
+    const int NC = 64 * P.W;
+    int* mn = sh_min + wave * NC;
+    for (int c = lane; c < NC; c += 64) mn[c] = 0x7fffffff;
+    __builtin_amdgcn_wave_barrier();
+    if (r >= P.nNets) return;
+    const long long k0 = P.krp[r], k1 = P.krp[r + 1];
+    for (long long k = k0 + lane; k < k1; k += 64) {
+        const int j = P.kcol[k];
+        const int cf = P.colors[j];
+        if (cf >= 0) {
+            const int old = atomicMin(&mn[cf], -1 - j);  // final colours: negative keys (always beat tentative ones)
+            if (check && old < 0 && old != -1 - j) P.ctrl[2] = 1u;  // two FINAL columns of one net share a colour
+        } else {
+            if (check) P.ctrl[2] = 1u;  // an uncoloured column
+            const int ct = P.tent[j];
+            if (ct >= 0) atomicMin(&mn[ct], j);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (check) return;
+    for (long long k = k0 + lane; k < k1; k += 64) {
+        const int j = P.kcol[k];
+        if (P.colors[j] >= 0) continue;
+        const int ct = P.tent[j];
+        if (ct >= 0 && mn[ct] != j) P.lose[j] = 1;
+    }
+}
+__global__ void k_spec_commit(SpecView P) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n || P.colors[j] >= 0) return;
+    const int ct = P.tent[j];
+    const bool won = ct >= 0 && !P.lose[j];
+    if (won) P.colors[j] = ct;
+    P.tent[j] = -1;
+    P.lose[j] = 0;
+    // columns still to colour: one atomic per wave (a counter hit by every thread retires one add per ~17 ns)
+    const unsigned long long m = __ballot(!won);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(&P.ctrl[0], (unsigned)__builtin_popcountll(m));
+}
+// one wave per net: bitmap of the final colours of its columns
+__global__ __launch_bounds__(256) void k_spec_netbits(SpecView P) {
+    extern __shared__ unsigned long long sh_bits[];  // 4 waves x W words
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long r = (long long)blockIdx.x * 4 + wave;
+    unsigned long long* bits = sh_bits + wave * P.W;
+    for (int w = lane; w < P.W; w += 64) bits[w] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (r >= P.nNets) return;
+    for (long long k = P.krp[r] + lane; k < P.krp[r + 1]; k += 64) {
+        const int c = P.colors[P.kcol[k]];
+        if (c >= 0) atomicOr(&bits[c >> 6], 1ull << (c & 63));
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int w = lane; w < P.W; w += 64) P.F[r * P.W + w] = bits[w];
+}
+
+// speculative colouring on the device; same inputs as color_firstfit_device.  Returns false if it could not be used.
+inline bool color_speculative_device(long long n, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
+                                     const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors, hipStream_t st,
+                                     int* roundsOut = nullptr) {
+    const long long nKeep = (long long)keep.size();
+    const bool dbg = getenv("DAS_DEBUG_TIMING") != nullptr;
+    double tq = wall_seconds();
+    auto lap = [&](const char* what) { if (dbg) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]     speculative colouring: %s %.2f s\n", what, t2 - tq); tq = t2; } };
+    std::vector<long long> krp(nKeep + 1, 0);
+    long long maxNet = 0;
+    for (long long q = 0; q < nKeep; q++) {
+        const long long len = rowptr[keep[q] + 1] - rowptr[keep[q]];
+        krp[q + 1] = krp[q] + len;
+        maxNet = std::max(maxNet, len);
+    }
+    uvector<int> kcol(krp[nKeep]);
+#pragma omp parallel for schedule(static)
+    for (long long q = 0; q < nKeep; q++) std::copy(col.begin() + rowptr[keep[q]], col.begin() + rowptr[keep[q] + 1], kcol.begin() + krp[q]);
+    std::vector<int> posOfRow((long long)rowptr.size() - 1, -1);
+    for (long long q = 0; q < nKeep; q++) posOfRow[keep[q]] = (int)q;
+    uvector<int> crowK(crow.size());
+#pragma omp parallel for schedule(static)
+    for (long long q = 0; q < (long long)crow.size(); q++) crowK[q] = posOfRow[crow[q]];
+    lap("host preparation");
+    DevBuf<long long> d_cptr, d_krp;
+    DevBuf<int> d_crow, d_kcol, d_colors(n), d_tent(n);
+    DevBuf<unsigned char> d_lose(n);
+    DevBuf<unsigned> d_ctrl(4);
+    d_cptr.upload(cptr); d_krp.upload(krp);
+    d_crow.upload(crowK.data(), crowK.size()); d_kcol.upload(kcol.data(), kcol.size());
+    lap("upload");
+    // the spread of the first picks: a little above the longest net (a lower bound of the colour count)
+    int S = (int)std::max<long long>(8, maxNet + maxNet / 4);
+    if (const char* e = getenv("DAS_COLOR_SPREAD")) S = std::max(1, atoi(e));
+    for (int W = (int)std::max<long long>(8, ((long long)(2 * S) + 63) / 64); W <= 1024; W *= 2) {
+        DevBuf<unsigned long long> d_F((size_t)nKeep * W);
+        DAS_HIP(hipMemsetAsync(d_F.p, 0, (size_t)nKeep * W * sizeof(unsigned long long), st));
+        DAS_HIP(hipMemsetAsync(d_colors.p, 0xff, n * sizeof(int), st));
+        DAS_HIP(hipMemsetAsync(d_tent.p, 0xff, n * sizeof(int), st));
+        DAS_HIP(hipMemsetAsync(d_lose.p, 0, n, st));
+        SpecView V{n, nKeep, d_cptr.p, d_crow.p, d_krp.p, d_kcol.p, W, d_F.p, d_colors.p, d_tent.p, d_lose.p, d_ctrl.p};
+        const unsigned gNet = (unsigned)((nKeep + 3) / 4);
+        bool overflow = false;
+        unsigned left = 1u;
+        int round = 0;
+        for (; left != 0u && round < 100000; round++) {
+            DAS_HIP(hipMemsetAsync(d_ctrl.p, 0, 4 * sizeof(unsigned), st));
+            hipLaunchKernelGGL(k_spec_assign, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, V, S, (unsigned)round);
+            hipLaunchKernelGGL(k_spec_conflict, dim3(gNet), dim3(256), (size_t)4 * 64 * W * sizeof(int), st, V, 0);
+            hipLaunchKernelGGL(k_spec_commit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, V);
+            hipLaunchKernelGGL(k_spec_netbits, dim3(gNet), dim3(256), (size_t)4 * W * sizeof(unsigned long long), st, V);
+            unsigned ctrl[4] = {0, 0, 0, 0};
+            DAS_HIP(hipMemcpyAsync(ctrl, d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, st));
+            DAS_HIP(hipStreamSynchronize(st));
+            left = ctrl[0];
+            if (ctrl[1]) { overflow = true; break; }
+        }
+        if (overflow) continue;  // more colours than the bitmaps hold: twice the words
+        if (left != 0u) return false;
+        // validity: every net holds pairwise different final colours
+        DAS_HIP(hipMemsetAsync(d_ctrl.p, 0, 4 * sizeof(unsigned), st));
+        hipLaunchKernelGGL(k_spec_conflict, dim3(gNet), dim3(256), (size_t)4 * 64 * W * sizeof(int), st, V, 1);
+        unsigned ctrl[4] = {0, 0, 0, 0};
+        DAS_HIP(hipMemcpyAsync(ctrl, d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, st));
+        DAS_HIP(hipStreamSynchronize(st));
+        if (ctrl[2]) return false;
+        colors.resize(n);
+        d_colors.download(colors.data(), n);
+        if (roundsOut) *roundsOut = round;
+        if (dbg) fprintf(stderr, "[dafoam_amd]     speculative colouring: %d rounds, spread %d, %d bitmap words per net\n", round, S, W);
+        lap("kernels");
+        return true;
+    }
+    return false;
+}
+
 }  // namespace das

@@ -987,6 +987,7 @@ struct das_solver {
         }
     };
     std::map<std::string, FaceFn> functions;
+    int colorRounds = 0;        // rounds of the speculative device colouring (0: another algorithm ran)
     long long geomVersion = 0;  // bumped by das_update_of_mesh
     // everything else the Jacobian depends on besides the states and the geometry: patch values, old-time fields, options
     // (normalizeStates, residual / discretisation switches).  Every setter bumps the epoch; a cached operator is only
@@ -1070,8 +1071,13 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
             if (s->inited && s->opt.geti("amd.coloringOnDevice"))
                 fn = [s](long long nn, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
                          const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors) {
-                    const bool ok = color_firstfit_device(nn, keep, cptr, crow, rowptr, col, colors, s->stream);
-                    if (!ok) fprintf(stderr, "[dafoam_amd] device colouring gave up (more than 4096 colours or a timeout): host first-fit instead\n");
+                    // amd.coloringAlgorithm "speculative" (default): rounds of speculative first-fit over net bitmaps;
+                    // "firstfit": the serial first-fit as a data-flow kernel (fewest colours, 20 x the time at 2 M cells)
+                    auto it = s->opt.s.find("amd.coloringAlgorithm");
+                    const bool spec = it == s->opt.s.end() || it->second != "firstfit";
+                    const bool ok = spec ? color_speculative_device(nn, keep, cptr, crow, rowptr, col, colors, s->stream, &s->colorRounds)
+                                         : color_firstfit_device(nn, keep, cptr, crow, rowptr, col, colors, s->stream);
+                    if (!ok) fprintf(stderr, "[dafoam_amd] device colouring gave up (too many colours or a timeout): host first-fit instead\n");
                     return ok;
                 };
             s->nColors = d2_coloring(s->con_full, s->colors, ctr.data(), fn);

@@ -539,17 +539,32 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
 }
 
 bool validate_coloring(const JacCon& con, const std::vector<int>& colors) {
-    std::vector<long long> seen;
-    for (long long r = 0; r < con.n; r++) {
-        for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) {
-            int c = colors[con.col[k]];
-            if (c < 0) return false;
-            if ((size_t)c >= seen.size()) seen.resize(c + 1, -1);
-            if (seen[c] == r) return false;
-            seen[c] = r;
+    // reference DAColoring::validateColoring (DAColoring.C:931-1037): no row holds two columns of one colour.  Rows are independent:
+    // every thread checks a contiguous range with its own "colour last seen in row" table (was serial: 1.6 s at 2 M cells)
+    int ncol = 0;
+    for (long long j = 0; j < con.n; j++) {
+        if (colors[j] < 0) return false;
+        ncol = std::max(ncol, colors[j] + 1);
+    }
+    bool ok = true;
+#pragma omp parallel
+    {
+        std::vector<long long> seen((size_t)ncol, -1);
+#pragma omp for schedule(static)
+        for (long long r = 0; r < con.n; r++) {
+            if (!ok) continue;
+            for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) {
+                const int c = colors[con.col[k]];
+                if (seen[c] == r) {
+#pragma omp atomic write
+                    ok = false;
+                    break;
+                }
+                seen[c] = r;
+            }
         }
     }
-    return true;
+    return ok;
 }
 
 void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
