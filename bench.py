@@ -262,6 +262,12 @@ def main():
                 cpu = cpu_baseline(a, dev_index, ncell)
             except Exception as e:  # noqa: BLE001 - the baseline must never break the line
                 cpu = {"error": str(e)[:300]}
+            try:  # per-component figure AT the bench size (no "scaled by 0.1" for the product itself)
+                cpu["dRdWTPsi_at_bench_size"] = cpu_spmv_at_bench_size(L, h, n, op_nnz)
+                if "ms" in cpu["dRdWTPsi_at_bench_size"] and spmv_ms:
+                    cpu["dRdWTPsi_at_bench_size"]["gpu_ms"] = spmv_ms
+            except Exception as e:  # noqa: BLE001
+                cpu["dRdWTPsi_at_bench_size"] = {"error": str(e)[:300]}
         pc_desc = ("node-block ILU(0) of FD dRdWTPC over the whole rank (8-slot cell nodes, 8x8 fp%s blocks), factorised on the device, "
                    "two sync-free sweeps per apply; + piecewise-constant pressure coarse space (%s)" % ("32" if a.fp32_factor else "64", a.coarse_mode)) if a.pctype == "bilu" else \
             "RAS(overlap 1)+ILU(1) of FD dRdWTPC, RCB blocks of <= 1024 cells, one workgroup per block"
@@ -356,6 +362,58 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     return out
+
+
+def cpu_spmv_at_bench_size(L, h, n, op_nnz, seconds=8.0):
+    """dRdW^T.psi of the SAME operator on the host cores, at the bench size (no extrapolation): the CSR arrays are copied back
+    from the device (das_op_export) and multiplied by the oracle's C kernel, one contiguous row chunk of equal nnz per thread
+    (ctypes releases the GIL).  Skipped when the host cannot hold the matrix twice over."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import linear as OL
+
+    need = 12.0 * op_nnz + 8.0 * n
+    try:
+        with open("/proc/meminfo") as f:
+            avail = [int(ln.split()[1]) * 1024.0 for ln in f if ln.startswith("MemAvailable")][0]
+    except (OSError, IndexError, ValueError):
+        avail = 0.0
+    if avail < 2.5 * need:
+        return {"skipped": f"host MemAvailable {avail / 1e9:.0f} GB < 2.5 x {need / 1e9:.0f} GB"}
+    t0 = time.perf_counter()
+    rp, ci, v = np.empty(n + 1, np.int64), np.empty(op_nnz, np.int32), np.empty(op_nnz, np.float64)
+    rc = L.das_op_export(h, rp.ctypes.data_as(C.POINTER(C.c_longlong)), ci.ctypes.data_as(C.POINTER(C.c_int)), v.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc < 0:
+        return {"skipped": L.das_last_error().decode()[:200]}
+    t_copy = time.perf_counter() - t0
+    threads = max(1, min(64, os.cpu_count() or 1))
+    cuts = np.searchsorted(rp, np.linspace(0, op_nnz, threads + 1))
+    cuts[0], cuts[-1] = 0, n
+    lib = OL.lib()
+    x = np.random.default_rng(2).uniform(-1.0, 1.0, n)
+    y = np.empty(n)
+    lp, ip, dp = C.POINTER(C.c_longlong), C.POINTER(C.c_int), C.POINTER(C.c_double)
+    xp, cip, vp = x.ctypes.data_as(dp), ci.ctypes.data_as(ip), v.ctypes.data_as(dp)
+
+    def chunk(t):
+        a, b = int(cuts[t]), int(cuts[t + 1])
+        if b > a:  # rp holds absolute offsets: a row range needs no copy
+            lib.csr_spmv(b - a, C.cast(C.addressof(rp.ctypes.data_as(lp).contents) + 8 * a, lp), cip, vp, xp,
+                         C.cast(C.addressof(y.ctypes.data_as(dp).contents) + 8 * a, dp))
+
+    pool = ThreadPoolExecutor(max_workers=threads)
+    list(pool.map(chunk, range(threads)))  # warm-up (page faults of y)
+    reps, t1 = 0, time.perf_counter()
+    while reps < 3 or time.perf_counter() - t1 < seconds:
+        list(pool.map(chunk, range(threads)))
+        reps += 1
+        if reps >= 50:
+            break
+    dt = (time.perf_counter() - t1) / reps
+    pool.shutdown()
+    bytes_ = 12.0 * op_nnz + 4.0 * (n + 1) + 16.0 * n
+    return {"ms": dt * 1e3, "GBps": bytes_ / dt / 1e9, "threads": threads, "repetitions": reps, "device_to_host_copy_s": t_copy,
+            "what": "the bench operator itself (CSR copied back from the device), oracle C kernel csr_spmv, one row chunk of equal nnz per thread"}
 
 
 def cpu_baseline(a, dev_index, ncell_gpu):

@@ -219,6 +219,7 @@ _SIGS = {
     "das_destroy_drdwt_matrix_free": (C.c_int, [_VP]),
     "das_op_nnz": (C.c_longlong, [_VP]),
     "das_op_format_bytes": (C.c_longlong, [_VP]),
+    "das_op_export": (C.c_int, [_VP, c_ll_p, c_int_p, c_double_p]),
     "das_calc_drdwold_t_psi": (C.c_int, [_VP, C.c_int, c_double_p, c_double_p]),
     "das_set_old_time_fields": (C.c_int, [_VP, c_double_p, c_double_p]),
     "das_calc_jac_vec_product": (C.c_int, [_VP, c_double_p, c_double_p]),

@@ -16,111 +16,112 @@
 
 namespace das {
 
-constexpr int COLOR_BITWORDS = 64;  // 64 x 64 = 4096 colours per forbidden set (LDS bitmap per wavefront)
+constexpr int COLOR_MAXW = 64;  // up to 64 x 64 = 4096 colours (bitmap words per net: 8, doubled on overflow)
 
 struct ColorView {
     long long nGroups;
     const long long* gstart;   // nGroups+1: first column of every group (columns of a group share their kept-row list)
-    const long long* cptr;     // n+1: kept rows of a column
-    const int* crow;           // kept-row ids
-    const long long* krp;      // nKeep+1
-    const int* kcol;           // columns of the kept rows
+    const long long* cptr;     // n+1: kept rows ("nets") of a column
+    const int* crow;           // net ids (positions in the kept-row list)
+    const int* cpos;           // position of the column inside that net's (ascending) column list
+    int W;                     // bitmap words per net
+    unsigned long long* F;     // nNets x W: colours used by the columns of a net that are coloured so far
+    unsigned* done;            // nNets: how many columns of a net are coloured so far
     int* colors;               // n, -1 = not coloured yet
-    unsigned* ctrl;            // [0] ticket (one per group), [1] abort / overflow flag
+    unsigned* ctrl;            // [0] ticket (4 groups each), [1] abort (1) / overflow: more than 64 W colours (2)
 };
 
-// One workgroup per column group (ticket order = column order).  The four wavefronts share the kept rows of the group's
-// first column; every wavefront takes two rows at a time and keeps up to ten neighbour-colour gathers in flight per lane
-// (the per-group latency is what the dependent chain of the first-fit multiplies).
+// The serial first-fit, column j = smallest colour not used by a lower-numbered column sharing a kept row, as a data-flow
+// computation over NET BITMAPS.  Round 2 gathered the colours of the whole distance-2 neighbourhood with multiplicity (~63
+// nets x ~275 columns = 17 k words per column, 2e11 gathers at 2 M cells: 9.8 s, work-bound).  Here a net carries the bitmap
+// of the colours its columns use and a counter of how many of its columns are coloured.  Inside a net the columns are
+// coloured in ascending order (each waits for the ones before it), so column j at position pos of net r may proceed when
+// done[r] == pos, and the bitmap then holds exactly the colours of its lower-numbered columns: the forbidden set of j is the
+// OR of ~63 bitmaps (63 x W words instead of 17 k), its publication 63 atomicOr + 63 counter increments.  One wavefront per
+// column group, four groups per ticket, ticket order = column order (a waiting wave only waits for groups that are already
+// running); bounded spins.  The result is bit-identical to the host's serial sweep (tested).
 __global__ __launch_bounds__(256) void k_color_firstfit(ColorView P) {
     __shared__ unsigned sh_ticket;
-    __shared__ unsigned long long fb[COLOR_BITWORDS];
+    __shared__ unsigned long long fbs[4][COLOR_MAXW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = P.W;
     for (;;) {
-        __syncthreads();  // the previous group is done with fb / sh_ticket
+        __syncthreads();  // the previous groups are done with fbs / sh_ticket
         if (threadIdx.x == 0) sh_ticket = atomicAdd(&P.ctrl[0], 1u);
-        if (threadIdx.x < COLOR_BITWORDS) fb[threadIdx.x] = 0ull;
+        if (lane < W) fbs[wave][lane] = 0ull;
         __syncthreads();
-        const long long g = sh_ticket;
-        if (g >= P.nGroups) return;
-        const long long j0 = P.gstart[g], j1 = P.gstart[g + 1];
+        const long long g = (long long)sh_ticket * 4 + wave;
+        if ((long long)sh_ticket * 4 >= P.nGroups) return;
+        if (g >= P.nGroups) continue;
+        const long long j0 = P.gstart[g];
+        const int m = (int)(P.gstart[g + 1] - j0);
         const long long q0 = P.cptr[j0], q1 = P.cptr[j0 + 1];
-        for (long long q = q0 + 2 * wave; q < q1; q += 8) {
-            int jn[10], c[10];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const bool rowOk = q + h < q1;
-                const int r = rowOk ? P.crow[q + h] : 0;
-                const long long k0 = P.krp[r], k1 = rowOk ? P.krp[r + 1] : k0;
-#pragma unroll
-                for (int u = 0; u < 5; u++) {
-                    const long long k = k0 + lane + 64 * u;
-                    jn[5 * h + u] = k < k1 ? P.kcol[k] : 0x7fffffff;
+        // 1. wait until every net has coloured the columns in front of this group
+        bool dead = false;
+        for (long long q = q0 + lane; q < q1; q += 64) {
+            const int r = P.crow[q];
+            const unsigned need = (unsigned)P.cpos[q];
+            unsigned spins = 0;
+            while (__hip_atomic_load(&P.done[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0u &&
+                    (__hip_atomic_load(&P.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 24))) {
+                    __hip_atomic_store(&P.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
+                    break;
                 }
-                // rows longer than 320 entries: the tail goes through the generic loop below
-                for (long long k = k0 + lane + 320; k < k1; k += 64) {
-                    const int jx = P.kcol[k];
-                    if (jx >= j0) continue;
-                    int cx = P.colors[jx];
-                    while (cx < 0) cx = __hip_atomic_load(&P.colors[jx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cx < 64 * COLOR_BITWORDS) atomicOr(&fb[cx >> 6], 1ull << (cx & 63));
-                    else __hip_atomic_store(&P.ctrl[1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 10; u++) c[u] = jn[u] < j0 ? P.colors[jn[u]] : 0;  // (may be a stale -1 from this CU's L1)
-#pragma unroll
-            for (int u = 0; u < 10; u++) {
-                if (jn[u] >= j0) continue;  // not coloured yet in the serial order, a member of this group, or padding
-                int cx = c[u];
-                unsigned spins = 0;
-                while (cx < 0) {
-                    __builtin_amdgcn_s_sleep(4);  // a waiting lane must not flood the memory system (polling-cost)
-                    cx = __hip_atomic_load(&P.colors[jn[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (cx < 0 && (++spins & 1023u) == 0u) {
-                        if (__hip_atomic_load(&P.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || spins > (1u << 24)) {
-                            __hip_atomic_store(&P.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            cx = 0;
-                        }
-                    }
-                }
-                if (cx >= 64 * COLOR_BITWORDS) { __hip_atomic_store(&P.ctrl[1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); cx = 64 * COLOR_BITWORDS - 1; }
-                atomicOr(&fb[cx >> 6], 1ull << (cx & 63));
             }
         }
-        __syncthreads();
-        if (wave == 0) {
-            // the members of the group take the smallest free colours one after the other
-            unsigned long long mine = fb[lane];
-            for (long long j = j0; j < j1; j++) {
-                const unsigned long long w = ~mine;
-                int best = w ? (lane * 64 + __builtin_ctzll(w)) : (1 << 30);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
-                if (best >= 64 * COLOR_BITWORDS) { best = 64 * COLOR_BITWORDS - 1; if (lane == 0) __hip_atomic_store(&P.ctrl[1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                if (lane == (best >> 6)) mine |= 1ull << (best & 63);
-                if (lane == 0) __hip_atomic_store(&P.colors[j], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__any(dead)) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // 2. forbidden set = OR of the nets' bitmaps (read past the L1 / the other XCDs' L2: agent scope)
+        for (long long q = q0 + lane; q < q1; q += 64) {
+            const unsigned long long* f = P.F + (long long)P.crow[q] * W;
+            for (int w = 0; w < W; w++) {
+                const unsigned long long x = __hip_atomic_load(&f[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x) atomicOr(&fbs[wave][w], x);
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        // 3. the members of the group take the smallest free colours one after the other (lane w owns word w)
+        unsigned long long mine = lane < W ? fbs[wave][lane] : ~0ull;
+        int cs[8];
+        const int mm = m < 8 ? m : 8;
+        bool over = false;
+        for (int i = 0; i < mm; i++) {
+            const unsigned long long wz = ~mine;
+            int best = wz ? (lane * 64 + __builtin_ctzll(wz)) : (1 << 30);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+            if (best >= 64 * W) { over = true; best = 64 * W - 1; }
+            if (lane == (best >> 6)) mine |= 1ull << (best & 63);
+            cs[i] = best;
+        }
+        if (over || m > 8) { if (lane == 0) __hip_atomic_store(&P.ctrl[1], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        for (int i = 0; i < mm; i++) if (lane == 0) P.colors[j0 + i] = cs[i];
+        // 4. publish: the colours into every net's bitmap, THEN the counters (release order)
+        for (long long q = q0 + lane; q < q1; q += 64) {
+            unsigned long long* f = P.F + (long long)P.crow[q] * W;
+            for (int i = 0; i < mm; i++)
+                __hip_atomic_fetch_or(&f[cs[i] >> 6], 1ull << (cs[i] & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        for (long long q = q0 + lane; q < q1; q += 64)
+            __hip_atomic_fetch_add(&P.done[P.crow[q]], (unsigned)mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// colours of the serial first-fit on the device.  keep/cptr/crow: the kept (non-dominated) rows and the CSC over them
-// (das_jaccon.cpp); returns false if the device path could not be used (more than 4096 colours, timeout): the caller then
-// falls back to... nothing - the host algorithm is run instead, loudly.
+// colours of the serial first-fit on the device.  keep/cptr/crow/cpos: the kept (non-dominated) rows and the CSC over them with
+// the position of every column inside its nets (das_jaccon.cpp); returns false if the device path could not be used (more than
+// 4096 colours, timeout): the caller then runs the host algorithm instead, loudly.
 inline bool color_firstfit_device(long long n, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
-                                  const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors, hipStream_t st) {
+                                  const uvector<int>& cpos, const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors,
+                                  hipStream_t st) {
     const long long nKeep = (long long)keep.size();
     const bool dbg = getenv("DAS_DEBUG_TIMING") != nullptr;
     double tq = wall_seconds();
     auto lap = [&](const char* what) { if (dbg) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]     device colouring: %s %.2f s\n", what, t2 - tq); tq = t2; } };
-    // compact pattern of the kept rows
-    std::vector<long long> krp(nKeep + 1, 0);
-    for (long long q = 0; q < nKeep; q++) krp[q + 1] = krp[q] + (rowptr[keep[q] + 1] - rowptr[keep[q]]);
-    uvector<int> kcol(krp[nKeep]);
-#pragma omp parallel for schedule(static)
-    for (long long q = 0; q < nKeep; q++) std::copy(col.begin() + rowptr[keep[q]], col.begin() + rowptr[keep[q] + 1], kcol.begin() + krp[q]);
-    // crow holds row ids of the full pattern: translate to kept-row positions
+    // crow holds row ids of the full pattern: translate to kept-row positions (net ids)
     std::vector<int> posOfRow;
     {
         long long nrows = (long long)rowptr.size() - 1;
@@ -139,40 +140,49 @@ inline bool color_firstfit_device(long long n, const std::vector<long long>& kee
             const long long len = cptr[j + 1] - cptr[j];
             isStart[j] = !(cptr[j] - cptr[j - 1] == len && std::equal(crow.begin() + cptr[j], crow.begin() + cptr[j + 1], crow.begin() + cptr[j - 1]));
         }
+        // a group of more than 8 columns is cut (the kernel colours at most 8 members at once)
         gstart.reserve(n);
-        for (long long j = 0; j < n; j++) if (isStart[j]) gstart.push_back(j);
+        long long run = 0;
+        for (long long j = 0; j < n; j++) {
+            if (isStart[j] || run == 8) { gstart.push_back(j); run = 0; }
+            run++;
+        }
     }
     lap("host preparation");
     const long long nGroups = (long long)gstart.size();
     gstart.push_back(n);
-    DevBuf<long long> d_gstart, d_cptr, d_krp;
-    DevBuf<int> d_crow, d_kcol, d_colors(n);
-    DevBuf<unsigned> d_ctrl(2);
-    d_gstart.upload(gstart); d_cptr.upload(cptr); d_krp.upload(krp);
-    d_crow.upload(crowK.data(), crowK.size()); d_kcol.upload(kcol.data(), kcol.size());
-    DAS_HIP(hipMemsetAsync(d_colors.p, 0xff, n * sizeof(int), st));
-    DAS_HIP(hipMemsetAsync(d_ctrl.p, 0, 2 * sizeof(unsigned), st));
-    DAS_HIP(hipStreamSynchronize(st));
+    DevBuf<long long> d_gstart, d_cptr;
+    DevBuf<int> d_crow, d_cpos, d_colors(n);
+    DevBuf<unsigned> d_ctrl(2), d_done(std::max<long long>(1, nKeep));
+    d_gstart.upload(gstart); d_cptr.upload(cptr);
+    d_crow.upload(crowK.data(), crowK.size()); d_cpos.upload(cpos.data(), cpos.size());
     lap("upload");
-    ColorView V{nGroups, d_gstart.p, d_cptr.p, d_crow.p, d_krp.p, d_kcol.p, d_colors.p, d_ctrl.p};
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    // workgroups in flight = the window of consecutive column groups being coloured.  Neighbouring groups conflict, so the
-    // parallelism inside the window comes from the rows / planes of cells it spans: measured, the kernel time falls like
-    // 1 / window up to the residency limit (200 k cells: 5.8 s with 64 workgroups, 0.8 s with 1024; profiles/README.md)
     long long wgs = (long long)cus * 8;
     if (const char* e = getenv("DAS_COLOR_WGS")) wgs = std::max(1, atoi(e));
-    const int grid = (int)std::min<long long>(wgs, nGroups + 1);
-    hipLaunchKernelGGL(k_color_firstfit, dim3(grid), dim3(256), 0, st, V);
-    DAS_HIP(hipGetLastError());
-    unsigned ctrl[2] = {0, 0};
-    DAS_HIP(hipMemcpyAsync(ctrl, d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, st));
-    DAS_HIP(hipStreamSynchronize(st));
-    lap("kernel");
-    if (ctrl[1] != 0u) return false;
-    colors.resize(n);
-    d_colors.download(colors.data(), n);
-    return true;
+    const int grid = (int)std::min<long long>(wgs, (nGroups + 3) / 4 + 1);
+    (void)col;
+    for (int W = 8; W <= COLOR_MAXW; W *= 2) {
+        DevBuf<unsigned long long> d_F((size_t)std::max<long long>(1, nKeep) * W);
+        DAS_HIP(hipMemsetAsync(d_F.p, 0, d_F.n * sizeof(unsigned long long), st));
+        DAS_HIP(hipMemsetAsync(d_done.p, 0, d_done.n * sizeof(unsigned), st));
+        DAS_HIP(hipMemsetAsync(d_colors.p, 0xff, n * sizeof(int), st));
+        DAS_HIP(hipMemsetAsync(d_ctrl.p, 0, 2 * sizeof(unsigned), st));
+        ColorView V{nGroups, d_gstart.p, d_cptr.p, d_crow.p, d_cpos.p, W, d_F.p, d_done.p, d_colors.p, d_ctrl.p};
+        hipLaunchKernelGGL(k_color_firstfit, dim3(grid), dim3(256), 0, st, V);
+        DAS_HIP(hipGetLastError());
+        unsigned ctrl[2] = {0, 0};
+        DAS_HIP(hipMemcpyAsync(ctrl, d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, st));
+        DAS_HIP(hipStreamSynchronize(st));
+        if (ctrl[1] == 2u) continue;  // more than 64 W colours: wider bitmaps
+        lap("kernel");
+        if (ctrl[1] != 0u) return false;
+        colors.resize(n);
+        d_colors.download(colors.data(), n);
+        return true;
+    }
+    return false;
 }
 
 // =====================================================================================================================

@@ -77,6 +77,81 @@ struct DevBuf {
     }
 };
 
+// ---- large device buffer through the virtual-memory API ----------------------------------------------------------
+// Measured on the MI355X (tools/gpu/alloc_bench.hip, profiles/r03h_alloc_bench.log): hipMalloc returns 8 or 32 GB at once, but
+// one 128 GB block takes 4.6 s - and the Krylov basis of the reference's default restart (1000 vectors) IS 129 GB at 2 M cells:
+// the first adjoint solve paid 3-4 s just to get it.  Reserving the address range and mapping 2 GB physical chunks
+// (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess) costs milliseconds for the same amount; the kernels see
+// one contiguous range.  Any failure of the VM path falls back to hipMalloc.
+template <class T>
+struct VmBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    bool vmm = false;
+    size_t reserved = 0, chunkBytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<size_t> sizes;
+    VmBuf() = default;
+    VmBuf(const VmBuf&) = delete;
+    VmBuf& operator=(const VmBuf&) = delete;
+    ~VmBuf() { release(); }
+    void release() {
+        if (vmm && p) {
+            size_t off = 0;
+            for (size_t i = 0; i < handles.size(); i++) {
+                (void)hipMemUnmap((char*)p + off, sizes[i]);
+                (void)hipMemRelease(handles[i]);
+                off += sizes[i];
+            }
+            (void)hipMemAddressFree(p, reserved);
+        } else if (p) {
+            (void)hipFree(p);
+        }
+        handles.clear(); sizes.clear();
+        p = nullptr; n = 0; vmm = false; reserved = 0;
+    }
+    bool try_vmm(size_t bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) return false;
+        const size_t align = std::max<size_t>(gran, (size_t)2 << 20);
+        const size_t total = (bytes + align - 1) / align * align;
+        void* base = nullptr;
+        if (hipMemAddressReserve(&base, total, align, nullptr, 0) != hipSuccess || !base) { (void)hipGetLastError(); return false; }
+        p = (T*)base; reserved = total; vmm = true;
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        const size_t chunk = (size_t)2 << 30;
+        for (size_t off = 0; off < total; off += chunk) {
+            const size_t sz = std::min(chunk, total - off);
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { (void)hipGetLastError(); release(); return false; }
+            if (hipMemMap((char*)base + off, sz, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); (void)hipGetLastError(); release(); return false; }
+            handles.push_back(h); sizes.push_back(sz);
+            if (hipMemSetAccess((char*)base + off, sz, &acc, 1) != hipSuccess) { (void)hipGetLastError(); release(); return false; }
+        }
+        return true;
+    }
+    void alloc(size_t n_) {
+        release();
+        if (!n_) return;
+        const size_t bytes = n_ * sizeof(T);
+        // small buffers: plain hipMalloc (fast below tens of GB, and the test meshes allocate thousands of them)
+        if (bytes >= ((size_t)8 << 30) && !getenv("DAS_NO_VMM") && try_vmm(bytes)) { n = n_; return; }
+        DAS_HIP(hipMalloc((void**)&p, bytes));
+        n = n_;
+    }
+    void zero() {
+        if (n) DAS_HIP(hipMemset(p, 0, n * sizeof(T)));
+    }
+};
+
 // ---- options: flattened DAOPTION keys (reference dafoam/pyDAFoam.py:39-661) ---------------------
 struct Options {
     std::map<std::string, double> d;

@@ -929,7 +929,8 @@ struct das_ksp {
         std::vector<int> h_agg;     // local aggregate of every cell (-1: not owned), as handed out by das_ksp_get_coarse
     } coarse;
     int restart = 0;
-    DevBuf<double> V, w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
+    VmBuf<double> V;  // Krylov basis: up to 129 GB (reference default restart at 2 M cells) - mapped through the VM API
+    DevBuf<double> w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
     std::unique_ptr<struct GmresRun> run;
     std::unique_ptr<struct BlockWork> block;
     std::vector<double> block_res0, block_res;
@@ -1070,13 +1071,14 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
             ColorDeviceFn fn = nullptr;
             if (s->inited && s->opt.geti("amd.coloringOnDevice"))
                 fn = [s](long long nn, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
-                         const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors) {
-                    // amd.coloringAlgorithm "speculative" (default): rounds of speculative first-fit over net bitmaps;
-                    // "firstfit": the serial first-fit as a data-flow kernel (fewest colours, 20 x the time at 2 M cells)
+                         const uvector<int>& cpos, const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors) {
+                    // amd.coloringAlgorithm "firstfit" (default): the serial first-fit as a data-flow kernel over net bitmaps (the
+                    // host's serial colours, bit for bit); "speculative": rounds of speculate / detect / retry over the same bitmaps
+                    // (order-independent, ~20 % more colours; kept for patterns whose index order gives no wavefront parallelism)
                     auto it = s->opt.s.find("amd.coloringAlgorithm");
-                    const bool spec = it == s->opt.s.end() || it->second != "firstfit";
+                    const bool spec = it != s->opt.s.end() && it->second == "speculative";
                     const bool ok = spec ? color_speculative_device(nn, keep, cptr, crow, rowptr, col, colors, s->stream, &s->colorRounds)
-                                         : color_firstfit_device(nn, keep, cptr, crow, rowptr, col, colors, s->stream);
+                                         : color_firstfit_device(nn, keep, cptr, crow, cpos, rowptr, col, colors, s->stream);
                     if (!ok) fprintf(stderr, "[dafoam_amd] device colouring gave up (too many colours or a timeout): host first-fit instead\n");
                     return ok;
                 };
@@ -3165,6 +3167,18 @@ static void function_gradient(das_solver* s, const char* name, double seed, doub
 }
 
 long long das_op_nnz(das_solver_t* s) { return (s && s->op) ? s->op->m.nnz : -1; }
+// the operator initializedRdWTMatrixFree assembled, as CSR on the host (bench.py: the CPU baseline multiplies the SAME matrix)
+int das_op_export(das_solver_t* s, long long* rowptr, int* colidx, double* vals) {
+    DAS_TRY
+    DAS_CHECK(s && s->op, DAS_ERR_STATE, "initializedRdWTMatrixFree() has not been called");
+    DAS_CHECK(rowptr && colidx && vals, DAS_ERR_ARG, "null argument");
+    const Mat& M = s->op->m;
+    M.rowptr.download(rowptr, M.n + 1);
+    M.col.download(colidx, M.nnz);
+    M.val.download(vals, M.nnz);
+    return DAS_OK;
+    DAS_CATCH
+}
 // bytes of matrix data one dRdW^T.psi product streams in the operator's storage format (packed vector rows + CSR scalar rows)
 long long das_op_format_bytes(das_solver_t* s) {
     if (!s || !s->op) return -1;

@@ -281,26 +281,32 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
     // colouring constraint (for the reference's tables every row of a cell / owned face is a subset
     // of that cell's pRes row).  Generic: the subset test decides, no solver-specific assumption.
     long long nAnch = 0;
+#pragma omp parallel for reduction(max : nAnch) schedule(static)
     for (long long r = 0; r < n; r++) nAnch = std::max<long long>(nAnch, con.anchor[r] + 1);
     std::vector<long long> dom(nAnch, -1);
-    for (long long r = 0; r < n; r++) {
+    for (long long r = 0; r < n; r++) {  // (serial: rows of one anchor are not contiguous across the state blocks)
         long long len = con.rowptr[r + 1] - con.rowptr[r];
         long long& d = dom[con.anchor[r]];
         if (d < 0 || len > con.rowptr[d + 1] - con.rowptr[d]) d = r;
     }
     std::vector<long long> keep;
-    keep.reserve(nAnch * 2);
-    for (long long r = 0; r < n; r++) {
-        long long len = con.rowptr[r + 1] - con.rowptr[r];
-        if (!len) continue;
-        long long d = dom[con.anchor[r]];
-        if (d != r && is_subset(&con.col[con.rowptr[r]], len, &con.col[con.rowptr[d]], con.rowptr[d + 1] - con.rowptr[d])) continue;
-        keep.push_back(r);
+    {
+        // the subset tests are independent per row: flags in parallel, then the kept rows in ascending order
+        std::vector<unsigned char> kept(n, 0);
+#pragma omp parallel for schedule(dynamic, 4096)
+        for (long long r = 0; r < n; r++) {
+            long long len = con.rowptr[r + 1] - con.rowptr[r];
+            if (!len) continue;
+            long long d = dom[con.anchor[r]];
+            kept[r] = !(d != r && is_subset(&con.col[con.rowptr[r]], len, &con.col[con.rowptr[d]], con.rowptr[d + 1] - con.rowptr[d]));
+        }
+        keep.reserve(nAnch * 2);
+        for (long long r = 0; r < n; r++) if (kept[r]) keep.push_back(r);
     }
     lap("prune");
     // CSC over kept rows: stable chunked counting (like JacCon::build_transpose_and_maps), int row ids, no zero-fill
     std::vector<long long> cptr(n + 1, 0);
-    uvector<int> crow;
+    uvector<int> crow, cpos;  // cpos: position of the column inside the (ascending) column list of that kept row
     {
         const long long nk = (long long)keep.size();
         const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 32LL, nk}));
@@ -314,23 +320,28 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
             for (long long q = q0[t]; q < q0[t + 1]; q++)
                 for (long long k = con.rowptr[keep[q]]; k < con.rowptr[keep[q] + 1]; k++) cnt[t][con.col[k]]++;
         }
-        for (long long j = 0; j < n; j++) {
-            long long tot = 0;
-            for (int t = 0; t < T; t++) tot += cnt[t][j];
-            cptr[j + 1] = cptr[j] + tot;
-        }
+        // per column: total over the chunks (-> cptr by a serial prefix over n values) and the offset of every chunk inside it
 #pragma omp parallel for schedule(static)
         for (long long j = 0; j < n; j++) {
             int acc = 0;
             for (int t = 0; t < T; t++) { int c = cnt[t][j]; cnt[t][j] = acc; acc += c; }
+            cptr[j + 1] = acc;
         }
+        for (long long j = 0; j < n; j++) cptr[j + 1] += cptr[j];
         crow.resize(cptr[n]);
+        if (device_fn) cpos.resize(cptr[n]);
+        const bool wantPos = (bool)device_fn;
 #pragma omp parallel for schedule(static, 1) num_threads(T)
         for (int t = 0; t < T; t++) {
             uvector<int>& pos = cnt[t];
             for (long long q = q0[t]; q < q0[t + 1]; q++) {
                 const long long r = keep[q];
-                for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) { const int j = con.col[k]; crow[cptr[j] + pos[j]++] = (int)r; }
+                for (long long k = con.rowptr[r]; k < con.rowptr[r + 1]; k++) {
+                    const int j = con.col[k];
+                    const long long dst = cptr[j] + pos[j]++;
+                    crow[dst] = (int)r;
+                    if (wantPos) cpos[dst] = (int)(k - con.rowptr[r]);
+                }
             }
         }
     }
@@ -374,7 +385,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         }
     };
     lap("csc");
-    if (device_fn && device_fn(n, keep, cptr, crow, con.rowptr, con.col, colors)) {
+    if (device_fn && device_fn(n, keep, cptr, crow, cpos, con.rowptr, con.col, colors)) {
         lap("device first-fit");
         int ncd = 0;
         for (long long j = 0; j < n; j++) ncd = std::max(ncd, colors[j] + 1);
@@ -587,17 +598,14 @@ void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
     }
     lap("count");
     t_rowptr.assign(n + 1, 0);
-    for (long long j = 0; j < n; j++) {
-        long long tot = 0;
-        for (int t = 0; t < T; t++) tot += cnt[t][j];
-        t_rowptr[j + 1] = t_rowptr[j] + tot;
-    }
-    // cnt[t][j] := offset of chunk t inside transposed row j
+    // cnt[t][j] := offset of chunk t inside transposed row j; row lengths -> t_rowptr by a serial prefix over n values
 #pragma omp parallel for schedule(static)
     for (long long j = 0; j < n; j++) {
         int acc = 0;
         for (int t = 0; t < T; t++) { int c = cnt[t][j]; cnt[t][j] = acc; acc += c; }
+        t_rowptr[j + 1] = acc;
     }
+    for (long long j = 0; j < n; j++) t_rowptr[j + 1] += t_rowptr[j];
     lap("prefix");
     t_col.resize(nnz);
     lap("alloc");

@@ -82,7 +82,8 @@ struct JacCon {
 // `device_fn` (optional): called with the kept rows and the CSC over them; if it returns true it has written `colors`
 // (the device first-fit of das_color.hpp), otherwise the host variants run.
 using ColorDeviceFn = std::function<bool(long long n, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
-                                         const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors)>;
+                                         const uvector<int>& cpos, const std::vector<long long>& rowptr, const uvector<int>& col,
+                                         std::vector<int>& colors)>;
 int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres = nullptr, const ColorDeviceFn& device_fn = nullptr);
 bool validate_coloring(const JacCon& con, const std::vector<int>& colors);
 

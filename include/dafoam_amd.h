@@ -213,6 +213,8 @@ long long das_op_nnz(das_solver_t* s);
 /* bytes of matrix data one dRdW^T.psi product streams in the operator's storage format: vector-state rows packed as group
  * rows (one int32 column list + three fp64 value planes per 16 entries, csrc/das_opmat.hpp), scalar rows as CSR (12 B/entry) */
 long long das_op_format_bytes(das_solver_t* s);
+/* the operator of initializedRdWTMatrixFree as CSR arrays on the host (rowptr[n+1], colidx[das_op_nnz], vals[das_op_nnz]) */
+int das_op_export(das_solver_t* s, long long* rowptr, int* colidx, double* vals);
 
 /* ---- unsteady adjoint terms (DAScalarTransportFoam, BASELINE configs[0]) ---------------------------------------------
  * das_calc_drdwold_t_psi <- calcdRdWOldTPsiAD(oldTimeLevel, psi, dRdWOldTPsi)  pyDASolvers.pyx:240 (DASolver.C:1910-1969):
