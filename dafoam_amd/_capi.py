@@ -74,6 +74,7 @@ class das_case_t(C.Structure):
         ("transport_sutherland", C.c_int),
         ("sutherland_As", C.c_double),
         ("sutherland_Ts", C.c_double),
+        ("beta_fi_nuTilda", c_double_p),
     ]
 
 
@@ -123,6 +124,8 @@ class CaseStruct:
         k["y_wall"] = None if case.y_wall is None else np.ascontiguousarray(case.y_wall, dtype=np.float64)
         k["phi_frozen"] = None if case.phi is None else np.ascontiguousarray(case.phi, dtype=np.float64)
         k["T_old"] = None if case.T_old is None else np.ascontiguousarray(case.T_old, dtype=np.float64)
+        bfi = getattr(case, "beta_fi", None)
+        k["beta_fi"] = None if bfi is None else np.ascontiguousarray(bfi, dtype=np.float64)
         s = self.struct = das_case_t()
         s.solver = SOLVER_IDS[case.solver_name]
         s.n_points, s.n_faces, s.n_internal_faces, s.n_cells, s.n_patches = (
@@ -147,6 +150,7 @@ class CaseStruct:
         s.deltaT = case.deltaT
         th = getattr(case, "thermo", None) or {}
         s.Cp, s.molWeight, s.mu, s.Pr, s.Prt = (th.get("Cp", 1005.0), th.get("molWeight", 28.96), th.get("mu", 1.8e-5), th.get("Pr", 0.7), th.get("Prt", 1.0))
+        s.beta_fi_nuTilda = _dp(k["beta_fi"])
         s.transport_sutherland = 1 if th.get("transport", "const") == "sutherland" else 0
         s.sutherland_As, s.sutherland_Ts = th.get("As", 1.4792e-06), th.get("Ts", 116.0)
         mrf = getattr(case, "mrf", None)
@@ -225,6 +229,9 @@ _SIGS = {
     "das_calc_jac_vec_product": (C.c_int, [_VP, c_double_p, c_double_p]),
     "das_set_patch_value": (C.c_int, [_VP, c_int_p, C.c_int, C.c_char_p, c_double_p]),
     "das_get_patch_value": (C.c_int, [_VP, C.c_int, C.c_char_p, c_double_p]),
+    "das_set_field": (C.c_int, [_VP, C.c_char_p, c_double_p]),
+    "das_get_field": (C.c_int, [_VP, C.c_char_p, c_double_p]),
+    "das_calc_dfield_product": (C.c_int, [_VP, C.c_char_p, C.c_char_p, C.c_char_p, c_double_p, c_double_p]),
     "das_calc_dbc_product": (C.c_int, [_VP, c_int_p, C.c_int, C.c_char_p, c_double_p, C.c_char_p, C.c_char_p, c_double_p, c_double_p]),
     "das_define_force_function": (C.c_int, [_VP, C.c_char_p, c_int_p, C.c_int, c_double_p, C.c_double]),
     "das_define_face_function": (C.c_int, [_VP, C.c_char_p, C.c_char_p, c_int_p, c_int_p, C.c_int, c_double_p, c_double_p, C.c_double, C.c_double]),

@@ -12,6 +12,11 @@ struct CaseParams {
     double As = 1.4792e-06, Ts = 116.0;
     double om[3] = {0, 0, 0}, org[3] = {0, 0, 0};
     std::vector<double> phi_frozen, T_old;
+    // `field` inputs (reference DAInputField.C): betaFINuTilda per cell; the pointers are what the kernels read (device memory
+    // in the library, the host vector in the test harness), null = field absent (= 1) / no tangent
+    std::vector<double> beta_fi;
+    const double* betaFI_ptr = nullptr;
+    const double* dBetaFI_ptr = nullptr;
     void from_case(const das_case_t* c) {
         solver = c->solver;
         nu = c->nu;
@@ -42,6 +47,7 @@ struct CaseParams {
                 DAS_CHECK(As > 0 && Ts >= 0, DAS_ERR_ARG, "sutherland transport needs As > 0, Ts >= 0");
             }
         }
+        if (c->beta_fi_nuTilda) beta_fi.assign(c->beta_fi_nuTilda, c->beta_fi_nuTilda + c->n_cells);
         if (c->phi_frozen) phi_frozen.assign(c->phi_frozen, c->phi_frozen + c->n_faces);
         if (c->T_old) T_old.assign(c->T_old, c->T_old + c->n_cells);
         if (solver == DAS_SOLVER_SCALARTRANSPORTFOAM)
@@ -86,6 +92,8 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.transonicPC = cp.transonicPC;
     p.mrf = cp.mrf;
     p.wTU = nullptr;
+    p.betaFI = cp.betaFI_ptr;
+    p.dBetaFI = cp.dBetaFI_ptr;
     for (int k = 0; k < 3; k++) { p.om[k] = cp.om[k]; p.org[k] = cp.org[k]; }
     return p;
 }

@@ -78,19 +78,26 @@ struct DevBuf {
 };
 
 // ---- large device buffer through the virtual-memory API ----------------------------------------------------------
-// Measured on the MI355X (tools/gpu/alloc_bench.hip, profiles/r03h_alloc_bench.log): hipMalloc returns 8 or 32 GB at once, but
-// one 128 GB block takes 4.6 s - and the Krylov basis of the reference's default restart (1000 vectors) IS 129 GB at 2 M cells:
-// the first adjoint solve paid 3-4 s just to get it.  Reserving the address range and mapping 2 GB physical chunks
-// (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess) costs milliseconds for the same amount; the kernels see
-// one contiguous range.  Any failure of the VM path falls back to hipMalloc.
+// The Krylov basis of the reference's default restart (1000 vectors) is 129 GB at 2 M cells.  Measured on the MI355X
+// (tools/gpu/alloc_bench.hip, profiles/r03h_alloc_bench.log; bench runs r03g / r03i): getting such a block right after other
+// multi-GB buffers were freed (the assembly maps, a smaller basis) stalls for 3-5 s - freed HBM is scrubbed before it is handed
+// out again - whether it comes from hipMalloc or from hipMemCreate.  So the basis is never allocated in one piece and never
+// re-allocated: the address range for the largest basis the memory budget allows is RESERVED once (free), and 2 GB physical
+// chunks are mapped on demand while the iteration advances (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess):
+// a solve that converges after 464 vectors maps 60 GB, not 129, the mapping of the next chunk costs milliseconds, and the
+// scrubbing of freed memory overlaps with the first iterations.  The kernels see one contiguous range.  Any failure of the VM
+// path falls back to one hipMalloc of the whole range.
 template <class T>
 struct VmBuf {
     T* p = nullptr;
-    size_t n = 0;
+    size_t n = 0;        // reserved elements (the capacity the kernels may address once mapped)
+    size_t mappedBytes = 0;
     bool vmm = false;
-    size_t reserved = 0, chunkBytes = 0;
+    size_t reservedBytes = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;
     std::vector<size_t> sizes;
+    hipMemAllocationProp prop = {};
+    static constexpr size_t CHUNK = (size_t)2 << 30;
     VmBuf() = default;
     VmBuf(const VmBuf&) = delete;
     VmBuf& operator=(const VmBuf&) = delete;
@@ -103,53 +110,58 @@ struct VmBuf {
                 (void)hipMemRelease(handles[i]);
                 off += sizes[i];
             }
-            (void)hipMemAddressFree(p, reserved);
+            (void)hipMemAddressFree(p, reservedBytes);
         } else if (p) {
             (void)hipFree(p);
         }
         handles.clear(); sizes.clear();
-        p = nullptr; n = 0; vmm = false; reserved = 0;
+        p = nullptr; n = 0; vmm = false; reservedBytes = 0; mappedBytes = 0;
     }
-    bool try_vmm(size_t bytes) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        hipMemAllocationProp prop = {};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = dev;
-        size_t gran = 0;
-        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) return false;
-        const size_t align = std::max<size_t>(gran, (size_t)2 << 20);
-        const size_t total = (bytes + align - 1) / align * align;
-        void* base = nullptr;
-        if (hipMemAddressReserve(&base, total, align, nullptr, 0) != hipSuccess || !base) { (void)hipGetLastError(); return false; }
-        p = (T*)base; reserved = total; vmm = true;
-        hipMemAccessDesc acc = {};
-        acc.location = prop.location;
-        acc.flags = hipMemAccessFlagsProtReadWrite;
-        const size_t chunk = (size_t)2 << 30;
-        for (size_t off = 0; off < total; off += chunk) {
-            const size_t sz = std::min(chunk, total - off);
-            hipMemGenericAllocationHandle_t h;
-            if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { (void)hipGetLastError(); release(); return false; }
-            if (hipMemMap((char*)base + off, sz, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); (void)hipGetLastError(); release(); return false; }
-            handles.push_back(h); sizes.push_back(sz);
-            if (hipMemSetAccess((char*)base + off, sz, &acc, 1) != hipSuccess) { (void)hipGetLastError(); release(); return false; }
-        }
-        return true;
-    }
-    void alloc(size_t n_) {
+    // reserve the address range for n_ elements (nothing is mapped yet on the VM path)
+    void reserve(size_t n_) {
         release();
         if (!n_) return;
         const size_t bytes = n_ * sizeof(T);
-        // small buffers: plain hipMalloc (fast below tens of GB, and the test meshes allocate thousands of them)
-        if (bytes >= ((size_t)8 << 30) && !getenv("DAS_NO_VMM") && try_vmm(bytes)) { n = n_; return; }
-        DAS_HIP(hipMalloc((void**)&p, bytes));
-        n = n_;
+        int dev = 0;
+        if (bytes >= ((size_t)4 << 30) && !getenv("DAS_NO_VMM") && hipGetDevice(&dev) == hipSuccess) {
+            prop = hipMemAllocationProp{};
+            prop.type = hipMemAllocationTypePinned;
+            prop.location.type = hipMemLocationTypeDevice;
+            prop.location.id = dev;
+            size_t gran = 0;
+            if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0) {
+                const size_t align = std::max<size_t>(gran, (size_t)2 << 20);
+                const size_t total = (bytes + align - 1) / align * align;
+                void* base = nullptr;
+                if (hipMemAddressReserve(&base, total, align, nullptr, 0) == hipSuccess && base) {
+                    p = (T*)base; reservedBytes = total; vmm = true; n = n_;
+                    return;
+                }
+                (void)hipGetLastError();
+            }
+        }
+        DAS_HIP(hipMalloc((void**)&p, bytes));  // small buffers (fast) or no VM support
+        n = n_; mappedBytes = bytes;
     }
-    void zero() {
-        if (n) DAS_HIP(hipMemset(p, 0, n * sizeof(T)));
+    // make the first `count` elements addressable
+    void ensure(size_t count) {
+        if (!vmm) return;
+        const size_t need = std::min(reservedBytes, count * sizeof(T));
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        while (mappedBytes < need) {
+            const size_t sz = std::min(CHUNK, reservedBytes - mappedBytes);
+            hipMemGenericAllocationHandle_t h;
+            DAS_HIP(hipMemCreate(&h, sz, &prop, 0));
+            hipError_t e = hipMemMap((char*)p + mappedBytes, sz, 0, h, 0);
+            if (e != hipSuccess) { (void)hipMemRelease(h); DAS_HIP(e); }
+            handles.push_back(h); sizes.push_back(sz);
+            DAS_HIP(hipMemSetAccess((char*)p + mappedBytes, sz, &acc, 1));
+            mappedBytes += sz;
+        }
     }
+    void alloc(size_t n_) { reserve(n_); ensure(n_); }
 };
 
 // ---- options: flattened DAOPTION keys (reference dafoam/pyDAFoam.py:39-661) ---------------------

@@ -14,6 +14,7 @@
 #include <ctime>
 #include <functional>
 #include <numeric>
+#include <thread>
 
 #include "das_case.hpp"
 #include "das_jaccon.hpp"
@@ -929,7 +930,8 @@ struct das_ksp {
         std::vector<int> h_agg;     // local aggregate of every cell (-1: not owned), as handed out by das_ksp_get_coarse
     } coarse;
     int restart = 0;
-    VmBuf<double> V;  // Krylov basis: up to 129 GB (reference default restart at 2 M cells) - mapped through the VM API
+    VmBuf<double> V;  // Krylov basis: up to 129 GB (reference default restart at 2 M cells) - mapped chunk by chunk through the VM API
+    long long Vn = 0; // vector length the basis was reserved for
     DevBuf<double> w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
     std::unique_ptr<struct GmresRun> run;
     std::unique_ptr<struct BlockWork> block;
@@ -989,6 +991,7 @@ struct das_solver {
     };
     std::map<std::string, FaceFn> functions;
     int colorRounds = 0;        // rounds of the speculative device colouring (0: another algorithm ran)
+    DevBuf<double> d_betaFI, d_dBetaFI;  // `field` input betaFINuTilda and its tangent (das_set_field / das_calc_dfield_product)
     long long geomVersion = 0;  // bumped by das_update_of_mesh
     // everything else the Jacobian depends on besides the states and the geometry: patch values, old-time fields, options
     // (normalizeStates, residual / discretisation switches).  Every setter bumps the epoch; a cached operator is only
@@ -1054,6 +1057,13 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
     s->con_full.build(s->mesh, s->st_full);
     s->con_pc.build(s->mesh, s->st_pc);
     double t2 = wall_seconds();
+    // the transposed structures need no colours: a second host thread builds them while this one prepares and runs the
+    // colouring (whose 3 s data-flow kernel at 2 M cells leaves the host idle)
+    std::exception_ptr tErr;
+    std::thread transposer([&]() {
+        try { s->con_full.build_transpose(); s->con_pc.build_transpose(); } catch (...) { tErr = std::current_exception(); }
+    });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{transposer};
     if (preset) {
         s->colors.assign(preset, preset + s->n);
         int mx = -1;
@@ -1088,11 +1098,13 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
     double t3 = wall_seconds();
     DAS_CHECK(validate_coloring(s->con_full, s->colors), DAS_ERR_INTERNAL, "Conflicting Colors Found!");
     double t4 = wall_seconds();
-    s->con_full.build_transpose_and_maps(s->colors);
-    s->con_pc.build_transpose_and_maps(s->colors);
+    transposer.join();
+    if (tErr) std::rethrow_exception(tErr);
+    s->con_full.build_colour_lists(s->colors);
+    s->con_pc.build_colour_lists(s->colors);
     if (s->opt.geti("debug"))
-        fprintf(stderr, "[dafoam_amd] runColoring: pattern %.2f s, colouring %.2f s, validate %.2f s, transpose+maps %.2f s\n", t2 - t1, t3 - t2,
-                t4 - t3, wall_seconds() - t4);
+        fprintf(stderr, "[dafoam_amd] runColoring: pattern %.2f s, colouring (beside the transposes) %.2f s, validate %.2f s, wait for the transposes + colour lists %.2f s\n",
+                t2 - t1, t3 - t2, t4 - t3, wall_seconds() - t4);
     s->colored = true;
     for (int k = 0; k < 2; k++) s->cd[k].ready = false;
     if (s->opt.geti("debug"))
@@ -1845,10 +1857,18 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
     long long budget = (long long)(32.0 * 1024 * 1024 * 1024);
     auto it = s->opt.i.find("amd.maxKrylovBytes");
     if (it != s->opt.i.end()) budget = it->second;
-    restart = std::max<long long>(1, std::min<long long>(restart, budget / (8 * n) - 2));
-    if (k->restart != restart || k->V.n != (size_t)((restart + 2) * n)) {
+    const long long maxVec = std::max<long long>(3, budget / (8 * n));  // vectors the budget holds (restart + 2 of them are needed)
+    restart = std::max<long long>(1, std::min<long long>(restart, maxVec - 2));
+    // the basis: address range for the larger of this restart and what the reference's default restart (1000) would need inside
+    // the budget - reserved ONCE, so that a later solve with another restart never frees and re-allocates it; physical memory is
+    // mapped while the iteration advances (VmBuf::ensure in gmres_map_basis)
+    const long long wantVec = std::max<long long>(restart + 2, std::min<long long>(maxVec, 1002));
+    if (k->V.n < (size_t)((restart + 2) * n) || k->Vn != n) {
+        k->V.reserve((size_t)(wantVec * n));
+        k->Vn = n;
+    }
+    if (k->restart != restart || k->w.n != (size_t)n) {
         k->restart = (int)restart;
-        k->V.alloc((restart + 2) * n);  // m + 1 basis vectors and the pending vector of the delayed re-orthogonalisation
         k->w.alloc(n); k->z.alloc(n); k->r.alloc(n); k->xdev.alloc(n); k->bdev.alloc(n);
         k->z.zero();  // multi-GPU: ghost entries are never written by the PC and must stay zero
         int nb = nblk(n, MD_CHUNK);
@@ -1856,6 +1876,8 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
         k->hdev.alloc(4 * (restart + 3));
     }
 }
+// basis slots [0, nvec) are about to be written / read: map them (a no-op once mapped; milliseconds per new 2 GB chunk)
+static inline void gmres_map_basis(das_solver* s, das_ksp* k, long long nvec) { k->V.ensure((size_t)(nvec * s->n)); }
 
 // dev_out[0..m) = V^T w (V = m vectors of stride n starting at Vbase), dev_out[m] = w.w; summed over the ranks
 static void multidot_dev(das_solver* s, das_ksp* k, const double* Vbase, int m, const double* w, double* dev_out) {
@@ -2000,6 +2022,7 @@ static void gmres_begin(das_solver* s, das_ksp* k, const double* d_rhs, double* 
 static void gmres_cycle_start(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
     const long long n = s->n;
+    gmres_map_basis(s, k, 3);
     hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, k->r.p, k->V.p);
     std::fill(G.g.begin(), G.g.end(), 0.0);
     G.g[0] = G.beta;
@@ -2017,6 +2040,7 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
     const long long n = s->n;
     const int B = 256, m = G.m, j = G.j;
     hipStream_t st = s->stream;
+    gmres_map_basis(s, k, j + 3);
     const bool alwaysRefine = s->opt.geti("amd.cgsAlwaysRefine") != 0;
     const bool mgs = s->opt.geti("adjEqnOption.useMGSO") != 0;
     std::vector<double>&H = G.H, &hh = G.hh, &h2 = G.h2, &cs = G.cs, &sn = G.sn, &g = G.g;
@@ -2125,6 +2149,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     const long long n = s->n;
     const int m = G.m, j = G.pend;
     hipStream_t st = s->stream;
+    gmres_map_basis(s, k, j + 3);
     double* u = k->V.p + (long long)j * n;
     pc_apply_full(s, k, u, k->z.p);
     apply_operator(s, k->z.p, k->w.p);
@@ -2706,6 +2731,7 @@ int das_init_solver(das_solver_t* s, int device) {
     DAS_HIP(hipStreamCreate(&s->stream));
     s->own_stream = true;
     if (!s->owned.empty()) s->d_owned.upload(s->owned);
+    if (!s->cp.beta_fi.empty()) { s->d_betaFI.upload(s->cp.beta_fi); s->cp.betaFI_ptr = s->d_betaFI.p; }
     const Mesh& m = s->mesh;
     s->d_fg.upload(m.fg); s->d_cg.upload(m.cg);
     s->d_cf_ptr.upload(m.cf_ptr); s->d_cf_face.upload(m.cf_face); s->d_cf_other.upload(m.cf_other);
@@ -3287,6 +3313,73 @@ int das_calc_dbc_product(das_solver_t* s, const int* patches, int np, const char
     }
     DAS_HIP(hipGetLastError());
     DAS_HIP(hipMemcpyAsync(product, s->d_tmp1.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
+    return DAS_OK;
+    DAS_CATCH
+}
+
+// ---- `field` inputs (reference DAInputField.C): betaFINuTilda ----------------------------------------------------
+static void check_field(const char* name) {
+    DAS_CHECK(name && std::string(name) == "betaFINuTilda", DAS_ERR_ARG,
+              std::string("field input: fieldName \"") + (name ? name : "") + "\" is not implemented (betaFINuTilda is)");
+}
+int das_set_field(das_solver_t* s, const char* fieldName, const double* values) {
+    DAS_TRY
+    DAS_CHECK(s && values, DAS_ERR_ARG, "null argument");
+    check_field(fieldName);
+    DAS_CHECK(s->cp.solver != DAS_SOLVER_SCALARTRANSPORTFOAM, DAS_ERR_ARG, "betaFINuTilda needs a Spalart-Allmaras solver");
+    s->cp.beta_fi.assign(values, values + s->mesh.nC);
+    if (s->inited) {
+        DAS_HIP(hipStreamSynchronize(s->stream));
+        s->d_betaFI.upload(s->cp.beta_fi);
+        s->cp.betaFI_ptr = s->d_betaFI.p;
+    }
+    s->opEpoch++;
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_get_field(das_solver_t* s, const char* fieldName, double* values) {
+    DAS_TRY
+    DAS_CHECK(s && values, DAS_ERR_ARG, "null argument");
+    check_field(fieldName);
+    for (int c = 0; c < s->mesh.nC; c++) values[c] = s->cp.beta_fi.empty() ? 1.0 : s->cp.beta_fi[c];
+    return DAS_OK;
+    DAS_CATCH
+}
+// product_c = seeds . dR/d(field_c): every residual row depends on the field value of its own cell only, so ONE dual pass
+// with a unit tangent on all cells carries every derivative, and product_c = seed of the cell's nuTildaRes row x its tangent
+__global__ void k_field_product(long long N, long long offN, const Dual<1>* __restrict__ R, const double* __restrict__ seeds, double* __restrict__ out) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < N) out[c] = seeds[offN + c] * R[offN + c].d[0];
+}
+int das_calc_dfield_product(das_solver_t* s, const char* fieldName, const char* outputName, const char* outputType, const double* seeds,
+                            double* product) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(outputType && seeds && product, DAS_ERR_ARG, "null argument");
+    check_field(fieldName);
+    const std::string ot = outputType;
+    DAS_CHECK(ot == "residual" || ot == "function", DAS_ERR_ARG, "outputType not supported on this path: " + ot);
+    const long long N = s->mesh.nC, n = s->n;
+    if (ot == "function") {  // the patch-integral functions do not see the production term
+        (void)get_function(s, outputName);
+        std::fill(product, product + N, 0.0);
+        return DAS_OK;
+    }
+    hipStream_t st = s->stream;
+    const int B = 256;
+    if (s->cp.beta_fi.empty()) { s->cp.beta_fi.assign(N, 1.0); s->d_betaFI.upload(s->cp.beta_fi); s->cp.betaFI_ptr = s->d_betaFI.p; }
+    if (s->d_dBetaFI.n != (size_t)N) { std::vector<double> one(N, 1.0); s->d_dBetaFI.upload(one); }
+    struct Restore { das_solver* s; ~Restore() { s->cp.dBetaFI_ptr = nullptr; } } restore{s};
+    s->cp.dBetaFI_ptr = s->d_dBetaFI.p;
+    ResParams prm = make_params(s->cp, s->opt, 0);
+    if (s->d_Wd.n != (size_t)n) { s->d_Wd.alloc(n); s->d_Rd.alloc(n); }
+    hipLaunchKernelGGL(k_lift, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_W.p, s->d_Wd.p);  // states carry no tangent
+    eval_residual<Dual<1>>(s->dm, s->cp, prm, s->d_Wd.p, s->d_Rd.p, s->wk1, s->d_phiF.p, s->d_Told.p, st);
+    DAS_HIP(hipMemcpyAsync(s->d_tmp2.p, seeds, n * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_field_product, dim3(nblk(N, B)), dim3(B), 0, st, N, (long long)prm.offN * N, s->d_Rd.p, s->d_tmp2.p, s->d_tmp1.p);
+    DAS_HIP(hipGetLastError());
+    DAS_HIP(hipMemcpyAsync(product, s->d_tmp1.p, N * sizeof(double), hipMemcpyDeviceToHost, st));
     DAS_HIP(hipStreamSynchronize(st));
     return DAS_OK;
     DAS_CATCH

@@ -579,6 +579,11 @@ bool validate_coloring(const JacCon& con, const std::vector<int>& colors) {
 }
 
 void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
+    build_transpose();
+    build_colour_lists(colors);
+}
+
+void JacCon::build_transpose() {
     // Stable parallel counting transpose: the rows are cut into T contiguous chunks; pass 1 counts the entries of every
     // column per chunk, a prefix over (column, chunk) gives each chunk its start inside every transposed row, pass 2
     // lets every chunk fill its rows in ascending order.  Transposed rows come out sorted by residual index and the
@@ -620,6 +625,9 @@ void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
     }
     cnt.clear();
     lap("fill");
+}
+
+void JacCon::build_colour_lists(const std::vector<int>& colors) {
     // the columns sorted by colour (stable counting sort)
     int ncol = 0;
     for (long long jj = 0; jj < n; jj++) ncol = std::max(ncol, colors[jj] + 1);
@@ -631,7 +639,6 @@ void JacCon::build_transpose_and_maps(const std::vector<int>& colors) {
         std::vector<long long> pos(cl_ptr.begin(), cl_ptr.end() - 1);
         for (long long jj = 0; jj < n; jj++) cl_cols[pos[colors[jj]]++] = (int)jj;
     }
-    lap("colour lists");
 }
 
 }  // namespace das

@@ -74,6 +74,8 @@ struct JacCon {
     std::vector<int> cl_cols;
     void build(const Mesh& m, const Stencil& st);
     void build_transpose_and_maps(const std::vector<int>& colors);
+    void build_transpose();                                   // t_rowptr / t_col (needs no colours: can run beside the colouring)
+    void build_colour_lists(const std::vector<int>& colors);  // cl_ptr / cl_cols
 };
 
 // distance-2 (column) colouring of `con`: greedy first-fit over the non-dominated rows.

@@ -59,6 +59,9 @@ struct ResParams {
     double om[3], org[3];
     // DATurboFoam work array of the launch (typed by the kernel's scalar type): Teff.U per cell (3N)
     void* wTU;
+    // `field` input betaFINuTilda (per cell; null = 1) and its tangent (null = 0)
+    const double* betaFI;
+    const double* dBetaFI;
 };
 #define DAS_TREF 298.15
 
@@ -663,7 +666,10 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     const double cw36 = SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3;
     T fw = gg * dpow((1.0 + cw36) / (g6 + cw36), 1.0 / 6.0);
     T convdiff = ((dN + bdN) * nc + offN - sN - bsN) * rV;
-    T nres = convdiff - rho_c * ((SA_CB2 / SA_SIGMA) * (gNc[0] * gNc[0] + gNc[1] * gNc[1] + gNc[2] * gNc[2]) + SA_CB1 * Stilda * nc)
+    // betaFINuTilda: the field-inversion multiplier of the production term (reference DASpalartAllmaras.C:445-485, betaFINuTilda_;
+    // 1 unless a `field` input sets it, DAInputField.C); its tangent is the seed of calcJacTVecProduct(field -> residual)
+    const T betaFI = prm.betaFI ? MkSeed<T>::make(prm.betaFI[c], prm.dBetaFI ? prm.dBetaFI[c] : 0.0) : T(1.0);
+    T nres = convdiff - rho_c * ((SA_CB2 / SA_SIGMA) * (gNc[0] * gNc[0] + gNc[1] * gNc[1] + gNc[2] * gNc[2]) + SA_CB1 * Stilda * nc * betaFI)
              + SA_CW1 * rho_c * fw * nc / (y * y) * nc;
     if (!prm.normN) nres = nres * cgc.V;
     R[prm.offN * N + c] = nres;

@@ -387,6 +387,9 @@ class pyDASolvers:
             return 2
         if inputType == "patchVar":  # reference DAInputPatchVar.H: 1 (scalar) or 3 (vector)
             return 3 if self._input_entry(inputName, inputType)["varType"] == "vector" else 1
+        if inputType == "field":  # reference DAInputField.H size(): the selected cells (here: all) x 1 for a scalar field
+            self._field_entry(inputName)
+            return self._case.mesh.n_cells
         return check(lib().das_get_input_size(self._h, inputName.encode(), inputType.encode()))
 
     # -- boundary-value inputs (reference src/adjoint/DAInput/DAInputPatchVelocity.C, DAInputPatchVar.C) ---------
@@ -399,6 +402,21 @@ class pyDASolvers:
         if inputType == "patchVar" and e.get("varType") not in ("scalar", "vector"):
             raise _capi.DASError("varType not valid")
         return e
+
+    def _field_entry(self, inputName):
+        """inputInfo entry of a `field` input (reference DAInputField.C:33-86): fieldName, fieldType "scalar"; cellSetName /
+        vector fields are not implemented here."""
+        e = self._input_entry(inputName, "field")
+        if e.get("fieldType", "scalar") != "scalar":
+            raise _capi.DASError("field input: only fieldType scalar is implemented")
+        if "cellSetName" in e:
+            raise _capi.DASError("field input: cellSetName is not implemented (the field covers all cells)")
+        return e
+
+    def getField(self, fieldName):
+        out = np.zeros(self._case.mesh.n_cells)
+        check(lib().das_get_field(self._h, fieldName.encode(), dptr(out)))
+        return out
 
     def _patch_ids(self, entry):
         names = [p.name for p in self._case.mesh.patches]
@@ -431,6 +449,10 @@ class pyDASolvers:
         assert len(inputs) == inputSize, "invalid input array size!"
         if inputType == "stateVar":
             return self.updateOFFields(np.ascontiguousarray(inputs, dtype=np.float64))
+        if inputType == "field":
+            # DAInputField::run (reference DAInputField.C:88-151): the input array IS the volScalarField (all cells; scalar fields)
+            e = self._field_entry(inputName)
+            return check(lib().das_set_field(self._h, e["fieldName"].encode(), dptr(np.ascontiguousarray(inputs, dtype=np.float64))))
         if inputType not in ("patchVelocity", "patchVar"):
             raise _capi.DASError(f"inputType not supported on this path: {inputType}")
         field, val, _ = self._patch_input_tangents(inputName, inputType, inputs)
@@ -607,6 +629,13 @@ class pyDASolvers:
         assert len(seeds) == outputSize, "invalid seed array size!"
         assert len(product) == inputSize, "invalid product array size!"
         seeds_s = np.ascontiguousarray(self._to_state(seeds)) if outputType == "residual" else seeds
+        if inputType == "field":
+            # run(input), then ONE forward-mode pass with a unit tangent on every cell (das_calc_dfield_product)
+            self.setSolverInput(inputName, inputType, inputSize, inputs)
+            e = self._field_entry(inputName)
+            check(lib().das_calc_dfield_product(self._h, e["fieldName"].encode(), outputName.encode(), outputType.encode(),
+                                                dptr(np.ascontiguousarray(seeds_s, dtype=np.float64)), dptr(product)))
+            return
         if inputType in ("patchVelocity", "patchVar"):
             # run(input), then one forward-mode pass per input component
             self.setSolverInput(inputName, inputType, inputSize, inputs)

@@ -115,6 +115,9 @@ typedef struct das_case {
      * mu = As sqrt(T) / (1 + Ts / T), alpha = mu Cv (1.32 + 1.77 R / Cv) / Cp; 0 = "const" transport (mu, Pr above) */
     int transport_sutherland;
     double sutherland_As, sutherland_Ts;
+    /* betaFINuTilda (n_cells, may be NULL = 1): the field-inversion multiplier of the Spalart-Allmaras production term
+     * (reference DASpalartAllmaras.C betaFINuTilda_), the volScalarField a `field` input assigns (DAInputField.C:88-110) */
+    const double* beta_fi_nuTilda;
 } das_case_t;
 
 const char* das_last_error(void);
@@ -242,6 +245,15 @@ int das_calc_jac_vec_product(das_solver_t* s, const double* v, double* product);
  *                          host) or "function" (seeds: 1).  One forward-mode (dual number) pass. */
 int das_set_patch_value(das_solver_t* s, const int* patch_ids, int npatch, const char* field, const double* value);
 int das_get_patch_value(das_solver_t* s, int patch_id, const char* field, double* value);
+/* `field` inputs (reference DAInputField.C: a design variable that IS a volScalarField; inputInfo type "field"):
+ * fieldName "betaFINuTilda" (values[nCells]).  das_calc_dfield_product: product[c] = sum_i seeds[i] dR_i/dfield_c (outputType
+ * "residual"; ONE forward-mode residual pass with a unit tangent on every cell - a residual row depends on the field value of
+ * its own cell only) or 0 for the patch-integral functions (outputType "function"), i.e. calcJacTVecProduct(field -> ...)
+ * of DASolver.C:1690-1839. */
+int das_set_field(das_solver_t* s, const char* fieldName, const double* values);
+int das_get_field(das_solver_t* s, const char* fieldName, double* values);
+int das_calc_dfield_product(das_solver_t* s, const char* fieldName, const char* outputName, const char* outputType, const double* seeds,
+                            double* product);
 int das_calc_dbc_product(das_solver_t* s, const int* patch_ids, int npatch, const char* field, const double* tangent, const char* outputName,
                          const char* outputType, const double* seeds, double* product);
 int das_define_force_function(das_solver_t* s, const char* name, const int* patch_ids, int npatch, const double* direction, double scale);

@@ -153,6 +153,13 @@ def bc_vector(code, val, Xc, delta, phib, n):
     return Xb, vic, vbc, gic, gbc
 
 
+def _beta_fi(case, N):
+    """betaFINuTilda: field-inversion multiplier of the SA production term (reference DASpalartAllmaras.C:445-485), 1 unless the
+    case carries `beta_fi` (a `field` input, DAInputField.C)."""
+    b = getattr(case, "beta_fi", None)
+    return 1.0 if b is None else np.asarray(b)
+
+
 def fv1_of(chi):
     chi3 = chi**3
     return chi3 / (chi3 + SA["Cv1"] ** 3)
@@ -461,7 +468,7 @@ def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "
     nuTildaRes = (
         conv_diff
         - SA["Cb2"] / SA["sigmaNut"] * (gradN * gradN).sum(1)
-        - SA["Cb1"] * Stilda * nuT
+        - SA["Cb1"] * Stilda * nuT * _beta_fi(case, N)
         + SA["Cw1"] * fw * nuT / (y * y) * nuT
     )
     # (relax() leaves M & psi unchanged)

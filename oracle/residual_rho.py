@@ -32,7 +32,7 @@ import numpy as np
 
 from dafoam_amd.meshgen import BC_FIXED_VALUE, BC_SYMMETRY, NUT_LOWRE_WALL, NUT_SPALDING_WALL, NUT_SYMMETRY
 
-from .residual import SA, SMALL, VSMALL, BCTable, Ops, _abs, _max, _min, bc_scalar, bc_vector, dev2T, fv1_of, relax_diag, sadd, spalding_nut
+from .residual import SA, SMALL, VSMALL, BCTable, Ops, _abs, _beta_fi, _max, _min, bc_scalar, bc_vector, dev2T, fv1_of, relax_diag, sadd, spalding_nut
 
 RR = 8314.47  # Foam::constant::thermodynamic::RR [J/(kmol K)]
 TREF = 298.15
@@ -326,7 +326,7 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
     bCn = bCn + gn_b * ngBC
     offN = sadd(oi, up * nuT[ni], N) + sadd(ni, lo * nuT[oi], N)
     conv_diff = ((dN + sadd(bcell, iCn, N)) * nuT + offN - sN - sadd(bcell, bCn, N)) / V
-    nuTildaRes = (conv_diff - SA["Cb2"] / SA["sigmaNut"] * rho * (gradN * gradN).sum(1) - SA["Cb1"] * rho * Stilda * nuT
+    nuTildaRes = (conv_diff - SA["Cb2"] / SA["sigmaNut"] * rho * (gradN * gradN).sum(1) - SA["Cb1"] * rho * Stilda * nuT * _beta_fi(case, N)
                   + SA["Cw1"] * rho * fw * nuT / (y * y) * nuT)
 
     if "URes" not in normalize:

@@ -37,6 +37,7 @@ extern "C" int emu_residual(const das_case_t* c, const double* Win, long long n,
         mesh.build(c);
         CaseParams cp;
         cp.from_case(c);
+        if (!cp.beta_fi.empty()) cp.betaFI_ptr = cp.beta_fi.data();
         Options opt;
         ResParams prm = make_params(cp, opt, isPC);
         if (!dir) {
@@ -77,6 +78,29 @@ extern "C" int emu_residual_bc(const das_case_t* c, const double* Win, long long
         return 0;
     } catch (const std::exception& e) {
         fprintf(stderr, "emu_residual_bc: %s\n", e.what());
+        return -1;
+    }
+}
+
+// dR/d(betaFINuTilda).tangent: the `field` input seeds of das_calc_dfield_product (tangent[nCells])
+extern "C" int emu_residual_field(const das_case_t* c, const double* Win, long long n, const double* tangent, double* Rd) {
+    try {
+        Mesh mesh;
+        mesh.build(c);
+        CaseParams cp;
+        cp.from_case(c);
+        if (cp.beta_fi.empty()) cp.beta_fi.assign(mesh.nC, 1.0);
+        cp.betaFI_ptr = cp.beta_fi.data();
+        cp.dBetaFI_ptr = tangent;
+        Options opt;
+        ResParams prm = make_params(cp, opt, 0);
+        std::vector<Dual<1>> W(n), R(n);
+        for (long long i = 0; i < n; i++) W[i] = Dual<1>(Win[i]);
+        eval<Dual<1>>(mesh, cp, prm, W, R);
+        for (long long i = 0; i < n; i++) Rd[i] = R[i].d[0];
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "emu_residual_field: %s\n", e.what());
         return -1;
     }
 }

@@ -1028,6 +1028,80 @@ def test_speculative_device_coloring_is_valid_and_close_to_first_fit(kind):
         assert np.abs((M.to_scipy() - A).tocsr().data).max() <= 1e-10 * np.abs(A.data).max()
 
 
+def test_field_input_betaFINuTilda_product_and_total_derivative():
+    """calcJacTVecProduct(field -> residual | function) for the `field` input betaFINuTilda (reference DAInputField.C,
+    DASolver.C:1690-1839; the design variable of DAFoam's field inversion): the residual with a non-trivial field, the product
+    psi^T dR/dbeta (ONE forward-mode pass, das_calc_dfield_product) against the oracle's complex step, dF/dbeta = 0 for a force,
+    and the operator assembled after setSolverInput (the operator epoch: the cached dRdW^T must not be reused)."""
+    import copy
+
+    from dafoam_amd.pyDASolvers import Mat
+
+    case = channel_case(8, 7, 6, wall_function=True)
+    g = Geometry(case.mesh)
+    N, n = g.nC, case.states.size
+    rng = np.random.default_rng(4)
+    beta = 1.0 + 0.2 * rng.standard_normal(N)
+    D = make(case, inputInfo={"beta": {"type": "field", "fieldName": "betaFINuTilda", "fieldType": "scalar", "components": ["solver", "function"]}},
+             function={"CD": {"type": "force", "source": "patchToFace", "patches": ["bottom"], "directionMode": "fixedDirection", "direction": [1.0, 0.0, 0.0], "scale": 1.0}})
+    W = case.states
+    D.solverAD.initializedRdWTMatrixFree()  # operator at beta = 1
+    psi = rng.standard_normal(n)
+    prod = np.zeros(N)
+    D.solverAD.calcJacTVecProduct("beta", "field", beta, "residuals", "residual", psi, prod)
+    assert np.array_equal(D.solver.getField("betaFINuTilda"), beta)
+    cb = copy.copy(case)
+    cb.beta_fi = beta
+    R = np.zeros(n)
+    D.solver.getResiduals(R)
+    Ro = residual(cb, g, W)
+    for nm, sl in blocks(case, g):
+        assert relerr(R[sl], Ro[sl]) < 1e-12, nm
+    # psi^T dR/dbeta_c: per cell, from one complex step (a row depends on its own cell's beta only)
+    cc = copy.copy(case)
+    cc.beta_fi = beta + 1e-30j * np.ones(N)
+    dR = residual(cc, g, W.astype(complex)).imag / 1e-30
+    ref = psi[4 * N : 5 * N] * dR[4 * N : 5 * N]
+    assert np.abs(dR[: 4 * N]).max() == 0.0 and relerr(prod, ref) < 1e-12
+    pf = np.ones(N)
+    D.solverAD.calcJacTVecProduct("beta", "field", beta, "CD", "function", np.ones(1), pf)
+    assert np.all(pf == 0.0)
+    # the operator cached before setSolverInput(field) is stale: the next product re-assembles at the new field
+    sc = J.state_scales(case, g, NORM_STATES)
+    v = rng.standard_normal(n)
+    pa = np.zeros(n)
+    D.solverAD.calcJacTVecProduct("s", "stateVar", W, "r", "residual", psi, pa)
+    Jv = residual(cb, g, W + 1j * 1e-30 * (sc * v)).imag / 1e-30
+    assert abs(psi @ Jv - pa @ v) <= 1e-10 * abs(psi @ Jv)
+    with pytest.raises(Exception, match="not implemented"):
+        D2 = make(case, inputInfo={"a": {"type": "field", "fieldName": "alphaPorosity", "fieldType": "scalar"}})
+        D2.solverAD.calcJacTVecProduct("a", "field", beta, "residuals", "residual", psi, prod)
+
+
+def test_krylov_basis_is_mapped_on_demand_and_never_reallocated():
+    """The basis address range is reserved once for the largest restart the memory budget allows and 2 GB chunks are mapped
+    while the iteration advances (VmBuf, csrc/das_common.hpp): solves with different restarts on one KSP - first a short
+    one, then the reference default - give the single-restart answers, and a restart that does not fit the budget is capped."""
+    case = bench_channel_case(60, 30, 24)  # 43 k cells, n = 347 k: the default 1002-vector range (2.8 GB) goes through hipMalloc ...
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-8, "gmresAbsTol": 1e-30, "printInfo": 0, "gmresMaxIters": 1000, "gmresRestart": 30})
+    n = case.states.size
+    g = Geometry(case.mesh)
+    rhs = np.zeros(n)
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= J.state_scales(case, g, NORM_STATES)
+    psi30, fail30 = D.solveAdjoint(rhs)
+    it30 = D.ksp.info()["iters"]
+    D.solver.updateDAOption({"adjEqnOption": {"gmresRestart": 1000}})
+    psi1k, fail1k = D.solveAdjoint(rhs)
+    it1k = D.ksp.info()["iters"]
+    assert fail30 == 0 and fail1k == 0 and it1k <= it30 and relerr(psi30, psi1k) < 1e-5
+    # ... and a budget of 6 GB with n = 347 k states holds 2160 vectors: amd.maxKrylovBytes small forces the VM path's cap
+    D2 = make(case, adjEqnOption={"gmresRelTol": 1e-8, "gmresAbsTol": 1e-30, "printInfo": 0, "gmresMaxIters": 1000, "gmresRestart": 1000},
+              amd={"maxKrylovBytes": int(40 * 8 * n)})
+    psic, failc = D2.solveAdjoint(rhs)
+    assert failc == 0 and relerr(psic, psi1k) < 1e-5 and D2.ksp.info()["iters"] >= it1k
+
+
 def test_cell_state_ordering():
     """adjStateOrdering "cell" (reference DAIndex.C:602-651): every state-length array crosses the boundary in the
     cell-by-cell ordering; results are the permuted "state"-ordering results."""

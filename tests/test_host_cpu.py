@@ -879,3 +879,32 @@ def test_cyclic_aware_partition_extended_submesh_residuals(variant, world):
             assert np.abs(R[owned] - ref[owned]).max() <= 1e-11 * np.abs(Rg).max(), (variant, world, mode, rank)
             seen[key[owned]] += 1
         assert np.all(seen == 1)
+
+
+def test_field_input_betaFINuTilda_kernel_bodies_vs_oracle():
+    """`field` input (reference DAInputField.C) betaFINuTilda - the field-inversion multiplier of the SA production term
+    (DASpalartAllmaras.C:445-485): residual with a non-trivial field, and the tangent w.r.t. the field (the seeds of
+    das_calc_dfield_product) against the oracle's complex step.  A residual row depends on the value of its own cell only."""
+    case = channel_case(6, 5, 4, wall_function=True)
+    g = Geometry(case.mesh)
+    N = g.nC
+    rng = np.random.default_rng(3)
+    case.beta_fi = 1.0 + 0.3 * rng.standard_normal(N)
+    Rv, _ = _emu_res(case, case.states, 0)
+    Ro = residual(case, g, case.states)
+    for nm, sl in blocks(case, g):
+        assert relerr(Rv[sl], Ro[sl]) < 1e-12, nm
+    c1 = channel_case(6, 5, 4, wall_function=True)
+    assert relerr(Rv[4 * N : 5 * N], residual(c1, g, c1.states)[4 * N : 5 * N]) > 1e-3  # the field does act on nuTildaRes
+    t = rng.standard_normal(N)
+    L = _emu()
+    L.emu_residual_field.argtypes = [C.POINTER(das_case_t), _capi.c_double_p, C.c_longlong, _capi.c_double_p, _capi.c_double_p]
+    Rd = np.zeros(case.states.size)
+    assert L.emu_residual_field(CaseStruct(case).byref(), dptr(case.states), case.states.size, dptr(t), dptr(Rd)) == 0
+    import copy
+
+    cc = copy.copy(case)
+    cc.beta_fi = case.beta_fi + 1e-30j * t
+    cs = residual(cc, g, case.states.astype(complex)).imag / 1e-30
+    assert relerr(Rd, cs) < 1e-12
+    assert np.all(Rd[: 4 * N] == 0.0) and np.all(Rd[5 * N :] == 0.0)  # only the cell's own nuTildaRes row
