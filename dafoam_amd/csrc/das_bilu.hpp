@@ -241,6 +241,136 @@ __global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep(BiluView P, co
 // contended L2 atomic retires every ~17 ns: 290 k tickets per XCD and sweep at 2 M cells = 5 ms.  Together with the fp32
 // result (half the factor bytes, same time) this fixes the picture of the sweeps: neither bandwidth nor the per-node load
 // chain bounds them, the ticket rate and the dependent hops do; 8 nodes per ticket is the measured optimum.)
+// ---- the same sweep for S right-hand sides at once (block GMRES, das_block.hpp) ------------------------------------
+// The sweeps are bound by the ticket rate and the dependent hops, not by bytes (see above), so S systems through ONE sweep cost
+// little more than one: the ticket, the row extent, the factor blocks and the polling round trip of a node are shared, only the
+// multiply-accumulate, the reduce-scatter and the published values are per system.  Work vectors ym / zm hold S values per
+// slot, [(node * 8 + slot) * S + r], so that a lane polls the S values of "its" x_k with one 16- or 32-byte load; b and out
+// are column-major n x S (ld = leading dimension).
+template <class VT, bool UPPER, int S>
+__global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep_m(BiluView P, double* __restrict__ ym, double* __restrict__ zm, const double* __restrict__ b,
+                                                                     double* __restrict__ out, long long ld, int sleepReps, int perXcd) {
+    __shared__ unsigned sh_chunk[2];
+    constexpr int WAVES = BILU_WG / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 3, k = lane & 7;
+    const long long* __restrict__ ptr = P.ptr[UPPER ? 1 : 0];
+    const int* __restrict__ col = P.col[UPPER ? 1 : 0];
+    const VT* __restrict__ val = reinterpret_cast<const VT*>(sizeof(VT) == 4 ? (const void*)P.valf[UPPER ? 1 : 0] : (const void*)P.val[UPPER ? 1 : 0]);
+    double* xs = UPPER ? zm : ym;
+    const unsigned xcd = perXcd ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0u;
+    unsigned* ctr = &P.ctrl[((UPPER ? 8 : 0) + xcd) * BILU_CTRL_STRIDE];
+    for (unsigned it = 0;; it++) {
+        if (threadIdx.x == 0)
+            sh_chunk[it & 1] = perXcd ? __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) * 8u + xcd
+                                      : __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const long long q0 = (long long)sh_chunk[it & 1] * WAVES;
+        if (q0 >= P.nNodes) return;
+        const long long q = q0 + wave;
+        if (q >= P.nNodes) continue;
+        const long long e0 = ptr[q];
+        const int nE = (int)(ptr[q + 1] - e0);
+        double acc[S][8];
+#pragma unroll
+        for (int r = 0; r < S; r++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[r][i] = 0.0;
+        double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, vn[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int c = 0, cn = 0;
+        auto load_pass = [&](int a0, double (&vv)[8], int& cc) {
+            const int nb = min(8, nE - a0);
+            if (g < nb) {
+                cc = col[e0 + a0 + g];
+                const VT* base = val + (e0 + a0) * BILU_NB2;
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) bilu_load_pair<VT>(base + ((qq * nb + g) * 8 + k) * 2, vv[2 * qq], vv[2 * qq + 1]);
+            }
+        };
+        if (nE > 0) load_pass(0, v, c);
+        const long long p = UPPER ? (long long)P.nNodes - 1 - q : q;
+        int gi;
+        double rhs[S], dinv = 0.0;
+        if (!UPPER) {
+            gi = P.nodeUnk[p * BILU_NB + g];
+#pragma unroll
+            for (int r = 0; r < S; r++) rhs[r] = gi >= 0 ? b[gi + r * ld] : 0.0;
+        } else {
+            gi = P.nodeUnk[p * BILU_NB + k];
+#pragma unroll
+            for (int r = 0; r < S; r++) rhs[r] = ym[(p * BILU_NB + g) * S + r];
+            dinv = P.invD[p * BILU_NB2 + k * 8 + g];
+        }
+        for (int a0 = 0; a0 < nE; a0 += 8) {
+            const bool act = g < min(8, nE - a0);
+            if (a0 + 8 < nE) load_pass(a0 + 8, vn, cn);
+            const double* xp = xs + ((long long)c * BILU_NB + k) * S;
+            unsigned long long xb[S];
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+                if (act) {
+#pragma unroll
+                    for (int r = 0; r < S; r++) { xb[r] = bilu_load_sc1(xp + r); ok = ok && xb[r] != BILU_SENTINEL; }
+                }
+                if (__all(ok)) break;
+                for (int w = 0; w < sleepReps; w++) __builtin_amdgcn_s_sleep(2);
+                if ((++spins & 1023u) == 0u) {
+                    const unsigned ab = __hip_atomic_load(&P.ctrl[BILU_CTRL_ABORT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ab != 0u || spins >= BILU_SPIN_LIMIT) {
+                        if (lane == 0) __hip_atomic_store(&P.ctrl[BILU_CTRL_ABORT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;
+                    }
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int r = 0; r < S; r++) {
+                    const double xk = __longlong_as_double((long long)xb[r]);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) acc[r][i] += v[i] * xk;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = vn[i];
+            c = cn;
+        }
+#pragma unroll
+        for (int r = 0; r < S; r++) {
+            double a4[4], a2[2], a1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const double snd = (g & 4) ? acc[r][i] : acc[r][i + 4], keep = (g & 4) ? acc[r][i + 4] : acc[r][i];
+                a4[i] = keep + __shfl_xor(snd, 32, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const double snd = (g & 2) ? a4[i] : a4[i + 2], keep = (g & 2) ? a4[i + 2] : a4[i];
+                a2[i] = keep + __shfl_xor(snd, 16, 64);
+            }
+            {
+                const double snd = (g & 1) ? a2[0] : a2[1], keep = (g & 1) ? a2[1] : a2[0];
+                a1 = keep + __shfl_xor(snd, 8, 64);
+            }
+            a1 += __shfl_xor(a1, 1, 64);
+            a1 += __shfl_xor(a1, 2, 64);
+            a1 += __shfl_xor(a1, 4, 64);
+            if (!UPPER) {
+                if (k == 0) bilu_store_sc1(&ym[(p * BILU_NB + g) * S + r], rhs[r] - a1);
+            } else {
+                double w = dinv * (rhs[r] - a1);
+                w += __shfl_xor(w, 8, 64);
+                w += __shfl_xor(w, 16, 64);
+                w += __shfl_xor(w, 32, 64);
+                if (g == 0) {
+                    bilu_store_sc1(&zm[(p * BILU_NB + k) * S + r], w);
+                    if (gi >= 0) out[gi + r * ld] = w;
+                }
+            }
+        }
+    }
+}
+
 // scalar CSR (rows = states, 16 lanes per row) -> dense node blocks (row-major 8x8 per block entry)
 __global__ __launch_bounds__(256) void k_bilu_scatter(long long n, const long long* __restrict__ rp, const int* __restrict__ ci,
                                                       const double* __restrict__ v, const int* __restrict__ unkNode,
@@ -401,6 +531,8 @@ struct NodeILU {
     DevBuf<double> Lval, Uval, invD, y, z;
     DevBuf<float> Lvalf, Uvalf;
     DevBuf<unsigned> ctrl;
+    DevBuf<double> ym, zm;  // work vectors of the multi right-hand-side sweeps (allocated on first use)
+    int mS = 0;
     BiluView view;
     double t_struct = 0, t_scatter = 0, t_factor = 0, t_pack = 0;
     long long factor_bytes() const { return (nL + nU) * BILU_NB2 * (fp32 ? 4 : 8) + (long long)nNodes * BILU_NB2 * 8; }
@@ -753,6 +885,29 @@ inline void bilu_apply(NodeILU& P, const double* b, double* out, hipStream_t st)
         hipLaunchKernelGGL((k_bilu_sweep<double, false>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
         hipLaunchKernelGGL((k_bilu_sweep<double, true>), dim3(grid), dim3(BILU_WG), 0, st, P.view, b, out, sl, px);
     }
+}
+
+// S right-hand sides through one pair of sweeps (S = 2 or 4): b, out column-major with leading dimension ld
+template <int S>
+inline void bilu_apply_multi_s(NodeILU& P, const double* b, double* out, long long ld, hipStream_t st) {
+    const long long nslots = (long long)P.nNodes * BILU_NB * S;
+    if (P.mS < S || P.ym.n < (size_t)nslots) { P.ym.alloc((size_t)P.nNodes * BILU_NB * 4); P.zm.alloc((size_t)P.nNodes * BILU_NB * 4); P.mS = 4; }
+    hipLaunchKernelGGL(k_bilu_reset, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, nslots, P.ym.p, P.zm.p, P.ctrl.p);
+    const int grid = P.launchGrid, sl = P.launchSleep, px = P.launchPerXcd;
+    if (P.fp32) {
+        hipLaunchKernelGGL((k_bilu_sweep_m<float, false, S>), dim3(grid), dim3(BILU_WG), 0, st, P.view, P.ym.p, P.zm.p, b, out, ld, sl, px);
+        hipLaunchKernelGGL((k_bilu_sweep_m<float, true, S>), dim3(grid), dim3(BILU_WG), 0, st, P.view, P.ym.p, P.zm.p, b, out, ld, sl, px);
+    } else {
+        hipLaunchKernelGGL((k_bilu_sweep_m<double, false, S>), dim3(grid), dim3(BILU_WG), 0, st, P.view, P.ym.p, P.zm.p, b, out, ld, sl, px);
+        hipLaunchKernelGGL((k_bilu_sweep_m<double, true, S>), dim3(grid), dim3(BILU_WG), 0, st, P.view, P.ym.p, P.zm.p, b, out, ld, sl, px);
+    }
+}
+// any number of right-hand sides: groups of 4, then 2, then 1
+inline void bilu_apply_multi(NodeILU& P, const double* b, double* out, long long ld, int nrhs, hipStream_t st) {
+    int r = 0;
+    for (; r + 4 <= nrhs; r += 4) bilu_apply_multi_s<4>(P, b + (long long)r * ld, out + (long long)r * ld, ld, st);
+    for (; r + 2 <= nrhs; r += 2) bilu_apply_multi_s<2>(P, b + (long long)r * ld, out + (long long)r * ld, ld, st);
+    for (; r < nrhs; r++) bilu_apply(P, b + (long long)r * ld, out + (long long)r * ld, st);
 }
 
 // abort flag of the sweeps (set when a bounded spin ran out): checked by the solver at its synchronisation points

@@ -75,6 +75,10 @@ Options::Options() {
     i["amd.pcFactorFP32"] = 0;      // store the ILU factors of the preconditioner in fp32 (operator stays fp64)
     i["amd.keepAssemblyMaps"] = 0;  // 1: keep the coloured-assembly maps in HBM between assemblies (adjPCLag loops on small meshes)
     i["amd.cgsAlwaysRefine"] = 0;   // 1: CGS2 every iteration; 0: refine if needed (reference default)
+    i["amd.blockBatchedPC"] = 1;    // block GMRES: all right-hand sides through one pair of preconditioner sweeps (0: column by column)
+    i["amd.opPackVector"] = 1;      // Krylov operator: vector-state rows packed as group rows (das_opmat.hpp)
+    s["amd.coloringAlgorithm"] = "firstfit";  // device colouring: "firstfit" (serial colours, data-flow over net bitmaps) | "speculative"
+    i["amd.pcCoarseGlobal"] = 1;    // multi-GPU: one global pressure coarse space (das_ksp_set_global_coarse) instead of one per rank
     // "dcgs2": classical Gram-Schmidt with DELAYED re-orthogonalisation - the second projection of step j and the first of
     // step j+1 share one pass over the basis (2 instead of 4 basis reads per iteration, same iterates); "cgs": the
     // reference's KSP_GMRES_CGS_REFINE_IFNEEDED.  adjEqnOption.useMGSO = 1 selects modified Gram-Schmidt in both cases.

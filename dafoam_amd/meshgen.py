@@ -424,6 +424,7 @@ def channel_case(
             bcs["outlet"] = dict(cut)
     y = wall_distance(mesh, g.C, g.Cf, g.Sf)
     case = FoamCase(mesh=mesh, solver_name="DASimpleFoam", nu=nu, bcs=bcs, y_wall=y)
+    case._input_geometry = (mesh, g)  # (reused by prolong_channel_state: the metrics of a 2 M-cell mesh take seconds in numpy)
     # smooth synthetic state: turbulent-like profile in wall distance + perturbation
     rng = np.random.default_rng(seed)
     N, F = mesh.n_cells, mesh.n_faces
@@ -698,7 +699,9 @@ def prolong_channel_state(case: FoamCase, dims, coarse, i0=0, nx_global=None):
     p = field(Wc[3 * Nc : 4 * Nc])
     nt = np.maximum(field(Wc[4 * Nc : 5 * Nc]), 1e-12)
     mesh = case.mesh
-    g = _InputGeometry(mesh)
+    cached = getattr(case, "_input_geometry", None)
+    g = cached[1] if cached is not None and cached[0] is mesh else _InputGeometry(mesh)
+    case._input_geometry = None  # one use: the case may be copied / pickled afterwards
     nIF = mesh.n_internal_faces
     own, nei = mesh.owner, mesh.neighbour
     Uf = g.w[:, None] * U[own[:nIF]] + (1 - g.w[:, None]) * U[nei]

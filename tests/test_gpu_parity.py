@@ -583,6 +583,13 @@ def test_block_gmres_multi_rhs_matches_direct_solve(nrhs):
         assert relerr(psi[:, r], lu.solve(rhs[:, r])) <= 1e-6, r
     psi0, fail0 = D.solveAdjoint(np.ascontiguousarray(rhs[:, 0]))
     assert fail0 == 0 and relerr(psi[:, 0], psi0) <= 1e-6
+    # the preconditioner of the block path takes all right-hand sides through ONE pair of sweeps (k_bilu_sweep_m, groups of 4 /
+    # 2 / 1); column by column (amd.blockBatchedPC 0) is the same operator: same iteration count, same psi
+    it_b = D.ksp.info()["iters"]
+    D1 = make(case, adjEqnOption={"gmresRelTol": 1e-10, "gmresAbsTol": 1e-16, "gmresMaxIters": 400, "gmresRestart": 400, "printInfo": 0},
+              amd={"blockBatchedPC": 0})
+    psi1, fail1 = D1.solveAdjoint(rhs)
+    assert fail1 == 0 and relerr(psi1, psi) <= 1e-8
 
 
 def test_sutherland_transport_residual_and_jacobian():
