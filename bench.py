@@ -161,6 +161,11 @@ def main():
     ksp = KSP()
     t0 = time.time()
     D.solverAD.createMLRKSPMatrixFree(pc, ksp)
+    global_coarse = 0
+    if sharded is not None:
+        # one pressure coarse space over all ranks (das_ksp_set_global_coarse) instead of one per rank
+        sharded.pc, sharded.ksp = pc, ksp
+        global_coarse = sharded.install_global_coarse()
     t_pc = time.time() - t0
     t0 = time.time()
     D.solverAD.initializedRdWTMatrixFree()
@@ -233,17 +238,17 @@ def main():
 
     # ---- solve to tolerance (N = 1): the reference's defaults ----------------------------------------------------------
     solve = None
-    if world == 1 and not a.no_solve:
+    if not a.no_solve:  # N > 1: the same calls on every rank - ONE global solve (collective inside the library)
         # the reference's defaults: gmresRestart = gmresMaxIters = 1000 (pyDAFoam.py:526-548)
         D.solver.updateDAOption({"adjEqnOption": {"gmresRestart": a.solve_restart, "gmresMaxIters": a.solve_maxit, "gmresRelTol": 1e-6, "gmresAbsTol": 1e-14}})
         sol.zero_()
-        torch.cuda.synchronize()
+        barrier()
         t0 = time.perf_counter()
         check(L.das_ksp_begin_device(h, ksp.handle, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()), 0))
         while not check(L.das_ksp_advance(h, ksp.handle, 1000)):
             pass
         fail = check(L.das_ksp_end(h, ksp.handle))
-        torch.cuda.synchronize()
+        barrier()
         t_solve = time.perf_counter() - t0
         inf = ksp.info()
         hist = ksp.history()
@@ -304,6 +309,7 @@ def main():
                 "pc": pc_desc,
                 "pc_factor_entries": fac_entries,
                 "pc_coarse_aggregates": int(L.das_ksp_get_coarse(ksp.handle, None)),
+                "pc_coarse_aggregates_global": int(global_coarse) if world > 1 else None,
                 "pc_coarse_mode": a.coarse_mode,
                 "coarse_ms": L.das_timer_avg_ms(h, b"coarse"),
                 "halo_ms": L.das_timer_avg_ms(h, b"halo") if world > 1 else None,

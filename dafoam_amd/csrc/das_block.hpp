@@ -21,14 +21,19 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 #define TSG_WAVES 4
 
 // partial[(chunk * Kpad + i) * 16 + r] = sum over the chunk's rows of V_i[row] * W_r[row]   (i < K, r < s <= 16)
-// grid = (nChunks / TSG_WAVES, ceil(K / (16 TSG_TILES))), one wave per (row chunk, group of 64 basis vectors)
+// grid = (nChunks / TSG_WAVES, ceil(K / (16 TSG_TILES))), one wave per (row chunk, group of 64 basis vectors).
+// Row mapping (round 3; the first version read 4 consecutive rows of 16 vectors per instruction - 32-byte segments, and ran only
+// 256 waves: 4 x off the bandwidth in the profile): a step covers 16 rows; lane (vector li, quarter lk) loads rows
+// base + 4 lk .. + 3 of ITS vector as two 16-byte loads, i.e. every vector contributes one full 128-byte line per step, and the
+// four MFMAs of the step take k = lk with row base + 4 lk + t - the sum over rows does not care in which order they enter, as long
+// as the A (V) and B (W) fragments use the same mapping.
 __global__ __launch_bounds__(64 * TSG_WAVES) void k_tsgemm_tn(long long n, int K, int s, const double* __restrict__ V, long long ldv,
                                                               const double* __restrict__ W, long long ldw, long long rowsPerChunk, int Kpad,
                                                               double* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
     const long long chunk = (long long)blockIdx.x * TSG_WAVES + (threadIdx.x >> 6);
     const int i0 = blockIdx.y * 16 * TSG_TILES;
-    const long long r0 = chunk * rowsPerChunk, r1 = min(n, r0 + rowsPerChunk);
+    const long long r0 = chunk * rowsPerChunk, r1 = min(n, r0 + rowsPerChunk);  // rowsPerChunk is a multiple of 16, r0 16-byte aligned
     const int li = lane & 15, lk = lane >> 4;
     mfma_d4 acc[TSG_TILES];
 #pragma unroll
@@ -43,15 +48,31 @@ __global__ __launch_bounds__(64 * TSG_WAVES) void k_tsgemm_tn(long long n, int K
         vact[t] = i < K;
         vp[t] = V + (long long)min(i, K - 1) * ldv;
     }
-    for (long long base = r0; base < r1; base += 4) {  // wave-uniform trip count (MFMA needs the whole wave); rows >= r1 contribute 0
-        const long long row = base + lk;
-        const bool in = row < r1;
-        const double b = (wact && in) ? wp[row] : 0.0;
+    const bool al = ((ldv | ldw) & 1) == 0;  // even leading dimensions: 16-byte aligned row quadruples
+    for (long long base = r0; base < r1; base += 16) {  // wave-uniform trip count (MFMA needs the whole wave)
+        const long long row = base + 4 * lk;
+        double bq[4], aq[TSG_TILES][4];
+        if (row + 3 < r1 && al) {
+            const double2 b01 = *reinterpret_cast<const double2*>(wp + row), b23 = *reinterpret_cast<const double2*>(wp + row + 2);
+            bq[0] = wact ? b01.x : 0.0; bq[1] = wact ? b01.y : 0.0; bq[2] = wact ? b23.x : 0.0; bq[3] = wact ? b23.y : 0.0;
 #pragma unroll
-        for (int t = 0; t < TSG_TILES; t++) {
-            const double a = (vact[t] && in) ? vp[t][row] : 0.0;
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+            for (int t = 0; t < TSG_TILES; t++) {
+                const double2 a01 = *reinterpret_cast<const double2*>(vp[t] + row), a23 = *reinterpret_cast<const double2*>(vp[t] + row + 2);
+                aq[t][0] = vact[t] ? a01.x : 0.0; aq[t][1] = vact[t] ? a01.y : 0.0; aq[t][2] = vact[t] ? a23.x : 0.0; aq[t][3] = vact[t] ? a23.y : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool in = row + u < r1;
+                bq[u] = (wact && in) ? wp[row + u] : 0.0;
+#pragma unroll
+                for (int t = 0; t < TSG_TILES; t++) aq[t][u] = (vact[t] && in) ? vp[t][row + u] : 0.0;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int t = 0; t < TSG_TILES; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq[t][u], bq[u], acc[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < TSG_TILES; t++)
@@ -61,14 +82,17 @@ __global__ __launch_bounds__(64 * TSG_WAVES) void k_tsgemm_tn(long long n, int K
             if (i < Kpad) partial[(chunk * Kpad + i) * 16 + li] = acc[t][v];
         }
 }
-// C[i * s + r] = sum over chunks of partial
-__global__ void k_tsgemm_reduce(int K, int s, int Kpad, long long nChunks, const double* __restrict__ partial, double* __restrict__ C) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// C[i * s + r] = sum over chunks of partial: one wavefront per entry (lanes over the chunks, fixed order: deterministic)
+__global__ __launch_bounds__(256) void k_tsgemm_reduce(int K, int s, int Kpad, long long nChunks, const double* __restrict__ partial, double* __restrict__ C) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (idx >= K * s) return;
     const int i = idx / s, r = idx % s;
     double acc = 0.0;
-    for (long long c = 0; c < nChunks; c++) acc += partial[(c * Kpad + i) * 16 + r];
-    C[idx] = acc;
+    for (long long c = lane; c < nChunks; c += 64) acc += partial[(c * Kpad + i) * 16 + r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) C[idx] = acc;
 }
 
 // W_r[row] -= sum_i V_i[row] * C[i * s + r]: one wave per 64 rows (4 row tiles of 16), K loop in steps of 4
@@ -122,11 +146,24 @@ __global__ __launch_bounds__(256) void k_spmm_wave(long long n, int s, const lon
     double acc[S];
 #pragma unroll
     for (int r = 0; r < S; r++) acc[r] = 0.0;
-    for (long long k = rp[row] + lane; k < rp[row + 1]; k += 16) {
-        const double a = v[k];
-        const double* x = Xr + (long long)ci[k] * S;
+    constexpr int U = S <= 4 ? 4 : 2;  // entries in flight per lane (value, column, S gathered doubles each)
+    const long long b = rp[row], e = rp[row + 1];
+    for (long long k = b + lane; k - lane < e; k += U * 16) {
+        double a[U];
+        int c[U];
 #pragma unroll
-        for (int r = 0; r < S; r++) acc[r] += a * x[r];
+        for (int u = 0; u < U; u++) {
+            const long long kk = k + u * 16;
+            const long long kc = kk < e ? kk : e - 1;  // clamped + masked: the tail keeps all U loads in flight
+            a[u] = kk < e ? v[kc] : 0.0;
+            c[u] = ci[kc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const double* x = Xr + (long long)c[u] * S;
+#pragma unroll
+            for (int r = 0; r < S; r++) acc[r] += a[u] * x[r];
+        }
     }
 #pragma unroll
     for (int r = 0; r < S; r++) {

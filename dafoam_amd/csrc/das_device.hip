@@ -31,26 +31,31 @@ namespace das {
 // =====================================================================================================
 // kernel wrappers around the templated bodies
 // =====================================================================================================
+// (Round 3, measured and dropped - profiles/r03m_tile_launch_order_2M_rejected.log: a tile launch order for these kernels - cells
+// grouped into compact RCB tiles, natural order inside, XCD-aware block -> tile mapping so that one XCD's L2 sees one region.  With
+// tiles of individually sorted cells every kernel got 25-40 % slower (13-cell runs: partial lines); with 64-cell memory runs as the
+// unit the assembly of dRdWT took 1.26 s against 1.19 s in the natural order.  The k+-1 neighbours that miss the 4 MB L2 are served
+// by the 256 MB Infinity Cache; the kernels already run at ~5.5 TB/s of their FETCH_SIZE traffic.)
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_grad(DevMesh m, ResParams prm, const T* __restrict__ W, T* nut, T* gU, T* gP, T* gN, T* gH) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_grad<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, (T*)prm.wTU);
 }
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_cell(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gU, const T* gP,
                                               const T* gN, const T* gH, T* R, T* rAU, T* HbyA) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_cell<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, R, rAU, HbyA, (const T*)prm.wTU);
 }
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_face(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gP, const T* rAU,
                                               const T* HbyA, T* q, T* R) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < m.nF) body_face<T, RHO>(f, m, prm, W, nut, gP, rAU, HbyA, q, R);
 }
 template <class T, bool RHO>
 __global__ __launch_bounds__(256) void k_pres(DevMesh m, ResParams prm, const T* q, T* R) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_pres<T, RHO>(c, m, prm, q, R);
 }
 // face-integral objectives: value (atomic sums per group), forward-mode tangent, coloured dual-number gradient scatter
@@ -2335,20 +2340,20 @@ struct BlockWork {
     DevBuf<double> V, W, Z, R, Xr, partial, Cdev, Tdev;
     int s = 0, m = 0;
 };
-static constexpr int TSG_CHUNKS = 256;  // row chunks of the TN product (one wave each)
+static constexpr int TSG_CHUNKS = 1024;  // row chunks of the TN product (one wave each per group of 64 basis vectors)
 
 // C_host (K x sv, row-major) = V^T W  (V: K vectors, W: sv vectors, both column-major with leading dimension n)
 static void block_tn(das_solver* s, BlockWork& bw, const double* V, int K, const double* W, int sv, double* C_host) {
     const long long n = s->n;
     long long rpc = (n + TSG_CHUNKS - 1) / TSG_CHUNKS;
-    rpc = (rpc + 3) / 4 * 4;
+    rpc = (rpc + 15) / 16 * 16;
     const int gy = (K + 16 * TSG_TILES - 1) / (16 * TSG_TILES);
     const int Kpad = gy * 16 * TSG_TILES;
     const size_t need = (size_t)TSG_CHUNKS * Kpad * 16;
     if (bw.partial.n < need) bw.partial.alloc(need);
     if (bw.Cdev.n < (size_t)K * sv) bw.Cdev.alloc((size_t)K * sv + 1024);
     hipLaunchKernelGGL(k_tsgemm_tn, dim3(TSG_CHUNKS / TSG_WAVES, gy), dim3(64 * TSG_WAVES), 0, s->stream, n, K, sv, V, n, W, n, rpc, Kpad, bw.partial.p);
-    hipLaunchKernelGGL(k_tsgemm_reduce, dim3(nblk((long long)K * sv, 256)), dim3(256), 0, s->stream, K, sv, Kpad, (long long)TSG_CHUNKS, bw.partial.p,
+    hipLaunchKernelGGL(k_tsgemm_reduce, dim3(nblk((long long)K * sv, 4)), dim3(256), 0, s->stream, K, sv, Kpad, (long long)TSG_CHUNKS, bw.partial.p,
                        bw.Cdev.p);
     DAS_HIP(hipMemcpyAsync(C_host, bw.Cdev.p, (size_t)K * sv * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     DAS_HIP(hipStreamSynchronize(s->stream));
