@@ -303,3 +303,50 @@ def test_four_rank_general_partition_compressible_and_cyclic(kind):
         assert fail == 0 and relres < 1e-9, (rank, fail, iters, relres)
         psi_s[keys] = psi
     assert not np.isnan(psi_s).any() and relerr(psi_s, psi_g) <= 1e-6
+
+
+def _worker_native_world1(rank, world, port, q, gstate):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from dafoam_amd.distributed import ShardedAdjoint
+
+        S = ShardedAdjoint(NX, NY, NZ, OPTS, device_index=0, global_state=gstate, case_kw=CASE_KW)
+        native = bool(S._comm_native)
+        S.setup()
+        psi, fail = S.solve(_rhs_from_keys(S.key))
+        info = S.ksp.info()
+        q.put((0, native, S.key[S.owned], psi[S.owned], fail, info["iters"], info["res"] / info["res0"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_rccl_transport_executes_on_one_gpu():
+    """The native transport (csrc/das_comm.hpp: RCCL bound by dlopen, ncclGetUniqueId / ncclCommInitRank, the in-stream
+    ncclAllReduce of every Gram-Schmidt pass and of the coarse restriction) on the ONE GPU of the test box: a world of one rank
+    under the nccl backend.  There are no peers, so ncclSend / ncclRecv are not reached (they need a second device - the
+    two-rank nccl test above skips here), but everything else of the path a multi-GPU job takes runs: library binding,
+    communicator creation, the agreed two-step set-up, all-reduces issued from C++ inside the iteration loop.  The adjoint
+    vector equals the plain single-domain solve."""
+    import torch
+
+    from dafoam_amd.distributed import SlabPartition, state_table
+    from dafoam_amd.pyDAFoam import PYDAFOAM
+
+    gcase = _converged_global()
+    gkey, _, _ = state_table(SlabPartition(NX, NY, NZ, 0, 1), gcase.mesh)
+    res = _spawn(_worker_native_world1, 1, ((gkey, gcase.states, gcase.y_wall),))
+    _, native, keys, psi, fail, iters, relres = res[0]
+    assert native, "the native RCCL transport was not installed (load / CommInitRank failed: see stderr)"
+    assert fail == 0 and relres < 1e-8
+    D = PYDAFOAM(options=OPTS, case=gcase)
+    psi_g, fail_g = D.solveAdjoint(_rhs_from_keys(gkey))
+    look = dict(zip(gkey.tolist(), range(gkey.size)))
+    psi_s = np.full(gkey.size, np.nan)
+    psi_s[[look[k] for k in keys.tolist()]] = psi
+    assert fail_g == 0 and not np.isnan(psi_s).any() and relerr(psi_s, psi_g) <= 1e-6
