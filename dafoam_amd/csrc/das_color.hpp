@@ -111,6 +111,52 @@ __global__ __launch_bounds__(256) void k_color_firstfit(ColorView P) {
     }
 }
 
+// the kernel driver shared by both front ends: device arrays in, colours out (false: more than 4096 colours or a timeout)
+inline bool color_firstfit_run(long long n, long long nNets, const std::vector<long long>& gstartHost, const long long* d_cptr, const int* d_crow,
+                               const int* d_cpos, std::vector<int>& colors, hipStream_t st) {
+    const long long nGroups = (long long)gstartHost.size() - 1;
+    DevBuf<long long> d_gstart;
+    d_gstart.upload(gstartHost);
+    DevBuf<int> d_colors(n);
+    DevBuf<unsigned> d_ctrl(2), d_done(std::max<long long>(1, nNets));
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long long wgs = (long long)cus * 8;
+    if (const char* e = getenv("DAS_COLOR_WGS")) wgs = std::max(1, atoi(e));
+    const int grid = (int)std::min<long long>(wgs, (nGroups + 3) / 4 + 1);
+    for (int W = 8; W <= COLOR_MAXW; W *= 2) {
+        DevBuf<unsigned long long> d_F((size_t)std::max<long long>(1, nNets) * W);
+        DAS_HIP(hipMemsetAsync(d_F.p, 0, d_F.n * sizeof(unsigned long long), st));
+        DAS_HIP(hipMemsetAsync(d_done.p, 0, d_done.n * sizeof(unsigned), st));
+        DAS_HIP(hipMemsetAsync(d_colors.p, 0xff, n * sizeof(int), st));
+        DAS_HIP(hipMemsetAsync(d_ctrl.p, 0, 2 * sizeof(unsigned), st));
+        ColorView V{nGroups, d_gstart.p, d_cptr, d_crow, d_cpos, W, d_F.p, d_done.p, d_colors.p, d_ctrl.p};
+        hipLaunchKernelGGL(k_color_firstfit, dim3(grid), dim3(256), 0, st, V);
+        DAS_HIP(hipGetLastError());
+        unsigned ctrl[2] = {0, 0};
+        DAS_HIP(hipMemcpyAsync(ctrl, d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, st));
+        DAS_HIP(hipStreamSynchronize(st));
+        if (ctrl[1] == 2u) continue;  // more than 64 W colours: wider bitmaps
+        if (ctrl[1] != 0u) return false;
+        colors.resize(n);
+        d_colors.download(colors.data(), n);
+        return true;
+    }
+    return false;
+}
+// groups from start flags: maximal runs of columns with identical net lists, cut at 8 members
+inline std::vector<long long> color_groups_from_flags(long long n, const std::vector<unsigned char>& isStart) {
+    std::vector<long long> gstart;
+    gstart.reserve(n / 2 + 2);
+    long long run = 0;
+    for (long long j = 0; j < n; j++) {
+        if (isStart[j] || run == 8) { gstart.push_back(j); run = 0; }
+        run++;
+    }
+    gstart.push_back(n);
+    return gstart;
+}
+
 // colours of the serial first-fit on the device.  keep/cptr/crow/cpos: the kept (non-dominated) rows and the CSC over them with
 // the position of every column inside its nets (das_jaccon.cpp); returns false if the device path could not be used (more than
 // 4096 colours, timeout): the caller then runs the host algorithm instead, loudly.
@@ -132,57 +178,23 @@ inline bool color_firstfit_device(long long n, const std::vector<long long>& kee
 #pragma omp parallel for schedule(static)
     for (long long q = 0; q < (long long)crow.size(); q++) crowK[q] = posOfRow[crow[q]];
     // groups: maximal runs of consecutive columns with identical kept-row lists (the xyz components of a cell's U)
-    std::vector<long long> gstart;
-    {
-        std::vector<unsigned char> isStart(n, 1);
+    std::vector<unsigned char> isStart(n, 1);
 #pragma omp parallel for schedule(static)
-        for (long long j = 1; j < n; j++) {
-            const long long len = cptr[j + 1] - cptr[j];
-            isStart[j] = !(cptr[j] - cptr[j - 1] == len && std::equal(crow.begin() + cptr[j], crow.begin() + cptr[j + 1], crow.begin() + cptr[j - 1]));
-        }
-        // a group of more than 8 columns is cut (the kernel colours at most 8 members at once)
-        gstart.reserve(n);
-        long long run = 0;
-        for (long long j = 0; j < n; j++) {
-            if (isStart[j] || run == 8) { gstart.push_back(j); run = 0; }
-            run++;
-        }
+    for (long long j = 1; j < n; j++) {
+        const long long len = cptr[j + 1] - cptr[j];
+        isStart[j] = !(cptr[j] - cptr[j - 1] == len && std::equal(crow.begin() + cptr[j], crow.begin() + cptr[j + 1], crow.begin() + cptr[j - 1]));
     }
+    const std::vector<long long> gstart = color_groups_from_flags(n, isStart);
     lap("host preparation");
-    const long long nGroups = (long long)gstart.size();
-    gstart.push_back(n);
-    DevBuf<long long> d_gstart, d_cptr;
-    DevBuf<int> d_crow, d_cpos, d_colors(n);
-    DevBuf<unsigned> d_ctrl(2), d_done(std::max<long long>(1, nKeep));
-    d_gstart.upload(gstart); d_cptr.upload(cptr);
+    DevBuf<long long> d_cptr;
+    DevBuf<int> d_crow, d_cpos;
+    d_cptr.upload(cptr);
     d_crow.upload(crowK.data(), crowK.size()); d_cpos.upload(cpos.data(), cpos.size());
     lap("upload");
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    long long wgs = (long long)cus * 8;
-    if (const char* e = getenv("DAS_COLOR_WGS")) wgs = std::max(1, atoi(e));
-    const int grid = (int)std::min<long long>(wgs, (nGroups + 3) / 4 + 1);
     (void)col;
-    for (int W = 8; W <= COLOR_MAXW; W *= 2) {
-        DevBuf<unsigned long long> d_F((size_t)std::max<long long>(1, nKeep) * W);
-        DAS_HIP(hipMemsetAsync(d_F.p, 0, d_F.n * sizeof(unsigned long long), st));
-        DAS_HIP(hipMemsetAsync(d_done.p, 0, d_done.n * sizeof(unsigned), st));
-        DAS_HIP(hipMemsetAsync(d_colors.p, 0xff, n * sizeof(int), st));
-        DAS_HIP(hipMemsetAsync(d_ctrl.p, 0, 2 * sizeof(unsigned), st));
-        ColorView V{nGroups, d_gstart.p, d_cptr.p, d_crow.p, d_cpos.p, W, d_F.p, d_done.p, d_colors.p, d_ctrl.p};
-        hipLaunchKernelGGL(k_color_firstfit, dim3(grid), dim3(256), 0, st, V);
-        DAS_HIP(hipGetLastError());
-        unsigned ctrl[2] = {0, 0};
-        DAS_HIP(hipMemcpyAsync(ctrl, d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, st));
-        DAS_HIP(hipStreamSynchronize(st));
-        if (ctrl[1] == 2u) continue;  // more than 64 W colours: wider bitmaps
-        lap("kernel");
-        if (ctrl[1] != 0u) return false;
-        colors.resize(n);
-        d_colors.download(colors.data(), n);
-        return true;
-    }
-    return false;
+    const bool ok = color_firstfit_run(n, nKeep, gstart, d_cptr.p, d_crow.p, d_cpos.p, colors, st);
+    lap("kernel");
+    return ok;
 }
 
 // =====================================================================================================================

@@ -23,6 +23,7 @@
 #include "das_block.hpp"
 #include "das_color.hpp"
 #include "das_opmat.hpp"
+#include "das_graph.hpp"
 
 #include <omp.h>
 
@@ -882,6 +883,7 @@ struct KernelTimer {
 
 struct ConDev {  // device copy of a JacCon (assembly maps + transposed structure)
     bool ready = false;
+    bool onDevice = false;  // transposed structure generated on the device (das_graph.hpp): the host JacCon holds none
     DevBuf<long long> t_rowptr;
     DevBuf<int> cl_cols;
     DevBuf<int> t_col;
@@ -1051,6 +1053,28 @@ static void compute_scales(das_solver* s) {
     if (s->inited) s->d_scale.upload(s->h_scale);
 }
 
+// ---- graph set-up on the device (das_graph.hpp): transposed structures and colouring input from the host's row-major pattern
+static bool graph_on_device(das_solver* s) {
+    if (!s->inited) return false;
+    auto it = s->opt.i.find("amd.graphOnDevice");
+    return it == s->opt.i.end() || it->second != 0;
+}
+static void upload_pattern(const JacCon& j, DevPattern& P) {
+    P.n = j.n; P.nnz = j.nnz;
+    P.rowptr.upload(j.rowptr);
+    P.col.upload(j.col.data(), j.col.size());
+}
+// transposed structure of pattern isPC into s->cd[isPC]; `keepRowMajor`: hand the uploaded row-major pattern back (colouring)
+static void device_build_con(das_solver* s, int isPC, DevPattern* keepRowMajor = nullptr) {
+    ConDev& c = s->cd[isPC ? 1 : 0];
+    const JacCon& j = isPC ? s->con_pc : s->con_full;
+    DevPattern local;
+    DevPattern& P = keepRowMajor ? *keepRowMajor : local;
+    upload_pattern(j, P);
+    device_transpose(P, c.t_rowptr, c.t_col, s->stream);
+    c.onDevice = true;
+}
+
 // preset != nullptr: colours read from a dRdWColoring file (reference DAJacCon::readJacConColoring :1980-2019) - they
 // are validated against the connectivity exactly like the reference does (DAColoring::validateColoring)
 static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
@@ -1064,11 +1088,17 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
     double t2 = wall_seconds();
     // the transposed structures need no colours: a second host thread builds them while this one prepares and runs the
     // colouring (whose 3 s data-flow kernel at 2 M cells leaves the host idle)
+    // (with a device the transposed structures are generated there, das_graph.hpp)
+    const bool devGraph = graph_on_device(s);
     std::exception_ptr tErr;
     std::thread transposer([&]() {
+        if (devGraph) return;
         try { s->con_full.build_transpose(); s->con_pc.build_transpose(); } catch (...) { tErr = std::current_exception(); }
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{transposer};
+    for (int k = 0; k < 2; k++) { s->cd[k].ready = false; s->cd[k].onDevice = false; }
+    DevPattern fullRowMajor;
+    bool fullTransposed = false;
     if (preset) {
         s->colors.assign(preset, preset + s->n);
         int mx = -1;
@@ -1097,7 +1127,47 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
                     if (!ok) fprintf(stderr, "[dafoam_amd] device colouring gave up (too many colours or a timeout): host first-fit instead\n");
                     return ok;
                 };
-            s->nColors = d2_coloring(s->con_full, s->colors, ctr.data(), fn);
+            // device graph path: the kept rows come from the host's dominance pruning; the transposed full pattern, the
+            // column -> net incidence (with positions) and the groups are derived on the device, then the same first-fit kernel
+            ColorGraphFn gfn = nullptr;
+            {
+                auto ita = s->opt.s.find("amd.coloringAlgorithm");
+                const bool spec = ita != s->opt.s.end() && ita->second == "speculative";
+                if (devGraph && s->opt.geti("amd.coloringOnDevice") && !spec)
+                    gfn = [s, &fullRowMajor, &fullTransposed](long long nn, const std::vector<long long>& keep, std::vector<int>& colors) {
+                        const bool dbg = getenv("DAS_DEBUG_TIMING") != nullptr;
+                        double tq = wall_seconds();
+                        auto lap = [&](const char* what) { if (dbg) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]     device graph: %s %.2f s\n", what, t2 - tq); tq = t2; } };
+                        hipStream_t st = s->stream;
+                        device_build_con(s, 0, &fullRowMajor);
+                        fullTransposed = true;
+                        lap("upload + transpose of the full pattern");
+                        ConDev& c = s->cd[0];
+                        const long long nKeep = (long long)keep.size();
+                        std::vector<int> netOfRow((size_t)nn, -1);
+                        for (long long q = 0; q < nKeep; q++) netOfRow[keep[q]] = (int)q;
+                        DevBuf<int> d_net, d_cnt((size_t)nn);
+                        d_net.upload(netOfRow);
+                        hipLaunchKernelGGL(k_net_count, dim3((unsigned)((nn + 15) / 16)), dim3(256), 0, st, nn, c.t_rowptr.p, c.t_col.p, d_net.p, d_cnt.p);
+                        DevBuf<long long> d_cptr((size_t)nn + 1);
+                        const long long tot = device_exclusive_scan(nn, d_cnt.p, d_cptr.p, st);
+                        DevBuf<int> d_crow((size_t)std::max<long long>(1, tot)), d_cpos((size_t)std::max<long long>(1, tot));
+                        hipLaunchKernelGGL(k_net_fill, dim3((unsigned)((nn + 15) / 16)), dim3(256), 0, st, nn, c.t_rowptr.p, c.t_col.p, d_net.p, fullRowMajor.rowptr.p,
+                                           fullRowMajor.col.p, d_cptr.p, d_crow.p, d_cpos.p);
+                        DevBuf<unsigned char> d_start((size_t)nn);
+                        hipLaunchKernelGGL(k_group_flags, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, nn, d_cptr.p, d_crow.p, d_start.p);
+                        DAS_HIP(hipGetLastError());
+                        std::vector<unsigned char> isStart = d_start.to_host();
+                        const std::vector<long long> gstart = color_groups_from_flags(nn, isStart);
+                        fullRowMajor.rowptr.release(); fullRowMajor.col.release();
+                        lap("nets, positions, groups");
+                        const bool ok = color_firstfit_run(nn, nKeep, gstart, d_cptr.p, d_crow.p, d_cpos.p, colors, st);
+                        lap("first-fit kernel");
+                        if (!ok) fprintf(stderr, "[dafoam_amd] device colouring gave up (too many colours or a timeout): host first-fit instead\n");
+                        return ok;
+                    };
+            }
+            s->nColors = d2_coloring(s->con_full, s->colors, ctr.data(), fn, gfn);
         }
     }
     double t3 = wall_seconds();
@@ -1107,11 +1177,14 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
     if (tErr) std::rethrow_exception(tErr);
     s->con_full.build_colour_lists(s->colors);
     s->con_pc.build_colour_lists(s->colors);
+    if (devGraph) {
+        if (!fullTransposed) device_build_con(s, 0);
+        device_build_con(s, 1);
+    }
     if (s->opt.geti("debug"))
         fprintf(stderr, "[dafoam_amd] runColoring: pattern %.2f s, colouring (beside the transposes) %.2f s, validate %.2f s, wait for the transposes + colour lists %.2f s\n",
                 t2 - t1, t3 - t2, t4 - t3, wall_seconds() - t4);
     s->colored = true;
-    for (int k = 0; k < 2; k++) s->cd[k].ready = false;
     if (s->opt.geti("debug"))
         fprintf(stderr, "[dafoam_amd] dRdWCon: n=%lld nnz=%lld (PC %lld) colours=%d  %.2f s\n", s->n, s->con_full.nnz, s->con_pc.nnz,
                 s->nColors, wall_seconds() - t);
@@ -1123,8 +1196,12 @@ static ConDev& ensure_con_dev(das_solver* s, int isPC) {
     if (!c.ready) {
         const JacCon& j = isPC ? s->con_pc : s->con_full;
         c.cl_cols.upload(j.cl_cols);
-        c.t_rowptr.upload(j.t_rowptr);
-        c.t_col.upload(j.t_col.data(), j.t_col.size());
+        if (c.onDevice) {
+            if (!c.t_col.p) device_build_con(s, isPC);  // released after an assembly (amd.keepAssemblyMaps 0): generated again
+        } else {
+            c.t_rowptr.upload(j.t_rowptr);
+            c.t_col.upload(j.t_col.data(), j.t_col.size());
+        }
         s->d_colors.upload(s->colors);
         c.ready = true;
     }
@@ -1204,8 +1281,15 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
     const bool useBound = !(bound < 1.0e-16);
     if (!useBound && !masked) {
         M.nnz = jc.nnz;
-        M.rowptr.upload(jc.t_rowptr);
-        M.col.upload(jc.t_col.data(), jc.t_col.size());
+        if (c.onDevice) {
+            M.rowptr.alloc((size_t)n + 1);
+            M.col.alloc((size_t)std::max<long long>(1, jc.nnz));
+            DAS_HIP(hipMemcpyAsync(M.rowptr.p, c.t_rowptr.p, (n + 1) * sizeof(long long), hipMemcpyDeviceToDevice, st));
+            DAS_HIP(hipMemcpyAsync(M.col.p, c.t_col.p, jc.nnz * sizeof(int), hipMemcpyDeviceToDevice, st));
+        } else {
+            M.rowptr.upload(jc.t_rowptr);
+            M.col.upload(jc.t_col.data(), jc.t_col.size());
+        }
         M.val = std::move(vals);
     } else {
         DevBuf<int> cnt(n);

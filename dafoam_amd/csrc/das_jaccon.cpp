@@ -271,7 +271,7 @@ static bool is_subset(const int* a, long long na, const int* b, long long nb) {
     return i == na;
 }
 
-int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres, const ColorDeviceFn& device_fn) {
+int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres, const ColorDeviceFn& device_fn, const ColorGraphFn& graph_fn) {
     const long long n = con.n;
     colors.assign(n, -1);
     const bool dbgT = getenv("DAS_DEBUG_TIMING") != nullptr;
@@ -304,6 +304,12 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         for (long long r = 0; r < n; r++) if (kept[r]) keep.push_back(r);
     }
     lap("prune");
+    if (graph_fn && graph_fn(n, keep, colors)) {
+        lap("device graph + first-fit");
+        int ncd = 0;
+        for (long long j = 0; j < n; j++) ncd = std::max(ncd, colors[j] + 1);
+        return ncd;
+    }
     // CSC over kept rows: stable chunked counting (like JacCon::build_transpose_and_maps), int row ids, no zero-fill
     std::vector<long long> cptr(n + 1, 0);
     uvector<int> crow, cpos;  // cpos: position of the column inside the (ascending) column list of that kept row

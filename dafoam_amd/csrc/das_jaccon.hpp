@@ -86,7 +86,11 @@ struct JacCon {
 using ColorDeviceFn = std::function<bool(long long n, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
                                          const uvector<int>& cpos, const std::vector<long long>& rowptr, const uvector<int>& col,
                                          std::vector<int>& colors)>;
-int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres = nullptr, const ColorDeviceFn& device_fn = nullptr);
+// `graph_fn` (optional): called right after the dominance pruning with the kept rows only - a device path that derives the
+// column -> net incidence itself (das_graph.hpp); if it returns true it has written `colors` and no host CSC is built
+using ColorGraphFn = std::function<bool(long long n, const std::vector<long long>& keep, std::vector<int>& colors)>;
+int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centres = nullptr, const ColorDeviceFn& device_fn = nullptr,
+                const ColorGraphFn& graph_fn = nullptr);
 bool validate_coloring(const JacCon& con, const std::vector<int>& colors);
 
 }  // namespace das
