@@ -1,5 +1,8 @@
 // Shared declarations of the MI355X-native adjoint hot path (host side).
 #pragma once
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -98,11 +101,29 @@ struct VmBuf {
     std::vector<size_t> sizes;
     hipMemAllocationProp prop = {};
     static constexpr size_t CHUNK = (size_t)2 << 30;
+    // chunks are mapped by a helper thread AHEAD of the iteration (request), the solver only waits if it catches up (ensure):
+    // hipMemCreate can block for tens of milliseconds while freed HBM is still being scrubbed
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t targetBytes = 0;
+    bool stopping = false;
+    int device = 0;
+    std::string workerError;
     VmBuf() = default;
     VmBuf(const VmBuf&) = delete;
     VmBuf& operator=(const VmBuf&) = delete;
     ~VmBuf() { release(); }
+    void stop_worker() {
+        if (worker.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); stopping = true; }
+            cv.notify_all();
+            worker.join();
+        }
+        stopping = false;
+    }
     void release() {
+        stop_worker();
         if (vmm && p) {
             size_t off = 0;
             for (size_t i = 0; i < handles.size(); i++) {
@@ -115,19 +136,18 @@ struct VmBuf {
             (void)hipFree(p);
         }
         handles.clear(); sizes.clear();
-        p = nullptr; n = 0; vmm = false; reservedBytes = 0; mappedBytes = 0;
+        p = nullptr; n = 0; vmm = false; reservedBytes = 0; mappedBytes = 0; targetBytes = 0; workerError.clear();
     }
     // reserve the address range for n_ elements (nothing is mapped yet on the VM path)
     void reserve(size_t n_) {
         release();
         if (!n_) return;
         const size_t bytes = n_ * sizeof(T);
-        int dev = 0;
-        if (bytes >= ((size_t)4 << 30) && !getenv("DAS_NO_VMM") && hipGetDevice(&dev) == hipSuccess) {
+        if (bytes >= ((size_t)4 << 30) && !getenv("DAS_NO_VMM") && hipGetDevice(&device) == hipSuccess) {
             prop = hipMemAllocationProp{};
             prop.type = hipMemAllocationTypePinned;
             prop.location.type = hipMemLocationTypeDevice;
-            prop.location.id = dev;
+            prop.location.id = device;
             size_t gran = 0;
             if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0) {
                 const size_t align = std::max<size_t>(gran, (size_t)2 << 20);
@@ -135,6 +155,7 @@ struct VmBuf {
                 void* base = nullptr;
                 if (hipMemAddressReserve(&base, total, align, nullptr, 0) == hipSuccess && base) {
                     p = (T*)base; reservedBytes = total; vmm = true; n = n_;
+                    worker = std::thread([this]() { this->map_loop(); });
                     return;
                 }
                 (void)hipGetLastError();
@@ -143,23 +164,49 @@ struct VmBuf {
         DAS_HIP(hipMalloc((void**)&p, bytes));  // small buffers (fast) or no VM support
         n = n_; mappedBytes = bytes;
     }
-    // make the first `count` elements addressable
-    void ensure(size_t count) {
-        if (!vmm) return;
-        const size_t need = std::min(reservedBytes, count * sizeof(T));
+    void map_loop() {
+        (void)hipSetDevice(device);
         hipMemAccessDesc acc = {};
         acc.location = prop.location;
         acc.flags = hipMemAccessFlagsProtReadWrite;
-        while (mappedBytes < need) {
-            const size_t sz = std::min(CHUNK, reservedBytes - mappedBytes);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&]() { return stopping || (mappedBytes < targetBytes && workerError.empty()); });
+            if (stopping) return;
+            const size_t off = mappedBytes, sz = std::min(CHUNK, reservedBytes - off);
+            lk.unlock();
             hipMemGenericAllocationHandle_t h;
-            DAS_HIP(hipMemCreate(&h, sz, &prop, 0));
-            hipError_t e = hipMemMap((char*)p + mappedBytes, sz, 0, h, 0);
-            if (e != hipSuccess) { (void)hipMemRelease(h); DAS_HIP(e); }
-            handles.push_back(h); sizes.push_back(sz);
-            DAS_HIP(hipMemSetAccess((char*)p + mappedBytes, sz, &acc, 1));
-            mappedBytes += sz;
+            hipError_t e = hipMemCreate(&h, sz, &prop, 0);
+            bool created = e == hipSuccess;
+            if (created) e = hipMemMap((char*)p + off, sz, 0, h, 0);
+            if (e == hipSuccess) e = hipMemSetAccess((char*)p + off, sz, &acc, 1);
+            lk.lock();
+            if (e != hipSuccess) {
+                if (created) (void)hipMemRelease(h);
+                (void)hipGetLastError();
+                workerError = std::string("mapping a chunk of the Krylov basis failed: ") + hipGetErrorString(e);
+            } else {
+                handles.push_back(h); sizes.push_back(sz);
+                mappedBytes = off + sz;
+            }
+            cv.notify_all();
         }
+    }
+    // ask for the first `count` elements to become addressable (asynchronous)
+    void request(size_t count) {
+        if (!vmm) return;
+        const size_t need = std::min(reservedBytes, count * sizeof(T));
+        { std::lock_guard<std::mutex> lk(mu); if (need > targetBytes) targetBytes = need; }
+        cv.notify_all();
+    }
+    // wait until the first `count` elements are addressable
+    void ensure(size_t count) {
+        if (!vmm) return;
+        request(count);
+        const size_t need = std::min(reservedBytes, count * sizeof(T));
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return mappedBytes >= need || !workerError.empty(); });
+        if (!workerError.empty()) throw Error(DAS_ERR_INTERNAL, workerError);
     }
     void alloc(size_t n_) { reserve(n_); ensure(n_); }
 };

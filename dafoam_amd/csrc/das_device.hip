@@ -1966,7 +1966,11 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
     }
 }
 // basis slots [0, nvec) are about to be written / read: map them (a no-op once mapped; milliseconds per new 2 GB chunk)
-static inline void gmres_map_basis(das_solver* s, das_ksp* k, long long nvec) { k->V.ensure((size_t)(nvec * s->n)); }
+// the helper thread of the buffer maps 64 vectors ahead of the iteration; the solver waits only if it catches up
+static inline void gmres_map_basis(das_solver* s, das_ksp* k, long long nvec) {
+    k->V.request((size_t)((nvec + 64) * s->n));
+    k->V.ensure((size_t)(nvec * s->n));
+}
 
 // dev_out[0..m) = V^T w (V = m vectors of stride n starting at Vbase), dev_out[m] = w.w; summed over the ranks
 static void multidot_dev(das_solver* s, das_ksp* k, const double* Vbase, int m, const double* w, double* dev_out) {
