@@ -268,9 +268,22 @@ struct Mesh {
     // cell -> cells CSR (face neighbours, ascending)
     std::vector<int> cc_ptr, cc;
     void build(const das_case_t* c);
+    struct GeomTopo geom_topo() const;  // das_geom.hpp
     void compute_geometry(const double* y_wall);
     void build_addressing();
 };
+
+// mesh points: the cells whose residual rows feel a point, a colouring of the points with pairwise disjoint sets, FD steps
+struct PointInfluence {
+    int rings = 0, nColors = 0;
+    std::vector<long long> ptr;      // nP + 1
+    std::vector<int> cells;          // influenced cells of every point, ascending
+    std::vector<int> color;          // nP (-1: a point no face uses)
+    std::vector<int> cptr, cpoints;  // colour -> points
+    std::vector<double> h;           // nP: central-difference step of the point (point_steps)
+};
+void build_point_influence(const Mesh& m, int rings, int threads, PointInfluence& out);
+void point_steps(const Mesh& m, double relStep, std::vector<double>& h);
 
 double wall_seconds();
 

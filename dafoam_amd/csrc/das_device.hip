@@ -24,6 +24,7 @@
 #include "das_color.hpp"
 #include "das_opmat.hpp"
 #include "das_graph.hpp"
+#include "das_volcoord.hpp"
 
 #include <omp.h>
 
@@ -60,14 +61,6 @@ __global__ __launch_bounds__(256) void k_pres(DevMesh m, ResParams prm, const T*
     if (c < m.nC) body_pres<T, RHO>(c, m, prm, q, R);
 }
 // face-integral objectives: value (atomic sums per group), forward-mode tangent, coloured dual-number gradient scatter
-struct FaceFnView {
-    const int* faces;
-    const unsigned char* group;  // 0 / 1: denominator / numerator set of ratio functions (all 0 otherwise)
-    const double* w;             // per-face weight (value pass: base weights; derivative passes: effective weights)
-    const double* dir;           // 3 per face (force / moment), may be null for the other kinds
-    int nf, kind;
-    double gammaFn, RFn;
-};
 template <bool RHO>
 __global__ __launch_bounds__(256) void k_fn_value(DevMesh m, ResParams prm, const double* __restrict__ W, const double* nut, const double* gU,
                                                   FaceFnView fn, double* out2) {
@@ -1000,6 +993,19 @@ struct das_solver {
     int colorRounds = 0;        // rounds of the speculative device colouring (0: another algorithm ran)
     DevBuf<double> d_betaFI, d_dBetaFI;  // `field` input betaFINuTilda and its tangent (das_set_field / das_calc_dfield_product)
     long long geomVersion = 0;  // bumped by das_update_of_mesh
+    // mesh-sensitivity product (das_volcoord.hpp): point influence sets + colours (topology only: built once), device copies
+    struct VolCoord {
+        PointInfluence inf;
+        bool built = false, uploaded = false;
+        double relStep = 0.0;
+        long long hGeom = -1;  // geometry version the steps h were computed for
+        DevBuf<long long> d_ptr;
+        DevBuf<int> d_cells, d_cpoints, d_face_ptr, d_face_pts, d_bad, d_fnPtr, d_fnIdx;
+        DevBuf<double> d_h, d_X0, d_X, d_Rp, d_Rm, d_seeds, d_tc, d_out, d_fvp, d_fvm;
+        DevBuf<FaceGeom> d_fg0;
+        DevBuf<CellGeom> d_cg0;
+        double buildSeconds = 0.0, seconds = 0.0;
+    } vc;
     // everything else the Jacobian depends on besides the states and the geometry: patch values, old-time fields, options
     // (normalizeStates, residual / discretisation switches).  Every setter bumps the epoch; a cached operator is only
     // reused by calcJacTVecProduct when its epoch is current
@@ -3496,6 +3502,224 @@ int das_calc_dfield_product(das_solver_t* s, const char* fieldName, const char* 
     DAS_HIP(hipGetLastError());
     DAS_HIP(hipMemcpyAsync(product, s->d_tmp1.p, N * sizeof(double), hipMemcpyDeviceToHost, st));
     DAS_HIP(hipStreamSynchronize(st));
+    return DAS_OK;
+    DAS_CATCH
+}
+
+// ---- mesh-sensitivity product over all points (das_volcoord.hpp) -----------------------------------------------------
+static GeomTopo device_geom_topo(das_solver* s) {
+    das_solver::VolCoord& v = s->vc;
+    const Mesh& m = s->mesh;
+    if (v.d_face_ptr.n != m.face_ptr.size()) { v.d_face_ptr.upload(m.face_ptr); v.d_face_pts.upload(m.face_pts); v.d_bad.alloc(1); }
+    GeomTopo t;
+    t.nC = m.nC; t.nF = m.nF; t.nIF = m.nIF;
+    t.face_ptr = v.d_face_ptr.p; t.face_pts = v.d_face_pts.p;
+    t.owner = s->d_owner.p; t.neigh = s->d_neigh.p;
+    t.cf_ptr = s->d_cf_ptr.p; t.cf_face = s->d_cf_face.p;
+    t.bpatch = s->d_bpatch.p; t.cyc = s->d_cyc.p; t.bc = s->d_bc.p;
+    return t;
+}
+// the three metric passes on the device: points X -> s->d_fg / s->d_cg (frozen wall distance kept)
+static void device_geometry(das_solver* s, const GeomTopo& t, const double* X) {
+    const int B = 256;
+    hipStream_t st = s->stream;
+    hipLaunchKernelGGL(k_geom_face, dim3(nblk(t.nF, B)), dim3(B), 0, st, t, X, s->d_fg.p);
+    hipLaunchKernelGGL(k_geom_cell, dim3(nblk(t.nC, B)), dim3(B), 0, st, t, (const FaceGeom*)s->d_fg.p, s->d_cg.p, s->vc.d_bad.p);
+    hipLaunchKernelGGL(k_geom_weights, dim3(nblk(t.nF, B)), dim3(B), 0, st, t, (const CellGeom*)s->d_cg.p, s->d_fg.p);
+}
+static void ensure_point_influence(das_solver* s) {
+    das_solver::VolCoord& v = s->vc;
+    const int rings = (int)s->opt.geti("amd.volCoordRings");
+    const double rel = s->opt.getd("amd.volCoordRelStep");
+    DAS_CHECK(rings >= 1 && rel > 0, DAS_ERR_ARG, "amd.volCoordRings >= 1 and amd.volCoordRelStep > 0 expected");
+    if (!(v.built && v.inf.rings == rings)) {  // topology only: survives mesh updates
+        const double t0 = wall_seconds();
+        build_point_influence(s->mesh, rings, (int)s->opt.geti("amd.setupThreads"), v.inf);
+        v.built = true;
+        v.uploaded = false;
+        v.hGeom = -1;
+        v.buildSeconds = wall_seconds() - t0;
+    }
+    if (v.relStep != rel || v.hGeom != s->geomVersion) {
+        point_steps(s->mesh, rel, v.inf.h);
+        v.relStep = rel;
+        v.hGeom = s->geomVersion;
+        if (s->inited) v.d_h.upload(v.inf.h);
+    }
+    if (s->inited && !v.uploaded) {
+        v.d_ptr.upload(v.inf.ptr);
+        v.d_cells.upload(v.inf.cells);
+        v.d_cpoints.upload(v.inf.cpoints);
+        v.d_h.upload(v.inf.h);
+        v.uploaded = true;
+    }
+}
+// debug / test aid: the metrics the DEVICE passes produce for `points`, without touching the solver's geometry
+int das_debug_device_geometry(das_solver_t* s, const double* points, double* fg12, double* cg5) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(points && fg12 && cg5, DAS_ERR_ARG, "null argument");
+    static_assert(sizeof(FaceGeom) == 12 * sizeof(double) && sizeof(CellGeom) == 5 * sizeof(double), "geometry records are plain doubles");
+    const Mesh& m = s->mesh;
+    das_solver::VolCoord& v = s->vc;
+    const GeomTopo t = device_geom_topo(s);
+    DAS_HIP(hipStreamSynchronize(s->stream));
+    v.d_fg0.alloc(m.nF); v.d_cg0.alloc(m.nC);
+    DAS_HIP(hipMemcpy(v.d_fg0.p, s->d_fg.p, m.nF * sizeof(FaceGeom), hipMemcpyDeviceToDevice));
+    DAS_HIP(hipMemcpy(v.d_cg0.p, s->d_cg.p, m.nC * sizeof(CellGeom), hipMemcpyDeviceToDevice));
+    v.d_X.upload(points, 3 * (size_t)m.nP);
+    DAS_HIP(hipMemsetAsync(v.d_bad.p, 0, sizeof(int), s->stream));
+    device_geometry(s, t, v.d_X.p);
+    DAS_HIP(hipGetLastError());
+    DAS_HIP(hipStreamSynchronize(s->stream));
+    DAS_HIP(hipMemcpy(fg12, s->d_fg.p, m.nF * sizeof(FaceGeom), hipMemcpyDeviceToHost));
+    DAS_HIP(hipMemcpy(cg5, s->d_cg.p, m.nC * sizeof(CellGeom), hipMemcpyDeviceToHost));
+    DAS_HIP(hipMemcpy(s->d_fg.p, v.d_fg0.p, m.nF * sizeof(FaceGeom), hipMemcpyDeviceToDevice));
+    DAS_HIP(hipMemcpy(s->d_cg.p, v.d_cg0.p, m.nC * sizeof(CellGeom), hipMemcpyDeviceToDevice));
+    v.d_fg0.release(); v.d_cg0.release();
+    return DAS_OK;
+    DAS_CATCH
+}
+// host-side structure of the product (no GPU needed): sizes, then colours / influence sets / steps
+int das_point_influence_build(das_solver_t* s, int* nColors, long long* nEntries) {
+    DAS_TRY
+    DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
+    ensure_point_influence(s);
+    if (nColors) *nColors = s->vc.inf.nColors;
+    if (nEntries) *nEntries = (long long)s->vc.inf.cells.size();
+    return DAS_OK;
+    DAS_CATCH
+}
+int das_point_influence_get(das_solver_t* s, int* colors, long long* ptr, int* cells, double* steps) {
+    DAS_TRY
+    DAS_CHECK(s && s->vc.built, DAS_ERR_STATE, "das_point_influence_build has not been called");
+    const PointInfluence& I = s->vc.inf;
+    if (colors) std::copy(I.color.begin(), I.color.end(), colors);
+    if (ptr) std::copy(I.ptr.begin(), I.ptr.end(), ptr);
+    if (cells) std::copy(I.cells.begin(), I.cells.end(), cells);
+    if (steps) std::copy(I.h.begin(), I.h.end(), steps);
+    return DAS_OK;
+    DAS_CATCH
+}
+// calcJacTVecProduct(volCoord -> residual | function), reference DASolver.C:1690-1839 + DAInputVolCoord: the full product vector
+// (3 nPoints) at the current states and points.  info4 (optional) = {colours, residual passes, seconds of the passes, seconds of
+// the one-off influence / colouring build}
+int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const char* outputType, const double* seeds, double* product,
+                               double* info4) {
+    DAS_TRY
+    need_init(s);
+    DAS_CHECK(outputType && seeds && product, DAS_ERR_ARG, "null argument");
+    const std::string ot = outputType;
+    DAS_CHECK(ot == "residual" || ot == "function", DAS_ERR_ARG, "outputType not supported on this path: " + ot);
+    DAS_CHECK(s->owned.empty(), DAS_ERR_ARG, "the volCoord product runs on an undecomposed mesh (sharded solvers: use calcVolCoordDirectionalProduct)");
+    const Mesh& m = s->mesh;
+    const bool isFn = ot == "function";
+    das_solver::FaceFn* fn = nullptr;
+    if (isFn) {
+        fn = &get_function(s, outputName);
+        // weights / directions that depend on the metrics themselves (moment arms, area fractions) are built on the host
+        DAS_CHECK(!fn->isMoment && (fn->kind == DAS_FN_FORCE || fn->kind == DAS_FN_MASSFLOW), DAS_ERR_ARG,
+                  "volCoord product of this function type is not implemented (force and massFlowRate are; use calcVolCoordDirectionalProduct)");
+    }
+    ensure_point_influence(s);
+    das_solver::VolCoord& v = s->vc;
+    const PointInfluence& I = v.inf;
+    const GeomTopo t = device_geom_topo(s);
+    hipStream_t st = s->stream;
+    const int B = 256;
+    const long long n = s->n;
+    const size_t n3 = 3 * (size_t)m.nP;
+    v.d_X0.upload(m.points.data(), n3);
+    v.d_X.upload(m.points.data(), n3);
+    v.d_out.alloc(n3);
+    v.d_tc.alloc(m.nC);
+    DAS_HIP(hipMemsetAsync(v.d_out.p, 0, n3 * sizeof(double), st));
+    DAS_HIP(hipMemsetAsync(v.d_bad.p, 0, sizeof(int), st));
+    v.d_fg0.alloc(m.nF); v.d_cg0.alloc(m.nC);
+    DAS_HIP(hipMemcpyAsync(v.d_fg0.p, s->d_fg.p, m.nF * sizeof(FaceGeom), hipMemcpyDeviceToDevice, st));
+    DAS_HIP(hipMemcpyAsync(v.d_cg0.p, s->d_cg.p, m.nC * sizeof(CellGeom), hipMemcpyDeviceToDevice, st));
+    // whatever happens below, the solver's metrics are the unperturbed ones afterwards
+    struct Restore {
+        das_solver* s;
+        ~Restore() {
+            das_solver::VolCoord& v = s->vc;
+            (void)hipStreamSynchronize(s->stream);
+            (void)hipMemcpy(s->d_fg.p, v.d_fg0.p, s->mesh.nF * sizeof(FaceGeom), hipMemcpyDeviceToDevice);
+            (void)hipMemcpy(s->d_cg.p, v.d_cg0.p, s->mesh.nC * sizeof(CellGeom), hipMemcpyDeviceToDevice);
+            v.d_fg0.release(); v.d_cg0.release(); v.d_Rp.release(); v.d_Rm.release(); v.d_seeds.release();
+            v.d_X.release(); v.d_X0.release(); v.d_tc.release(); v.d_fvp.release(); v.d_fvm.release();
+        }
+    } restore{s};
+    const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
+    ResParams prm0 = make_params(s->cp, s->opt, 0);
+    RowLayout L{};
+    int nf = 0;
+    if (!isFn) {
+        const Stencil stn = make_stencil(s->cp.solver, m.nC, m.nF, s->opt, false, s->cp.hasT != 0);
+        DAS_CHECK(stn.states.size() <= 8, DAS_ERR_INTERNAL, "more than 8 state blocks");
+        L.nb = (int)stn.states.size();
+        for (int b = 0; b < L.nb; b++) { L.off[b] = stn.states[b].offset; L.kind[b] = (int)stn.states[b].kind; }
+        v.d_Rp.alloc(n); v.d_Rm.alloc(n);
+        v.d_seeds.upload(seeds, n);
+    } else {
+        DAS_CHECK(s->cp.solver == DAS_SOLVER_SIMPLEFOAM || rho, DAS_ERR_ARG, "function needs a flow solver");
+        nf = (int)fn->faces.size();
+        v.d_fvp.alloc(nf); v.d_fvm.alloc(nf);
+        // cell -> slots of its function faces
+        std::vector<int> cptr(m.nC + 1, 0), cidx(nf);
+        for (int k = 0; k < nf; k++) cptr[m.owner[fn->faces[k]] + 1]++;
+        for (int c = 0; c < m.nC; c++) cptr[c + 1] += cptr[c];
+        std::vector<int> pos(cptr.begin(), cptr.end() - 1);
+        for (int k = 0; k < nf; k++) cidx[pos[m.owner[fn->faces[k]]]++] = k;
+        v.d_fnPtr.upload(cptr); v.d_fnIdx.upload(cidx);
+    }
+    auto output_pass = [&](double* Rout, double* fvOut) {
+        if (!isFn) {
+            eval_residual<double>(s->dm, s->cp, prm0, s->d_W.p, Rout, s->wk, s->d_phiF.p, s->d_Told.p, st);
+            return;
+        }
+        const ResParams prm = s->wk.bind(s->cp.solver, s->dm.nC, s->dm.nF, prm0);
+        if (rho) {
+            hipLaunchKernelGGL((k_grad<double, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
+            hipLaunchKernelGGL((k_fn_face<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
+        } else {
+            hipLaunchKernelGGL((k_grad<double, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
+            hipLaunchKernelGGL((k_fn_face<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
+        }
+    };
+    const double t0 = wall_seconds();
+    long long passes = 0;
+    for (int col = 0; col < I.nColors; col++) {
+        const int np = I.cptr[col + 1] - I.cptr[col];
+        if (np == 0) continue;
+        const int* pts = v.d_cpoints.p + I.cptr[col];
+        for (int axis = 0; axis < 3; axis++) {
+            for (int side = 0; side < 2; side++) {
+                hipLaunchKernelGGL(k_move_points, dim3(nblk(np, B)), dim3(B), 0, st, np, pts, (const double*)v.d_h.p, side == 0 ? 1.0 : -1.0, axis,
+                                   (const double*)v.d_X0.p, v.d_X.p);
+                device_geometry(s, t, v.d_X.p);
+                output_pass(side == 0 ? v.d_Rp.p : v.d_Rm.p, side == 0 ? v.d_fvp.p : v.d_fvm.p);
+                passes++;
+            }
+            hipLaunchKernelGGL(k_move_points, dim3(nblk(np, B)), dim3(B), 0, st, np, pts, (const double*)v.d_h.p, 0.0, axis, (const double*)v.d_X0.p, v.d_X.p);
+            if (!isFn)
+                hipLaunchKernelGGL(k_vc_rows, dim3(nblk(m.nC, B)), dim3(B), 0, st, s->dm, L, (const double*)v.d_seeds.p, (const double*)v.d_Rp.p,
+                                   (const double*)v.d_Rm.p, v.d_tc.p);
+            else
+                hipLaunchKernelGGL(k_vc_fn_cells, dim3(nblk(m.nC, B)), dim3(B), 0, st, m.nC, (const int*)v.d_fnPtr.p, (const int*)v.d_fnIdx.p, seeds[0],
+                                   (const double*)v.d_fvp.p, (const double*)v.d_fvm.p, v.d_tc.p);
+            hipLaunchKernelGGL(k_vc_gather, dim3(nblk(np, 4)), dim3(256), 0, st, np, pts, (const long long*)v.d_ptr.p, (const int*)v.d_cells.p,
+                               (const double*)v.d_tc.p, (const double*)v.d_h.p, axis, v.d_out.p);
+        }
+        DAS_HIP(hipGetLastError());
+    }
+    int bad = 0;
+    DAS_HIP(hipMemcpyAsync(&bad, v.d_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipMemcpyAsync(product, v.d_out.p, n3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
+    DAS_CHECK(!bad, DAS_ERR_INTERNAL, "a perturbed mesh of the volCoord product has a non-positive cell volume (amd.volCoordRelStep too large?)");
+    v.seconds = wall_seconds() - t0;
+    if (info4) { info4[0] = I.nColors; info4[1] = (double)passes; info4[2] = v.seconds; info4[3] = v.buildSeconds; }
     return DAS_OK;
     DAS_CATCH
 }

@@ -970,4 +970,14 @@ DAS_HD void body_T(int c, const DevMesh& m, const ResParams& prm, const T* W, co
     R[c] = res;
 }
 
+// a face-integral objective as the kernels see it (k_fn_value / k_fn_grad / k_fn_face)
+struct FaceFnView {
+    const int* faces;
+    const unsigned char* group;  // 0 / 1: denominator / numerator set of ratio functions (all 0 otherwise)
+    const double* w;             // per-face weight (value pass: base weights; derivative passes: effective weights)
+    const double* dir;           // 3 per face (force / moment), may be null for the other kinds
+    int nf, kind;
+    double gammaFn, RFn;
+};
+
 }  // namespace das

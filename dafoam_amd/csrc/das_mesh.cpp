@@ -9,6 +9,7 @@
 #include <cmath>
 
 #include "das_common.hpp"
+#include "das_geom.hpp"
 
 namespace das {
 
@@ -78,6 +79,8 @@ Options::Options() {
     i["amd.blockBatchedPC"] = 1;    // block GMRES: all right-hand sides through one pair of preconditioner sweeps (0: column by column)
     i["amd.opPackVector"] = 1;      // Krylov operator: vector-state rows packed as group rows (das_opmat.hpp)
     s["amd.coloringAlgorithm"] = "firstfit";  // device colouring: "firstfit" (serial colours, data-flow over net bitmaps) | "speculative"
+    i["amd.volCoordRings"] = 3;     // mesh-sensitivity product: face-neighbour rings a point's influence is followed over (the deepest stencil table)
+    d["amd.volCoordRelStep"] = 1e-4;  // ... central-difference step of a point, relative to the smallest adjacent cell thickness
     i["amd.pcCoarseGlobal"] = 1;    // multi-GPU: one global pressure coarse space (das_ksp_set_global_coarse) instead of one per rank
     // "dcgs2": classical Gram-Schmidt with DELAYED re-orthogonalisation - the second projection of step j and the first of
     // step j+1 share one pass over the basis (2 instead of 4 basis reads per iteration, same iterates); "cgs": the
@@ -171,129 +174,35 @@ void Mesh::build(const das_case_t* c) {
         DAS_CHECK(patch_size[q] == patch_size[p], DAS_ERR_ARG, "cyclic patch pair with different sizes");
         for (int k = 0; k < patch_size[p]; k++) cyc_face[patch_start[p] - nIF + k] = patch_start[q] + k;
     }
-    compute_geometry(c->y_wall);
     build_addressing();
+    compute_geometry(c->y_wall);
 }
 
-static inline void cross(const double* a, const double* b, double* c) {
-    c[0] = a[1] * b[2] - a[2] * b[1];
-    c[1] = a[2] * b[0] - a[0] * b[2];
-    c[2] = a[0] * b[1] - a[1] * b[0];
+// primitiveMesh::makeFaceCentresAndAreas / makeCellCentresAndVols and surfaceInterpolation::makeWeights /
+// makeNonOrthDeltaCoeffs / makeNonOrthCorrectionVectors: three passes over the per-entity bodies of das_geom.hpp (the device
+// kernels of the mesh-sensitivity product run the same bodies).  Needs build_addressing() (cell -> faces lists).
+GeomTopo Mesh::geom_topo() const {
+    GeomTopo t;
+    t.nC = nC; t.nF = nF; t.nIF = nIF;
+    t.face_ptr = face_ptr.data(); t.face_pts = face_pts.data();
+    t.owner = owner.data(); t.neigh = neighbour.data();
+    t.cf_ptr = cf_ptr.data(); t.cf_face = cf_face.data();
+    t.bpatch = bface_patch.data(); t.cyc = cyc_face.data(); t.bc = bc.data();
+    return t;
 }
-
-// primitiveMesh::makeFaceCentresAndAreas / makeCellCentresAndVols and
-// surfaceInterpolation::makeWeights / makeNonOrthDeltaCoeffs / makeNonOrthCorrectionVectors.
 void Mesh::compute_geometry(const double* y_wall) {
+    DAS_CHECK((int)cf_ptr.size() == nC + 1, DAS_ERR_INTERNAL, "compute_geometry needs the cell -> faces addressing");
     fg.assign(nF, FaceGeom{});
     cg.assign(nC, CellGeom{});
-    for (int f = 0; f < nF; f++) {
-        int b = face_ptr[f], e = face_ptr[f + 1], nv = e - b;
-        FaceGeom& g = fg[f];
-        const double* P = points.data();
-        if (nv == 3) {
-            const double *p0 = P + 3 * face_pts[b], *p1 = P + 3 * face_pts[b + 1], *p2 = P + 3 * face_pts[b + 2];
-            double a[3], c2[3], n[3];
-            for (int k = 0; k < 3; k++) { a[k] = p1[k] - p0[k]; c2[k] = p2[k] - p0[k]; g.Cf[k] = (p0[k] + p1[k] + p2[k]) / 3.0; }
-            cross(a, c2, n);
-            for (int k = 0; k < 3; k++) g.Sf[k] = 0.5 * n[k];
-        } else {
-            double fc[3] = {0, 0, 0};
-            for (int i = b; i < e; i++) for (int k = 0; k < 3; k++) fc[k] += P[3 * face_pts[i] + k];
-            for (int k = 0; k < 3; k++) fc[k] /= nv;
-            double sumN[3] = {0, 0, 0}, sumA = 0, sumAc[3] = {0, 0, 0};
-            for (int i = 0; i < nv; i++) {
-                const double* p = P + 3 * face_pts[b + i];
-                const double* q = P + 3 * face_pts[b + (i + 1) % nv];
-                double u[3], v[3], n[3];
-                for (int k = 0; k < 3; k++) { u[k] = q[k] - p[k]; v[k] = fc[k] - p[k]; }
-                cross(u, v, n);
-                double a = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-                for (int k = 0; k < 3; k++) { sumN[k] += n[k]; sumAc[k] += a * (p[k] + q[k] + fc[k]); }
-                sumA += a;
-            }
-            for (int k = 0; k < 3; k++) { g.Cf[k] = sumAc[k] / (3.0 * sumA); g.Sf[k] = 0.5 * sumN[k]; }
-        }
-        g.magSf = std::sqrt(g.Sf[0] * g.Sf[0] + g.Sf[1] * g.Sf[1] + g.Sf[2] * g.Sf[2]);
-    }
-    // cells
-    std::vector<double> cEst(3 * (size_t)nC, 0.0);
-    std::vector<int> cnt(nC, 0);
-    for (int f = 0; f < nF; f++) {
-        for (int k = 0; k < 3; k++) cEst[3 * (size_t)owner[f] + k] += fg[f].Cf[k];
-        cnt[owner[f]]++;
-        if (f < nIF) { for (int k = 0; k < 3; k++) cEst[3 * (size_t)neighbour[f] + k] += fg[f].Cf[k]; cnt[neighbour[f]]++; }
-    }
-    for (int c = 0; c < nC; c++) for (int k = 0; k < 3; k++) cEst[3 * (size_t)c + k] /= cnt[c];
-    std::vector<double> V3(nC, 0.0), Cs(3 * (size_t)nC, 0.0);
-    for (int f = 0; f < nF; f++) {
-        const FaceGeom& g = fg[f];
-        int o = owner[f];
-        double pv = 0;
-        for (int k = 0; k < 3; k++) pv += g.Sf[k] * (g.Cf[k] - cEst[3 * (size_t)o + k]);
-        for (int k = 0; k < 3; k++) Cs[3 * (size_t)o + k] += pv * (0.75 * g.Cf[k] + 0.25 * cEst[3 * (size_t)o + k]);
-        V3[o] += pv;
-        if (f < nIF) {
-            int n = neighbour[f];
-            double pn = 0;
-            for (int k = 0; k < 3; k++) pn += g.Sf[k] * (cEst[3 * (size_t)n + k] - g.Cf[k]);
-            for (int k = 0; k < 3; k++) Cs[3 * (size_t)n + k] += pn * (0.75 * g.Cf[k] + 0.25 * cEst[3 * (size_t)n + k]);
-            V3[n] += pn;
-        }
-    }
+    const GeomTopo t = geom_topo();
+    const double* P = points.data();
+    for (int f = 0; f < nF; f++) geom_face(f, t, P, fg[f]);
     for (int c = 0; c < nC; c++) {
-        for (int k = 0; k < 3; k++) cg[c].C[k] = Cs[3 * (size_t)c + k] / V3[c];
-        cg[c].V = V3[c] / 3.0;
+        const bool ok = geom_cell(c, t, fg.data(), cg[c]);
         cg[c].y = y_wall ? y_wall[c] : 1.0;
-        DAS_CHECK(cg[c].V > 0, DAS_ERR_ARG, "non-positive cell volume");
+        DAS_CHECK(ok, DAS_ERR_ARG, "non-positive cell volume");
     }
-    for (int f = 0; f < nF; f++) {
-        FaceGeom& g = fg[f];
-        const double* Co = cg[owner[f]].C;
-        if (f < nIF) {
-            const double* Cn = cg[neighbour[f]].C;
-            double so = 0, sn = 0, d[3], md = 0, nd = 0;
-            for (int k = 0; k < 3; k++) {
-                so += g.Sf[k] * (g.Cf[k] - Co[k]);
-                sn += g.Sf[k] * (Cn[k] - g.Cf[k]);
-                d[k] = Cn[k] - Co[k];
-                md += d[k] * d[k];
-                nd += g.Sf[k] / g.magSf * d[k];
-            }
-            so = std::fabs(so); sn = std::fabs(sn); md = std::sqrt(md);
-            g.w = sn / (so + sn);
-            g.nod = 1.0 / std::max(nd, 0.05 * md);
-            for (int k = 0; k < 3; k++) g.corr[k] = g.Sf[k] / g.magSf - d[k] * g.nod;
-        } else if (cyc_face[f - nIF] >= 0) {
-            // cyclicFvPatch::makeWeights / delta() for a translational pair: the neighbour cell is the owner of the
-            // paired face, seen at  Cf - Q (Cf' - C')  (its image across the pair)
-            const int f2 = cyc_face[f - nIF];
-            const FaceGeom& g2 = fg[f2];
-            const double* C2 = cg[owner[f2]].C;
-            const double* Q = bc[bface_patch[f - nIF]].Q;  // forwardT: neighbour-side vectors -> this side
-            double dOwn = 0, dNbr = 0, d[3], md = 0, nd = 0;
-            const double r2[3] = {g2.Cf[0] - C2[0], g2.Cf[1] - C2[1], g2.Cf[2] - C2[2]};
-            for (int k = 0; k < 3; k++) {
-                dOwn += g.Sf[k] / g.magSf * (g.Cf[k] - Co[k]);
-                dNbr += g2.Sf[k] / g2.magSf * r2[k];
-                d[k] = (g.Cf[k] - Co[k]) - (Q[3 * k] * r2[0] + Q[3 * k + 1] * r2[1] + Q[3 * k + 2] * r2[2]);
-                md += d[k] * d[k];
-            }
-            for (int k = 0; k < 3; k++) nd += g.Sf[k] / g.magSf * d[k];
-            md = std::sqrt(md);
-            g.w = dNbr / (dOwn + dNbr);
-            g.nod = 1.0 / std::max(nd, 0.05 * md);
-            for (int k = 0; k < 3; k++) g.corr[k] = g.Sf[k] / g.magSf - d[k] * g.nod;
-        } else {
-            // non-coupled patch: fvPatch::delta() is the PATCH-NORMAL part of Cf - Cn (OpenFOAM v1712+, fvPatch.C "Use patch-normal
-            // delta for all non-coupled BCs"), so deltaCoeffs = nonOrthDeltaCoeffs = 1 / |nf . (Cf - Cn)|; identical to 1/|Cf - Cn|
-            // on orthogonal wall cells, different on sheared ones (bump, airfoil)
-            double nd = 0;
-            for (int k = 0; k < 3; k++) nd += g.Sf[k] / g.magSf * (g.Cf[k] - Co[k]);
-            g.w = 1.0;
-            g.nod = 1.0 / std::fabs(nd);
-            g.corr[0] = g.corr[1] = g.corr[2] = 0.0;
-        }
-    }
+    for (int f = 0; f < nF; f++) geom_weights(f, t, cg.data(), fg.data(), fg[f]);
 }
 
 void Mesh::build_addressing() {
@@ -336,6 +245,117 @@ void Mesh::build_addressing() {
     }
     cc_ptr[nC] = w;
     cc.resize(w);
+}
+
+// ---- points: who feels a point, and which points may move together ------------------------------------------------------
+// The residual rows of a cell (its cell-centred rows and the phi rows of the faces it owns) reach at most `rings` face-neighbour
+// rings (pRes: 3, the deepest table of the reference, DAStateInfo*.C); a metric of a cell or face of that stencil depends on the
+// points of the cell / of the two cells of the face.  Hence: the rows that can change when point p moves belong to the cells
+// within `rings` rings of the cells touching p.  Two points whose sets are disjoint can be perturbed in the same residual pass:
+// a greedy first-fit colouring over per-cell colour bitmaps (the structure of the Jacobian colouring, with points as columns
+// and cells as nets) groups them.
+// central-difference step of every point: relStep x the smallest thickness V / max |Sf| of the cells at the point
+void point_steps(const Mesh& m, double relStep, std::vector<double>& h) {
+    std::vector<double> thick(m.nC);
+    for (int c = 0; c < m.nC; c++) {
+        double amax = 0.0;
+        for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) amax = std::max(amax, m.fg[m.cf_face[s] & 0x7fffffff].magSf);
+        thick[c] = m.cg[c].V / amax;
+    }
+    h.assign(m.nP, 1e300);
+    for (int f = 0; f < m.nF; f++) {
+        const double l = f < m.nIF ? std::min(thick[m.owner[f]], thick[m.neighbour[f]]) : thick[m.owner[f]];
+        for (int i = m.face_ptr[f]; i < m.face_ptr[f + 1]; i++) h[m.face_pts[i]] = std::min(h[m.face_pts[i]], relStep * l);
+    }
+    for (int p = 0; p < m.nP; p++) if (h[p] == 1e300) h[p] = 0.0;
+}
+void build_point_influence(const Mesh& m, int rings, int threads, PointInfluence& out) {
+    const int nP = m.nP, nC = m.nC;
+    out.rings = rings;
+    // point -> touching cells
+    std::vector<long long> pcPtr((size_t)nP + 1, 0);
+    for (int f = 0; f < m.nF; f++)
+        for (int i = m.face_ptr[f]; i < m.face_ptr[f + 1]; i++) pcPtr[m.face_pts[i] + 1] += f < m.nIF ? 2 : 1;
+    for (int p = 0; p < nP; p++) pcPtr[p + 1] += pcPtr[p];
+    std::vector<int> pc(pcPtr[nP]);
+    {
+        std::vector<long long> pos(pcPtr.begin(), pcPtr.end() - 1);
+        for (int f = 0; f < m.nF; f++)
+            for (int i = m.face_ptr[f]; i < m.face_ptr[f + 1]; i++) {
+                const int p = m.face_pts[i];
+                pc[pos[p]++] = m.owner[f];
+                if (f < m.nIF) pc[pos[p]++] = m.neighbour[f];
+            }
+    }
+    threads = std::max(1, threads);
+    std::vector<std::vector<int>> lists(nP);
+#pragma omp parallel num_threads(threads)
+    {
+        std::vector<int> stamp(nC, -1), cur, nxt, all;
+#pragma omp for schedule(dynamic, 256)
+        for (int p = 0; p < nP; p++) {
+            cur.clear(); all.clear();
+            for (long long q = pcPtr[p]; q < pcPtr[p + 1]; q++) {
+                const int c = pc[q];
+                if (stamp[c] == p) continue;
+                stamp[c] = p; cur.push_back(c); all.push_back(c);
+            }
+            for (int r = 0; r < rings; r++) {
+                nxt.clear();
+                for (int c : cur)
+                    for (int q = m.cc_ptr[c]; q < m.cc_ptr[c + 1]; q++) {
+                        const int o = m.cc[q];
+                        if (stamp[o] == p) continue;
+                        stamp[o] = p; nxt.push_back(o); all.push_back(o);
+                    }
+                cur.swap(nxt);
+            }
+            std::sort(all.begin(), all.end());
+            lists[p] = all;
+        }
+    }
+    out.ptr.assign((size_t)nP + 1, 0);
+    for (int p = 0; p < nP; p++) out.ptr[p + 1] = out.ptr[p] + (long long)lists[p].size();
+    out.cells.resize(out.ptr[nP]);
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int p = 0; p < nP; p++) {
+        std::copy(lists[p].begin(), lists[p].end(), out.cells.begin() + out.ptr[p]);
+        std::vector<int>().swap(lists[p]);
+    }
+    // serial first-fit: colour(p) = smallest colour no cell of its set has seen yet
+    int W = 4;  // 64-bit words per cell bitmap, grown on demand
+    std::vector<unsigned long long> bits((size_t)nC * W, 0ull);
+    out.color.assign(nP, -1);
+    out.nColors = 0;
+    std::vector<unsigned long long> acc;
+    for (int p = 0; p < nP; p++) {
+        if (out.ptr[p + 1] == out.ptr[p]) continue;  // a point no face uses
+        acc.assign(W, 0ull);
+        for (long long q = out.ptr[p]; q < out.ptr[p + 1]; q++) {
+            const unsigned long long* b = &bits[(size_t)out.cells[q] * W];
+            for (int w = 0; w < W; w++) acc[w] |= b[w];
+        }
+        int col = -1;
+        for (int w = 0; w < W && col < 0; w++)
+            if (~acc[w]) col = 64 * w + __builtin_ctzll(~acc[w]);
+        if (col < 0) {  // all 64 W colours taken around this point: widen the bitmaps
+            const int W2 = 2 * W;
+            std::vector<unsigned long long> nb((size_t)nC * W2, 0ull);
+            for (int c = 0; c < nC; c++) std::copy(&bits[(size_t)c * W], &bits[(size_t)c * W] + W, &nb[(size_t)c * W2]);
+            bits.swap(nb);
+            col = 64 * W;
+            W = W2;
+        }
+        out.color[p] = col;
+        out.nColors = std::max(out.nColors, col + 1);
+        for (long long q = out.ptr[p]; q < out.ptr[p + 1]; q++) bits[(size_t)out.cells[q] * W + (col >> 6)] |= 1ull << (col & 63);
+    }
+    out.cptr.assign(out.nColors + 1, 0);
+    for (int p = 0; p < nP; p++) if (out.color[p] >= 0) out.cptr[out.color[p] + 1]++;
+    for (int c = 0; c < out.nColors; c++) out.cptr[c + 1] += out.cptr[c];
+    out.cpoints.resize(out.cptr[out.nColors]);
+    std::vector<int> pos(out.cptr.begin(), out.cptr.end() - 1);
+    for (int p = 0; p < nP; p++) if (out.color[p] >= 0) out.cpoints[pos[out.color[p]]++] = p;
 }
 
 }  // namespace das

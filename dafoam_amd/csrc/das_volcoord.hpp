@@ -1,0 +1,102 @@
+// Mesh-sensitivity product  product = [dOutput/dX]^T seeds  for ALL mesh points at once (3 nPoints entries), on the device.
+//
+// Reference: calcJacTVecProduct(inputType "volCoord" -> residual | function), DASolver.C:1690-1839 with DAInputVolCoord.C:
+// one reverse sweep of the CoDiPack tape from the seeded outputs back to the point coordinates.  There is no tape here.  The
+// product is assembled from coloured central differences that never leave the GPU:
+//   * the cells whose residual rows can feel point p (its influence set, build_point_influence in das_mesh.cpp) are disjoint
+//     for two points of one colour, so ONE pass moves every point of a colour by +h_p (then -h_p) along one axis;
+//   * per pass: k_move_points -> the three metric passes of das_geom.hpp as kernels (k_geom_face / cell / weights, 21 M
+//     entity updates at 2 M cells) -> the ordinary residual evaluation (or k_grad + k_fn_face for an objective);
+//   * t_i = sum over the rows of cell i of seeds_r (R+_r - R-_r)  (k_vc_rows: cell rows + the phi rows of the faces the cell
+//     owns), then one wavefront per moved point gathers  product[3 p + axis] = sum_{i in influence(p)} t_i / (2 h_p)
+//     (k_vc_gather) - fixed summation order, no atomics: the product is bit-reproducible.
+// Cost: 2 x 3 x nColours metric + residual passes (a few hundred colours on a hex mesh); accuracy: central differences with
+// a step of 1e-4 of the smallest adjacent cell thickness (truncation ~1e-8, rounding ~1e-12 relative).
+#pragma once
+#include "das_geom.hpp"
+#include "das_kernels.hpp"
+
+namespace das {
+
+__global__ __launch_bounds__(256) void k_geom_face(GeomTopo t, const double* __restrict__ P, FaceGeom* fg) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < t.nF) geom_face(f, t, P, fg[f]);
+}
+__global__ __launch_bounds__(256) void k_geom_cell(GeomTopo t, const FaceGeom* __restrict__ fg, CellGeom* cg, int* bad) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < t.nC && !geom_cell(c, t, fg, cg[c])) atomicExch(bad, 1);
+}
+__global__ __launch_bounds__(256) void k_geom_weights(GeomTopo t, const CellGeom* __restrict__ cg, FaceGeom* fg) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < t.nF) geom_weights(f, t, cg, fg, fg[f]);
+}
+// X[3 p + axis] = X0[3 p + axis] + sgn h_p for the points of one colour (sgn = 0 restores them)
+__global__ void k_move_points(int np, const int* __restrict__ pts, const double* __restrict__ h, double sgn, int axis, const double* __restrict__ X0,
+                              double* __restrict__ X) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= np) return;
+    const long long p = pts[k];
+    X[3 * p + axis] = X0[3 * p + axis] + sgn * h[p];
+}
+
+struct RowLayout {  // DAIndex "state" ordering: block b holds 3 N (vector), N (scalar) or nF (face) rows from off[b]
+    int nb;
+    long long off[8];
+    int kind[8];
+};
+// t_i = sum over the rows of cell i of seeds_r (Rp_r - Rm_r): its cell-centred rows and the face rows of the faces it owns
+__global__ __launch_bounds__(256) void k_vc_rows(DevMesh m, RowLayout L, const double* __restrict__ seeds, const double* __restrict__ Rp,
+                                                 const double* __restrict__ Rm, double* __restrict__ tc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m.nC) return;
+    double acc = 0.0;
+    for (int b = 0; b < L.nb; b++) {
+        if (L.kind[b] == KIND_VEC) {
+            for (int q = 0; q < 3; q++) { const long long r = L.off[b] + 3LL * c + q; acc += seeds[r] * (Rp[r] - Rm[r]); }
+        } else if (L.kind[b] == KIND_SCL) {
+            const long long r = L.off[b] + c;
+            acc += seeds[r] * (Rp[r] - Rm[r]);
+        } else {
+            for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
+                const int fe = m.cf_face[s];
+                if (fe < 0) continue;  // the cell is the face's neighbour: the row belongs to the owner
+                const long long r = L.off[b] + fe;
+                acc += seeds[r] * (Rp[r] - Rm[r]);
+            }
+        }
+    }
+    tc[c] = acc;
+}
+// objective outputs: per-face values of a face-integral function (the summands of k_fn_value)
+template <bool RHO>
+__global__ __launch_bounds__(256) void k_fn_face(DevMesh m, ResParams prm, const double* __restrict__ W, const double* nut, const double* gU,
+                                                 FaceFnView fn, double* __restrict__ fv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= fn.nf) return;
+    double dir[3] = {0.0, 0.0, 0.0};
+    if (fn.dir) { dir[0] = fn.dir[3 * k]; dir[1] = fn.dir[3 * k + 1]; dir[2] = fn.dir[3 * k + 2]; }
+    fv[k] = fn.w[k] * body_facefn<double, RHO>(fn.faces[k], m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
+}
+// t_i = seed x sum over the function faces of cell i of (fv+ - fv-)   (cellFn: CSR cell -> function-face slots)
+__global__ __launch_bounds__(256) void k_vc_fn_cells(int nC, const int* __restrict__ cfPtr, const int* __restrict__ cfIdx, double seed,
+                                                     const double* __restrict__ fvp, const double* __restrict__ fvm, double* __restrict__ tc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nC) return;
+    double acc = 0.0;
+    for (int q = cfPtr[c]; q < cfPtr[c + 1]; q++) acc += fvp[cfIdx[q]] - fvm[cfIdx[q]];
+    tc[c] = seed * acc;
+}
+// one wavefront per moved point: product[3 p + axis] = sum over its influence set of t_i / (2 h_p)
+__global__ __launch_bounds__(256) void k_vc_gather(int np, const int* __restrict__ pts, const long long* __restrict__ ptr, const int* __restrict__ cells,
+                                                   const double* __restrict__ tc, const double* __restrict__ h, int axis, double* __restrict__ product) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= np) return;
+    const long long p = pts[k];
+    double acc = 0.0;
+    for (long long q = ptr[p] + lane; q < ptr[p + 1]; q += 64) acc += tc[cells[q]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) product[3 * p + axis] = acc / (2.0 * h[p]);
+}
+
+}  // namespace das

@@ -390,6 +390,8 @@ class pyDASolvers:
         if inputType == "field":  # reference DAInputField.H size(): the selected cells (here: all) x 1 for a scalar field
             self._field_entry(inputName)
             return self._case.mesh.n_cells
+        if inputType == "volCoord":  # reference DAInputVolCoord.H size() = nLocalPoints * 3
+            return self.getNLocalPoints() * 3
         return check(lib().das_get_input_size(self._h, inputName.encode(), inputType.encode()))
 
     # -- boundary-value inputs (reference src/adjoint/DAInput/DAInputPatchVelocity.C, DAInputPatchVar.C) ---------
@@ -449,6 +451,9 @@ class pyDASolvers:
         assert len(inputs) == inputSize, "invalid input array size!"
         if inputType == "stateVar":
             return self.updateOFFields(np.ascontiguousarray(inputs, dtype=np.float64))
+        if inputType == "volCoord":
+            # DAInputVolCoord::run (reference DAInputVolCoord.C:46-70): the input array is the point field; mesh.movePoints
+            return self.updateOFMesh(inputs)
         if inputType == "field":
             # DAInputField::run (reference DAInputField.C:88-151): the input array IS the volScalarField (all cells; scalar fields)
             e = self._field_entry(inputName)
@@ -534,6 +539,30 @@ class pyDASolvers:
         finally:
             self.updateOFMesh(X0)
         return (vals[0] - vals[1]) / (2.0 * eps)
+
+    def pointInfluence(self):
+        """Host-side structure of the volCoord product (no GPU needed): dict(colors[nPoints], nColors, ptr, cells, steps) - the
+        cells whose residual rows can feel a point (CSR), a colouring of the points with pairwise disjoint sets, the
+        central-difference step of every point."""
+        nc, ne = C.c_int(0), C.c_longlong(0)
+        check(lib().das_point_influence_build(self._h, C.byref(nc), C.byref(ne)))
+        P = self.getNLocalPoints()
+        col = np.zeros(P, np.int32)
+        ptr = np.zeros(P + 1, np.int64)
+        cells = np.zeros(ne.value, np.int32)
+        h = np.zeros(P)
+        check(lib().das_point_influence_get(self._h, col.ctypes.data_as(_capi.c_int_p), ptr.ctypes.data_as(_capi.c_ll_p),
+                                            cells.ctypes.data_as(_capi.c_int_p), dptr(h)))
+        return dict(colors=col, nColors=nc.value, ptr=ptr, cells=cells, steps=h)
+
+    def deviceGeometry(self, points):
+        """The metrics the DEVICE passes of the volCoord product compute for `points` (test aid): (fg[nF, 12], cg[nC, 5]) in the
+        record layout of csrc/das_common.hpp (Sf, magSf, w, nod, corr, Cf | C, V, y)."""
+        m = self._case.mesh
+        fg = np.zeros(12 * m.n_faces)
+        cg = np.zeros(5 * m.n_cells)
+        check(lib().das_debug_device_geometry(self._h, dptr(np.ascontiguousarray(points, dtype=np.float64)), dptr(fg), dptr(cg)))
+        return fg.reshape(-1, 12), cg.reshape(-1, 5)
 
     def geometry(self):
         """fvMesh metrics computed by the library (host side)."""
@@ -629,6 +658,17 @@ class pyDASolvers:
         assert len(seeds) == outputSize, "invalid seed array size!"
         assert len(product) == inputSize, "invalid product array size!"
         seeds_s = np.ascontiguousarray(self._to_state(seeds)) if outputType == "residual" else seeds
+        if inputType == "volCoord":
+            # run(input) = movePoints, then the full product over all points from coloured central differences on the device
+            X0 = np.zeros(inputSize)
+            self.getOFMeshPoints(X0)
+            if not np.array_equal(X0, np.asarray(inputs, dtype=np.float64)):
+                self.updateOFMesh(inputs)
+            info = np.zeros(4)
+            check(lib().das_calc_dvolcoord_product(self._h, outputName.encode(), outputType.encode(),
+                                                   dptr(np.ascontiguousarray(seeds_s, dtype=np.float64)), dptr(product), dptr(info)))
+            self._volCoordInfo = dict(colors=int(info[0]), passes=int(info[1]), seconds=float(info[2]), build_seconds=float(info[3]))
+            return
         if inputType == "field":
             # run(input), then ONE forward-mode pass with a unit tangent on every cell (das_calc_dfield_product)
             self.setSolverInput(inputName, inputType, inputSize, inputs)

@@ -151,6 +151,21 @@ long long das_get_n_local_faces(das_solver_t* s);
  * das_get_of_mesh_points <- getOFMeshPoints  pyDASolvers.pyx:278 */
 int das_update_of_mesh(das_solver_t* s, const double* points);
 int das_get_of_mesh_points(das_solver_t* s, double* points);
+/* das_calc_dvolcoord_product <- calcJacTVecProduct(inputType "volCoord" -> outputType "residual" | "function")
+ *   pyDASolvers.pyx:333-366 -> DASolver.C:1690-1839 with DAInput/DAInputVolCoord.C:33-70: the FULL product vector
+ *   product[3 p + k] = sum_i seeds[i] dOutput_i/dX[p][k] over all mesh points, at the current states and points.  The reference
+ *   gets it from one reverse sweep of its AD tape; here coloured central differences of the point coordinates run entirely on the
+ *   device (metrics + residual re-evaluated per colour, csrc/das_volcoord.hpp).  seeds: n states (residual) or 1 (function:
+ *   force without moment arm, massFlowRate).  info4 (may be NULL) = {point colours, residual passes, seconds, build seconds}.
+ * das_point_influence_build / _get: the host-side structure behind it (no GPU needed): point colours, the cells whose residual
+ *   rows feel a point (CSR), the finite-difference step per point.
+ * das_debug_device_geometry: the metrics the device passes produce for `points` (records of 12 / 5 doubles: FaceGeom, CellGeom of
+ *   csrc/das_common.hpp), solver geometry untouched - test aid. */
+int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const char* outputType, const double* seeds, double* product /*3P*/,
+                               double* info4);
+int das_point_influence_build(das_solver_t* s, int* nColors, long long* nEntries);
+int das_point_influence_get(das_solver_t* s, int* colors /*P*/, long long* ptr /*P+1*/, int* cells /*nEntries*/, double* steps /*P*/);
+int das_debug_device_geometry(das_solver_t* s, const double* points /*3P*/, double* fg12 /*12F*/, double* cg5 /*5N*/);
 /* ---- host-side mesh geometry (fvMesh metrics; no GPU needed) - used by tests and input generators */
 int das_get_geometry(das_solver_t* s, double* Sf /*3F*/, double* Cf /*3F*/, double* C /*3N*/, double* V /*N*/,
                      double* weights /*Fi*/, double* nonOrthDeltaCoeffs /*Fi*/, double* nonOrthCorr /*3Fi*/,

@@ -908,3 +908,71 @@ def test_field_input_betaFINuTilda_kernel_bodies_vs_oracle():
     cs = residual(cc, g, case.states.astype(complex)).imag / 1e-30
     assert relerr(Rd, cs) < 1e-12
     assert np.all(Rd[: 4 * N] == 0.0) and np.all(Rd[5 * N :] == 0.0)  # only the cell's own nuTildaRes row
+
+
+def _rows_of_cells(case, cells):
+    """state-ordered rows owned by `cells`: their cell-centred rows and the phi rows of the faces they own"""
+    m = case.mesh
+    N, nF = m.n_cells, m.n_faces
+    own = np.zeros(N, bool)
+    own[cells] = True
+    mask = []
+    n = case.states.size
+    ncellblocks = (n - nF - 3 * N) // N
+    mask.append(np.repeat(own, 3))
+    for _ in range(ncellblocks):
+        mask.append(own)
+    mask.append(own[np.asarray(m.owner)[:nF]])
+    return np.concatenate(mask)
+
+
+@pytest.mark.parametrize("kind", ["simple_wf", "rho", "turbo_cyclic"])
+def test_point_influence_sets_cover_every_dependency_and_colouring_is_valid(kind):
+    """Structure behind calcJacTVecProduct(volCoord -> ...): (1) brute force - moving ONE point changes no residual row outside
+    the rows of its influence set (kernel bodies on the CPU, every point of a small mesh, all three axes); (2) two points of one
+    colour have disjoint influence sets; (3) the steps are a fixed fraction of the smallest adjacent cell thickness."""
+    import copy
+
+    if kind == "simple_wf":
+        case = channel_case(13, 11, 10, wall_function=True, bump=0.1, skew=0.05)
+        name, norm = "DASimpleFoam", NORM_STATES
+    elif kind == "rho":
+        case = rho_channel_case(11, 10, 9, wall_function=True)
+        name, norm = "DARhoSimpleFoam", NORM_STATES_RHO
+    else:  # rotational cyclic pair + MRF: influence sets run through the pair
+        case = periodic_channel_case(11, 10, 9, wall_function=True, sector=(0.5, 0.12), solver_name="DATurboFoam", mrf_omega=60.0)
+        name, norm = "DATurboFoam", NORM_STATES_RHO
+    s = pyDASolvers(f"{name} -python".encode(), options(case, normalizeStates=norm), case=case)
+    I = s.pointInfluence()
+    assert np.diff(I["ptr"]).max() < 0.25 * case.mesh.n_cells  # the sets are local: the brute-force check below discriminates
+    P, N = case.mesh.n_points, case.mesh.n_cells
+    assert I["colors"].min() >= 0 and I["nColors"] == I["colors"].max() + 1
+    # (2) per colour, every cell is claimed by at most one point
+    for c in range(I["nColors"]):
+        pts = np.nonzero(I["colors"] == c)[0]
+        cells = np.concatenate([I["cells"][I["ptr"][p]:I["ptr"][p + 1]] for p in pts])
+        assert np.unique(cells).size == cells.size, f"colour {c}: overlapping influence sets"
+    # (3)
+    g = Geometry(case.mesh)
+    assert np.all(I["steps"] > 0) and I["steps"].max() <= 1e-4 * np.cbrt(g.V.max()) * 1.0001
+    # (1)
+    W = case.states
+    R0, _ = _emu_res(case, W)
+    rng = np.random.default_rng(0)
+    pts = rng.choice(P, 50, replace=False)
+    with_two = pyDASolvers(f"{name} -python".encode(), options(case, normalizeStates=norm, amd={"volCoordRings": 2}), case=case).pointInfluence()
+    escaped = 0
+    for p in pts:
+        inside = _rows_of_cells(case, I["cells"][I["ptr"][p]:I["ptr"][p + 1]])
+        for ax in range(3):
+            c2 = copy.copy(case)
+            c2.mesh = copy.copy(case.mesh)
+            X = np.array(case.mesh.points, dtype=np.float64).reshape(-1, 3).copy()
+            X[p, ax] += 50.0 * I["steps"][p]
+            c2.mesh.points = X
+            R1, _ = _emu_res(c2, W)
+            changed = R1 != R0
+            assert not np.any(changed & ~inside), f"point {p} axis {ax}: a row outside the influence set changed"
+            assert np.any(changed), f"point {p} axis {ax}: nothing changed"
+            escaped += int(np.any(changed & ~_rows_of_cells(case, with_two["cells"][with_two["ptr"][p]:with_two["ptr"][p + 1]])))
+    assert escaped > 0  # ... and three rings are needed: two-ring sets miss rows (the pRes table reaches level 3)
