@@ -3617,9 +3617,9 @@ int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const ch
     das_solver::FaceFn* fn = nullptr;
     if (isFn) {
         fn = &get_function(s, outputName);
-        // weights / directions that depend on the metrics themselves (moment arms, area fractions) are built on the host
-        DAS_CHECK(!fn->isMoment && (fn->kind == DAS_FN_FORCE || fn->kind == DAS_FN_MASSFLOW), DAS_ERR_ARG,
-                  "volCoord product of this function type is not implemented (force and massFlowRate are; use calcVolCoordDirectionalProduct)");
+        // area-averaged functions carry the metrics in host-built weights (magSf / patch area): not differentiated here
+        DAS_CHECK(fn->kind == DAS_FN_FORCE || fn->kind == DAS_FN_MASSFLOW, DAS_ERR_ARG,
+                  "volCoord product of this function type is not implemented (force, moment and massFlowRate are; use calcVolCoordDirectionalProduct)");
     }
     ensure_point_influence(s);
     das_solver::VolCoord& v = s->vc;
@@ -3648,8 +3648,10 @@ int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const ch
             (void)hipMemcpy(s->d_cg.p, v.d_cg0.p, s->mesh.nC * sizeof(CellGeom), hipMemcpyDeviceToDevice);
             v.d_fg0.release(); v.d_cg0.release(); v.d_Rp.release(); v.d_Rm.release(); v.d_seeds.release();
             v.d_X.release(); v.d_X0.release(); v.d_tc.release(); v.d_fvp.release(); v.d_fvm.release();
+            if (fn) fn->uploaded = false;  // moment arms were recomputed from perturbed face centres: re-upload the host copy
         }
-    } restore{s};
+        das_solver::FaceFn* fn;
+    } restore{s, (fn && fn->isMoment) ? fn : nullptr};
     const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
     ResParams prm0 = make_params(s->cp, s->opt, 0);
     RowLayout L{};
@@ -3679,6 +3681,9 @@ int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const ch
             return;
         }
         const ResParams prm = s->wk.bind(s->cp.solver, s->dm.nC, s->dm.nF, prm0);
+        if (fn->isMoment)
+            hipLaunchKernelGGL(k_fn_moment_dir, dim3(nblk(nf, B)), dim3(B), 0, st, nf, (const int*)fn->d_faces.p, (const FaceGeom*)s->d_fg.p, fn->vecA[0], fn->vecA[1],
+                               fn->vecA[2], fn->vecB[0], fn->vecB[1], fn->vecB[2], fn->d_dir.p);
         if (rho) {
             hipLaunchKernelGGL((k_grad<double, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
             hipLaunchKernelGGL((k_fn_face<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);

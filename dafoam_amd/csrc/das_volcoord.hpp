@@ -77,6 +77,17 @@ __global__ __launch_bounds__(256) void k_fn_face(DevMesh m, ResParams prm, const
     if (fn.dir) { dir[0] = fn.dir[3 * k]; dir[1] = fn.dir[3 * k + 1]; dir[2] = fn.dir[3 * k + 2]; }
     fv[k] = fn.w[k] * body_facefn<double, RHO>(fn.faces[k], m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
 }
+// moment functions: (r x F) . axis = F . (axis x r), r = Cf - center - the per-face direction follows the moved face centres
+__global__ void k_fn_moment_dir(int nf, const int* __restrict__ faces, const FaceGeom* __restrict__ fg, double a0, double a1, double a2, double c0, double c1,
+                                double c2, double* __restrict__ dir) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nf) return;
+    const FaceGeom& g = fg[faces[k]];
+    const double r0 = g.Cf[0] - c0, r1 = g.Cf[1] - c1, r2 = g.Cf[2] - c2;
+    dir[3 * k] = a1 * r2 - a2 * r1;
+    dir[3 * k + 1] = a2 * r0 - a0 * r2;
+    dir[3 * k + 2] = a0 * r1 - a1 * r0;
+}
 // t_i = seed x sum over the function faces of cell i of (fv+ - fv-)   (cellFn: CSR cell -> function-face slots)
 __global__ __launch_bounds__(256) void k_vc_fn_cells(int nC, const int* __restrict__ cfPtr, const int* __restrict__ cfIdx, double seed,
                                                      const double* __restrict__ fvp, const double* __restrict__ fvm, double* __restrict__ tc) {

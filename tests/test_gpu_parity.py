@@ -903,13 +903,22 @@ def test_volcoord_full_product_vector_on_the_device():
     dirF = S.calcVolCoordDirectionalProduct(dX, "CD", "function", np.ones(1), eps=1e-6)
     # (the directional product is ONE central difference of the whole mesh with a step that is not small against the wall cells)
     assert abs(pR @ dX - dirR) <= 1e-6 * np.abs(pR * dX).sum() and abs(pF @ dX - dirF) <= 1e-7 * np.abs(pF * dX).sum()
-    # moment arms / area fractions depend on the metrics through host-built weights: rejected loudly, not silently wrong
+    # moment: the arms follow the moved face centres; area-averaged functions (weights magSf / patch area built on the host) are
+    # rejected loudly, not silently wrong
     from dafoam_amd._capi import DASError
 
     D2 = make(case, function={"CM": {"type": "moment", "source": "patchToFace", "patches": walls, "axis": [0.0, 0.0, 1.0],
-                                     "center": [0.0, 0.0, 0.0], "scale": 1.0}})
+                                     "center": [0.25, 0.05, 0.0], "scale": 1.0},
+                              "PT": {"type": "totalPressure", "source": "patchToFace", "patches": ["inlet"], "scale": 1.0}})
+    pM = np.zeros(P3)
+    D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, "CM", "function", np.ones(1), pM)
+    dirM = D2.solverAD.calcVolCoordDirectionalProduct(dX, "CM", "function", np.ones(1), eps=1e-6)
+    assert abs(pM @ dX - dirM) <= 1e-7 * np.abs(pM * dX).sum() and np.abs(pM).max() > 0
+    v0 = D2.solverAD.calcFunction("CM")
+    D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, "CM", "function", np.ones(1), pM)
+    assert D2.solverAD.calcFunction("CM") == v0  # the host copy of the moment arms is back
     with pytest.raises(DASError, match="not implemented"):
-        D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, "CM", "function", np.ones(1), np.zeros(P3))
+        D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, "PT", "function", np.ones(1), np.zeros(P3))
 
 
 @pytest.mark.parametrize("kind", ["simple", "rho", "scalar"])
