@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--nx", type=int, default=int(os.environ.get("DAS_BENCH_NX", 250)))
     ap.add_argument("--ny", type=int, default=int(os.environ.get("DAS_BENCH_NY", 100)))
     ap.add_argument("--nz", type=int, default=int(os.environ.get("DAS_BENCH_NZ", 80)))
+    ap.add_argument("--workload", default=os.environ.get("DAS_BENCH_WORKLOAD", "channel"),
+                    help="channel: nx x ny x nz bump channel (default, state prolonged from a converged coarse primal); naca: NACA0012 O-grid of "
+                         "--naca n_around n_normal nz cells extruded in span (synthetic boundary-layer state), N = 1 only")
+    ap.add_argument("--naca", type=int, nargs=3, default=[800, 250, 10])
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("DAS_BENCH_CPU_SECONDS", 15.0)))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the solve-to-tolerance phase")
@@ -136,8 +140,13 @@ def main():
         case = sharded.case
         ncell = a.nx * a.ny * a.nz
     else:
-        # state = prolongation of a converged coarse primal (dafoam_amd/data/channel_primal_coarse.npz)
-        case = bench_channel_case(a.nx, a.ny, a.nz)
+        if a.workload == "naca":
+            from dafoam_amd.meshgen import naca0012_case
+
+            case = naca0012_case(a.naca[0], a.naca[1], a.naca[2], span=0.1 * a.naca[2])
+        else:
+            # state = prolongation of a converged coarse primal (dafoam_amd/data/channel_primal_coarse.npz)
+            case = bench_channel_case(a.nx, a.ny, a.nz)
         ncell = case.mesh.n_cells
         D = PYDAFOAM(options=opts, case=case)
     t_case = time.time() - t_setup
@@ -292,8 +301,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell hex mesh per GPU ({a.nx}x{a.ny}x{a.nz} bump channel, wall-normal "
-                            f"grading; state: prolonged converged coarse primal), full GMRES adjoint, 8 states/cell, reference stencil tables; "
+                "workload": (f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell hex mesh per GPU ({a.nx}x{a.ny}x{a.nz} bump channel, wall-normal "
+                             f"grading; state: prolonged converged coarse primal)" if a.workload != "naca" else
+                             f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell NACA0012 O-grid ({a.naca[0]} around x {a.naca[1]} normal x {a.naca[2]} "
+                             f"spanwise hexahedra, first cell 2e-5 chords, far field 20 chords; synthetic boundary-layer state)")
+                            + f", full GMRES adjoint, 8 states/cell, reference stencil tables; "
                             f"timed iterations sit at Krylov basis sizes j in [{a.warmup}, {a.warmup + a.steps})",
                 "cells_per_gpu": ncell,
                 "global_cells": ncell * world,

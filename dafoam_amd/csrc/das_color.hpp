@@ -10,7 +10,9 @@
 // preconditioner sweeps (das_bilu.hpp).  Result: exactly the colours of the serial first-fit (410 instead of ~500 at
 // 200 k cells, i.e. ~20 % fewer residual passes per Jacobian), in a fraction of the host time.
 #pragma once
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 
 #include "das_common.hpp"
 
@@ -29,6 +31,7 @@ struct ColorView {
     unsigned* done;            // nNets: how many columns of a net are coloured so far
     int* colors;               // n, -1 = not coloured yet
     unsigned* ctrl;            // [0] ticket (4 groups each), [1] abort (1) / overflow: more than 64 W colours (2)
+    unsigned* host;            // pinned HOST memory seen by the device: [0] progress (tickets drawn, written now and then), [1] stop request of the watchdog
 };
 
 // The serial first-fit, column j = smallest colour not used by a lower-numbered column sharing a kept row, as a data-flow
@@ -47,7 +50,22 @@ __global__ __launch_bounds__(256) void k_color_firstfit(ColorView P) {
     const int W = P.W;
     for (;;) {
         __syncthreads();  // the previous groups are done with fbs / sh_ticket
-        if (threadIdx.x == 0) sh_ticket = atomicAdd(&P.ctrl[0], 1u);
+        if (threadIdx.x == 0) {  // (an aborted run - watchdog or a dead wave - hands out no further work)
+            unsigned t = 0xFFFFFFFFu;
+            if (__hip_atomic_load(&P.ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                t = atomicAdd(&P.ctrl[0], 1u);
+                if ((t & 1023u) == 0u) {
+                    // every 1024th ticket talks to the host: progress out, stop request in (copies on a side stream do not run
+                    // beside this persistent kernel - measured: the first one returned after 26 s)
+                    __hip_atomic_store(&P.host[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (__hip_atomic_load(&P.host[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                        __hip_atomic_store(&P.ctrl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        t = 0xFFFFFFFFu;
+                    }
+                }
+            }
+            sh_ticket = t;
+        }
         if (lane < W) fbs[wave][lane] = 0ull;
         __syncthreads();
         const long long g = (long long)sh_ticket * 4 + wave;
@@ -111,9 +129,14 @@ __global__ __launch_bounds__(256) void k_color_firstfit(ColorView P) {
     }
 }
 
-// the kernel driver shared by both front ends: device arrays in, colours out (false: more than 4096 colours or a timeout)
-inline bool color_firstfit_run(long long n, long long nNets, const std::vector<long long>& gstartHost, const long long* d_cptr, const int* d_crow,
-                               const int* d_cpos, std::vector<int>& colors, hipStream_t st) {
+// the kernel driver shared by both front ends: device arrays in, colours out.  Returns 1 on success, 0 if the kernel could not
+// be used (more than 4096 colours, a dead wave), -1 if the WATCHDOG stopped it: the data-flow first-fit is as parallel as the
+// column numbering lets it be - a wavefront sweep on a lexicographic hex numbering (3 s at 2 M cells), but a numbering whose
+// rows wrap around (an O-grid: the first cell of ring j+1 neighbours the LAST cells of ring j) serialises it completely
+// (measured: 63 s at 2 M cells).  The host watches the ticket counter through a side stream; when the projected run time
+// exceeds max(10 s, 1 us per column) it raises the abort flag and the caller switches to the order-independent algorithm.
+inline int color_firstfit_run(long long n, long long nNets, const std::vector<long long>& gstartHost, const long long* d_cptr, const int* d_crow,
+                              const int* d_cpos, std::vector<int>& colors, hipStream_t st) {
     const long long nGroups = (long long)gstartHost.size() - 1;
     DevBuf<long long> d_gstart;
     d_gstart.upload(gstartHost);
@@ -124,25 +147,55 @@ inline bool color_firstfit_run(long long n, long long nNets, const std::vector<l
     long long wgs = (long long)cus * 8;
     if (const char* e = getenv("DAS_COLOR_WGS")) wgs = std::max(1, atoi(e));
     const int grid = (int)std::min<long long>(wgs, (nGroups + 3) / 4 + 1);
+    double limit = std::max(10.0, 1.0e-6 * (double)n);
+    if (const char* e = getenv("DAS_COLOR_LIMIT")) limit = atof(e);
+    const double totalTickets = (double)((nGroups + 3) / 4);
+    struct Side {  // an event to poll and two words of pinned host memory the kernel can see
+        hipEvent_t ev = nullptr; unsigned* pin = nullptr;
+        ~Side() { if (ev) (void)hipEventDestroy(ev); if (pin) (void)hipHostFree(pin); }
+    } side;
+    DAS_HIP(hipEventCreateWithFlags(&side.ev, hipEventDisableTiming));
+    DAS_HIP(hipHostMalloc((void**)&side.pin, 4 * sizeof(unsigned), hipHostMallocMapped));
+    unsigned* d_host = nullptr;
+    DAS_HIP(hipHostGetDevicePointer((void**)&d_host, side.pin, 0));
     for (int W = 8; W <= COLOR_MAXW; W *= 2) {
         DevBuf<unsigned long long> d_F((size_t)std::max<long long>(1, nNets) * W);
         DAS_HIP(hipMemsetAsync(d_F.p, 0, d_F.n * sizeof(unsigned long long), st));
         DAS_HIP(hipMemsetAsync(d_done.p, 0, d_done.n * sizeof(unsigned), st));
         DAS_HIP(hipMemsetAsync(d_colors.p, 0xff, n * sizeof(int), st));
         DAS_HIP(hipMemsetAsync(d_ctrl.p, 0, 2 * sizeof(unsigned), st));
-        ColorView V{nGroups, d_gstart.p, d_cptr, d_crow, d_cpos, W, d_F.p, d_done.p, d_colors.p, d_ctrl.p};
+        ColorView V{nGroups, d_gstart.p, d_cptr, d_crow, d_cpos, W, d_F.p, d_done.p, d_colors.p, d_ctrl.p, d_host};
+        volatile unsigned* pin = side.pin;
+        pin[0] = 0u; pin[1] = 0u;
+        DAS_HIP(hipStreamSynchronize(st));
         hipLaunchKernelGGL(k_color_firstfit, dim3(grid), dim3(256), 0, st, V);
         DAS_HIP(hipGetLastError());
+        DAS_HIP(hipEventRecord(side.ev, st));
+        const double t0 = wall_seconds();
+        bool stopped = false;
+        while (hipEventQuery(side.ev) == hipErrorNotReady) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            const double el = wall_seconds() - t0;
+            if (el < std::min(1.0, 0.5 * limit) || stopped) continue;
+            const double projected = el * totalTickets / std::max(1.0, (double)pin[0]);
+            if (projected > limit) {
+                pin[1] = 1u;
+                stopped = true;
+                fprintf(stderr, "[dafoam_amd] data-flow first-fit colouring stopped after %.1f s (%.0f of %.0f tickets: %.0f s projected, limit %.0f s) - this column numbering "
+                                "serialises it\n", el, (double)side.pin[0], totalTickets, projected, limit);
+            }
+        }
         unsigned ctrl[2] = {0, 0};
         DAS_HIP(hipMemcpyAsync(ctrl, d_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, st));
         DAS_HIP(hipStreamSynchronize(st));
+        if (stopped) return -1;
         if (ctrl[1] == 2u) continue;  // more than 64 W colours: wider bitmaps
-        if (ctrl[1] != 0u) return false;
+        if (ctrl[1] != 0u) return 0;
         colors.resize(n);
         d_colors.download(colors.data(), n);
-        return true;
+        return 1;
     }
-    return false;
+    return 0;
 }
 // groups from start flags: maximal runs of columns with identical net lists, cut at 8 members
 inline std::vector<long long> color_groups_from_flags(long long n, const std::vector<unsigned char>& isStart) {
@@ -192,9 +245,9 @@ inline bool color_firstfit_device(long long n, const std::vector<long long>& kee
     d_crow.upload(crowK.data(), crowK.size()); d_cpos.upload(cpos.data(), cpos.size());
     lap("upload");
     (void)col;
-    const bool ok = color_firstfit_run(n, nKeep, gstart, d_cptr.p, d_crow.p, d_cpos.p, colors, st);
+    const int rc = color_firstfit_run(n, nKeep, gstart, d_cptr.p, d_crow.p, d_cpos.p, colors, st);
     lap("kernel");
-    return ok;
+    return rc == 1;
 }
 
 // =====================================================================================================================
@@ -330,37 +383,13 @@ __global__ __launch_bounds__(256) void k_spec_netbits(SpecView P) {
     for (int w = lane; w < P.W; w += 64) P.F[r * P.W + w] = bits[w];
 }
 
-// speculative colouring on the device; same inputs as color_firstfit_device.  Returns false if it could not be used.
-inline bool color_speculative_device(long long n, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
-                                     const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors, hipStream_t st,
-                                     int* roundsOut = nullptr) {
-    const long long nKeep = (long long)keep.size();
+// the rounds of the speculative colouring on device arrays: column -> nets (cptr / crow) and net -> columns (krp / kcol)
+inline bool color_speculative_run(long long n, long long nKeep, long long maxNet, const long long* d_cptr, const int* d_crow, const long long* d_krp,
+                                  const int* d_kcol, std::vector<int>& colors, hipStream_t st, int* roundsOut = nullptr) {
     const bool dbg = getenv("DAS_DEBUG_TIMING") != nullptr;
-    double tq = wall_seconds();
-    auto lap = [&](const char* what) { if (dbg) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]     speculative colouring: %s %.2f s\n", what, t2 - tq); tq = t2; } };
-    std::vector<long long> krp(nKeep + 1, 0);
-    long long maxNet = 0;
-    for (long long q = 0; q < nKeep; q++) {
-        const long long len = rowptr[keep[q] + 1] - rowptr[keep[q]];
-        krp[q + 1] = krp[q] + len;
-        maxNet = std::max(maxNet, len);
-    }
-    uvector<int> kcol(krp[nKeep]);
-#pragma omp parallel for schedule(static)
-    for (long long q = 0; q < nKeep; q++) std::copy(col.begin() + rowptr[keep[q]], col.begin() + rowptr[keep[q] + 1], kcol.begin() + krp[q]);
-    std::vector<int> posOfRow((long long)rowptr.size() - 1, -1);
-    for (long long q = 0; q < nKeep; q++) posOfRow[keep[q]] = (int)q;
-    uvector<int> crowK(crow.size());
-#pragma omp parallel for schedule(static)
-    for (long long q = 0; q < (long long)crow.size(); q++) crowK[q] = posOfRow[crow[q]];
-    lap("host preparation");
-    DevBuf<long long> d_cptr, d_krp;
-    DevBuf<int> d_crow, d_kcol, d_colors(n), d_tent(n);
+    DevBuf<int> d_colors(n), d_tent(n);
     DevBuf<unsigned char> d_lose(n);
     DevBuf<unsigned> d_ctrl(4);
-    d_cptr.upload(cptr); d_krp.upload(krp);
-    d_crow.upload(crowK.data(), crowK.size()); d_kcol.upload(kcol.data(), kcol.size());
-    lap("upload");
     // the spread of the first picks: a little above the longest net (a lower bound of the colour count)
     int S = (int)std::max<long long>(8, maxNet + maxNet / 4);
     if (const char* e = getenv("DAS_COLOR_SPREAD")) S = std::max(1, atoi(e));
@@ -370,7 +399,7 @@ inline bool color_speculative_device(long long n, const std::vector<long long>& 
         DAS_HIP(hipMemsetAsync(d_colors.p, 0xff, n * sizeof(int), st));
         DAS_HIP(hipMemsetAsync(d_tent.p, 0xff, n * sizeof(int), st));
         DAS_HIP(hipMemsetAsync(d_lose.p, 0, n, st));
-        SpecView V{n, nKeep, d_cptr.p, d_crow.p, d_krp.p, d_kcol.p, W, d_F.p, d_colors.p, d_tent.p, d_lose.p, d_ctrl.p};
+        SpecView V{n, nKeep, d_cptr, d_crow, d_krp, d_kcol, W, d_F.p, d_colors.p, d_tent.p, d_lose.p, d_ctrl.p};
         const unsigned gNet = (unsigned)((nKeep + 3) / 4);
         bool overflow = false;
         unsigned left = 1u;
@@ -400,10 +429,42 @@ inline bool color_speculative_device(long long n, const std::vector<long long>& 
         d_colors.download(colors.data(), n);
         if (roundsOut) *roundsOut = round;
         if (dbg) fprintf(stderr, "[dafoam_amd]     speculative colouring: %d rounds, spread %d, %d bitmap words per net\n", round, S, W);
-        lap("kernels");
         return true;
     }
     return false;
+}
+// speculative colouring on the device; same inputs as color_firstfit_device.  Returns false if it could not be used.
+inline bool color_speculative_device(long long n, const std::vector<long long>& keep, const std::vector<long long>& cptr, const uvector<int>& crow,
+                                     const std::vector<long long>& rowptr, const uvector<int>& col, std::vector<int>& colors, hipStream_t st,
+                                     int* roundsOut = nullptr) {
+    const long long nKeep = (long long)keep.size();
+    const bool dbg = getenv("DAS_DEBUG_TIMING") != nullptr;
+    double tq = wall_seconds();
+    auto lap = [&](const char* what) { if (dbg) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]     speculative colouring: %s %.2f s\n", what, t2 - tq); tq = t2; } };
+    std::vector<long long> krp(nKeep + 1, 0);
+    long long maxNet = 0;
+    for (long long q = 0; q < nKeep; q++) {
+        const long long len = rowptr[keep[q] + 1] - rowptr[keep[q]];
+        krp[q + 1] = krp[q] + len;
+        maxNet = std::max(maxNet, len);
+    }
+    uvector<int> kcol(krp[nKeep]);
+#pragma omp parallel for schedule(static)
+    for (long long q = 0; q < nKeep; q++) std::copy(col.begin() + rowptr[keep[q]], col.begin() + rowptr[keep[q] + 1], kcol.begin() + krp[q]);
+    std::vector<int> posOfRow((long long)rowptr.size() - 1, -1);
+    for (long long q = 0; q < nKeep; q++) posOfRow[keep[q]] = (int)q;
+    uvector<int> crowK(crow.size());
+#pragma omp parallel for schedule(static)
+    for (long long q = 0; q < (long long)crow.size(); q++) crowK[q] = posOfRow[crow[q]];
+    lap("host preparation");
+    DevBuf<long long> d_cptr, d_krp;
+    DevBuf<int> d_crow, d_kcol;
+    d_cptr.upload(cptr); d_krp.upload(krp);
+    d_crow.upload(crowK.data(), crowK.size()); d_kcol.upload(kcol.data(), kcol.size());
+    lap("upload");
+    const bool ok = color_speculative_run(n, nKeep, maxNet, d_cptr.p, d_crow.p, d_krp.p, d_kcol.p, colors, st, roundsOut);
+    lap("kernels");
+    return ok;
 }
 
 }  // namespace das

@@ -101,6 +101,7 @@ struct VmBuf {
     std::vector<size_t> sizes;
     hipMemAllocationProp prop = {};
     static constexpr size_t CHUNK = (size_t)2 << 30;
+    size_t granularity = (size_t)2 << 20;
     // chunks are mapped by a helper thread AHEAD of the iteration (request), the solver only waits if it catches up (ensure):
     // hipMemCreate can block for tens of milliseconds while freed HBM is still being scrubbed
     std::thread worker;
@@ -151,7 +152,10 @@ struct VmBuf {
             size_t gran = 0;
             if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0) {
                 const size_t align = std::max<size_t>(gran, (size_t)2 << 20);
-                const size_t total = (bytes + align - 1) / align * align;
+                granularity = align;
+                // whole 2 GB chunks only (address space is free; mapping a partial last chunk failed in hipMemSetAccess on ROCm 7.2)
+                const size_t unit = std::max(align, CHUNK / align * align);
+                const size_t total = (bytes + unit - 1) / unit * unit;
                 void* base = nullptr;
                 if (hipMemAddressReserve(&base, total, align, nullptr, 0) == hipSuccess && base) {
                     p = (T*)base; reservedBytes = total; vmm = true; n = n_;
@@ -173,18 +177,30 @@ struct VmBuf {
         for (;;) {
             cv.wait(lk, [&]() { return stopping || (mappedBytes < targetBytes && workerError.empty()); });
             if (stopping) return;
-            const size_t off = mappedBytes, sz = std::min(CHUNK, reservedBytes - off);
+            const size_t off = mappedBytes;
+            size_t sz = std::min(CHUNK, reservedBytes - off);
             lk.unlock();
             hipMemGenericAllocationHandle_t h;
             hipError_t e = hipMemCreate(&h, sz, &prop, 0);
+            // (a 2 GB physical chunk may not exist in fragmented HBM although smaller ones do)
+            while (e != hipSuccess && sz > ((size_t)128 << 20) && sz % granularity == 0) {
+                (void)hipGetLastError();
+                sz = std::max((size_t)128 << 20, sz / 4 / granularity * granularity);
+                e = hipMemCreate(&h, sz, &prop, 0);
+            }
+            const char* what = "hipMemCreate";
             bool created = e == hipSuccess;
-            if (created) e = hipMemMap((char*)p + off, sz, 0, h, 0);
-            if (e == hipSuccess) e = hipMemSetAccess((char*)p + off, sz, &acc, 1);
+            if (created) { e = hipMemMap((char*)p + off, sz, 0, h, 0); what = "hipMemMap"; }
+            if (e == hipSuccess) { e = hipMemSetAccess((char*)p + off, sz, &acc, 1); what = "hipMemSetAccess"; }
             lk.lock();
             if (e != hipSuccess) {
                 if (created) (void)hipMemRelease(h);
                 (void)hipGetLastError();
-                workerError = std::string("mapping a chunk of the Krylov basis failed: ") + hipGetErrorString(e);
+                size_t fr = 0, tot = 0;
+                (void)hipMemGetInfo(&fr, &tot);
+                workerError = std::string("mapping more of the Krylov basis failed (") + what + ": " + hipGetErrorString(e) + "; " +
+                              std::to_string(mappedBytes >> 20) + " MiB mapped, chunk " + std::to_string(sz >> 20) + " MiB, device memory free " +
+                              std::to_string(fr >> 20) + " of " + std::to_string(tot >> 20) + " MiB)";
             } else {
                 handles.push_back(h); sizes.push_back(sz);
                 mappedBytes = off + sz;
@@ -199,14 +215,18 @@ struct VmBuf {
         { std::lock_guard<std::mutex> lk(mu); if (need > targetBytes) targetBytes = need; }
         cv.notify_all();
     }
-    // wait until the first `count` elements are addressable
-    void ensure(size_t count) {
-        if (!vmm) return;
+    // wait until the first `count` elements are addressable; false: the device has no memory left for them (what is mapped stays
+    // usable - the Krylov solver closes its cycle there)
+    bool try_ensure(size_t count) {
+        if (!vmm) return count <= n;
         request(count);
         const size_t need = std::min(reservedBytes, count * sizeof(T));
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&]() { return mappedBytes >= need || !workerError.empty(); });
-        if (!workerError.empty()) throw Error(DAS_ERR_INTERNAL, workerError);
+        return mappedBytes >= need;
+    }
+    void ensure(size_t count) {
+        if (!try_ensure(count)) throw Error(DAS_ERR_INTERNAL, workerError.empty() ? std::string("Krylov basis: request beyond the reserved range") : workerError);
     }
     void alloc(size_t n_) { reserve(n_); ensure(n_); }
 };

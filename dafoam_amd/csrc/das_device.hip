@@ -1167,10 +1167,31 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
                         DAS_HIP(hipGetLastError());
                         std::vector<unsigned char> isStart = d_start.to_host();
                         const std::vector<long long> gstart = color_groups_from_flags(nn, isStart);
-                        fullRowMajor.rowptr.release(); fullRowMajor.col.release();
                         lap("nets, positions, groups");
-                        const bool ok = color_firstfit_run(nn, nKeep, gstart, d_cptr.p, d_crow.p, d_cpos.p, colors, st);
+                        const int rc = color_firstfit_run(nn, nKeep, gstart, d_cptr.p, d_crow.p, d_cpos.p, colors, st);
                         lap("first-fit kernel");
+                        bool ok = rc == 1;
+                        if (rc == -1) {
+                            // the watchdog stopped the data-flow sweep (a numbering without wavefront parallelism): the
+                            // order-independent rounds over the same bitmaps; net -> columns = the kept rows of the pattern
+                            const JacCon& jc = s->con_full;
+                            std::vector<long long> krp((size_t)nKeep + 1, 0);
+                            long long maxNet = 0;
+                            for (long long q = 0; q < nKeep; q++) {
+                                const long long len = jc.rowptr[keep[q] + 1] - jc.rowptr[keep[q]];
+                                krp[q + 1] = krp[q] + len;
+                                maxNet = std::max(maxNet, len);
+                            }
+                            DevBuf<long long> d_krp, d_keep;
+                            d_krp.upload(krp); d_keep.upload(keep);
+                            DevBuf<int> d_kcol((size_t)std::max<long long>(1, krp[nKeep]));
+                            hipLaunchKernelGGL(k_rows_gather, dim3((unsigned)((nKeep + 3) / 4)), dim3(256), 0, st, nKeep, d_keep.p, fullRowMajor.rowptr.p, fullRowMajor.col.p,
+                                               d_krp.p, d_kcol.p);
+                            DAS_HIP(hipGetLastError());
+                            ok = color_speculative_run(nn, nKeep, maxNet, d_cptr.p, d_crow.p, d_krp.p, d_kcol.p, colors, st, &s->colorRounds);
+                            lap("speculative rounds");
+                        }
+                        fullRowMajor.rowptr.release(); fullRowMajor.col.release();
                         if (!ok) fprintf(stderr, "[dafoam_amd] device colouring gave up (too many colours or a timeout): host first-fit instead\n");
                         return ok;
                     };
@@ -1975,9 +1996,10 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
 }
 // basis slots [0, nvec) are about to be written / read: map them (a no-op once mapped; milliseconds per new 2 GB chunk)
 // the helper thread of the buffer maps 64 vectors ahead of the iteration; the solver waits only if it catches up
-static inline void gmres_map_basis(das_solver* s, das_ksp* k, long long nvec) {
+// false: the device cannot hold that many vectors (gmres_advance then closes the cycle: the mapped part is the restart length)
+static inline bool gmres_map_basis(das_solver* s, das_ksp* k, long long nvec) {
     k->V.request((size_t)((nvec + 64) * s->n));
-    k->V.ensure((size_t)(nvec * s->n));
+    return k->V.try_ensure((size_t)(nvec * s->n));
 }
 
 // dev_out[0..m) = V^T w (V = m vectors of stride n starting at Vbase), dev_out[m] = w.w; summed over the ranks
@@ -2080,6 +2102,7 @@ struct GmresRun {
     bool open = false;        // inside an Arnoldi cycle
     bool fixed = false;       // no convergence exit (bench)
     int m = 0, j = 0;
+    bool memWarned = false;
     long long its = 0, maxIts = 0;
     double beta = 0, target = 0, rtol = 0, atol = 0, t0 = 0;
     const double* d_rhs = nullptr;
@@ -2147,7 +2170,7 @@ static void gmres_begin(das_solver* s, das_ksp* k, const double* d_rhs, double* 
 static void gmres_cycle_start(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
     const long long n = s->n;
-    gmres_map_basis(s, k, 3);
+    DAS_CHECK(gmres_map_basis(s, k, 3), DAS_ERR_INTERNAL, "GMRES: no device memory for three Krylov vectors (" + k->V.workerError + ")");
     hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, k->r.p, k->V.p);
     std::fill(G.g.begin(), G.g.end(), 0.0);
     G.g[0] = G.beta;
@@ -2165,7 +2188,6 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
     const long long n = s->n;
     const int B = 256, m = G.m, j = G.j;
     hipStream_t st = s->stream;
-    gmres_map_basis(s, k, j + 3);
     const bool alwaysRefine = s->opt.geti("amd.cgsAlwaysRefine") != 0;
     const bool mgs = s->opt.geti("adjEqnOption.useMGSO") != 0;
     std::vector<double>&H = G.H, &hh = G.hh, &h2 = G.h2, &cs = G.cs, &sn = G.sn, &g = G.g;
@@ -2274,7 +2296,6 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     const long long n = s->n;
     const int m = G.m, j = G.pend;
     hipStream_t st = s->stream;
-    gmres_map_basis(s, k, j + 3);
     double* u = k->V.p + (long long)j * n;
     pc_apply_full(s, k, u, k->z.p);
     apply_operator(s, k->z.p, k->w.p);
@@ -2384,6 +2405,16 @@ static bool gmres_advance(das_solver* s, das_ksp* k, long long nsteps) {
         if (gmres_over(G)) return true;
         if (G.beta == 0.0) return true;
         if (!G.open) gmres_cycle_start(s, k);
+        // the step writes basis slots up to (pending vector) + 2: map them; if the device has no memory left for them the cycle
+        // ends here - the mapped part of the basis is the restart length from now on
+        if (!gmres_map_basis(s, k, ((G.dcgs2 && !G.safeOrth) ? G.pend : G.j) + 3)) {
+            DAS_CHECK(G.j >= 1, DAS_ERR_INTERNAL, "GMRES: the Krylov basis cannot grow beyond its first vectors (" + k->V.workerError + ")");
+            if (!G.memWarned) fprintf(stderr, "[dafoam_amd] GMRES restarts after %d vectors: %s\n", G.j, k->V.workerError.c_str());
+            G.memWarned = true;
+            gmres_cycle_end(s, k);
+            t--;  // no iteration was done in this pass of the loop
+            continue;
+        }
         const double res = gmres_iter(s, k);
         const bool stop = !G.fixed && (res <= G.target || G.its >= G.maxIts);
         if (G.j < 0 || G.j >= G.m || stop) {

@@ -199,4 +199,14 @@ __global__ __launch_bounds__(256) void k_group_flags(long long n, const long lon
     isStart[j] = same ? 0 : 1;
 }
 
+// out[dst[q] ..] = the columns of row rows[q] of a CSR pattern (one wavefront per selected row)
+__global__ __launch_bounds__(256) void k_rows_gather(long long nSel, const long long* __restrict__ rows, const long long* __restrict__ rowptr,
+                                                     const int* __restrict__ col, const long long* __restrict__ dst, int* __restrict__ out) {
+    const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nSel) return;
+    const long long b = rowptr[rows[q]], len = rowptr[rows[q] + 1] - b, o = dst[q];
+    for (long long k = lane; k < len; k += 64) out[o + k] = col[b + k];
+}
+
 }  // namespace das

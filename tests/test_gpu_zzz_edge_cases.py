@@ -108,3 +108,40 @@ def test_gmres_failure_rule_and_restart():
     assert fail2 == 0 and relerr(psi2, spla.spsolve(A.tocsc(), rhs)) <= 1e-5
 
 
+
+
+def test_coloring_watchdog_switches_to_the_order_independent_algorithm_on_an_ogrid(monkeypatch, capfd):
+    """The data-flow first-fit colours as fast as the column numbering allows: on an O-grid (NACA0012 generator: the first cell
+    of ring j+1 neighbours the last cells of ring j) every ring waits for the whole ring before it - the sweep is serial (63 s
+    at 2 M cells, profiles/r03u_*).  The host watches the kernel's progress through pinned memory and, when the projected run
+    time exceeds the limit, stops it and runs the speculative rounds on the same device arrays.  Forced here with a tiny limit:
+    the colouring must be valid (the library validates it; checked again with the oracle's validator), deterministic, and
+    the Jacobian assembled with it must give the same dRdW^T.psi as the forward-mode product identity demands."""
+    from dafoam_amd.meshgen import naca0012_case
+
+    case = naca0012_case(360, 90, 1)
+    monkeypatch.setenv("DAS_COLOR_LIMIT", "0.05")
+    D = make(case)
+    D.solver.runColoring()
+    err = capfd.readouterr().err
+    assert "first-fit colouring stopped" in err, err[-2000:]
+    cs, ns = D.solver.getColoring()
+    assert cs.min() >= 0 and ns == cs.max() + 1
+    assert J.validate_coloring(D.solver.getConnectivity(0), cs.astype(np.int64))
+    D2 = make(case)
+    D2.solver.runColoring()
+    assert np.array_equal(D2.solver.getColoring()[0], cs)
+    monkeypatch.delenv("DAS_COLOR_LIMIT")
+    Df = make(case)  # without the limit: the serial first-fit finishes (a small mesh) with fewer colours
+    Df.solver.runColoring()
+    nf = Df.solver.getColoring()[1]
+    assert nf <= ns <= 1.35 * nf + 8, (ns, nf)
+    # a.(J v) == (J^T a).v with J^T assembled through the fallback colouring
+    n = case.states.size
+    rng = np.random.default_rng(1)
+    a, v = rng.standard_normal(n), rng.standard_normal(n)
+    D.solverAD.initializedRdWTMatrixFree()
+    JTa, Jv = np.zeros(n), np.zeros(n)
+    D.solverAD.calcJacTVecProduct("states", "stateVar", case.states, "residual", "residual", a, JTa)
+    D.solverAD.calcJacVecProduct(v, Jv)
+    assert abs(a @ Jv - JTa @ v) <= 1e-9 * (np.abs(a * Jv).sum() + np.abs(JTa * v).sum())
