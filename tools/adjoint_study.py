@@ -19,6 +19,8 @@ ap.add_argument("--threads", type=int, nargs="+", default=[32])
 ap.add_argument("--pctype", nargs="+", default=["bilu"])
 ap.add_argument("--krylov-gb", type=float, default=32.0)
 ap.add_argument("--case", default="channel", choices=["channel", "naca"], help="naca: --n = cells around, wall-normal, spanwise (BASELINE configs[1]: 800 250 1)")
+ap.add_argument("--span", type=float, default=0.1, help="naca: spanwise extent of the extrusion")
+ap.add_argument("--perturb", type=float, default=0.02, help="naca: amplitude of the seeded perturbation of the synthetic state")
 ap.add_argument("--coarse-agg", type=int, nargs="+", default=[-1])
 ap.add_argument("--coarse-mode", nargs="+", default=["additive"])
 ap.add_argument("--pc-iters", type=int, nargs="+", default=[1], help="adjEqnOption.localPCIters (Richardson sweeps around the factorisation)")
@@ -30,7 +32,7 @@ from dafoam_amd.meshgen import channel_case, bench_channel_case, naca0012_case
 from dafoam_amd.pyDAFoam import PYDAFOAM
 from dafoam_amd.pyDASolvers import KSP, Mat, Vec
 from dafoam_amd import _capi
-case = naca0012_case(*a.n, wall_function=a.wf) if a.case == "naca" else bench_channel_case(*a.n, wall_function=a.wf)
+case = naca0012_case(*a.n, wall_function=a.wf, span=a.span, perturb=a.perturb) if a.case == "naca" else bench_channel_case(*a.n, wall_function=a.wf)
 opts = {"solverName": "DASimpleFoam", "debug": True, "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0},
         "adjEqnOption": {"gmresRestart": a.restart, "gmresMaxIters": a.maxit, "gmresRelTol": a.rtol, "printInfo": 0}}
 D = PYDAFOAM(options=opts, case=case)
