@@ -61,29 +61,46 @@ __global__ __launch_bounds__(256) void k_pres(DevMesh m, ResParams prm, const T*
     if (c < m.nC) body_pres<T, RHO>(c, m, prm, q, R);
 }
 // face-integral objectives: value (atomic sums per group), forward-mode tangent, coloured dual-number gradient scatter
+// (deterministic: per-face / per-block values first, then ONE workgroup sums them in a fixed order - the atomicAdd versions of
+//  round 2 summed in arrival order)
 template <bool RHO>
 __global__ __launch_bounds__(256) void k_fn_value(DevMesh m, ResParams prm, const double* __restrict__ W, const double* nut, const double* gU,
-                                                  FaceFnView fn, double* out2) {
+                                                  FaceFnView fn, double* __restrict__ fv) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= fn.nf) return;
     double dir[3] = {0.0, 0.0, 0.0};
     if (fn.dir) { dir[0] = fn.dir[3 * k]; dir[1] = fn.dir[3 * k + 1]; dir[2] = fn.dir[3 * k + 2]; }
-    double v = fn.w[k] * body_facefn<double, RHO>(fn.faces[k], m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
-    atomicAdd(&out2[fn.group[k]], v);
+    fv[k] = fn.w[k] * body_facefn<double, RHO>(fn.faces[k], m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
 }
-// tangent of the objective for seeded boundary values (dF/d(BC value), one forward pass)
+// out2[g] = sum of fv[k] over the entries of group g (group == nullptr: everything is group 0); one workgroup, fixed order
+__global__ __launch_bounds__(256) void k_group_sum(long long cnt, const unsigned char* __restrict__ group, const double* __restrict__ fv, double* __restrict__ out2) {
+    __shared__ double sh[2][256];
+    double a0 = 0.0, a1 = 0.0;
+    for (long long k = threadIdx.x; k < cnt; k += 256) {
+        const double v = fv[k];
+        if (group && group[k]) a1 += v; else a0 += v;
+    }
+    sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = sh[0][0]; out2[1] = sh[1][0]; }
+}
+// tangent of the objective for seeded boundary values (dF/d(BC value), one forward pass): per-face summands
 template <bool RHO>
 __global__ __launch_bounds__(256) void k_fn_tangent(DevMesh m, ResParams prm, const Dual<1>* __restrict__ W, const Dual<1>* nut, const Dual<1>* gU,
-                                                    FaceFnView fn, double seed, double* out) {
+                                                    FaceFnView fn, double seed, double* __restrict__ fv) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= fn.nf) return;
     double dir[3] = {0.0, 0.0, 0.0};
     if (fn.dir) { dir[0] = fn.dir[3 * k]; dir[1] = fn.dir[3 * k + 1]; dir[2] = fn.dir[3 * k + 2]; }
     Dual<1> v = body_facefn<Dual<1>, RHO>(fn.faces[k], m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
-    if (v.d[0] != 0.0) atomicAdd(out, seed * fn.w[k] * v.d[0]);
+    fv[k] = seed * fn.w[k] * v.d[0];
 }
-// out += sum_i psi_i * dR_i  (dR = tangent part of a dual residual)
-__global__ __launch_bounds__(256) void k_tangent_dot(long long n, const Dual<1>* __restrict__ R, const double* __restrict__ psi, double* out) {
+// part[b] = sum over the block's rows of psi_i * dR_i  (dR = tangent part of a dual residual); k_group_sum adds the parts
+__global__ __launch_bounds__(256) void k_tangent_dot(long long n, const Dual<1>* __restrict__ R, const double* __restrict__ psi, double* __restrict__ part) {
     __shared__ double sh[256];
     double acc = 0.0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += psi[i] * R[i].d[0];
@@ -93,7 +110,7 @@ __global__ __launch_bounds__(256) void k_tangent_dot(long long n, const Dual<1>*
         if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(out, sh[0]);
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
 // the derivative of q_f w.r.t. the (unique) state of colour `col` in the stencil of face f (cell c and its face
 // neighbours: U, p, (T), nuTilda) is accumulated into dFdW
@@ -979,7 +996,7 @@ struct das_solver {
         std::vector<double> w0, dir;  // base weights (nf), directions (3 nf, force/moment only)
         DevBuf<int> d_faces;
         DevBuf<unsigned char> d_group;
-        DevBuf<double> d_w0, d_weff, d_dir;
+        DevBuf<double> d_w0, d_weff, d_dir, d_fv;  // d_fv: per-face summands of the last value / tangent pass
         bool uploaded = false;
         // definition (kept so that the geometry-dependent weights / directions can be rebuilt after updateOFMesh)
         bool isMoment = false;
@@ -3283,14 +3300,15 @@ static void function_sums(das_solver* s, das_solver::FaceFn& fn, double S[2]) {
     const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
     ResParams prm = s->wk.bind(s->cp.solver, s->dm.nC, s->dm.nF, make_params(s->cp, s->opt, 0));
     const int B = 256, nf = (int)fn.faces.size();
-    DAS_HIP(hipMemsetAsync(s->d_tmp1.p, 0, 2 * sizeof(double), s->stream));
+    if (fn.d_fv.n != (size_t)nf) fn.d_fv.alloc(nf);
     if (rho) {
         hipLaunchKernelGGL((k_grad<double, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
-        hipLaunchKernelGGL((k_fn_value<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.view(fn.d_w0.p), s->d_tmp1.p);
+        hipLaunchKernelGGL((k_fn_value<true>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.view(fn.d_w0.p), fn.d_fv.p);
     } else {
         hipLaunchKernelGGL((k_grad<double, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
-        hipLaunchKernelGGL((k_fn_value<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.view(fn.d_w0.p), s->d_tmp1.p);
+        hipLaunchKernelGGL((k_fn_value<false>), dim3(nblk(nf, B)), dim3(B), 0, s->stream, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn.view(fn.d_w0.p), fn.d_fv.p);
     }
+    hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(256), 0, s->stream, (long long)nf, (const unsigned char*)fn.d_group.p, (const double*)fn.d_fv.p, s->d_tmp1.p);
     DAS_HIP(hipGetLastError());
     DAS_HIP(hipMemcpyAsync(S, s->d_tmp1.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     DAS_HIP(hipStreamSynchronize(s->stream));
@@ -3450,20 +3468,25 @@ int das_calc_dbc_product(das_solver_t* s, const int* patches, int np, const char
     if (ot == "residual") {
         eval_residual<Dual<1>>(s->dm, s->cp, prm, s->d_Wd.p, s->d_Rd.p, s->wk1, s->d_phiF.p, s->d_Told.p, st);
         DAS_HIP(hipMemcpyAsync(s->d_tmp2.p, seeds, n * sizeof(double), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_tangent_dot, dim3(1024), dim3(256), 0, st, n, s->d_Rd.p, s->d_tmp2.p, s->d_tmp1.p);
+        DevBuf<double> part(1024);
+        hipLaunchKernelGGL(k_tangent_dot, dim3(1024), dim3(256), 0, st, n, s->d_Rd.p, s->d_tmp2.p, part.p);
+        hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(256), 0, st, 1024LL, (const unsigned char*)nullptr, (const double*)part.p, s->d_tmp1.p);
+        DAS_HIP(hipStreamSynchronize(st));  // part goes out of scope
     } else {
         das_solver::FaceFn& fn = get_function(s, outputName);
         function_effective_weights(s, fn);
         DAS_HIP(hipMemsetAsync(s->d_tmp1.p, 0, sizeof(double), st));  // function_sums used the scratch
         prm = s->wk1.bind(s->cp.solver, s->dm.nC, s->dm.nF, prm);
         const int nf = (int)fn.faces.size();
+        if (fn.d_fv.n != (size_t)nf) fn.d_fv.alloc(nf);
         if (rho) {
             hipLaunchKernelGGL((k_grad<Dual<1>, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
-            hipLaunchKernelGGL((k_fn_tangent<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seeds[0], s->d_tmp1.p);
+            hipLaunchKernelGGL((k_fn_tangent<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seeds[0], fn.d_fv.p);
         } else {
             hipLaunchKernelGGL((k_grad<Dual<1>, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
-            hipLaunchKernelGGL((k_fn_tangent<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seeds[0], s->d_tmp1.p);
+            hipLaunchKernelGGL((k_fn_tangent<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, fn.view(fn.d_weff.p), seeds[0], fn.d_fv.p);
         }
+        hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(256), 0, st, (long long)nf, (const unsigned char*)nullptr, (const double*)fn.d_fv.p, s->d_tmp1.p);
     }
     DAS_HIP(hipGetLastError());
     DAS_HIP(hipMemcpyAsync(product, s->d_tmp1.p, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -3719,10 +3742,10 @@ int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const ch
                                fn->vecA[2], fn->vecB[0], fn->vecB[1], fn->vecB[2], fn->d_dir.p);
         if (rho) {
             hipLaunchKernelGGL((k_grad<double, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
-            hipLaunchKernelGGL((k_fn_face<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
+            hipLaunchKernelGGL((k_fn_value<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
         } else {
             hipLaunchKernelGGL((k_grad<double, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
-            hipLaunchKernelGGL((k_fn_face<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
+            hipLaunchKernelGGL((k_fn_value<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
         }
     };
     const double t0 = wall_seconds();

@@ -6,7 +6,7 @@
 //   * the cells whose residual rows can feel point p (its influence set, build_point_influence in das_mesh.cpp) are disjoint
 //     for two points of one colour, so ONE pass moves every point of a colour by +h_p (then -h_p) along one axis;
 //   * per pass: k_move_points -> the three metric passes of das_geom.hpp as kernels (k_geom_face / cell / weights, 21 M
-//     entity updates at 2 M cells) -> the ordinary residual evaluation (or k_grad + k_fn_face for an objective);
+//     entity updates at 2 M cells) -> the ordinary residual evaluation (or k_grad + k_fn_value, the per-face summands, for an objective);
 //   * t_i = sum over the rows of cell i of seeds_r (R+_r - R-_r)  (k_vc_rows: cell rows + the phi rows of the faces the cell
 //     owns), then one wavefront per moved point gathers  product[3 p + axis] = sum_{i in influence(p)} t_i / (2 h_p)
 //     (k_vc_gather) - fixed summation order, no atomics: the product is bit-reproducible.
@@ -66,16 +66,6 @@ __global__ __launch_bounds__(256) void k_vc_rows(DevMesh m, RowLayout L, const d
         }
     }
     tc[c] = acc;
-}
-// objective outputs: per-face values of a face-integral function (the summands of k_fn_value)
-template <bool RHO>
-__global__ __launch_bounds__(256) void k_fn_face(DevMesh m, ResParams prm, const double* __restrict__ W, const double* nut, const double* gU,
-                                                 FaceFnView fn, double* __restrict__ fv) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= fn.nf) return;
-    double dir[3] = {0.0, 0.0, 0.0};
-    if (fn.dir) { dir[0] = fn.dir[3 * k]; dir[1] = fn.dir[3 * k + 1]; dir[2] = fn.dir[3 * k + 2]; }
-    fv[k] = fn.w[k] * body_facefn<double, RHO>(fn.faces[k], m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
 }
 // moment functions: (r x F) . axis = F . (axis x r), r = Cf - center - the per-face direction follows the moved face centres
 __global__ void k_fn_moment_dir(int nf, const int* __restrict__ faces, const FaceGeom* __restrict__ fg, double a0, double a1, double a2, double c0, double c1,
