@@ -1107,18 +1107,17 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
     s->st_pc = make_stencil(s->cp.solver, s->mesh.nC, s->mesh.nF, s->opt, true, s->cp.hasT != 0);
     double t1 = wall_seconds();
     s->con_full.build(s->mesh, s->st_full);
+    s->con_pc.build(s->mesh, s->st_pc);
     double t2 = wall_seconds();
-    // what needs no colours is built by a second host thread while this one prepares and runs the colouring (whose 3 s
-    // data-flow kernel at 2 M cells leaves the host idle): the preconditioner's pattern, and - without a device - the
-    // transposed structures (with a device those are generated there, das_graph.hpp)
+    // without a device the transposed structures (no colours needed) are built by a second host thread beside the colouring; with
+    // a device they are generated there (das_graph.hpp).  (Measured and dropped: building the preconditioner's pattern in that
+    // thread beside the device colouring - the prune and the upload of the operator pattern slowed down by as much as was
+    // gained, 8.98 -> 9.80 s: the host phases are memory-bound, profiles/r03y_setup_phases_2M.log.)
     const bool devGraph = graph_on_device(s);
     std::exception_ptr tErr;
     std::thread transposer([&]() {
-        try {
-            s->con_pc.build(s->mesh, s->st_pc);
-            if (devGraph) return;
-            s->con_full.build_transpose(); s->con_pc.build_transpose();
-        } catch (...) { tErr = std::current_exception(); }
+        if (devGraph) return;
+        try { s->con_full.build_transpose(); s->con_pc.build_transpose(); } catch (...) { tErr = std::current_exception(); }
     });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{transposer};
     for (int k = 0; k < 2; k++) { s->cd[k].ready = false; s->cd[k].onDevice = false; }
@@ -1228,7 +1227,7 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
         device_build_con(s, 1);
     }
     if (s->opt.geti("debug"))
-        fprintf(stderr, "[dafoam_amd] runColoring: operator pattern %.2f s, colouring (beside the PC pattern) %.2f s, validate %.2f s, wait for the second thread + colour lists %.2f s\n",
+        fprintf(stderr, "[dafoam_amd] runColoring: patterns %.2f s, colouring %.2f s, validate %.2f s, wait for the second thread + colour lists %.2f s\n",
                 t2 - t1, t3 - t2, t4 - t3, wall_seconds() - t4);
     s->colored = true;
     if (s->opt.geti("debug"))
