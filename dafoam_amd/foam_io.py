@@ -273,8 +273,166 @@ def _bc_entry(e, vec):
     return (code, tuple(np.atleast_1d(v)) if vec else float(v))
 
 
-def read_case(case_dir, solver_name="DASimpleFoam", time="0", y_wall=None) -> FoamCase:
-    """DASimpleFoam / DARhoSimpleFoam case directory -> FoamCase (phi = interp(U).Sf if 0/phi is absent)."""
+# ---- system/fvSchemes, system/fvSolution ------------------------------------------------------------------------------------
+# The reference takes its discretisation from the case (DAResidualSimpleFoam.C:123-132 builds fvm::div(phi, U) etc. through the
+# run-time selected schemes, DASpalartAllmaras.C:428-447 likewise; relaxation through fvSolution).  The HIP kernels implement ONE
+# scheme set (DESIGN.md section 3 - the set of the reference's own regression cases); the reader below makes that explicit: the
+# relaxation factors and the SIMPLE switches of the case are honoured, every scheme entry is compared with the implemented set
+# and a case that asks for anything else is rejected with the list of offending entries instead of being run with other numerics.
+IMPLEMENTED_SCHEMES = {
+    "ddtSchemes": {"default": ["steadyState"]},
+    "gradSchemes": {"default": ["Gauss linear"], "grad(U)": ["Gauss linear"], "grad(p)": ["Gauss linear"], "grad(nuTilda)": ["Gauss linear"]},
+    "divSchemes": {
+        "default": ["none"],
+        "div(phi,U)": ["bounded Gauss linearUpwindV grad(U)"],
+        "div(phi,nuTilda)": ["bounded Gauss upwind"],
+        "div(pc)": ["bounded Gauss upwind"],
+        "div((nuEff*dev2(T(grad(U)))))": ["Gauss linear"],
+        # compressible solvers
+        "div(phi,T)": ["bounded Gauss upwind"], "div(phi,h)": ["bounded Gauss upwind"], "div(phi,e)": ["bounded Gauss upwind"],
+        "div(phi,K)": ["bounded Gauss upwind"], "div(phi,Ekp)": ["bounded Gauss upwind"], "div(phid,p)": ["Gauss upwind", "bounded Gauss upwind"],
+        "div(((rho*nuEff)*dev2(T(grad(U)))))": ["Gauss linear"],
+    },
+    "laplacianSchemes": {"default": ["Gauss linear corrected"]},
+    "interpolationSchemes": {"default": ["linear"]},
+    "snGradSchemes": {"default": ["corrected"]},
+}
+
+
+def _dict_block(text, name):
+    """body of `name { ... }` at any depth of an (already comment-stripped) OpenFOAM dictionary, or None"""
+    m = re.search(r"(?<![\w.:-])" + re.escape(name) + r"\s*\{", text)
+    if not m:
+        return None
+    depth, i = 1, m.end()
+    while depth and i < len(text):
+        depth += text[i] == "{"
+        depth -= text[i] == "}"
+        i += 1
+    return text[m.end() : i - 1]
+
+
+def _flat_entries(body):
+    """`key value...;` entries of a dictionary body (sub-dictionaries skipped); keys may be quoted regular expressions"""
+    out, i = {}, 0
+    body = re.sub(r"\{[^{}]*\}", "", body)  # (one level of nesting is all these dictionaries have)
+    for m in re.finditer(r'("[^"]+"|[^\s;{}]+)\s+([^;{}]*);', body):
+        out[m.group(1).strip('"')] = " ".join(m.group(2).split())
+    return out
+
+
+def read_fv_schemes(case_dir):
+    """system/fvSchemes -> {section: {entry: scheme string}} (None if the file does not exist)"""
+    path = os.path.join(case_dir, "system", "fvSchemes")
+    if not os.path.exists(path):
+        return None
+    text = _strip(open(path).read())
+    out = {}
+    for sec in ("ddtSchemes", "gradSchemes", "divSchemes", "laplacianSchemes", "interpolationSchemes", "snGradSchemes", "wallDist"):
+        b = _dict_block(text, sec)
+        if b is not None:
+            out[sec] = _flat_entries(b)
+    return out
+
+
+def check_schemes(schemes):
+    """Entries of a parsed fvSchemes that differ from the scheme set the kernels implement: list of "section/entry: value"."""
+    bad = []
+    for sec, allowed in IMPLEMENTED_SCHEMES.items():
+        for key, val in (schemes.get(sec) or {}).items():
+            ok = allowed.get(key, allowed.get("default") if key != "default" else None)
+            if ok is None or val not in ok:
+                bad.append(f"{sec}/{key}: {val}")
+    wd = (schemes.get("wallDist") or {}).get("method")
+    if wd is not None and wd not in ("meshWaveFrozen", "meshWave"):
+        bad.append(f"wallDist/method: {wd}")
+    return bad
+
+
+def read_fv_solution(case_dir):
+    """system/fvSolution -> dict(relax={field: factor}, consistent, transonic, nNonOrthogonalCorrectors) (None without the file).
+    relaxationFactors/equations (and fields) entries may be quoted regular expressions like "(U|T|nuTilda)"."""
+    path = os.path.join(case_dir, "system", "fvSolution")
+    if not os.path.exists(path):
+        return None
+    text = _strip(open(path).read())
+    out = {"relax": {}, "relax_fields": {}, "consistent": False, "transonic": False, "nNonOrthogonalCorrectors": 0}
+    simple = _dict_block(text, "SIMPLE")
+    if simple is not None:
+        e = _flat_entries(simple)
+        truth = lambda v: str(v).lower() in ("true", "yes", "on", "1")  # noqa: E731
+        out["consistent"] = truth(e.get("consistent", "false"))
+        out["transonic"] = truth(e.get("transonic", "false"))
+        out["nNonOrthogonalCorrectors"] = int(e.get("nNonOrthogonalCorrectors", 0))
+    rf = _dict_block(text, "relaxationFactors")
+    if rf is not None:
+        for sub, dst in (("equations", "relax"), ("fields", "relax_fields")):
+            b = _dict_block(rf, sub)
+            if b is None:
+                continue
+            for key, val in _flat_entries(b).items():
+                for name in ("U", "nuTilda", "T", "h", "e", "p", "rho"):
+                    if re.fullmatch(key, name) or (key.endswith(".*") and re.fullmatch(key, name)):
+                        out[dst].setdefault(name, float(val))
+    return out
+
+
+def apply_system_dicts(case: FoamCase, case_dir, strict=True):
+    """Honour system/fvSolution (equation relaxation factors, SIMPLE consistent / transonic) and verify system/fvSchemes against
+    the implemented scheme set.  strict: a case that asks for other schemes - or for field relaxation of p, which changes the
+    fixed point of the residual this library evaluates - raises NotImplementedError naming the entries."""
+    sch = read_fv_schemes(case_dir)
+    if sch is not None:
+        bad = check_schemes(sch)
+        if bad and strict:
+            raise NotImplementedError("system/fvSchemes asks for schemes the GPU kernels do not implement (DESIGN.md section 3): " + "; ".join(bad))
+        case.scheme_mismatches = bad
+    sol = read_fv_solution(case_dir)
+    if sol is not None:
+        relax = dict(case.relax)
+        for k in ("U", "nuTilda"):
+            if k in sol["relax"]:
+                relax[k] = sol["relax"][k]
+        for k in ("T", "h", "e"):
+            if k in sol["relax"]:
+                relax["T"] = sol["relax"][k]
+        case.relax = relax
+        case.simple_consistent = bool(sol["consistent"])
+        case.transonic = bool(sol["transonic"])
+    return case
+
+
+def write_system_dicts(case_dir, case: FoamCase):
+    """system/fvSchemes + system/fvSolution of the scheme set the kernels implement, with the case's relaxation factors."""
+    os.makedirs(os.path.join(case_dir, "system"), exist_ok=True)
+    comp = case.solver_name != "DASimpleFoam"
+    with open(os.path.join(case_dir, "system", "fvSchemes"), "w") as f:
+        f.write(_HEADER.format(cls="dictionary", loc="system", obj="fvSchemes"))
+        f.write("ddtSchemes { default steadyState; }\ngradSchemes { default Gauss linear; }\ndivSchemes\n{\n    default none;\n")
+        f.write("    div(phi,U) bounded Gauss linearUpwindV grad(U);\n    div(phi,nuTilda) bounded Gauss upwind;\n    div(pc) bounded Gauss upwind;\n")
+        if comp:
+            f.write("    div(phi,T) bounded Gauss upwind;\n    div(phi,h) bounded Gauss upwind;\n    div(phi,K) bounded Gauss upwind;\n"
+                    "    div(phid,p) Gauss upwind;\n    div(((rho*nuEff)*dev2(T(grad(U))))) Gauss linear;\n")
+        else:
+            f.write("    div((nuEff*dev2(T(grad(U))))) Gauss linear;\n")
+        f.write("}\nlaplacianSchemes { default Gauss linear corrected; }\ninterpolationSchemes { default linear; }\nsnGradSchemes { default corrected; }\n"
+                "wallDist { method meshWaveFrozen; }\n")
+    with open(os.path.join(case_dir, "system", "fvSolution"), "w") as f:
+        f.write(_HEADER.format(cls="dictionary", loc="system", obj="fvSolution"))
+        f.write("SIMPLE\n{\n    nNonOrthogonalCorrectors 0;\n")
+        f.write(f"    consistent {'true' if getattr(case, 'simple_consistent', False) else 'false'};\n")
+        f.write(f"    transonic {'true' if getattr(case, 'transonic', False) else 'false'};\n}}\n")
+        f.write("relaxationFactors\n{\n    equations\n    {\n")
+        f.write(f"        U {case.relax.get('U', 0.7):.17g};\n        nuTilda {case.relax.get('nuTilda', 0.7):.17g};\n")
+        if comp or getattr(case, "has_T", False):
+            f.write(f"        \"(T|h|e)\" {case.relax.get('T', 1.0):.17g};\n")
+        f.write("    }\n}\n")
+
+
+def read_case(case_dir, solver_name="DASimpleFoam", time="0", y_wall=None, strict_schemes=True) -> FoamCase:
+    """DASimpleFoam / DARhoSimpleFoam case directory -> FoamCase (phi = interp(U).Sf if 0/phi is absent).  system/fvSolution
+    (relaxation factors, SIMPLE switches) is honoured and system/fvSchemes is verified against the implemented scheme set when
+    the files exist (apply_system_dicts)."""
     from .meshgen import _InputGeometry, wall_distance_exact as wall_distance
 
     mesh = read_polymesh(case_dir)
@@ -346,7 +504,7 @@ def read_case(case_dir, solver_name="DASimpleFoam", time="0", y_wall=None) -> Fo
                     if cnt == pt.size:
                         phi[sl] = np.array(body.split(), dtype=np.float64)
     case.states = np.concatenate([U.ravel(), p, nuT, phi])
-    return case
+    return apply_system_dicts(case, case_dir, strict=strict_schemes)
 
 
 def write_case(case_dir, case: FoamCase, time="0"):
@@ -399,6 +557,7 @@ def write_case(case_dir, case: FoamCase, time="0"):
     with open(os.path.join(case_dir, "constant", "transportProperties"), "w") as f:
         f.write(_HEADER.format(cls="dictionary", loc="constant", obj="transportProperties"))
         f.write(f"transportModel  Newtonian;\n\nnu              [0 2 -1 0 0 0 0] {case.nu:.17g};\n")
+    write_system_dicts(case_dir, case)
     nIF = mesh.n_internal_faces
     with open(os.path.join(tdir, "phi"), "w") as f:
         f.write(_HEADER.format(cls="surfaceScalarField", loc=time, obj="phi"))

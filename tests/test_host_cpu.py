@@ -976,3 +976,44 @@ def test_point_influence_sets_cover_every_dependency_and_colouring_is_valid(kind
             assert np.any(changed), f"point {p} axis {ax}: nothing changed"
             escaped += int(np.any(changed & ~_rows_of_cells(case, with_two["cells"][with_two["ptr"][p]:with_two["ptr"][p + 1]])))
     assert escaped > 0  # ... and three rings are needed: two-ring sets miss rows (the pRes table reaches level 3)
+
+
+def test_case_discretisation_is_read_and_verified(tmp_path):
+    """system/fvSolution is honoured (equation relaxation factors incl. quoted regular-expression keys, SIMPLE consistent /
+    transonic), system/fvSchemes is verified against the ONE scheme set the kernels implement (the reference
+    builds its operators through the run-time selected schemes of the case, DAResidualSimpleFoam.C:123-132): a case asking
+    for anything else is rejected with the offending entries, not run with other numerics."""
+    from dafoam_amd import foam_io
+
+    case = channel_case(4, 3, 3, wall_function=True)
+    case.relax = {"U": 0.8, "nuTilda": 0.6, "T": 1.0}
+    case.simple_consistent = True
+    d = str(tmp_path)
+    foam_io.write_case(d, case)
+    sch = foam_io.read_fv_schemes(d)
+    assert sch["divSchemes"]["div(phi,U)"] == "bounded Gauss linearUpwindV grad(U)" and foam_io.check_schemes(sch) == []
+    back = foam_io.read_case(d, y_wall=case.y_wall)
+    assert back.relax["U"] == 0.8 and back.relax["nuTilda"] == 0.6 and back.simple_consistent and not back.transonic
+    # the relaxation factor reaches the residual: the kernel bodies on the re-read case equal the oracle with the same factors
+    g = Geometry(back.mesh)
+    Rv, _ = _emu_res(back, back.states)
+    assert relerr(Rv, residual(back, g, back.states)) < 1e-12
+    c07 = channel_case(4, 3, 3, wall_function=True)
+    assert relerr(_emu_res(c07, c07.states)[0], Rv) > 1e-3
+    # a tutorial-style fvSolution: regular-expression keys, field relaxation of p present but not used by the residual
+    with open(os.path.join(d, "system", "fvSolution"), "w") as f:
+        f.write('FoamFile { version 2.0; format ascii; class dictionary; object fvSolution; }\n'
+                'solvers { "(p|p_rgh)" { solver GAMG; tolerance 1e-8; } }\n'
+                'SIMPLE { nNonOrthogonalCorrectors 0; consistent no; transonic yes; }\n'
+                'relaxationFactors { fields { p 0.3; } equations { "(U|T|nuTilda)" 0.75; } } // comment\n')
+    sol = foam_io.read_fv_solution(d)
+    assert sol["relax"] == {"U": 0.75, "nuTilda": 0.75, "T": 0.75} and sol["relax_fields"] == {"p": 0.3} and sol["transonic"] and not sol["consistent"]
+    # other schemes: rejected, with names
+    text = open(os.path.join(d, "system", "fvSchemes")).read()
+    with open(os.path.join(d, "system", "fvSchemes"), "w") as f:
+        f.write(text.replace("div(phi,nuTilda) bounded Gauss upwind", "div(phi,nuTilda) bounded Gauss linearUpwind grad(nuTilda)")
+                .replace("default Gauss linear corrected", "default Gauss linear limited 0.33"))
+    with pytest.raises(NotImplementedError, match=r"divSchemes/div\(phi,nuTilda\).*laplacianSchemes/default"):
+        foam_io.read_case(d, y_wall=case.y_wall)
+    lax = foam_io.read_case(d, y_wall=case.y_wall, strict_schemes=False)
+    assert len(lax.scheme_mismatches) == 2
