@@ -3670,11 +3670,22 @@ int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const ch
     const Mesh& m = s->mesh;
     const bool isFn = ot == "function";
     das_solver::FaceFn* fn = nullptr;
-    if (isFn) {
-        fn = &get_function(s, outputName);
-        // area-averaged functions carry the metrics in host-built weights (magSf / patch area): not differentiated here
-        DAS_CHECK(fn->kind == DAS_FN_FORCE || fn->kind == DAS_FN_MASSFLOW, DAS_ERR_ARG,
-                  "volCoord product of this function type is not implemented (force, moment and massFlowRate are; use calcVolCoordDirectionalProduct)");
+    if (isFn) fn = &get_function(s, outputName);
+    // area-averaged functions: coefficients of the linearised functional (k_fn_area_avg) from the group sums at the base mesh
+    double cN[2] = {0.0, 0.0}, cA[2] = {0.0, 0.0};
+    const bool areaAvg = isFn && (fn->kind == DAS_FN_TOTALPRESSURE || fn->kind == DAS_FN_TOTALTEMPERATURE);
+    if (areaAvg) {
+        double S[2], A[2] = {0.0, 0.0};
+        function_sums(s, *fn, S);  // S_g = sum of w0 q: totalPressure scale N0 / A0 (one group), ratio functions N_g / A_g
+        for (size_t q = 0; q < fn->faces.size(); q++) A[fn->group[q]] += m.fg[fn->faces[q]].magSf;
+        if (!fn->ratio) {
+            cN[0] = fn->scale / A[0];
+            cA[0] = -S[0] / A[0];
+        } else {
+            const double F = S[1] / S[0];  // F = (N1 / A1) / (N0 / A0)
+            cN[1] = F / (S[1] * A[1]); cA[1] = -F / A[1];
+            cN[0] = -F / (S[0] * A[0]); cA[0] = F / A[0];
+        }
     }
     ensure_point_influence(s);
     das_solver::VolCoord& v = s->vc;
@@ -3741,10 +3752,12 @@ int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const ch
                                fn->vecA[2], fn->vecB[0], fn->vecB[1], fn->vecB[2], fn->d_dir.p);
         if (rho) {
             hipLaunchKernelGGL((k_grad<double, true>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
-            hipLaunchKernelGGL((k_fn_value<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
+            if (areaAvg) hipLaunchKernelGGL((k_fn_area_avg<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), cN[0], cN[1], cA[0], cA[1], fvOut);
+            else hipLaunchKernelGGL((k_fn_value<true>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
         } else {
             hipLaunchKernelGGL((k_grad<double, false>), dim3(nblk(s->dm.nC, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, s->wk.gP.p, s->wk.gN.p, s->wk.gH.p);
-            hipLaunchKernelGGL((k_fn_value<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
+            if (areaAvg) hipLaunchKernelGGL((k_fn_area_avg<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), cN[0], cN[1], cA[0], cA[1], fvOut);
+            else hipLaunchKernelGGL((k_fn_value<false>), dim3(nblk(nf, B)), dim3(B), 0, st, s->dm, prm, s->d_W.p, s->wk.nut.p, s->wk.gU.p, fn->view(fn->d_w0.p), fvOut);
         }
     };
     const double t0 = wall_seconds();

@@ -78,6 +78,21 @@ __global__ void k_fn_moment_dir(int nf, const int* __restrict__ faces, const Fac
     dir[3 * k + 1] = a2 * r0 - a0 * r2;
     dir[3 * k + 2] = a0 * r1 - a1 * r0;
 }
+// area-averaged functions (totalPressure: F = scale N / A; totalTemperatureRatio: F = (N1 / A1) / (N0 / A0) with N_g = sum |Sf| q,
+// A_g = sum |Sf| over the faces of group g): the host-built weights |Sf| / A carry the metrics, so the product differentiates the
+// LINEARISED functional  fv_k = cN[g] |Sf_k| q_k + cA[g] |Sf_k|  (cN = dF/dN_g, cA = dF/dA_g at the unperturbed mesh) on the
+// perturbed metrics instead
+template <bool RHO>
+__global__ __launch_bounds__(256) void k_fn_area_avg(DevMesh m, ResParams prm, const double* __restrict__ W, const double* nut, const double* gU,
+                                                     FaceFnView fn, double cN0, double cN1, double cA0, double cA1, double* __restrict__ fv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= fn.nf) return;
+    double dir[3] = {0.0, 0.0, 0.0};
+    const int f = fn.faces[k];
+    const double q = body_facefn<double, RHO>(f, m, prm, W, nut, gU, fn.kind, dir, fn.gammaFn, fn.RFn);
+    const double a = m.fg[f].magSf;
+    fv[k] = fn.group[k] ? (cN1 * q + cA1) * a : (cN0 * q + cA0) * a;
+}
 // t_i = seed x sum over the function faces of cell i of (fv+ - fv-)   (cellFn: CSR cell -> function-face slots)
 __global__ __launch_bounds__(256) void k_vc_fn_cells(int nC, const int* __restrict__ cfPtr, const int* __restrict__ cfIdx, double seed,
                                                      const double* __restrict__ fvp, const double* __restrict__ fvm, double* __restrict__ tc) {

@@ -156,7 +156,7 @@ int das_get_of_mesh_points(das_solver_t* s, double* points);
  *   product[3 p + k] = sum_i seeds[i] dOutput_i/dX[p][k] over all mesh points, at the current states and points.  The reference
  *   gets it from one reverse sweep of its AD tape; here coloured central differences of the point coordinates run entirely on the
  *   device (metrics + residual re-evaluated per colour, csrc/das_volcoord.hpp).  seeds: n states (residual) or 1 (function:
- *   force, moment, massFlowRate).  info4 (may be NULL) = {point colours, residual passes, seconds, build seconds}.
+ *   any defined face function).  info4 (may be NULL) = {point colours, residual passes, seconds, build seconds}.
  * das_point_influence_build / _get: the host-side structure behind it (no GPU needed): point colours, the cells whose residual
  *   rows feel a point (CSR), the finite-difference step per point.
  * das_debug_device_geometry: the metrics the device passes produce for `points` (records of 12 / 5 doubles: FaceGeom, CellGeom of

@@ -903,22 +903,42 @@ def test_volcoord_full_product_vector_on_the_device():
     dirF = S.calcVolCoordDirectionalProduct(dX, "CD", "function", np.ones(1), eps=1e-6)
     # (the directional product is ONE central difference of the whole mesh with a step that is not small against the wall cells)
     assert abs(pR @ dX - dirR) <= 1e-6 * np.abs(pR * dX).sum() and abs(pF @ dX - dirF) <= 1e-7 * np.abs(pF * dX).sum()
-    # moment: the arms follow the moved face centres; area-averaged functions (weights magSf / patch area built on the host) are
-    # rejected loudly, not silently wrong
-    from dafoam_amd._capi import DASError
-
+    # moment: the arms follow the moved face centres; totalPressure: the area average is differentiated through its linearisation
     D2 = make(case, function={"CM": {"type": "moment", "source": "patchToFace", "patches": walls, "axis": [0.0, 0.0, 1.0],
                                      "center": [0.25, 0.05, 0.0], "scale": 1.0},
                               "PT": {"type": "totalPressure", "source": "patchToFace", "patches": ["inlet"], "scale": 1.0}})
-    pM = np.zeros(P3)
-    D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, "CM", "function", np.ones(1), pM)
-    dirM = D2.solverAD.calcVolCoordDirectionalProduct(dX, "CM", "function", np.ones(1), eps=1e-6)
-    assert abs(pM @ dX - dirM) <= 1e-7 * np.abs(pM * dX).sum() and np.abs(pM).max() > 0
+    for nm in ("CM", "PT"):
+        pM = np.zeros(P3)
+        D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, nm, "function", np.ones(1), pM)
+        dirM = D2.solverAD.calcVolCoordDirectionalProduct(dX, nm, "function", np.ones(1), eps=1e-6)
+        assert abs(pM @ dX - dirM) <= 1e-7 * np.abs(pM * dX).sum() and np.abs(pM).max() > 0, nm
     v0 = D2.solverAD.calcFunction("CM")
     D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, "CM", "function", np.ones(1), pM)
-    assert D2.solverAD.calcFunction("CM") == v0  # the host copy of the moment arms is back
-    with pytest.raises(DASError, match="not implemented"):
-        D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, "PT", "function", np.ones(1), np.zeros(P3))
+    assert D2.solverAD.calcFunction("CM") == v0  # the host copy of the moment arms is back (and the sums are deterministic)
+
+
+def test_volcoord_product_compressible_and_ratio_objective():
+    """The volCoord product for DARhoSimpleFoam: residual seeds and the totalTemperatureRatio objective (a quotient of two area
+    averages: differentiated through its linearisation at the base mesh) against the directional product - one central
+    difference of the whole mesh through the HOST metrics."""
+    case = rho_channel_case(9, 7, 6, wall_function=True)
+    D = make(case, normalizeStates=norm_states(case),
+             function={"TTR": {"type": "totalTemperatureRatio", "source": "patchToFace", "patches": ["inlet", "outlet"], "inletPatches": ["inlet"],
+                               "outletPatches": ["outlet"], "scale": 1.0},
+                       "MFR": {"type": "massFlowRate", "source": "patchToFace", "patches": ["outlet"], "scale": 1.0}})
+    S = D.solverAD
+    n, P3 = case.states.size, 3 * case.mesh.n_points
+    X0 = case.mesh.points.ravel().copy()
+    Xr = case.mesh.points
+    # a displacement field that also deforms the inlet and outlet planes (the objectives live there)
+    dX = np.stack([0.05 * np.sin(3 * Xr[:, 1] / 0.2) * Xr[:, 0], 0.03 * Xr[:, 1] * (1 + Xr[:, 0]), 0.02 * Xr[:, 2] * (1 + 0.5 * Xr[:, 0]) * (1 + Xr[:, 1])], axis=1).ravel()
+    seeds = np.random.default_rng(5).standard_normal(n)
+    for nm, ot, sd in (("residual", "residual", seeds), ("TTR", "function", np.ones(1)), ("MFR", "function", np.ones(1))):
+        p = np.zeros(P3)
+        S.calcJacTVecProduct("x", "volCoord", X0, nm, ot, sd, p)
+        ref = S.calcVolCoordDirectionalProduct(dX, nm, ot, sd, eps=1e-6)
+        assert np.abs(p).max() > 0 and abs(ref) > 1e-3 * np.abs(p * dX).sum(), nm  # a real sensitivity, not two zeros
+        assert abs(p @ dX - ref) <= 1e-6 * np.abs(p * dX).sum(), (nm, p @ dX, ref)
 
 
 @pytest.mark.parametrize("kind", ["simple", "rho", "scalar"])
