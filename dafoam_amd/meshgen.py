@@ -253,14 +253,26 @@ class _InputGeometry:
         nv = np.diff(mesh.face_ptr)
         assert np.all(nv == nv[0]), "input generator handles uniform polygons"
         k = int(nv[0])
-        P = mesh.points[mesh.face_pts.reshape(F, k)]  # (F,k,3)
-        fc = P.mean(axis=1)
-        Pn = np.roll(P, -1, axis=1)
-        n = np.cross(Pn - P, fc[:, None, :] - P)  # (F,k,3)
-        a = np.linalg.norm(n, axis=2)
-        c = P + Pn + fc[:, None, :]
-        self.Sf = 0.5 * n.sum(axis=1)
-        self.Cf = (a[:, :, None] * c).sum(axis=1) / (3.0 * a.sum(axis=1)[:, None])
+        # (component-wise over the k triangles of the fan: np.cross / np.roll on (F, k, 3) temporaries cost 4x as much at 6 M faces)
+        fp = mesh.face_pts.reshape(F, k)
+        X = [np.ascontiguousarray(mesh.points[:, d]) for d in range(3)]
+        Pk = [[X[d][fp[:, i]] for d in range(3)] for i in range(k)]  # k x 3 arrays of length F
+        fc = [sum(Pk[i][d] for i in range(k)) / k for d in range(3)]
+        Sf = [np.zeros(F) for _ in range(3)]
+        ac = [np.zeros(F) for _ in range(3)]
+        asum = np.zeros(F)
+        for i in range(k):
+            p, q = Pk[i], Pk[(i + 1) % k]
+            u = [q[d] - p[d] for d in range(3)]
+            v = [fc[d] - p[d] for d in range(3)]
+            n = [u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]]
+            a = np.sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2])
+            asum += a
+            for d in range(3):
+                Sf[d] += n[d]
+                ac[d] += a * (p[d] + q[d] + fc[d])
+        self.Sf = 0.5 * np.stack(Sf, axis=1)
+        self.Cf = np.stack(ac, axis=1) / (3.0 * asum)[:, None]
         N = mesh.n_cells
         nIF = mesh.n_internal_faces
         own, nei = mesh.owner, mesh.neighbour
@@ -298,7 +310,7 @@ def wall_distance(mesh: PolyMesh, cell_centres, face_centres, face_areas) -> np.
         return np.full(mesh.n_cells, 1.0)
     idx = np.concatenate(idx)
     tree = cKDTree(face_centres[idx])
-    _, nn = tree.query(cell_centres)
+    _, nn = tree.query(cell_centres, workers=-1)
     f = idx[nn]
     n = face_areas[f] / np.linalg.norm(face_areas[f], axis=1)[:, None]
     d = np.abs(np.einsum("ij,ij->i", cell_centres - face_centres[f], n))
@@ -317,7 +329,7 @@ def wall_distance_exact(mesh: PolyMesh, cell_centres, face_centres, face_areas, 
         return np.full(mesh.n_cells, 1.0)
     idx = np.concatenate(idx)
     k = int(min(k, idx.size))
-    _, nn = cKDTree(face_centres[idx]).query(cell_centres, k=k)
+    _, nn = cKDTree(face_centres[idx]).query(cell_centres, k=k, workers=-1)
     nn = nn.reshape(len(cell_centres), k)
     best = np.full(len(cell_centres), np.inf)
     pts = mesh.points
