@@ -68,6 +68,15 @@ def read_points(path):
     return a
 
 
+def write_points(path, points):
+    """a polyMesh `points` file (vectorField) at `path` (directories created)"""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    with open(path, "w") as f:
+        f.write(_HEADER.format(cls="vectorField", loc=os.path.dirname(path), obj="points"))
+        f.write(f"{pts.shape[0]}\n(\n" + "\n".join("(%.17g %.17g %.17g)" % tuple(p) for p in pts) + "\n)\n")
+
+
 def read_labels(path):
     n, body = _list_body(_strip(open(path).read()))
     a = np.array(body.split(), dtype=np.int64)

@@ -282,6 +282,8 @@ class pyDASolvers:
             self._perm = self._cell_ordering_permutation()
         self.updateDAOption(pyOptions)
         self._inputInfo = dict(pyOptions.get("inputInfo") or {}) if isinstance(pyOptions, dict) else {}
+        self._primalBC = dict(pyOptions.get("primalBC") or {}) if isinstance(pyOptions, dict) else {}
+        self._checkMeshThreshold = dict(pyOptions.get("checkMeshThreshold") or {}) if isinstance(pyOptions, dict) else {}
         self._patchVelocity = [0.0, 0.0]  # DAGlobalVar::patchVelocity = [UMag, AoA(deg)], set by DAInputPatchVelocity::run
         self._flowdir_fns = {}
         self._define_functions(pyOptions.get("function") if isinstance(pyOptions, dict) else None)
@@ -893,6 +895,198 @@ class pyDASolvers:
         assert len(psi) == self.getNLocalAdjointStates(), "invalid array size!"
         psi_s = np.ascontiguousarray(self._to_state(np.asarray(psi, dtype=np.float64)))
         return foam_io.write_adjoint_fields(caseDir, self._case, function, writeTime, psi_s, self._state_blocks())
+
+    # -- the rest of the reference's pyDASolvers surface that a runScript / mphys_dafoam.py touches around the hot path ------
+    caseDir = "."  # where the IO methods read / write (the reference runs inside its case directory)
+
+    def calcOutput(self, outputName, outputType, output):
+        """pyDASolvers.pyx:204-206 -> DAOutput::run: the function value (1 entry) or the residual vector (state ordering of the
+        caller: adjStateOrdering) at the current states."""
+        assert len(output) == self.getOutputSize(outputName, outputType), "invalid array size!"
+        if outputType == "function":
+            output[0] = self.calcFunction(outputName)
+        elif outputType == "residual":
+            R = np.zeros(self.getNLocalAdjointStates())
+            self.getResiduals(R)
+            output[:] = R
+        else:
+            raise _capi.DASError(f"outputType not supported on this path: {outputType}")
+
+    def hasVolCoordInput(self):
+        """DASolver::hasVolCoordInput (DASolver.C:4149-4164): 1 if an inputInfo entry has type volCoord."""
+        return int(any(isinstance(e, dict) and e.get("type") == "volCoord" for e in self._inputInfo.values()))
+
+    def getInputDistributed(self, inputName, inputType):
+        """DAInput*::distributed(): 1 for inputs that are partitioned over the ranks (DAInputStateVar.H:57, DAInputVolCoord.H:57; a
+        field input says so itself, DAInputField.H:110-114), 0 for the global ones (patchVelocity, patchVar)."""
+        if inputType in ("stateVar", "volCoord"):
+            return 1
+        if inputType == "field":
+            return int(self._field_entry(inputName).get("distributed", 1))
+        if inputType in ("patchVelocity", "patchVar"):
+            return 0
+        raise _capi.DASError(f"inputType not supported on this path: {inputType}")
+
+    def getOutputDistributed(self, outputName, outputType):
+        """DAOutputResidual.H:59 (1), DAOutputFunction.H:76 (0)."""
+        if outputType == "residual":
+            return 1
+        if outputType == "function":
+            return 0
+        raise _capi.DASError(f"outputType not supported on this path: {outputType}")
+
+    def getOFField(self, fieldName, fieldType, field):
+        """pyDASolvers.pyx:283-289: the internal field `fieldName` (a state of this solver) of the current states, cell by cell
+        (vectors interleaved xyz)."""
+        N = self.getNLocalCells()
+        assert len(field) == (3 * N if fieldType == "vector" else N), "invalid array size!"
+        W = np.zeros(self.getNLocalAdjointStates())
+        check(lib().das_get_of_fields(self._h, dptr(W)))
+        for nm, kind, off, size in self._state_blocks():
+            if nm == fieldName and kind != "face":
+                if (kind == "vec") != (fieldType == "vector"):
+                    raise _capi.DASError(f"fieldType {fieldType} does not match field {fieldName}")
+                field[:] = W[off : off + size]
+                return
+        raise _capi.DASError(f"field {fieldName} is not a cell-centred state of {self._case.solver_name}")
+
+    def getOFFieldGlobal(self, fieldName, fieldType, field):
+        """pyDASolvers.pyx:291-295 (the field gathered over all ranks): one domain here - the sharded wrapper owns the gather."""
+        if self.getNGlobalCells() != self.getNLocalCells():
+            raise _capi.DASError("getOFFieldGlobal on a sharded solver: gather through dafoam_amd.distributed")
+        return self.getOFField(fieldName, fieldType, field)
+
+    def getGlobalXvIndex(self, pointI, coordI):
+        """DAIndex::getGlobalXvIndex (DAIndex.C:757-775): 3 * (global point) + coordinate; one domain: the local numbering."""
+        assert 0 <= pointI < self.getNLocalPoints() and 0 <= coordI < 3
+        return 3 * int(pointI) + int(coordI)
+
+    def checkMesh(self):
+        """DASolver::checkMesh -> DACheckMesh::run (DACheckMesh.C:49-77: OpenFOAM's checkGeometry with the thresholds of the
+        checkMeshThreshold option): 1 = mesh quality passes.  Checked here on the library's metrics: cell volumes > 0, face
+        orientation d.Sf > 0 (at most maxIncorrectlyOrientedFaces violations), non-orthogonality angle, skewness (distance of
+        the face centre from the point where the line of centres meets the face, over |d|, OpenFOAM primitiveMeshTools::
+        faceSkewness) and cell aspect ratio (primitiveMeshTools::cellClosedness) below the thresholds."""
+        th = dict(maxAspectRatio=1000.0, maxNonOrth=70.0, maxSkewness=4.0, maxIncorrectlyOrientedFaces=0)
+        th.update({k: (v[1] if isinstance(v, list) else v) for k, v in self._checkMeshThreshold.items()})
+        g = self.geometry()
+        m = self._case.mesh
+        nIF, N = m.n_internal_faces, m.n_cells
+        own, nei = np.asarray(m.owner), np.asarray(m.neighbour)
+        Sf, Cf, Cc, V = g["Sf"].reshape(-1, 3), g["Cf"].reshape(-1, 3), g["C"].reshape(-1, 3), g["V"]
+        self.meshQuality = q = {}
+        q["minVolume"] = float(V.min())
+        d = Cc[nei] - Cc[own[:nIF]]
+        dn = np.einsum("ij,ij->i", d, Sf[:nIF])
+        magd, magS = np.linalg.norm(d, axis=1), np.linalg.norm(Sf[:nIF], axis=1)
+        q["incorrectlyOrientedFaces"] = int(np.count_nonzero(dn <= 0))
+        cosang = np.clip(dn / np.maximum(magd * magS, 1e-300), -1.0, 1.0)
+        q["maxNonOrth"] = float(np.degrees(np.arccos(cosang)).max()) if nIF else 0.0
+        t = np.einsum("ij,ij->i", Cf[:nIF] - Cc[own[:nIF]], Sf[:nIF]) / np.where(dn != 0, dn, 1.0)
+        sk = np.linalg.norm(Cf[:nIF] - (Cc[own[:nIF]] + t[:, None] * d), axis=1) / np.maximum(magd, 1e-300)
+        q["maxSkewness"] = float(sk.max()) if nIF else 0.0
+        sumMag = np.zeros((N, 3))
+        absS = np.abs(Sf)
+        for k in range(3):
+            sumMag[:, k] = np.bincount(own, absS[:, k], N) + np.bincount(nei, absS[:nIF, k], N)
+        lo = np.maximum(sumMag.min(axis=1), 1e-300)
+        q["maxAspectRatio"] = float(np.maximum(sumMag.max(axis=1) / lo, sumMag.sum(axis=1) / 6.0 / np.maximum(V, 1e-300) ** (2.0 / 3.0)).max())
+        ok = (q["minVolume"] > 0 and q["incorrectlyOrientedFaces"] <= th["maxIncorrectlyOrientedFaces"] and q["maxNonOrth"] <= th["maxNonOrth"]
+              and q["maxSkewness"] <= th["maxSkewness"] and q["maxAspectRatio"] <= th["maxAspectRatio"])
+        return int(ok)
+
+    # time bookkeeping of the steady solvers (pyDASolvers.pyx:358,400-410,464): iterations play the role of time
+    def setTime(self, time, timeIndex):
+        self._time, self._timeIndex = float(time), int(timeIndex)
+
+    def getDeltaT(self):
+        return float(getattr(self._case, "deltaT", 1.0))
+
+    def getEndTime(self):
+        return float(getattr(self, "_endTime", getattr(self, "_time", 0.0)))
+
+    def getLatestTime(self):
+        return float(getattr(self, "_time", 0.0))
+
+    def getPrevPrimalSolTime(self):
+        return float(getattr(self, "_prevPrimalSolTime", getattr(self, "_time", 0.0)))
+
+    def getDdtSchemeOrder(self):
+        """1 (Euler) for the unsteady scalar transport residual, the steady solvers have no time derivative (DASolver::getDdtSchemeOrder)."""
+        return 1
+
+    def getdFScaling(self, functionName, timeIdx=-1):
+        """DASolver::getdFScaling: the weight of a time instance in a time-averaged objective; 1 for steady solvers."""
+        return 1.0
+
+    def getTimeOpFuncVal(self, functionName):
+        """DASolver::getTimeOpFuncVal: the time-operated (final / averaged) objective; steady solvers: the value at the current states."""
+        return self.calcFunction(functionName)
+
+    def updateBoundaryConditions(self, fieldName, fieldType):
+        """pyDASolvers.pyx:364: boundary values are re-evaluated inline by every kernel from the states - nothing is stored."""
+        return None
+
+    def setPrimalBoundaryConditions(self, printInfo=1):
+        """DASolver::setPrimalBoundaryConditions (DASolver.C:3790-4030): the primalBC option {name: {variable, patches, value}}
+        written into the patch table (fixedValue / inletOutlet patches)."""
+        for name, e in (self._primalBC or {}).items():
+            if not isinstance(e, dict) or "variable" not in e:
+                continue
+            ids = np.ascontiguousarray(self._patch_ids(e), dtype=np.int32)
+            val = np.ascontiguousarray(np.atleast_1d(np.asarray(e["value"], dtype=np.float64)))
+            check(lib().das_set_patch_value(self._h, ids.ctypes.data_as(_capi.c_int_p), ids.size, str(e["variable"]).encode(), dptr(val)))
+            if printInfo:
+                print(f"primalBC {name}: {e['variable']} on {e['patches']} = {val.tolist()}")
+
+    # mesh / state files (pyDASolvers.pyx:361,382-395 -> DASolver::readMeshPoints / writeMeshPoints / readStateVars)
+    def _points_path(self, timeVal):
+        import os
+
+        return os.path.join(self.caseDir, ("%g" % timeVal) if timeVal is not None else "constant", "polyMesh", "points")
+
+    def writeMeshPoints(self, points, timeVal):
+        from . import foam_io
+
+        assert len(points) == self.getNLocalPoints() * 3, "invalid array size!"
+        foam_io.write_points(self._points_path(timeVal), np.asarray(points, dtype=np.float64).reshape(-1, 3))
+
+    def readMeshPoints(self, timeVal):
+        from . import foam_io
+
+        self.updateOFMesh(np.ascontiguousarray(foam_io.read_points(self._points_path(timeVal)).ravel()))
+
+    def writeCurrentMeshPointsToConstant(self):
+        X = np.zeros(self.getNLocalPoints() * 3)
+        self.getOFMeshPoints(X)
+        self.writeMeshPoints(X, None)
+
+    def writeFailedMesh(self):
+        """DASolver::writeFailedMesh: the current points under the time directory 9999 for inspection (pyDAFoam.py:1240-1256)."""
+        X = np.zeros(self.getNLocalPoints() * 3)
+        self.getOFMeshPoints(X)
+        self.writeMeshPoints(X, 9999)
+
+    def readStateVars(self, timeVal, timeLevel=0):
+        """DASolver::readStateVars (DASolver.C:3478-3600): the state fields of time directory timeVal -> the solver (timeLevel 0)."""
+        import os
+
+        from . import foam_io
+
+        if timeLevel != 0:
+            raise _capi.DASError("readStateVars: old-time levels are set through setOldTimeFields on this path")
+        m = self._case.mesh
+        N = m.n_cells
+        tdir = os.path.join(self.caseDir, "%g" % timeVal)
+        W = np.zeros(self.getNLocalAdjointStates())
+        check(lib().das_get_of_fields(self._h, dptr(W)))
+        for nm, kind, off, size in self._state_blocks():
+            path = os.path.join(tdir, nm)
+            if kind == "face" or not os.path.exists(path):
+                continue  # phi is a derived field in a time directory written by a primal (kept as it is here)
+            vals, _ = foam_io.read_field(path, N, 3 if kind == "vec" else 1)
+            W[off : off + size] = np.asarray(vals, dtype=np.float64).ravel()
+        check(lib().das_update_of_fields(self._h, dptr(W)))
 
     def getElapsedClockTime(self):
         return lib().das_get_elapsed_clock_time(self._h)

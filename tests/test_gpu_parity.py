@@ -917,6 +917,29 @@ def test_volcoord_full_product_vector_on_the_device():
     assert D2.solverAD.calcFunction("CM") == v0  # the host copy of the moment arms is back (and the sums are deterministic)
 
 
+def test_primal_bc_option_and_calc_output():
+    """setPrimalBoundaryConditions (the primalBC option -> patch table, DASolver.C:3790-4030) and calcOutput (pyDASolvers.pyx:204:
+    function value / residual vector) - small methods of the reference surface that need the device."""
+    case = channel_case(6, 5, 4, wall_function=True)
+    D = make(case, primalBC={"U0": {"variable": "U", "patches": ["inlet"], "value": [12.0, 0.5, 0.0]}},
+             function={"CD": {"type": "force", "source": "patchToFace", "patches": ["bottom"], "directionMode": "fixedDirection", "direction": [1.0, 0.0, 0.0], "scale": 1.0}})
+    S = D.solver
+    n = case.states.size
+    R0, R1, out1 = np.zeros(n), np.zeros(n), np.zeros(1)
+    S.calcOutput("residual", "residual", R0)
+    S.setPrimalBoundaryConditions(printInfo=0)
+    S.calcOutput("residual", "residual", R1)
+    S.calcOutput("CD", "function", out1)
+    import copy
+
+    c2 = copy.copy(case)
+    c2.bcs = copy.deepcopy(case.bcs)
+    c2.bcs["inlet"]["U"] = (c2.bcs["inlet"]["U"][0], np.array([12.0, 0.5, 0.0]))
+    g = Geometry(case.mesh)
+    assert relerr(R0, residual(case, g, case.states)) < 1e-12 and relerr(R1, residual(c2, g, case.states)) < 1e-12 and relerr(R1, R0) > 1e-3
+    assert out1[0] == S.calcFunction("CD")
+
+
 def test_volcoord_product_compressible_and_ratio_objective():
     """The volCoord product for DARhoSimpleFoam: residual seeds and the totalTemperatureRatio objective (a quotient of two area
     averages: differentiated through its linearisation at the base mesh) against the directional product - one central

@@ -1017,3 +1017,54 @@ def test_case_discretisation_is_read_and_verified(tmp_path):
         foam_io.read_case(d, y_wall=case.y_wall)
     lax = foam_io.read_case(d, y_wall=case.y_wall, strict_schemes=False)
     assert len(lax.scheme_mismatches) == 2
+
+
+def test_api_surface_methods_around_the_hot_path(tmp_path):
+    """The small methods of the reference's pyDASolvers class a runScript / mphys_dafoam.py calls around solve_linear
+    (pyDASolvers.pyx:198-206,283-303,320,361-410,464-468): distributed flags, calcOutput sizes, getOFField, getGlobalXvIndex,
+    checkMesh with the checkMeshThreshold option, mesh-point and state files, primalBC."""
+    case = channel_case(6, 5, 4, wall_function=True)
+    opts = options(case, inputInfo={"aero_vol_coords": {"type": "volCoord", "components": ["solver", "function"]},
+                                    "patchV": {"type": "patchVelocity", "patches": ["inlet"], "flowAxis": "x", "normalAxis": "y", "components": ["solver"]}},
+                   primalBC={"U0": {"variable": "U", "patches": ["inlet"], "value": [12.0, 0.5, 0.0]}})
+    s = pyDASolvers(b"DASimpleFoam -python", opts, case=case)
+    N, P = case.mesh.n_cells, case.mesh.n_points
+    assert s.hasVolCoordInput() == 1 and pyDASolvers(b"DASimpleFoam -python", options(case), case=case).hasVolCoordInput() == 0
+    assert s.getInputDistributed("aero_vol_coords", "volCoord") == 1 and s.getInputDistributed("patchV", "patchVelocity") == 0
+    assert s.getOutputDistributed("residual", "residual") == 1 and s.getOutputDistributed("CD", "function") == 0
+    assert s.getInputSize("aero_vol_coords", "volCoord") == 3 * P and s.getGlobalXvIndex(7, 2) == 23
+    U, p = np.zeros(3 * N), np.zeros(N)
+    s.getOFField("U", "vector", U)
+    s.getOFField("p", "scalar", p)
+    assert np.array_equal(U, case.states[:3 * N]) and np.array_equal(p, case.states[3 * N:4 * N])
+    with pytest.raises(_capi.DASError):
+        s.getOFField("phi", "scalar", p)
+    # checkMesh: the generated channel passes; a folded mesh and a tight threshold do not
+    assert s.checkMesh() == 1 and s.meshQuality["incorrectlyOrientedFaces"] == 0 and 0 < s.meshQuality["maxNonOrth"] < 70
+    tight = pyDASolvers(b"DASimpleFoam -python", options(case, checkMeshThreshold={"maxNonOrth": 0.5 * s.meshQuality["maxNonOrth"], "maxSkewness": 4.0,
+                                                                                   "maxAspectRatio": 1000.0, "maxIncorrectlyOrientedFaces": 0}), case=case)
+    assert tight.checkMesh() == 0
+    # mesh points through files: write, move, read back
+    s.caseDir = str(tmp_path)
+    X0 = np.zeros(3 * P)
+    s.getOFMeshPoints(X0)
+    s.writeMeshPoints(X0 * 1.01, 3)
+    s.readMeshPoints(3)
+    X1 = np.zeros(3 * P)
+    s.getOFMeshPoints(X1)
+    assert np.allclose(X1, 1.01 * X0, rtol=1e-15)
+    s.writeCurrentMeshPointsToConstant()
+    s.writeFailedMesh()
+    assert os.path.exists(os.path.join(str(tmp_path), "constant", "polyMesh", "points")) and os.path.exists(os.path.join(str(tmp_path), "9999", "polyMesh", "points"))
+    # state files of a time directory
+    from dafoam_amd import foam_io
+
+    c2 = channel_case(6, 5, 4, wall_function=True, perturb=0.05, seed=3)
+    foam_io.write_case(str(tmp_path), c2, time="100")
+    s.readStateVars(100)
+    W = np.zeros(case.states.size)
+    s.getOFFields(W)
+    assert np.array_equal(W[:5 * N], c2.states[:5 * N]) and np.array_equal(W[5 * N:], case.states[5 * N:])
+    # time bookkeeping of the steady solvers
+    s.setTime(500.0, 500)
+    assert s.getLatestTime() == 500.0 and s.getDeltaT() == 1.0 and s.getdFScaling("CD") == 1.0 and s.getDdtSchemeOrder() == 1
