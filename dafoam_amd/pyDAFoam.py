@@ -143,7 +143,7 @@ class DAOPTION(object):
 class PYDAFOAM(object):
     """Main driver (reference PYDAFOAM, pyDAFoam.py:664).  ``case`` replaces the OpenFOAM case directory."""
 
-    def __init__(self, comm=None, options=None, case=None):
+    def __init__(self, comm=None, options=None, case=None, initSolver=True):
         assert options is not None, "options must be provided (reference pyDAFoam.py:679-686)"
         self.name = "PYDAFOAM"
         self.dtype = "d"  # pyDAFoam.py:713
@@ -157,7 +157,20 @@ class PYDAFOAM(object):
         # patch names of the case (the reference reads constant/polyMesh/boundary, pyDAFoam.py:1553-1563)
         self.boundaries = {p.name: {"type": p.type, "nFaces": p.size, "startFace": p.start} for p in case.mesh.patches} if case is not None else {}
         self._checkOptions()
-        self._initSolver()
+        self._readMeshInfo()
+        self._computeBasicFamilyInfo()
+        # the family groups of the reference (pyDAFoam.py:743-756): every patch, the wall-like patches, the design surfaces
+        self.allSurfacesGroup = "allSurfaces"
+        self.addFamilyGroup(self.allSurfacesGroup, self.basicFamilies)
+        self.allWallsGroup = "allWalls"
+        self.addFamilyGroup(self.allWallsGroup, self.wallList)
+        self.designSurfacesGroup = "designSurfaces"
+        ds = self.getOption("designSurfaces")
+        self.addFamilyGroup(self.designSurfacesGroup, self.wallList if "ALL_OPENFOAM_WALL_PATCHES" in ds else list(ds))
+        self.mesh = None  # the volume-mesh warping object (setMesh)
+        self.solver = self.solverAD = None
+        if initSolver:  # (False: options + mesh families only - no device needed)
+            self._initSolver()
         self.dRdWTPC = None
         self.ksp = None
         self.nSolveAdjoints = 0
@@ -261,9 +274,194 @@ class PYDAFOAM(object):
 
     def setVolCoords(self, vol_coords):
         """pyDAFoam.py:2111-2119"""
+        self.xv = np.asarray(vol_coords, dtype=self.dtype).reshape(-1, 3).copy()
+        if self.solver is None:
+            return
         self.solver.updateOFMesh(vol_coords)
         if self.solverAD is not self.solver:
             self.solverAD.updateOFMesh(vol_coords)
+
+    # ---------------------------------------------------------------- surface families (pyDAFoam.py:941-1125,1553-1800)
+    # What pyGeo / IDWarp and mphys need around the solver: the boundary patches as "families" of surface points.  The
+    # reference parses constant/polyMesh; here the FoamCase holds the same arrays.  A family is a list of basic-family ids, a
+    # basic family a patch with its unique point ids ("indicesRed", ascending) and its faces in that reduced numbering
+    # ("facesRed"); surface arrays of a group are the concatenation over its (sorted) basic families.
+    def _readMeshInfo(self):
+        """pyDAFoam.py:1553-1563: point coordinates xv0 / xv, faces, owners, neighbours, boundaries."""
+        if self._case is None:
+            self.xv0 = self.xv = np.zeros((0, 3))
+            self.faces, self.owners, self.neighbours = [], np.zeros(0, int), np.zeros(0, int)
+            return
+        m = self._case.mesh
+        self.xv0 = np.array(m.points, dtype=self.dtype).reshape(-1, 3)
+        self.xv = self.xv0.copy()
+        self.faces = [m.face_pts[m.face_ptr[f]:m.face_ptr[f + 1]].tolist() for f in range(m.n_faces)] if m.n_faces < 200000 else None
+        self.owners, self.neighbours = np.asarray(m.owner), np.asarray(m.neighbour)
+        for pt in m.patches:
+            self.boundaries[pt.name]["faces"] = np.arange(pt.start, pt.start + pt.size)
+
+    def _computeBasicFamilyInfo(self):
+        """pyDAFoam.py:1674-1748: per patch the unique point ids and the faces in that reduced numbering; wall-like patches."""
+        self.families = {}
+        self.basicFamilies = sorted(self.boundaries.keys())
+        self.wallList = []
+        m = self._case.mesh if self._case is not None else None
+        for counter, name in enumerate(self.basicFamilies):
+            self.families[name] = [counter]
+            bc = self.boundaries[name]
+            fids = np.asarray(bc.get("faces", []), dtype=np.int64)
+            if fids.size:
+                lo, hi = m.face_ptr[fids], m.face_ptr[fids + 1]
+                flat = np.concatenate([m.face_pts[a:b] for a, b in zip(lo, hi)]) if np.any(hi - lo != hi[0] - lo[0]) else \
+                    m.face_pts[(lo[:, None] + np.arange(hi[0] - lo[0])[None, :]).ravel()]
+                indices, inv = np.unique(flat, return_inverse=True)
+                sizes = (hi - lo).astype(np.int64)
+                cuts = np.concatenate([[0], np.cumsum(sizes)])
+                bc["facesRed"] = [inv[cuts[i]:cuts[i + 1]].tolist() for i in range(fids.size)]
+                bc["indicesRed"] = indices.tolist()
+            else:
+                bc["facesRed"], bc["indicesRed"] = [], []
+            if bc["type"] in ("wall", "slip", "cyclic"):
+                self.wallList.append(name)
+
+    def addFamilyGroup(self, groupName, families):
+        """pyDAFoam.py:941-977: a named union of families (groups may be nested)."""
+        if groupName in self.families:
+            raise Error("The specified groupName '%s' already exists in the mesh file or has already been added." % groupName)
+        indices = []
+        for fam in families:
+            if fam not in self.families:
+                raise Error("The specified family '%s' for group '%s', does not exist in the mesh file or has not already been added. "
+                            "The current list of families (original and grouped) is: %s" % (fam, groupName, repr(self.families.keys())))
+            indices.extend(self.families[fam])
+        self.families[groupName] = sorted(np.unique(indices).tolist())
+
+    def printFamilyList(self):
+        print(self.families)
+
+    def _getSurfaceSize(self, groupName):
+        """pyDAFoam.py:1630-1660: (points, faces) of a group."""
+        if groupName is None:
+            groupName = self.allSurfacesGroup
+        if groupName not in self.families:
+            raise Error("'%s' is not a family in the OpenFoam Case or has not been added as a combination of families" % groupName)
+        nPts = sum(len(self.boundaries[self.basicFamilies[i]]["indicesRed"]) for i in self.families[groupName])
+        nCells = sum(len(self.boundaries[self.basicFamilies[i]]["facesRed"]) for i in self.families[groupName])
+        return nPts, nCells
+
+    def getSurfaceCoordinates(self, groupName=None):
+        """pyDAFoam.py:1594-1628: the (nPoints, 3) coordinates of the group's surface points (current volume coordinates)."""
+        if groupName is None:
+            groupName = self.allWallsGroup
+        npts, _ = self._getSurfaceSize(groupName)
+        ids = [np.asarray(self.boundaries[self.basicFamilies[i]]["indicesRed"], dtype=np.int64) for i in self.families[groupName]]
+        xs = np.zeros((npts, 3), self.dtype)
+        if npts:
+            xs[:] = self.xv[np.concatenate(ids)]
+        return xs
+
+    def getSurfaceConnectivity(self, groupName=None):
+        """pyDAFoam.py:1000-1047: (conn, faceSizes) of the group's faces in the numbering of getSurfaceCoordinates."""
+        if groupName is None:
+            groupName = self.allWallsGroup
+        conn, faceSizes, offset = [], [], 0
+        for i in self.families[groupName]:
+            bc = self.boundaries[self.basicFamilies[i]]
+            if bc["facesRed"]:
+                for face in bc["facesRed"]:
+                    conn.extend(v + offset for v in face)
+                    faceSizes.append(len(face))
+                offset += len(bc["indicesRed"])
+        return conn, faceSizes
+
+    def getTriangulatedMeshSurface(self, groupName=None, **kwargs):
+        """pyDAFoam.py:1049-1113: [p0, v1, v2] - every face as a fan of triangles about its average point (for DVConstraints)."""
+        if groupName is None:
+            groupName = self.allWallsGroup
+        pts = self.getSurfaceCoordinates(groupName)
+        conn, faceSizes = self.getSurfaceConnectivity(groupName)
+        p0, v1, v2, c = [], [], [], 0
+        for fs in faceSizes:
+            nodes = conn[c:c + fs]
+            avg = pts[nodes].mean(axis=0)
+            for k in range(fs):
+                p0.append(avg)
+                v1.append(pts[nodes[k]] - avg)
+                v2.append(pts[nodes[(k + 1) % fs]] - avg)
+            c += fs
+        return [p0, v1, v2]
+
+    def mapVector(self, vec1, groupName1, groupName2, vec2=None):
+        """pyDAFoam.py:1768-1850: a surface array on group 1 -> the layout of group 2 (entries of families in both groups are
+        copied, the others stay what vec2 held / zero)."""
+        if groupName1 not in self.families or groupName2 not in self.families:
+            raise Error("'%s' or '%s' is not a family in the mesh file or has not been added as a combination of families" % (groupName1, groupName2))
+        if vec2 is None:
+            vec2 = np.zeros((self._getSurfaceSize(groupName2)[0], 3), self.dtype)
+        start1, off = {}, 0
+        for i in self.families[groupName1]:
+            start1[i] = off
+            off += len(self.boundaries[self.basicFamilies[i]]["indicesRed"])
+        off = 0
+        for i in self.families[groupName2]:
+            n = len(self.boundaries[self.basicFamilies[i]]["indicesRed"])
+            if i in start1:
+                vec2[off:off + n] = vec1[start1[i]:start1[i] + n]
+            off += n
+        return vec2
+
+    def getSolverMeshIndices(self):
+        """pyDAFoam.py:1750-1766: the global indices of this rank's volume coordinates for the warping object (one domain: 0..3P)."""
+        return np.arange(self.xv0.size)
+
+    def setMesh(self, mesh):
+        """pyDAFoam.py:979-998: attach the volume-mesh warping object (IDWarp USMesh interface: setExternalMeshIndices,
+        setSurfaceDefinition, setSurfaceCoordinates)."""
+        self.mesh = mesh
+        self.mesh.setExternalMeshIndices(self.getSolverMeshIndices())
+        conn, faceSizes = self.getSurfaceConnectivity(self.allWallsGroup)
+        self.mesh.setSurfaceDefinition(self.getSurfaceCoordinates(self.allWallsGroup), conn, faceSizes)
+
+    def setSurfaceCoordinates(self, coordinates, groupName=None):
+        """pyDAFoam.py:1565-1592: new surface points of a group -> the warping object (which returns volume coordinates later)."""
+        if self.mesh is None:
+            return
+        if groupName is None:
+            groupName = self.allWallsGroup
+        self._updateGeomInfo = True
+        surf = self.mapVector(coordinates, groupName, self.allWallsGroup, self.getSurfaceCoordinates(self.allWallsGroup))
+        self.mesh.setSurfaceCoordinates(surf)
+
+    def set_solver_input(self, inputs, DVGeo=None):
+        """pyDAFoam.py:1350-1374 (called by mphys_dafoam.py solve_nonlinear / linearize / apply_linear): every inputInfo entry
+        attached to the solver component is handed to both solver objects.  The forward-mode seeds of the reference's ADF build
+        are not mirrored (the GPU path differentiates through calcJacTVecProduct / calcJacVecProduct): useAD mode "forward" with
+        a seeded design variable is rejected instead of being ignored."""
+        inputDict = self.getOption("inputInfo")
+        if self.getOption("useAD")["mode"] == "forward" and self.getOption("useAD").get("dvName", "None") not in ("None", None, ""):
+            raise Error("set_solver_input: forward-mode seeds (useAD mode forward + dvName) are not available on this path")
+        for inputName in list(inputDict.keys()):
+            if "solver" not in inputDict[inputName].get("components", ["solver"]):
+                continue
+            inputType = inputDict[inputName]["type"]
+            value = np.ascontiguousarray(inputs[inputName], dtype=np.float64).ravel()
+            if inputType == "volCoord":
+                self.xv = value.reshape(-1, 3).copy()
+            self.solver.setSolverInput(inputName, inputType, len(value), value, np.zeros(len(value)))
+            if self.solverAD is not self.solver:
+                self.solverAD.setSolverInput(inputName, inputType, len(value), value, np.zeros(len(value)))
+
+    def setPrimalBoundaryConditions(self, printInfo=1, printInfoAD=0):
+        """pyDAFoam.py:1662-1667"""
+        self.solver.setPrimalBoundaryConditions(printInfo)
+        if self.solverAD is not self.solver:
+            self.solverAD.setPrimalBoundaryConditions(printInfoAD)
+
+    def readStateVars(self, timeVal=0.0, deltaT=0.0):
+        """pyDAFoam.py:1321-1348: the state fields of a time directory -> both solver objects (steady: one time level)."""
+        self.solver.readStateVars(timeVal, 0)
+        if self.solverAD is not self.solver:
+            self.solverAD.readStateVars(timeVal, 0)
 
     def getResiduals(self):
         """pyDAFoam.py:2121-2130"""

@@ -1068,3 +1068,62 @@ def test_api_surface_methods_around_the_hot_path(tmp_path):
     # time bookkeeping of the steady solvers
     s.setTime(500.0, 500)
     assert s.getLatestTime() == 500.0 and s.getDeltaT() == 1.0 and s.getdFScaling("CD") == 1.0 and s.getDdtSchemeOrder() == 1
+
+
+def test_surface_families_for_geometry_and_warping_tools():
+    """The family machinery pyGeo / IDWarp / mphys use around the solver (reference pyDAFoam.py:941-1125,1553-1800): basic
+    families = patches with their unique points and faces in reduced numbering, the allSurfaces / allWalls / designSurfaces
+    groups, surface coordinates and connectivity in the group's concatenated numbering, the triangulated surface for
+    DVConstraints, mapVector between groups, and the hand-over to a warping object (setMesh / setSurfaceCoordinates)."""
+    from dafoam_amd.pyDAFoam import PYDAFOAM, Error
+
+    case = channel_case(5, 4, 3, wall_function=True, bump=0.1)
+    D = PYDAFOAM(options=options(case, designSurfaces=["bottom"]), case=case, initSolver=False)
+    m = case.mesh
+    assert D.basicFamilies == sorted(p.name for p in m.patches) and sorted(D.wallList) == ["bottom", "top"]
+    assert D.families["allWalls"] == sorted(D.families["bottom"] + D.families["top"]) and D.families["designSurfaces"] == D.families["bottom"]
+    # coordinates + connectivity reproduce every wall face
+    xs = D.getSurfaceCoordinates()
+    conn, sizes = D.getSurfaceConnectivity()
+    walls = [p for p in sorted(m.patches, key=lambda q: q.name) if p.type == "wall"]
+    assert len(sizes) == sum(p.size for p in walls) and xs.shape == (D._getSurfaceSize("allWalls")[0], 3)
+    c, k = 0, 0
+    for p in walls:
+        for f in range(p.start, p.start + p.size):
+            ref = m.points[m.face_pts[m.face_ptr[f]:m.face_ptr[f + 1]]]
+            assert np.array_equal(xs[conn[c:c + sizes[k]]], ref)
+            c += sizes[k]
+            k += 1
+    # triangulated surface: the fan areas add up to the wall area
+    p0, v1, v2 = D.getTriangulatedMeshSurface("bottom")
+    g = Geometry(m)
+    bot = next(p for p in m.patches if p.name == "bottom")
+    area = 0.5 * np.linalg.norm(np.cross(np.array(v1), np.array(v2)), axis=1).sum()
+    assert abs(area - np.linalg.norm(g.bSf[bot.start - g.nIF: bot.start - g.nIF + bot.size], axis=1).sum()) < 1e-12 * area
+    # mapVector: allWalls -> designSurfaces keeps the bottom part, back again zero-fills the top part
+    a = np.arange(xs.size, dtype=float).reshape(-1, 3)
+    nb = D._getSurfaceSize("bottom")[0]
+    low = D.mapVector(a, "allWalls", "designSurfaces")
+    assert low.shape == (nb, 3) and np.array_equal(low, a[:nb])
+    up = D.mapVector(low, "designSurfaces", "allWalls")
+    assert np.array_equal(up[:nb], a[:nb]) and np.all(up[nb:] == 0)
+    with pytest.raises(Error):
+        D.addFamilyGroup("allWalls", ["bottom"])
+    with pytest.raises(Error):
+        D.addFamilyGroup("g", ["nonexistent"])
+    D.addFamilyGroup("io", ["inlet", "outlet"])
+    assert D._getSurfaceSize("io")[1] == 2 * 4 * 3
+
+    # a warping object receives indices, surface definition and new surface coordinates
+    class Warp:
+        def setExternalMeshIndices(self, ind): self.ind = ind
+        def setSurfaceDefinition(self, pts, conn, sizes): self.defn = (pts.copy(), list(conn), list(sizes))
+        def setSurfaceCoordinates(self, pts): self.surf = pts.copy()
+
+    w = Warp()
+    D.setMesh(w)
+    assert np.array_equal(w.ind, np.arange(3 * m.n_points)) and np.array_equal(w.defn[0], xs)
+    D.setSurfaceCoordinates(low + 1.0, "designSurfaces")
+    assert np.array_equal(w.surf[:nb], low + 1.0) and np.array_equal(w.surf[nb:], xs[nb:])
+    D.setVolCoords(1.5 * m.points.ravel())
+    assert np.array_equal(D.getSurfaceCoordinates(), 1.5 * xs)

@@ -374,3 +374,36 @@ def test_pydasolvers_api_surface():
     stale = [n for n in NOT_IMPLEMENTED if n in mine or n not in ref]
     assert not stale, f"NOT_IMPLEMENTED entries that are implemented or no longer upstream: {stale}"
     assert len([n for n in ref if n in mine]) >= 55
+
+
+PYDAFOAM_NOT_IMPLEMENTED = {
+    "_solverRegistry": "module-level table of OpenFOAM solver names of the Cython build",
+    "_initializeOptions": "option initialisation lives in __init__ / _initOption here",
+    "_initializeComm": "MPI communicator set-up: one process per GPU is launched by torch.distributed (dafoam_amd/distributed.py)",
+    "_readOFGrid": "polyMesh reader of the OpenFOAM case directory: dafoam_amd.foam_io.read_polymesh",
+    "_writeDecomposeParDict": "decomposePar front end: the mesh is partitioned in memory (dafoam_amd/distributed.py)",
+    "_writeOpenFoamHeader": "decomposePar front end",
+    "runDecomposePar": "decomposePar front end: ShardedAdjointGeneral.scattered() partitions in memory",
+    "deletePrevPrimalSolTime": "time-directory housekeeping of the OpenFOAM front end",
+    "renameSolution": "time-directory housekeeping of the OpenFOAM front end",
+    "deformDynamicMesh": "unsteady dynamic-mesh cases - outside the hot path",
+    "readDynamicMeshPoints": "unsteady dynamic-mesh cases - outside the hot path",
+    "calcFFD2XvSeeds": "forward-mode (ADF build) seeds through pyGeo / IDWarp - the ADF build is not mirrored",
+    "setPrimalInitialConditions": "primalInitCondition option of the OpenFOAM front end: states arrive through the FoamCase / setStates",
+    "getNRegressionParameters": "regression models (DARegression) - outside the hot path",
+}
+
+
+def test_pydafoam_api_surface():
+    """Every method of the reference's PYDAFOAM class (dafoam/pyDAFoam.py) is provided by dafoam_amd.pyDAFoam.PYDAFOAM under the
+    same name or listed in PYDAFOAM_NOT_IMPLEMENTED with the reason."""
+    from dafoam_amd.pyDAFoam import PYDAFOAM
+
+    tree = ast.parse(open(os.path.join(REF, "dafoam", "pyDAFoam.py")).read())
+    ref = [f.name for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "PYDAFOAM" for f in c.body if isinstance(f, ast.FunctionDef)]
+    assert len(ref) >= 45
+    mine = set(dir(PYDAFOAM))
+    missing = [n for n in ref if n not in mine and n not in PYDAFOAM_NOT_IMPLEMENTED]
+    assert not missing, f"reference methods neither implemented nor listed: {missing}"
+    stale = [n for n in PYDAFOAM_NOT_IMPLEMENTED if n in mine or n not in ref]
+    assert not stale, stale
