@@ -244,19 +244,24 @@ struct Options {
 };
 
 // ---- face / cell records as consumed by the kernels (AoS records, fully consumed per access) ----
-struct FaceGeom {      // 12 doubles = 96 B per face
-    double Sf[3];      // area vector owner -> neighbour (outward on boundary)
-    double magSf;
-    double w;          // linear interpolation weight of the owner value (1 on boundary)
-    double nod;        // nonOrthDeltaCoeffs (boundary: deltaCoeffs = 1/|Cf - C|)
-    double corr[3];    // nonOrthCorrectionVectors (0 on boundary)
-    double Cf[3];
+// (templated on the scalar: double everywhere except in the mesh-sensitivity pass, where the metrics carry tangents - Dual<1>)
+template <class G>
+struct FaceGeomT {     // 12 scalars (double: 96 B per face)
+    G Sf[3];           // area vector owner -> neighbour (outward on boundary)
+    G magSf;
+    G w;               // linear interpolation weight of the owner value (1 on boundary)
+    G nod;             // nonOrthDeltaCoeffs (boundary: deltaCoeffs = 1/|Cf - C|)
+    G corr[3];         // nonOrthCorrectionVectors (0 on boundary)
+    G Cf[3];
 };
-struct CellGeom {  // 5 doubles
-    double C[3];
-    double V;
-    double y;  // frozen wall distance
+template <class G>
+struct CellGeomT {  // 5 scalars
+    G C[3];
+    G V;
+    G y;  // frozen wall distance
 };
+typedef FaceGeomT<double> FaceGeom;
+typedef CellGeomT<double> CellGeom;
 
 struct PatchBC {  // per patch, small table
     int type;

@@ -38,25 +38,25 @@ namespace das {
 // tiles of individually sorted cells every kernel got 25-40 % slower (13-cell runs: partial lines); with 64-cell memory runs as the
 // unit the assembly of dRdWT took 1.26 s against 1.19 s in the natural order.  The k+-1 neighbours that miss the 4 MB L2 are served
 // by the 256 MB Infinity Cache; the kernels already run at ~5.5 TB/s of their FETCH_SIZE traffic.)
-template <class T, bool RHO>
-__global__ __launch_bounds__(256) void k_grad(DevMesh m, ResParams prm, const T* __restrict__ W, T* nut, T* gU, T* gP, T* gN, T* gH) {
+template <class T, bool RHO, class G = double>
+__global__ __launch_bounds__(256) void k_grad(DevMeshT<G> m, ResParams prm, const T* __restrict__ W, T* nut, T* gU, T* gP, T* gN, T* gH) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_grad<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, (T*)prm.wTU);
 }
-template <class T, bool RHO>
-__global__ __launch_bounds__(256) void k_cell(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gU, const T* gP,
+template <class T, bool RHO, class G = double>
+__global__ __launch_bounds__(256) void k_cell(DevMeshT<G> m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gU, const T* gP,
                                               const T* gN, const T* gH, T* R, T* rAU, T* HbyA) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_cell<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, R, rAU, HbyA, (const T*)prm.wTU);
 }
-template <class T, bool RHO>
-__global__ __launch_bounds__(256) void k_face(DevMesh m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gP, const T* rAU,
+template <class T, bool RHO, class G = double>
+__global__ __launch_bounds__(256) void k_face(DevMeshT<G> m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gP, const T* rAU,
                                               const T* HbyA, T* q, T* R) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < m.nF) body_face<T, RHO>(f, m, prm, W, nut, gP, rAU, HbyA, q, R);
 }
-template <class T, bool RHO>
-__global__ __launch_bounds__(256) void k_pres(DevMesh m, ResParams prm, const T* q, T* R) {
+template <class T, bool RHO, class G = double>
+__global__ __launch_bounds__(256) void k_pres(DevMeshT<G> m, ResParams prm, const T* q, T* R) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_pres<T, RHO>(c, m, prm, q, R);
 }

@@ -104,7 +104,11 @@ template <int K> DAS_HD Dual<K>& operator*=(Dual<K>& a, double b) { a = a * b; r
 // value with a prescribed first tangent (forward-mode seeding of parameters, e.g. boundary values)
 template <class T> struct MkSeed;
 template <> struct MkSeed<double> { static DAS_HD double make(double v, double) { return v; } };
-template <int K> struct MkSeed<Dual<K>> { static DAS_HD Dual<K> make(double v, double dv) { Dual<K> r(v); r.d[0] = dv; return r; } };
+template <int K> struct MkSeed<Dual<K>> {
+    static DAS_HD Dual<K> make(double v, double dv) { Dual<K> r(v); r.d[0] = dv; return r; }
+    // the value may carry tangents itself (a patch velocity computed from perturbed metrics): the seed is added to them
+    static DAS_HD Dual<K> make(const Dual<K>& v, double dv) { Dual<K> r = v; r.d[0] += dv; return r; }
+};
 
 // elementary functions (generic names usable with double as well)
 DAS_HD double dsqrt(double a) { return sqrt(a); }

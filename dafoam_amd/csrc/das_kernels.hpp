@@ -27,10 +27,11 @@
 
 namespace das {
 
-struct DevMesh {
+template <class G>
+struct DevMeshT {  // G: the scalar of the metrics (double; Dual<1> in the mesh-sensitivity pass)
     int nC, nF, nIF;
-    const FaceGeom* fg;
-    const CellGeom* cg;
+    const FaceGeomT<G>* fg;
+    const CellGeomT<G>* cg;
     const int* cf_ptr;
     const int* cf_face;
     const int* cf_other;
@@ -40,6 +41,7 @@ struct DevMesh {
     const PatchBC* bc;
     const int* cyc;     // boundary face -> paired face of a cyclic pair, -1 otherwise
 };
+typedef DevMeshT<double> DevMesh;
 
 struct ResParams {
     double nu, alphaU, alphaN, DT, deltaT;
@@ -73,15 +75,17 @@ DAS_HD T mu_of(const ResParams& prm, const T& Tk) {
 }
 
 // Omega x (x - origin)
-DAS_HD void mrf_velocity(const ResParams& prm, const double* x, double* v) {
-    const double r0 = x[0] - prm.org[0], r1 = x[1] - prm.org[1], r2 = x[2] - prm.org[2];
+template <class G>
+DAS_HD void mrf_velocity(const ResParams& prm, const G* x, G* v) {
+    const G r0 = x[0] - prm.org[0], r1 = x[1] - prm.org[1], r2 = x[2] - prm.org[2];
     v[0] = prm.om[1] * r2 - prm.om[2] * r1;
     v[1] = prm.om[2] * r0 - prm.om[0] * r2;
     v[2] = prm.om[0] * r1 - prm.om[1] * r0;
 }
 // (Omega x (Cf - origin)) . Sf : what makeRelative subtracts per unit density
-DAS_HD double mrf_face_flux(const ResParams& prm, const FaceGeom& g) {
-    double v[3];
+template <class G>
+DAS_HD G mrf_face_flux(const ResParams& prm, const FaceGeomT<G>& g) {
+    G v[3];
     mrf_velocity(prm, g.Cf, v);
     return v[0] * g.Sf[0] + v[1] * g.Sf[1] + v[2] * g.Sf[2];
 }
@@ -121,7 +125,8 @@ DAS_HD void rot_ten(const double* Q, T* g) {  // g[3i+j] = d_i U_j  ->  Q g Q^T
         for (int j = 0; j < 3; j++) g[3 * i + j] = t[3 * i] * Q[3 * j] + t[3 * i + 1] * Q[3 * j + 1] + t[3 * i + 2] * Q[3 * j + 2];
 }
 // the rotation of the cyclic patch of boundary face f, or null (internal faces, translational pairs)
-DAS_HD const double* cyclic_rotation(const DevMesh& m, int f) {
+template <class G>
+DAS_HD const double* cyclic_rotation(const DevMeshT<G>& m, int f) {
     if (f < m.nIF) return nullptr;
     const PatchBC& pb = m.bc[m.bpatch[f - m.nIF]];
     return pb.rot ? pb.Q : nullptr;
@@ -134,14 +139,14 @@ DAS_HD T fv1_of(const T& chi) {
 }
 
 // ---- patch-field coefficients: x_b = vic*x_c + vbc ; snGrad_b = gic*x_c + gbc ---------------------
-template <class T>
+template <class T, class G = double>
 struct ScalarBC {
     T xb;
-    double vic, gic;
+    G vic, gic;
     T vbc, gbc;  // carry the tangent of the patch value (dR/d(BC value) seeds)
 };
-template <class T>
-DAS_HD void bc_scalar(int code, double value, double dvalue, double delta, double phib, const T& xc, ScalarBC<T>& o) {
+template <class T, class G>
+DAS_HD void bc_scalar(int code, double value, double dvalue, const G& delta, double phib, const T& xc, ScalarBC<T, G>& o) {
     double f = 0.0;
     if (code == DAS_BC_FIXED_VALUE) f = 1.0;
     else if (code == DAS_BC_INLET_OUTLET) f = phib >= 0.0 ? 0.0 : 1.0;
@@ -152,20 +157,20 @@ DAS_HD void bc_scalar(int code, double value, double dvalue, double delta, doubl
     o.gbc = (f * delta) * val;
     o.xb = o.vic * xc + o.vbc;
 }
-template <class T>
+template <class T, class G = double>
 struct VectorBC {
     T xb[3];
-    double vic[3], gic[3];
+    G vic[3], gic[3];
     T vbc[3], gbc[3];
 };
-template <class T>
-DAS_HD void bc_vector(int code, const double* value, const double* dvalue, double delta, double phib, const double* n, const T* Xc, VectorBC<T>& o) {
+template <class T, class G, class V>
+DAS_HD void bc_vector(int code, const V* value, const double* dvalue, const G& delta, double phib, const G* n, const T* Xc, VectorBC<T, G>& o) {
     if (code == DAS_BC_SYMMETRY) {
         // basicSymmetry/transformFvPatchField: x_b = X - n (n.X); snGradTransformDiag = |n|
         T nX = n[0] * Xc[0] + n[1] * Xc[1] + n[2] * Xc[2];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            double sd = fabs(n[k]);
+            G sd = dabs(n[k]);
             o.xb[k] = Xc[k] - n[k] * nX;
             o.vic[k] = 1.0 - sd;
             o.vbc[k] = o.xb[k] - o.vic[k] * Xc[k];
@@ -194,7 +199,7 @@ DAS_HD void bc_vector(int code, const double* value, const double* dvalue, doubl
 // the implicit-function derivative.
 #define DAS_SPALDING_MAXITER 1000
 template <class T>
-DAS_HD T spalding_nut(const T& magUp, const T& magGradU, double y, const T& nu) {
+DAS_HD T spalding_nut(const T& magUp, const T& magGradU, const T& y, const T& nu) {
     const double kappa = 0.41, E = 9.8;
     T ut = dsqrt(nu * magGradU);
     if (!(val(ut) > DAS_ROOTVSMALL)) return T(0.0);
@@ -212,25 +217,25 @@ DAS_HD T spalding_nut(const T& magUp, const T& magGradU, double y, const T& nu) 
     return dmax(ut * ut / (magGradU + DAS_ROOTVSMALL) - nu, 0.0);
 }
 
-template <class T>
+template <class T, class G = double>
 struct BFace {
-    VectorBC<T> U;
-    ScalarBC<T> p, n;
-    ScalarBC<T> Tt, he;  // compressible only
+    VectorBC<T, G> U;
+    ScalarBC<T, G> p, n;
+    ScalarBC<T, G> Tt, he;  // compressible only
     T rho_b, nu_b, mu_b;  // compressible only (incompressible: rho_b = 1, nu_b = nu)
     T nut_b;
-    double nrm[3];
+    G nrm[3];
 };
 
 // evaluate all patch fields of one boundary face from the owner cell's values
-template <class T, bool RHO>
-DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc, const ResParams& prm, const T* Uc, const T& pc,
-                       const T& Tc, const T& nc, const T& nut_c, double phib, BFace<T>& o) {
+template <class T, bool RHO, class G>
+DAS_HD void eval_bface(const PatchBC& bc, const FaceGeomT<G>& g, const CellGeomT<G>& cgc, const ResParams& prm, const T* Uc, const T& pc,
+                       const T& Tc, const T& nc, const T& nut_c, double phib, BFace<T, G>& o) {
 #pragma unroll
     for (int k = 0; k < 3; k++) o.nrm[k] = g.Sf[k] / g.magSf;
     if (prm.mrf && bc.mrf_included && bc.U_code == DAS_BC_FIXED_VALUE) {
         // MRFZone::correctBoundaryVelocity: fixedValue patches that rotate with the zone carry Omega x r
-        double uw[3];
+        G uw[3];
         const double zero[3] = {0.0, 0.0, 0.0};
         mrf_velocity(prm, g.Cf, uw);
         bc_vector<T>(bc.U_code, uw, zero, g.nod, phib, o.nrm, Uc, o.U);
@@ -260,7 +265,7 @@ DAS_HD void eval_bface(const PatchBC& bc, const FaceGeom& g, const CellGeom& cgc
         T d0 = Uc[0] - o.U.xb[0], d1 = Uc[1] - o.U.xb[1], d2 = Uc[2] - o.U.xb[2];
         T magUp = dsqrt(d0 * d0 + d1 * d1 + d2 * d2);
         T magGradU = magUp * g.nod;
-        double yw = fabs((g.Cf[0] - cgc.C[0]) * o.nrm[0] + (g.Cf[1] - cgc.C[1]) * o.nrm[1] + (g.Cf[2] - cgc.C[2]) * o.nrm[2]);
+        const T yw = dabs((g.Cf[0] - cgc.C[0]) * o.nrm[0] + (g.Cf[1] - cgc.C[1]) * o.nrm[1] + (g.Cf[2] - cgc.C[2]) * o.nrm[2]);
         o.nut_b = spalding_nut<T>(magUp, magGradU, yw, o.nu_b);
     } else {
         o.nut_b = o.n.xb * fv1_of<T>(o.n.xb / o.nu_b);
@@ -286,11 +291,11 @@ DAS_HD void teff_dot_u(const T* g, const T& muEff, const T* U, T* q) {
 
 // ================================================================================ k_grad
 // per cell: nut = nuTilda*fv1 ; Gauss-linear gradients of U, p, nuTilda (and he = Cp (T - Tref) when RHO)
-template <class T, bool RHO>
-DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W, T* nut, T* gradU, T* gradP, T* gradN, T* gradH,
+template <class T, bool RHO, class G>
+DAS_HD void body_grad(int c, const DevMeshT<G>& m, const ResParams& prm, const T* W, T* nut, T* gradU, T* gradP, T* gradN, T* gradH,
                       T* TU = nullptr) {
     const long long N = m.nC;
-    const CellGeom& cgc = m.cg[c];
+    const CellGeomT<G>& cgc = m.cg[c];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
     T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
     const bool energy = RHO || prm.hasT;  // an energy-like scalar with a gradient (he, or the passive T)
@@ -307,12 +312,12 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
         int fe = m.cf_face[s];
         int f = fe & 0x7fffffff;
         bool nb = fe < 0;
-        const FaceGeom& g = m.fg[f];
+        const FaceGeomT<G>& g = m.fg[f];
         T Uf[3], pf, nf, hf(0.0);
         double sg = nb ? -1.0 : 1.0;
         if (m.cf_other[s] >= 0) {  // internal face, or a cyclic boundary face (the paired cell acts as the neighbour)
             int o = m.cf_other[s];
-            double wc = nb ? 1.0 - g.w : g.w;
+            G wc = nb ? G(1.0 - g.w) : g.w;
             T Uo[3] = {W[3LL * o], W[3LL * o + 1], W[3LL * o + 2]};
             const double* Qr = cyclic_rotation(m, f);
             if (Qr) rot_vec<T>(Qr, Uo);
@@ -323,7 +328,7 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
             if (RHO) hf = prm.Cp * (wc * Tc + (1.0 - wc) * W[prm.offT * N + o] - DAS_TREF);
             else if (energy) hf = wc * Tc + (1.0 - wc) * W[prm.offT * N + o];
         } else {
-            BFace<T> b;
+            BFace<T, G> b;
             eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, cgc, prm, Uc, pc, Tc, nc, nut_c, val(W[prm.offPhi * N + f]), b);
 #pragma unroll
             for (int k = 0; k < 3; k++) Uf[k] = b.U.xb[k];
@@ -333,7 +338,7 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
         }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            double S = sg * g.Sf[i];
+            G S = sg * g.Sf[i];
 #pragma unroll
             for (int j = 0; j < 3; j++) gU[3 * i + j] += S * Uf[j];
             gP[i] += S * pf;
@@ -341,7 +346,7 @@ DAS_HD void body_grad(int c, const DevMesh& m, const ResParams& prm, const T* W,
             if (energy) gH[i] += S * hf;
         }
     }
-    double rV = 1.0 / cgc.V;
+    G rV = 1.0 / cgc.V;
 #pragma unroll
     for (int k = 0; k < 9; k++) gradU[9LL * c + k] = gU[k] * rV;
 #pragma unroll
@@ -378,11 +383,11 @@ DAS_HD void dev2T_scaled(const T* g, const T& nuEff, T* tau) {
 // ================================================================================ k_cell
 // per cell: U-equation (diag/off-diag/source incl. boundary coeffs), relax, URes, rAU, HbyA, the SA residual and
 // (RHO) the energy residual TRes = EEqn & he.  RHO: phi is the mass flux, muEff = mu + rho nut replaces nuEff.
-template <class T, bool RHO>
-DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const T* gradP,
+template <class T, bool RHO, class G>
+DAS_HD void body_cell(int c, const DevMeshT<G>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const T* gradP,
                       const T* gradN, const T* gradH, T* R, T* rAU, T* HbyA, const T* TU = nullptr) {
     const long long N = m.nC;
-    const CellGeom& cgc = m.cg[c];
+    const CellGeomT<G>& cgc = m.cg[c];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
     T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
     const bool energy = RHO || prm.hasT;  // energy equation (RHO) or the passive T equation of DASimpleFoam
@@ -407,7 +412,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
 
     const bool turbo = RHO && prm.turbo;
     const bool mrf = prm.mrf != 0;
-    double vC_c[3] = {0.0, 0.0, 0.0};
+    G vC_c[3] = {G(0.0), G(0.0), G(0.0)};
     if (mrf) mrf_velocity(prm, cgc.C, vC_c);
     T D0(0.0), sumOff(0.0), sumPhi(0.0), vmaxs(0.0), vmins(0.0);
     T offU[3], src[3], bdiag[3], bsrc[3];
@@ -420,12 +425,12 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
         int fe = m.cf_face[s];
         int f = fe & 0x7fffffff;
         bool nb = fe < 0;
-        const FaceGeom& g = m.fg[f];
+        const FaceGeomT<G>& g = m.fg[f];
         T phi = W[prm.offPhi * N + f];
         double sg = nb ? -1.0 : 1.0;
         if (m.cf_other[s] >= 0) {  // internal face, or a cyclic boundary face (the paired cell acts as the neighbour)
             int o = m.cf_other[s];
-            const CellGeom& cgo = m.cg[o];
+            const CellGeomT<G>& cgo = m.cg[o];
             double pv = val(phi);
             double wu = pv >= 0.0 ? 1.0 : 0.0;  // upwind weight of the owner value = pos0(flux)
             T dcoef, off;
@@ -449,8 +454,8 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
             for (int k = 0; k < 9; k++) gUo[k] = gradU[9LL * o + k];
             T gNo[3] = {gradN[3LL * o], gradN[3LL * o + 1], gradN[3LL * o + 2]};
             if (Qr) { rot_ten<T>(Qr, gUo); rot_vec<T>(Qr, gNo); }
-            const double wl = g.w;
-            const double wc = nb ? 1.0 - wl : wl, wo = 1.0 - wc;
+            const G wl = g.w;
+            const G wc = nb ? G(1.0 - wl) : wl, wo = 1.0 - wc;
             // ---- momentum diffusion  -fvm::laplacian(rho nuEff,U)  (Gauss linear corrected)
             T gam = (wc * muEff_c + wo * muEff_o) * g.magSf;
             T cd = gam * g.nod;
@@ -464,12 +469,12 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 bool pos = pv > 0.0;
                 bool upIsC = (pos != nb);  // upwind cell is the owner when flux > 0
                 const T* gUp = upIsC ? gUc : gUo;
-                const double* Cup = upIsC ? cgc.C : cgo.C;
-                double d[3] = {g.Cf[0] - Cup[0], g.Cf[1] - Cup[1], g.Cf[2] - Cup[2]};
+                const G* Cup = upIsC ? cgc.C : cgo.C;
+                G d[3] = {g.Cf[0] - Cup[0], g.Cf[1] - Cup[1], g.Cf[2] - Cup[2]};
                 if (f >= m.nIF && !upIsC) {  // cyclic: the neighbour's face-centre offset lives at the paired face
-                    const FaceGeom& g2 = m.fg[m.cyc[f - m.nIF]];
+                    const FaceGeomT<G>& g2 = m.fg[m.cyc[f - m.nIF]];
                     d[0] = g2.Cf[0] - cgo.C[0]; d[1] = g2.Cf[1] - cgo.C[1]; d[2] = g2.Cf[2] - cgo.C[2];
-                    if (Qr) rot_vec<double>(Qr, d);
+                    if (Qr) rot_vec<G>(Qr, d);
                 }
                 T corr[3], mx[3];
 #pragma unroll
@@ -540,9 +545,9 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                            + g.Sf[2] * (wc * TU[3LL * c + 2] + wo * TUo[2]);
                     sE += sg * qf;
                     if (mrf) {
-                        double vC_o[3];
+                        G vC_o[3];
                         mrf_velocity(prm, cgo.C, vC_o);
-                        if (Qr) rot_vec<double>(Qr, vC_o);
+                        if (Qr) rot_vec<G>(Qr, vC_o);
                         T p_o = W[prm.offP * N + o];
                         T wf = g.Sf[0] * (wc * (pc * vC_c[0]) + wo * (p_o * vC_o[0])) + g.Sf[1] * (wc * (pc * vC_c[1]) + wo * (p_o * vC_o[1]))
                                + g.Sf[2] * (wc * (pc * vC_c[2]) + wo * (p_o * vC_o[2]));
@@ -551,7 +556,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                 }
             }
         } else {
-            BFace<T> b;
+            BFace<T, G> b;
             double pv = val(phi);
             eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, cgc, prm, Uc, pc, Tc, nc, nut_c, pv, b);
             sumPhi += phi;
@@ -608,7 +613,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
                         T wb[3];
                         if (pb_.mrf_included) { wb[0] = b.U.xb[0]; wb[1] = b.U.xb[1]; wb[2] = b.U.xb[2]; }
                         else {
-                            double vF[3];
+                            G vF[3];
                             mrf_velocity(prm, g.Cf, vF);
                             wb[0] = T(vF[0]); wb[1] = T(vF[1]); wb[2] = T(vF[2]);
                         }
@@ -630,7 +635,7 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
     // fvMatrix::relax (see DESIGN.md "relax"): diagonal dominance fix-up with boundary max/min contributions
     T D = dmax(dabs(D0 + vmaxs), sumOff) * (1.0 / prm.alphaU) - vmins;
     T dD = D - D0;
-    const double rV = 1.0 / cgc.V;
+    const G rV = 1.0 / cgc.V;
     T avgb = (bdiag[0] + bdiag[1] + bdiag[2]) * (1.0 / 3.0);
     T A = (D + avgb) * rV;
     T rA = 1.0 / A;
@@ -651,8 +656,8 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
         R[prm.offT * N + c] = tres;
     }
     // ---- SA source terms (DASpalartAllmaras.C:124-178,445-485)
-    const double y = cgc.y;
-    const double k2y2 = (SA_KAPPA * y) * (SA_KAPPA * y);
+    const G y = cgc.y;
+    const G k2y2 = (SA_KAPPA * y) * (SA_KAPPA * y);
     T chi = nc / nu_c;
     T fv1 = fv1_of<T>(chi);
     T fv2 = 1.0 - chi / (1.0 + chi * fv1);
@@ -677,21 +682,21 @@ DAS_HD void body_cell(int c, const DevMesh& m, const ResParams& prm, const T* W,
 
 // ================================================================================ k_face
 // per face: phiHbyA, pressure flux, q = flux - phiHbyA (consumed by k_pres) and phiRes
-template <class T, bool RHO>
-DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradP, const T* rAU,
+template <class T, bool RHO, class G>
+DAS_HD void body_face(int f, const DevMeshT<G>& m, const ResParams& prm, const T* W, const T* nut, const T* gradP, const T* rAU,
                       const T* HbyA, T* q, T* R) {
     const long long N = m.nC;
-    const FaceGeom& g = m.fg[f];
+    const FaceGeomT<G>& g = m.fg[f];
     T phiHbyA, flux;
     const bool turbo = RHO && prm.turbo;
-    const double rel = prm.mrf ? mrf_face_flux(prm, g) : 0.0;
+    const G rel = prm.mrf ? mrf_face_flux(prm, g) : G(0.0);
     if (turbo) {
         // DAResidualTurboFoam.C:146-212.  "phiHbyA" below is what enters div(): phiHbyA (+ SIMPLEC correction), or the
         // convective flux phid_f p_upwind of fvm::div(phid,p) in the transonic form.
         T snGradP, rho_f;
         if (f < m.nIF || m.cyc[f - m.nIF] >= 0) {  // internal or cyclic face
             int o = m.owner[f], n = f < m.nIF ? m.neigh[f] : m.owner[m.cyc[f - m.nIF]];
-            const double wl = g.w, wn = 1.0 - g.w;
+            const G wl = g.w, wn = 1.0 - g.w;
             T po = W[prm.offP * N + o], pn = W[prm.offP * N + n];
             T psio = 1.0 / (prm.Rgas * W[prm.offT * N + o]), psin = 1.0 / (prm.Rgas * W[prm.offT * N + n]);
             T ro = po * psio, rn = pn * psin;
@@ -723,7 +728,7 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
             const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
             T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
             T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c], Tc = W[prm.offT * N + c];
-            BFace<T> b;
+            BFace<T, G> b;
             eval_bface<T, RHO>(bc, g, m.cg[c], prm, Uc, pc, Tc, nc, nut[c], val(W[prm.offPhi * N + f]), b);
             T Hb[3] = {HbyA[3LL * c], HbyA[3LL * c + 1], HbyA[3LL * c + 2]};
             if (bc.U_code == DAS_BC_SYMMETRY) {
@@ -758,7 +763,7 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
     }
     if (f < m.nIF || m.cyc[f - m.nIF] >= 0) {  // internal or cyclic face
         int o = m.owner[f], n = f < m.nIF ? m.neigh[f] : m.owner[m.cyc[f - m.nIF]];
-        const double wl = g.w, wn = 1.0 - g.w;
+        const G wl = g.w, wn = 1.0 - g.w;
         T gPn[3] = {gradP[3LL * n], gradP[3LL * n + 1], gradP[3LL * n + 2]};
         T Hn[3] = {HbyA[3LL * n], HbyA[3LL * n + 1], HbyA[3LL * n + 2]};
         const double* Qr = cyclic_rotation(m, f);
@@ -782,7 +787,7 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
         T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
         T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
         T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
-        BFace<T> b;
+        BFace<T, G> b;
         eval_bface<T, RHO>(bc, g, m.cg[c], prm, Uc, pc, Tc, nc, nut[c], val(W[prm.offPhi * N + f]), b);
         T Hb[3] = {HbyA[3LL * c], HbyA[3LL * c + 1], HbyA[3LL * c + 2]};
         if (bc.U_code == DAS_BC_SYMMETRY) {
@@ -806,8 +811,8 @@ DAS_HD void body_face(int f, const DevMesh& m, const ResParams& prm, const T* W,
 
 // ================================================================================ k_pres
 // incompressible: pRes = (laplacian(rAU,p) - div(phiHbyA))/V = sum(q)/V ; compressible: pEqn = div(phiHbyA) - laplacian -> -sum(q)/V
-template <class T, bool RHO>
-DAS_HD void body_pres(int c, const DevMesh& m, const ResParams& prm, const T* q, T* R) {
+template <class T, bool RHO, class G>
+DAS_HD void body_pres(int c, const DevMeshT<G>& m, const ResParams& prm, const T* q, T* R) {
     const long long N = m.nC;
     T s(0.0);
     for (int k = m.cf_ptr[c]; k < m.cf_ptr[c + 1]; k++) {
@@ -825,15 +830,15 @@ DAS_HD void body_pres(int c, const DevMesh& m, const ResParams& prm, const T* q,
 // DAFunctionForce::calcFunction (reference src/adjoint/DAFunction/DAFunctionForce.C:79-158) for one boundary face:
 //   F_f = scale * ( S_f p_b + S_f . devRhoReff_b ) . dir,  devRhoReff = (-rho nuEff) dev(twoSymm(grad U))
 //   (reference DATurbulenceModel.C:360-376), boundary field from the boundary values of nuEff, rho and grad(U).
-template <class T, bool RHO>
-DAS_HD T body_force(int f, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const double* dir, double scale) {
+template <class T, bool RHO, class G>
+DAS_HD T body_force(int f, const DevMeshT<G>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const double* dir, double scale) {
     const long long N = m.nC;
-    const FaceGeom& g = m.fg[f];
+    const FaceGeomT<G>& g = m.fg[f];
     const int c = m.owner[f];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
     T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
     T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
-    BFace<T> b;
+    BFace<T, G> b;
     eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, m.cg[c], prm, Uc, pc, Tc, nc, nut[c], val(W[prm.offPhi * N + f]), b);
     T gUb[9], dsn[3];
 #pragma unroll
@@ -876,17 +881,17 @@ DAS_HD T body_force(int f, const DevMesh& m, const ResParams& prm, const T* W, c
 #define DAS_FN_MASSFLOW 1
 #define DAS_FN_TOTALPRESSURE 2
 #define DAS_FN_TOTALTEMPERATURE 3
-template <class T, bool RHO>
-DAS_HD T body_facefn(int f, const DevMesh& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, int kind, const double* dir,
+template <class T, bool RHO, class G>
+DAS_HD T body_facefn(int f, const DevMeshT<G>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, int kind, const double* dir,
                      double gammaFn, double RFn) {
     if (kind == DAS_FN_FORCE) return body_force<T, RHO>(f, m, prm, W, nut, gradU, dir, 1.0);
     const long long N = m.nC;
-    const FaceGeom& g = m.fg[f];
+    const FaceGeomT<G>& g = m.fg[f];
     const int c = m.owner[f];
     T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
     T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c];
     T Tc = RHO ? W[prm.offT * N + c] : T(0.0);
-    BFace<T> b;
+    BFace<T, G> b;
     eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, m.cg[c], prm, Uc, pc, Tc, nc, nut[c], val(W[prm.offPhi * N + f]), b);
     T U2 = b.U.xb[0] * b.U.xb[0] + b.U.xb[1] * b.U.xb[1] + b.U.xb[2] * b.U.xb[2];
     if (kind == DAS_FN_MASSFLOW) return b.rho_b * (b.U.xb[0] * g.Sf[0] + b.U.xb[1] * g.Sf[1] + b.U.xb[2] * g.Sf[2]);
@@ -896,47 +901,47 @@ DAS_HD T body_facefn(int f, const DevMesh& m, const ResParams& prm, const T* W, 
 }
 
 // ================================================================================ DAScalarTransportFoam
-template <class T>
-DAS_HD void body_gradT(int c, const DevMesh& m, const ResParams& prm, const T* W, const double* phiF, T* gradT) {
-    const CellGeom& cgc = m.cg[c];
+template <class T, class G>
+DAS_HD void body_gradT(int c, const DevMeshT<G>& m, const ResParams& prm, const T* W, const double* phiF, T* gradT) {
+    const CellGeomT<G>& cgc = m.cg[c];
     T Tc = W[c];
     T gT[3] = {T(0.0), T(0.0), T(0.0)};
     for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
         int fe = m.cf_face[s];
         int f = fe & 0x7fffffff;
         bool nb = fe < 0;
-        const FaceGeom& g = m.fg[f];
+        const FaceGeomT<G>& g = m.fg[f];
         double sg = nb ? -1.0 : 1.0;
         T Tf;
         if (f < m.nIF) {
-            double wc = nb ? 1.0 - g.w : g.w;
+            G wc = nb ? G(1.0 - g.w) : g.w;
             Tf = wc * Tc + (1.0 - wc) * W[m.cf_other[s]];
         } else {
             const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
-            ScalarBC<T> b;
+            ScalarBC<T, G> b;
             bc_scalar<T>(bc.T_code, bc.T_val, bc.dT_val, g.nod, phiF[f], Tc, b);
             Tf = b.xb;
         }
 #pragma unroll
         for (int i = 0; i < 3; i++) gT[i] += (sg * g.Sf[i]) * Tf;
     }
-    double rV = 1.0 / cgc.V;
+    G rV = 1.0 / cgc.V;
 #pragma unroll
     for (int i = 0; i < 3; i++) gradT[3LL * c + i] = gT[i] * rV;
 }
 
 // TRes = (ddt(T) + div(phi,T) - laplacian(DT,T)) & T   (Euler, Gauss upwind, Gauss linear corrected)
-template <class T>
-DAS_HD void body_T(int c, const DevMesh& m, const ResParams& prm, const T* W, const double* phiF, const double* Told,
+template <class T, class G>
+DAS_HD void body_T(int c, const DevMeshT<G>& m, const ResParams& prm, const T* W, const double* phiF, const double* Told,
                    const T* gradT, T* R) {
-    const CellGeom& cgc = m.cg[c];
+    const CellGeomT<G>& cgc = m.cg[c];
     T Tc = W[c];
     T d(0.0), off(0.0), sS(0.0), bd(0.0), bs(0.0);
     for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
         int fe = m.cf_face[s];
         int f = fe & 0x7fffffff;
         bool nb = fe < 0;
-        const FaceGeom& g = m.fg[f];
+        const FaceGeomT<G>& g = m.fg[f];
         double sg = nb ? -1.0 : 1.0;
         double phi = phiF[f];
         if (f < m.nIF) {
@@ -945,24 +950,24 @@ DAS_HD void body_T(int c, const DevMesh& m, const ResParams& prm, const T* W, co
             double dcoef, offc;
             if (!nb) { dcoef = wu * phi; offc = (1.0 - wu) * phi; }
             else { dcoef = -(1.0 - wu) * phi; offc = -wu * phi; }
-            double gam = prm.DT * g.magSf;
-            double cd = gam * g.nod;
+            G gam = prm.DT * g.magSf;
+            G cd = gam * g.nod;
             d += dcoef + cd;
             off += (offc - cd) * W[o];
-            double wc = nb ? 1.0 - g.w : g.w, wo = 1.0 - wc;
+            G wc = nb ? G(1.0 - g.w) : g.w, wo = 1.0 - wc;
             T cv = g.corr[0] * (wc * gradT[3LL * c] + wo * gradT[3LL * o]) + g.corr[1] * (wc * gradT[3LL * c + 1] + wo * gradT[3LL * o + 1])
                    + g.corr[2] * (wc * gradT[3LL * c + 2] + wo * gradT[3LL * o + 2]);
             sS += (sg * gam) * cv;
         } else {
             const PatchBC& bc = m.bc[m.bpatch[f - m.nIF]];
-            ScalarBC<T> b;
+            ScalarBC<T, G> b;
             bc_scalar<T>(bc.T_code, bc.T_val, bc.dT_val, g.nod, phi, Tc, b);
-            double gam_b = prm.DT * g.magSf;
+            G gam_b = prm.DT * g.magSf;
             bd += phi * b.vic - gam_b * b.gic;
             bs += gam_b * b.gbc - phi * b.vbc;
         }
     }
-    double rdt = cgc.V / prm.deltaT;
+    G rdt = cgc.V / prm.deltaT;
     d += rdt;
     sS += rdt * Told[c];
     T res = ((d + bd) * Tc + off - sS - bs) * (1.0 / cgc.V);

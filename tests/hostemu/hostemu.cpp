@@ -5,9 +5,14 @@
 
 using namespace das;
 
+template <class T, class MV>
+static void eval_on(const MV& m, const CaseParams& cp, const ResParams& prm, const std::vector<T>& W, std::vector<T>& R);
 template <class T>
 static void eval(const Mesh& mesh, const CaseParams& cp, const ResParams& prm, const std::vector<T>& W, std::vector<T>& R) {
-    DevMesh m = host_view(mesh);
+    eval_on<T>(host_view(mesh), cp, prm, W, R);
+}
+template <class T, class MV>
+static void eval_on(const MV& m, const CaseParams& cp, const ResParams& prm, const std::vector<T>& W, std::vector<T>& R) {
     const long long N = m.nC;
     if (cp.solver == DAS_SOLVER_SIMPLEFOAM) {
         std::vector<T> nut(N), gU(9 * N), gP(3 * N), gN(3 * N), gH(3 * N), rAU(N), HbyA(3 * N), q(m.nF);
@@ -101,6 +106,44 @@ extern "C" int emu_residual_field(const das_case_t* c, const double* Win, long l
         return 0;
     } catch (const std::exception& e) {
         fprintf(stderr, "emu_residual_field: %s\n", e.what());
+        return -1;
+    }
+}
+
+// dR/dX . dX with the METRICS as dual numbers: points X + eps dX -> das_geom.hpp bodies in Dual<1> -> the same kernel bodies with
+// T = G = Dual<1> (states without tangents).  The exact counterpart of the finite-difference mesh products.
+#include "../../dafoam_amd/csrc/das_geom.hpp"
+extern "C" int emu_residual_geom(const das_case_t* c, const double* Win, long long n, const double* dX, double* Rd) {
+    try {
+        Mesh mesh;
+        mesh.build(c);
+        CaseParams cp;
+        cp.from_case(c);
+        if (!cp.beta_fi.empty()) cp.betaFI_ptr = cp.beta_fi.data();
+        Options opt;
+        ResParams prm = make_params(cp, opt, 0);
+        typedef Dual<1> D;
+        std::vector<D> P(3 * (size_t)mesh.nP);
+        for (size_t i = 0; i < P.size(); i++) { P[i].v = mesh.points[i]; P[i].d[0] = dX[i]; }
+        std::vector<FaceGeomT<D>> fg(mesh.nF);
+        std::vector<CellGeomT<D>> cg(mesh.nC);
+        const GeomTopo t = mesh.geom_topo();
+        for (int f = 0; f < mesh.nF; f++) geom_face<D>(f, t, P.data(), fg[f]);
+        for (int k = 0; k < mesh.nC; k++) { geom_cell<D>(k, t, fg.data(), cg[k]); cg[k].y = D(mesh.cg[k].y); }
+        for (int f = 0; f < mesh.nF; f++) geom_weights<D>(f, t, cg.data(), fg.data(), fg[f]);
+        DevMeshT<D> m;
+        m.nC = mesh.nC; m.nF = mesh.nF; m.nIF = mesh.nIF;
+        m.fg = fg.data(); m.cg = cg.data();
+        m.cf_ptr = mesh.cf_ptr.data(); m.cf_face = mesh.cf_face.data(); m.cf_other = mesh.cf_other.data();
+        m.owner = mesh.owner.data(); m.neigh = mesh.neighbour.data();
+        m.bpatch = mesh.bface_patch.data(); m.bc = mesh.bc.data(); m.cyc = mesh.cyc_face.data();
+        std::vector<D> W(n), R(n);
+        for (long long i = 0; i < n; i++) W[i] = D(Win[i]);
+        eval_on<D>(m, cp, prm, W, R);
+        for (long long i = 0; i < n; i++) Rd[i] = R[i].d[0];
+        return 0;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "emu_residual_geom: %s\n", e.what());
         return -1;
     }
 }

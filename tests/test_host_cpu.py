@@ -168,7 +168,8 @@ def test_kernel_bodies_bc_value_tangent(kind):
     for pname, field, fid, t in probes:
         code, v0 = case.bcs[pname][field]
         Rd = np.zeros(W.size)
-        assert L.emu_residual_bc(CaseStruct(case).byref(), dptr(W), W.size, names.index(pname), fid, dptr(t), dptr(Rd)) == 0
+        cs = CaseStruct(case)  # (kept alive: the struct points into arrays the wrapper owns)
+        assert L.emu_residual_bc(cs.byref(), dptr(W), W.size, names.index(pname), fid, dptr(t), dptr(Rd)) == 0
         vmax = float(np.max(np.abs(v0)))
         h = 1e-4 * vmax if vmax > 0 else 1e-6
         Rpm = []
@@ -900,7 +901,8 @@ def test_field_input_betaFINuTilda_kernel_bodies_vs_oracle():
     L = _emu()
     L.emu_residual_field.argtypes = [C.POINTER(das_case_t), _capi.c_double_p, C.c_longlong, _capi.c_double_p, _capi.c_double_p]
     Rd = np.zeros(case.states.size)
-    assert L.emu_residual_field(CaseStruct(case).byref(), dptr(case.states), case.states.size, dptr(t), dptr(Rd)) == 0
+    cs = CaseStruct(case)
+    assert L.emu_residual_field(cs.byref(), dptr(case.states), case.states.size, dptr(t), dptr(Rd)) == 0
     import copy
 
     cc = copy.copy(case)
@@ -1127,3 +1129,56 @@ def test_surface_families_for_geometry_and_warping_tools():
     assert np.array_equal(w.surf[:nb], low + 1.0) and np.array_equal(w.surf[nb:], xs[nb:])
     D.setVolCoords(1.5 * m.points.ravel())
     assert np.array_equal(D.getSurfaceCoordinates(), 1.5 * xs)
+
+
+@pytest.mark.parametrize("kind", ["simple_wf", "simple_T", "rho", "turbo_cyclic_mrf", "scalar"])
+def test_dual_number_metrics_give_the_exact_mesh_derivative(kind):
+    """The kernel bodies are templated on the scalar of the METRICS as well (csrc/das_kernels.hpp: DevMeshT<G>, das_geom.hpp
+    bodies on Dual<1> points): with T = G = Dual<1> one pass gives dR/dX . dX exactly - the forward-mode counterpart of the
+    reference's reverse sweep through the mesh metrics (DASolver.C:1690-1839 with DAInputVolCoord).  Checked against central
+    differences of the same bodies on moved points, for every solver family.  The step is tiny on purpose: the residual is only
+    piecewise smooth in the coordinates (the V-limiter of linearUpwindV, upwind switches) and a difference across a kink that
+    lies 1e-4 cell sizes away is off by tens of per cent at that cell - the dual numbers give the derivative AT the point."""
+    import copy
+
+    if kind == "simple_wf":
+        case = channel_case(6, 5, 4, wall_function=True, bump=0.1, skew=0.05)
+    elif kind == "simple_T":
+        case = simple_T_channel_case(6, 5, 4, wall_function=True)
+    elif kind == "rho":
+        case = rho_channel_case(6, 5, 4, wall_function=True)
+    elif kind == "turbo_cyclic_mrf":
+        case = periodic_channel_case(6, 5, 5, wall_function=True, sector=(0.5, 0.12), solver_name="DATurboFoam", mrf_omega=60.0)
+    else:
+        case = scalar_transport_case()
+    L = _emu()
+    L.emu_residual_geom.argtypes = [C.POINTER(das_case_t), _capi.c_double_p, C.c_longlong, _capi.c_double_p, _capi.c_double_p]
+    W = case.states
+    n = W.size
+    X = np.array(case.mesh.points, dtype=np.float64)
+    rng = np.random.default_rng(4)
+    dX = rng.standard_normal(X.shape)
+    if any(pt.type == "symmetry" for pt in case.mesh.patches):
+        # the symmetry planes of the generators are z = const: keep them planar.  basicSymmetry's snGradTransformDiag is |n_k|, a
+        # kink at n_k = 0 - tilting the plane has a one-sided derivative only (the dual numbers take the + side, a central
+        # difference averages the two)
+        dX[:, 2] = 0.0
+    Rd = np.zeros(n)
+    cs = CaseStruct(case)  # (kept alive: the struct points into arrays the wrapper owns)
+    dXc = np.ascontiguousarray(dX.ravel())
+    assert L.emu_residual_geom(cs.byref(), dptr(W), n, dptr(dXc), dptr(Rd)) == 0
+
+    def fd(h):
+        out = []
+        for sgn in (1.0, -1.0):
+            c2 = copy.copy(case)
+            c2.mesh = copy.copy(case.mesh)
+            c2.mesh.points = X + sgn * h * dX
+            out.append(_emu_res(c2, W)[0])
+        return (out[0] - out[1]) / (2 * h)
+
+    g = Geometry(case.mesh)
+    ref = fd(1e-6 * np.cbrt(g.V.min()))
+    scale = np.abs(ref).max()
+    err = np.abs(Rd - ref)
+    assert scale > 0 and err.max() <= 1e-5 * scale and np.percentile(err, 95) <= 1e-7 * scale, (err.max(), np.percentile(err, 95), scale)
