@@ -140,13 +140,13 @@ __global__ __launch_bounds__(256) void k_fn_grad(DevMesh m, ResParams prm, const
     }
 }
 
-template <class T>
-__global__ __launch_bounds__(256) void k_gradT(DevMesh m, ResParams prm, const T* __restrict__ W, const double* phiF, T* gT) {
+template <class T, class G = double>
+__global__ __launch_bounds__(256) void k_gradT(DevMeshT<G> m, ResParams prm, const T* __restrict__ W, const double* phiF, T* gT) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_gradT<T>(c, m, prm, W, phiF, gT);
 }
-template <class T>
-__global__ __launch_bounds__(256) void k_T(DevMesh m, ResParams prm, const T* __restrict__ W, const double* phiF, const double* Told,
+template <class T, class G = double>
+__global__ __launch_bounds__(256) void k_T(DevMeshT<G> m, ResParams prm, const T* __restrict__ W, const double* phiF, const double* Told,
                                            const T* gT, T* R) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_T<T>(c, m, prm, W, phiF, Told, gT, R);
@@ -175,26 +175,26 @@ struct ResWork {
 static inline int nblk(long long n, int b) { return (int)((n + b - 1) / b); }
 
 // one residual evaluation R(W): DAResidual::masterFunction (reference DAResidual.C:100-171)
-template <class T>
-static void eval_residual(const DevMesh& dm, const CaseParams& cp, const ResParams& prm_in, const T* W, T* R, ResWork<T>& wk,
+template <class T, class G = double>
+static void eval_residual(const DevMeshT<G>& dm, const CaseParams& cp, const ResParams& prm_in, const T* W, T* R, ResWork<T>& wk,
                           const double* d_phiF, const double* d_Told, hipStream_t st) {
     const ResParams prm = wk.bind(cp.solver, dm.nC, dm.nF, prm_in);
     const int B = 256;
     if (cp.solver == DAS_SOLVER_SIMPLEFOAM) {
-        hipLaunchKernelGGL((k_grad<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, wk.gH.p);
-        hipLaunchKernelGGL((k_cell<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p,
+        hipLaunchKernelGGL((k_grad<T, false, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, wk.gH.p);
+        hipLaunchKernelGGL((k_cell<T, false, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p,
                            (const T*)wk.gH.p, R, wk.rAU.p, wk.HbyA.p);
-        hipLaunchKernelGGL((k_face<T, false>), dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
-        hipLaunchKernelGGL((k_pres<T, false>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, wk.q.p, R);
+        hipLaunchKernelGGL((k_face<T, false, G>), dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
+        hipLaunchKernelGGL((k_pres<T, false, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, wk.q.p, R);
     } else if (DAS_IS_COMPRESSIBLE(cp.solver)) {
-        hipLaunchKernelGGL((k_grad<T, true>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, wk.gH.p);
-        hipLaunchKernelGGL((k_cell<T, true>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p,
+        hipLaunchKernelGGL((k_grad<T, true, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, wk.gH.p);
+        hipLaunchKernelGGL((k_cell<T, true, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p,
                            (const T*)wk.gH.p, R, wk.rAU.p, wk.HbyA.p);
-        hipLaunchKernelGGL((k_face<T, true>), dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
-        hipLaunchKernelGGL((k_pres<T, true>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, wk.q.p, R);
+        hipLaunchKernelGGL((k_face<T, true, G>), dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
+        hipLaunchKernelGGL((k_pres<T, true, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, wk.q.p, R);
     } else {
-        hipLaunchKernelGGL(k_gradT<T>, dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, d_phiF, wk.gT.p);
-        hipLaunchKernelGGL(k_T<T>, dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, d_phiF, d_Told, wk.gT.p, R);
+        hipLaunchKernelGGL((k_gradT<T, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, d_phiF, wk.gT.p);
+        hipLaunchKernelGGL((k_T<T, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, d_phiF, d_Told, wk.gT.p, R);
     }
     DAS_HIP(hipGetLastError());
 }
@@ -3578,9 +3578,9 @@ static GeomTopo device_geom_topo(das_solver* s) {
 static void device_geometry(das_solver* s, const GeomTopo& t, const double* X) {
     const int B = 256;
     hipStream_t st = s->stream;
-    hipLaunchKernelGGL(k_geom_face, dim3(nblk(t.nF, B)), dim3(B), 0, st, t, X, s->d_fg.p);
-    hipLaunchKernelGGL(k_geom_cell, dim3(nblk(t.nC, B)), dim3(B), 0, st, t, (const FaceGeom*)s->d_fg.p, s->d_cg.p, s->vc.d_bad.p);
-    hipLaunchKernelGGL(k_geom_weights, dim3(nblk(t.nF, B)), dim3(B), 0, st, t, (const CellGeom*)s->d_cg.p, s->d_fg.p);
+    hipLaunchKernelGGL(k_geom_face<double>, dim3(nblk(t.nF, B)), dim3(B), 0, st, t, X, s->d_fg.p);
+    hipLaunchKernelGGL(k_geom_cell<double>, dim3(nblk(t.nC, B)), dim3(B), 0, st, t, (const FaceGeom*)s->d_fg.p, s->d_cg.p, s->vc.d_bad.p);
+    hipLaunchKernelGGL(k_geom_weights<double>, dim3(nblk(t.nF, B)), dim3(B), 0, st, t, (const CellGeom*)s->d_cg.p, s->d_fg.p);
 }
 static void ensure_point_influence(das_solver* s) {
     das_solver::VolCoord& v = s->vc;
@@ -3656,6 +3656,102 @@ int das_point_influence_get(das_solver_t* s, int* colors, long long* ptr, int* c
     return DAS_OK;
     DAS_CATCH
 }
+// exact mode of the product (amd.volCoordMode "dual", the default): Dual<1> points -> Dual<1> metrics -> Dual<1> residual
+static void volcoord_product_dual(das_solver* s, das_solver::FaceFn* fn, bool areaAvg, const double* cN, const double* cA, const double* seeds,
+                                  double* product, double* info4) {
+    typedef Dual<1> D;
+    const Mesh& m = s->mesh;
+    das_solver::VolCoord& v = s->vc;
+    const PointInfluence& I = v.inf;
+    const GeomTopo t = device_geom_topo(s);
+    hipStream_t st = s->stream;
+    const int B = 256;
+    const long long n = s->n;
+    const size_t n3 = 3 * (size_t)m.nP;
+    const bool isFn = fn != nullptr;
+    const bool rho = DAS_IS_COMPRESSIBLE(s->cp.solver);
+    DevBuf<double> d_X0, d_out(n3), d_tc((size_t)m.nC), d_seeds, d_fvd;
+    DevBuf<D> d_XD(n3), d_Wd((size_t)n), d_Rd;
+    DevBuf<FaceGeomT<D>> d_fgD((size_t)m.nF);
+    DevBuf<CellGeomT<D>> d_cgD((size_t)m.nC);
+    DevBuf<int> d_fnPtr, d_fnIdx;
+    d_X0.upload(m.points.data(), n3);
+    DAS_HIP(hipMemsetAsync(d_out.p, 0, n3 * sizeof(double), st));
+    DAS_HIP(hipMemsetAsync(v.d_bad.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_points_lift, dim3(nblk((long long)n3, B)), dim3(B), 0, st, (long long)n3, (const double*)d_X0.p, d_XD.p);
+    hipLaunchKernelGGL(k_cell_y, dim3(nblk(m.nC, B)), dim3(B), 0, st, m.nC, (const CellGeom*)s->d_cg.p, d_cgD.p);
+    hipLaunchKernelGGL(k_lift, dim3(nblk(n, B)), dim3(B), 0, st, n, s->d_W.p, d_Wd.p);  // states carry no tangent
+    DevMeshT<D> dmD;
+    dmD.nC = m.nC; dmD.nF = m.nF; dmD.nIF = m.nIF;
+    dmD.fg = d_fgD.p; dmD.cg = d_cgD.p;
+    dmD.cf_ptr = s->dm.cf_ptr; dmD.cf_face = s->dm.cf_face; dmD.cf_other = s->dm.cf_other;
+    dmD.owner = s->dm.owner; dmD.neigh = s->dm.neigh; dmD.bpatch = s->dm.bpatch; dmD.bc = s->dm.bc; dmD.cyc = s->dm.cyc;
+    ResParams prm0 = make_params(s->cp, s->opt, 0);
+    RowLayout L{};
+    int nf = 0;
+    if (!isFn) {
+        const Stencil stn = make_stencil(s->cp.solver, m.nC, m.nF, s->opt, false, s->cp.hasT != 0);
+        DAS_CHECK(stn.states.size() <= 8, DAS_ERR_INTERNAL, "more than 8 state blocks");
+        L.nb = (int)stn.states.size();
+        for (int b = 0; b < L.nb; b++) { L.off[b] = stn.states[b].offset; L.kind[b] = (int)stn.states[b].kind; }
+        d_Rd.alloc((size_t)n);
+        d_seeds.upload(seeds, (size_t)n);
+    } else {
+        DAS_CHECK(s->cp.solver == DAS_SOLVER_SIMPLEFOAM || rho, DAS_ERR_ARG, "function needs a flow solver");
+        nf = (int)fn->faces.size();
+        d_fvd.alloc((size_t)nf);
+        std::vector<int> cptr(m.nC + 1, 0), cidx(nf);
+        for (int k = 0; k < nf; k++) cptr[m.owner[fn->faces[k]] + 1]++;
+        for (int c = 0; c < m.nC; c++) cptr[c + 1] += cptr[c];
+        std::vector<int> pos(cptr.begin(), cptr.end() - 1);
+        for (int k = 0; k < nf; k++) cidx[pos[m.owner[fn->faces[k]]]++] = k;
+        d_fnPtr.upload(cptr); d_fnIdx.upload(cidx);
+    }
+    const double t0 = wall_seconds();
+    long long passes = 0;
+    for (int col = 0; col < I.nColors; col++) {
+        const int np = I.cptr[col + 1] - I.cptr[col];
+        if (np == 0) continue;
+        const int* pts = v.d_cpoints.p + I.cptr[col];
+        for (int axis = 0; axis < 3; axis++) {
+            hipLaunchKernelGGL(k_points_seed, dim3(nblk(np, B)), dim3(B), 0, st, np, pts, axis, 1.0, d_XD.p);
+            hipLaunchKernelGGL(k_geom_face<D>, dim3(nblk(t.nF, B)), dim3(B), 0, st, t, (const D*)d_XD.p, d_fgD.p);
+            hipLaunchKernelGGL(k_geom_cell<D>, dim3(nblk(t.nC, B)), dim3(B), 0, st, t, (const FaceGeomT<D>*)d_fgD.p, d_cgD.p, v.d_bad.p);
+            hipLaunchKernelGGL(k_geom_weights<D>, dim3(nblk(t.nF, B)), dim3(B), 0, st, t, (const CellGeomT<D>*)d_cgD.p, d_fgD.p);
+            if (!isFn) {
+                eval_residual<D, D>(dmD, s->cp, prm0, d_Wd.p, d_Rd.p, s->wk1, s->d_phiF.p, s->d_Told.p, st);
+                hipLaunchKernelGGL(k_vc_rows_dual, dim3(nblk(m.nC, B)), dim3(B), 0, st, s->dm, L, (const double*)d_seeds.p, (const D*)d_Rd.p, d_tc.p);
+            } else {
+                const ResParams prm = s->wk1.bind(s->cp.solver, s->dm.nC, s->dm.nF, prm0);
+                const FaceFnView fv = fn->view(fn->d_w0.p);
+                if (rho) {
+                    hipLaunchKernelGGL((k_grad<D, true, D>), dim3(nblk(m.nC, B)), dim3(B), 0, st, dmD, prm, (const D*)d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
+                    hipLaunchKernelGGL((k_fn_dual<true>), dim3(nblk(nf, B)), dim3(B), 0, st, dmD, prm, (const D*)d_Wd.p, (const D*)s->wk1.nut.p, (const D*)s->wk1.gU.p, fv,
+                                       (int)fn->isMoment, fn->vecA[0], fn->vecA[1], fn->vecA[2], fn->vecB[0], fn->vecB[1], fn->vecB[2], (int)areaAvg, cN[0], cN[1], cA[0], cA[1], d_fvd.p);
+                } else {
+                    hipLaunchKernelGGL((k_grad<D, false, D>), dim3(nblk(m.nC, B)), dim3(B), 0, st, dmD, prm, (const D*)d_Wd.p, s->wk1.nut.p, s->wk1.gU.p, s->wk1.gP.p, s->wk1.gN.p, s->wk1.gH.p);
+                    hipLaunchKernelGGL((k_fn_dual<false>), dim3(nblk(nf, B)), dim3(B), 0, st, dmD, prm, (const D*)d_Wd.p, (const D*)s->wk1.nut.p, (const D*)s->wk1.gU.p, fv,
+                                       (int)fn->isMoment, fn->vecA[0], fn->vecA[1], fn->vecA[2], fn->vecB[0], fn->vecB[1], fn->vecB[2], (int)areaAvg, cN[0], cN[1], cA[0], cA[1], d_fvd.p);
+                }
+                hipLaunchKernelGGL(k_vc_fn_cells_dual, dim3(nblk(m.nC, B)), dim3(B), 0, st, m.nC, (const int*)d_fnPtr.p, (const int*)d_fnIdx.p, seeds[0],
+                                   (const double*)d_fvd.p, d_tc.p);
+            }
+            hipLaunchKernelGGL(k_points_seed, dim3(nblk(np, B)), dim3(B), 0, st, np, pts, axis, 0.0, d_XD.p);
+            hipLaunchKernelGGL(k_vc_gather, dim3(nblk(np, 4)), dim3(256), 0, st, np, pts, (const long long*)v.d_ptr.p, (const int*)v.d_cells.p,
+                               (const double*)d_tc.p, (const double*)nullptr, axis, d_out.p);
+            passes++;
+        }
+        DAS_HIP(hipGetLastError());
+    }
+    int bad = 0;
+    DAS_HIP(hipMemcpyAsync(&bad, v.d_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipMemcpyAsync(product, d_out.p, n3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    DAS_HIP(hipStreamSynchronize(st));
+    DAS_CHECK(!bad, DAS_ERR_INTERNAL, "non-positive cell volume in the volCoord product");
+    v.seconds = wall_seconds() - t0;
+    if (info4) { info4[0] = I.nColors; info4[1] = (double)passes; info4[2] = v.seconds; info4[3] = v.buildSeconds; }
+}
+
 // calcJacTVecProduct(volCoord -> residual | function), reference DASolver.C:1690-1839 + DAInputVolCoord: the full product vector
 // (3 nPoints) at the current states and points.  info4 (optional) = {colours, residual passes, seconds of the passes, seconds of
 // the one-off influence / colouring build}
@@ -3688,6 +3784,15 @@ int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const ch
         }
     }
     ensure_point_influence(s);
+    {
+        auto itm = s->opt.s.find("amd.volCoordMode");
+        const std::string mode = itm == s->opt.s.end() ? std::string("dual") : itm->second;
+        DAS_CHECK(mode == "dual" || mode == "fd", DAS_ERR_ARG, "amd.volCoordMode: dual | fd");
+        if (mode == "dual") {
+            volcoord_product_dual(s, fn, areaAvg, cN, cA, seeds, product, info4);
+            return DAS_OK;
+        }
+    }
     das_solver::VolCoord& v = s->vc;
     const PointInfluence& I = v.inf;
     const GeomTopo t = device_geom_topo(s);

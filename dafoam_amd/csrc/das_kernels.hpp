@@ -830,8 +830,8 @@ DAS_HD void body_pres(int c, const DevMeshT<G>& m, const ResParams& prm, const T
 // DAFunctionForce::calcFunction (reference src/adjoint/DAFunction/DAFunctionForce.C:79-158) for one boundary face:
 //   F_f = scale * ( S_f p_b + S_f . devRhoReff_b ) . dir,  devRhoReff = (-rho nuEff) dev(twoSymm(grad U))
 //   (reference DATurbulenceModel.C:360-376), boundary field from the boundary values of nuEff, rho and grad(U).
-template <class T, bool RHO, class G>
-DAS_HD T body_force(int f, const DevMeshT<G>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const double* dir, double scale) {
+template <class T, bool RHO, class G, class DV>
+DAS_HD T body_force(int f, const DevMeshT<G>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const DV* dir, double scale) {
     const long long N = m.nC;
     const FaceGeomT<G>& g = m.fg[f];
     const int c = m.owner[f];
@@ -881,8 +881,8 @@ DAS_HD T body_force(int f, const DevMeshT<G>& m, const ResParams& prm, const T* 
 #define DAS_FN_MASSFLOW 1
 #define DAS_FN_TOTALPRESSURE 2
 #define DAS_FN_TOTALTEMPERATURE 3
-template <class T, bool RHO, class G>
-DAS_HD T body_facefn(int f, const DevMeshT<G>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, int kind, const double* dir,
+template <class T, bool RHO, class G, class DV>
+DAS_HD T body_facefn(int f, const DevMeshT<G>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, int kind, const DV* dir,
                      double gammaFn, double RFn) {
     if (kind == DAS_FN_FORCE) return body_force<T, RHO>(f, m, prm, W, nut, gradU, dir, 1.0);
     const long long N = m.nC;

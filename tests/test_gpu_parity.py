@@ -800,7 +800,7 @@ def test_shape_total_derivative_vs_primal_fd():
     gF, gR = np.zeros(dX.size), np.zeros(dX.size)
     D.solverAD.calcJacTVecProduct("x", "volCoord", X, "CD", "function", np.ones(1), gF)
     D.solverAD.calcJacTVecProduct("x", "volCoord", X, "residual", "residual", psi, gR)
-    assert abs((gF - gR) @ dX - fd) <= 3e-4 * abs(fd) and abs((gF - gR) @ dX - total) <= 1e-5 * abs(total)
+    assert abs((gF - gR) @ dX - fd) <= 3e-4 * abs(fd) and abs((gF - gR) @ dX - total) <= 1e-4 * abs(total)
 
 
 def test_device_geometry_passes_equal_the_host_metrics():
@@ -824,12 +824,15 @@ def test_device_geometry_passes_equal_the_host_metrics():
         assert np.array_equal(cg[:, 4], case.y_wall)  # frozen wall distance
 
 
-def test_volcoord_full_product_vector_on_the_device():
+@pytest.mark.parametrize("mode", ["dual", "fd"])
+def test_volcoord_full_product_vector_on_the_device(mode):
     """calcJacTVecProduct(volCoord -> residual | function) (reference DASolver.C:1690-1839, DAInputVolCoord): the FULL product
-    vector over all mesh points from coloured central differences on the device.  Checked (1) entry by entry against central
-    differences of the ORACLE's residual / force on meshes with one moved point, (2) contracted with a displacement field
-    against the directional product (one FD of the whole mesh), (3) for bit-reproducibility, (4) that states, points and
-    metrics are what they were afterwards."""
+    vector over all mesh points on the device.  amd.volCoordMode "dual" (default): Dual<1> points -> metrics -> residual, one
+    pass per point colour and axis, exact; "fd": coloured central differences.  Checked (1) entry by entry against difference
+    quotients of the ORACLE's residual / force on meshes with one moved point ("fd": the SAME step, 1e-8; "dual": a step small
+    enough that no limiter switch lies inside it, 1e-5), (2) contracted with a displacement field against the directional product
+    (one FD of the whole mesh), (3) for bit-reproducibility, (4) that states, points and metrics are what they were afterwards,
+    (5) moment and area-averaged objectives."""
     import copy
 
     from oracle.functions import force
@@ -837,11 +840,12 @@ def test_volcoord_full_product_vector_on_the_device():
     base = converged_case((10, 8, 6), lengths=(1.0, 0.2, 0.2), grading_y=2.0)
     case = channel_case(10, 8, 6, lengths=(1.0, 0.2, 0.2), grading_y=2.0, perturb=0.0, bump=0.1)
     case.y_wall, case.states = base.y_wall, base.states  # not converged on the bumped mesh: R != 0, all terms active
-    g = Geometry(case.mesh)
     W = case.states
     walls, d = ["bottom", "top"], [1.0, 0.0, 0.0]
-    D = make(case, function={"CD": {"type": "force", "source": "patchToFace", "patches": walls, "directionMode": "fixedDirection",
-                                    "direction": d, "scale": 1.0}})
+    fns = {"CD": {"type": "force", "source": "patchToFace", "patches": walls, "directionMode": "fixedDirection", "direction": d, "scale": 1.0},
+           "CM": {"type": "moment", "source": "patchToFace", "patches": walls, "axis": [0.0, 0.0, 1.0], "center": [0.25, 0.05, 0.0], "scale": 1.0},
+           "PT": {"type": "totalPressure", "source": "patchToFace", "patches": ["inlet"], "scale": 1.0}}
+    D = make(case, function=fns, amd={"volCoordMode": mode})
     S = D.solverAD
     n, P3 = W.size, 3 * case.mesh.n_points
     rng = np.random.default_rng(3)
@@ -853,7 +857,7 @@ def test_volcoord_full_product_vector_on_the_device():
     pR = np.zeros(P3)
     S.calcJacTVecProduct("x", "volCoord", X0, "residual", "residual", seeds, pR)
     info = S._volCoordInfo
-    assert 50 < info["colors"] < 600 and info["passes"] == 6 * info["colors"]
+    assert 50 < info["colors"] < 600 and info["passes"] == (3 if mode == "dual" else 6) * info["colors"]
     pF = np.zeros(P3)
     S.calcJacTVecProduct("x", "volCoord", X0, "CD", "function", np.ones(1), pF)
     # (4)
@@ -873,6 +877,7 @@ def test_volcoord_full_product_vector_on_the_device():
                                          for f in range(pt.start, pt.start + pt.size)]))
     pick = list(rng.choice(case.mesh.n_points, 6, replace=False)) + list(rng.choice(wall_pts, 6, replace=False))
     scaleR, scaleF = np.abs(pR).max(), np.abs(pF).max()
+
     def oracle_fd(p, ax, h):
         vals = []
         for sgn in (1.0, -1.0):
@@ -887,34 +892,50 @@ def test_volcoord_full_product_vector_on_the_device():
 
     for p in pick:
         for ax in range(3):
-            # the same difference quotient from the oracle (the residual is only piecewise smooth in the point coordinates: the
-            # quotient converges like O(h) at some wall points, so a reference with another step differs by 1e-6 .. 1e-5)
-            refR, refF = oracle_fd(p, ax, steps[p])
-            assert abs(pR[3 * p + ax] - refR) <= 1e-8 * abs(refR) + 1e-9 * scaleR, (p, ax, pR[3 * p + ax], refR)
-            assert abs(pF[3 * p + ax] - refF) <= 1e-8 * abs(refF) + 1e-9 * scaleF, (p, ax, pF[3 * p + ax], refF)
-    for p in pick[::4]:  # and the quotient sits within 1e-5 of its limit (a quarter of the step)
-        refR, refF = oracle_fd(p, 1, 0.25 * steps[p])
-        assert abs(pR[3 * p + 1] - refR) <= 1e-5 * abs(refR) + 1e-7 * scaleR and abs(pF[3 * p + 1] - refF) <= 1e-5 * abs(refF) + 1e-7 * scaleF
+            if mode == "fd":
+                # the same difference quotient from the oracle (the residual is only piecewise smooth in the point coordinates:
+                # a reference with another step differs by 1e-6 .. 1e-5 at some wall points, by much more next to a limiter switch)
+                refR, refF = oracle_fd(p, ax, steps[p])
+                tolr, tols = 1e-8, 1e-9
+            else:
+                refR, refF = oracle_fd(p, ax, 0.02 * steps[p])
+                tolr, tols = 1e-5, 1e-6
+            assert abs(pR[3 * p + ax] - refR) <= tolr * abs(refR) + tols * scaleR, (p, ax, pR[3 * p + ax], refR)
+            assert abs(pF[3 * p + ax] - refF) <= tolr * abs(refF) + tols * scaleF, (p, ax, pF[3 * p + ax], refF)
     assert 0 < np.count_nonzero(pF) < P3  # the force only feels the points near the walls (here: all but the mid-channel layers)
-    # (2) contraction with a smooth displacement field
+    # (2) contraction with a smooth displacement field (the directional product is ONE central difference of the whole mesh with a
+    #     step that is not small against the wall cells: agreement to 1e-6 of the sum of the terms for "fd", a few 1e-5 for "dual")
     Xr = case.mesh.points
     dX = np.stack([0.3 * np.sin(3 * Xr[:, 1] / 0.2) * Xr[:, 0], 0.2 * Xr[:, 0] * (1 - Xr[:, 0]) + 0 * Xr[:, 1], 0.1 * np.cos(2 * Xr[:, 0])], axis=1).ravel()
+    tol = 1e-6 if mode == "fd" else 1e-4
     dirR = S.calcVolCoordDirectionalProduct(dX, "residual", "residual", seeds, eps=1e-6)
-    dirF = S.calcVolCoordDirectionalProduct(dX, "CD", "function", np.ones(1), eps=1e-6)
-    # (the directional product is ONE central difference of the whole mesh with a step that is not small against the wall cells)
-    assert abs(pR @ dX - dirR) <= 1e-6 * np.abs(pR * dX).sum() and abs(pF @ dX - dirF) <= 1e-7 * np.abs(pF * dX).sum()
-    # moment: the arms follow the moved face centres; totalPressure: the area average is differentiated through its linearisation
-    D2 = make(case, function={"CM": {"type": "moment", "source": "patchToFace", "patches": walls, "axis": [0.0, 0.0, 1.0],
-                                     "center": [0.25, 0.05, 0.0], "scale": 1.0},
-                              "PT": {"type": "totalPressure", "source": "patchToFace", "patches": ["inlet"], "scale": 1.0}})
-    for nm in ("CM", "PT"):
+    assert abs(pR @ dX - dirR) <= tol * np.abs(pR * dX).sum(), (pR @ dX, dirR)
+    # (5)
+    for nm in ("CD", "CM", "PT"):
         pM = np.zeros(P3)
-        D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, nm, "function", np.ones(1), pM)
-        dirM = D2.solverAD.calcVolCoordDirectionalProduct(dX, nm, "function", np.ones(1), eps=1e-6)
-        assert abs(pM @ dX - dirM) <= 1e-7 * np.abs(pM * dX).sum() and np.abs(pM).max() > 0, nm
-    v0 = D2.solverAD.calcFunction("CM")
-    D2.solverAD.calcJacTVecProduct("x", "volCoord", X0, "CM", "function", np.ones(1), pM)
-    assert D2.solverAD.calcFunction("CM") == v0  # the host copy of the moment arms is back (and the sums are deterministic)
+        S.calcJacTVecProduct("x", "volCoord", X0, nm, "function", np.ones(1), pM)
+        dirM = S.calcVolCoordDirectionalProduct(dX, nm, "function", np.ones(1), eps=1e-6)
+        assert np.abs(pM).max() > 0 and abs(pM @ dX - dirM) <= (1e-7 if mode == "fd" else 1e-5) * np.abs(pM * dX).sum(), (nm, pM @ dX, dirM)
+    v0 = S.calcFunction("CM")
+    S.calcJacTVecProduct("x", "volCoord", X0, "CM", "function", np.ones(1), pM)
+    assert S.calcFunction("CM") == v0  # the host copy of the moment arms is untouched / back, and the sums are deterministic
+
+
+def test_volcoord_dual_and_difference_modes_agree_away_from_switches():
+    """The two modes of the product agree to 1e-6 of the largest entry on 95 % of the entries; the rest sit next to a limiter /
+    upwind switch, where the difference quotient is not the derivative (CPU: test_dual_number_metrics_give_the_exact_...)."""
+    case = channel_case(9, 7, 6, wall_function=True, bump=0.1)
+    n, P3 = case.states.size, 3 * case.mesh.n_points
+    seeds = np.random.default_rng(8).standard_normal(n)
+    X0 = case.mesh.points.ravel().copy()
+    out = {}
+    for mode in ("dual", "fd"):
+        D = make(case, amd={"volCoordMode": mode})
+        out[mode] = np.zeros(P3)
+        D.solverAD.calcJacTVecProduct("x", "volCoord", X0, "residual", "residual", seeds, out[mode])
+    err = np.abs(out["dual"] - out["fd"])
+    scale = np.abs(out["dual"]).max()
+    assert scale > 0 and np.percentile(err, 95) <= 1e-6 * scale and np.percentile(err, 50) <= 1e-8 * scale, (np.percentile(err, [50, 95, 100]), scale)
 
 
 def test_primal_bc_option_and_calc_output():
@@ -961,7 +982,7 @@ def test_volcoord_product_compressible_and_ratio_objective():
         S.calcJacTVecProduct("x", "volCoord", X0, nm, ot, sd, p)
         ref = S.calcVolCoordDirectionalProduct(dX, nm, ot, sd, eps=1e-6)
         assert np.abs(p).max() > 0 and abs(ref) > 1e-3 * np.abs(p * dX).sum(), nm  # a real sensitivity, not two zeros
-        assert abs(p @ dX - ref) <= 1e-6 * np.abs(p * dX).sum(), (nm, p @ dX, ref)
+        assert abs(p @ dX - ref) <= 1e-5 * np.abs(p * dX).sum(), (nm, p @ dX, ref)
 
 
 @pytest.mark.parametrize("kind", ["simple", "rho", "scalar"])
