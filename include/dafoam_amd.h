@@ -154,8 +154,9 @@ int das_get_of_mesh_points(das_solver_t* s, double* points);
 /* das_calc_dvolcoord_product <- calcJacTVecProduct(inputType "volCoord" -> outputType "residual" | "function")
  *   pyDASolvers.pyx:333-366 -> DASolver.C:1690-1839 with DAInput/DAInputVolCoord.C:33-70: the FULL product vector
  *   product[3 p + k] = sum_i seeds[i] dOutput_i/dX[p][k] over all mesh points, at the current states and points.  The reference
- *   gets it from one reverse sweep of its AD tape; here coloured central differences of the point coordinates run entirely on the
- *   device (metrics + residual re-evaluated per colour, csrc/das_volcoord.hpp).  seeds: n states (residual) or 1 (function:
+ *   gets it from one reverse sweep of its AD tape; here coloured forward-mode passes run entirely on the device: the points of a
+ *   colour carry a unit tangent, metrics and residual follow as Dual<1> (exact; option amd.volCoordMode "fd": central
+ *   differences; csrc/das_volcoord.hpp).  seeds: n states (residual) or 1 (function:
  *   any defined face function).  info4 (may be NULL) = {point colours, residual passes, seconds, build seconds}.
  * das_point_influence_build / _get: the host-side structure behind it (no GPU needed): point colours, the cells whose residual
  *   rows feel a point (CSR), the finite-difference step per point.
