@@ -236,6 +236,7 @@ _SIGS = {
     "das_point_influence_build": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "das_point_influence_get": (C.c_int, [_VP, c_int_p, c_ll_p, c_int_p, c_double_p]),
     "das_debug_device_geometry": (C.c_int, [_VP, c_double_p, c_double_p, c_double_p]),
+    "das_debug_strength_aggregates": (C.c_int, [_VP, C.c_int, c_int_p, C.POINTER(C.c_int)]),
     "das_calc_dbc_product": (C.c_int, [_VP, c_int_p, C.c_int, C.c_char_p, c_double_p, C.c_char_p, C.c_char_p, c_double_p, c_double_p]),
     "das_define_force_function": (C.c_int, [_VP, C.c_char_p, c_int_p, C.c_int, c_double_p, C.c_double]),
     "das_define_face_function": (C.c_int, [_VP, C.c_char_p, C.c_char_p, c_int_p, c_int_p, C.c_int, c_double_p, c_double_p, C.c_double, C.c_double]),

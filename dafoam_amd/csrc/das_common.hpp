@@ -310,6 +310,9 @@ struct PointInfluence {
 void build_point_influence(const Mesh& m, int rings, int threads, PointInfluence& out);
 void point_steps(const Mesh& m, double relStep, std::vector<double>& h);
 
+// aggregates along the strongest pressure-Laplacian couplings (at most maxAgg of them); ownedCell: optional mask; returns the count
+int strength_aggregates(const Mesh& m, const std::vector<unsigned char>* ownedCell, int maxAgg, std::vector<int>& agg);
+
 double wall_seconds();
 
 }  // namespace das

@@ -1910,11 +1910,19 @@ static void setup_coarse(das_solver* s, das_ksp* k) {
     for (long long c = 0; c < N; c++) if (s->owned.empty() || s->owned[sd->offset + c]) owned.push_back((int)c);
     if (owned.size() < 64) return;
     if (want < 0) want = std::min<long long>(1024, std::max<long long>(16, (long long)owned.size() / 2048));
-    const int nagg = (int)std::min<long long>(want, std::min<long long>(2048, (long long)owned.size() / 4));
+    int nagg = (int)std::min<long long>(want, std::min<long long>(2048, (long long)owned.size() / 4));
     if (nagg < 2) return;
-    // recursive coordinate bisection into nagg parts of (almost) equal size
     std::vector<int> agg(N, -1);
-    {
+    const bool byStrength = s->opt.gets("amd.pcCoarseAggregation") == "strength";
+    DAS_CHECK(byStrength || s->opt.gets("amd.pcCoarseAggregation") == "rcb", DAS_ERR_ARG, "amd.pcCoarseAggregation: rcb | strength");
+    if (byStrength) {
+        // aggregates along the strongest pressure-Laplacian couplings (das_mesh.cpp): at most nagg of them
+        std::vector<unsigned char> mask;
+        if (!s->owned.empty()) { mask.resize(N); for (long long c = 0; c < N; c++) mask[c] = s->owned[sd->offset + c]; }
+        nagg = strength_aggregates(m, s->owned.empty() ? nullptr : &mask, nagg, agg);
+        if (nagg < 2) return;
+    } else {
+        // recursive coordinate bisection into nagg parts of (almost) equal size
         struct Rg { long long b, e; int a0, na; };
         std::vector<Rg> stack{{0, (long long)owned.size(), 0, nagg}};
         while (!stack.empty()) {
@@ -3632,6 +3640,16 @@ int das_debug_device_geometry(das_solver_t* s, const double* points, double* fg1
     DAS_HIP(hipMemcpy(s->d_fg.p, v.d_fg0.p, m.nF * sizeof(FaceGeom), hipMemcpyDeviceToDevice));
     DAS_HIP(hipMemcpy(s->d_cg.p, v.d_cg0.p, m.nC * sizeof(CellGeom), hipMemcpyDeviceToDevice));
     v.d_fg0.release(); v.d_cg0.release();
+    return DAS_OK;
+    DAS_CATCH
+}
+// host-side (no GPU needed): the aggregates amd.pcCoarseAggregation "strength" would use for at most maxAgg aggregates
+int das_debug_strength_aggregates(das_solver_t* s, int maxAgg, int* agg, int* nAgg) {
+    DAS_TRY
+    DAS_CHECK(s && agg && nAgg && maxAgg >= 1, DAS_ERR_ARG, "bad argument");
+    std::vector<int> a;
+    *nAgg = strength_aggregates(s->mesh, nullptr, maxAgg, a);
+    std::copy(a.begin(), a.end(), agg);
     return DAS_OK;
     DAS_CATCH
 }

@@ -62,6 +62,10 @@ Options::Options() {
     s["amd.pcType"] = "bilu";       // "bilu": global node-block ILU(0), sync-free sweeps (das_bilu.hpp); "ras": RAS + ILU(k) blocks in LDS
     i["amd.pcCoarseAggregates"] = -1;  // two-level PC: piecewise-constant coarse space on the pressure (-1 auto, 0 off, n aggregates)
     s["amd.pcCoarseField"] = "p";
+    // aggregates of the coarse space: "rcb" (recursive coordinate bisection of the cell centres, isotropic in space) | "strength"
+    // (repeated pairwise matching along the strongest pressure-Laplacian coupling |Sf| / |d|: the aggregates follow the thin
+    // direction of stretched cells - measured on the CPU: NACA0012 adjoint 763 -> 360 iterations where space-filling blocks give 530)
+    s["amd.pcCoarseAggregation"] = "rcb";
     s["amd.pcCoarseMode"] = "additive";  // additive | deflated (A-DEF1: one extra operator product per apply)
     i["amd.coloringOnDevice"] = 1;   // serial first-fit colouring as a data-flow kernel (das_color.hpp); 0: host variants
     d["amd.primalTau0"] = 1.0;          // Newton primal: initial pseudo-time factor (diagonal scaled by 1 + 1/tau), SER growth
@@ -357,6 +361,78 @@ void build_point_influence(const Mesh& m, int rings, int threads, PointInfluence
     out.cpoints.resize(out.cptr[out.nColors]);
     std::vector<int> pos(out.cptr.begin(), out.cptr.end() - 1);
     for (int p = 0; p < nP; p++) if (out.color[p] >= 0) out.cpoints[pos[out.color[p]]++] = p;
+}
+
+// ---- strength-of-connection aggregates for the pressure coarse space ---------------------------------------------------------
+// The coupling of two face-neighbour cells in the pressure Laplacian is ~ |Sf| nonOrthDeltaCoeff (area over distance).  Every
+// pass matches each aggregate with its strongest unmatched neighbour (sequential sweep in index order: deterministic) and sums
+// the couplings of the merged pairs; passes continue until at most `maxAgg` aggregates are left or nothing can be merged.
+int strength_aggregates(const Mesh& m, const std::vector<unsigned char>* ownedCell, int maxAgg, std::vector<int>& agg) {
+    const int N = m.nC;
+    agg.assign(N, -1);
+    // owned cells -> compact ids
+    int cnt = 0;
+    for (int c = 0; c < N; c++) if (!ownedCell || (*ownedCell)[c]) agg[c] = cnt++;
+    if (cnt == 0) return 0;
+    struct Edge { int u, v; double w; };
+    std::vector<Edge> edges;
+    edges.reserve((size_t)m.nF);
+    for (int f = 0; f < m.nF; f++) {
+        int o = m.owner[f], nb = -1;
+        if (f < m.nIF) nb = m.neighbour[f];
+        else if (m.cyc_face[f - m.nIF] >= 0) { nb = m.owner[m.cyc_face[f - m.nIF]]; if (nb < o) continue; }  // one edge per pair
+        if (nb < 0 || agg[o] < 0 || agg[nb] < 0 || o == nb) continue;
+        edges.push_back({agg[o], agg[nb], m.fg[f].magSf * m.fg[f].nod});
+    }
+    std::vector<int> cur(cnt);  // aggregate id of every compact cell
+    for (int i = 0; i < cnt; i++) cur[i] = i;
+    int nA = cnt;
+    std::vector<int> match, best;
+    std::vector<double> bw;
+    std::vector<long long> ptr;
+    std::vector<int> adj;
+    std::vector<double> adjw;
+    while (nA > maxAgg && !edges.empty()) {
+        // adjacency of the current aggregate graph
+        ptr.assign((size_t)nA + 1, 0);
+        for (const Edge& e : edges) { ptr[e.u + 1]++; ptr[e.v + 1]++; }
+        for (int i = 0; i < nA; i++) ptr[i + 1] += ptr[i];
+        adj.resize(ptr[nA]); adjw.resize(ptr[nA]);
+        {
+            std::vector<long long> pos(ptr.begin(), ptr.end() - 1);
+            for (const Edge& e : edges) { adj[pos[e.u]] = e.v; adjw[pos[e.u]++] = e.w; adj[pos[e.v]] = e.u; adjw[pos[e.v]++] = e.w; }
+        }
+        match.assign(nA, -1);
+        int nNew = 0;
+        for (int i = 0; i < nA; i++) {
+            if (match[i] >= 0) continue;
+            int bj = -1;
+            double bwv = 0.0;
+            for (long long q = ptr[i]; q < ptr[i + 1]; q++) {
+                const int j = adj[q];
+                if (match[j] >= 0 || j == i) continue;
+                if (adjw[q] > bwv || (adjw[q] == bwv && bj >= 0 && j < bj)) { bwv = adjw[q]; bj = j; }
+            }
+            match[i] = nNew;
+            if (bj >= 0) match[bj] = nNew;
+            nNew++;
+        }
+        if (nNew == nA) break;  // nothing merged
+        for (int i = 0; i < cnt; i++) cur[i] = match[cur[i]];
+        // coarse edges: relabel, drop self loops, merge duplicates
+        for (Edge& e : edges) { int a = match[e.u], b = match[e.v]; if (a > b) std::swap(a, b); e.u = a; e.v = b; }
+        edges.erase(std::remove_if(edges.begin(), edges.end(), [](const Edge& e) { return e.u == e.v; }), edges.end());
+        std::sort(edges.begin(), edges.end(), [](const Edge& a, const Edge& b) { return a.u != b.u ? a.u < b.u : a.v < b.v; });
+        size_t w = 0;
+        for (size_t r = 0; r < edges.size(); r++) {
+            if (w > 0 && edges[w - 1].u == edges[r].u && edges[w - 1].v == edges[r].v) edges[w - 1].w += edges[r].w;
+            else edges[w++] = edges[r];
+        }
+        edges.resize(w);
+        nA = nNew;
+    }
+    for (int c = 0; c < N; c++) if (agg[c] >= 0) agg[c] = cur[agg[c]];
+    return nA;
 }
 
 }  // namespace das

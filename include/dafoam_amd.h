@@ -167,6 +167,9 @@ int das_calc_dvolcoord_product(das_solver_t* s, const char* outputName, const ch
 int das_point_influence_build(das_solver_t* s, int* nColors, long long* nEntries);
 int das_point_influence_get(das_solver_t* s, int* colors /*P*/, long long* ptr /*P+1*/, int* cells /*nEntries*/, double* steps /*P*/);
 int das_debug_device_geometry(das_solver_t* s, const double* points /*3P*/, double* fg12 /*12F*/, double* cg5 /*5N*/);
+/* das_debug_strength_aggregates: the aggregates of the pressure coarse space under option amd.pcCoarseAggregation "strength"
+ *   (repeated pairwise matching along the strongest |Sf| / |d| coupling until at most maxAgg are left); host only - test aid. */
+int das_debug_strength_aggregates(das_solver_t* s, int maxAgg, int* agg /*N*/, int* nAgg);
 /* ---- host-side mesh geometry (fvMesh metrics; no GPU needed) - used by tests and input generators */
 int das_get_geometry(das_solver_t* s, double* Sf /*3F*/, double* Cf /*3F*/, double* C /*3N*/, double* V /*N*/,
                      double* weights /*Fi*/, double* nonOrthDeltaCoeffs /*Fi*/, double* nonOrthCorr /*3Fi*/,

@@ -1182,3 +1182,39 @@ def test_dual_number_metrics_give_the_exact_mesh_derivative(kind):
     scale = np.abs(ref).max()
     err = np.abs(Rd - ref)
     assert scale > 0 and err.max() <= 1e-5 * scale and np.percentile(err, 95) <= 1e-7 * scale, (err.max(), np.percentile(err, 95), scale)
+
+
+def test_strength_based_aggregates_follow_the_stretched_cells():
+    """amd.pcCoarseAggregation "strength" (opt-in; csrc/das_mesh.cpp strength_aggregates): repeated pairwise matching along the
+    strongest pressure-Laplacian coupling |Sf| / |d|.  On the NACA0012 O-grid (cells 10^2 .. 10^4 times longer than thick at the
+    wall) the aggregates must run along the wall normal - the direction the slow pressure modes of the adjoint are smooth in
+    (tools/naca_coarse_study.py: 763 -> 360 GMRES iterations with such aggregates, 530 with space-filling blocks) - be
+    deterministic, cover every cell once and respect the requested maximum."""
+    from dafoam_amd.meshgen import naca0012_case
+
+    na, nn = 64, 24
+    case = naca0012_case(na, nn, 1)
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    N = case.mesh.n_cells
+    agg, agg2 = np.zeros(N, np.int32), np.zeros(N, np.int32)
+    cnt, cnt2 = C.c_int(0), C.c_int(0)
+    L = _capi.lib()
+    assert L.das_debug_strength_aggregates(s._h, 64, agg.ctypes.data_as(_capi.c_int_p), C.byref(cnt)) == 0
+    assert L.das_debug_strength_aggregates(s._h, 64, agg2.ctypes.data_as(_capi.c_int_p), C.byref(cnt2)) == 0
+    assert np.array_equal(agg, agg2) and cnt.value == cnt2.value
+    nA = cnt.value
+    assert 16 < nA <= 64 and agg.min() == 0 and agg.max() == nA - 1 and np.unique(agg).size == nA
+    # shape: extent in the wall-normal index j against the extent around the airfoil (i, periodic), cell = i + na j
+    i, j = np.arange(N) % na, np.arange(N) // na
+    ext_j = np.array([np.ptp(j[agg == a]) + 1 for a in range(nA)])
+    ext_i = []
+    for a in range(nA):
+        ia = np.sort(np.unique(i[agg == a]))
+        gaps = np.diff(np.concatenate([ia, [ia[0] + na]]))
+        ext_i.append(na - gaps.max() + 1)  # smallest periodic window that holds them
+    ext_i = np.array(ext_i)
+    near_wall = np.array([j[agg == a].min() == 0 for a in range(nA)])
+    assert near_wall.sum() >= 8 and np.median(ext_j[near_wall] / ext_i[near_wall]) >= 3.0, (ext_j[near_wall], ext_i[near_wall])
+    # sizes are balanced within the factor pairwise matching gives
+    sizes = np.bincount(agg)
+    assert sizes.max() <= 8 * max(1, sizes.min()) or sizes.max() <= 2 * N // nA
