@@ -19,6 +19,7 @@ ap.add_argument("--threads", type=int, nargs="+", default=[32])
 ap.add_argument("--pctype", nargs="+", default=["bilu"])
 ap.add_argument("--krylov-gb", type=float, default=32.0)
 ap.add_argument("--case", default="channel", choices=["channel", "naca"], help="naca: --n = cells around, wall-normal, spanwise (BASELINE configs[1]: 800 250 1)")
+ap.add_argument("--coarse-aggregation", nargs="+", default=["rcb"], help="amd.pcCoarseAggregation: rcb | strength (one run per value)")
 ap.add_argument("--span", type=float, default=0.1, help="naca: spanwise extent of the extrusion")
 ap.add_argument("--perturb", type=float, default=0.02, help="naca: amplitude of the seeded perturbation of the synthetic state")
 ap.add_argument("--coarse-agg", type=int, nargs="+", default=[-1])
@@ -52,8 +53,9 @@ if a.combos:
         runs.append((a.pctype[0], a.block[0], a.overlap[0], a.fill[0], int(f32), a.threads[0], int(cagg), cmode, int(pit), int(rest[0]) if rest else 1))
 else:
     runs = [r + (1,) for r in runs]
-for pct, b, ov, fl, f32, nth, cagg, cmode, pit, design in runs:
-    D.solver.updateDAOption({"amd": {"pcSweepDesign": design, "pcType": pct, "pcCoarseAggregates": cagg, "pcCoarseMode": cmode, "maxKrylovBytes": int(a.krylov_gb * 2**30), "pcBlockCells": b, "pcFactorFP32": f32, "setupThreads": nth}, "adjEqnOption": {"asmOverlap": ov, "pcFillLevel": fl, "localPCIters": pit}})
+runs = [r + (ag,) for r in runs for ag in a.coarse_aggregation]
+for pct, b, ov, fl, f32, nth, cagg, cmode, pit, design, cag in runs:
+    D.solver.updateDAOption({"amd": {"pcCoarseAggregation": cag, "pcSweepDesign": design, "pcType": pct, "pcCoarseAggregates": cagg, "pcCoarseMode": cmode, "maxKrylovBytes": int(a.krylov_gb * 2**30), "pcBlockCells": b, "pcFactorFP32": f32, "setupThreads": nth}, "adjEqnOption": {"asmOverlap": ov, "pcFillLevel": fl, "localPCIters": pit}})
     ksp = KSP(); t = time.time(); D.solverAD.createMLRKSPMatrixFree(pc, ksp); t_ilu = time.time() - t
     x = Vec(n); r = Vec(n); r.array[:] = rhs
     L.das_timer_reset(D.solver._h); L.das_timer_enable(D.solver._h, 1)
@@ -61,7 +63,7 @@ for pct, b, ov, fl, f32, nth, cagg, cmode, pit, design in runs:
     info = ksp.info()
     h = ksp.history(); print("   hist", " ".join(f"{v/h[0]:.1e}" for v in h[::max(1,len(h)//12)]))
     nag, cms = L.das_ksp_get_coarse(ksp.handle, None), L.das_timer_avg_ms(D.solver._h, b"coarse")
-    print(f"pc {pct} sweep-design {design} pcIters {pit} coarse {cagg}/{cmode} ({nag} aggregates, {cms:.3f} ms) block {b} overlap {ov} fill {fl} fp32 {f32} threads {nth} nblocks {L.das_ksp_get_n_blocks(ksp.handle)}: ilu {t_ilu:.2f}s  iters {info['iters']} fail {fail} relres {info['res']/info['res0']:.2e} solve {ts:.3f}s "
+    print(f"pc {pct} aggregation {cag} sweep-design {design} pcIters {pit} coarse {cagg}/{cmode} ({nag} aggregates, {cms:.3f} ms) block {b} overlap {ov} fill {fl} fp32 {f32} threads {nth} nblocks {L.das_ksp_get_n_blocks(ksp.handle)}: ilu {t_ilu:.2f}s  iters {info['iters']} fail {fail} relres {info['res']/info['res0']:.2e} solve {ts:.3f}s "
           f"-> {info['iters']/ts:.1f} it/s  spmv {L.das_timer_avg_ms(D.solver._h,b'spmv'):.3f} ms pc {L.das_timer_avg_ms(D.solver._h,b'pc'):.3f} ms")
     L.das_timer_enable(D.solver._h, 0)
     ksp.destroy() if hasattr(ksp, 'destroy') else None
