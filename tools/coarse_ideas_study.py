@@ -12,7 +12,7 @@ from dafoam_amd.pyDASolvers import pyDASolvers
 from common import options, norm_states
 which=sys.argv[1]
 if which=="channel":
-    nx,ny,nz=40,12,10; case=bench_channel_case(nx,ny,nz)
+    nx,ny,nz=[int(v) for v in sys.argv[2:5]] if len(sys.argv) >= 5 else (40,12,10); case=bench_channel_case(nx,ny,nz)
 else:
     nx,ny,nz=96,32,1; case=naca0012_case(nx,ny,nz,span=0.1)
 g=Geometry(case.mesh); N=g.nC
@@ -28,7 +28,7 @@ kk,jj,ii=np.meshgrid(np.arange(nz),np.arange(ny),np.arange(nx),indexing="ij")
 def blocks(bi,bj,bk):
     nbi,nbj=(nx+bi-1)//bi,(ny+bj-1)//bj
     return ((kk//bk)*(nbi*nbj)+(jj//bj)*nbi+(ii//bi)).ravel()
-agg=blocks(4,4,5) if which=="channel" else blocks(3,8,1)
+agg=blocks(4,4,5) if which=="channel" else blocks(3,8,1)  # (channel: 4 cells along x per aggregate at every size)
 nagg=agg.max()+1
 Zp=sp.csr_matrix((np.ones(N),(np.arange(N),agg)),shape=(N,nagg))
 def run(label, pc):
