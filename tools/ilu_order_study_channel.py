@@ -24,7 +24,7 @@ def order(keys, rev=()):
     ks=[(-q if t in rev else q) for t,q in enumerate(keys)]
     key=np.lexsort(ks[::-1]); return np.concatenate([key[~late[key]], key[late[key]]])
 nat=np.argsort(S["natural"])
-orders={"library natural": nat,
+orders={"library default (rcm of the cell graph)": nat,
         "i fastest, j, k; late nodes last": order((k,j,i)),
         "k fastest, i, j slowest": order((j,i,k)),
         "j fastest, k, i slowest (planes of constant x)": order((i,k,j)),

@@ -25,7 +25,7 @@ late=cell<0
 def order(keys):
     key=np.lexsort(keys[::-1])  # first key slowest
     return np.concatenate([key[~late[key]], key[late[key]]])
-orders={"natural (i fastest, then j, then k)": np.argsort(S["natural"]),
+orders={"library default (rcm of the cell graph)": np.argsort(S["natural"]),
         "k fastest, then i, then j": order((j,i,k)),
         "k fastest, then j, then i": order((i,j,k)),
         "j fastest, then i, then k": order((k,i,j)),
