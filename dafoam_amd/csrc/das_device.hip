@@ -2734,6 +2734,8 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
     const int pcLag = (int)std::max<long long>(1, s->opt.geti("amd.primalPCLag"));
     const double serExp = s->opt.getd("amd.primalSERExponent");
     const long long linIters = s->opt.geti("amd.primalLinearIters");
+    const bool ramp = s->opt.gets("amd.primalTauMode") == "ramp";
+    const double growth = s->opt.getd("amd.primalTauGrowth"), growthMax = s->opt.getd("amd.primalTauGrowthMax"), tauMax = s->opt.getd("amd.primalTauMax");
     ensure_coloring(s);
     // Krylov options of the inner solves (restored afterwards)
     const Options saved = s->opt;
@@ -2794,10 +2796,26 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
             if (rnew == rnew && rnew < 1.5 * rn) break;
             omega *= 0.5;
         }
+        const bool accepted = rnew == rnew && rnew < 1.5 * rn;
+        if (ramp && !accepted) {
+            // no damped update is acceptable: the step is rejected, the pseudo-time step cut, the preconditioner rebuilt
+            tau *= 0.1;
+            sincePC = pcLag;
+            info.steps = step + 1;
+            info.hist.push_back(rn);
+            if (s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] Newton primal step %d: REJECTED (|R| would be %.3e), tau -> %.2e\n", step + 1, rnew, tau);
+            DAS_CHECK(tau > 1e-8, DAS_ERR_INTERNAL, "Newton primal: pseudo-time step collapsed");
+            continue;
+        }
         DAS_HIP(hipMemcpyAsync(s->d_W.p, Wn.p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
         DAS_HIP(hipMemcpyAsync(Rc.p, Rn.p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
         // a preconditioner built for a much smaller tau is rebuilt early
-        const double tauNew = std::min(1e12, tau0 * std::pow(info.res0 / std::max(rnew, 1e-300), serExp));
+        // "ser": switched evolution relaxation on the INITIAL residual (tau = tau0 (|R0|/|R|)^p - fine when the start is close,
+        // e.g. a prolonged coarse solution); "ramp": the CFL ramp of implicit RANS solvers - tau grows by at least `growth` per
+        // full step (a start far from the solution first RAISES the residual norm while the boundary layers form: tying tau to
+        // |R0|/|R| would shrink it there), by the residual drop (^p) when that is larger, and shrinks with a damped update
+        const double tauNew = !ramp ? std::min(1e12, tau0 * std::pow(info.res0 / std::max(rnew, 1e-300), serExp))
+                                    : std::min(tauMax, tau * (omega == 1.0 ? std::max(growth, std::min(growthMax, std::pow(rn / std::max(rnew, 1e-300), serExp))) : std::max(omega, 0.25)));
         if (tauNew > 4.0 * tau || tauNew < 0.25 * tau) sincePC = pcLag;
         tau = tauNew;
         rn = rnew;

@@ -70,6 +70,12 @@ Options::Options() {
     i["amd.coloringOnDevice"] = 1;   // serial first-fit colouring as a data-flow kernel (das_color.hpp); 0: host variants
     d["amd.primalTau0"] = 1.0;          // Newton primal: initial pseudo-time factor (diagonal scaled by 1 + 1/tau), SER growth
     d["amd.primalSERExponent"] = 1.5;   // tau = tau0 (|R0| / |R|)^exponent (measured: 1.0 -> 52+ steps, 1.5 -> 20-29, 2.0 -> 17-21 on the bench channels)
+    // pseudo-time control: "ser" (tau = tau0 (|R0|/|R|)^p: starts close to the solution) | "ramp" (CFL ramp: tau grows by >= primalTauGrowth
+    // per accepted full step, by the residual drop^p if larger (<= primalTauGrowthMax), shrinks with damped / rejected steps: cold starts)
+    s["amd.primalTauMode"] = "ser";
+    d["amd.primalTauGrowth"] = 1.5;
+    d["amd.primalTauGrowthMax"] = 10.0;
+    d["amd.primalTauMax"] = 1.0e12;
     d["amd.primalLinearTol"] = 1.0e-3;  // relative tolerance of the inner GMRES solves
     i["amd.primalLinearIters"] = 300;
     i["amd.primalPCLag"] = 3;           // Newton steps per preconditioner rebuild

@@ -864,6 +864,17 @@ def naca0012_xy(t):
     return x, np.where(t < 0.5, -yt, yt)
 
 
+def naca_normal_distribution(ny, first_cell=2.0e-5, radius=20.0):
+    """Wall-normal point distribution of the O-grid: geometric growth from `first_cell` to `radius` over ny cells."""
+    lo, hi = 1.0 + 1e-9, 2.0
+    f = lambda r: first_cell * (r**ny - 1.0) / (r - 1.0) - radius  # noqa: E731
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if f(mid) < 0 else (lo, mid)
+    r = 0.5 * (lo + hi)
+    return first_cell * (r ** np.arange(ny + 1) - 1.0) / (r - 1.0)
+
+
 def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first_cell=2.0e-5, U0=10.0, aoa_deg=2.0, nu=1.5e-5, nuTilda0=4.5e-5,
                   wall_function=False, seed=0, perturb=0.02) -> FoamCase:
     """DASimpleFoam + SA around a NACA0012 (chord 1) on a single-block O-grid of n_around x n_normal x nz hexahedra, extruded
@@ -874,14 +885,7 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
     free stream at `aoa_deg`, p fixedValue), front / back (symmetry).  States: a smooth synthetic boundary-layer-like flow
     (seeded perturbation) - the adjoint operator's conditioning does not depend on primal convergence."""
     nx, ny = int(n_around), int(n_normal)
-    # wall-normal distribution: geometric growth with ratio r from the first cell height to the outer radius
-    lo, hi = 1.0 + 1e-9, 2.0
-    f = lambda r: first_cell * (r**ny - 1.0) / (r - 1.0) - radius  # noqa: E731
-    for _ in range(200):
-        mid = 0.5 * (lo + hi)
-        lo, hi = (mid, hi) if f(mid) < 0 else (lo, mid)
-    r = 0.5 * (lo + hi)
-    d = first_cell * (r ** np.arange(ny + 1) - 1.0) / (r - 1.0)      # distance from the wall, d[0] = 0, d[ny] = radius
+    d = naca_normal_distribution(ny, first_cell, radius)             # distance from the wall, d[0] = 0, d[ny] = radius
     sblend = d / d[-1]
     t = np.arange(nx) / nx
     xa, ya = naca0012_xy(t)
@@ -995,3 +999,96 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
     case = FoamCase(mesh=mesh, solver_name="DASimpleFoam", nu=nu, bcs=bcs, y_wall=y)
     case.states = np.concatenate([U.ravel(), p, nuT, phi])
     return case
+
+
+def naca_fluxes_from_velocity(case: FoamCase, U):
+    """phi of every face from cell velocities: linear interpolation on internal faces, the boundary value of the patch
+    condition on the rest (wall 0, far field: the owner cell / free stream by flow direction, symmetry 0)."""
+    mesh = case.mesh
+    g = _InputGeometry(mesh)
+    nIF, F = mesh.n_internal_faces, mesh.n_faces
+    own, nei = mesh.owner, mesh.neighbour
+    phi = np.zeros(F)
+    phi[:nIF] = np.einsum("ij,ij->i", g.w[:, None] * U[own[:nIF]] + (1 - g.w[:, None]) * U[nei], g.Sf[:nIF])
+    for pt in mesh.patches:
+        if pt.name == "farfield":
+            sl = slice(pt.start, pt.start + pt.size)
+            Uinf = np.asarray(case.bcs["farfield"]["U"][1], dtype=float)
+            out = np.einsum("ij,ij->i", U[own[sl]], g.Sf[sl])
+            phi[sl] = np.where(out > 0.0, out, g.Sf[sl] @ Uinf)
+    return phi
+
+
+def prolong_naca_state(coarse_dims, coarse_states, fine_case: FoamCase, fine_dims, first_cell=2.0e-5, radius=20.0, coarse_first_cell=None):
+    """Cell fields of a 2-D (one spanwise layer) NACA0012 O-grid solution interpolated to a finer O-grid of the same family
+    (grid sequencing of the primal: the reference users start a fine case from `mapFields` of a coarse one).  Bilinear in
+    (contour parameter, wall distance along the ray); phi is rebuilt from the interpolated velocity."""
+    nxc, nyc = coarse_dims
+    nxf, nyf = fine_dims
+    Nc, Nf = nxc * nyc, nxf * nyf
+    assert fine_case.mesh.n_cells == Nf, "prolong_naca_state works on one spanwise layer"
+    dc = naca_normal_distribution(nyc, first_cell if coarse_first_cell is None else coarse_first_cell, radius)
+    df = naca_normal_distribution(nyf, first_cell, radius)
+    # logarithmic wall-distance coordinate of the cell centres (geometric stretching -> uniform in the index)
+    sc, sf = np.log(0.5 * (dc[1:] + dc[:-1])), np.log(0.5 * (df[1:] + df[:-1]))
+    jf = np.interp(sf, sc, np.arange(nyc))                              # fractional coarse j of every fine j (clamped)
+    j0 = np.clip(np.floor(jf).astype(int), 0, nyc - 2) if nyc > 1 else np.zeros(nyf, int)
+    wj = np.clip(jf - j0, 0.0, 1.0)
+    tf = (np.arange(nxf) + 0.5) / nxf * nxc - 0.5                        # fractional coarse i (periodic)
+    i0 = np.floor(tf).astype(int)
+    wi = tf - i0
+    i0m, i1m = i0 % nxc, (i0 + 1) % nxc
+    j1 = np.minimum(j0 + 1, nyc - 1)
+
+    def interp(fc):                                                     # fc[(nyc, nxc)] -> (nyf, nxf)
+        a = fc[j0][:, i0m] * (1 - wi)[None, :] + fc[j0][:, i1m] * wi[None, :]
+        b = fc[j1][:, i0m] * (1 - wi)[None, :] + fc[j1][:, i1m] * wi[None, :]
+        return a * (1 - wj)[:, None] + b * wj[:, None]
+
+    Wc = np.asarray(coarse_states)
+    Uc = Wc[: 3 * Nc].reshape(nyc, nxc, 3)
+    U = np.stack([interp(Uc[:, :, k]) for k in range(3)], axis=2).reshape(Nf, 3)
+    U[:, 2] = 0.0
+    p = interp(Wc[3 * Nc : 4 * Nc].reshape(nyc, nxc)).ravel()
+    nuT = np.maximum(interp(Wc[4 * Nc : 5 * Nc].reshape(nyc, nxc)).ravel(), 1e-14)
+    phi = naca_fluxes_from_velocity(fine_case, U)
+    return np.concatenate([U.ravel(), p, nuT, phi])
+
+
+def extrude_naca_state(case2d: FoamCase, states2d, case3d: FoamCase, dims):
+    """A one-layer solution copied to every spanwise layer of the extruded mesh (same n_around x n_normal): with symmetry planes
+    front and back the 2-D solution IS the solution of the extruded case - cell fields repeat, in-plane face fluxes scale with
+    the layer thickness, spanwise fluxes vanish."""
+    nx, ny, nz = dims
+    m2, m3 = case2d.mesh, case3d.mesh
+    N2, N3 = m2.n_cells, m3.n_cells
+    assert N2 == nx * ny and N3 == nx * ny * nz
+    W2 = np.asarray(states2d)
+    U = np.tile(W2[: 3 * N2].reshape(N2, 3), (nz, 1))
+    p, nuT = np.tile(W2[3 * N2 : 4 * N2], nz), np.tile(W2[4 * N2 : 5 * N2], nz)
+    phi2 = W2[5 * N2 :]
+    g2, g3 = _InputGeometry(m2), _InputGeometry(m3)
+    a2, a3 = np.linalg.norm(g2.Sf, axis=1), np.linalg.norm(g3.Sf, axis=1)
+    nIF2, nIF3 = m2.n_internal_faces, m3.n_internal_faces
+    phi3 = np.zeros(m3.n_faces)
+    # internal faces: in-plane faces of layer k pair (own % N2, nei % N2) within the same layer
+    key2 = m2.owner[:nIF2].astype(np.int64) * N2 + m2.neighbour.astype(np.int64)
+    o2 = np.argsort(key2)
+    own3, nei3 = m3.owner[:nIF3].astype(np.int64), m3.neighbour.astype(np.int64)
+    same = (own3 // N2) == (nei3 // N2)
+    key3 = (own3[same] % N2) * N2 + (nei3[same] % N2)
+    pos = np.searchsorted(key2[o2], key3)
+    assert np.all(key2[o2][pos] == key3)
+    f2 = o2[pos]
+    idx3 = np.nonzero(same)[0]
+    phi3[idx3] = phi2[f2] * a3[idx3] / a2[f2]
+    sl2 = {pt.name: pt for pt in m2.patches}
+    for pt in m3.patches:
+        if pt.name in ("airfoil", "farfield"):
+            q = sl2[pt.name]
+            cell2face = np.full(N2, -1, dtype=np.int64)
+            cell2face[m2.owner[q.start : q.start + q.size]] = np.arange(q.start, q.start + q.size)
+            f3 = np.arange(pt.start, pt.start + pt.size)
+            f2b = cell2face[m3.owner[f3] % N2]
+            phi3[f3] = phi2[f2b] * a3[f3] / a2[f2b]
+    return np.concatenate([U.ravel(), p, nuT, phi3])

@@ -30,7 +30,125 @@ def build(force=False):
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
         subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", _SO, _SRC, "-lm"])
+    build_omp(force)
     return _SO
+
+
+_SRC_OMP = os.path.join(_HERE, "csrc", "oracle_krylov_omp.c")
+_SO_OMP = os.path.join(_HERE, "_build", "liboracle_krylov_omp.so")
+_lib_omp = None
+
+
+def build_omp(force=False):
+    os.makedirs(os.path.dirname(_SO_OMP), exist_ok=True)
+    if force or not os.path.exists(_SO_OMP) or os.path.getmtime(_SO_OMP) < os.path.getmtime(_SRC_OMP):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-o", _SO_OMP, _SRC_OMP, "-lm"])
+    return _SO_OMP
+
+
+def lib_omp():
+    global _lib_omp
+    if _lib_omp is None:
+        L = C.CDLL(build_omp())
+        vp = C.c_void_p
+        L.okry_create.restype = vp
+        L.okry_create.argtypes = [C.c_int]
+        L.okry_threads.argtypes = [vp]
+        L.okry_free.argtypes = [vp]
+        L.okry_stream_GBps.restype = C.c_double
+        L.okry_stream_GBps.argtypes = [vp, C.c_longlong, C.c_int]
+        L.okry_set_operator.argtypes = [vp, C.c_longlong, _lp, _ip, _dp]
+        L.okry_spmv.argtypes = [vp, _dp, _dp]
+        L.okry_set_pc_ilu0.argtypes = [vp, C.c_longlong, _lp, _ip, _dp, _ip, C.c_double]
+        L.okry_pc_levels.argtypes = [vp, _ip, _ip]
+        L.okry_pc_nnz.restype = C.c_longlong
+        L.okry_pc_nnz.argtypes = [vp]
+        L.okry_set_coarse.argtypes = [vp, C.c_longlong, C.c_longlong, _ip, C.c_int, _dp]
+        L.okry_coarse_operator.argtypes = [C.c_longlong, C.c_longlong, _ip, C.c_int, _lp, _ip, _dp, _dp]
+        L.okry_pc.argtypes = [vp, _dp, _dp]
+        L.okry_gmres.argtypes = [vp, _dp, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, _dp, C.c_int, _dp]
+        _lib_omp = L
+    return _lib_omp
+
+
+class OmpKrylov:
+    """All-core CPU solver of the adjoint system (oracle/csrc/oracle_krylov_omp.c): CSR operator with first-touch placement,
+    ONE global level-scheduled scalar ILU(0) of the PC matrix in a caller-given unknown order, optional additive coarse
+    correction on one scalar cell field, GMRES(CGS2).  Matrices are passed as raw CSR arrays (rowptr int64, col int32, values
+    fp64) so that the bench-size systems (10^9 entries) never go through scipy."""
+
+    def __init__(self, threads=0):
+        self.L = lib_omp()
+        self.h = C.c_void_p(self.L.okry_create(int(threads)))
+        self.threads = int(self.L.okry_threads(self.h))
+        self.n = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.okry_free(self.h)
+            self.h = None
+
+    @staticmethod
+    def _csr(A):
+        if isinstance(A, tuple):
+            rp, ci, v = A
+        else:
+            A = sp.csr_matrix(A)
+            rp, ci, v = A.indptr, A.indices, A.data
+        return (np.ascontiguousarray(rp, dtype=np.int64), np.ascontiguousarray(ci, dtype=np.int32), np.ascontiguousarray(v, dtype=np.float64))
+
+    def stream_GBps(self, n_doubles=1 << 27, reps=5):
+        return float(self.L.okry_stream_GBps(self.h, int(n_doubles), int(reps)))
+
+    def set_operator(self, A):
+        rp, ci, v = self._csr(A)
+        self.n = rp.size - 1
+        assert self.L.okry_set_operator(self.h, self.n, _p(rp, _lp), _p(ci, _ip), _p(v, _dp)) == 0
+
+    def set_pc(self, P, perm=None, shift=1e-12):
+        rp, ci, v = self._csr(P)
+        self.n = rp.size - 1
+        pm = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+        rc = self.L.okry_set_pc_ilu0(self.h, self.n, _p(rp, _lp), _p(ci, _ip), _p(v, _dp), _p(pm, _ip) if pm is not None else None, float(shift))
+        assert rc >= 0, rc
+        a, b = C.c_int(0), C.c_int(0)
+        self.L.okry_pc_levels(self.h, C.byref(a), C.byref(b))
+        self.levels = (a.value, b.value)
+        self.nshift = rc
+        return rc
+
+    def set_coarse(self, P, offset, ncells, agg):
+        """Additive correction Z (Z^T P_ff Z)^-1 Z^T on the scalar cell field at `offset` (aggregate id per cell)."""
+        rp, ci, v = self._csr(P)
+        agg = np.ascontiguousarray(agg, dtype=np.int32)
+        nagg = int(agg.max()) + 1
+        E = np.zeros((nagg, nagg))
+        self.L.okry_coarse_operator(int(offset), int(ncells), _p(agg, _ip), nagg, _p(rp, _lp), _p(ci, _ip), _p(v, _dp), _p(E, _dp))
+        Einv = np.ascontiguousarray(np.linalg.inv(E))
+        self.L.okry_set_coarse(self.h, int(offset), int(ncells), _p(agg, _ip), nagg, _p(Einv, _dp))
+        return nagg
+
+    def matvec(self, x):
+        y = np.empty(self.n)
+        self.L.okry_spmv(self.h, _p(np.ascontiguousarray(x, dtype=np.float64), _dp), _p(y, _dp))
+        return y
+
+    def pc_solve(self, b):
+        x = np.empty(self.n)
+        self.L.okry_pc(self.h, _p(np.ascontiguousarray(b, dtype=np.float64), _dp), _p(x, _dp))
+        return x
+
+    def gmres(self, rhs, restart=1000, max_iters=1000, rel_tol=1e-6, abs_tol=1e-14, tol_diff=1e2, fixed_iters=0):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        x = np.empty(self.n)
+        cap = int(max(max_iters, fixed_iters)) + 8
+        hist = np.zeros(cap)
+        info = np.zeros(8)
+        fail = self.L.okry_gmres(self.h, _p(rhs, _dp), _p(x, _dp), int(restart), int(max_iters), float(rel_tol), float(abs_tol), float(tol_diff), int(fixed_iters),
+                                 _p(hist, _dp), cap, _p(info, _dp))
+        assert fail >= 0, "allocation failure in okry_gmres"
+        return x, dict(iters=int(info[0]), res0=float(info[1]), res=float(info[2]), seconds=float(info[3]), seconds_spmv=float(info[4]), seconds_pc=float(info[5]),
+                       seconds_orth=float(info[6]), hist=hist[: int(info[7])].copy(), fail=int(fail))
 
 
 def lib():

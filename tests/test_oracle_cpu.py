@@ -253,3 +253,56 @@ def test_threaded_baseline_operators():
     rhs = np.ones(A.shape[0]) * sc
     psi, info = OL.gmres(T.matvec, rhs, T.pc_solve, restart=200, max_iters=400, rel_tol=1e-8)
     assert info["fail"] == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) < 1e-5
+
+
+def test_all_core_cpu_krylov_matches_the_serial_kernels_and_a_direct_solve():
+    """oracle/csrc/oracle_krylov_omp.c (bench.py cpu_baseline at the bench size, psi parity at 200 k cells): the OpenMP CSR
+    product == scipy, the level-scheduled permuted ILU(0) == the serial ILU(0) kernel of oracle_linalg.c on the permuted matrix
+    (bit for bit: same elimination order inside a row), the additive coarse correction == its numpy formula, GMRES(CGS2)
+    iterates == oracle.linear.gmres with the same preconditioner, and the solution == a sparse direct solve - on the adjoint
+    matrix of a small channel."""
+    import scipy.sparse as sp
+
+    case = channel_case(6, 5, 4)
+    g = Geometry(case.mesh)
+    sc = J.state_scales(case, g, NORM_STATES)
+    con = J.connectivity(case, g)
+    col, _ = J.greedy_coloring(con)
+    A = J.jacobian_colored(case, g, case.states, con, col, sc, mode="cs", lower_bound=0).tocsr()
+    A.sort_indices()
+    n, N = A.shape[0], g.nC
+    rng = np.random.default_rng(3)
+    K = OL.OmpKrylov(3)
+    K.set_operator(A)
+    x = rng.standard_normal(n)
+    assert np.abs(K.matvec(x) - A @ x).max() < 1e-12 * np.abs(A @ x).max()
+    # cell-by-cell unknown order (U, p, nuTilda of a cell, then the faces) as the permutation
+    perm = np.concatenate([np.array([3 * c, 3 * c + 1, 3 * c + 2, 3 * N + c, 4 * N + c]) for c in range(N)] + [np.arange(5 * N, n)]).astype(np.int32)
+    K.set_pc(A, perm)
+    Ap = sp.csr_matrix(A[perm][:, perm])
+    Ap.sort_indices()
+    ilu = OL.ILU(Ap, fill=0)
+    b = rng.standard_normal(n)
+    ref = np.empty(n)
+    ref[perm] = ilu.solve(b[perm])
+    assert np.array_equal(K.pc_solve(b), ref)
+    agg = (np.arange(N) * 5 // N).astype(np.int32)
+    nagg = K.set_coarse(A, 3 * N, N, agg)
+    Z = sp.csr_matrix((np.ones(N), (np.arange(N), agg)), shape=(N, nagg))
+    E = (Z.T @ A[3 * N : 4 * N, 3 * N : 4 * N] @ Z).toarray()
+    ref2 = ref.copy()
+    ref2[3 * N : 4 * N] += Z @ np.linalg.solve(E, Z.T @ b[3 * N : 4 * N])
+    assert relerr(K.pc_solve(b), ref2) < 1e-12
+    rhs = np.zeros(n)
+    rhs[0 : 3 * N : 3] = g.V
+    rhs *= sc
+    xs, info = K.gmres(rhs, restart=60, max_iters=600, rel_tol=1e-12)
+    xo, io = OL.gmres(lambda v: A @ v, rhs, K.pc_solve, restart=60, max_iters=600, rel_tol=1e-12)
+    assert info["fail"] == 0 and info["iters"] == io["iters"]
+    m = min(len(info["hist"]), len(io["hist"]), 40)
+    assert np.allclose(info["hist"][:m], io["hist"][:m], rtol=1e-6, atol=1e-12 * info["hist"][0])
+    assert relerr(xs, spla.spsolve(A.tocsc(), rhs)) < 1e-8
+    # fixed-iteration timing mode runs exactly the requested count
+    _, inf = K.gmres(rhs, restart=7, fixed_iters=20)
+    assert inf["iters"] == 20
+    assert K.stream_GBps(1 << 20, 2) > 0
