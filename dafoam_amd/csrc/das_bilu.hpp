@@ -376,7 +376,8 @@ __global__ __launch_bounds__(256) void k_bilu_scatter(long long n, const long lo
                                                       const double* __restrict__ v, const int* __restrict__ unkNode,
                                                       const unsigned char* __restrict__ unkSlot, const long long* __restrict__ bptr,
                                                       const int* __restrict__ bcol, const unsigned char* __restrict__ late, double* __restrict__ bval,
-                                                      unsigned long long* dropped, int transpose, double diagScale) {
+                                                      unsigned long long* dropped, int transpose, double diagScale, long long shiftExLo,
+                                                      long long shiftExHi, long long shiftEnd) {
     const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l16 = threadIdx.x & 15;
     if (row >= n) return;
@@ -399,7 +400,10 @@ __global__ __launch_bounds__(256) void k_bilu_scatter(long long n, const long lo
             if (cm < J) lo = mid + 1; else hi = mid - 1;
         }
         if (e < 0) { if (!(late[I] && late[J])) atomicAdd(dropped, 1ull); continue; }  // late-late couplings are dropped by design
-        bval[e * BILU_NB2 + r * 8 + c] = (j == row) ? v[k] * diagScale : v[k];  // diagScale = 1 + 1/tau: pseudo-transient shift
+        // diagScale = 1 + 1/tau: pseudo-transient shift, on the rows below shiftEnd outside [shiftExLo, shiftExHi) (the Newton primal
+        // leaves the pressure and flux rows unshifted, see run_newton_primal)
+        const bool shifted = row < shiftEnd && !(row >= shiftExLo && row < shiftExHi);
+        bval[e * BILU_NB2 + r * 8 + c] = (j == row && shifted) ? v[k] * diagScale : v[k];
     }
 }
 __global__ void k_bilu_pad_diag(int nNodes, const int* __restrict__ nodeUnk, const long long* __restrict__ bdiag, double* __restrict__ bval) {
@@ -745,7 +749,8 @@ inline void bilu_launch_shape(NodeILU& P, hipStream_t st);
 // Numeric setup on the device from the assembled PC matrix (device CSR, rows = states).
 inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned, int reach,
                        bool fp32, long long An, const long long* d_rp, const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P,
-                       bool debug, int nthr, bool rcm, bool transpose = false, double diagScale = 1.0) {
+                       bool debug, int nthr, bool rcm, bool transpose = false, double diagScale = 1.0, long long shiftExLo = 0,
+                       long long shiftExHi = 0, long long shiftEnd = (long long)1 << 62) {
     const double t0 = wall_seconds();
     std::vector<char> cellOwned(m.nC, 1);
     if (!owned.empty()) {
@@ -775,7 +780,7 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     P.t_struct = wall_seconds() - t0;
     double t1 = wall_seconds();
     hipLaunchKernelGGL(k_bilu_scatter, dim3((unsigned)((An + 15) / 16)), dim3(256), 0, st, An, d_rp, d_ci, d_av, d_unkNode.p, d_unkSlot.p, d_bptr.p,
-                       d_bcol.p, d_late.p, bval.p, d_dropped.p, transpose ? 1 : 0, diagScale);
+                       d_bcol.p, d_late.p, bval.p, d_dropped.p, transpose ? 1 : 0, diagScale, shiftExLo, shiftExHi, shiftEnd);
     hipLaunchKernelGGL(k_bilu_pad_diag, dim3((unsigned)(((long long)nN * BILU_NB + 255) / 256)), dim3(256), 0, st, nN, P.nodeUnk.p, d_bdiag.p, bval.p);
     DAS_HIP(hipGetLastError());
     unsigned long long dropped = 0;

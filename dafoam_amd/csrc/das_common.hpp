@@ -126,6 +126,7 @@ struct VmBuf {
     void release() {
         stop_worker();
         if (vmm && p) {
+            (void)hipDeviceSynchronize();  // nothing in flight may still address the range (hipFree synchronises implicitly, hipMemUnmap does not)
             size_t off = 0;
             for (size_t i = 0; i < handles.size(); i++) {
                 (void)hipMemUnmap((char*)p + off, sizes[i]);

@@ -538,11 +538,13 @@ __global__ void k_mul(long long n, const double* __restrict__ s, double* __restr
 }
 
 // ---- Newton primal helpers ------------------------------------------------------------------------------------------------
-__global__ void k_extract_diag(long long n, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v, double* __restrict__ d) {
+__global__ void k_extract_diag(long long n, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v, double* __restrict__ d,
+                               long long exLo, long long exHi, long long end) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double a = 0.0;
-    for (long long k = rp[i]; k < rp[i + 1]; k++) if (ci[k] == i) { a = v[k]; break; }
+    if (i < end && !(i >= exLo && i < exHi))
+        for (long long k = rp[i]; k < rp[i + 1]; k++) if (ci[k] == i) { a = v[k]; break; }
     d[i] = a;
 }
 __global__ void k_add_diag_prod(long long n, double a, const double* __restrict__ d, const double* __restrict__ x, double* __restrict__ y) {
@@ -933,6 +935,7 @@ struct das_ksp {
     bool useBilu = false;
     bool pcTranspose = false;   // factorise jacPCMat^T (forward system of the Newton primal)
     double pcDiagScale = 1.0;   // 1 + 1/tau on the diagonal (pseudo-transient shift)
+    long long shiftExLo = 0, shiftExHi = 0, shiftEnd = (long long)1 << 62;  // ... on the rows below shiftEnd outside [shiftExLo, shiftExHi)
     struct CoarsePC {
         bool active = false, deflated = false;
         bool global = false;        // multi-GPU: ONE coarse space over all ranks (das_ksp_set_global_coarse), else per rank
@@ -1833,7 +1836,7 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     const int reach = pc_stencil_reach(s);
     const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
     bilu_setup(s->mesh, s->st_full.states, s->n, s->owned, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
-               k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s), k->pcTranspose, k->pcDiagScale);
+               k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s), k->pcTranspose, k->pcDiagScale, k->shiftExLo, k->shiftExHi, k->shiftEnd);
     k->useBilu = true;
     k->pc.setup_seconds = wall_seconds() - t0;
     k->pc.nBlocks = 1;
@@ -1867,7 +1870,8 @@ static void coarse_build_operator(das_solver* s, das_ksp* k, int naggG, int aggO
     const Mat& P = k->pcmat->m;
     // rows: cells of every aggregate present on this rank (transposed storage: rows = states); columns: owned residual cells
     hipLaunchKernelGGL(k_coarse_assemble, dim3(naggG), dim3(256), 0, s->stream, naggG, C.aptrAll.p, C.cellsAll.p, N, C.off, P.rowptr.p, P.col.p, P.val.p,
-                       k->pcTranspose ? C.aggRow.p : C.agg.p, E.p, k->pcTranspose ? 1 : 0, k->pcDiagScale);
+                       k->pcTranspose ? C.aggRow.p : C.agg.p, E.p, k->pcTranspose ? 1 : 0,
+                       (C.off < k->shiftEnd && !(C.off >= k->shiftExLo && C.off < k->shiftExHi)) ? k->pcDiagScale : 1.0);
     if (C.global) {
         DAS_CHECK(!k->pcTranspose, DAS_ERR_ARG, "global coarse space: adjoint preconditioner only");
         if (!(s->halo.active && s->halo.allreduce(E.p, naggG * naggG, s->stream)) && s->allreduce_cb) s->allreduce_cb(E.p, naggG * naggG, s->comm_user);
@@ -2735,6 +2739,19 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
     const double serExp = s->opt.getd("amd.primalSERExponent");
     const long long linIters = s->opt.geti("amd.primalLinearIters");
     const bool ramp = s->opt.gets("amd.primalTauMode") == "ramp";
+    // WHERE the pseudo-time term acts.  "momentum" (default): on the transported cell fields (U, T, nuTilda) only - implicit
+    // under-relaxation of the transport equations, the pressure and the face fluxes follow algebraically, as in a coupled
+    // pressure-based solver.  "all" (round 2): every row.  Measured with the host-emulated kernel bodies and exact Jacobians on
+    // the NACA0012 O-grid (round 4): with the term on the pressure rows the pseudo-time evolution itself is UNSTABLE beyond
+    // tau ~ 3 (a disturbance grows ~1.3x per step until it explodes; with the line search the residual just wanders), without
+    // it the residual falls monotonically while tau ramps up.  Starts close to the solution (the prolonged channel state) do
+    // not notice the difference: tau is large after a few steps.
+    const bool ptMomentum = s->opt.gets("amd.primalPseudoTimeFields") == "momentum";
+    long long pLo = 0, pHi = 0, phiLo = (long long)1 << 62;
+    for (const StateDef& q : s->st_full.states) {
+        if (q.name == "p") { pLo = q.offset; pHi = q.offset + q.size; }
+        if (q.name == "phi") phiLo = q.offset;
+    }
     const double growth = s->opt.getd("amd.primalTauGrowth"), growthMax = s->opt.getd("amd.primalTauGrowthMax"), tauMax = s->opt.getd("amd.primalTauMax");
     ensure_coloring(s);
     // Krylov options of the inner solves (restored afterwards)
@@ -2768,15 +2785,21 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
         if (!(rn == rn)) break;
         if (sincePC >= pcLag) {
             // jacPCMat at the current states (coloured FD), transposed node-block ILU with the pseudo-transient diagonal
+            // ONE Krylov object for the whole run: only its preconditioner is rebuilt - the basis (a mapped virtual range at
+            // >= 4 GB) and the work vectors stay (round 4: ~160 create / map / unmap cycles of the basis at 200 k cells ended in a
+            // device memory fault, and the re-mapping was pure overhead)
+            if (k) { k->pcmat = nullptr; DAS_HIP(hipStreamSynchronize(st)); }
             P.reset(assemble(s, 1, 0));
-            k.reset(new das_ksp);
+            if (!k) k.reset(new das_ksp);
             k->pcmat = P.get();
             k->pcTranspose = true;
             k->pcDiagScale = 1.0 + 1.0 / tau;
+            if (ptMomentum) { k->shiftExLo = pLo; k->shiftExHi = pHi; k->shiftEnd = phiLo; }
             setup_node_ilu(s, k.get());
             setup_coarse(s, k.get());
             if (s->fwd.diag.n != (size_t)n) s->fwd.diag.alloc(n);
-            hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n, B)), dim3(B), 0, st, n, P->m.rowptr.p, P->m.col.p, P->m.val.p, s->fwd.diag.p);
+            hipLaunchKernelGGL(k_extract_diag, dim3(nblk(n, B)), dim3(B), 0, st, n, P->m.rowptr.p, P->m.col.p, P->m.val.p, s->fwd.diag.p, k->shiftExLo,
+                               k->shiftExHi, k->shiftEnd);
             sincePC = 0;
             info.pcBuilds++;
         }
@@ -4183,7 +4206,12 @@ int das_ksp_set_global_coarse(das_solver_t* s, das_ksp_t* k, int naggGlobal, int
         if (C.h_agg[c] >= 0) DAS_CHECK(rows[c] == aggOffset + C.h_agg[c], DAS_ERR_ARG, "owned cells must carry offset + local aggregate");
     }
     coarse_build_operator(s, k, naggGlobal, aggOffset, rows);
-    return C.active ? DAS_OK : 1;  // 1: singular coarse operator, no coarse correction (all ranks see the same matrix)
+    if (C.active) return DAS_OK;
+    // singular global coarse operator (every rank sees the same summed matrix, so every rank lands here): fall back to the
+    // per-rank coarse spaces that were in place before the call (the failed build must not leave the
+    // preconditioner without any coarse correction)
+    coarse_build_operator(s, k, C.nagg, 0, C.h_agg);
+    return 1;
     DAS_CATCH
 }
 int das_ksp_get_history(das_ksp_t* k, double* hist, int cap) {

@@ -72,6 +72,7 @@ Options::Options() {
     d["amd.primalSERExponent"] = 1.5;   // tau = tau0 (|R0| / |R|)^exponent (measured: 1.0 -> 52+ steps, 1.5 -> 20-29, 2.0 -> 17-21 on the bench channels)
     // pseudo-time control: "ser" (tau = tau0 (|R0|/|R|)^p: starts close to the solution) | "ramp" (CFL ramp: tau grows by >= primalTauGrowth
     // per accepted full step, by the residual drop^p if larger (<= primalTauGrowthMax), shrinks with damped / rejected steps: cold starts)
+    s["amd.primalPseudoTimeFields"] = "momentum";  // rows that get the pseudo-time term: "momentum" (U, T, nuTilda) | "all"
     s["amd.primalTauMode"] = "ser";
     d["amd.primalTauGrowth"] = 1.5;
     d["amd.primalTauGrowthMax"] = 10.0;

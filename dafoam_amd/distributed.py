@@ -371,6 +371,15 @@ class ShardedAdjoint:
         rows = np.ascontiguousarray(w[p0 : p0 + N].cpu().numpy().round().astype(np.int32))
         from . import _capi
 
+        # the library validates the same conditions and would throw on ONE rank before the collective all-reduce of E, leaving the
+        # peers blocked: agree on the validation result first
+        ntot = int(cnt.sum())
+        ok = off >= 0 and off + int(nloc) <= ntot and rows.min() >= -1 and rows.max() < ntot and bool(np.all(rows[agg >= 0] == agg[agg >= 0] + off))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cpu" if stage else self.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            return 0
+
         rc = _capi.check(self.L.das_ksp_set_global_coarse(self.h, self.ksp.handle, int(cnt.sum()), off, rows.ctypes.data_as(_capi.c_int_p)))
         return int(cnt.sum()) if rc == 0 else 0
 
