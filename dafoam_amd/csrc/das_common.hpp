@@ -90,6 +90,17 @@ struct DevBuf {
 // a solve that converges after 464 vectors maps 60 GB, not 129, the mapping of the next chunk costs milliseconds, and the
 // scrubbing of freed memory overlaps with the first iterations.  The kernels see one contiguous range.  Any failure of the VM
 // path falls back to one hipMalloc of the whole range.
+// mapped virtual ranges of released VmBufs (never unmapped; see VmBuf::release)
+struct VmRange {
+    void* p = nullptr;
+    size_t reservedBytes = 0, mappedBytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<size_t> sizes;
+    int device = 0;
+};
+inline std::vector<VmRange>& vm_cache() { static std::vector<VmRange> c; return c; }
+inline std::mutex& vm_cache_mutex() { static std::mutex m; return m; }
+
 template <class T>
 struct VmBuf {
     T* p = nullptr;
@@ -126,14 +137,14 @@ struct VmBuf {
     void release() {
         stop_worker();
         if (vmm && p) {
-            (void)hipDeviceSynchronize();  // nothing in flight may still address the range (hipFree synchronises implicitly, hipMemUnmap does not)
-            size_t off = 0;
-            for (size_t i = 0; i < handles.size(); i++) {
-                (void)hipMemUnmap((char*)p + off, sizes[i]);
-                (void)hipMemRelease(handles[i]);
-                off += sizes[i];
-            }
-            (void)hipMemAddressFree(p, reservedBytes);
+            // the range is NOT unmapped: it goes to a process-wide cache and is handed to the next buffer that fits (round 4: a
+            // range reserved AFTER an earlier one had been unmapped and freed faulted as soon as its second chunk was written -
+            // "write access to a read-only page", twice, at 200 k cells - and re-mapping gigabytes per solver was pure overhead)
+            (void)hipDeviceSynchronize();  // nothing in flight may still address the range when its next owner starts writing
+            VmRange r;
+            r.p = (void*)p; r.reservedBytes = reservedBytes; r.mappedBytes = mappedBytes; r.handles = handles; r.sizes = sizes; r.device = device;
+            std::lock_guard<std::mutex> lk(vm_cache_mutex());
+            vm_cache().push_back(std::move(r));
         } else if (p) {
             (void)hipFree(p);
         }
@@ -157,6 +168,21 @@ struct VmBuf {
                 // whole 2 GB chunks only (address space is free; mapping a partial last chunk failed in hipMemSetAccess on ROCm 7.2)
                 const size_t unit = std::max(align, CHUNK / align * align);
                 const size_t total = (bytes + unit - 1) / unit * unit;
+                {   // a cached range of this device that is large enough (smallest fit), with whatever it has mapped already
+                    std::lock_guard<std::mutex> lk(vm_cache_mutex());
+                    std::vector<VmRange>& cache = vm_cache();
+                    int best = -1;
+                    for (size_t i = 0; i < cache.size(); i++)
+                        if (cache[i].device == device && cache[i].reservedBytes >= total && (best < 0 || cache[i].reservedBytes < cache[best].reservedBytes)) best = (int)i;
+                    if (best >= 0) {
+                        VmRange r = std::move(cache[best]);
+                        cache.erase(cache.begin() + best);
+                        p = (T*)r.p; reservedBytes = r.reservedBytes; mappedBytes = r.mappedBytes; handles = std::move(r.handles); sizes = std::move(r.sizes);
+                        vmm = true; n = n_;
+                        worker = std::thread([this]() { this->map_loop(); });
+                        return;
+                    }
+                }
                 void* base = nullptr;
                 if (hipMemAddressReserve(&base, total, align, nullptr, 0) == hipSuccess && base) {
                     p = (T*)base; reservedBytes = total; vmm = true; n = n_;

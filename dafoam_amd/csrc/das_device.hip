@@ -1101,6 +1101,28 @@ static void device_build_con(das_solver* s, int isPC, DevPattern* keepRowMajor =
     c.onDevice = true;
 }
 
+// longest chain c_1 < c_2 < ... of cells in which consecutive cells are at most two face-neighbour rings apart: a lower bound of the
+// dependent chain of the data-flow first-fit colouring in column order (columns conflict over even longer distances)
+static long long cell_chain_depth(const Mesh& m) {
+    std::vector<int> depth(m.nC, 0);
+    long long best = 0;
+    for (int c = 0; c < m.nC; c++) {
+        int d = 0;
+        for (int q = m.cf_ptr[c]; q < m.cf_ptr[c + 1]; q++) {
+            const int n1 = m.cf_other[q];
+            if (n1 < 0) continue;
+            if (n1 < c) d = std::max(d, depth[n1]);
+            for (int r = m.cf_ptr[n1]; r < m.cf_ptr[n1 + 1]; r++) {
+                const int n2 = m.cf_other[r];
+                if (n2 >= 0 && n2 < c) d = std::max(d, depth[n2]);
+            }
+        }
+        depth[c] = d + 1;
+        best = std::max<long long>(best, d + 1);
+    }
+    return best;
+}
+
 // preset != nullptr: colours read from a dRdWColoring file (reference DAJacCon::readJacConColoring :1980-2019) - they
 // are validated against the connectivity exactly like the reference does (DAColoring::validateColoring)
 static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
@@ -1187,8 +1209,15 @@ static void ensure_coloring(das_solver* s, const int* preset = nullptr) {
                         std::vector<unsigned char> isStart = d_start.to_host();
                         const std::vector<long long> gstart = color_groups_from_flags(nn, isStart);
                         lap("nets, positions, groups");
-                        const int rc = color_firstfit_run(nn, nKeep, gstart, d_cptr.p, d_crow.p, d_cpos.p, colors, st);
-                        lap("first-fit kernel");
+                        // a numbering whose lower-numbered 2-ring neighbours chain through (nearly) all cells - an O-grid whose ring j+1
+                        // starts next to the END of ring j - serialises the data-flow sweep (2 M-cell NACA0012: 63 s until the watchdog
+                        // fired, round 3): estimated on the cell graph BEFORE the launch, such meshes go straight to the speculative rounds
+                        const bool autoAlg = s->opt.gets("amd.coloringAlgorithm") == "auto";
+                        const long long depth = autoAlg ? cell_chain_depth(s->mesh) : 0;
+                        const bool deep = autoAlg && depth > std::max<long long>(20000, s->mesh.nC / 50);
+                        if (s->opt.geti("debug") && autoAlg) fprintf(stderr, "[dafoam_amd] colouring: dependency depth of the cell numbering ~%lld (%d cells) -> %s\n", depth, s->mesh.nC, deep ? "speculative rounds" : "data-flow first-fit");
+                        const int rc = deep ? -1 : color_firstfit_run(nn, nKeep, gstart, d_cptr.p, d_crow.p, d_cpos.p, colors, st);
+                        lap(deep ? "dependency-depth estimate" : "first-fit kernel");
                         bool ok = rc == 1;
                         if (rc == -1) {
                             // the watchdog stopped the data-flow sweep (a numbering without wavefront parallelism): the

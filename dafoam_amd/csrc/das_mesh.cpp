@@ -89,7 +89,9 @@ Options::Options() {
     i["amd.cgsAlwaysRefine"] = 0;   // 1: CGS2 every iteration; 0: refine if needed (reference default)
     i["amd.blockBatchedPC"] = 1;    // block GMRES: all right-hand sides through one pair of preconditioner sweeps (0: column by column)
     i["amd.opPackVector"] = 1;      // Krylov operator: vector-state rows packed as group rows (das_opmat.hpp)
-    s["amd.coloringAlgorithm"] = "firstfit";  // device colouring: "firstfit" (serial colours, data-flow over net bitmaps) | "speculative"
+    // device colouring: "firstfit" (serial colours, data-flow over net bitmaps) | "speculative" (order-independent rounds, ~20 % more colours) |
+    // "auto" (default): first-fit unless the cell numbering has no wavefront parallelism (estimated dependency depth, ensure_coloring)
+    s["amd.coloringAlgorithm"] = "auto";
     s["amd.volCoordMode"] = "dual";  // mesh-sensitivity product: "dual" (exact: Dual<1> points -> metrics -> residual) | "fd" (coloured central differences)
     i["amd.volCoordRings"] = 3;     // mesh-sensitivity product: face-neighbour rings a point's influence is followed over (the deepest stencil table)
     d["amd.volCoordRelStep"] = 1e-4;  // ... central-difference step of a point, relative to the smallest adjacent cell thickness

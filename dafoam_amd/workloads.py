@@ -1,0 +1,87 @@
+"""Host-side drivers that prepare the BASELINE workloads on the GPU: what a DAFoam run script does between reading the case and
+calling the adjoint - here: converge the DASimpleFoam + SA primal on the NACA0012 O-grid family (BASELINE configs[1] / [2]).
+
+The reference always linearises about a CONVERGED primal (`DAFoamSolver.solve_nonlinear` before `solve_linear`,
+dafoam/mphys/mphys_dafoam.py:314-433; its users start fine cases from `mapFields` of coarser ones).  The same sequence with this
+library's primal (`PYDAFOAM.solvePrimal` -> das_solve_primal, pseudo-transient Newton-Krylov): solve on a coarse O-grid from a
+smooth initial field, prolong, solve on the next finer one, ...; a spanwise extrusion of the finest 2-D solution is (up to the
+spanwise part of the momentum diagonal in the Rhie-Chow term, ~1e-5 relative) the solution of the extruded case with symmetry
+planes, and a few Newton steps on the extruded mesh remove that rest.  Everything here runs through the public API; no oracle."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .meshgen import extrude_naca_state, naca0012_case, prolong_naca_state
+
+NACA_PRIMAL_AMD = {"primalTauMode": "ramp", "primalTau0": 1.0, "primalTauGrowth": 1.5, "primalSERExponent": 1.0, "primalLinearIters": 300,
+                   "primalLinearTol": 1e-2, "primalPseudoTimeFields": "momentum", "coloringAlgorithm": "speculative"}
+
+
+def naca_levels(n_around, n_normal, coarsest=100):
+    """Grid-sequencing levels, coarse to fine: (n_around, n_normal) halved while at least `coarsest` cells stay around the airfoil."""
+    lv = [(int(n_around), int(n_normal))]
+    while lv[-1][0] // 2 >= coarsest and lv[-1][1] // 2 >= 8:
+        lv.append((lv[-1][0] // 2, lv[-1][1] // 2))
+    return lv[::-1]
+
+
+def naca_converged_primal(n_around=800, n_normal=250, options=None, first_cell=2.0e-5, rel_tol=1e-8, max_steps=120, coarsest=100, verbose=False,
+                          case_kwargs=None):
+    """Converged DASimpleFoam + SA state on the one-layer NACA0012 O-grid of n_around x n_normal cells.  Returns (case, info):
+    the FoamCase with `states` = the converged primal, info = list of per-level dicts (dims, steps, linearIterations, res0, res,
+    seconds, fail).  `options`: PYDAFOAM options (amd.primal* entries are overridden by the cold-start settings)."""
+    from .pyDAFoam import PYDAFOAM
+
+    levels = naca_levels(n_around, n_normal, coarsest)
+    fcs = [first_cell * 2 ** (len(levels) - 1 - i) for i in range(len(levels))]   # same growth ratio on every level
+    opts = dict(options or {})
+    opts["amd"] = dict(opts.get("amd", {}), **NACA_PRIMAL_AMD)
+    ckw = dict(case_kwargs or {})
+    ckw.setdefault("perturb", 0.0)
+    W_prev, info, case = None, [], None
+    for li, ((nx, ny), fc) in enumerate(zip(levels, fcs)):
+        t0 = time.time()
+        case = naca0012_case(nx, ny, 1, first_cell=fc, **ckw)
+        if W_prev is not None:
+            case.states = prolong_naca_state(levels[li - 1], W_prev, case, (nx, ny), first_cell=fc, coarse_first_cell=fcs[li - 1])
+        D = PYDAFOAM(options=opts, case=case)
+        fail, inf = D.solver.solvePrimal(maxSteps=max_steps, relTol=rel_tol, absTol=0.0)
+        W_prev = D.getStates().copy()
+        case.states = W_prev
+        rec = dict(dims=(nx, ny), first_cell=fc, steps=inf["steps"], linearIterations=inf["linearIterations"], res0=inf["res0"], res=inf["res"],
+                   fail=int(fail), seconds=time.time() - t0)
+        info.append(rec)
+        if verbose:
+            print(f"[naca primal] level {nx} x {ny}: {rec['steps']} Newton steps, {rec['linearIterations']} GMRES iterations, |R| {rec['res0']:.3e} -> {rec['res']:.3e}, "
+                  f"{rec['seconds']:.1f} s, fail {rec['fail']}", flush=True)
+        del D
+    return case, info
+
+
+def naca_extruded_case(case2d, dims2d, nz, dz=0.1, first_cell=2.0e-5, options=None, polish_steps=3, polish_tol=1e-3, verbose=False, case_kwargs=None):
+    """The one-layer solution extruded to nz spanwise layers of thickness dz (symmetry planes front / back), polished by a few
+    Newton steps on the extruded mesh.  Returns (case3d, info)."""
+    from .pyDAFoam import PYDAFOAM
+
+    nx, ny = dims2d
+    ckw = dict(case_kwargs or {})
+    ckw.setdefault("perturb", 0.0)
+    t0 = time.time()
+    case3 = naca0012_case(nx, ny, nz, span=dz * nz, first_cell=first_cell, **ckw)
+    case3.states = extrude_naca_state(case2d, case2d.states, case3, (nx, ny, nz))
+    info = dict(dims=(nx, ny, nz), steps=0, seconds=0.0)
+    if polish_steps > 0:
+        opts = dict(options or {})
+        # a start next to the solution: large pseudo-time step at once
+        opts["amd"] = dict(opts.get("amd", {}), **dict(NACA_PRIMAL_AMD, primalTau0=1.0e3, primalTauGrowth=10.0))
+        D = PYDAFOAM(options=opts, case=case3)
+        fail, inf = D.solver.solvePrimal(maxSteps=polish_steps, relTol=polish_tol, absTol=0.0)
+        case3.states = D.getStates().copy()
+        info.update(steps=inf["steps"], linearIterations=inf["linearIterations"], res0=inf["res0"], res=inf["res"], fail=int(fail))
+        del D
+    info["seconds"] = time.time() - t0
+    if verbose:
+        print(f"[naca primal] extruded {nx} x {ny} x {nz}: {info}", flush=True)
+    return case3, info

@@ -18,8 +18,8 @@ ap.add_argument("--lin-tol", type=float, default=1e-2)
 ap.add_argument("--out", default="gpurun_out/naca")
 ap.add_argument("--adjoint-levels", type=int, nargs="*", default=[2, 3], help="level indices whose 2-D adjoint is solved")
 ap.add_argument("--extrude", type=int, nargs="*", default=[2, 4, 2, 8], help="pairs (level index, nz) of extruded adjoints")
-ap.add_argument("--dz", type=float, default=0.1)
-ap.add_argument("--orderings", nargs="+", default=["rcm", "natural"])
+ap.add_argument("--dz", type=float, nargs="+", default=[0.1], help="spanwise layer thickness per --extrude pair (last value repeats)")
+ap.add_argument("--orderings", nargs="+", default=["rcm"])
 ap.add_argument("--coarse", type=int, nargs="+", default=[-1])
 ap.add_argument("--synthetic-too", action="store_true", help="also solve the adjoint about the synthetic noisy state (round-3 workload)")
 ap.add_argument("--polish", type=int, default=0, help="Newton steps on the extruded mesh before its adjoint")
@@ -39,7 +39,7 @@ fcs = [a.first_cell * 2 ** (len(levels) - 1 - i) for i in range(len(levels))]
 
 def opts(extra_amd=None, adj=None):
     amd = {"coloringAlgorithm": "speculative", "primalTauMode": "ramp", "primalTau0": a.tau0, "primalTauGrowth": a.growth, "primalSERExponent": a.ser,
-           "primalLinearIters": a.lin_iters, "primalLinearTol": a.lin_tol, "maxKrylovBytes": int(64 * 2**30)}
+           "primalLinearIters": a.lin_iters, "primalLinearTol": a.lin_tol, "maxKrylovBytes": int(140 * 2**30)}
     amd.update(extra_amd or {})
     o = {"solverName": "DASimpleFoam", "debug": True, "normalizeStates": dict(NORM), "primalMinResTol": a.tol,
          "adjEqnOption": dict({"gmresRestart": 1000, "gmresMaxIters": 1000, "gmresRelTol": 1e-6, "printInfo": 0}, **(adj or {})), "amd": amd}
@@ -107,7 +107,8 @@ for q in range(len(a.extrude) // 2):
         continue
     case2, W2, ok = conv[li]
     nx, ny = levels[li]
-    case3 = naca0012_case(nx, ny, nz, span=a.dz * nz, first_cell=fcs[li], perturb=0.0)
+    dz = a.dz[min(q, len(a.dz) - 1)]
+    case3 = naca0012_case(nx, ny, nz, span=dz * nz, first_cell=fcs[li], perturb=0.0)
     case3.states = extrude_naca_state(case2, W2, case3, (nx, ny, nz))
     if a.polish:
         D = PYDAFOAM(options=opts({"primalTau0": 1e3}), case=case3)
@@ -115,4 +116,4 @@ for q in range(len(a.extrude) // 2):
         print(f"POLISH {nx}x{ny}x{nz}: |R| {info['res0']:.3e} -> {info['res']:.3e} steps {info['steps']} lin {info['linearIterations']}", flush=True)
         case3.states = D.getStates()
         del D
-    adjoint_matrix(case3, f"3D-extruded-converged({ok})", (nx, ny, nz))
+    adjoint_matrix(case3, f"3D-extruded-converged({ok}) dz {dz}", (nx, ny, nz))
