@@ -54,12 +54,13 @@ def parse():
     ap.add_argument("--global-cells", type=int, default=int(os.environ.get("DAS_BENCH_GLOBAL_CELLS", 0)),
                     help="STRONG scaling (channel workload): ONE fixed global mesh of about this many cells (nx chosen as a multiple of the rank count, ny x nz "
                          "kept) cut into N slabs - e.g. 10000000 for the north-star 10 M-cell case at 2/4/8 GPUs; 0 (default): weak scaling, nx x ny x nz cells per GPU")
-    ap.add_argument("--naca-dz", type=float, default=0.1, help="naca: spanwise layer thickness (chords)")
+    ap.add_argument("--naca-dz", type=float, default=0.025, help="naca: spanwise layer thickness (chords); 160 layers x 0.025 = a wing section of aspect ratio 4 between symmetry planes")
     ap.add_argument("--naca-synthetic", action="store_true", help="naca: the round-3 synthetic noisy boundary-layer state instead of the converged primal")
     ap.add_argument("--window-at-warmup", action="store_true", help="time the K steps at basis sizes [W, W+K) instead of around the mean depth of the full solve")
     ap.add_argument("--no-parity", action="store_true", help="skip the 200 k-cell psi parity leg (GPU vs all-core CPU port)")
     ap.add_argument("--ordering", default=os.environ.get("DAS_BENCH_ORDERING", "rcm"), help="adjEqnOption.jacMatReOrdering: rcm | natural")
-    ap.add_argument("--naca", type=int, nargs=3, default=[800, 250, 10])
+    ap.add_argument("--naca", type=int, nargs=3, default=[200, 63, 160], help="naca: cells around the section, wall-normal, spanwise layers")
+    ap.add_argument("--naca-first-cell", type=float, default=4.0e-5, help="naca: first cell height (chords) of the section")
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("DAS_BENCH_CPU_SECONDS", 15.0)))
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the solve-to-tolerance phase")
@@ -167,10 +168,11 @@ def main():
             from dafoam_amd.workloads import naca_converged_primal, naca_extruded_case
 
             t0 = time.time()
-            case2d, lv = naca_converged_primal(a.naca[0], a.naca[1], options=opts, verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
+            case2d, lv = naca_converged_primal(a.naca[0], a.naca[1], options=opts, first_cell=a.naca_first_cell, verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
             t2d = time.time() - t0
             if a.naca[2] > 1:
-                case, ex = naca_extruded_case(case2d, (a.naca[0], a.naca[1]), a.naca[2], dz=a.naca_dz, options=opts, verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
+                case, ex = naca_extruded_case(case2d, (a.naca[0], a.naca[1]), a.naca[2], dz=a.naca_dz, first_cell=a.naca_first_cell, options=opts,
+                                              verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
             else:
                 case, ex = case2d, None
             primal = {"method": "pseudo-transient Newton-Krylov (das_solve_primal), grid sequencing on the one-layer O-grid, spanwise extrusion, Newton polish",
@@ -180,7 +182,7 @@ def main():
         elif a.workload == "naca":
             from dafoam_amd.meshgen import naca0012_case
 
-            case = naca0012_case(a.naca[0], a.naca[1], a.naca[2], span=a.naca_dz * a.naca[2])
+            case = naca0012_case(a.naca[0], a.naca[1], a.naca[2], span=a.naca_dz * a.naca[2], first_cell=a.naca_first_cell)
         else:
             # state = prolongation of a converged coarse primal (dafoam_amd/data/channel_primal_coarse.npz)
             case = bench_channel_case(a.nx, a.ny, a.nz)
@@ -358,7 +360,7 @@ def main():
                 "workload": (f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell hex mesh per GPU ({a.nx}x{a.ny}x{a.nz} bump channel, wall-normal "
                              f"grading; state: prolonged converged coarse primal)" if a.workload != "naca" else
                              f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell NACA0012 wing section (O-grid, {a.naca[0]} around x {a.naca[1]} normal x {a.naca[2]} "
-                             f"spanwise hexahedra, first cell 2e-5 chords, far field 20 chords, U 10 m/s, AoA 2 deg, Re 6.7e5; "
+                             f"spanwise hexahedra of {a.naca_dz} chords, first cell {a.naca_first_cell:g} chords, far field 20 chords, U 10 m/s, AoA 2 deg, Re 6.7e5; "
                              + ("synthetic noisy boundary-layer state)" if a.naca_synthetic else
                                 "linearised about the primal CONVERGED on the GPU: Newton-Krylov, grid sequencing, |R| = %.2e)" % primal_residual_norm))
                             + f", full GMRES adjoint, 8 states/cell, reference stencil tables; "
@@ -538,7 +540,7 @@ def cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu_sp
 def psi_parity_200k(a, dev_index, case2d=None):
     """BASELINE.md section 3 / VERDICT round 3 item 2: the adjoint vector of a 200 k-cell system of the bench family (naca: the
     one-layer 800 x 250 O-grid = BASELINE configs[1], about the converged primal; channel: 100 x 50 x 40) solved to 1e-10 by the GPU
-    path (reference budget, restart 1000) and, independently, by the all-core CPU port on the exported matrices:
+    path and, independently, by the all-core CPU port on the exported matrices:
     |psi_gpu - psi_cpu| / |psi_cpu| (north_star bar 1e-6)."""
     from dafoam_amd import _capi
     from dafoam_amd.meshgen import bench_channel_case
@@ -547,14 +549,17 @@ def psi_parity_200k(a, dev_index, case2d=None):
 
     L = _capi.lib()
     if a.workload == "naca":
-        if case2d is None:
-            from dafoam_amd.workloads import naca_converged_primal
+        from dafoam_amd.workloads import naca_converged_primal, naca_extruded_case
 
-            case2d, _ = naca_converged_primal(a.naca[0], a.naca[1], options=make_opts(a, dev_index, 1000, 1000, 1e-10))
-        case, what = case2d, f"NACA0012 O-grid {a.naca[0]} x {a.naca[1]} x 1 (BASELINE configs[1]), converged primal"
+        o10 = make_opts(a, dev_index, 1000, 1000, 1e-10)
+        if case2d is None:
+            case2d, _ = naca_converged_primal(a.naca[0], a.naca[1], options=o10, first_cell=a.naca_first_cell)
+        nzp = max(1, int(round(200000.0 / (a.naca[0] * a.naca[1]))))
+        case, _ = naca_extruded_case(case2d, (a.naca[0], a.naca[1]), nzp, dz=0.1, first_cell=a.naca_first_cell, options=o10) if nzp > 1 else (case2d, None)
+        what = f"NACA0012 wing section {a.naca[0]} x {a.naca[1]} x {nzp} (the bench's converged section, {nzp} spanwise layers of 0.1 chords: BASELINE configs[1] size)"
     else:
         case, what = bench_channel_case(100, 50, 40), "bump channel 100 x 50 x 40"
-    D = PYDAFOAM(options=make_opts(a, dev_index, 1000, 2000, 1e-10), case=case)
+    D = PYDAFOAM(options=make_opts(a, dev_index, 2000, 2000, 1e-10), case=case)  # restart 2000: no restart inside the plateau of the residual history
     n, N = D.getNLocalAdjointStates(), case.mesh.n_cells
     D.solver.runColoring()
     P = Mat()
@@ -574,11 +579,11 @@ def psi_parity_200k(a, dev_index, case2d=None):
     h = D.solver._h
     threads = int(os.environ.get("DAS_BENCH_CPU_THREADS", os.cpu_count() or 1))
     K, prep = _cpu_solver(L, h, ksp, P, n, N, int(L.das_op_nnz(h)), int(L.das_mat_nnz(P.handle)), threads)
-    psi_cpu, cinf = K.gmres(rhs, restart=400, max_iters=4000, rel_tol=1e-10, abs_tol=1e-300)
+    psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=1e-10, abs_tol=1e-300)
     return {"system": what, "cells": int(N), "states": int(n), "rel_tol_both": 1e-10,
             "gpu": {"iterations": int(ginf["iters"]), "seconds": t_gpu, "fail": int(gfail), "rel_residual": ginf["res"] / ginf["res0"] if ginf["res0"] else None},
             "cpu": {"iterations": int(cinf["iters"]), "seconds": cinf["seconds"], "fail": int(cinf["fail"]), "rel_residual": cinf["res"] / cinf["res0"] if cinf["res0"] else None,
-                    "threads": K.threads, "gmresRestart": 400, "prep_seconds": prep["prep_seconds"], "ilu_levels": prep["ilu_levels"]},
+                    "threads": K.threads, "gmresRestart": 1500, "prep_seconds": prep["prep_seconds"], "ilu_levels": prep["ilu_levels"]},
             "psi_rel_diff_gpu_vs_cpu": float(np.linalg.norm(psi_gpu - psi_cpu) / np.linalg.norm(psi_cpu)), "bar": 1e-6}
 
 

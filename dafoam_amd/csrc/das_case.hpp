@@ -63,6 +63,7 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.DT = cp.DT;
     p.deltaT = cp.deltaT;
     p.isPC = isPC;
+    p.convBlend = isPC ? opt.getd("amd.pcUpwindBlend") : 1.0;
     p.constrainHbyA = (int)opt.geti("useConstrainHbyA");
     p.normU = opt.list_has("normalizeResiduals", "URes");
     p.normP = opt.list_has("normalizeResiduals", "pRes");

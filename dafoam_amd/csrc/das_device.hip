@@ -2782,6 +2782,10 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
         if (q.name == "phi") phiLo = q.offset;
     }
     const double growth = s->opt.getd("amd.primalTauGrowth"), growthMax = s->opt.getd("amd.primalTauGrowthMax"), tauMax = s->opt.getd("amd.primalTauMax");
+    const double acceptFactor = s->opt.getd("amd.primalAcceptFactor"), tauMin = s->opt.getd("amd.primalTauMin");
+    const bool rejectDamped = ramp && s->opt.gets("amd.primalDampedSteps") == "reject";
+    int nRejected = 0;
+    double tauPC = 0.0;
     ensure_coloring(s);
     // Krylov options of the inner solves (restored afterwards)
     const Options saved = s->opt;
@@ -2823,6 +2827,7 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
             k->pcmat = P.get();
             k->pcTranspose = true;
             k->pcDiagScale = 1.0 + 1.0 / tau;
+            tauPC = tau;
             if (ptMomentum) { k->shiftExLo = pLo; k->shiftExHi = pHi; k->shiftEnd = phiLo; }
             setup_node_ilu(s, k.get());
             setup_coarse(s, k.get());
@@ -2839,24 +2844,28 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
         run_gmres(s, k.get(), rhs.p, dw.p, 0);
         s->fwd.on = false;
         info.linIters += k->iters;
-        // backtracking: accept the first step that does not blow the residual up
+        // backtracking: accept the first step that does not blow the residual up.  amd.primalDampedSteps "reject" (ramp mode): a
+        // step that needs damping is NOT taken at all - the pseudo-time step is halved and the step recomputed (a damped Newton
+        // update of a strongly under-relaxed system is a poor direction; rejecting keeps the iteration on the pseudo-time path),
+        // unless tau has already reached its floor amd.primalTauMin, where the damped update is the last resort
         double omega = 1.0, rnew = rn;
-        for (int ls = 0; ls < 8; ls++) {
+        const int maxHalvings = (rejectDamped && tau > tauMin) ? 1 : 8;
+        for (int ls = 0; ls < maxHalvings; ls++) {
             hipLaunchKernelGGL(k_newton_update, dim3(nblk(n, B)), dim3(B), 0, st, n, n0, n1, omega, s->d_W.p, s->d_scale.p, dw.p, Wn.p);
             residual_at(Wn.p, Rn.p);
             rnew = device_norm2(s, k.get(), Rn.p);
-            if (rnew == rnew && rnew < 1.5 * rn) break;
-            omega *= 0.5;
+            if (rnew == rnew && rnew < acceptFactor * rn) break;
+            if (ls + 1 < maxHalvings) omega *= 0.5;
         }
-        const bool accepted = rnew == rnew && rnew < 1.5 * rn;
+        const bool accepted = rnew == rnew && rnew < acceptFactor * rn;
         if (ramp && !accepted) {
-            // no damped update is acceptable: the step is rejected, the pseudo-time step cut, the preconditioner rebuilt
-            tau *= 0.1;
-            sincePC = pcLag;
+            // no (damped) update is acceptable: the step is rejected, the pseudo-time step cut, the preconditioner rebuilt
+            tau = std::max(tauMin, tau * (rejectDamped ? 0.5 : 0.1));
+            if (tau < 0.25 * tauPC || tau > 4.0 * tauPC) sincePC = pcLag;
             info.steps = step + 1;
             info.hist.push_back(rn);
-            if (s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] Newton primal step %d: REJECTED (|R| would be %.3e), tau -> %.2e\n", step + 1, rnew, tau);
-            DAS_CHECK(tau > 1e-8, DAS_ERR_INTERNAL, "Newton primal: pseudo-time step collapsed");
+            if (s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] Newton primal step %d: REJECTED (|R| would be %.3e, %d GMRES iterations), tau -> %.2e\n", step + 1, rnew, k->iters, tau);
+            if (++nRejected > 40) break;  // the pseudo-time path is lost
             continue;
         }
         DAS_HIP(hipMemcpyAsync(s->d_W.p, Wn.p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -2868,8 +2877,8 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
         // |R0|/|R| would shrink it there), by the residual drop (^p) when that is larger, and shrinks with a damped update
         const double tauNew = !ramp ? std::min(1e12, tau0 * std::pow(info.res0 / std::max(rnew, 1e-300), serExp))
                                     : std::min(tauMax, tau * (omega == 1.0 ? std::max(growth, std::min(growthMax, std::pow(rn / std::max(rnew, 1e-300), serExp))) : std::max(omega, 0.25)));
-        if (tauNew > 4.0 * tau || tauNew < 0.25 * tau) sincePC = pcLag;
-        tau = tauNew;
+        if (tauNew > 4.0 * tauPC || tauNew < 0.25 * tauPC) sincePC = pcLag;
+        tau = std::max(tauMin, tauNew);
         rn = rnew;
         info.steps = step + 1;
         info.hist.push_back(rn);

@@ -46,6 +46,9 @@ typedef DevMeshT<double> DevMesh;
 struct ResParams {
     double nu, alphaU, alphaN, DT, deltaT;
     int isPC, constrainHbyA;
+    // weight of the explicit linearUpwindV correction: 1 in the operator residual, amd.pcUpwindBlend (default 0 = div(pc) upwind, the
+    // reference's PC scheme) in the PC residual - a PC matrix between the first-order and the operator's discretisation
+    double convBlend;
     int normU, normP, normN, normPhi, normT;  // 1 = residual listed in normalizeResiduals
     // state-block offsets in units of nC (DAIndex "state" ordering): SimpleFoam [U|p|nuTilda|phi] = 3,-,4,5;
     // RhoSimpleFoam [U|p|T|nuTilda|phi] = 3,4,5,6
@@ -464,8 +467,8 @@ DAS_HD void body_cell(int c, const DevMeshT<G>& m, const ResParams& prm, const T
             sumOff += dabs(offTot);
 #pragma unroll
             for (int k = 0; k < 3; k++) offU[k] += offTot * Uo[k];
-            // ---- linearUpwindV explicit correction (skipped for the PC residual: div(pc) = upwind)
-            if (!prm.isPC) {
+            // ---- linearUpwindV explicit correction (PC residual: div(pc) = upwind, i.e. weight 0, unless amd.pcUpwindBlend > 0)
+            if (prm.convBlend > 0.0) {
                 bool pos = pv > 0.0;
                 bool upIsC = (pos != nb);  // upwind cell is the owner when flux > 0
                 const T* gUp = upIsC ? gUc : gUo;
@@ -495,7 +498,7 @@ DAS_HD void body_cell(int c, const DevMeshT<G>& m, const ResParams& prm, const T
                 }
                 T pout = sg * phi;
 #pragma unroll
-                for (int j = 0; j < 3; j++) src[j] -= pout * corr[j];
+                for (int j = 0; j < 3; j++) src[j] -= prm.convBlend * (pout * corr[j]);
             }
             // ---- non-orthogonal correction of the laplacian and the explicit dev2 stress term
             T tau_o[9];

@@ -66,17 +66,25 @@ Options::Options() {
     // (repeated pairwise matching along the strongest pressure-Laplacian coupling |Sf| / |d|: the aggregates follow the thin
     // direction of stretched cells - measured on the CPU: NACA0012 adjoint 763 -> 360 iterations where space-filling blocks give 530)
     s["amd.pcCoarseAggregation"] = "rcb";
+    // PC residual: weight of the explicit second-order (linearUpwindV) correction of div(phi,U).  0 = the reference's div(pc) = upwind.  Measured
+    // (round 4, NACA0012, exact LU of the PC matrix as preconditioner): the first-order / second-order mismatch IS the plateau of the
+    // adjoint solve (96 iterations at 3200 cells with an exact solve of the first-order matrix, 9 with the operator on the PC pattern); an
+    // incomplete factorisation tolerates a partial correction only (ILU(0): 155 -> 132 at 0.35, unstable from 0.5)
+    d["amd.pcUpwindBlend"] = 0.0;
     s["amd.pcCoarseMode"] = "additive";  // additive | deflated (A-DEF1: one extra operator product per apply)
     i["amd.coloringOnDevice"] = 1;   // serial first-fit colouring as a data-flow kernel (das_color.hpp); 0: host variants
     d["amd.primalTau0"] = 1.0;          // Newton primal: initial pseudo-time factor (diagonal scaled by 1 + 1/tau), SER growth
     d["amd.primalSERExponent"] = 1.5;   // tau = tau0 (|R0| / |R|)^exponent (measured: 1.0 -> 52+ steps, 1.5 -> 20-29, 2.0 -> 17-21 on the bench channels)
     // pseudo-time control: "ser" (tau = tau0 (|R0|/|R|)^p: starts close to the solution) | "ramp" (CFL ramp: tau grows by >= primalTauGrowth
     // per accepted full step, by the residual drop^p if larger (<= primalTauGrowthMax), shrinks with damped / rejected steps: cold starts)
-    s["amd.primalPseudoTimeFields"] = "momentum";  // rows that get the pseudo-time term: "momentum" (U, T, nuTilda) | "all"
+    s["amd.primalPseudoTimeFields"] = "all";  // rows that get the pseudo-time term: "all" | "momentum" (U, T, nuTilda only: cold starts, see run_newton_primal)
     s["amd.primalTauMode"] = "ser";
     d["amd.primalTauGrowth"] = 1.5;
     d["amd.primalTauGrowthMax"] = 10.0;
     d["amd.primalTauMax"] = 1.0e12;
+    d["amd.primalTauMin"] = 1.0e-3;
+    d["amd.primalAcceptFactor"] = 1.5;      // a step may raise |R| by at most this factor
+    s["amd.primalDampedSteps"] = "accept";  // ramp mode: "accept" a damped update and shrink tau with it | "reject" it, halve tau, recompute
     d["amd.primalLinearTol"] = 1.0e-3;  // relative tolerance of the inner GMRES solves
     i["amd.primalLinearIters"] = 300;
     i["amd.primalPCLag"] = 3;           // Newton steps per preconditioner rebuild

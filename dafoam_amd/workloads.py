@@ -15,8 +15,14 @@ import numpy as np
 
 from .meshgen import extrude_naca_state, naca0012_case, prolong_naca_state
 
-NACA_PRIMAL_AMD = {"primalTauMode": "ramp", "primalTau0": 1.0, "primalTauGrowth": 1.5, "primalSERExponent": 1.0, "primalLinearIters": 300,
-                   "primalLinearTol": 1e-2, "primalPseudoTimeFields": "momentum", "coloringAlgorithm": "speculative"}
+# COLD start (coarsest level, free stream + boundary-layer guess): CFL ramp, pseudo-time term on the transport rows only - with the term on
+# the pressure rows the pseudo-time evolution itself is unstable there (round 4, CPU twin with exact Jacobians: blow-up beyond tau ~ 3)
+NACA_PRIMAL_AMD = {"primalTauMode": "ramp", "primalTau0": 1.0, "primalTauGrowth": 1.5, "primalSERExponent": 1.0, "primalLinearIters": 1000,
+                   "primalLinearTol": 1e-2, "primalPseudoTimeFields": "momentum"}
+# PROLONGED start (every finer level): close to the solution - switched evolution relaxation on the initial residual with the term on all
+# rows (the round-2 scheme of the channel workloads); measured on the 400 x 125 level: 28 steps / 15 s, where the ramp variants stall
+NACA_PRIMAL_AMD_FINE = {"primalTauMode": "ser", "primalTau0": 1.0, "primalSERExponent": 1.5, "primalLinearIters": 1000, "primalLinearTol": 1e-3,
+                        "primalPseudoTimeFields": "all"}
 
 
 def naca_levels(n_around, n_normal, coarsest=100):
@@ -36,8 +42,6 @@ def naca_converged_primal(n_around=800, n_normal=250, options=None, first_cell=2
 
     levels = naca_levels(n_around, n_normal, coarsest)
     fcs = [first_cell * 2 ** (len(levels) - 1 - i) for i in range(len(levels))]   # same growth ratio on every level
-    opts = dict(options or {})
-    opts["amd"] = dict(opts.get("amd", {}), **NACA_PRIMAL_AMD)
     ckw = dict(case_kwargs or {})
     ckw.setdefault("perturb", 0.0)
     W_prev, info, case = None, [], None
@@ -46,6 +50,8 @@ def naca_converged_primal(n_around=800, n_normal=250, options=None, first_cell=2
         case = naca0012_case(nx, ny, 1, first_cell=fc, **ckw)
         if W_prev is not None:
             case.states = prolong_naca_state(levels[li - 1], W_prev, case, (nx, ny), first_cell=fc, coarse_first_cell=fcs[li - 1])
+        opts = dict(options or {})
+        opts["amd"] = dict(opts.get("amd", {}), **(NACA_PRIMAL_AMD if W_prev is None else NACA_PRIMAL_AMD_FINE))
         D = PYDAFOAM(options=opts, case=case)
         fail, inf = D.solver.solvePrimal(maxSteps=max_steps, relTol=rel_tol, absTol=0.0)
         W_prev = D.getStates().copy()
@@ -75,7 +81,7 @@ def naca_extruded_case(case2d, dims2d, nz, dz=0.1, first_cell=2.0e-5, options=No
     if polish_steps > 0:
         opts = dict(options or {})
         # a start next to the solution: large pseudo-time step at once
-        opts["amd"] = dict(opts.get("amd", {}), **dict(NACA_PRIMAL_AMD, primalTau0=1.0e3, primalTauGrowth=10.0))
+        opts["amd"] = dict(opts.get("amd", {}), **dict(NACA_PRIMAL_AMD_FINE, primalTau0=1.0e3))
         D = PYDAFOAM(options=opts, case=case3)
         fail, inf = D.solver.solvePrimal(maxSteps=polish_steps, relTol=polish_tol, absTol=0.0)
         case3.states = D.getStates().copy()

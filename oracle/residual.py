@@ -265,7 +265,7 @@ def unpack_simple(W, N, F):
     return U, p, nuT, phi
 
 
-def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "nuTildaRes", "phiRes"),
+def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "nuTildaRes", "phiRes"), pc_blend=0.0,
                     use_constrain_hbya=True, return_parts=False):
     """R(W) for DASimpleFoam + Spalart-Allmaras in DAIndex 'state' ordering:
     [URes (3N, xyz interleaved) | pRes (N) | nuTildaRes (N) | phiRes (F, internal then boundary)]."""
@@ -335,7 +335,8 @@ def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "
     iC = phi_b[:, None] * UvIC  # internalCoeffs (vector per boundary face)
     bC = -phi_b[:, None] * UvBC  # boundaryCoeffs
     src = np.zeros((N, 3), dtype=dt)
-    if not isPC:
+    conv_blend = float(pc_blend) if isPC else 1.0  # weight of the explicit linearUpwindV correction (PC: amd.pcUpwindBlend, default 0)
+    if conv_blend > 0.0:
         pos = np.real(phi_i) > 0
         d_o = g.Cf[:nIF] - g.C[oi]
         d_n = g.Cf[:nIF] - g.C[ni]
@@ -354,7 +355,7 @@ def simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "
             1.0 + 0 * mxc,
         )
         corr = corr * scale[:, None]
-        fcorr = phi_i[:, None] * corr
+        fcorr = conv_blend * phi_i[:, None] * corr
         src = src - (sadd(oi, fcorr, N) - sadd(ni, fcorr, N))
     # - fvm::laplacian(nuEff, U)  (Gauss linear corrected)
     gam = ops.interp(nuEff) * g.magSf[:nIF]

@@ -66,7 +66,7 @@ def mrf_fields(case, g):
     return dict(om=om, vC=np.cross(om, g.C - o), vFb=vF[nIF:], rel_i=rel[:nIF], rel_b=rel[nIF:], incl=incl)
 
 
-def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "nuTildaRes", "phiRes"), use_constrain_hbya=True,
+def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes", "nuTildaRes", "phiRes"), use_constrain_hbya=True, pc_blend=0.0,
                         return_parts=False, turbo=None):
     if turbo is None:
         turbo = case.solver_name == "DATurboFoam"
@@ -148,7 +148,8 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
     iC = phi_b[:, None] * UvIC
     bC = -phi_b[:, None] * UvBC
     src = np.zeros((N, 3), dtype=dt)
-    if not isPC:
+    conv_blend = float(pc_blend) if isPC else 1.0  # weight of the explicit linearUpwindV correction (PC: amd.pcUpwindBlend, default 0)
+    if conv_blend > 0.0:
         pos = np.real(phi_i) > 0
         d_o, d_n = g.Cf[:nIF] - g.C[oi], g.Cf[:nIF] - g.C[ni]
         c_o = np.einsum("fi,fij->fj", d_o, gradU[oi])
@@ -159,7 +160,7 @@ def rho_simple_residual(case, g, W, isPC=False, normalize=("URes", "pRes", "TRes
         sfc, mxc = (corr * corr).sum(1), (corr * mx).sum(1)
         scale = np.where(np.real(sfc) > 0, np.where(np.real(mxc) < 0, 0.0 * mxc, np.where(np.real(sfc) > np.real(mxc), mxc / (sfc + VSMALL), 1.0 + 0 * mxc)),
                          1.0 + 0 * mxc)
-        fcorr = phi_i[:, None] * corr * scale[:, None]
+        fcorr = conv_blend * phi_i[:, None] * corr * scale[:, None]
         src = src - (sadd(oi, fcorr, N) - sadd(ni, fcorr, N))
     gam = ops.interp(muEff) * g.magSf[:nIF]
     gam_b = muEff_b * g.bMagSf

@@ -36,6 +36,8 @@ static void eval_on(const MV& m, const CaseParams& cp, const ResParams& prm, con
     }
 }
 
+static double g_pcBlend = 0.0;  // amd.pcUpwindBlend of the emulated PC residual
+extern "C" void emu_set_pc_blend(double b) { g_pcBlend = b; }
 extern "C" int emu_residual(const das_case_t* c, const double* Win, long long n, int isPC, const double* dir, double* Rv, double* Rd) {
     try {
         Mesh mesh;
@@ -44,6 +46,7 @@ extern "C" int emu_residual(const das_case_t* c, const double* Win, long long n,
         cp.from_case(c);
         if (!cp.beta_fi.empty()) cp.betaFI_ptr = cp.beta_fi.data();
         Options opt;
+        opt.d["amd.pcUpwindBlend"] = g_pcBlend;
         ResParams prm = make_params(cp, opt, isPC);
         if (!dir) {
             std::vector<double> W(Win, Win + n), R(n);

@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from common import NORM_STATES, NORM_STATES_RHO, blocks, options, relerr, unrolled_maps
+from common import NORM_STATES, NORM_STATES_RHO, blocks, norm_states, options, relerr, unrolled_maps
 from dafoam_amd import _capi
 from dafoam_amd._capi import CaseStruct, das_case_t, dptr
 from dafoam_amd.meshgen import (channel_case, periodic_channel_case, renumber_case, rho_channel_case, scalar_transport_case, simple_T_channel_case,
@@ -137,6 +137,35 @@ def test_kernel_bodies_match_oracle_simplefoam(wall_function, isPC):
     _, Rd = _emu_res(case, W, isPC, v)
     for nm, sl in blocks(case, g):
         assert relerr(Rd[sl], cs[sl]) < 1e-10, nm
+
+
+def test_pc_upwind_blend_option_kernel_bodies_match_oracle():
+    """amd.pcUpwindBlend (round 4): the PC residual with a partial second-order (linearUpwindV) correction - weight 0 is the
+    reference's div(pc) = upwind, weight 1 the operator's scheme on the PC stencil.  Kernel bodies vs the oracle for both
+    incompressible and compressible solvers, values and forward-mode tangents; the operator residual ignores the option."""
+    E = _emu()
+    E.emu_set_pc_blend.argtypes = [C.c_double]
+    try:
+        for case in (channel_case(7, 6, 5, wall_function=True), rho_channel_case(6, 6, 5)):
+            g = Geometry(case.mesh)
+            W = case.states
+            sc = J.state_scales(case, g, norm_states(case))
+            v = np.random.default_rng(5).standard_normal(W.size) * sc
+            R_pc0, _ = _emu_res(case, W, 1)
+            R_op, _ = _emu_res(case, W, 0)
+            E.emu_set_pc_blend(0.35)
+            Rv, Rd = _emu_res(case, W, 1, v)
+            Ro = residual(case, g, W, isPC=True, pc_blend=0.35)
+            cs = residual(case, g, W + 1j * 1e-30 * v, isPC=True, pc_blend=0.35).imag / 1e-30
+            for nm, sl in blocks(case, g):
+                assert relerr(Rv[sl], Ro[sl]) < 1e-12, nm
+                assert relerr(Rd[sl], cs[sl]) < 1e-10, nm
+            assert relerr(Rv, R_pc0) > 1e-6  # the option does something ...
+            assert np.allclose(Rv, R_pc0 + 0.35 * (residual(case, g, W, isPC=True, pc_blend=1.0) - R_pc0), rtol=1e-9, atol=1e-9 * np.abs(Rv).max())  # ... linear in the weight
+            assert np.array_equal(_emu_res(case, W, 0)[0], R_op)  # the operator residual does not see it
+            E.emu_set_pc_blend(0.0)
+    finally:
+        E.emu_set_pc_blend(0.0)
 
 
 def test_kernel_bodies_match_oracle_scalar_transport():
@@ -1218,3 +1247,39 @@ def test_strength_based_aggregates_follow_the_stretched_cells():
     # sizes are balanced within the factor pairwise matching gives
     sizes = np.bincount(agg)
     assert sizes.max() <= 8 * max(1, sizes.min()) or sizes.max() <= 2 * N // nA
+
+
+def test_naca_grid_sequencing_helpers():
+    """dafoam_amd.workloads / meshgen helpers of the NACA0012 primal (round 4): the level list, the prolongation of a section
+    solution to the next finer O-grid (exact for fields that are constant, bounded by the coarse extrema, phi rebuilt from the
+    interpolated velocity) and the spanwise extrusion of a one-layer state - whose residual, layer by layer, is the one-layer
+    residual (up to the spanwise diffusion coefficient in the momentum diagonal, ~1e-5 relative, through the Rhie-Chow term)."""
+    from dafoam_amd.meshgen import extrude_naca_state, naca0012_case, prolong_naca_state
+    from dafoam_amd.workloads import naca_levels
+
+    assert naca_levels(800, 250) == [(100, 31), (200, 62), (400, 125), (800, 250)]
+    assert naca_levels(200, 63) == [(100, 31), (200, 63)]
+    assert naca_levels(64, 20) == [(64, 20)]
+    c = naca0012_case(48, 16, 1, first_cell=4e-4, perturb=0.0)
+    f = naca0012_case(96, 32, 1, first_cell=2e-4, perturb=0.0)
+    Nc, Nf = 48 * 16, 96 * 32
+    Wc = c.states.copy()
+    Wc[3 * Nc : 4 * Nc] = 7.0  # a constant pressure is reproduced exactly
+    Wf = prolong_naca_state((48, 16), Wc, f, (96, 32), first_cell=2e-4, coarse_first_cell=4e-4)
+    assert Wf.shape == f.states.shape and np.allclose(Wf[3 * Nf : 4 * Nf], 7.0)
+    Uc, Uf = Wc[: 3 * Nc].reshape(Nc, 3), Wf[: 3 * Nf].reshape(Nf, 3)
+    assert Uf[:, 0].max() <= Uc[:, 0].max() + 1e-12 and Uf[:, 0].min() >= Uc[:, 0].min() - 1e-12 and np.all(Uf[:, 2] == 0.0)
+    assert np.all(Wf[4 * Nf : 5 * Nf] > 0.0)
+    # the interpolated smooth field is close to the generator's own field on the fine mesh (same analytic profile)
+    assert np.abs(Uf - f.states[: 3 * Nf].reshape(Nf, 3)).max() < 0.25 * np.abs(Uc).max()
+    f3 = naca0012_case(96, 32, 3, span=0.3, first_cell=2e-4, perturb=0.0)
+    W2 = naca0012_case(96, 32, 1, first_cell=2e-4, perturb=0.02).states  # a rough state: the identity must hold for any one-layer state
+    f2 = naca0012_case(96, 32, 1, first_cell=2e-4, perturb=0.0)
+    W3 = extrude_naca_state(f2, W2, f3, (96, 32, 3))
+    R2 = residual(f2, Geometry(f2.mesh), W2)
+    R3 = residual(f3, Geometry(f3.mesh), W3)
+    N2, N3 = Nf, 3 * Nf
+    for k in range(3):
+        assert relerr(R3[3 * k * N2 : 3 * (k + 1) * N2], R2[: 3 * N2]) < 1e-8
+        assert relerr(R3[3 * N3 + k * N2 : 3 * N3 + (k + 1) * N2], R2[3 * N2 : 4 * N2]) < 1e-4
+        assert relerr(R3[4 * N3 + k * N2 : 4 * N3 + (k + 1) * N2], R2[4 * N2 : 5 * N2]) < 1e-8

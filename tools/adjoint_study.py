@@ -25,6 +25,7 @@ ap.add_argument("--perturb", type=float, default=0.02, help="naca: amplitude of 
 ap.add_argument("--coarse-agg", type=int, nargs="+", default=[-1])
 ap.add_argument("--coarse-mode", nargs="+", default=["additive"])
 ap.add_argument("--pc-iters", type=int, nargs="+", default=[1], help="adjEqnOption.localPCIters (Richardson sweeps around the factorisation)")
+ap.add_argument("--blend", type=float, default=0.0, help="amd.pcUpwindBlend")
 ap.add_argument("--combos", nargs="+", default=None, help="explicit list fp32:pcIters:coarseAgg:coarseMode[:sweepDesign] instead of the full product")
 a = ap.parse_args()
 import __graft_entry__ as ge
@@ -35,7 +36,7 @@ from dafoam_amd.pyDASolvers import KSP, Mat, Vec
 from dafoam_amd import _capi
 case = naca0012_case(*a.n, wall_function=a.wf, span=a.span, perturb=a.perturb) if a.case == "naca" else bench_channel_case(*a.n, wall_function=a.wf)
 opts = {"solverName": "DASimpleFoam", "debug": True, "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0},
-        "adjEqnOption": {"gmresRestart": a.restart, "gmresMaxIters": a.maxit, "gmresRelTol": a.rtol, "printInfo": 0}}
+        "adjEqnOption": {"gmresRestart": a.restart, "gmresMaxIters": a.maxit, "gmresRelTol": a.rtol, "printInfo": 0}, "amd": {"pcUpwindBlend": a.blend}}
 D = PYDAFOAM(options=opts, case=case)
 n = D.getNLocalAdjointStates()
 t = time.time(); D.solver.runColoring(); print(f"coloring {time.time()-t:.2f}s")
