@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--naca-synthetic", action="store_true", help="naca: the round-3 synthetic noisy boundary-layer state instead of the converged primal")
     ap.add_argument("--window-at-warmup", action="store_true", help="time the K steps at basis sizes [W, W+K) instead of around the mean depth of the full solve")
     ap.add_argument("--no-parity", action="store_true", help="skip the 200 k-cell psi parity leg (GPU vs all-core CPU port)")
+    ap.add_argument("--pc-blend", type=float, default=None, help="amd.pcUpwindBlend: weight of the second-order (linearUpwindV) correction in the PC residual "
+                         "(the reference user's choice of div(pc) in fvSchemes); default 0.5 for naca, 0 (upwind) for channel")
     ap.add_argument("--ordering", default=os.environ.get("DAS_BENCH_ORDERING", "rcm"), help="adjEqnOption.jacMatReOrdering: rcm | natural")
     ap.add_argument("--naca", type=int, nargs=3, default=[200, 63, 160], help="naca: cells around the section, wall-normal, spanwise layers")
     ap.add_argument("--naca-first-cell", type=float, default=4.0e-5, help="naca: first cell height (chords) of the section")
@@ -96,8 +98,7 @@ def make_opts(a, dev_index, restart, maxit, rtol):
         "adjEqnOption": {"gmresRestart": int(restart), "gmresMaxIters": int(maxit), "gmresRelTol": rtol, "gmresAbsTol": 1e-300, "printInfo": 0,
                          "jacMatReOrdering": a.ordering},
         "amd": {"pcType": a.pctype, "pcFactorFP32": a.fp32_factor, "maxKrylovBytes": int(a.krylov_gb * 2**30),
-                "pcCoarseAggregates": a.coarse_agg, "pcCoarseMode": a.coarse_mode, "gmresOrthogonalization": a.orth,
-                **({"coloringAlgorithm": "speculative"} if a.workload == "naca" else {})},  # O-grid numbering serialises the data-flow first-fit
+                "pcCoarseAggregates": a.coarse_agg, "pcCoarseMode": a.coarse_mode, "gmresOrthogonalization": a.orth, "pcUpwindBlend": float(a.pc_blend or 0.0)},
         "amdDevice": dev_index,
     }
 
@@ -146,6 +147,8 @@ def main():
     t_setup = time.time()
     if world > 1 or a.global_cells > 0:
         a.workload = "channel"  # the sharded path partitions the structured channel into slabs
+    if a.pc_blend is None:
+        a.pc_blend = 0.5 if a.workload == "naca" else 0.0
     opts = make_opts(a, dev_index, a.solve_restart, a.solve_maxit, 1e-6)
     sharded = None
     primal, case2d = None, None
@@ -328,7 +331,7 @@ def main():
         cpu, parity = None, None
         if not a.no_cpu and world == 1:
             try:
-                cpu = cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, spmv_ms, pc_ms)
+                cpu = cpu_port_at_bench_size(a, L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, spmv_ms, pc_ms)
             except Exception as e:  # noqa: BLE001 - the baseline must never break the line
                 cpu = {"error": repr(e)[:300]}
         if not a.no_parity and not a.no_cpu and world == 1:
@@ -387,6 +390,7 @@ def main():
                 "pc_coarse_aggregates": int(L.das_ksp_get_coarse(ksp.handle, None)),
                 "pc_coarse_aggregates_global": int(global_coarse) if world > 1 else None,
                 "pc_coarse_mode": a.coarse_mode,
+                "pc_upwind_blend": a.pc_blend,
                 "coarse_ms": L.das_timer_avg_ms(h, b"coarse"),
                 "halo_ms": L.das_timer_avg_ms(h, b"halo") if world > 1 else None,
                 # adjoint setup (what the reference does between the primal and the Krylov solve) vs. building the synthetic input
@@ -469,8 +473,11 @@ def _node_order_permutation(ksp, n):
     return perm
 
 
-def _cpu_solver(L, h, ksp, pc, n, N, op_nnz, pc_nnz, threads):
-    """The oracle's all-core port loaded with the operator and the PC matrix of the GPU run (copied back from the device)."""
+def _cpu_solver(L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, threads, blend=0.0):
+    """The oracle's all-core port loaded with the operator and the PC matrix of the GPU run (copied back from the device).  With
+    amd.pcUpwindBlend > 0 the CPU side gets its own PC matrix assembled with the reference's first-order div(pc): a SCALAR ILU(0)
+    does not tolerate the blended matrix (CPU study of round 4), the node-block factorisation of the GPU does."""
+    from dafoam_amd.pyDASolvers import Mat
     from oracle import linear as OL
 
     t0 = time.perf_counter()
@@ -478,7 +485,16 @@ def _cpu_solver(L, h, ksp, pc, n, N, op_nnz, pc_nnz, threads):
     A = _export(L, L.das_op_export, h, n, op_nnz)
     K.set_operator(A)
     del A
-    P = _export(L, L.das_mat_export, pc.handle, n, pc_nnz)
+    pc_cpu = pc
+    if blend:
+        D.solver.updateDAOption({"amd": {"pcUpwindBlend": 0.0}})
+        pc_cpu = Mat()
+        D.solver.calcdRdWT(1, pc_cpu)
+        D.solver.updateDAOption({"amd": {"pcUpwindBlend": float(blend)}})
+        pc_nnz = int(L.das_mat_nnz(pc_cpu.handle))
+    P = _export(L, L.das_mat_export, pc_cpu.handle, n, pc_nnz)
+    if pc_cpu is not pc:
+        pc_cpu.destroy()
     perm = _node_order_permutation(ksp, n)
     K.set_pc(P, perm)
     nagg, agg = ksp.coarse(N)
@@ -491,7 +507,7 @@ def _cpu_solver(L, h, ksp, pc, n, N, op_nnz, pc_nnz, threads):
                    ordering="GPU node elimination order" if perm is not None else "natural (state) order")
 
 
-def cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu_spmv_ms, gpu_pc_ms):
+def cpu_port_at_bench_size(a, L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu_spmv_ms, gpu_pc_ms):
     """CPU restatement (kind "port": the oracle's OpenMP C kernels, oracle/csrc/oracle_krylov_omp.c - NOT DAFoam) AT THE BENCH SIZE on
     all host cores: the operator dRdW^T and the PC matrix dRdWTPC of this very run are copied back from the device; right-
     preconditioned GMRES(CGS2) with the row-chunked first-touch SpMV, ONE global level-scheduled ILU(0) of dRdWTPC (the reference:
@@ -506,7 +522,7 @@ def cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu_sp
     if avail < need:
         return {"skipped": f"host MemAvailable {avail / 1e9:.0f} GB < {need / 1e9:.0f} GB"}
     threads = int(os.environ.get("DAS_BENCH_CPU_THREADS", os.cpu_count() or 1))
-    K, prep = _cpu_solver(L, h, ksp, pc, n, N, op_nnz, pc_nnz, threads)
+    K, prep = _cpu_solver(L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, threads, blend=a.pc_blend)
     stream = K.stream_GBps(1 << 28, 5)
     _, pilot = K.gmres(rhs_h, restart=4, fixed_iters=4)
     per_it = pilot["seconds"] / 4
@@ -578,7 +594,7 @@ def psi_parity_200k(a, dev_index, case2d=None):
     psi_gpu = x.array.copy()
     h = D.solver._h
     threads = int(os.environ.get("DAS_BENCH_CPU_THREADS", os.cpu_count() or 1))
-    K, prep = _cpu_solver(L, h, ksp, P, n, N, int(L.das_op_nnz(h)), int(L.das_mat_nnz(P.handle)), threads)
+    K, prep = _cpu_solver(L, D, h, ksp, P, n, N, int(L.das_op_nnz(h)), int(L.das_mat_nnz(P.handle)), threads, blend=a.pc_blend)
     psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=1e-10, abs_tol=1e-300)
     return {"system": what, "cells": int(N), "states": int(n), "rel_tol_both": 1e-10,
             "gpu": {"iterations": int(ginf["iters"]), "seconds": t_gpu, "fail": int(gfail), "rel_residual": ginf["res"] / ginf["res0"] if ginf["res0"] else None},

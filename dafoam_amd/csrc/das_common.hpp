@@ -38,6 +38,35 @@ struct Error : std::runtime_error {
     } while (0)
 
 // ---- device buffer -------------------------------------------------------------------------
+// mapped virtual ranges of released VmBufs (never unmapped; see VmBuf::release)
+struct VmRange {
+    void* p = nullptr;
+    size_t reservedBytes = 0, mappedBytes = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<size_t> sizes;
+    int device = 0;
+};
+inline std::vector<VmRange>& vm_cache() { static std::vector<VmRange> c; return c; }
+inline std::mutex& vm_cache_mutex() { static std::mutex m; return m; }
+// last resort of a failed hipMalloc: give the physical memory of the cached (idle) ranges back to the device.  The ranges are
+// dropped for good - a range that was unmapped is never handed out again (see VmBuf::release)
+inline size_t vm_cache_trim() {
+    std::lock_guard<std::mutex> lk(vm_cache_mutex());
+    size_t freed = 0;
+    for (VmRange& r : vm_cache()) {
+        size_t off = 0;
+        for (size_t i = 0; i < r.handles.size(); i++) {
+            (void)hipMemUnmap((char*)r.p + off, r.sizes[i]);
+            (void)hipMemRelease(r.handles[i]);
+            off += r.sizes[i];
+            freed += r.sizes[i];
+        }
+        // the address range itself stays reserved (never freed: a later reservation must not land on it)
+    }
+    vm_cache().clear();
+    return freed;
+}
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -60,7 +89,14 @@ struct DevBuf {
     void alloc(size_t n_) {
         release();
         n = n_;
-        if (n) DAS_HIP(hipMalloc((void**)&p, n * sizeof(T)));
+        if (!n) return;
+        if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            // out of memory: idle Krylov ranges of destroyed solvers may still hold mapped memory (VmBuf cache) - release it and retry
+            if (vm_cache_trim() > 0) (void)hipDeviceSynchronize();
+            DAS_HIP(hipMalloc((void**)&p, n * sizeof(T)));
+        }
     }
     void upload(const T* h, size_t cnt) {
         if (cnt > n) alloc(cnt);
@@ -90,16 +126,6 @@ struct DevBuf {
 // a solve that converges after 464 vectors maps 60 GB, not 129, the mapping of the next chunk costs milliseconds, and the
 // scrubbing of freed memory overlaps with the first iterations.  The kernels see one contiguous range.  Any failure of the VM
 // path falls back to one hipMalloc of the whole range.
-// mapped virtual ranges of released VmBufs (never unmapped; see VmBuf::release)
-struct VmRange {
-    void* p = nullptr;
-    size_t reservedBytes = 0, mappedBytes = 0;
-    std::vector<hipMemGenericAllocationHandle_t> handles;
-    std::vector<size_t> sizes;
-    int device = 0;
-};
-inline std::vector<VmRange>& vm_cache() { static std::vector<VmRange> c; return c; }
-inline std::mutex& vm_cache_mutex() { static std::mutex m; return m; }
 
 template <class T>
 struct VmBuf {

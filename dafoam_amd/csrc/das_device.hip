@@ -2037,7 +2037,10 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
     // the basis: address range for the larger of this restart and what the reference's default restart (1000) would need inside
     // the budget - reserved ONCE, so that a later solve with another restart never frees and re-allocates it; physical memory is
     // mapped while the iteration advances (VmBuf::ensure in gmres_map_basis)
-    const long long wantVec = std::max<long long>(restart + 2, std::min<long long>(maxVec, 1002));
+    long long wantVec = std::max<long long>(restart + 2, std::min<long long>(maxVec, 1002));
+    // the over-reservation is free only on the virtual-memory path (>= 4 GB, VmBuf::reserve); below that the range is one hipMalloc of
+    // real memory: then exactly what this restart needs (~2.8 GB per KSP on small cases otherwise)
+    if ((size_t)wantVec * (size_t)n * sizeof(double) < ((size_t)4 << 30) || getenv("DAS_NO_VMM")) wantVec = restart + 2;
     if (k->V.n < (size_t)((restart + 2) * n) || k->Vn != n) {
         k->V.reserve((size_t)(wantVec * n));
         k->Vn = n;

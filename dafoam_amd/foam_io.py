@@ -379,17 +379,27 @@ def read_fv_solution(case_dir):
             b = _dict_block(rf, sub)
             if b is None:
                 continue
-            for key, val in _flat_entries(b).items():
-                for name in ("U", "nuTilda", "T", "h", "e", "p", "rho"):
-                    if re.fullmatch(key, name) or (key.endswith(".*") and re.fullmatch(key, name)):
-                        out[dst].setdefault(name, float(val))
+            # OpenFOAM's dictionary lookup: an exact keyword wins; among the regular-expression keys the LAST matching one
+            ent = _flat_entries(b)
+            for name in ("U", "nuTilda", "T", "h", "e", "p", "rho"):
+                if name in ent:
+                    out[dst][name] = float(ent[name])
+                    continue
+                for key, val in ent.items():
+                    try:
+                        hit = re.fullmatch(key, name) is not None
+                    except re.error:  # an unquoted keyword that is not a valid pattern can only match literally
+                        hit = False
+                    if hit:
+                        out[dst][name] = float(val)
     return out
 
 
 def apply_system_dicts(case: FoamCase, case_dir, strict=True):
     """Honour system/fvSolution (equation relaxation factors, SIMPLE consistent / transonic) and verify system/fvSchemes against
-    the implemented scheme set.  strict: a case that asks for other schemes - or for field relaxation of p, which changes the
-    fixed point of the residual this library evaluates - raises NotImplementedError naming the entries."""
+    the implemented scheme set.  strict: a case that asks for other schemes raises NotImplementedError naming the entries.  Field
+    relaxation factors (p) and nNonOrthogonalCorrectors are parameters of the SIMPLE ITERATION, not of its fixed point R(W) = 0
+    that this library evaluates: they are read (read_fv_solution) and deliberately not used."""
     sch = read_fv_schemes(case_dir)
     if sch is not None:
         bad = check_schemes(sch)

@@ -138,6 +138,9 @@ class DAOPTION(object):
         ## directory of the dRdWColoring_<nProcs>.bin cache (the reference keeps it in the case directory,
         ## DAJacCon.C:1886-2019); "" = do not cache
         self.amdColoringDir = ""
+        # solvePrimal: residual norm that primalMinResTol refers to (0 = the norm at the states the first primal of this object starts
+        # from); set it when a run restarts from already converged fields, whose own start norm is ~0
+        self.amdPrimalResRef = 0.0
 
 
 class PYDAFOAM(object):
@@ -453,6 +456,7 @@ class PYDAFOAM(object):
 
     def setPrimalBoundaryConditions(self, printInfo=1, printInfoAD=0):
         """pyDAFoam.py:1662-1667"""
+        self._primalResRef = None  # new boundary values = a new problem: solvePrimal takes its reference norm anew
         self.solver.setPrimalBoundaryConditions(printInfo)
         if self.solverAD is not self.solver:
             self.solverAD.setPrimalBoundaryConditions(printInfoAD)
@@ -516,10 +520,16 @@ class PYDAFOAM(object):
         (`primalMaxRes < primalMinResTol`, DASolver.C:188: primalMaxRes is the largest of OpenFOAM's normalised initial
         residuals, O(1) for a start from scratch): here the residual 2-norm divided by the norm at the states the FIRST
         primal of this object started from, so that a warm-started call inside an optimisation loop converges to the same
-        level instead of 1e-8 below an already converged start.  The failure flag follows
+        level instead of 1e-8 below an already converged start.  The reference norm is taken anew after
+        setPrimalBoundaryConditions (a different problem), and `amdPrimalResRef` > 0 overrides it - needed when the very first call
+        starts from converged fields, whose own norm is ~0 (a deviation from the reference, where primalMaxRes is OpenFOAM's
+        normalised initial residual, DASolver.C:188).  The failure flag follows
         DASolver::checkPrimalFailure (DASolver.C:2722-2760): fail when primalMaxRes / primalMinResTol > primalMinResTolDiff."""
         tol = float(self.getOption("primalMinResTol"))
         ref = getattr(self, "_primalResRef", None)
+        user_ref = float(self.getOption("amdPrimalResRef") or 0.0)
+        if user_ref > 0.0:
+            ref = self._primalResRef = user_ref
         if ref is None:
             R = np.zeros(self.getNLocalAdjointStates())
             self.solver.getResiduals(R)

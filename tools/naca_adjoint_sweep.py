@@ -7,8 +7,10 @@ sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser()
 ap.add_argument("--nz", type=int, nargs="+", default=[1, 16])
 ap.add_argument("--dz", type=float, default=0.1)
+ap.add_argument("--section", type=int, nargs=2, default=None, help="converge this section (n_around n_normal) by grid sequencing instead of loading the 200 x 63 data file")
+ap.add_argument("--first-cell", type=float, default=2e-5)
 ap.add_argument("--combos", nargs="+", default=["-1:additive:rcb:1", "512:additive:rcb:1", "2048:additive:rcb:1", "-1:deflated:rcb:1", "2048:deflated:rcb:1", "-1:additive:strength:1",
-                                                "2048:additive:strength:1", "-1:additive:rcb:2", "0:additive:rcb:1"], help="coarseAgg:coarseMode:aggregation:localPCIters")
+                                                "2048:additive:strength:1", "-1:additive:rcb:2", "0:additive:rcb:1"], help="coarseAgg:coarseMode:aggregation:localPCIters (coarseAgg 'a' = automatic)")
 ap.add_argument("--maxit", type=int, default=1500)
 ap.add_argument("--blend", type=float, nargs="+", default=[0.0], help="amd.pcUpwindBlend values (the PC matrix is re-assembled per value)")
 ap.add_argument("--polish", type=int, default=2)
@@ -21,11 +23,19 @@ from dafoam_amd.pyDAFoam import PYDAFOAM
 from dafoam_amd.pyDASolvers import KSP, Mat, Vec
 from dafoam_amd import _capi
 L = _capi.lib()
-d = np.load(os.path.join(ROOT, "dafoam_amd", "data", "naca_primal_200x63.npz"))
-nx, ny = [int(v) for v in d["dims"]]
-fc = float(d["first_cell"])
-case2 = naca0012_case(nx, ny, 1, first_cell=fc, perturb=0.0)
-case2.states = d["states"].copy()
+if a.section:
+    from dafoam_amd.workloads import naca_converged_primal
+    nx, ny = a.section
+    fc = a.first_cell
+    t0 = time.time()
+    case2, lv = naca_converged_primal(nx, ny, options={"solverName": "DASimpleFoam", "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0}}, first_cell=fc, verbose=True)
+    print(f"primal by grid sequencing: {time.time() - t0:.1f} s", flush=True)
+else:
+    d = np.load(os.path.join(ROOT, "dafoam_amd", "data", "naca_primal_200x63.npz"))
+    nx, ny = [int(v) for v in d["dims"]]
+    fc = float(d["first_cell"])
+    case2 = naca0012_case(nx, ny, 1, first_cell=fc, perturb=0.0)
+    case2.states = d["states"].copy()
 opts = {"solverName": "DASimpleFoam", "debug": False, "normalizeStates": {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0},
         "adjEqnOption": {"gmresRestart": a.maxit, "gmresMaxIters": a.maxit, "gmresRelTol": 1e-6, "printInfo": 0}, "amd": {"maxKrylovBytes": int(140 * 2**30)}}
 for nz in a.nz:
@@ -46,6 +56,7 @@ for nz in a.nz:
       pc = Mat(); D.solver.calcdRdWT(1, pc)
       for c in a.combos:
         cagg, cmode, cag, pit = c.split(":")
+        cagg = -1 if cagg == "a" else cagg
         D.solver.updateDAOption({"amd": {"pcCoarseAggregates": int(cagg), "pcCoarseMode": cmode, "pcCoarseAggregation": cag}, "adjEqnOption": {"localPCIters": int(pit)}})
         ksp = KSP(); t = time.time(); D.solverAD.createMLRKSPMatrixFree(pc, ksp); t_ilu = time.time() - t
         x = Vec(n); r = Vec(n); r.array[:] = rhs
