@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--naca-dz", type=float, default=0.025, help="naca: spanwise layer thickness (chords); 160 layers x 0.025 = a wing section of aspect ratio 4 between symmetry planes")
     ap.add_argument("--naca-synthetic", action="store_true", help="naca: the round-3 synthetic noisy boundary-layer state instead of the converged primal")
     ap.add_argument("--window-at-warmup", action="store_true", help="time the K steps at basis sizes [W, W+K) instead of around the mean depth of the full solve")
+    ap.add_argument("--parity-tol", type=float, default=1e-9, help="relative residual both sides of the psi parity leg are solved to (bar on the psi difference: 1e-6)")
     ap.add_argument("--no-parity", action="store_true", help="skip the 200 k-cell psi parity leg (GPU vs all-core CPU port)")
     ap.add_argument("--pc-blend", type=float, default=None, help="amd.pcUpwindBlend: weight of the second-order (linearUpwindV) correction in the PC residual "
                          "(the reference user's choice of div(pc) in fvSchemes); default 0.5 for naca, 0 (upwind) for channel")
@@ -73,7 +74,7 @@ def parse():
     ap.add_argument("--solve-maxit", type=int, default=1000)
     ap.add_argument("--converge-primal", action="store_true", help="converge the flow state with the GPU Newton-Krylov primal before the adjoint (opt-in: the adjoint's conditioning does not depend on it, DESIGN.md section 6b)")
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
-    ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE", "additive"))
+    ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE"), help="amd.pcCoarseMode additive | deflated (default: deflated for naca, additive for channel)")
     ap.add_argument("--orth", default=os.environ.get("DAS_BENCH_ORTH", "dcgs2"), help="dcgs2 (delayed re-orthogonalisation, 2 basis reads / iteration) | cgs (reference: refine if needed)")
     return ap.parse_args()
 
@@ -89,6 +90,15 @@ def pmc_traffic(op_nnz, kernel):
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+_T0 = time.time()
+
+
+def stage(msg):
+    """Progress on stderr (DAS_BENCH_VERBOSE=1): where the time of a run goes; never on stdout (ONE JSON line there)."""
+    if os.environ.get("DAS_BENCH_VERBOSE"):
+        print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def make_opts(a, dev_index, restart, maxit, rtol):
@@ -149,6 +159,8 @@ def main():
         a.workload = "channel"  # the sharded path partitions the structured channel into slabs
     if a.pc_blend is None:
         a.pc_blend = 0.5 if a.workload == "naca" else 0.0
+    if a.coarse_mode is None:
+        a.coarse_mode = "deflated" if a.workload == "naca" else "additive"
     opts = make_opts(a, dev_index, a.solve_restart, a.solve_maxit, 1e-6)
     sharded = None
     primal, case2d = None, None
@@ -192,6 +204,7 @@ def main():
         ncell = case.mesh.n_cells
         D = PYDAFOAM(options=opts, case=case)
     t_case = time.time() - t_setup
+    stage(f"case ready ({ncell} cells)")
     if a.converge_primal and world == 1 and primal is None:
         t0 = time.time()
         D.setOption("primalMinResTol", 1e-8) if hasattr(D, "setOption") else None
@@ -233,6 +246,7 @@ def main():
     rhs = torch.from_numpy(rhs_h).cuda()
     sol = torch.zeros(n, dtype=torch.float64, device="cuda")
     setup_s = time.time() - t_setup
+    stage(f"adjoint set-up done: colouring {t_color:.1f} s, dRdWTPC {t_pcmat:.1f} s, factorisation {t_pc:.1f} s, dRdWT {t_op:.1f} s")
 
     def check(rc):
         if rc < 0:
@@ -271,6 +285,7 @@ def main():
                  "rel_residual_at_1000_iterations": float(hist[1000] / hist[0]) if len(hist) > 1000 else None,
                  "rel_residual_every_100": [float(v / hist[0]) for v in hist[::100]],
                  "iterations_per_sec_whole_solve": its / t_solve}
+        stage(f"solve: {its} iterations, {t_solve:.1f} s, fail {fail}")
 
     # ---- timed window (driver contract): W' untimed iterations, then EXACTLY K timed, inside ONE Arnoldi cycle.  W' = the mean basis
     # depth of the full solve minus K/2 (>= --warmup): the window rate is then the mean per-iteration rate of the whole solve ----------
@@ -325,20 +340,23 @@ def main():
     orth = a.orth
     moved_bytes = spmv_bytes + pc_bytes + (16.0 if orth == "dcgs2" else 32.0) * jmean * n + 48.0 * n
     ms_step = dt / a.steps * 1e3
+    stage(f"window: {a.steps} steps at depth {j0}: {ms_step:.2f} ms per step")
 
     out = None
     if rank == 0:
         cpu, parity = None, None
         if not a.no_cpu and world == 1:
             try:
-                cpu = cpu_port_at_bench_size(a, L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, spmv_ms, pc_ms)
+                cpu = cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, spmv_ms, pc_ms)
             except Exception as e:  # noqa: BLE001 - the baseline must never break the line
                 cpu = {"error": repr(e)[:300]}
+            stage(f"cpu port at the bench size: {({k: v for k, v in cpu.items() if k in ('value', 'ms_per_iteration', 'error', 'skipped')})}")
         if not a.no_parity and not a.no_cpu and world == 1:
             try:
                 parity = psi_parity_200k(a, dev_index, case2d)
             except Exception as e:  # noqa: BLE001
                 parity = {"error": repr(e)[:300]}
+            stage(f"psi parity leg: {({k: v for k, v in parity.items() if k in ('psi_rel_diff_gpu_vs_cpu', 'error')})}")
             if cpu is not None and parity is not None:
                 cpu["psi_rel_diff_gpu_vs_cpu"] = parity.get("psi_rel_diff_gpu_vs_cpu")
         pc_desc = ("node-block ILU(0) of FD dRdWTPC over the whole rank (8-slot cell nodes, 8x8 fp%s blocks), factorised on the device, "
@@ -463,21 +481,9 @@ def _export(L, fn, handle, n, nnz):
     return rp, ci, v
 
 
-def _node_order_permutation(ksp, n):
-    """Unknown order of the CPU port's ILU(0): cell by cell in the elimination order of the GPU preconditioner's nodes (the
-    reference reorders inside PETSc: jacMatReOrdering, DALinearEqn.C:238-290).  None if the structure is not a permutation."""
-    nu = ksp.pcStructure()["nodeUnk"].ravel()
-    perm = nu[nu >= 0].astype(np.int32)
-    if perm.size != n or np.unique(perm).size != n:
-        return None
-    return perm
-
-
-def _cpu_solver(L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, threads, blend=0.0):
-    """The oracle's all-core port loaded with the operator and the PC matrix of the GPU run (copied back from the device).  With
-    amd.pcUpwindBlend > 0 the CPU side gets its own PC matrix assembled with the reference's first-order div(pc): a SCALAR ILU(0)
-    does not tolerate the blended matrix (CPU study of round 4), the node-block factorisation of the GPU does."""
-    from dafoam_amd.pyDASolvers import Mat
+def _cpu_solver(L, h, ksp, pc, n, N, op_nnz, pc_nnz, threads):
+    """The oracle's all-core port loaded with the operator and the PC matrix of the GPU run (copied back from the device): CSR SpMV,
+    the node-block ILU(0) restated for the host on the SAME node structure (KSP.pcStructure) and PC matrix, the same aggregates."""
     from oracle import linear as OL
 
     t0 = time.perf_counter()
@@ -485,35 +491,26 @@ def _cpu_solver(L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, threads, blend=0.0):
     A = _export(L, L.das_op_export, h, n, op_nnz)
     K.set_operator(A)
     del A
-    pc_cpu = pc
-    if blend:
-        D.solver.updateDAOption({"amd": {"pcUpwindBlend": 0.0}})
-        pc_cpu = Mat()
-        D.solver.calcdRdWT(1, pc_cpu)
-        D.solver.updateDAOption({"amd": {"pcUpwindBlend": float(blend)}})
-        pc_nnz = int(L.das_mat_nnz(pc_cpu.handle))
-    P = _export(L, L.das_mat_export, pc_cpu.handle, n, pc_nnz)
-    if pc_cpu is not pc:
-        pc_cpu.destroy()
-    perm = _node_order_permutation(ksp, n)
-    K.set_pc(P, perm)
+    P = _export(L, L.das_mat_export, pc.handle, n, pc_nnz)
+    S = ksp.pcStructure()
+    K.set_pc_bilu(P, S)
     nagg, agg = ksp.coarse(N)
     if nagg > 0 and agg.min() >= 0:
         K.set_coarse(P, 3 * N, N, agg)
     else:
         nagg = 0
     del P
-    return K, dict(prep_seconds=time.perf_counter() - t0, ilu_levels=list(K.levels), shifted_pivots=int(K.nshift), coarse_aggregates=int(nagg),
-                   ordering="GPU node elimination order" if perm is not None else "natural (state) order")
+    return K, dict(prep_seconds=time.perf_counter() - t0, ilu_levels=int(S["lvlPtr"].size - 1), nodes=int(S["nodeUnk"].shape[0]), blocks=int(S["bcol"].size),
+                   shifted_pivots=int(K.nshift), coarse_aggregates=int(nagg))
 
 
-def cpu_port_at_bench_size(a, L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu_spmv_ms, gpu_pc_ms):
+def cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu_spmv_ms, gpu_pc_ms):
     """CPU restatement (kind "port": the oracle's OpenMP C kernels, oracle/csrc/oracle_krylov_omp.c - NOT DAFoam) AT THE BENCH SIZE on
     all host cores: the operator dRdW^T and the PC matrix dRdWTPC of this very run are copied back from the device; right-
-    preconditioned GMRES(CGS2) with the row-chunked first-touch SpMV, ONE global level-scheduled ILU(0) of dRdWTPC (the reference:
-    ILU(pcFillLevel) of one sub-domain per rank) + the same pressure coarse space, threaded multi-dot / multi-axpy.  A bounded
-    sample of iterations (about --cpu-seconds) at basis sizes j < sample: no extrapolation."""
-    need = 12.0 * (op_nnz + pc_nnz) * 2.2
+    preconditioned GMRES(CGS2) with the row-chunked first-touch SpMV, the SAME preconditioner restated for the host (node-block
+    ILU(0) on the library's node structure, level-parallel factorisation and sweeps; + the same pressure coarse space, additive),
+    threaded multi-dot / multi-axpy.  A bounded sample of iterations (about --cpu-seconds) at basis sizes j < sample: no extrapolation."""
+    need = 12.0 * (op_nnz + pc_nnz) * 2.2 + 9.0 * 64 * 30 * N
     try:
         with open("/proc/meminfo") as f:
             avail = [int(ln.split()[1]) * 1024.0 for ln in f if ln.startswith("MemAvailable")][0]
@@ -522,7 +519,7 @@ def cpu_port_at_bench_size(a, L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu
     if avail < need:
         return {"skipped": f"host MemAvailable {avail / 1e9:.0f} GB < {need / 1e9:.0f} GB"}
     threads = int(os.environ.get("DAS_BENCH_CPU_THREADS", os.cpu_count() or 1))
-    K, prep = _cpu_solver(L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, threads, blend=a.pc_blend)
+    K, prep = _cpu_solver(L, h, ksp, pc, n, N, op_nnz, pc_nnz, threads)
     stream = K.stream_GBps(1 << 28, 5)
     _, pilot = K.gmres(rhs_h, restart=4, fixed_iters=4)
     per_it = pilot["seconds"] / 4
@@ -538,16 +535,16 @@ def cpu_port_at_bench_size(a, L, D, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu
         "kind": "port",
         "sample": f"{iters} GMRES iterations (basis sizes j < {iters}) of the SAME {N}-cell system at the bench size - operator ({op_nnz} nnz) and PC matrix ({pc_nnz} nnz) "
                   f"copied back from the device - with the oracle's OpenMP C port (gcc -O3 -march=native -fopenmp, {K.threads} threads, first-touch placement): CSR SpMV, "
-                  f"one global level-scheduled scalar ILU(0) of dRdWTPC in the {prep['ordering']} ({prep['ilu_levels'][0]} + {prep['ilu_levels'][1]} levels) + "
-                  f"pressure coarse space ({prep['coarse_aggregates']} aggregates), CGS2 with threaded multi-dot / multi-axpy; {inf['seconds']:.1f} s timed, prep "
-                  f"{prep['prep_seconds']:.1f} s (untimed: device-to-host copies, permutation, level sets, factorisation)",
+                  f"the node-block ILU(0) of the GPU path restated for the host ({prep['nodes']} nodes, {prep['blocks']} dense 8x8 blocks, {prep['ilu_levels']} levels, "
+                  f"level-parallel) + pressure coarse space ({prep['coarse_aggregates']} aggregates, additive), CGS2 with threaded multi-dot / multi-axpy; {inf['seconds']:.1f} s "
+                  f"timed, prep {prep['prep_seconds']:.1f} s (untimed: device-to-host copies, block scatter, factorisation)",
         "host_cpus": os.cpu_count(),
         "host_stream_triad_GBps": stream,
         "seconds_timed": inf["seconds"],
         "iterations_timed": iters,
         "ms_per_iteration": inf["seconds"] / iters * 1e3,
         "dRdWTPsi_at_bench_size": {"ms": spmv_ms, "GBps": bytes_ / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else None, "gpu_ms": gpu_spmv_ms},
-        "pc_apply_at_bench_size": {"ms": pc_ms, "gpu_ms": gpu_pc_ms, "ilu_levels": prep["ilu_levels"]},
+        "pc_apply_at_bench_size": {"ms": pc_ms, "gpu_ms": gpu_pc_ms, "levels": prep["ilu_levels"]},
         "orthogonalisation_ms_mean": inf["seconds_orth"] / iters * 1e3,
         "prep": prep,
     }
@@ -567,7 +564,7 @@ def psi_parity_200k(a, dev_index, case2d=None):
     if a.workload == "naca":
         from dafoam_amd.workloads import naca_converged_primal, naca_extruded_case
 
-        o10 = make_opts(a, dev_index, 1000, 1000, 1e-10)
+        o10 = make_opts(a, dev_index, 1000, 1000, a.parity_tol)
         if case2d is None:
             case2d, _ = naca_converged_primal(a.naca[0], a.naca[1], options=o10, first_cell=a.naca_first_cell)
         nzp = max(1, int(round(200000.0 / (a.naca[0] * a.naca[1]))))
@@ -575,7 +572,7 @@ def psi_parity_200k(a, dev_index, case2d=None):
         what = f"NACA0012 wing section {a.naca[0]} x {a.naca[1]} x {nzp} (the bench's converged section, {nzp} spanwise layers of 0.1 chords: BASELINE configs[1] size)"
     else:
         case, what = bench_channel_case(100, 50, 40), "bump channel 100 x 50 x 40"
-    D = PYDAFOAM(options=make_opts(a, dev_index, 2000, 2000, 1e-10), case=case)  # restart 2000: no restart inside the plateau of the residual history
+    D = PYDAFOAM(options=make_opts(a, dev_index, 2000, 2000, a.parity_tol), case=case)  # restart 2000: no restart inside the plateau of the residual history
     n, N = D.getNLocalAdjointStates(), case.mesh.n_cells
     D.solver.runColoring()
     P = Mat()
@@ -594,12 +591,13 @@ def psi_parity_200k(a, dev_index, case2d=None):
     psi_gpu = x.array.copy()
     h = D.solver._h
     threads = int(os.environ.get("DAS_BENCH_CPU_THREADS", os.cpu_count() or 1))
-    K, prep = _cpu_solver(L, D, h, ksp, P, n, N, int(L.das_op_nnz(h)), int(L.das_mat_nnz(P.handle)), threads, blend=a.pc_blend)
-    psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=1e-10, abs_tol=1e-300)
-    return {"system": what, "cells": int(N), "states": int(n), "rel_tol_both": 1e-10,
+    K, prep = _cpu_solver(L, h, ksp, P, n, N, int(L.das_op_nnz(h)), int(L.das_mat_nnz(P.handle)), threads)
+    psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=a.parity_tol, abs_tol=1e-300, max_seconds=float(os.environ.get("DAS_BENCH_PARITY_CPU_SECONDS", 420)))
+    return {"system": what, "cells": int(N), "states": int(n), "rel_tol_both": a.parity_tol,
             "gpu": {"iterations": int(ginf["iters"]), "seconds": t_gpu, "fail": int(gfail), "rel_residual": ginf["res"] / ginf["res0"] if ginf["res0"] else None},
             "cpu": {"iterations": int(cinf["iters"]), "seconds": cinf["seconds"], "fail": int(cinf["fail"]), "rel_residual": cinf["res"] / cinf["res0"] if cinf["res0"] else None,
-                    "threads": K.threads, "gmresRestart": 1500, "prep_seconds": prep["prep_seconds"], "ilu_levels": prep["ilu_levels"]},
+                    "threads": K.threads, "gmresRestart": 1500, "prep_seconds": prep["prep_seconds"], "ilu_levels": prep["ilu_levels"],
+                    "pc": "node-block ILU(0) restated for the host + additive pressure coarse space"},
             "psi_rel_diff_gpu_vs_cpu": float(np.linalg.norm(psi_gpu - psi_cpu) / np.linalg.norm(psi_cpu)), "bar": 1e-6}
 
 

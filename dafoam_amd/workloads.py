@@ -81,7 +81,8 @@ def naca_extruded_case(case2d, dims2d, nz, dz=0.1, first_cell=2.0e-5, options=No
     if polish_steps > 0:
         opts = dict(options or {})
         # a start next to the solution: large pseudo-time step at once
-        opts["amd"] = dict(opts.get("amd", {}), **dict(NACA_PRIMAL_AMD_FINE, primalTau0=1.0e3))
+        # (measured at 2 M cells: ramp / transport-rows mode from tau 1e3: |R| 0.78 -> 1.4e-3 in 2 steps; the ser / all-rows mode stalls here)
+        opts["amd"] = dict(opts.get("amd", {}), **dict(NACA_PRIMAL_AMD, primalTau0=1.0e3, primalTauGrowth=10.0))
         D = PYDAFOAM(options=opts, case=case3)
         fail, inf = D.solver.solvePrimal(maxSteps=polish_steps, relTol=polish_tol, absTol=0.0)
         case3.states = D.getStates().copy()

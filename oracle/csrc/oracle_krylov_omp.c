@@ -36,6 +36,14 @@ typedef struct {
     int *rowsL, *rowsU;
     int nshift;
     double *xp, *bp;
+    /* alternative preconditioner: node-block ILU(0) (dense 8x8 blocks on a node pattern, level order = node order) */
+    int has_bilu, nNodes, nLv;
+    int* nodeUnk;   /* nNodes x 8, -1 = empty slot */
+    ll* bptr; int* bcol; ll* bdiag;
+    double* bval;   /* 64 per block: L blocks (row-scaled by the pivot inverse), U blocks */
+    double* invD;   /* 64 per node */
+    int* lvlPtr;
+    double *by, *bx; /* nNodes x 8 work vectors */
     /* coarse space */
     int has_coarse, nagg;
     ll coff, cN;
@@ -72,10 +80,15 @@ static void free_pc(okry* k) {
     k->frp = NULL; k->fci = NULL; k->fv = NULL; k->fdiag = NULL; k->perm = NULL; k->lpL = k->lpU = NULL; k->rowsL = k->rowsU = NULL; k->xp = k->bp = NULL;
     k->has_pc = 0;
 }
+static void free_bilu(okry* k) {
+    free(k->nodeUnk); free(k->bptr); free(k->bcol); free(k->bdiag); free(k->bval); free(k->invD); free(k->lvlPtr); free(k->by); free(k->bx);
+    k->nodeUnk = NULL; k->bptr = NULL; k->bcol = NULL; k->bdiag = NULL; k->bval = NULL; k->invD = NULL; k->lvlPtr = NULL; k->by = k->bx = NULL;
+    k->has_bilu = 0;
+}
 static void free_coarse(okry* k) { free(k->agg); free(k->Einv); free(k->cr); free(k->cz); k->agg = NULL; k->Einv = k->cr = k->cz = NULL; k->has_coarse = 0; }
 void okry_free(okry* k) {
     if (!k) return;
-    free_op(k); free_pc(k); free_coarse(k);
+    free_op(k); free_pc(k); free_bilu(k); free_coarse(k);
     free(k);
 }
 
@@ -270,6 +283,157 @@ int okry_set_pc_ilu0(okry* k, ll n, const ll* rp, const int* ci, const double* v
 int okry_pc_levels(const okry* k, int* nlevL, int* nlevU) { if (nlevL) *nlevL = k->nlevL; if (nlevU) *nlevU = k->nlevU; return k->has_pc; }
 ll okry_pc_nnz(const okry* k) { return k->has_pc ? k->frp[k->n] : 0; }
 
+/* ---- node-block ILU(0): the product's default preconditioner (csrc/das_bilu.hpp) restated for the host -------------------------------
+ * nodes of <= 8 unknowns (nodeUnk, -1 = empty slot -> identity), block pattern bptr / bcol over nodes IN PROCESSING ORDER (sorted
+ * columns, symmetric pattern), levels lvlPtr (nodes of one level are mutually independent and contiguous).  Block IKJ factorisation with
+ * dense 8x8 blocks, pivot blocks inverted by Gauss-Jordan with row pivoting and a non-zero pivot shift; level-parallel sweeps. */
+static int inv8(double* a, double* out, double shift) { /* a is destroyed */
+    int nshift = 0;
+    for (int i = 0; i < 64; i++) out[i] = (i / 8 == i % 8) ? 1.0 : 0.0;
+    for (int c = 0; c < 8; c++) {
+        int pr = c; double best = fabs(a[c * 8 + c]);
+        for (int r = c + 1; r < 8; r++) if (fabs(a[r * 8 + c]) > best) { best = fabs(a[r * 8 + c]); pr = r; }
+        if (pr != c) for (int q = 0; q < 8; q++) { double t = a[c * 8 + q]; a[c * 8 + q] = a[pr * 8 + q]; a[pr * 8 + q] = t; t = out[c * 8 + q]; out[c * 8 + q] = out[pr * 8 + q]; out[pr * 8 + q] = t; }
+        double piv = a[c * 8 + c];
+        if (fabs(piv) < 1e-300 || piv != piv) { piv = (piv < 0 ? -1.0 : 1.0) * shift; a[c * 8 + c] = piv; nshift++; }
+        const double ip = 1.0 / piv;
+        for (int q = 0; q < 8; q++) { a[c * 8 + q] *= ip; out[c * 8 + q] *= ip; }
+        for (int r = 0; r < 8; r++) {
+            if (r == c) continue;
+            const double f = a[r * 8 + c];
+            if (f == 0.0) continue;
+            for (int q = 0; q < 8; q++) { a[r * 8 + q] -= f * a[c * 8 + q]; out[r * 8 + q] -= f * out[c * 8 + q]; }
+        }
+    }
+    return nshift;
+}
+static inline void mm8(const double* a, const double* b, double* c) { /* c = a b */
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) {
+            double s = 0.0;
+            for (int q = 0; q < 8; q++) s += a[i * 8 + q] * b[q * 8 + j];
+            c[i * 8 + j] = s;
+        }
+}
+int okry_set_pc_bilu(okry* k, ll n, const ll* rp, const int* ci, const double* v, int nNodes, const int* nodeUnk, const ll* bptr, const int* bcol,
+                     int nLv, const int* lvlPtr, double shift) {
+    free_bilu(k);
+    if (k->n && k->n != n) return -2;
+    k->n = n;
+    const int nt = k->nt;
+    const ll nB = bptr[nNodes];
+    k->nNodes = nNodes; k->nLv = nLv;
+    k->nodeUnk = (int*)xmalloc((size_t)nNodes * 8 * sizeof(int));
+    k->bptr = (ll*)xmalloc((nNodes + 1) * sizeof(ll));
+    k->bcol = (int*)xmalloc(nB * sizeof(int));
+    k->bdiag = (ll*)xmalloc(nNodes * sizeof(ll));
+    k->bval = (double*)xmalloc((size_t)nB * 64 * 8);
+    k->invD = (double*)xmalloc((size_t)nNodes * 64 * 8);
+    k->lvlPtr = (int*)malloc((nLv + 1) * sizeof(int));
+    k->by = (double*)xmalloc((size_t)nNodes * 8 * 8); k->bx = (double*)xmalloc((size_t)nNodes * 8 * 8);
+    int* unkNode = (int*)xmalloc(n * sizeof(int));
+    unsigned char* unkSlot = (unsigned char*)xmalloc(n);
+    if (!k->nodeUnk || !k->bptr || !k->bcol || !k->bdiag || !k->bval || !k->invD || !k->lvlPtr || !k->by || !k->bx || !unkNode || !unkSlot) return -1;
+    memcpy(k->lvlPtr, lvlPtr, (nLv + 1) * sizeof(int));
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (ll u = 0; u < n; u++) unkNode[u] = -1;
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int I = 0; I < nNodes; I++) {
+        k->bptr[I] = bptr[I];
+        if (I == nNodes - 1) k->bptr[nNodes] = bptr[nNodes];
+        for (int r = 0; r < 8; r++) { const int u = nodeUnk[(size_t)I * 8 + r]; k->nodeUnk[(size_t)I * 8 + r] = u; if (u >= 0) { unkNode[u] = I; unkSlot[u] = (unsigned char)r; } }
+        k->bdiag[I] = -1;
+        for (ll e = bptr[I]; e < bptr[I + 1]; e++) { k->bcol[e] = bcol[e]; if (bcol[e] == I) k->bdiag[I] = e; memset(k->bval + (size_t)e * 64, 0, 64 * 8); }
+    }
+    for (int I = 0; I < nNodes; I++) if (k->bdiag[I] < 0) { free(unkNode); free(unkSlot); return -3; }
+    /* scatter the scalar entries into the dense blocks (entries outside the node pattern are dropped by construction) */
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nt)
+    for (int I = 0; I < nNodes; I++) {
+        for (int r = 0; r < 8; r++) {
+            const int u = k->nodeUnk[(size_t)I * 8 + r];
+            if (u < 0) { k->bval[(size_t)k->bdiag[I] * 64 + r * 8 + r] = 1.0; continue; }  /* empty slot: identity row */
+            for (ll q = rp[u]; q < rp[u + 1]; q++) {
+                const int J = unkNode[ci[q]];
+                if (J < 0) continue;
+                ll lo = k->bptr[I], hi = k->bptr[I + 1] - 1, e = -1;
+                while (lo <= hi) { const ll mid = (lo + hi) >> 1; const int cm = k->bcol[mid]; if (cm == J) { e = mid; break; } if (cm < J) lo = mid + 1; else hi = mid - 1; }
+                if (e >= 0) k->bval[(size_t)e * 64 + r * 8 + unkSlot[ci[q]]] = v[q];
+            }
+        }
+    }
+    free(unkNode); free(unkSlot);
+    /* block IKJ, the nodes of one level in parallel */
+    int nshift = 0;
+#pragma omp parallel num_threads(nt) reduction(+ : nshift)
+    {
+        double tmp[64], lik[64];
+        for (int l = 0; l < nLv; l++) {
+#pragma omp for schedule(dynamic, 8)
+            for (int I = lvlPtr[l]; I < lvlPtr[l + 1]; I++) {
+                const ll ie = k->bptr[I + 1];
+                for (ll q = k->bptr[I]; q < k->bdiag[I]; q++) {
+                    const int K = k->bcol[q];
+                    mm8(k->bval + (size_t)q * 64, k->invD + (size_t)K * 64, lik);  /* L_IK = A_IK D_K^-1 */
+                    memcpy(k->bval + (size_t)q * 64, lik, 64 * 8);
+                    ll a = q + 1, b = k->bdiag[K] + 1;
+                    const ll be = k->bptr[K + 1];
+                    while (a < ie && b < be) {
+                        const int ca = k->bcol[a], cb = k->bcol[b];
+                        if (ca == cb) {
+                            mm8(lik, k->bval + (size_t)b * 64, tmp);
+                            double* d = k->bval + (size_t)a * 64;
+                            for (int t = 0; t < 64; t++) d[t] -= tmp[t];
+                            a++; b++;
+                        } else if (ca < cb) a++;
+                        else b++;
+                    }
+                }
+                memcpy(tmp, k->bval + (size_t)k->bdiag[I] * 64, 64 * 8);
+                nshift += inv8(tmp, k->invD + (size_t)I * 64, shift);
+            }
+        }
+    }
+    k->nshift = nshift;
+    k->has_bilu = 1;
+    return nshift;
+}
+static void bilu_apply(okry* k, const double* b, double* x) {
+    const int nN = k->nNodes;
+    double* y = k->by; double* z = k->bx;
+#pragma omp parallel num_threads(k->nt)
+    {
+        for (int l = 0; l < k->nLv; l++) {
+#pragma omp for schedule(static)
+            for (int I = k->lvlPtr[l]; I < k->lvlPtr[l + 1]; I++) {
+                double s[8];
+                for (int r = 0; r < 8; r++) { const int u = k->nodeUnk[(size_t)I * 8 + r]; s[r] = u >= 0 ? b[u] : 0.0; }
+                for (ll q = k->bptr[I]; q < k->bdiag[I]; q++) {
+                    const double* L = k->bval + (size_t)q * 64; const double* yk = y + (size_t)k->bcol[q] * 8;
+                    for (int r = 0; r < 8; r++) { double a = 0.0; for (int c = 0; c < 8; c++) a += L[r * 8 + c] * yk[c]; s[r] -= a; }
+                }
+                for (int r = 0; r < 8; r++) y[(size_t)I * 8 + r] = s[r];
+            }
+        }
+        for (int l = k->nLv - 1; l >= 0; l--) {
+#pragma omp for schedule(static)
+            for (int I = k->lvlPtr[l]; I < k->lvlPtr[l + 1]; I++) {
+                double s[8];
+                for (int r = 0; r < 8; r++) s[r] = y[(size_t)I * 8 + r];
+                for (ll q = k->bdiag[I] + 1; q < k->bptr[I + 1]; q++) {
+                    const double* U = k->bval + (size_t)q * 64; const double* zj = z + (size_t)k->bcol[q] * 8;
+                    for (int r = 0; r < 8; r++) { double a = 0.0; for (int c = 0; c < 8; c++) a += U[r * 8 + c] * zj[c]; s[r] -= a; }
+                }
+                const double* D = k->invD + (size_t)I * 64;
+                for (int r = 0; r < 8; r++) { double a = 0.0; for (int c = 0; c < 8; c++) a += D[r * 8 + c] * s[c]; z[(size_t)I * 8 + r] = a; }
+            }
+        }
+#pragma omp for schedule(static)
+        for (int I = 0; I < nN; I++)
+            for (int r = 0; r < 8; r++) { const int u = k->nodeUnk[(size_t)I * 8 + r]; if (u >= 0) x[u] = z[(size_t)I * 8 + r]; }
+    }
+}
+ll okry_bilu_blocks(const okry* k) { return k->has_bilu ? k->bptr[k->nNodes] : 0; }
+
 /* coarse space on the scalar cell field at offset `off` (N cells): Einv = (Z^T P_ff Z)^-1 given by the caller */
 int okry_set_coarse(okry* k, ll off, ll N, const int* agg, int nagg, const double* Einv) {
     free_coarse(k);
@@ -298,7 +462,9 @@ void okry_coarse_operator(ll off, ll N, const int* agg, int nagg, const ll* rp, 
 void okry_pc(okry* k, const double* b, double* x) {
     const double t0 = wall();
     const ll n = k->n;
+    if (k->has_bilu) { bilu_apply(k, b, x); goto coarse; }
     if (!k->has_pc) { memcpy(x, b, n * 8); return; }
+    {
     const ll* frp = k->frp; const int* fci = k->fci; const double* fv = k->fv; const ll* fdiag = k->fdiag;
     double* y = k->xp; double* bp = k->bp;
     const int* perm = k->perm;
@@ -327,6 +493,8 @@ void okry_pc(okry* k, const double* b, double* x) {
 #pragma omp for schedule(static)
         for (ll i = 0; i < n; i++) x[perm[i]] = y[i];
     }
+    }
+coarse:
     if (k->has_coarse) {
         const int na = k->nagg;
         memset(k->cr, 0, na * 8);
@@ -407,6 +575,8 @@ static double vnorm(const okry* k, const double* w) {
 /* Right-preconditioned restarted GMRES (CGS2).  fixed_iters > 0: exactly that many iterations (timing samples).
  * hist[0..histcap): residual norms (recurrence; true residual at restarts).  info[0]=iters, [1]=res0, [2]=res, [3]=seconds,
  * [4]=seconds in SpMV, [5]=PC, [6]=orthogonalisation.  Returns the reference's fail flag (DALinearEqn.C:422-434). */
+static double g_max_seconds = 0.0;  /* > 0: okry_gmres stops iterating (closing the current cycle) when this wall time is exceeded */
+void okry_set_max_seconds(double s) { g_max_seconds = s; }
 int okry_gmres(okry* k, const double* rhs, double* x, int restart, int maxit, double rtol, double atol, double tol_diff, int fixed_iters,
                double* hist, int histcap, double* info) {
     const ll n = k->n;
@@ -421,7 +591,7 @@ int okry_gmres(okry* k, const double* rhs, double* x, int restart, int maxit, do
     double* H = (double*)calloc((size_t)(m + 1) * m, 8);
     double *cs = (double*)calloc(m, 8), *sn = (double*)calloc(m, 8), *g = (double*)calloc(m + 1, 8), *y = (double*)calloc(m, 8);
     double *h = (double*)calloc(m + 1, 8), *h2 = (double*)calloc(m + 1, 8), *part = (double*)calloc((size_t)nt * (m + 1), 8);
-    int nalloc = 0, its = 0, nh = 0, rc = 0;
+    int nalloc = 0, its = 0, nh = 0, rc = 0, timed_out = 0;
 #pragma omp parallel for schedule(static) num_threads(nt)
     for (ll q = 0; q < n; q++) { x[q] = 0.0; r[q] = rhs[q]; }
     double beta = vnorm(k, r);
@@ -473,6 +643,7 @@ int okry_gmres(okry* k, const double* rhs, double* x, int restart, int maxit, do
             if (hist && nh < histcap) hist[nh++] = res;
             if (fixed_iters <= 0 && (res <= target || its >= maxit)) break;
             if (hn == 0.0) break;
+            if (g_max_seconds > 0.0 && wall() - tstart > g_max_seconds) { timed_out = 1; break; }
         }
         for (int i = j - 1; i >= 0; i--) {
             double s = g[i];
@@ -494,7 +665,7 @@ int okry_gmres(okry* k, const double* rhs, double* x, int restart, int maxit, do
         res = beta;
         if (hist && nh > 0) hist[nh - 1] = beta;
         done = fixed_iters > 0 ? its >= fixed_iters : (beta <= target || its >= maxit);
-        if (beta == 0.0) done = 1;
+        if (beta == 0.0 || timed_out) done = 1;
     }
     rc = (res0 > 0 && (res / res0 / rtol > tol_diff) && (res / atol > tol_diff)) ? 1 : 0;
 out:

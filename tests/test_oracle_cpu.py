@@ -306,3 +306,33 @@ def test_all_core_cpu_krylov_matches_the_serial_kernels_and_a_direct_solve():
     _, inf = K.gmres(rhs, restart=7, fixed_iters=20)
     assert inf["iters"] == 20
     assert K.stream_GBps(1 << 20, 2) > 0
+
+
+def test_host_node_block_ilu_matches_the_dense_block_restatement():
+    """oracle_krylov_omp.c okry_set_pc_bilu / bilu_apply (the CPU legs of bench.py and of the 200 k-cell psi parity test): the
+    level-parallel C restatement of the product's node-block ILU(0) on the structure the library's host code builds
+    (pyDASolvers.pcStructure) == the dense-block numpy restatement NodeBlockILU.solve, and GMRES with it solves the adjoint system."""
+    from common import options
+    from dafoam_amd.pyDASolvers import pyDASolvers
+
+    case = channel_case(7, 6, 5, wall_function=True)
+    g = Geometry(case.mesh)
+    sc = J.state_scales(case, g, NORM_STATES)
+    con = J.connectivity(case, g)
+    col, _ = J.greedy_coloring(con)
+    A = J.jacobian_colored(case, g, case.states, con, col, sc, mode="cs", lower_bound=0).tocsr()
+    A.sort_indices()
+    n, N = A.shape[0], g.nC
+    s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
+    S = s.pcStructure()
+    ref = OL.NodeBlockILU(A, S["nodeUnk"], S["bptr"].astype(np.int64), S["bcol"].astype(np.int64))
+    K = OL.OmpKrylov(3)
+    K.set_operator(A)
+    assert K.set_pc_bilu(A, S) == 0
+    b = np.random.default_rng(4).standard_normal(n)
+    assert relerr(K.pc_solve(b), ref.solve(b)) < 1e-11
+    rhs = np.zeros(n)
+    rhs[0 : 3 * N : 3] = g.V
+    rhs *= sc
+    x, info = K.gmres(rhs, restart=200, max_iters=400, rel_tol=1e-11)
+    assert info["fail"] == 0 and relerr(x, spla.spsolve(A.tocsc(), rhs)) < 1e-8
