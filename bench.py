@@ -346,16 +346,12 @@ def main():
     if rank == 0:
         cpu, parity = None, None
         if not a.no_cpu and world == 1:
-            try:
-                cpu = cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, spmv_ms, pc_ms)
-            except Exception as e:  # noqa: BLE001 - the baseline must never break the line
-                cpu = {"error": repr(e)[:300]}
+            cpu = _with_deadline(lambda: cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, spmv_ms, pc_ms),
+                                 float(os.environ.get("DAS_BENCH_CPU_DEADLINE", 240)), "cpu port at the bench size")
             stage(f"cpu port at the bench size: {({k: v for k, v in cpu.items() if k in ('value', 'ms_per_iteration', 'error', 'skipped')})}")
         if not a.no_parity and not a.no_cpu and world == 1:
-            try:
-                parity = psi_parity_200k(a, dev_index, case2d)
-            except Exception as e:  # noqa: BLE001
-                parity = {"error": repr(e)[:300]}
+            parity = _with_deadline(lambda: psi_parity_200k(a, dev_index, case2d), float(os.environ.get("DAS_BENCH_PARITY_DEADLINE", 420)), "psi parity leg") \
+                if not _OVERRUN else {"skipped": "the cpu port leg overran its deadline; the host is not usable for the CPU legs"}
             stage(f"psi parity leg: {({k: v for k, v in parity.items() if k in ('psi_rel_diff_gpu_vs_cpu', 'error')})}")
             if cpu is not None and parity is not None:
                 cpu["psi_rel_diff_gpu_vs_cpu"] = parity.get("psi_rel_diff_gpu_vs_cpu")
@@ -467,10 +463,51 @@ def main():
             },
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        if _OVERRUN:  # a CPU leg is still inside its C code: leave without waiting for it
+            sys.stderr.flush()
+            os._exit(0)
     if world > 1:
         dist.destroy_process_group()
     return out
+
+
+def _cpu_threads():
+    """Threads of the CPU legs: one per PHYSICAL core (half of the logical CPUs on an SMT host).  Measured (round 4): the level-parallel
+    sweeps synchronise ~10^3 times per application, and with every logical CPU occupied ONE descheduled thread turns each barrier
+    into a scheduler time slice (8-core container: 6.1 ms per apply with 8 threads, 42 ms with 9; on the 256-CPU bench host the
+    all-CPU run did not finish 12 iterations in 10 minutes)."""
+    if os.environ.get("DAS_BENCH_CPU_THREADS"):
+        return int(os.environ["DAS_BENCH_CPU_THREADS"])
+    c = os.cpu_count() or 1
+    return c // 2 if c >= 16 else max(1, c - 1)
+
+
+def _with_deadline(fn, seconds, what):
+    """Run a CPU leg in a helper thread and give up after `seconds`: the JSON line must come out whatever the host does.  The leg's
+    C code cannot be interrupted - a leg that overran keeps its thread, and main() leaves through os._exit after printing."""
+    import threading
+
+    box = {}
+
+    def run():
+        try:
+            box["out"] = fn()
+        except Exception as e:  # noqa: BLE001 - a baseline leg must never break the line
+            box["out"] = {"error": repr(e)[:300]}
+
+    th = threading.Thread(target=run, daemon=True)
+    t0 = time.time()
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        _OVERRUN.append(what)
+        return {"error": f"{what}: not finished after {time.time() - t0:.0f} s (deadline {seconds:.0f} s); last stage: {_CPU_STAGE[0]}"}
+    return box.get("out")
+
+
+_OVERRUN = []
+_CPU_STAGE = ["-"]
 
 
 def _export(L, fn, handle, n, nnz):
@@ -487,13 +524,23 @@ def _cpu_solver(L, h, ksp, pc, n, N, op_nnz, pc_nnz, threads):
     from oracle import linear as OL
 
     t0 = time.perf_counter()
+
+    def mark(what):
+        _CPU_STAGE[0] = f"{what} (+{time.perf_counter() - t0:.1f} s)"
+        stage("   cpu leg: " + _CPU_STAGE[0])
+
     K = OL.OmpKrylov(threads)
+    mark("device -> host copy of the operator")
     A = _export(L, L.das_op_export, h, n, op_nnz)
+    mark("first-touch copy of the operator")
     K.set_operator(A)
     del A
+    mark("device -> host copy of the PC matrix")
     P = _export(L, L.das_mat_export, pc.handle, n, pc_nnz)
     S = ksp.pcStructure()
+    mark("node-block ILU(0) on the host: scatter + factorisation")
     K.set_pc_bilu(P, S)
+    mark("coarse operator")
     nagg, agg = ksp.coarse(N)
     if nagg > 0 and agg.min() >= 0:
         K.set_coarse(P, 3 * N, N, agg)
@@ -518,10 +565,14 @@ def cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu_sp
         avail = 0.0
     if avail < need:
         return {"skipped": f"host MemAvailable {avail / 1e9:.0f} GB < {need / 1e9:.0f} GB"}
-    threads = int(os.environ.get("DAS_BENCH_CPU_THREADS", os.cpu_count() or 1))
+    threads = _cpu_threads()
     K, prep = _cpu_solver(L, h, ksp, pc, n, N, op_nnz, pc_nnz, threads)
+    _CPU_STAGE[0] = "host STREAM triad"
     stream = K.stream_GBps(1 << 28, 5)
+    _CPU_STAGE[0] = "GMRES pilot (4 iterations)"
     _, pilot = K.gmres(rhs_h, restart=4, fixed_iters=4)
+    stage(f"   cpu leg: pilot {pilot['seconds'] / 4 * 1e3:.0f} ms per iteration (spmv {pilot['seconds_spmv'] / 5 * 1e3:.0f}, pc {pilot['seconds_pc'] / 5 * 1e3:.0f})")
+    _CPU_STAGE[0] = "GMRES sample"
     per_it = pilot["seconds"] / 4
     iters = int(max(8, min(300, a.cpu_seconds / max(per_it, 1e-6))))
     _, inf = K.gmres(rhs_h, restart=iters, fixed_iters=iters)
@@ -590,9 +641,10 @@ def psi_parity_200k(a, dev_index, case2d=None):
     ginf = ksp.info()
     psi_gpu = x.array.copy()
     h = D.solver._h
-    threads = int(os.environ.get("DAS_BENCH_CPU_THREADS", os.cpu_count() or 1))
+    threads = _cpu_threads()
     K, prep = _cpu_solver(L, h, ksp, P, n, N, int(L.das_op_nnz(h)), int(L.das_mat_nnz(P.handle)), threads)
-    psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=a.parity_tol, abs_tol=1e-300, max_seconds=float(os.environ.get("DAS_BENCH_PARITY_CPU_SECONDS", 420)))
+    _CPU_STAGE[0] = "CPU GMRES of the parity system"
+    psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=a.parity_tol, abs_tol=1e-300, max_seconds=float(os.environ.get("DAS_BENCH_PARITY_CPU_SECONDS", 240)))
     return {"system": what, "cells": int(N), "states": int(n), "rel_tol_both": a.parity_tol,
             "gpu": {"iterations": int(ginf["iters"]), "seconds": t_gpu, "fail": int(gfail), "rel_residual": ginf["res"] / ginf["res0"] if ginf["res0"] else None},
             "cpu": {"iterations": int(cinf["iters"]), "seconds": cinf["seconds"], "fail": int(cinf["fail"]), "rel_residual": cinf["res"] / cinf["res0"] if cinf["res0"] else None,

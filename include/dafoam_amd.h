@@ -192,7 +192,9 @@ int das_calc_residuals(das_solver_t* s, int isPC, double* residuals);
 /* das_solve_primal <- solvePrimal()  pyDASolvers.pyx (DASimpleFoam::solvePrimal, DASimpleFoam.C:123-185): converge the
  * residuals of the current states.  The reference iterates SIMPLE; its fixed point is R(W) = 0, which is solved here by a
  * pseudo-transient Newton-Krylov method built from the adjoint's own kernels (forward-mode operator, transposed node-block
- * ILU + coarse space; options amd.primalTau0 / primalLinearTol / primalLinearIters / primalPCLag).  Returns 0 converged
+ * ILU + coarse space; options amd.primalTau0 / primalLinearTol / primalLinearIters / primalPCLag; pseudo-time control
+ * amd.primalTauMode "ser" | "ramp" (+ primalTauGrowth / GrowthMax / Max / Min, primalAcceptFactor, primalDampedSteps) and
+ * amd.primalPseudoTimeFields "all" | "momentum" (cold starts: the term on the transport rows only)).  Returns 0 converged
  * (|R| <= max(relTol |R0|, absTol)) / 1 not converged; info4 = {Newton steps, GMRES iterations, |R0|, |R|}. */
 int das_solve_primal(das_solver_t* s, int maxSteps, double relTol, double absTol, double* info4, double* hist, int histCap);
 int das_run_coloring(das_solver_t* s);
