@@ -473,14 +473,15 @@ def main():
 
 
 def _cpu_threads():
-    """Threads of the CPU legs: one per PHYSICAL core (half of the logical CPUs on an SMT host).  Measured (round 4): the level-parallel
-    sweeps synchronise ~10^3 times per application, and with every logical CPU occupied ONE descheduled thread turns each barrier
-    into a scheduler time slice (8-core container: 6.1 ms per apply with 8 threads, 42 ms with 9; on the 256-CPU bench host the
-    all-CPU run did not finish 12 iterations in 10 minutes)."""
+    """Threads of the CPU legs = the CPUs the process may really use (affinity AND the container's CFS quota, oracle.linear.available_cpus).
+    Measured (round 4, profiles/r05m_host_cpu.txt): the bench host shows 256 CPUs, the container's quota is 16; STREAM triad 488 GB/s
+    with 16 threads, 33-39 GB/s with 192-256 (throttled), and the level-parallel sweeps - ~2000 barriers per application - turn
+    every barrier into a scheduler time slice once more threads run than the quota pays for."""
     if os.environ.get("DAS_BENCH_CPU_THREADS"):
         return int(os.environ["DAS_BENCH_CPU_THREADS"])
-    c = os.cpu_count() or 1
-    return c // 2 if c >= 16 else max(1, c - 1)
+    from oracle.linear import available_cpus
+
+    return available_cpus()
 
 
 def _with_deadline(fn, seconds, what):

@@ -75,6 +75,33 @@ def lib_omp():
     return _lib_omp
 
 
+def available_cpus():
+    """CPUs this process may really use: the smaller of the affinity mask and the container's CFS quota (cgroup v2 `cpu.max`, v1
+    `cpu.cfs_quota_us`).  Round 4: the bench host shows 256 CPUs to a container whose quota is 16 - 128 OpenMP threads then run
+    throttled (host STREAM 68 GB/s instead of 490, every barrier a scheduler time slice); the CPU legs use this count."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, p = float(f1.read()), float(f2.read())
+                if q > 0:
+                    quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 class OmpKrylov:
     """All-core CPU solver of the adjoint system (oracle/csrc/oracle_krylov_omp.c): CSR operator with first-touch placement,
     ONE global level-scheduled scalar ILU(0) of the PC matrix in a caller-given unknown order, optional additive coarse
@@ -83,7 +110,7 @@ class OmpKrylov:
 
     def __init__(self, threads=0):
         self.L = lib_omp()
-        self.h = C.c_void_p(self.L.okry_create(int(threads)))
+        self.h = C.c_void_p(self.L.okry_create(int(threads) if int(threads) > 0 else available_cpus()))
         self.threads = int(self.L.okry_threads(self.h))
         self.n = 0
 

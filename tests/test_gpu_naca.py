@@ -105,17 +105,16 @@ def test_naca_wing_200k_cells_adjoint_in_budget_and_psi_against_the_cpu_port():
         assert fn(handle, rp.ctypes.data_as(C.POINTER(C.c_longlong)), ci.ctypes.data_as(C.POINTER(C.c_int)), v.ctypes.data_as(C.POINTER(C.c_double))) >= 0
         return rp, ci, v
 
-    ncpu = os.cpu_count() or 1
-    K = OL.OmpKrylov(ncpu // 2 if ncpu >= 16 else max(1, ncpu - 1))  # one thread per physical core: the level-parallel sweeps must never wait for a descheduled thread
+    K = OL.OmpKrylov(OL.available_cpus())  # affinity AND cgroup quota: more threads than the container is paid for run throttled
     K.set_operator(export(L.das_op_export, h, int(L.das_op_nnz(h))))
     Pm = export(L.das_mat_export, P.handle, int(L.das_mat_nnz(P.handle)))
     K.set_pc_bilu(Pm, ksp.pcStructure())  # the node-block ILU(0) restated for the host, same structure and PC matrix
     nagg, agg = ksp.coarse(N)
     if nagg > 0:
         K.set_coarse(Pm, 3 * N, N, agg)
-    psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=1e-10, abs_tol=1e-300, max_seconds=420.0)
+    psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=1e-10, abs_tol=1e-300, max_seconds=240.0)
     print("CPU port:", cinf["iters"], "iterations,", round(cinf["seconds"], 1), "s on", K.threads, "threads; levels", K.levels, "rel", cinf["res"] / cinf["res0"])
-    if cinf["res"] > 1e-10 * cinf["res0"] and cinf["seconds"] >= 420.0:
+    if cinf["res"] > 1e-10 * cinf["res0"] and cinf["seconds"] >= 240.0:
         pytest.skip(f"the host did not finish the independent CPU solve inside its time bound ({cinf['iters']} iterations, rel {cinf['res'] / cinf['res0']:.1e}); bench.py reports the same check")
     assert cinf["fail"] == 0
     err = np.linalg.norm(psi_gpu - psi_cpu) / np.linalg.norm(psi_cpu)
