@@ -121,21 +121,31 @@ def test_coloring_watchdog_switches_to_the_order_independent_algorithm_on_an_ogr
 
     case = naca0012_case(360, 90, 1)
     monkeypatch.setenv("DAS_COLOR_LIMIT", "0.05")
-    D = make(case)
+    ff = {"coloringAlgorithm": "firstfit"}  # round 4: the default "auto" would not launch the first-fit on this numbering at all (below)
+    D = make(case, amd=ff)
     D.solver.runColoring()
     err = capfd.readouterr().err
     assert "first-fit colouring stopped" in err, err[-2000:]
     cs, ns = D.solver.getColoring()
     assert cs.min() >= 0 and ns == cs.max() + 1
     assert J.validate_coloring(D.solver.getConnectivity(0), cs.astype(np.int64))
-    D2 = make(case)
+    D2 = make(case, amd=ff)
     D2.solver.runColoring()
     assert np.array_equal(D2.solver.getColoring()[0], cs)
     monkeypatch.delenv("DAS_COLOR_LIMIT")
-    Df = make(case)  # without the limit: the serial first-fit finishes (a small mesh) with fewer colours
+    Df = make(case, amd=ff)  # without the limit: the serial first-fit finishes (a small mesh) with fewer colours
     Df.solver.runColoring()
     nf = Df.solver.getColoring()[1]
     assert nf <= ns <= 1.35 * nf + 8, (ns, nf)
+    # round 4, amd.coloringAlgorithm "auto" (the default): the dependency depth of this numbering (one chain through all 32400
+    # cells) is estimated before the launch and the speculative rounds run at once - no watchdog, a valid colouring of about the
+    # same size
+    Da = make(case)
+    Da.solver.runColoring()
+    err = capfd.readouterr().err
+    assert "first-fit colouring stopped" not in err
+    ca, na = Da.solver.getColoring()
+    assert J.validate_coloring(Da.solver.getConnectivity(0), ca.astype(np.int64)) and nf <= na <= 1.35 * nf + 8, (na, nf)
     # a.(J v) == (J^T a).v with J^T assembled through the fallback colouring
     n = case.states.size
     rng = np.random.default_rng(1)
