@@ -2771,13 +2771,14 @@ static int run_newton_primal(das_solver* s, int maxSteps, double relTol, double 
     const double serExp = s->opt.getd("amd.primalSERExponent");
     const long long linIters = s->opt.geti("amd.primalLinearIters");
     const bool ramp = s->opt.gets("amd.primalTauMode") == "ramp";
-    // WHERE the pseudo-time term acts.  "momentum" (default): on the transported cell fields (U, T, nuTilda) only - implicit
-    // under-relaxation of the transport equations, the pressure and the face fluxes follow algebraically, as in a coupled
-    // pressure-based solver.  "all" (round 2): every row.  Measured with the host-emulated kernel bodies and exact Jacobians on
-    // the NACA0012 O-grid (round 4): with the term on the pressure rows the pseudo-time evolution itself is UNSTABLE beyond
-    // tau ~ 3 (a disturbance grows ~1.3x per step until it explodes; with the line search the residual just wanders), without
-    // it the residual falls monotonically while tau ramps up.  Starts close to the solution (the prolonged channel state) do
-    // not notice the difference: tau is large after a few steps.
+    // WHERE the pseudo-time term acts (amd.primalPseudoTimeFields).  "all" (default, round 2): every row.  "momentum": the transported
+    // cell fields (U, T, nuTilda) only - implicit under-relaxation of the transport equations, the pressure and the face fluxes follow
+    // algebraically, as in a coupled pressure-based solver.  Measured with the host-emulated kernel bodies and exact Jacobians on the
+    // NACA0012 O-grid (round 4, tools/naca_newton_cpu_twin.py): from a COLD start the term on the pressure rows makes the pseudo-time
+    // evolution itself unstable beyond tau ~ 3 (a disturbance grows ~1.3x per step until it explodes; with the line search the
+    // residual just wanders), without it the residual falls monotonically while tau ramps up.  From a start CLOSE to the solution (a
+    // prolonged coarse solution) it is the other way round: "all" + switched evolution relaxation crosses the unstable range in a
+    // few steps, the unshifted pressure rows of "momentum" make every small-tau system as hard as the tau = inf one.
     const bool ptMomentum = s->opt.gets("amd.primalPseudoTimeFields") == "momentum";
     long long pLo = 0, pHi = 0, phiLo = (long long)1 << 62;
     for (const StateDef& q : s->st_full.states) {
