@@ -40,7 +40,7 @@ def test_strong_scaling_bench_flow_one_and_two_ranks():
         c = d["config"]
         assert d["scaling"] == "strong" and d["n_gpus"] == n and d["steps"] == 10
         assert c["global_cells"] == 80 * 24 * 16 and c["cells_per_gpu"] * n == c["global_cells"]
-        assert c["solve"]["fail"] == 0 and c["solve"]["rel_residual"] <= 1e-6
+        assert c["solve"]["fail"] == 0 and c["solve"]["rel_residual"] <= 2e-6
         assert d["value"] > 0 and d["roofline"]["frac"] > 0
     assert d2["config"]["halo_ms"] is not None
     # the same global problem: the 2-rank solve (block-Jacobi ILU across ranks + ONE global coarse space) needs a comparable count
