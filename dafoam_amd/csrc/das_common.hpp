@@ -1,6 +1,10 @@
 // Shared declarations of the MI355X-native adjoint hot path (host side).
 #pragma once
+#include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
+#include <omp.h>
+#include <sched.h>
 #include <mutex>
 #include <thread>
 #include <hip/hip_runtime.h>
@@ -36,6 +40,38 @@ struct Error : std::runtime_error {
     do {                                              \
         if (!(cond)) throw das::Error((code), (msg)); \
     } while (0)
+
+// ---- host threads ---------------------------------------------------------------------------
+// CPUs this process may really use: the affinity mask AND the container's CFS quota (cgroup v2 cpu.max, v1 cpu.cfs_quota_us).  The
+// round-4 bench host shows 256 CPUs to a container whose quota is 16: OpenMP regions with 256 threads then run throttled (host
+// STREAM 33 GB/s instead of 488, profiles/r05m_host_cpu.txt).  das_create caps the OpenMP team size of the host phases (connectivity
+// pattern, prune, structure builders) to this number once per process.
+inline int usable_host_cpus() {
+    int n = omp_get_num_procs();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, c); }
+    double quota = -1.0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0}; double per = 0.0;
+        if (fscanf(f, "%63s %lf", q, &per) == 2 && std::string(q) != "max" && per > 0.0) quota = atof(q) / per;
+        fclose(f);
+    } else {
+        double q = -1.0, per = 0.0;
+        if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f1, "%lf", &q) != 1) q = -1.0; fclose(f1); }
+        if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lf", &per) != 1) per = 0.0; fclose(f2); }
+        if (q > 0.0 && per > 0.0) quota = q / per;
+    }
+    if (quota > 0.0) n = std::min(n, std::max(1, (int)(quota + 0.5)));
+    return std::max(1, n);
+}
+inline void cap_host_threads_once() {
+    static std::once_flag once;
+    std::call_once(once, []() {
+        if (getenv("DAS_KEEP_OMP_THREADS")) return;
+        const int u = usable_host_cpus();
+        if (omp_get_max_threads() > u) omp_set_num_threads(u);
+    });
+}
 
 // ---- device buffer -------------------------------------------------------------------------
 // mapped virtual ranges of released VmBufs (never unmapped; see VmBuf::release)

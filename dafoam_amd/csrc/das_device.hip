@@ -2921,6 +2921,7 @@ int das_device_count(void) {
 das_solver_t* das_create(const das_case_t* c) {
     try {
         DAS_CHECK(c, DAS_ERR_ARG, "null case");
+        cap_host_threads_once();  // OpenMP teams of the host phases: no more threads than the container's CPU quota pays for
         std::unique_ptr<das_solver> s(new das_solver);
         s->t0_wall = wall_seconds();
         s->t0_cpu = std::clock();

@@ -876,7 +876,7 @@ def naca_normal_distribution(ny, first_cell=2.0e-5, radius=20.0):
 
 
 def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first_cell=2.0e-5, U0=10.0, aoa_deg=2.0, nu=1.5e-5, nuTilda0=4.5e-5,
-                  wall_function=False, seed=0, perturb=0.02) -> FoamCase:
+                  wall_function=False, seed=0, perturb=0.02, y_wall_section=None) -> FoamCase:
     """DASimpleFoam + SA around a NACA0012 (chord 1) on a single-block O-grid of n_around x n_normal x nz hexahedra, extruded
     `span` in z with symmetry front/back (the reference's 2-D airfoil cases use one cell and `empty`/symmetry sides,
     tests/runRegTests_AeroOpt.py).  Wall-normal geometric stretching from `first_cell` (y+ ~ 1 at Re 6.7e5) to the far
@@ -969,7 +969,13 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
         mesh.face_pts = np.ascontiguousarray(allq[:, ::-1].ravel())
         g = _InputGeometry(mesh)
     assert np.all(g.V > 0) and np.all(np.einsum("ij,ij->i", g.Sf[:nIF], g.C[mesh.neighbour] - g.C[mesh.owner[:nIF]]) > 0)
-    y = wall_distance_exact(mesh, g.C, g.Cf, g.Sf)
+    # frozen wall distance: of an extrusion it is the section's, layer by layer (the symmetry planes are no walls) - `y_wall_section`
+    # (n_around * n_normal values of the one-layer case) saves the nearest-wall search over all cells of the extruded mesh
+    if y_wall_section is not None:
+        assert len(y_wall_section) == nx * ny
+        y = np.tile(np.asarray(y_wall_section, dtype=float), nz)
+    else:
+        y = wall_distance_exact(mesh, g.C, g.Cf, g.Sf)
     a = np.deg2rad(aoa_deg)
     Uinf = np.array([U0 * np.cos(a), U0 * np.sin(a), 0.0])
     wall_nut = NUT_SPALDING_WALL if wall_function else NUT_LOWRE_WALL
@@ -998,6 +1004,7 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
     phi[sl["farfield"]] = np.einsum("ij,ij->i", U[ownF[sl["farfield"]]], g.Sf[sl["farfield"]])
     case = FoamCase(mesh=mesh, solver_name="DASimpleFoam", nu=nu, bcs=bcs, y_wall=y)
     case.states = np.concatenate([U.ravel(), p, nuT, phi])
+    case._input_geometry = g  # reused by extrude_naca_state / naca_fluxes_from_velocity (a second pass over 6 M faces costs seconds)
     return case
 
 
@@ -1005,7 +1012,7 @@ def naca_fluxes_from_velocity(case: FoamCase, U):
     """phi of every face from cell velocities: linear interpolation on internal faces, the boundary value of the patch
     condition on the rest (wall 0, far field: the owner cell / free stream by flow direction, symmetry 0)."""
     mesh = case.mesh
-    g = _InputGeometry(mesh)
+    g = getattr(case, "_input_geometry", None) or _InputGeometry(mesh)
     nIF, F = mesh.n_internal_faces, mesh.n_faces
     own, nei = mesh.owner, mesh.neighbour
     phi = np.zeros(F)
@@ -1067,7 +1074,8 @@ def extrude_naca_state(case2d: FoamCase, states2d, case3d: FoamCase, dims):
     U = np.tile(W2[: 3 * N2].reshape(N2, 3), (nz, 1))
     p, nuT = np.tile(W2[3 * N2 : 4 * N2], nz), np.tile(W2[4 * N2 : 5 * N2], nz)
     phi2 = W2[5 * N2 :]
-    g2, g3 = _InputGeometry(m2), _InputGeometry(m3)
+    g2 = getattr(case2d, "_input_geometry", None) or _InputGeometry(m2)
+    g3 = getattr(case3d, "_input_geometry", None) or _InputGeometry(m3)
     a2, a3 = np.linalg.norm(g2.Sf, axis=1), np.linalg.norm(g3.Sf, axis=1)
     nIF2, nIF3 = m2.n_internal_faces, m3.n_internal_faces
     phi3 = np.zeros(m3.n_faces)

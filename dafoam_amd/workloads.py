@@ -75,7 +75,7 @@ def naca_extruded_case(case2d, dims2d, nz, dz=0.1, first_cell=2.0e-5, options=No
     ckw = dict(case_kwargs or {})
     ckw.setdefault("perturb", 0.0)
     t0 = time.time()
-    case3 = naca0012_case(nx, ny, nz, span=dz * nz, first_cell=first_cell, **ckw)
+    case3 = naca0012_case(nx, ny, nz, span=dz * nz, first_cell=first_cell, y_wall_section=case2d.y_wall, **ckw)
     case3.states = extrude_naca_state(case2d, case2d.states, case3, (nx, ny, nz))
     info = dict(dims=(nx, ny, nz), steps=0, seconds=0.0)
     if polish_steps > 0:
