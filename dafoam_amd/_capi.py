@@ -263,6 +263,10 @@ _SIGS = {
     "das_ksp_get_info": (C.c_int, [_VP, c_int_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_get_history": (C.c_int, [_VP, c_double_p, C.c_int]),
     "das_ksp_get_n_refine": (C.c_int, [_VP]),
+    "das_set_dense_eig_callback": (C.c_int, [_VP]),
+    "das_debug_gmres_dr_host": (C.c_int, [C.c_longlong, _VP, _VP, _VP, c_double_p, c_double_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_longlong, c_double_p, C.c_int,
+                                          c_double_p, c_double_p]),
+    "das_debug_gmres_dr_restart": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_get_status": (C.c_int, [_VP, c_int_p, c_int_p, c_int_p, c_int_p]),
     "das_ksp_get_coarse": (C.c_int, [_VP, c_int_p]),
     "das_ksp_set_global_coarse": (C.c_int, [_VP, _VP, C.c_int, C.c_int, c_int_p]),
@@ -312,7 +316,33 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        _install_dense_eig(L)
     return _lib
+
+
+_DENSE_EIG_FN = C.CFUNCTYPE(C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p)
+_dense_eig_keepalive = []
+
+
+def _install_dense_eig(L):
+    """The dense nonsymmetric eigen-solver of the deflated restart (amd.gmresDeflation): numpy.linalg.eig behind the callback the
+    C-ABI asks for (the library itself carries no LAPACK; a C host would pass LAPACK's dgeev the same way)."""
+
+    def eig(m, A, wr, wi, vr, vi):
+        try:
+            G = np.ctypeslib.as_array(A, shape=(m * m,)).reshape(m, m)
+            w, v = np.linalg.eig(G)
+            np.ctypeslib.as_array(wr, shape=(m,))[:] = w.real
+            np.ctypeslib.as_array(wi, shape=(m,))[:] = w.imag
+            np.ctypeslib.as_array(vr, shape=(m * m,))[:] = np.ascontiguousarray(v.T.real).ravel()
+            np.ctypeslib.as_array(vi, shape=(m * m,))[:] = np.ascontiguousarray(v.T.imag).ravel()
+            return 0
+        except Exception:  # noqa: BLE001 - never raise through the C boundary
+            return 1
+
+    cb = _DENSE_EIG_FN(eig)
+    _dense_eig_keepalive.append(cb)
+    L.das_set_dense_eig_callback(C.cast(cb, C.c_void_p))
 
 
 class DASError(RuntimeError):

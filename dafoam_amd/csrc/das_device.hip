@@ -2509,7 +2509,369 @@ static int gmres_end(das_solver* s, das_ksp* k) {
     return (relRatio > diff && absRatio > diff) ? 1 : 0;
 }
 
+// ---- GMRES with deflated restarting (opt-in: amd.gmresDeflation = k > 0; Morgan, SIAM J. Sci. Comput. 24 (2002) "GMRES-DR") ------------
+// A restart of length m (adjEqnOption.gmresRestart) keeps the k harmonic Ritz vectors of smallest magnitude: the next cycle starts from
+// the (k+1)-dimensional subspace span{harmonic Ritz vectors, residual}, for which an Arnoldi-like relation A M^-1 V_k = V_{k+1} Hbar_k
+// holds with a DENSE leading block, and continues Arnoldi from there.  Why (round 4, CPU prototype tools/gmres_dr_study.py): the residual
+// history of the airfoil adjoint is a plateau of hundreds of iterations followed by a fast drop - plain restarting inside the plateau
+// stalls (GMRES(100): 0.81 after 1500 iterations where full GMRES needs 302), deflated restarting needs 354-379 with 101-151 basis
+// vectors.  The basis is what limits the mesh size on one GPU (1000 vectors = 125 GB at 2 M cells).  Reference role: PETSc offers the
+// same idea as KSPDGMRES; the reference's default stays the undeflated solver, and so does this library's.
+// Orthogonalisation: classical Gram-Schmidt, always two passes.  The dense eigenproblem of the m x m harmonic matrix is solved through a
+// callback (das_set_dense_eig_callback; the Python mirror installs numpy.linalg.eig) - the library carries no LAPACK.
+typedef int (*das_dense_eig_fn)(int m, const double* A_rowmajor, double* wr, double* wi, double* vr_colmajor, double* vi_colmajor);
+static das_dense_eig_fn g_dense_eig = nullptr;
+
+namespace {
+// least-squares bookkeeping of min |c - Hbar y|: Qt (accumulated rotations), R = Qt Hbar, gt = Qt c
+struct DrLsq {
+    int m = 0;
+    std::vector<double> Qt, R, gt;
+    void reset(int m_, const std::vector<double>& c) {
+        m = m_;
+        Qt.assign((size_t)(m + 1) * (m + 1), 0.0);
+        for (int i = 0; i <= m; i++) Qt[(size_t)i * (m + 1) + i] = 1.0;
+        R.assign((size_t)(m + 1) * m, 0.0);
+        gt = c;
+    }
+    // append column `col` of Hbar whose entries 0..nr-1 may be non-zero; eliminates everything below the diagonal
+    double add_column(int col, int nr, const double* h) {
+        const int ld = m + 1;
+        std::vector<double> t(nr, 0.0);
+        for (int i = 0; i < nr; i++) { double a = 0.0; for (int q = 0; q < nr; q++) a += Qt[(size_t)i * ld + q] * h[q]; t[i] = a; }
+        for (int r = nr - 1; r > col; r--) {  // rotate rows (r-1, r) so that t[r] = 0
+            const double a = t[r - 1], b = t[r];
+            const double d = std::hypot(a, b);
+            if (d == 0.0) continue;
+            const double cc = a / d, ss = b / d;
+            t[r - 1] = d; t[r] = 0.0;
+            for (int q = 0; q < nr; q++) {
+                const double x = Qt[(size_t)(r - 1) * ld + q], y = Qt[(size_t)r * ld + q];
+                Qt[(size_t)(r - 1) * ld + q] = cc * x + ss * y; Qt[(size_t)r * ld + q] = -ss * x + cc * y;
+            }
+            // (earlier columns of R are zero in rows >= col: nothing to rotate there; later columns do not exist yet)
+            const double gx = gt[r - 1], gy = gt[r];
+            gt[r - 1] = cc * gx + ss * gy; gt[r] = -ss * gx + cc * gy;
+        }
+        for (int i = 0; i < nr; i++) R[(size_t)i * m + col] = t[i];
+        return std::fabs(gt[col + 1]);
+    }
+    void solve(int j, std::vector<double>& y) const {
+        y.assign(j, 0.0);
+        for (int i = j - 1; i >= 0; i--) {
+            double a = gt[i];
+            for (int q = i + 1; q < j; q++) a -= R[(size_t)i * m + q] * y[q];
+            y[i] = a / R[(size_t)i * m + i];
+        }
+    }
+};
+// dense LU solve (partial pivoting) of A^T f = e_last, A row-major n x n (destroyed)
+static bool dr_solve_transposed_last(int n, std::vector<double> A, std::vector<double>& f) {
+    // work on T = A^T
+    std::vector<double> T((size_t)n * n);
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) T[(size_t)i * n + j] = A[(size_t)j * n + i];
+    f.assign(n, 0.0); f[n - 1] = 1.0;
+    for (int c = 0; c < n; c++) {
+        int p = c; double best = std::fabs(T[(size_t)c * n + c]);
+        for (int r = c + 1; r < n; r++) if (std::fabs(T[(size_t)r * n + c]) > best) { best = std::fabs(T[(size_t)r * n + c]); p = r; }
+        if (best == 0.0) return false;
+        if (p != c) { for (int q = 0; q < n; q++) std::swap(T[(size_t)c * n + q], T[(size_t)p * n + q]); std::swap(f[c], f[p]); }
+        for (int r = c + 1; r < n; r++) {
+            const double l = T[(size_t)r * n + c] / T[(size_t)c * n + c];
+            if (l == 0.0) continue;
+            for (int q = c; q < n; q++) T[(size_t)r * n + q] -= l * T[(size_t)c * n + q];
+            f[r] -= l * f[c];
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double a = f[i];
+        for (int q = i + 1; q < n; q++) a -= T[(size_t)i * n + q] * f[q];
+        f[i] = a / T[(size_t)i * n + i];
+    }
+    return true;
+}
+}  // namespace
+
+// host part of a deflated restart (also exported for the CPU tier: das_debug_gmres_dr_restart).  In: Hbar ((m+1) x m row-major), the
+// residual vector rvec = c - Hbar y in the basis V_{m+1}, the wanted k.  Out: kk (k or k +- 1: a complex pair is never split), P1
+// ((m+1) x (kk+1) row-major, orthonormal columns: the new basis is V P1), Hnew ((kk+1) x kk row-major), cnew (kk+1).
+static int gmres_dr_restart_host(int m, int k, const std::vector<double>& Hb, const std::vector<double>& rvec, int& kk, std::vector<double>& P1,
+                                 std::vector<double>& Hnew, std::vector<double>& cnew) {
+    DAS_CHECK(g_dense_eig, DAS_ERR_STATE, "amd.gmresDeflation needs a dense eigen-solver callback (das_set_dense_eig_callback; the Python mirror installs numpy's)");
+    std::vector<double> Hm((size_t)m * m), f;
+    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Hm[(size_t)i * m + j] = Hb[(size_t)i * m + j];
+    if (!dr_solve_transposed_last(m, Hm, f)) return -1;
+    const double h2 = Hb[(size_t)m * m + (m - 1)] * Hb[(size_t)m * m + (m - 1)];
+    std::vector<double> Gm = Hm;
+    for (int i = 0; i < m; i++) Gm[(size_t)i * m + (m - 1)] += h2 * f[i];
+    std::vector<double> wr(m), wi(m), vr((size_t)m * m), vi((size_t)m * m);
+    if (g_dense_eig(m, Gm.data(), wr.data(), wi.data(), vr.data(), vi.data()) != 0) return -1;
+    std::vector<int> idx(m);
+    for (int i = 0; i < m; i++) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { const double ma = std::hypot(wr[a], wi[a]), mb = std::hypot(wr[b], wi[b]); return ma < mb || (ma == mb && a < b); });
+    // real basis of the invariant subspace of the k smallest harmonic Ritz values; a conjugate pair contributes (Re v, Im v) once
+    std::vector<std::vector<double>> cols;
+    std::vector<char> used(m, 0);
+    for (int q = 0; q < m && (int)cols.size() < k; q++) {
+        const int e = idx[q];
+        if (used[e]) continue;
+        used[e] = 1;
+        std::vector<double> re(m), im(m);
+        double imax = 0.0;
+        for (int i = 0; i < m; i++) { re[i] = vr[(size_t)e * m + i]; im[i] = vi[(size_t)e * m + i]; imax = std::max(imax, std::fabs(im[i])); }
+        cols.push_back(re);
+        if (std::fabs(wi[e]) > 0.0 && imax > 0.0) {
+            cols.push_back(im);
+            for (int q2 = q + 1; q2 < m; q2++) {  // its conjugate is the same two vectors
+                const int e2 = idx[q2];
+                if (!used[e2] && wr[e2] == wr[e] && wi[e2] == -wi[e]) { used[e2] = 1; break; }
+            }
+        }
+    }
+    kk = (int)cols.size();
+    if (kk > m - 1) { cols.resize(m - 1); kk = m - 1; }
+    // orthonormalise (modified Gram-Schmidt, twice) -> Pk (m x kk); drop numerically dependent columns
+    std::vector<std::vector<double>> Q;
+    for (auto& v : cols) {
+        for (int pass = 0; pass < 2; pass++)
+            for (auto& q : Q) { double d = 0.0; for (int i = 0; i < m; i++) d += q[i] * v[i]; for (int i = 0; i < m; i++) v[i] -= d * q[i]; }
+        double nv = 0.0; for (int i = 0; i < m; i++) nv += v[i] * v[i];
+        nv = std::sqrt(nv);
+        if (!(nv > 1e-10)) continue;
+        for (int i = 0; i < m; i++) v[i] /= nv;
+        Q.push_back(v);
+    }
+    kk = (int)Q.size();
+    if (kk == 0) return -1;
+    // P1 = [ [Pk; 0], rvec orthogonalised against it and normalised ]
+    P1.assign((size_t)(m + 1) * (kk + 1), 0.0);
+    for (int c = 0; c < kk; c++) for (int i = 0; i < m; i++) P1[(size_t)i * (kk + 1) + c] = Q[c][i];
+    std::vector<double> rv = rvec;
+    for (int pass = 0; pass < 2; pass++)
+        for (int c = 0; c < kk; c++) { double d = 0.0; for (int i = 0; i < m; i++) d += Q[c][i] * rv[i]; for (int i = 0; i < m; i++) rv[i] -= d * Q[c][i]; }
+    double nr = 0.0; for (int i = 0; i <= m; i++) nr += rv[i] * rv[i];
+    nr = std::sqrt(nr);
+    if (!(nr > 0.0)) return -1;
+    for (int i = 0; i <= m; i++) P1[(size_t)i * (kk + 1) + kk] = rv[i] / nr;
+    // Hnew = P1^T Hbar Pk, cnew = P1^T rvec
+    std::vector<double> HP((size_t)(m + 1) * kk, 0.0);
+    for (int i = 0; i <= m; i++) for (int c = 0; c < kk; c++) { double a = 0.0; for (int q = 0; q < m; q++) a += Hb[(size_t)i * m + q] * Q[c][q]; HP[(size_t)i * kk + c] = a; }
+    Hnew.assign((size_t)(kk + 1) * kk, 0.0);
+    for (int r = 0; r <= kk; r++) for (int c = 0; c < kk; c++) { double a = 0.0; for (int i = 0; i <= m; i++) a += P1[(size_t)i * (kk + 1) + r] * HP[(size_t)i * kk + c]; Hnew[(size_t)r * kk + c] = a; }
+    cnew.assign(kk + 1, 0.0);
+    for (int r = 0; r <= kk; r++) { double a = 0.0; for (int i = 0; i <= m; i++) a += P1[(size_t)i * (kk + 1) + r] * rvec[i]; cnew[r] = a; }
+    return 0;
+}
+
+// The iteration itself, written once over a small set of vector operations (Ops): the device solver below and the host twin of the CPU
+// tier (das_debug_gmres_dr_host) run THIS loop - what the CPU tests check is what the GPU executes, up to the kernels behind Ops, all of
+// which the undeflated solver already uses.  Ops: n; start(beta) [v_0 = r / beta]; arnoldi(j, h, ww, hn) [w = A M^-1 v_j orthogonalised
+// against v_0..v_j by two classical Gram-Schmidt passes: h[0..j] the summed coefficients, ww = |A M^-1 v_j|^2, hn = |w| afterwards,
+// v_{j+1} = w / hn if hn > 0]; update(j, y) [x += M^-1 (V_j y)]; true_residual() [r = b - A x, returns |r|]; compress(m, kk, P1)
+// [V[:, 0..kk] = V[:, 0..m] P1].
+struct DrResult { long long its = 0; double res0 = 0, res = 0; int nBreakdown = 0, nRestarts = 0, nDeflated = 0; };
+template <class Ops>
+static DrResult gmres_dr_loop(Ops& ops, int m, int kdef, double beta0, double target, long long maxIts, std::vector<double>& hist) {
+    DrResult out;
+    out.res0 = beta0;
+    kdef = std::max(1, std::min(kdef, m - 2));
+    std::vector<double> Hb((size_t)(m + 1) * m, 0.0), c(m + 1, 0.0), y, rvec(m + 1), hcol(m + 2), h(m + 2), P1, Hnew, cnew;
+    DrLsq L;
+    int j0 = 0;  // vectors 0..j0 of the basis and the leading (j0+1) x j0 block of Hbar are in place
+    bool first = true;
+    double beta = beta0;
+    while (beta > target && out.its < maxIts) {
+        if (first) {
+            ops.start(beta);
+            std::fill(Hb.begin(), Hb.end(), 0.0);
+            std::fill(c.begin(), c.end(), 0.0);
+            c[0] = beta;
+            j0 = 0;
+            first = false;
+        }
+        L.reset(m, c);
+        for (int col = 0; col < j0; col++) {  // the dense block carried over the restart
+            for (int i = 0; i <= j0; i++) hcol[i] = Hb[(size_t)i * m + col];
+            L.add_column(col, j0 + 1, hcol.data());
+        }
+        int j = j0;
+        double res = beta;
+        for (; j < m && out.its < maxIts;) {
+            double ww = 0.0, hn = 0.0;
+            ops.arnoldi(j, h.data(), ww, hn);
+            if (!(hn > GMRES_BREAKDOWN_TOL * std::sqrt(std::max(ww, 0.0)))) { hn = 0.0; out.nBreakdown++; }
+            for (int i = 0; i <= j; i++) { hcol[i] = h[i]; Hb[(size_t)i * m + j] = h[i]; }
+            hcol[j + 1] = hn; Hb[(size_t)(j + 1) * m + j] = hn;
+            res = L.add_column(j, j + 2, hcol.data());
+            out.its++;
+            hist.push_back(res);
+            j++;
+            if (res <= target || hn == 0.0) break;
+        }
+        L.solve(j, y);
+        ops.update(j, y.data());
+        beta = ops.true_residual();  // one operator product per cycle: the recurrence is checked against it
+        hist.back() = beta;
+        if (beta <= target || out.its >= maxIts) break;
+        const bool recurrenceOk = std::fabs(res - beta) <= 1e-6 * beta0 + 1e-3 * beta;
+        if (j < m || !recurrenceOk) { first = true; out.nRestarts++; continue; }  // breakdown / early exit / drifted recurrence: plain restart
+        // ---- deflated restart: rvec = c - Hbar y, harmonic Ritz vectors, compression of the basis
+        for (int i = 0; i <= m; i++) { double a = c[i]; for (int q = 0; q < m; q++) a -= Hb[(size_t)i * m + q] * y[q]; rvec[i] = a; }
+        int kk = 0;
+        if (gmres_dr_restart_host(m, kdef, Hb, rvec, kk, P1, Hnew, cnew) != 0) { first = true; out.nRestarts++; continue; }
+        ops.compress(m, kk, P1.data());
+        std::fill(Hb.begin(), Hb.end(), 0.0);
+        for (int r = 0; r <= kk; r++) for (int q = 0; q < kk; q++) Hb[(size_t)r * m + q] = Hnew[(size_t)r * kk + q];
+        std::fill(c.begin(), c.end(), 0.0);
+        for (int r = 0; r <= kk; r++) c[r] = cnew[r];
+        j0 = kk;
+        out.nDeflated++;
+    }
+    out.res = beta;
+    return out;
+}
+
+namespace {
+struct DrDeviceOps {
+    das_solver* s; das_ksp* k; GmresRun* G; int kdefMax;
+    DevBuf<double> scratch, Cdev;
+    void start(double beta) {
+        hipLaunchKernelGGL(k_scale_to, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, 1.0 / beta, k->r.p, k->V.p);
+    }
+    void arnoldi(int j, double* h, double& ww, double& hn) {
+        const long long n = s->n;
+        hipStream_t st = s->stream;
+        pc_apply_full(s, k, k->V.p + (long long)j * n, k->z.p);
+        apply_operator(s, k->z.p, k->w.p);
+        multidot(s, k, j + 1, k->w.p, G->hh.data());
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
+        multidot(s, k, j + 1, k->w.p, G->h2.data());
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
+        double hn2 = 0.0;
+        multidot(s, k, 0, k->w.p, &hn2);
+        k->nrefine++;
+        for (int i = 0; i <= j; i++) h[i] = G->hh[i] + G->h2[i];
+        ww = G->hh[j + 1];
+        hn = std::sqrt(std::max(hn2, 0.0));
+        if (hn > GMRES_BREAKDOWN_TOL * std::sqrt(std::max(ww, 0.0)))
+            hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, st, n, 1.0 / hn, k->w.p, k->V.p + (long long)(j + 1) * n);
+    }
+    void update(int j, const double* y) {
+        const long long n = s->n;
+        hipStream_t st = s->stream;
+        DAS_HIP(hipMemcpyAsync(k->hdev.p, y, j * sizeof(double), hipMemcpyHostToDevice, st));
+        DAS_HIP(hipStreamSynchronize(st));  // y is the caller's host vector
+        hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, k->V.p, n, k->hdev.p, k->w.p);
+        pc_apply_full(s, k, k->w.p, k->z.p);
+        hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, st, n, 1.0, k->z.p, 1.0, G->d_x);
+    }
+    double true_residual() { gmres_true_residual(s, k, *G, true); return G->beta; }
+    void compress(int m, int kk, const double* P1) {
+        const long long n = s->n;
+        hipStream_t st = s->stream;
+        if (scratch.n < (size_t)(kk + 1) * n) scratch.alloc((size_t)(kdefMax + 2) * n);
+        if (Cdev.n < (size_t)(m + 1) * 8) Cdev.alloc((size_t)(m + 1) * 8);
+        std::vector<double> Cblk;
+        for (int c0 = 0; c0 <= kk; c0 += 8) {  // Vnew[:, c0 : c0 + sv) = V[:, 0 : m + 1) P1[:, c0 : c0 + sv)
+            const int sv = std::min(8, kk + 1 - c0);
+            Cblk.assign((size_t)(m + 1) * sv, 0.0);
+            for (int i = 0; i <= m; i++) for (int r = 0; r < sv; r++) Cblk[(size_t)i * sv + r] = P1[(size_t)i * (kk + 1) + c0 + r];
+            DAS_HIP(hipMemcpyAsync(Cdev.p, Cblk.data(), Cblk.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_block_lincomb, dim3(nblk(n, 256)), dim3(256), 0, st, n, m + 1, sv, k->V.p, n, Cdev.p, scratch.p + (long long)c0 * n, n);
+            DAS_HIP(hipStreamSynchronize(st));  // Cblk / Cdev are reused by the next group
+        }
+        DAS_HIP(hipMemcpyAsync(k->V.p, scratch.p, (size_t)(kk + 1) * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+};
+// host twin of the vector operations (CPU tier): operator and preconditioner through callbacks, plain loops
+typedef void (*das_host_apply_fn)(const double* x, double* y, void* user);
+struct DrHostOps {
+    long long n; das_host_apply_fn A, M; void* user;
+    const double* b; double* x;
+    std::vector<double> V, w, z, r;
+    int m;
+    void start(double beta) { for (long long i = 0; i < n; i++) V[i] = r[i] / beta; }
+    void arnoldi(int j, double* h, double& ww, double& hn) {
+        M(V.data() + (size_t)j * n, z.data(), user);
+        A(z.data(), w.data(), user);
+        ww = 0.0; for (long long i = 0; i < n; i++) ww += w[i] * w[i];
+        std::vector<double> h1(j + 1), h2(j + 1);
+        for (int pass = 0; pass < 2; pass++) {
+            std::vector<double>& hp = pass ? h2 : h1;
+            for (int q = 0; q <= j; q++) { double a = 0.0; const double* v = V.data() + (size_t)q * n; for (long long i = 0; i < n; i++) a += v[i] * w[i]; hp[q] = a; }
+            for (int q = 0; q <= j; q++) { const double* v = V.data() + (size_t)q * n; for (long long i = 0; i < n; i++) w[i] -= hp[q] * v[i]; }
+        }
+        for (int q = 0; q <= j; q++) h[q] = h1[q] + h2[q];
+        double a = 0.0; for (long long i = 0; i < n; i++) a += w[i] * w[i];
+        hn = std::sqrt(a);
+        if (hn > GMRES_BREAKDOWN_TOL * std::sqrt(ww)) for (long long i = 0; i < n; i++) V[(size_t)(j + 1) * n + i] = w[i] / hn;
+    }
+    void update(int j, const double* y) {
+        std::fill(w.begin(), w.end(), 0.0);
+        for (int q = 0; q < j; q++) { const double* v = V.data() + (size_t)q * n; for (long long i = 0; i < n; i++) w[i] += y[q] * v[i]; }
+        M(w.data(), z.data(), user);
+        for (long long i = 0; i < n; i++) x[i] += z[i];
+    }
+    double true_residual() {
+        A(x, r.data(), user);
+        double a = 0.0;
+        for (long long i = 0; i < n; i++) { r[i] = b[i] - r[i]; a += r[i] * r[i]; }
+        return std::sqrt(a);
+    }
+    void compress(int mm, int kk, const double* P1) {
+        std::vector<double> Vn((size_t)(kk + 1) * n, 0.0);
+        for (int c = 0; c <= kk; c++)
+            for (int q = 0; q <= mm; q++) { const double p = P1[(size_t)q * (kk + 1) + c]; if (p == 0.0) continue; const double* v = V.data() + (size_t)q * n; double* o = Vn.data() + (size_t)c * n; for (long long i = 0; i < n; i++) o[i] += p * v[i]; }
+        std::copy(Vn.begin(), Vn.end(), V.begin());
+    }
+};
+}  // namespace
+
+static int run_gmres_dr(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x, int kdef) {
+    need_init(s);
+    DAS_CHECK(s->op || s->fwd.on, DAS_ERR_STATE, "initializedRdWTMatrixFree() must be called before solveLinearEqn()");
+    DAS_CHECK(!s->halo.active && !s->halo_cb, DAS_ERR_ARG, "amd.gmresDeflation is single-rank (the restart's small dense algebra is not replicated across ranks yet)");
+    gmres_ws(s, k);
+    if (k->useBilu) bilu_clear_abort(k->bilu, s->stream);
+    if (!k->run) k->run.reset(new GmresRun);
+    GmresRun& G = *k->run;
+    G = GmresRun();
+    const int m = k->restart;
+    DAS_CHECK(m >= 4, DAS_ERR_ARG, "amd.gmresDeflation needs gmresRestart >= 4");
+    G.m = m; G.d_rhs = d_rhs; G.d_x = d_x;
+    G.maxIts = s->opt.geti("adjEqnOption.gmresMaxIters");
+    G.rtol = s->opt.getd("adjEqnOption.gmresRelTol"); G.atol = s->opt.getd("adjEqnOption.gmresAbsTol");
+    G.hh.assign(2 * (m + 2), 0.0); G.h2.assign(2 * (m + 2), 0.0);
+    k->nrefine = 0; k->hist.clear();
+    G.t0 = wall_seconds();
+    gmres_true_residual(s, k, G, s->opt.geti("adjEqnOption.useNonZeroInitGuess") != 0);
+    k->res0 = G.beta;
+    k->hist.push_back(G.beta);
+    G.target = std::max(G.rtol * G.beta, G.atol);
+    DAS_CHECK(gmres_map_basis(s, k, m + 2), DAS_ERR_INTERNAL, "GMRES-DR: no device memory for the basis (" + k->V.workerError + ")");
+    DrDeviceOps ops{s, k, &G, std::max(1, std::min(kdef, m - 2))};
+    const DrResult R = gmres_dr_loop(ops, m, kdef, G.beta, G.target, G.maxIts, k->hist);
+    hipStream_t st = s->stream;
+    DAS_HIP(hipStreamSynchronize(st));
+    if (k->useBilu) DAS_CHECK(!bilu_aborted(k->bilu, st), DAS_ERR_INTERNAL, "preconditioner sweep timed out (bounded spin)");
+    G.its = R.its;
+    k->iters = (int)R.its;
+    k->nBreakdown = R.nBreakdown;
+    k->res = R.res;
+    k->reason = R.res <= G.target ? 0 : 1;
+    k->seconds = wall_seconds() - G.t0;
+    if (s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] GMRES-DR(%d, %d): %lld iterations, %d deflated restarts, %d plain restarts, |r| %.3e -> %.3e\n", m, kdef, R.its, R.nDeflated, R.nRestarts, R.res0, R.res);
+    const double absRatio = k->res / G.atol, relRatio = k->res0 > 0 ? k->res / k->res0 / G.rtol : 0.0, diff = s->opt.getd("adjEqnOption.gmresTolDiff");
+    return (relRatio > diff && absRatio > diff) ? 1 : 0;
+}
+
 static int run_gmres(das_solver* s, das_ksp* k, const double* d_rhs, double* d_x, int fixed_iters) {
+    {   // opt-in: deflated restarting (never for the fixed-iteration bench windows, the Newton primal's inner solves or several ranks)
+        auto it = s->opt.i.find("amd.gmresDeflation");
+        const long long kdef = it != s->opt.i.end() ? it->second : 0;
+        if (kdef > 0 && fixed_iters <= 0 && !s->fwd.on && s->opt.geti("adjEqnOption.gmresRestart") < s->opt.geti("adjEqnOption.gmresMaxIters"))
+            return run_gmres_dr(s, k, d_rhs, d_x, (int)kdef);
+    }
     gmres_begin(s, k, d_rhs, d_x, fixed_iters > 0);
     if (fixed_iters > 0) gmres_advance(s, k, fixed_iters);
     else while (!gmres_advance(s, k, 1 << 20)) {}
@@ -4213,6 +4575,40 @@ int das_ksp_get_info(das_ksp_t* k, int* iters, double* res0, double* res, double
     if (res) *res = k->res;
     if (seconds) *seconds = k->seconds;
     return DAS_OK;
+    DAS_CATCH
+}
+// dense nonsymmetric eigen-solver used by the deflated restart (amd.gmresDeflation): fn(m, A row-major, wr, wi, vr, vi) with the
+// eigenvector of eigenvalue e in vr / vi [e * m .. e * m + m) (real / imaginary parts); returns 0 on success.  Process-wide.
+int das_set_dense_eig_callback(void* fn) { g_dense_eig = (das_dense_eig_fn)fn; return DAS_OK; }
+// host algebra of one deflated restart (CPU tier: checked against the numpy restatement): Hbar (m+1) x m row-major, rvec (m+1);
+// outputs sized for k + 1: P1 (m+1) x (kk+1), Hnew (kk+1) x kk, cnew (kk+1) - all row-major; returns kk (< 0 on failure)
+int das_debug_gmres_dr_restart(int m, int kwant, const double* Hbar, const double* rvec, double* P1, double* Hnew, double* cnew) {
+    DAS_TRY
+    DAS_CHECK(m >= 2 && kwant >= 1 && Hbar && rvec && P1 && Hnew && cnew, DAS_ERR_ARG, "bad argument");
+    std::vector<double> Hb(Hbar, Hbar + (size_t)(m + 1) * m), rv(rvec, rvec + m + 1), p, h, c;
+    int kk = 0;
+    if (gmres_dr_restart_host(m, kwant, Hb, rv, kk, p, h, c) != 0) return -1;
+    std::copy(p.begin(), p.end(), P1); std::copy(h.begin(), h.end(), Hnew); std::copy(c.begin(), c.end(), cnew);
+    return kk;
+    DAS_CATCH
+}
+// the deflated-restart iteration (gmres_dr_loop, the loop the device solver runs) on host vectors with callback operator / preconditioner:
+// CPU tier.  info4 = {iterations, deflated restarts, plain restarts, breakdowns}; returns the reference's fail flag
+int das_debug_gmres_dr_host(long long n, void* A, void* M, void* user, const double* b, double* x, int m, int kdef, double rtol, double atol,
+                            long long maxIts, double* hist, int histCap, double* info4, double* res2) {
+    DAS_TRY
+    DAS_CHECK(n > 0 && A && M && b && x && m >= 4, DAS_ERR_ARG, "bad argument");
+    DrHostOps ops{n, (das_host_apply_fn)A, (das_host_apply_fn)M, user, b, x, std::vector<double>((size_t)(m + 2) * n, 0.0), std::vector<double>(n), std::vector<double>(n), std::vector<double>(n), m};
+    std::fill(x, x + n, 0.0);
+    const double beta0 = ops.true_residual();
+    std::vector<double> h{beta0};
+    const double target = std::max(rtol * beta0, atol);
+    const DrResult R = gmres_dr_loop(ops, m, kdef, beta0, target, maxIts, h);
+    if (hist) for (int i = 0; i < histCap && i < (int)h.size(); i++) hist[i] = h[i];
+    if (info4) { info4[0] = (double)R.its; info4[1] = R.nDeflated; info4[2] = R.nRestarts; info4[3] = R.nBreakdown; }
+    if (res2) { res2[0] = R.res0; res2[1] = R.res; }
+    const double absRatio = R.res / atol, relRatio = beta0 > 0 ? R.res / beta0 / rtol : 0.0;
+    return (relRatio > 1e2 && absRatio > 1e2) ? 1 : 0;
     DAS_CATCH
 }
 int das_ksp_get_n_refine(das_ksp_t* k) { return k ? k->nrefine : -1; }

@@ -108,6 +108,9 @@ Options::Options() {
     // step j+1 share one pass over the basis (2 instead of 4 basis reads per iteration, same iterates); "cgs": the
     // reference's KSP_GMRES_CGS_REFINE_IFNEEDED.  adjEqnOption.useMGSO = 1 selects modified Gram-Schmidt in both cases.
     s["amd.gmresOrthogonalization"] = "dcgs2";
+    // > 0: GMRES with deflated restarting (GMRES-DR): gmresRestart basis vectors, this many harmonic Ritz vectors carried across restarts
+    // (round 4: prototyped on the CPU, tools/gmres_dr_study.py; the device path has not been measured yet - opt-in, default off)
+    i["amd.gmresDeflation"] = 0;
 }
 double Options::getd(const std::string& k) const {
     auto it = d.find(k);

@@ -337,6 +337,17 @@ int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
 /* number of Gram-Schmidt refinement passes of the last solve (KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160); with
  * amd.gmresOrthogonalization "dcgs2": the number of explicit projections (exhausted Krylov space / lost orthogonality) */
 int das_ksp_get_n_refine(das_ksp_t* ksp);
+/* amd.gmresDeflation = k > 0 (opt-in; round 4, not yet measured on the device): GMRES with deflated restarting (GMRES-DR; PETSc's
+ * counterpart is KSPDGMRES, not the reference's default KSPGMRES of DALinearEqn.C:28-339): gmresRestart basis vectors, k harmonic
+ * Ritz vectors carried across restarts.  The dense m x m eigenproblem of a restart goes through a process-wide callback
+ * fn(m, A row-major, wr, wi, vr, vi) -> 0 (eigenvector e in vr / vi [e m, e m + m)); das_debug_gmres_dr_restart exposes the host
+ * algebra of one restart to the CPU tier (returns the number of kept vectors, which never splits a complex pair). */
+int das_set_dense_eig_callback(void* fn);
+int das_debug_gmres_dr_restart(int m, int kwant, const double* Hbar, const double* rvec, double* P1, double* Hnew, double* cnew);
+/* the deflated-restart iteration itself on HOST vectors (operator A and preconditioner M as callbacks fn(x, y, user)): the very loop the
+ * device solver runs, for the CPU tier; info4 = {iterations, deflated restarts, plain restarts, breakdowns}, res2 = {|r0|, |r|} */
+int das_debug_gmres_dr_host(long long n, void* A, void* M, void* user, const double* b, double* x, int m, int kdef, double rtol, double atol,
+                            long long maxIts, double* hist, int histCap, double* info4, double* res2);
 /* how the last solve ended: reason 0 = tolerance met (KSP_CONVERGED_RTOL/ATOL), 1 = gmresMaxIters reached (KSP_DIVERGED_ITS),
  * 2 = stopped on stagnation after a Krylov breakdown / at the attainable accuracy (PETSc: KSP_CONVERGED_HAPPY_BREAKDOWN /
  * KSP_DIVERGED_BREAKDOWN; the reference's failure flag is still the tolerance rule of DALinearEqn.C:422-434);

@@ -14,6 +14,7 @@ ap.add_argument("--combos", nargs="+", default=["-1:additive:rcb:1", "512:additi
 ap.add_argument("--maxit", type=int, default=1500)
 ap.add_argument("--blend", type=float, nargs="+", default=[0.0], help="amd.pcUpwindBlend values (the PC matrix is re-assembled per value)")
 ap.add_argument("--polish", type=int, default=2)
+ap.add_argument("--deflation", nargs="*", default=[], help="GMRES-DR runs after the sweep: pairs m:k (gmresRestart : amd.gmresDeflation), e.g. 300:100 200:70")
 a = ap.parse_args()
 import __graft_entry__ as ge
 ge.build()
@@ -69,4 +70,16 @@ for nz in a.nz:
         L.das_timer_enable(D.solver._h, 0)
         ksp.destroy()
       pc.destroy()
+    for mk in a.deflation:
+        mm, kk = [int(v) for v in mk.split(":")]
+        D.solver.updateDAOption({"amd": {"gmresDeflation": kk, "pcUpwindBlend": float(a.blend[-1])}, "adjEqnOption": {"gmresRestart": mm, "gmresMaxIters": a.maxit}})
+        pc = Mat(); D.solver.calcdRdWT(1, pc)
+        ksp = KSP(); D.solverAD.createMLRKSPMatrixFree(pc, ksp)
+        x = Vec(n); r = Vec(n); r.array[:] = rhs
+        t = time.time(); fail = D.solverAD.solveLinearEqn(ksp, r, x); ts = time.time() - t
+        info = ksp.info()
+        print(f"SWEEP {nx}x{ny}x{nz} GMRES-DR(m={mm}, k={kk}) blend {a.blend[-1]}: iters {info['iters']} fail {fail} rel {info['res'] / info['res0']:.2e} solve {ts:.2f}s "
+              f"({info['iters'] / ts:.1f} it/s, basis {mm + 2} vectors)", flush=True)
+        D.solver.updateDAOption({"amd": {"gmresDeflation": 0}, "adjEqnOption": {"gmresRestart": a.maxit}})
+        ksp.destroy(); pc.destroy()
     del D
