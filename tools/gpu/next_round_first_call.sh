@@ -2,10 +2,14 @@
 # re-measured on the final tree.  ~25 GPU-minutes.
 #   1. the full GPU tier on the final tree (round 4 verified only the new tests: profiles/r05n_*, and the bench line: r05j / r05l)
 #   2. the default bench line WITH the CPU legs (cpu port at the bench size with 16 threads, psi parity leg)
+#   2b. amd.gmresDeflation (GMRES-DR): the experimental GPU test, then the 2 M-cell wing with a 300- and a 200-vector basis
 #   3. PMC passes on the wing workload (roofline.traffic is null for it) + the counter calibration on pure streams of 4 / 8 / 16 B per lane
 export TMPDIR=/tmp
 O=gpurun_out/r06a; mkdir -p $O
 timeout 1100 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; tail -5 $O/pytest_gpu.log | cut -c1-200
+DAS_TEST_EXPERIMENTAL=1 timeout 200 python -m pytest tests/test_gpu_zzz_edge_cases.py -q -s -k gmres_deflated > $O/pytest_gmres_dr.log 2>&1; tail -4 $O/pytest_gmres_dr.log | cut -c1-200
+#   (then, if green: the deflated solver at size - 2 M-cell wing, basis 302 / 202 vectors instead of ~970)
+timeout 500 python tools/naca_adjoint_sweep.py --nz 160 --dz 0.025 --blend 0.5 --combos a:deflated:rcb:1 --maxit 1500 --deflation 300:100 200:70 > $O/wing_gmres_dr.log 2> $O/wing_gmres_dr.err; grep SWEEP $O/wing_gmres_dr.log
 DAS_BENCH_VERBOSE=1 timeout 700 python bench.py --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err; grep "^\[bench" $O/bench.err | cut -c1-250
 cd /tmp; R=$GRAFT_REPO_ROOT
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_fetch -o p -- python $R/bench.py --no-cpu --no-parity --no-solve --window-at-warmup --steps 5 --warmup 440 > /dev/null 2> $R/$O/pmc_fetch.err
