@@ -590,7 +590,7 @@ def cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu_sp
         "cores": K.threads,
         "kind": "port",
         "sample": f"{iters} GMRES iterations (basis sizes j < {iters}) of the SAME {N}-cell system at the bench size - operator ({op_nnz} nnz) and PC matrix ({pc_nnz} nnz) "
-                  f"copied back from the device - with the oracle's OpenMP C port (gcc -O3 -march=native -fopenmp, {K.threads} threads = every CPU the container may use "
+                  f"copied back from the device - with the oracle's OpenMP C port (gcc -O3 -march=x86-64-v3 -fopenmp, {K.threads} threads = every CPU the container may use "
                   f"(affinity and CFS quota; the host shows {os.cpu_count()}), first-touch placement): CSR SpMV, "
                   f"the node-block ILU(0) of the GPU path restated for the host ({prep['nodes']} nodes, {prep['blocks']} dense 8x8 blocks, {prep['ilu_levels']} levels, "
                   f"level-parallel) + pressure coarse space ({prep['coarse_aggregates']} aggregates, additive), CGS2 with threaded multi-dot / multi-axpy; {inf['seconds']:.1f} s "

@@ -29,7 +29,7 @@ _lp = C.POINTER(C.c_longlong)
 def build(force=False):
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", _SO, _SRC, "-lm"])
+        subprocess.check_call(["gcc", "-O3", "-march=x86-64-v3", "-fPIC", "-shared", "-o", _SO, _SRC, "-lm"])
     build_omp(force)
     return _SO
 
@@ -42,7 +42,7 @@ _lib_omp = None
 def build_omp(force=False):
     os.makedirs(os.path.dirname(_SO_OMP), exist_ok=True)
     if force or not os.path.exists(_SO_OMP) or os.path.getmtime(_SO_OMP) < os.path.getmtime(_SRC_OMP):
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-o", _SO_OMP, _SRC_OMP, "-lm"])
+        subprocess.check_call(["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-fPIC", "-shared", "-o", _SO_OMP, _SRC_OMP, "-lm"])
     return _SO_OMP
 
 
