@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the 200 k-cell psi parity leg (GPU vs all-core CPU port)")
     ap.add_argument("--pc-blend", type=float, default=None, help="amd.pcUpwindBlend: weight of the second-order (linearUpwindV) correction in the PC residual "
                          "(the reference user's choice of div(pc) in fvSchemes); default 0.5 for naca, 0 (upwind) for channel")
+    ap.add_argument("--deflation", type=int, default=int(os.environ.get("DAS_BENCH_DEFLATION", 0)),
+                    help="amd.gmresDeflation k > 0: the full solve runs GMRES with deflated restarting (basis = --solve-restart vectors, k harmonic Ritz vectors kept); "
+                         "opt-in, not yet measured on the device (DESIGN.md section 10 item 0b); the timed window stays the undeflated iteration at the solve's mean basis depth")
     ap.add_argument("--ordering", default=os.environ.get("DAS_BENCH_ORDERING", "rcm"), help="adjEqnOption.jacMatReOrdering: rcm | natural")
     ap.add_argument("--naca", type=int, nargs=3, default=[200, 63, 160], help="naca: cells around the section, wall-normal, spanwise layers")
     ap.add_argument("--naca-first-cell", type=float, default=4.0e-5, help="naca: first cell height (chords) of the section")
@@ -269,19 +272,31 @@ def main():
         sol.zero_()
         barrier()
         t0 = time.perf_counter()
-        check(L.das_ksp_begin_device(h, ksp.handle, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()), 0))
-        while not check(L.das_ksp_advance(h, ksp.handle, 1000)):
-            pass
-        fail = check(L.das_ksp_end(h, ksp.handle))
+        if a.deflation > 0 and world == 1:
+            # GMRES-DR through the host-vector entry (the deflated solver is not a begin / advance state machine)
+            from dafoam_amd.pyDASolvers import Vec
+
+            D.solver.updateDAOption({"amd": {"gmresDeflation": int(a.deflation)}})
+            bvec, xvec = Vec(n), Vec(n)
+            bvec.array[:] = rhs_h
+            fail = D.solverAD.solveLinearEqn(ksp, bvec, xvec)
+            D.solver.updateDAOption({"amd": {"gmresDeflation": 0}})
+        else:
+            check(L.das_ksp_begin_device(h, ksp.handle, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()), 0))
+            while not check(L.das_ksp_advance(h, ksp.handle, 1000)):
+                pass
+            fail = check(L.das_ksp_end(h, ksp.handle))
         barrier()
         t_solve = time.perf_counter() - t0
         inf = ksp.info()
         hist = ksp.history()
         its = int(inf["iters"])
         mean_depth = float(np.mean(np.arange(its) % r_eff)) if its > 0 else 0.0
+        if a.deflation > 0 and world == 1 and its > r_eff:  # later cycles run between depth k and m
+            mean_depth = (r_eff * 0.5 * r_eff + (its - r_eff) * 0.5 * (a.deflation + r_eff)) / its
         solve = {"converged": fail == 0, "fail": int(fail), "iterations": its, "time_to_tolerance_s": t_solve,
                  "rel_residual": inf["res"] / inf["res0"] if inf["res0"] else None, "gmresRelTol": 1e-6,
-                 "gmresRestart": r_eff, "gmresMaxIters": a.solve_maxit, "mean_basis_depth": mean_depth,
+                 "gmresRestart": r_eff, "gmresMaxIters": a.solve_maxit, "mean_basis_depth": mean_depth, "gmresDeflation": int(a.deflation) if world == 1 else 0,
                  "rel_residual_at_1000_iterations": float(hist[1000] / hist[0]) if len(hist) > 1000 else None,
                  "rel_residual_every_100": [float(v / hist[0]) for v in hist[::100]],
                  "iterations_per_sec_whole_solve": its / t_solve}
