@@ -1376,3 +1376,24 @@ def test_gmres_dr_loop_host_twin():
     # (3) first cycle == full GMRES: same iterates as the oracle's GMRES (CGS2) while no restart happens
     xo, io = OL.gmres(lambda v: A @ v, rhs, pc, restart=600, max_iters=600, rel_tol=1e-10, abs_tol=1e-300)
     assert abs(io["iters"] - i_full[0]) <= 1
+
+
+def test_bench_cpu_leg_guards():
+    """bench.py's guards around the CPU legs (round 4: a 256-thread CPU leg on a 16-CPU quota did not finish in ten minutes and took
+    the JSON line with it): a leg that overruns its deadline yields an error record naming the stage and marks the run for a hard exit
+    after the line is printed; a leg that raises yields an error record; the thread count honours the affinity mask."""
+    import importlib.util
+    import time
+
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._with_deadline(lambda: {"value": 1.0}, 5.0, "fast leg") == {"value": 1.0} and not bench._OVERRUN
+    out = bench._with_deadline(lambda: 1 / 0, 5.0, "failing leg")
+    assert "ZeroDivisionError" in out["error"] and not bench._OVERRUN
+    bench._CPU_STAGE[0] = "somewhere"
+    out = bench._with_deadline(lambda: time.sleep(1.0) or {"value": 2.0}, 0.05, "slow leg")
+    assert "slow leg" in out["error"] and "somewhere" in out["error"] and bench._OVERRUN == ["slow leg"]
+    from oracle.linear import available_cpus
+
+    assert 1 <= bench._cpu_threads() == available_cpus() <= len(os.sched_getaffinity(0))
