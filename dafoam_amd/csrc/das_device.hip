@@ -959,6 +959,7 @@ struct das_ksp {
     int iters = 0, nrefine = 0, reason = 0, nBreakdown = 0;
     double res0 = 0, res = 0, seconds = 0;
     std::vector<double> hist;
+    std::vector<int> cycleLens;  // columns of every closed Arnoldi cycle of the last solve (das_ksp_get_cycle_lengths)
 };
 
 struct das_solver {
@@ -2221,6 +2222,7 @@ static void gmres_begin(das_solver* s, das_ksp* k, const double* d_rhs, double* 
     if (G.dcgs2) { G.Hraw.assign((size_t)(m + 1) * m, 0.0); G.h1.assign(m + 2, 0.0); }
     k->nrefine = 0;
     k->hist.clear();
+    k->cycleLens.clear();
     G.t0 = wall_seconds();
     gmres_true_residual(s, k, G, s->opt.geti("adjEqnOption.useNonZeroInitGuess") != 0);
     k->res0 = G.beta;
@@ -2455,6 +2457,7 @@ static void gmres_cycle_end(das_solver* s, das_ksp* k) {
     hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, k->z.p, 1.0, G.d_x);
     gmres_true_residual(s, k, G, true);
     k->hist.back() = G.beta;
+    k->cycleLens.push_back(j);
     G.open = false;
 }
 // advance by up to `nsteps` iterations (cycles are opened / closed as needed); returns true when the solve is over
@@ -2467,7 +2470,13 @@ static bool gmres_advance(das_solver* s, das_ksp* k, long long nsteps) {
         if (!G.open) gmres_cycle_start(s, k);
         // the step writes basis slots up to (pending vector) + 2: map them; if the device has no memory left for them the cycle
         // ends here - the mapped part of the basis is the restart length from now on
-        if (!gmres_map_basis(s, k, ((G.dcgs2 && !G.safeOrth) ? G.pend : G.j) + 3)) {
+        // (a cycle of m columns holds m + 1 basis vectors - with the delayed scheme the pending vector of the last step sits in slot
+        // m and nothing is written behind it - so the request never exceeds the restart + 2 slots gmres_ws reserved: round 4 asked
+        // for pend + 3 = restart + 3 at the last step of a cycle and closed every malloc-path cycle one column early)
+        const long long wantSlots = std::min<long long>(((G.dcgs2 && !G.safeOrth) ? G.pend : G.j) + 3, (long long)G.m + 2);
+        if (!gmres_map_basis(s, k, wantSlots)) {
+            if (k->V.workerError.empty())
+                k->V.workerError = "request for " + std::to_string(wantSlots) + " basis vectors beyond the reserved range of " + std::to_string(k->V.n / (size_t)std::max<long long>(1, s->n)) + " (internal)";
             DAS_CHECK(G.j >= 1, DAS_ERR_INTERNAL, "GMRES: the Krylov basis cannot grow beyond its first vectors (" + k->V.workerError + ")");
             if (!G.memWarned) fprintf(stderr, "[dafoam_amd] GMRES restarts after %d vectors: %s\n", G.j, k->V.workerError.c_str());
             G.memWarned = true;
@@ -4659,6 +4668,14 @@ int das_ksp_get_history(das_ksp_t* k, double* hist, int cap) {
     int m = std::min<int>(cap, (int)k->hist.size());
     std::copy(k->hist.begin(), k->hist.begin() + m, hist);
     return m;
+    DAS_CATCH
+}
+int das_ksp_get_cycle_lengths(das_ksp_t* k, int* lens, int cap) {
+    DAS_TRY
+    DAS_CHECK(k && (lens || cap == 0), DAS_ERR_ARG, "null argument");
+    int m = std::min<int>(cap, (int)k->cycleLens.size());
+    std::copy(k->cycleLens.begin(), k->cycleLens.begin() + m, lens);
+    return (int)k->cycleLens.size();
     DAS_CATCH
 }
 int das_ksp_run_fixed_device(das_solver_t* s, das_ksp_t* ksp, const double* d_rhs, double* d_sol, int iters) {

@@ -226,6 +226,12 @@ class KSP:
         m = check(lib().das_ksp_get_history(self.handle, dptr(buf), buf.size))
         return buf[:m]
 
+    def cycleLengths(self):
+        """Columns of every closed Arnoldi cycle of the last solve (all but the last equal gmresRestart, DALinearEqn.C:155)."""
+        buf = np.zeros(max(1, self.getIterationNumber() + 2), np.int32)
+        m = check(lib().das_ksp_get_cycle_lengths(self.handle, buf.ctypes.data_as(_capi.c_int_p), buf.size))
+        return buf[:m].copy()
+
     def destroy(self):
         if self.handle:
             lib().das_ksp_destroy(self.handle)

@@ -334,6 +334,9 @@ int das_ksp_get_pc_structure_sizes(das_ksp_t* ksp, int* nNodes, long long* nBloc
 int das_ksp_get_pc_structure(das_ksp_t* ksp, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural);
 int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, double* seconds);
 int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
+/* columns of every closed Arnoldi cycle of the last solveLinearEqn (reference: KSPGMRESSetRestart, DALinearEqn.C:155 - every cycle
+ * but the last holds exactly gmresRestart columns); writes min(cap, count) entries, returns the count */
+int das_ksp_get_cycle_lengths(das_ksp_t* ksp, int* lens, int cap);
 /* number of Gram-Schmidt refinement passes of the last solve (KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160); with
  * amd.gmresOrthogonalization "dcgs2": the number of explicit projections (exhausted Krylov space / lost orthogonality) */
 int das_ksp_get_n_refine(das_ksp_t* ksp);

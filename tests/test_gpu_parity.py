@@ -1390,6 +1390,10 @@ def test_delayed_reorthogonalisation_matches_reference_gram_schmidt(restart):
         psi, fail = D.solveAdjoint(rhs)
         assert fail == 0
         out[name] = (psi, D.ksp.history(), D.ksp.info()["iters"])
+        # every cycle but the last closes at exactly gmresRestart columns (KSPGMRESSetRestart, DALinearEqn.C:155): round 4 closed the
+        # malloc-path cycles of "dcgs2" one column early (basis reservation restart + 2 against a request of restart + 3)
+        lens = D.ksp.cycleLengths()
+        assert lens.sum() == D.ksp.info()["iters"] and np.all(lens[:-1] == min(restart, 3000)) and 1 <= lens[-1] <= restart, (name, lens)
     for other in ("cgs", "mgs"):
         assert out["dcgs2"][2] == out[other][2]
         h1, h2 = out["dcgs2"][1], out[other][1]

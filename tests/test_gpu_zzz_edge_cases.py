@@ -159,8 +159,6 @@ def test_coloring_watchdog_switches_to_the_order_independent_algorithm_on_an_ogr
     assert abs(a @ Jv - JTa @ v) <= 1e-9 * (np.abs(a * Jv).sum() + np.abs(JTa * v).sum())
 
 
-@pytest.mark.skipif(not os.environ.get("DAS_TEST_EXPERIMENTAL"), reason="amd.gmresDeflation: written at the end of round 4 without GPU time left - the host twin of the same loop is "
-                    "tested in the CPU tier (test_gmres_dr_loop_host_twin); enable with DAS_TEST_EXPERIMENTAL=1 once the device path has been run")
 def test_gmres_deflated_restarting_matches_the_default_solver():
     """amd.gmresDeflation k (GMRES-DR): the same psi as the undeflated solver (1e-8), fewer iterations than plain restarting with the
     same basis length, on a converged channel case."""
