@@ -228,11 +228,11 @@ inline bool color_firstfit_device(long long n, const std::vector<long long>& kee
         for (long long q = 0; q < nKeep; q++) posOfRow[keep[q]] = (int)q;
     }
     uvector<int> crowK(crow.size());
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(das::host_threads())
     for (long long q = 0; q < (long long)crow.size(); q++) crowK[q] = posOfRow[crow[q]];
     // groups: maximal runs of consecutive columns with identical kept-row lists (the xyz components of a cell's U)
     std::vector<unsigned char> isStart(n, 1);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(das::host_threads())
     for (long long j = 1; j < n; j++) {
         const long long len = cptr[j + 1] - cptr[j];
         isStart[j] = !(cptr[j] - cptr[j - 1] == len && std::equal(crow.begin() + cptr[j], crow.begin() + cptr[j + 1], crow.begin() + cptr[j - 1]));
@@ -449,12 +449,12 @@ inline bool color_speculative_device(long long n, const std::vector<long long>& 
         maxNet = std::max(maxNet, len);
     }
     uvector<int> kcol(krp[nKeep]);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(das::host_threads())
     for (long long q = 0; q < nKeep; q++) std::copy(col.begin() + rowptr[keep[q]], col.begin() + rowptr[keep[q] + 1], kcol.begin() + krp[q]);
     std::vector<int> posOfRow((long long)rowptr.size() - 1, -1);
     for (long long q = 0; q < nKeep; q++) posOfRow[keep[q]] = (int)q;
     uvector<int> crowK(crow.size());
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(das::host_threads())
     for (long long q = 0; q < (long long)crow.size(); q++) crowK[q] = posOfRow[crow[q]];
     lap("host preparation");
     DevBuf<long long> d_cptr, d_krp;

@@ -64,14 +64,14 @@ inline int usable_host_cpus() {
     if (quota > 0.0) n = std::min(n, std::max(1, (int)(quota + 0.5)));
     return std::max(1, n);
 }
-inline void cap_host_threads_once() {
-    static std::once_flag once;
-    std::call_once(once, []() {
-        if (getenv("DAS_KEEP_OMP_THREADS")) return;
-        const int u = usable_host_cpus();
-        if (omp_get_max_threads() > u) omp_set_num_threads(u);
-    });
+// The cap is a number the host-phase parallel regions pass as num_threads(...) (host_threads()); the OpenMP runtime's own
+// num-threads ICV is per thread and belongs to the embedding application (torch, numpy): the library does not touch it
+// (ADVICE round 4).
+inline int host_thread_cap() {
+    static const int cap = getenv("DAS_KEEP_OMP_THREADS") ? omp_get_num_procs() : usable_host_cpus();
+    return cap;
 }
+inline int host_threads(int want = 1 << 30) { return std::max(1, std::min(std::min(want, host_thread_cap()), omp_get_max_threads())); }
 
 // ---- device buffer -------------------------------------------------------------------------
 // mapped virtual ranges of released VmBufs (never unmapped; see VmBuf::release)
@@ -202,7 +202,11 @@ struct VmBuf {
             // the range is NOT unmapped: it goes to a process-wide cache and is handed to the next buffer that fits (round 4: a
             // range reserved AFTER an earlier one had been unmapped and freed faulted as soon as its second chunk was written -
             // "write access to a read-only page", twice, at 200 k cells - and re-mapping gigabytes per solver was pure overhead)
+            int cur = -1;
+            (void)hipGetDevice(&cur);
+            if (cur != device) (void)hipSetDevice(device);  // (the range lives on `device`, not on the caller's current one)
             (void)hipDeviceSynchronize();  // nothing in flight may still address the range when its next owner starts writing
+            if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
             VmRange r;
             r.p = (void*)p; r.reservedBytes = reservedBytes; r.mappedBytes = mappedBytes; r.handles = handles; r.sizes = sizes; r.device = device;
             std::lock_guard<std::mutex> lk(vm_cache_mutex());
@@ -245,6 +249,9 @@ struct VmBuf {
                         return;
                     }
                 }
+                // nothing cached fits: the idle ranges hold physical memory this (larger) basis will need - give it back to the device
+                // (a later, larger solver otherwise runs out of memory next to tens of idle GB)
+                if (vm_cache_trim() > 0) (void)hipDeviceSynchronize();
                 void* base = nullptr;
                 if (hipMemAddressReserve(&base, total, align, nullptr, 0) == hipSuccess && base) {
                     p = (T*)base; reservedBytes = total; vmm = true; n = n_;
@@ -276,6 +283,15 @@ struct VmBuf {
                 (void)hipGetLastError();
                 sz = std::max((size_t)128 << 20, sz / 4 / granularity * granularity);
                 e = hipMemCreate(&h, sz, &prop, 0);
+            }
+            if (e != hipSuccess) {
+                // idle cached ranges of destroyed solvers may hold the memory this chunk needs (the range in use is not in the cache)
+                (void)hipGetLastError();
+                if (vm_cache_trim() > 0) {
+                    (void)hipDeviceSynchronize();
+                    sz = std::min(CHUNK, reservedBytes - off);
+                    e = hipMemCreate(&h, sz, &prop, 0);
+                }
             }
             const char* what = "hipMemCreate";
             bool created = e == hipSuccess;

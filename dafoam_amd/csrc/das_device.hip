@@ -665,6 +665,45 @@ __global__ void k_coarse_prolong(long long N, long long n, long long off, const 
     y[i] = set ? add : y[i] + add;
 }
 
+// A Z for the deflated coarse mode: row i of the operator summed over the field-block columns of every aggregate.  One thread per
+// row, entries in storage order (deterministic); a row whose field columns touch more than AZ_CAP aggregates sets `overflow` (the
+// caller then keeps the full operator product).  pass 0: counts -> cnt[i]; pass 1: fills (ptr from the prefix sum of the counts)
+constexpr int AZ_CAP = 12;
+__global__ __launch_bounds__(256) void k_az_build(long long n, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
+                                                  long long N, long long off, const int* __restrict__ agg, int pass, int* __restrict__ cnt,
+                                                  const long long* __restrict__ ptr, int* __restrict__ oa, double* __restrict__ ov, int* __restrict__ overflow) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int la[AZ_CAP];
+    double ls[AZ_CAP];
+    int m = 0;
+    for (long long k = rp[i]; k < rp[i + 1]; k++) {
+        const long long j = (long long)ci[k] - off;
+        if (j < 0 || j >= N) continue;
+        const int a = agg[j];
+        if (a < 0) continue;
+        int q = 0;
+        while (q < m && la[q] != a) q++;
+        if (q == m) {
+            if (m == AZ_CAP) { *overflow = 1; continue; }
+            la[m] = a; ls[m] = 0.0; m++;
+        }
+        ls[q] += v[k];
+    }
+    if (pass == 0) { cnt[i] = m; return; }
+    const long long b = ptr[i];
+    for (int q = 0; q < m; q++) { oa[b + q] = la[q]; ov[b + q] = ls[q]; }
+}
+// out = v - (A Z) u
+__global__ __launch_bounds__(256) void k_az_apply(long long n, const long long* __restrict__ ptr, const int* __restrict__ oa, const double* __restrict__ ov,
+                                                  const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.0;
+    for (long long k = ptr[i]; k < ptr[i + 1]; k++) acc += ov[k] * u[oa[k]];
+    out[i] = v[i] - acc;
+}
+
 // ---- RAS/ILU(k) apply: one workgroup per (overlapping) additive-Schwarz block -------------------------------------
 // Restricted additive Schwarz: the block solves on its extended (core + overlap) unknowns and writes back only the
 // core part (PETSc's default PC_ASM_RESTRICT, reference DALinearEqn.C:199-216).
@@ -948,6 +987,14 @@ struct das_ksp {
         DevBuf<long long> aptr, aptrAll;  // own aggregates (restriction) / all aggregates with local row cells (assembly)
         DevBuf<double> Einv, t, u, c, rr;
         std::vector<int> h_agg;     // local aggregate of every cell (-1: not owned), as handed out by das_ksp_get_coarse
+        // deflated mode, single rank, assembled operator: A Z as a sparse n x nagg matrix (rows hold the few aggregates their p-columns
+        // touch), so that the A-DEF1 term A (Z u) costs one pass over ~1.2 entries per row instead of a full operator product
+        DevBuf<long long> azPtr;
+        DevBuf<int> azAgg;
+        DevBuf<double> azVal;
+        const void* azOp = nullptr;  // the operator matrix A Z was built from (rebuilt when the operator is re-assembled)
+        long long azEpoch = -1, azNnz = 0;
+        bool azReady = false, azFailed = false;
     } coarse;
     int restart = 0;
     VmBuf<double> V;  // Krylov basis: up to 129 GB (reference default restart at 2 M cells) - mapped chunk by chunk through the VM API
@@ -1664,7 +1711,7 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     const double t_prep = wall_seconds();
     // every block touches ~100 MB of fresh host memory; beyond a few dozen threads the kernel's page-fault / mmap paths
     // serialise (measured on the 256-core MI355X host), hence the cap amd.setupThreads
-    const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
+    const int nthr = (int)std::max<long long>(1, std::min<long long>(das::host_threads(), s->opt.geti("amd.setupThreads")));
 #pragma omp parallel num_threads(nthr)
     {
         std::vector<int> cmark(m.nC, -1);
@@ -1775,7 +1822,7 @@ static void setup_block_ilu(das_solver* s, das_ksp* k) {
     std::vector<double> invd(next);
     P.h_core_perm.assign(P.h_core_off.back(), 0);
     for (int t = 0; t < 2; t++) { slev[t].resize(loff[t][nB]); slevOff[t] = loff[t]; }
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(das::host_threads())
     for (int b = 0; b < nB; b++) {
         BlockFactor& F = BF[b];
         std::copy(F.gidx.begin(), F.gidx.end(), gidx.begin() + boff[b]);
@@ -1864,7 +1911,7 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     const double t0 = wall_seconds();
     const Mat& A = k->pcmat->m;
     const int reach = pc_stencil_reach(s);
-    const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
+    const int nthr = (int)std::max<long long>(1, std::min<long long>(das::host_threads(), s->opt.geti("amd.setupThreads")));
     bilu_setup(s->mesh, s->st_full.states, s->n, s->owned, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
                k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s), k->pcTranspose, k->pcDiagScale, k->shiftExLo, k->shiftExHi, k->shiftEnd);
     k->useBilu = true;
@@ -1894,6 +1941,7 @@ static void coarse_build_operator(das_solver* s, das_ksp* k, int naggG, int aggO
         for (long long c = 0; c < N; c++) if (aggRowG[c] >= 0) cellsAll[pos[aggRowG[c]]++] = (int)c;
     }
     C.naggG = naggG; C.aggOff = aggOff; C.global = naggG > C.nagg;
+    C.azOp = nullptr; C.azReady = false;  // the sparse A Z of the deflated mode belongs to the old aggregates
     C.agg.upload(aggOwn); C.aggRow.upload(aggRowG); C.cellsAll.upload(cellsAll); C.aptrAll.upload(aptrAll);
     DevBuf<double> E((size_t)naggG * naggG);
     E.zero();
@@ -2080,6 +2128,39 @@ static void multidot(das_solver* s, das_ksp* k, int m, const double* w, double* 
 
 static void apply_operator(das_solver* s, const double* x, double* y);
 
+// deflated coarse mode: is the sparse A Z of the CURRENT operator available?  Built on first use per operator (two passes over the
+// assembled CSR, one thread per row: tens of milliseconds once, against one operator product saved in every iteration); only for the
+// single-rank assembled operator - several ranks (ghost rows + halo reduction), the matrix-free forward-mode operator and the Newton
+// primal's shifted operator keep the full product.  amd.pcCoarseSparseAZ 0 switches it off.
+static bool coarse_az_ready(das_solver* s, das_ksp* k) {
+    das_ksp::CoarsePC& C = k->coarse;
+    if (!s->op || s->fwd.on || s->halo.active || s->halo_cb || C.global) return false;
+    { auto it = s->opt.i.find("amd.pcCoarseSparseAZ"); if (it != s->opt.i.end() && it->second == 0) return false; }
+    const Mat& A = s->op->m;
+    if (C.azOp == (const void*)s->op.get() && C.azEpoch == s->op_epoch) return C.azReady;
+    C.azOp = (const void*)s->op.get(); C.azEpoch = s->op_epoch; C.azReady = false; C.azFailed = false;
+    const long long n = s->n;
+    hipStream_t st = s->stream;
+    DevBuf<int> cnt(n), ovf(1);
+    DAS_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_az_build, dim3(nblk(n, 256)), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.val.p, C.N, C.off, C.agg.p, 0, cnt.p, (const long long*)nullptr,
+                       (int*)nullptr, (double*)nullptr, ovf.p);
+    DAS_HIP(hipStreamSynchronize(st));
+    if (ovf.to_host()[0]) { C.azFailed = true; return false; }
+    std::vector<int> h = cnt.to_host();
+    std::vector<long long> ptr(n + 1, 0);
+    for (long long i = 0; i < n; i++) ptr[i + 1] = ptr[i] + h[i];
+    C.azNnz = ptr[n];
+    C.azPtr.upload(ptr);
+    C.azAgg.alloc((size_t)std::max<long long>(1, C.azNnz)); C.azVal.alloc((size_t)std::max<long long>(1, C.azNnz));
+    hipLaunchKernelGGL(k_az_build, dim3(nblk(n, 256)), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.val.p, C.N, C.off, C.agg.p, 1, cnt.p, C.azPtr.p, C.azAgg.p, C.azVal.p,
+                       ovf.p);
+    DAS_HIP(hipStreamSynchronize(st));
+    if (s->opt.geti("debug")) fprintf(stderr, "[dafoam_amd] deflated coarse mode: sparse A Z with %lld entries (%.2f per row)\n", C.azNnz, (double)C.azNnz / (double)n);
+    C.azReady = true;
+    return true;
+}
+
 // z = M^{-1} v: the factorisation, wrapped in globalPCIters x localPCIters Richardson sweeps on jacPCMat when the
 // options ask for more than one (reference DALinearEqn.C:173-205, 237-260: KSPRICHARDSON around ASM and around the
 // sub-domain ILU; with one sub-domain per GPU both iterate the same stationary scheme, so l x g sweeps in total)
@@ -2094,9 +2175,15 @@ static void pc_apply_full(das_solver* s, das_ksp* k, const double* v, double* z)
         if (C.deflated && (s->op || s->fwd.on)) {
             // A-DEF1: z = ILU^-1 (v - A c) + c,  c = Z E^-1 Z^T v
             hipLaunchKernelGGL(k_coarse_prolong, dim3(nblk(n, 256)), dim3(256), 0, s->stream, C.N, n, C.off, C.agg.p, C.u.p, C.c.p, 1);
-            s->timer.end("coarse", s->stream, ev);
-            apply_operator(s, C.c.p, C.rr.p);
-            hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, v, -1.0, C.rr.p);
+            if (coarse_az_ready(s, k)) {
+                // A c = (A Z) u with the precomputed sparse A Z: ~1.2 entries per row instead of the whole operator
+                hipLaunchKernelGGL(k_az_apply, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, C.azPtr.p, C.azAgg.p, C.azVal.p, C.u.p, v, C.rr.p);
+                s->timer.end("coarse", s->stream, ev);
+            } else {
+                s->timer.end("coarse", s->stream, ev);
+                apply_operator(s, C.c.p, C.rr.p);
+                hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, v, -1.0, C.rr.p);
+            }
             pc_apply(s, k, C.rr.p, z);
             hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, C.c.p, 1.0, z);
         } else {
@@ -3292,7 +3379,6 @@ int das_device_count(void) {
 das_solver_t* das_create(const das_case_t* c) {
     try {
         DAS_CHECK(c, DAS_ERR_ARG, "null case");
-        cap_host_threads_once();  // OpenMP teams of the host phases: no more threads than the container's CPU quota pays for
         std::unique_ptr<das_solver> s(new das_solver);
         s->t0_wall = wall_seconds();
         s->t0_cpu = std::clock();
@@ -4532,7 +4618,7 @@ int das_pc_structure_build(das_solver_t* s, int* nNodes, long long* nBlocks, int
     std::vector<int> unkNode, bcol;
     std::vector<unsigned char> unkSlot;
     std::vector<long long> bptr, bdiag;
-    const int nthr = (int)std::max<long long>(1, std::min<long long>(omp_get_max_threads(), s->opt.geti("amd.setupThreads")));
+    const int nthr = (int)std::max<long long>(1, std::min<long long>(das::host_threads(), s->opt.geti("amd.setupThreads")));
     bilu_build_structure(s->mesh, s->st_full.states, s->n, s->owned, cellOwned, rch, s->pcStruct, unkNode, unkSlot, bptr, bdiag, bcol, nthr, pc_ordering_rcm(s));
     if (nNodes) *nNodes = s->pcStruct.nNodes;
     if (nBlocks) *nBlocks = s->pcStruct.nnzB;

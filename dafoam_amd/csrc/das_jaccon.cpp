@@ -183,7 +183,7 @@ void JacCon::build(const Mesh& m, const Stencil& st) {
     // work items: (state block, entity index) in row order; rows of one item are consecutive
     struct Item { int block; int ent; long long row0; };
     // chunks of entities per block, processed in parallel, concatenated in order
-    const int nthreads = std::max(1, omp_get_max_threads());
+    const int nthreads = std::max(1, das::host_threads());
     struct Chunk { int block; int e0, e1; long long row0; uvector<int> col; std::vector<int> rowlen; };
     std::vector<Chunk> chunks;
     {
@@ -205,7 +205,7 @@ void JacCon::build(const Mesh& m, const Stencil& st) {
         }
         DAS_CHECK(r == n, DAS_ERR_INTERNAL, "row count mismatch in JacCon::build");
     }
-#pragma omp parallel
+#pragma omp parallel num_threads(das::host_threads())
     {
         RowBuilder rb(m, st);
         std::vector<int> row;
@@ -248,7 +248,7 @@ void JacCon::build(const Mesh& m, const Stencil& st) {
         long long off = 0;
         std::vector<long long> choff(chunks.size());
         for (size_t ci = 0; ci < chunks.size(); ci++) { choff[ci] = off; off += (long long)chunks[ci].col.size(); }
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(das::host_threads())
         for (long long ci = 0; ci < (long long)chunks.size(); ci++) {
             Chunk& ch = chunks[ci];
             std::copy(ch.col.begin(), ch.col.end(), col.begin() + choff[ci]);
@@ -281,7 +281,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
     // colouring constraint (for the reference's tables every row of a cell / owned face is a subset
     // of that cell's pRes row).  Generic: the subset test decides, no solver-specific assumption.
     long long nAnch = 0;
-#pragma omp parallel for reduction(max : nAnch) schedule(static)
+#pragma omp parallel for reduction(max : nAnch) schedule(static) num_threads(das::host_threads())
     for (long long r = 0; r < n; r++) nAnch = std::max<long long>(nAnch, con.anchor[r] + 1);
     std::vector<long long> dom(nAnch, -1);
     for (long long r = 0; r < n; r++) {  // (serial: rows of one anchor are not contiguous across the state blocks)
@@ -293,7 +293,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
     {
         // the subset tests are independent per row: flags in parallel, then the kept rows in ascending order
         std::vector<unsigned char> kept(n, 0);
-#pragma omp parallel for schedule(dynamic, 4096)
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(das::host_threads())
         for (long long r = 0; r < n; r++) {
             long long len = con.rowptr[r + 1] - con.rowptr[r];
             if (!len) continue;
@@ -315,7 +315,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
     uvector<int> crow, cpos;  // cpos: position of the column inside the (ascending) column list of that kept row
     {
         const long long nk = (long long)keep.size();
-        const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 32LL, nk}));
+        const int T = (int)std::max<long long>(1, std::min<long long>({(long long)das::host_threads(), 32LL, nk}));
         std::vector<long long> q0(T + 1);
         for (int t = 0; t <= T; t++) q0[t] = nk * t / T;
         std::vector<uvector<int>> cnt(T);
@@ -327,7 +327,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
                 for (long long k = con.rowptr[keep[q]]; k < con.rowptr[keep[q] + 1]; k++) cnt[t][con.col[k]]++;
         }
         // per column: total over the chunks (-> cptr by a serial prefix over n values) and the offset of every chunk inside it
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(das::host_threads())
         for (long long j = 0; j < n; j++) {
             int acc = 0;
             for (int t = 0; t < T; t++) { int c = cnt[t][j]; cnt[t][j] = acc; acc += c; }
@@ -397,7 +397,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         for (long long j = 0; j < n; j++) ncd = std::max(ncd, colors[j] + 1);
         return ncd;
     }
-    const int nth = std::max(1, omp_get_max_threads());
+    const int nth = std::max(1, das::host_threads());
     // Columns are grouped by the cell they live in (anchor) and the cell range is cut into spatially contiguous
     // chunks, so concurrent threads only interact near chunk boundaries (few conflicts, near-serial colour count).
     // DAS_PARALLEL_COLORING=1 selects this speculative variant: ~3.5x faster than serial for ~11 % more colours (451-457
@@ -419,7 +419,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         }
         for (int pass = 0; pass < 100; pass++) {
             std::vector<long long> redo;
-#pragma omp parallel
+#pragma omp parallel num_threads(das::host_threads())
             {
                 std::vector<long long> seen;  // colour -> column seen in this row
                 std::vector<long long> mine;
@@ -485,7 +485,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         // tile adjacency from the kept rows (bit matrix, OR-merged over threads)
         const size_t words = ((size_t)nT * nT + 63) / 64;
         std::vector<unsigned long long> adjBits(words, 0ULL);
-#pragma omp parallel
+#pragma omp parallel num_threads(das::host_threads())
         {
             std::vector<unsigned long long> mine(words, 0ULL);
             std::vector<int> tiles;
@@ -526,7 +526,7 @@ int d2_coloring(const JacCon& con, std::vector<int>& colors, const double* centr
         for (int t = 0; t < nT; t++) phaseTiles[phase[t]].push_back(t);
         for (int ph = 0; ph < nPh; ph++) {
             const std::vector<int>& tl = phaseTiles[ph];
-#pragma omp parallel
+#pragma omp parallel num_threads(das::host_threads())
             {
                 std::vector<long long> forb(4096, -1);
 #pragma omp for schedule(dynamic, 1)
@@ -564,7 +564,7 @@ bool validate_coloring(const JacCon& con, const std::vector<int>& colors) {
         ncol = std::max(ncol, colors[j] + 1);
     }
     bool ok = true;
-#pragma omp parallel
+#pragma omp parallel num_threads(das::host_threads())
     {
         std::vector<long long> seen((size_t)ncol, -1);
 #pragma omp for schedule(static)
@@ -597,7 +597,7 @@ void JacCon::build_transpose() {
     const bool dbg = getenv("DAS_DEBUG_TIMING") != nullptr;
     double tt = wall_seconds();
     auto lap = [&](const char* what) { if (dbg) { double t2 = wall_seconds(); fprintf(stderr, "[dafoam_amd]   maps: %s %.2f s\n", what, t2 - tt); tt = t2; } };
-    const int T = (int)std::max<long long>(1, std::min<long long>({(long long)omp_get_max_threads(), 32LL, n}));
+    const int T = (int)std::max<long long>(1, std::min<long long>({(long long)das::host_threads(), 32LL, n}));
     std::vector<long long> r0(T + 1);
     for (int t = 0; t <= T; t++) r0[t] = n * t / T;
     std::vector<uvector<int>> cnt(T);
@@ -610,7 +610,7 @@ void JacCon::build_transpose() {
     lap("count");
     t_rowptr.assign(n + 1, 0);
     // cnt[t][j] := offset of chunk t inside transposed row j; row lengths -> t_rowptr by a serial prefix over n values
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(das::host_threads())
     for (long long j = 0; j < n; j++) {
         int acc = 0;
         for (int t = 0; t < T; t++) { int c = cnt[t][j]; cnt[t][j] = acc; acc += c; }

@@ -70,8 +70,14 @@ Options::Options() {
     // (round 4, NACA0012, exact LU of the PC matrix as preconditioner): the first-order / second-order mismatch IS the plateau of the
     // adjoint solve (96 iterations at 3200 cells with an exact solve of the first-order matrix, 9 with the operator on the PC pattern); an
     // incomplete factorisation tolerates a partial correction only (ILU(0): 155 -> 132 at 0.35, unstable from 0.5)
-    d["amd.pcUpwindBlend"] = 0.0;
-    s["amd.pcCoarseMode"] = "additive";  // additive | deflated (A-DEF1: one extra operator product per apply)
+    // Round 5: the DEFAULT is 0.5 (round 4 measured it on every workload: NACA0012 wing 2 M cells - no convergence in 1000 iterations at 0,
+    // 905 at 0.5; 200 x 63 section 416 -> 327; channel 191 -> 184: indifferent); 0 restores the reference's upwind div(pc).
+    d["amd.pcUpwindBlend"] = 0.5;
+    // additive | deflated (A-DEF1).  Round 5: "deflated" is the default - the form the wing needs to converge inside the reference's
+    // 1000 / 1000 budget; its extra operator product per apply is replaced by the sparse A Z of the coarse space (coarse_az_ready:
+    // ~1.2 entries per row) wherever the operator is the assembled single-rank matrix
+    s["amd.pcCoarseMode"] = "deflated";
+    i["amd.pcCoarseSparseAZ"] = 1;   // deflated mode: A (Z u) through the precomputed sparse A Z (0: one full operator product per apply)
     i["amd.coloringOnDevice"] = 1;   // serial first-fit colouring as a data-flow kernel (das_color.hpp); 0: host variants
     d["amd.primalTau0"] = 1.0;          // Newton primal: initial pseudo-time factor (diagonal scaled by 1 + 1/tau), SER growth
     d["amd.primalSERExponent"] = 1.5;   // tau = tau0 (|R0| / |R|)^exponent (measured: 1.0 -> 52+ steps, 1.5 -> 20-29, 2.0 -> 17-21 on the bench channels)
@@ -312,7 +318,7 @@ void build_point_influence(const Mesh& m, int rings, int threads, PointInfluence
                 if (f < m.nIF) pc[pos[p]++] = m.neighbour[f];
             }
     }
-    threads = std::max(1, threads);
+    threads = das::host_threads(threads);
     std::vector<std::vector<int>> lists(nP);
 #pragma omp parallel num_threads(threads)
     {

@@ -133,7 +133,7 @@ class DAOPTION(object):
         self.wallDistanceMethod = "default"  # :650
         self.unsteadyCompOutput = {}  # :661
         # MI355X-specific additions (not in the reference)
-        self.amd = {"pcType": "bilu", "pcCoarseAggregates": -1, "pcCoarseField": "p", "pcCoarseMode": "additive", "pcBlockCells": 1024, "jacMode": 1, "pcJacMode": 0, "pcFactorFP32": 0, "cgsAlwaysRefine": 0, "gmresOrthogonalization": "dcgs2", "setupThreads": 32}
+        self.amd = {"pcType": "bilu", "pcCoarseAggregates": -1, "pcCoarseField": "p", "pcCoarseMode": "deflated", "pcUpwindBlend": 0.5, "pcBlockCells": 1024, "jacMode": 1, "pcJacMode": 0, "pcFactorFP32": 0, "cgsAlwaysRefine": 0, "gmresOrthogonalization": "dcgs2", "setupThreads": 32}
         self.amdDevice = 0
         ## directory of the dRdWColoring_<nProcs>.bin cache (the reference keeps it in the case directory,
         ## DAJacCon.C:1886-2019); "" = do not cache

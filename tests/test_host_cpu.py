@@ -839,7 +839,7 @@ def test_amd_option_defaults_and_profile_helpers(tmp_path):
     from dafoam_amd.pyDAFoam import DAOPTION
 
     d = DAOPTION()
-    assert d.amd["gmresOrthogonalization"] == "dcgs2" and d.amd["pcType"] == "bilu" and d.amd["pcCoarseMode"] == "additive"
+    assert d.amd["gmresOrthogonalization"] == "dcgs2" and d.amd["pcType"] == "bilu" and d.amd["pcCoarseMode"] == "deflated" and d.amd["pcUpwindBlend"] == 0.5
     case = channel_case(4, 4, 3)
     s = pyDASolvers(b"DASimpleFoam -python", options(case), case=case)
     buf = C.create_string_buffer(64)

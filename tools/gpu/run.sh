@@ -5,11 +5,11 @@
 # Stages:
 #   tier            the full GPU tier (pytest -m gpu), log kept
 #   test:<expr>     pytest -m gpu -k <expr>
-#   bench[:args]    the default bench line (args appended, ':' separated -> spaces)
+#   bench[:args]    the default bench line (args appended, ',' separated -> spaces)
 #   stats[:args]    rocprofv3 --kernel-trace --stats of bench.py --no-cpu --no-parity (args appended)
 #   pmc[:args]      two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with other trace domains) of the bench window
 #   calib           the PMC counter calibration on pure streams (tools/gpu/pmc_calib.hip)
-#   sweep:<args>    tools/naca_adjoint_sweep.py with the args (':' separated)
+#   sweep:<args>    tools/naca_adjoint_sweep.py with the args (',' separated)
 #   py:<script>[:args]   any python tool under tools/
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -17,7 +17,7 @@ TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 for st in "$@"; do
-  name=${st%%:*}; args=""; [ "$st" != "$name" ] && args=$(echo "${st#*:}" | tr ':' ' ')
+  name=${st%%:*}; args=""; [ "$st" != "$name" ] && args=$(echo "${st#*:}" | tr ',' ' ')
   t0=$(date +%s)
   case $name in
     tier)
