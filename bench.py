@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--parity-tol", type=float, default=1e-9, help="relative residual both sides of the psi parity leg are solved to (bar on the psi difference: 1e-6)")
     ap.add_argument("--no-parity", action="store_true", help="skip the 200 k-cell psi parity leg (GPU vs all-core CPU port)")
     ap.add_argument("--pc-blend", type=float, default=None, help="amd.pcUpwindBlend: weight of the second-order (linearUpwindV) correction in the PC residual "
-                         "(the reference user's choice of div(pc) in fvSchemes); default 0.5 for naca, 0 (upwind) for channel")
+                         "(the reference user's choice of div(pc) in fvSchemes); default: the library's (0.5)")
     ap.add_argument("--deflation", type=int, default=int(os.environ.get("DAS_BENCH_DEFLATION", 0)),
                     help="amd.gmresDeflation k > 0: the full solve runs GMRES with deflated restarting (basis = --solve-restart vectors, k harmonic Ritz vectors kept); "
                          "opt-in, not yet measured on the device (DESIGN.md section 10 item 0b); the timed window stays the undeflated iteration at the solve's mean basis depth")
@@ -77,7 +77,7 @@ def parse():
     ap.add_argument("--solve-maxit", type=int, default=1000)
     ap.add_argument("--converge-primal", action="store_true", help="converge the flow state with the GPU Newton-Krylov primal before the adjoint (opt-in: the adjoint's conditioning does not depend on it, DESIGN.md section 6b)")
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
-    ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE"), help="amd.pcCoarseMode additive | deflated (default: deflated for naca, additive for channel)")
+    ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE"), help="amd.pcCoarseMode additive | deflated (default: the library's, deflated)")
     ap.add_argument("--orth", default=os.environ.get("DAS_BENCH_ORTH", "dcgs2"), help="dcgs2 (delayed re-orthogonalisation, 2 basis reads / iteration) | cgs (reference: refine if needed)")
     return ap.parse_args()
 
@@ -110,8 +110,12 @@ def make_opts(a, dev_index, restart, maxit, rtol):
         "normalizeStates": dict(NORM),
         "adjEqnOption": {"gmresRestart": int(restart), "gmresMaxIters": int(maxit), "gmresRelTol": rtol, "gmresAbsTol": 1e-300, "printInfo": 0,
                          "jacMatReOrdering": a.ordering},
-        "amd": {"pcType": a.pctype, "pcFactorFP32": a.fp32_factor, "maxKrylovBytes": int(a.krylov_gb * 2**30),
-                "pcCoarseAggregates": a.coarse_agg, "pcCoarseMode": a.coarse_mode, "gmresOrthogonalization": a.orth, "pcUpwindBlend": float(a.pc_blend or 0.0)},
+        # amd.*: ONLY what the command line / the device budget asks for explicitly - the preconditioner is the library's own default
+        # (round 5: amd.pcUpwindBlend 0.5 + deflated coarse mode are library defaults, no longer bench switches)
+        "amd": dict({"maxKrylovBytes": int(a.krylov_gb * 2**30)},
+                    **({"pcType": a.pctype} if a.pctype != "bilu" else {}), **({"pcFactorFP32": a.fp32_factor} if a.fp32_factor else {}),
+                    **({"pcCoarseAggregates": a.coarse_agg} if a.coarse_agg != -1 else {}), **({"pcCoarseMode": a.coarse_mode} if a.coarse_mode else {}),
+                    **({"gmresOrthogonalization": a.orth} if a.orth != "dcgs2" else {}), **({"pcUpwindBlend": float(a.pc_blend)} if a.pc_blend is not None else {})),
         "amdDevice": dev_index,
     }
 
@@ -160,10 +164,6 @@ def main():
     t_setup = time.time()
     if world > 1 or a.global_cells > 0:
         a.workload = "channel"  # the sharded path partitions the structured channel into slabs
-    if a.pc_blend is None:
-        a.pc_blend = 0.5 if a.workload == "naca" else 0.0
-    if a.coarse_mode is None:
-        a.coarse_mode = "deflated" if a.workload == "naca" else "additive"
     opts = make_opts(a, dev_index, a.solve_restart, a.solve_maxit, 1e-6)
     sharded = None
     primal, case2d = None, None
@@ -373,7 +373,7 @@ def main():
             if cpu is not None and parity is not None:
                 cpu["psi_rel_diff_gpu_vs_cpu"] = parity.get("psi_rel_diff_gpu_vs_cpu")
         pc_desc = ("node-block ILU(0) of FD dRdWTPC over the whole rank (8-slot cell nodes, 8x8 fp%s blocks), factorised on the device, "
-                   "two sync-free sweeps per apply; + piecewise-constant pressure coarse space (%s)" % ("32" if a.fp32_factor else "64", a.coarse_mode)) if a.pctype == "bilu" else \
+                   "two sync-free sweeps per apply; + piecewise-constant pressure coarse space (%s)" % ("32" if a.fp32_factor else "64", D.getOption("amd")["pcCoarseMode"])) if a.pctype == "bilu" else \
             "RAS(overlap 1)+ILU(1) of FD dRdWTPC, RCB blocks of <= 1024 cells, one workgroup per block"
         out = {
             "metric": "adjoint_gmres_iterations_per_sec",
@@ -420,8 +420,9 @@ def main():
                 "pc_factor_entries": fac_entries,
                 "pc_coarse_aggregates": int(L.das_ksp_get_coarse(ksp.handle, None)),
                 "pc_coarse_aggregates_global": int(global_coarse) if world > 1 else None,
-                "pc_coarse_mode": a.coarse_mode,
-                "pc_upwind_blend": a.pc_blend,
+                "pc_coarse_mode": D.getOption("amd")["pcCoarseMode"],
+                "pc_upwind_blend": D.getOption("amd")["pcUpwindBlend"],
+                "pc_options_passed_by_bench": sorted(k for k in make_opts(a, dev_index, 1, 1, 1e-6)["amd"] if k != "maxKrylovBytes"),
                 "coarse_ms": L.das_timer_avg_ms(h, b"coarse"),
                 "halo_ms": L.das_timer_avg_ms(h, b"halo") if world > 1 else None,
                 # adjoint setup (what the reference does between the primal and the Krylov solve) vs. building the synthetic input
@@ -663,16 +664,29 @@ def psi_parity_200k(a, dev_index, case2d=None):
     t_gpu = time.perf_counter() - t0
     ginf = ksp.info()
     psi_gpu = x.array.copy()
-    h = D.solver._h
     threads = _cpu_threads()
-    K, prep = _cpu_solver(L, h, ksp, P, n, N, int(L.das_op_nnz(h)), int(L.das_mat_nnz(P.handle)), threads)
-    _CPU_STAGE[0] = "CPU GMRES of the parity system"
-    psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=a.parity_tol, abs_tol=1e-300, max_seconds=float(os.environ.get("DAS_BENCH_PARITY_CPU_SECONDS", 200)))
+    # the CPU side ASSEMBLES ITS OWN matrices (oracle/adjoint_host.py via oracle/parity_host.py: connectivity from the stencil tables, own
+    # colouring, the face-based residual port with dual numbers / finite differences) - no matrix of the device run is exported
+    from oracle.parity_host import host_adjoint_solve
+
+    def mark(what):
+        _CPU_STAGE[0] = what
+        stage("   parity leg: " + what)
+
+    blend = float(D.getOption("amd").get("pcUpwindBlend", 0.0))
+    psi_cpu, cinf = host_adjoint_solve(case, NORM, rhs, ksp.pcStructure(), ksp.coarse(N), threads, rel_tol=a.parity_tol, pc_blend=blend, restart=1500, max_iters=3000,
+                                       max_seconds=float(os.environ.get("DAS_BENCH_PARITY_CPU_SECONDS", 200)), stage=mark)
     return {"system": what, "cells": int(N), "states": int(n), "rel_tol_both": a.parity_tol,
             "gpu": {"iterations": int(ginf["iters"]), "seconds": t_gpu, "fail": int(gfail), "rel_residual": ginf["res"] / ginf["res0"] if ginf["res0"] else None},
-            "cpu": {"iterations": int(cinf["iters"]), "seconds": cinf["seconds"], "fail": int(cinf["fail"]), "rel_residual": cinf["res"] / cinf["res0"] if cinf["res0"] else None,
-                    "threads": K.threads, "gmresRestart": 1500, "prep_seconds": prep["prep_seconds"], "ilu_levels": prep["ilu_levels"],
-                    "pc": "node-block ILU(0) restated for the host + additive pressure coarse space"},
+            "cpu": {"matrices": "host-assembled", "iterations": int(cinf["iters"]), "seconds": cinf["seconds"], "fail": int(cinf["fail"]),
+                    "rel_residual": cinf["res"] / cinf["res0"] if cinf["res0"] else None, "threads": cinf["threads"], "gmresRestart": 1500,
+                    "colors": cinf["colors"], "dRdWT_nnz": cinf["dRdWT_nnz"], "dRdWTPC_nnz": cinf["dRdWTPC_nnz"],
+                    "jacobian_build_seconds": {"connectivity_and_colouring": cinf["connectivity_and_colouring_s"], "dRdWTPC_fd": cinf["dRdWTPC_fd_s"],
+                                               "dRdWT_dual": cinf["dRdWT_dual_s"], "total": cinf["jacobian_build_s"]},
+                    "factorisation_seconds": cinf["factorisation_s"],
+                    "assembled_by": "oracle/adjoint_host.py (OpenMP C++: stencil-table connectivity, first-fit colouring, face-based DASimpleFoam+SA residual, dual numbers for "
+                                    "dRdW^T, one-sided differences 1e-6 for dRdWTPC); solved by oracle/csrc/oracle_krylov_omp.c",
+                    "pc": "node-block ILU(0) of the HOST-assembled dRdWTPC on the library's node structure (integer tables) + additive pressure coarse space"},
             "psi_rel_diff_gpu_vs_cpu": float(np.linalg.norm(psi_gpu - psi_cpu) / np.linalg.norm(psi_cpu)), "bar": 1e-6}
 
 

@@ -56,11 +56,9 @@ def test_naca_wing_200k_cells_adjoint_in_budget_and_psi_against_the_cpu_port():
     1.6 M states), polished by Newton steps on the extruded mesh.  (1) The adjoint of the volume-mean x-velocity converges inside
     the reference's default budget gmresRestart = gmresMaxIters = 1000 at 1e-6 (fail = 0, DALinearEqn.C:422-434).  (2) psi: the
     same system solved to 1e-10 by the GPU path and - independently - by the oracle's all-core CPU port (OpenMP CSR SpMV,
-    the node-block ILU(0) restated for the host, GMRES; oracle/csrc/oracle_krylov_omp.c) on the matrices copied back from the device:
+    the node-block ILU(0) restated for the host, GMRES; oracle/csrc/oracle_krylov_omp.c) on matrices ASSEMBLED ON THE HOST by the oracle's own
+    C++ residual port (oracle/adjoint_host.py; round 5 - rounds 3-4 handed the CPU solver the matrices of the device):
     |psi_gpu - psi_cpu| <= 1e-6 |psi_cpu| (north_star bar)."""
-    import ctypes as C
-
-    from dafoam_amd import _capi
     from dafoam_amd.pyDAFoam import PYDAFOAM
     from dafoam_amd.pyDASolvers import KSP, Mat, Vec
     from dafoam_amd.workloads import naca_extruded_case
@@ -96,23 +94,15 @@ def test_naca_wing_200k_cells_adjoint_in_budget_and_psi_against_the_cpu_port():
     fail = D.solverAD.solveLinearEqn(ksp, b, x)
     assert fail == 0
     psi_gpu = x.array.copy()
-    L = _capi.lib()
-    h = D.solver._h
+    from oracle.parity_host import host_adjoint_solve
 
-    def export(fn, handle, nnz):
-        rp, ci, v = np.empty(n + 1, np.int64), np.empty(nnz, np.int32), np.empty(nnz, np.float64)
-        assert fn(handle, rp.ctypes.data_as(C.POINTER(C.c_longlong)), ci.ctypes.data_as(C.POINTER(C.c_int)), v.ctypes.data_as(C.POINTER(C.c_double))) >= 0
-        return rp, ci, v
-
-    K = OL.OmpKrylov(OL.available_cpus())  # affinity AND cgroup quota: more threads than the container is paid for run throttled
-    K.set_operator(export(L.das_op_export, h, int(L.das_op_nnz(h))))
-    Pm = export(L.das_mat_export, P.handle, int(L.das_mat_nnz(P.handle)))
-    K.set_pc_bilu(Pm, ksp.pcStructure())  # the node-block ILU(0) restated for the host, same structure and PC matrix
-    nagg, agg = ksp.coarse(N)
-    if nagg > 0:
-        K.set_coarse(Pm, 3 * N, N, agg)
-    psi_cpu, cinf = K.gmres(rhs, restart=1500, max_iters=3000, rel_tol=1e-10, abs_tol=1e-300, max_seconds=240.0)
-    print("CPU port:", cinf["iters"], "iterations,", round(cinf["seconds"], 1), "s on", K.threads, "threads; levels", K.levels, "rel", cinf["res"] / cinf["res0"])
+    # the CPU side assembles its OWN dRdW^T and dRdWTPC (oracle/adjoint_host.py: connectivity from the stencil tables, first-fit colouring,
+    # face-based residual with dual numbers / finite differences) - nothing of the device matrices is exported
+    blend = float(D.getOption("amd").get("pcUpwindBlend", 0.0))
+    psi_cpu, cinf = host_adjoint_solve(case, NORM, rhs, ksp.pcStructure(), ksp.coarse(N), OL.available_cpus(), rel_tol=1e-10, pc_blend=blend,
+                                       restart=1500, max_iters=3000, max_seconds=240.0)
+    print("CPU side (host-assembled):", cinf["iters"], "iterations,", round(cinf["seconds"], 1), "s GMRES +", round(cinf["jacobian_build_s"], 1), "s Jacobians on", cinf["threads"],
+          "threads;", cinf["colors"], "colours; rel", cinf["res"] / cinf["res0"])
     if cinf["res"] > 1e-10 * cinf["res0"] and cinf["seconds"] >= 240.0:
         pytest.skip(f"the host did not finish the independent CPU solve inside its time bound ({cinf['iters']} iterations, rel {cinf['res'] / cinf['res0']:.1e}); bench.py reports the same check")
     assert cinf["fail"] == 0
