@@ -263,6 +263,7 @@ _SIGS = {
     "das_ksp_get_info": (C.c_int, [_VP, c_int_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_get_history": (C.c_int, [_VP, c_double_p, C.c_int]),
     "das_ksp_get_cycle_lengths": (C.c_int, [_VP, c_int_p, C.c_int]),
+    "das_ksp_get_basis_info": (C.c_int, [_VP, c_int_p, c_double_p, c_double_p]),
     "das_ksp_get_n_refine": (C.c_int, [_VP]),
     "das_set_dense_eig_callback": (C.c_int, [_VP]),
     "das_debug_gmres_dr_host": (C.c_int, [C.c_longlong, _VP, _VP, _VP, c_double_p, c_double_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_longlong, c_double_p, C.c_int,

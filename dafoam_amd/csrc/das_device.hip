@@ -349,8 +349,10 @@ __global__ __launch_bounds__(256) void k_spmv_wave(long long n, const long long*
 #define SPMV_GRID(n) dim3(nblk((n), 256 / SPMV_LANES))
 
 // partial[i*nb + blk] = sum over this block's chunk of V_i . w   (i < m); last slot (i == m) = w . w
+// (VT: storage type of the Krylov basis - double, or float for the compressed basis of amd.krylovBasisPrecision; all sums in fp64)
 #define MD_CHUNK 1024
-__global__ __launch_bounds__(256) void k_multidot(long long n, int m, const double* __restrict__ V, long long ldv, const double* __restrict__ w,
+template <class VT>
+__global__ __launch_bounds__(256) void k_multidot(long long n, int m, const VT* __restrict__ V, long long ldv, const double* __restrict__ w,
                                                   double* __restrict__ partial, int nb) {
     __shared__ double red[4];
     long long base = (long long)blockIdx.x * MD_CHUNK;
@@ -363,11 +365,11 @@ __global__ __launch_bounds__(256) void k_multidot(long long n, int m, const doub
     for (int i = 0; i <= m; i++) {
         double s = 0.0;
         if (i < m) {
-            const double* vi = V + (long long)i * ldv;
+            const VT* vi = V + (long long)i * ldv;
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 long long k = base + threadIdx.x + 256 * t;
-                if (k < n) s += vi[k] * wr[t];
+                if (k < n) s += (double)vi[k] * wr[t];
             }
         } else {
 #pragma unroll
@@ -393,13 +395,14 @@ __global__ __launch_bounds__(256) void k_reduce(int nb, const double* __restrict
     if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 // w -= sum_i h_i V_i
-__global__ __launch_bounds__(256) void k_multiaxpy(long long n, int m, const double* __restrict__ V, long long ldv, const double* __restrict__ h,
-                                                   double* __restrict__ w) {
+template <class VT, class WT>
+__global__ __launch_bounds__(256) void k_multiaxpy(long long n, int m, const VT* __restrict__ V, long long ldv, const double* __restrict__ h,
+                                                   WT* __restrict__ w) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    double s = w[k];
-    for (int i = 0; i < m; i++) s -= h[i] * V[(long long)i * ldv + k];
-    w[k] = s;
+    double s = (double)w[k];
+    for (int i = 0; i < m; i++) s -= h[i] * (double)V[(long long)i * ldv + k];
+    w[k] = (WT)s;
 }
 // Two right-hand sides against K basis vectors in ONE pass over the basis (the fused inner products of the delayed
 // re-orthogonalisation, gmres_iter_dcgs2): partial[(r K + i) nbw + slot] = this wave's part of V_i . (r == 0 ? u : v).
@@ -409,8 +412,8 @@ __global__ __launch_bounds__(256) void k_multiaxpy(long long n, int m, const dou
 #define MD2_ROWS 16
 #endif
 #define MD2_CHUNK (256 * MD2_ROWS)
-template <int ROWS, bool FULL>
-__device__ __forceinline__ void multidot2_body(long long n, int K, const double* __restrict__ V, long long ldv, const double* __restrict__ u,
+template <int ROWS, bool FULL, class VT>
+__device__ __forceinline__ void multidot2_body(long long n, int K, const VT* __restrict__ V, long long ldv, const VT* __restrict__ u,
                                                const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
     const int lane = threadIdx.x & 63, g = lane >> 3;
     const long long base = (long long)blockIdx.x * (256 * ROWS) + threadIdx.x;
@@ -420,7 +423,7 @@ __device__ __forceinline__ void multidot2_body(long long n, int K, const double*
     for (int t = 0; t < ROWS; t++) {
         const long long k = FULL ? base + 256 * t : min(base + 256 * t, n - 1);  // clamped loads, masked below: no branches
         const double m = (FULL || base + 256 * t < n) ? 1.0 : 0.0;
-        ur[t] = m * u[k];
+        ur[t] = m * (double)u[k];
         vr[t] = m * v[k];
     }
     for (int i0 = 0; i0 < K; i0 += 4) {
@@ -429,9 +432,9 @@ __device__ __forceinline__ void multidot2_body(long long n, int K, const double*
         // loads in flight for registers and waits after every load)
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
-            const double* vi = V + (long long)min(i0 + ii, K - 1) * ldv;
+            const VT* vi = V + (long long)min(i0 + ii, K - 1) * ldv;
 #pragma unroll
-            for (int t = 0; t < ROWS; t++) x[ii][t] = vi[FULL ? base + 256 * t : min(base + 256 * t, n - 1)];  // ur, vr are zero beyond n
+            for (int t = 0; t < ROWS; t++) x[ii][t] = (double)vi[FULL ? base + 256 * t : min(base + 256 * t, n - 1)];  // ur, vr are zero beyond n
         }
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
@@ -466,11 +469,11 @@ __device__ __forceinline__ void multidot2_body(long long n, int K, const double*
         if ((lane & 7) == 0 && i < K) partial[((long long)(g & 1) * K + i) * nbw + slot] = a1;
     }
 }
-template <int ROWS>
-__global__ __launch_bounds__(256) void k_multidot2(long long n, int K, const double* __restrict__ V, long long ldv, const double* __restrict__ u,
+template <int ROWS, class VT>
+__global__ __launch_bounds__(256) void k_multidot2(long long n, int K, const VT* __restrict__ V, long long ldv, const VT* __restrict__ u,
                                                    const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
-    if ((long long)(blockIdx.x + 1) * (256 * ROWS) <= n) multidot2_body<ROWS, true>(n, K, V, ldv, u, v, partial, nbw);
-    else multidot2_body<ROWS, false>(n, K, V, ldv, u, v, partial, nbw);
+    if ((long long)(blockIdx.x + 1) * (256 * ROWS) <= n) multidot2_body<ROWS, true, VT>(n, K, V, ldv, u, v, partial, nbw);
+    else multidot2_body<ROWS, false, VT>(n, K, V, ldv, u, v, partial, nbw);
 }
 // The fused update of the delayed re-orthogonalisation, one pass over the basis: with Q = the j final vectors, u = slot j
 // (projected once), v = the operator applied to u:   q_j = (u - Q s) / alpha  -> slot j,
@@ -481,8 +484,8 @@ __global__ __launch_bounds__(256) void k_multidot2(long long n, int K, const dou
 #ifndef DCGS2_RPT
 #define DCGS2_RPT 2
 #endif
-template <int UNROLL, int RPT>
-__global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, double* __restrict__ V, long long ldv, const double* __restrict__ sc,
+template <int UNROLL, int RPT, class VT>
+__global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, VT* __restrict__ V, long long ldv, const double* __restrict__ sc,
                                                       double gamma, double ralpha, const double* __restrict__ v) {
     const long long k0 = ((long long)blockIdx.x * RPT) * blockDim.x + threadIdx.x;  // rows k0 + r * blockDim.x
     const double* s = sc;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, double
 #pragma unroll
         for (int t = 0; t < UNROLL; t++)
 #pragma unroll
-            for (int r = 0; r < RPT; r++) q[t][r] = V[(long long)(i + t) * ldv + kk[r]];
+            for (int r = 0; r < RPT; r++) q[t][r] = (double)V[(long long)(i + t) * ldv + kk[r]];
 #pragma unroll
         for (int t = 0; t < UNROLL; t++)
 #pragma unroll
@@ -505,28 +508,30 @@ __global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, double
     }
     for (; i < j; i++)
 #pragma unroll
-        for (int r = 0; r < RPT; r++) { const double q = V[(long long)i * ldv + kk[r]]; as[r] += s[i] * q; ac[r] += c[i] * q; }
+        for (int r = 0; r < RPT; r++) { const double q = (double)V[(long long)i * ldv + kk[r]]; as[r] += s[i] * q; ac[r] += c[i] * q; }
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
         const long long k = k0 + (long long)r * blockDim.x;
         if (k >= n) continue;
-        const double u = V[(long long)j * ldv + k];
-        V[(long long)j * ldv + k] = (u - as[r]) * ralpha;
-        V[(long long)(j + 1) * ldv + k] = (v[k] - gamma * u - ac[r]) * ralpha;
+        const double u = (double)V[(long long)j * ldv + k];
+        V[(long long)j * ldv + k] = (VT)((u - as[r]) * ralpha);
+        V[(long long)(j + 1) * ldv + k] = (VT)((v[k] - gamma * u - ac[r]) * ralpha);
     }
 }
 // y = sum_i c_i V_i
-__global__ __launch_bounds__(256) void k_lincomb(long long n, int m, const double* __restrict__ V, long long ldv, const double* __restrict__ c,
+template <class VT>
+__global__ __launch_bounds__(256) void k_lincomb(long long n, int m, const VT* __restrict__ V, long long ldv, const double* __restrict__ c,
                                                  double* __restrict__ y) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     double s = 0.0;
-    for (int i = 0; i < m; i++) s += c[i] * V[(long long)i * ldv + k];
+    for (int i = 0; i < m; i++) s += c[i] * (double)V[(long long)i * ldv + k];
     y[k] = s;
 }
-__global__ void k_scale_to(long long n, double a, const double* __restrict__ x, double* __restrict__ y) {
+template <class TI, class TO>
+__global__ void k_scale_to(long long n, double a, const TI* __restrict__ x, TO* __restrict__ y) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) y[k] = a * x[k];
+    if (k < n) y[k] = (TO)(a * (double)x[k]);
 }
 __global__ void k_axpby(long long n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -668,7 +673,7 @@ __global__ void k_coarse_prolong(long long N, long long n, long long off, const 
 // A Z for the deflated coarse mode: row i of the operator summed over the field-block columns of every aggregate.  One thread per
 // row, entries in storage order (deterministic); a row whose field columns touch more than AZ_CAP aggregates sets `overflow` (the
 // caller then keeps the full operator product).  pass 0: counts -> cnt[i]; pass 1: fills (ptr from the prefix sum of the counts)
-constexpr int AZ_CAP = 12;
+constexpr int AZ_CAP = 64;  // (round 5: 12 overflowed on the wing - RCB boxes next to the wall are 4 cells thick spanwise, a 7-cell stencil meets 3 x 3 x 2 of them)
 __global__ __launch_bounds__(256) void k_az_build(long long n, const long long* __restrict__ rp, const int* __restrict__ ci, const double* __restrict__ v,
                                                   long long N, long long off, const int* __restrict__ agg, int pass, int* __restrict__ cnt,
                                                   const long long* __restrict__ ptr, int* __restrict__ oa, double* __restrict__ ov, int* __restrict__ overflow) {
@@ -999,6 +1004,10 @@ struct das_ksp {
     int restart = 0;
     VmBuf<double> V;  // Krylov basis: up to 129 GB (reference default restart at 2 M cells) - mapped chunk by chunk through the VM API
     long long Vn = 0; // vector length the basis was reserved for
+    // compressed basis (amd.krylovBasisPrecision, gmres_ws): the basis vectors are STORED in fp32 (half the bytes of the two Gram-Schmidt
+    // passes, which are most of an iteration at depth > 150), all inner products / updates / the Hessenberg matrix stay fp64
+    bool vf32 = false;
+    DevBuf<double> ustage;  // fp64 copy of the basis vector the preconditioner is applied to (fp32 basis only)
     DevBuf<double> w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
     std::unique_ptr<struct GmresRun> run;
     std::unique_ptr<struct BlockWork> block;
@@ -2091,8 +2100,18 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
     // real memory: then exactly what this restart needs (~2.8 GB per KSP on small cases otherwise)
     if ((size_t)wantVec * (size_t)n * sizeof(double) < ((size_t)4 << 30) || getenv("DAS_NO_VMM")) wantVec = restart + 2;
     if (k->V.n < (size_t)((restart + 2) * n) || k->Vn != n) {
-        k->V.reserve((size_t)(wantVec * n));
+        k->V.reserve((size_t)(wantVec * n));  // (sized for fp64 vectors whatever the storage type of this solve: switching needs no new range)
         k->Vn = n;
+    }
+    {   // storage type of the basis.  "auto" (default): fp32 when the tolerance is looser than what a compressed basis delivers per cycle
+        // (CB-GMRES, Aliaga et al. 2022: the recurrence tracks the true residual to ~1e-7 of |r0|); always fp64 for tight tolerances
+        // (the parity tests solve to 1e-10 .. 1e-12), modified Gram-Schmidt, deflated restarting and the Newton primal's inner solves
+        std::string prec = "auto";
+        { auto ip = s->opt.s.find("amd.krylovBasisPrecision"); if (ip != s->opt.s.end()) prec = ip->second; }
+        DAS_CHECK(prec == "auto" || prec == "fp64" || prec == "fp32", DAS_ERR_ARG, "amd.krylovBasisPrecision: auto | fp64 | fp32");
+        const bool eligible = s->opt.geti("adjEqnOption.useMGSO") == 0 && !s->fwd.on;
+        k->vf32 = eligible && (prec == "fp32" || (prec == "auto" && s->opt.getd("adjEqnOption.gmresRelTol") >= 1e-7 && (size_t)(restart + 2) * (size_t)n * 8 >= ((size_t)1 << 30)));
+        if (k->vf32 && k->ustage.n != (size_t)n) k->ustage.alloc(n);
     }
     if (k->restart != restart || k->w.n != (size_t)n) {
         k->restart = (int)restart;
@@ -2107,12 +2126,17 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
 // the helper thread of the buffer maps 64 vectors ahead of the iteration; the solver waits only if it catches up
 // false: the device cannot hold that many vectors (gmres_advance then closes the cycle: the mapped part is the restart length)
 static inline bool gmres_map_basis(das_solver* s, das_ksp* k, long long nvec) {
-    k->V.request((size_t)((nvec + 64) * s->n));
-    return k->V.try_ensure((size_t)(nvec * s->n));
+    const long long per = k->vf32 ? (s->n + 1) / 2 : s->n;  // fp64 elements of the range one basis vector occupies
+    k->V.request((size_t)((nvec + 64) * per));
+    return k->V.try_ensure((size_t)(nvec * per));
 }
+// slot j of the basis in its storage type
+template <class VT>
+static inline VT* basis_slot(das_solver* s, das_ksp* k, long long j) { return reinterpret_cast<VT*>(k->V.p) + j * s->n; }
 
 // dev_out[0..m) = V^T w (V = m vectors of stride n starting at Vbase), dev_out[m] = w.w; summed over the ranks
-static void multidot_dev(das_solver* s, das_ksp* k, const double* Vbase, int m, const double* w, double* dev_out) {
+template <class VT>
+static void multidot_dev(das_solver* s, das_ksp* k, const VT* Vbase, int m, const double* w, double* dev_out) {
     const long long n = s->n;
     int nb = nblk(n, MD_CHUNK);
     hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, n, m, Vbase, n, w, k->partial.p, nb);
@@ -2120,8 +2144,9 @@ static void multidot_dev(das_solver* s, das_ksp* k, const double* Vbase, int m, 
     if (!(s->halo.active && s->halo.allreduce(dev_out, m + 1, s->stream)) && s->allreduce_cb) s->allreduce_cb(dev_out, m + 1, s->comm_user);
 }
 // h[0..m) = V^T w, h[m] = w.w  (device result in k->hdev, copied to host)
+template <class VT = double>
 static void multidot(das_solver* s, das_ksp* k, int m, const double* w, double* h_host) {
-    multidot_dev(s, k, k->V.p, m, w, k->hdev.p);
+    multidot_dev<VT>(s, k, basis_slot<VT>(s, k, 0), m, w, k->hdev.p);
     DAS_HIP(hipMemcpyAsync(h_host, k->hdev.p, (m + 1) * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     DAS_HIP(hipStreamSynchronize(s->stream));
 }
@@ -2146,7 +2171,11 @@ static bool coarse_az_ready(das_solver* s, das_ksp* k) {
     hipLaunchKernelGGL(k_az_build, dim3(nblk(n, 256)), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.val.p, C.N, C.off, C.agg.p, 0, cnt.p, (const long long*)nullptr,
                        (int*)nullptr, (double*)nullptr, ovf.p);
     DAS_HIP(hipStreamSynchronize(st));
-    if (ovf.to_host()[0]) { C.azFailed = true; return false; }
+    if (ovf.to_host()[0]) {
+        C.azFailed = true;
+        fprintf(stderr, "[dafoam_amd] deflated coarse mode: a row of the operator touches more than %d aggregates - keeping the full operator product per apply\n", AZ_CAP);
+        return false;
+    }
     std::vector<int> h = cnt.to_host();
     std::vector<long long> ptr(n + 1, 0);
     for (long long i = 0; i < n; i++) ptr[i + 1] = ptr[i] + h[i];
@@ -2253,6 +2282,9 @@ struct GmresRun {
     bool memWarned = false;
     long long its = 0, maxIts = 0;
     double beta = 0, target = 0, rtol = 0, atol = 0, t0 = 0;
+    double recTarget = 0;     // what the RECURRENCE residual is driven to: the target, or half of it with the fp32 (compressed) basis,
+                              // whose recurrence tracks the true residual only to ~1e-7 |r0| - so that the recomputed TRUE residual of
+                              // the closing cycle lands below the target instead of opening another cycle (and another plateau)
     const double* d_rhs = nullptr;
     double* d_x = nullptr;
     std::vector<double> H, cs, sn, g, hh, h2, y;
@@ -2315,12 +2347,14 @@ static void gmres_begin(das_solver* s, das_ksp* k, const double* d_rhs, double* 
     k->res0 = G.beta;
     k->hist.push_back(G.beta);
     G.target = std::max(G.rtol * G.beta, G.atol);
+    G.recTarget = k->vf32 ? 0.5 * G.target : G.target;
 }
 static void gmres_cycle_start(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
     const long long n = s->n;
     DAS_CHECK(gmres_map_basis(s, k, 3), DAS_ERR_INTERNAL, "GMRES: no device memory for three Krylov vectors (" + k->V.workerError + ")");
-    hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, k->r.p, k->V.p);
+    if (k->vf32) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, (const double*)k->r.p, basis_slot<float>(s, k, 0));
+    else hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, (const double*)k->r.p, k->V.p);
     std::fill(G.g.begin(), G.g.end(), 0.0);
     G.g[0] = G.beta;
     G.j = 0;
@@ -2329,19 +2363,28 @@ static void gmres_cycle_start(das_solver* s, das_ksp* k) {
     G.earlyClose = false;
     G.betaStart = G.beta;
 }
+// the basis vector in slot j as the fp64 input of the preconditioner (fp32 basis: converted into the staging vector)
+template <class VT>
+static const double* basis_as_double(das_solver* s, das_ksp* k, long long j) {
+    if (sizeof(VT) == sizeof(double)) return reinterpret_cast<const double*>(basis_slot<VT>(s, k, j));
+    hipLaunchKernelGGL(k_scale_to, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, 1.0, (const VT*)basis_slot<VT>(s, k, j), k->ustage.p);
+    return k->ustage.p;
+}
 // one Arnoldi step; returns the recurrence residual norm
+template <class VT>
 static double gmres_iter_dcgs2(das_solver* s, das_ksp* k);
-static double gmres_iter(das_solver* s, das_ksp* k) {
+template <class VT>
+static double gmres_iter_t(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
-    if (G.dcgs2 && !G.safeOrth) return gmres_iter_dcgs2(s, k);
+    if (G.dcgs2 && !G.safeOrth) return gmres_iter_dcgs2<VT>(s, k);
     const long long n = s->n;
     const int B = 256, m = G.m, j = G.j;
     hipStream_t st = s->stream;
     const bool alwaysRefine = s->opt.geti("amd.cgsAlwaysRefine") != 0;
     const bool mgs = s->opt.geti("adjEqnOption.useMGSO") != 0;
     std::vector<double>&H = G.H, &hh = G.hh, &h2 = G.h2, &cs = G.cs, &sn = G.sn, &g = G.g;
-    double* vj = k->V.p + (long long)j * n;
-    pc_apply_full(s, k, vj, k->z.p);
+    VT* const Vb = basis_slot<VT>(s, k, 0);
+    pc_apply_full(s, k, basis_as_double<VT>(s, k, j), k->z.p);
     apply_operator(s, k->z.p, k->w.p);
     double hn;
     std::fill(h2.begin(), h2.end(), 0.0);
@@ -2349,11 +2392,11 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
         // modified Gram-Schmidt: j+1 dependent (dot, axpy) pairs, coefficients stay on the device until the end
         double* hcol = k->hdev.p + (m + 2);
         for (int i = 0; i <= j; i++) {
-            multidot_dev(s, k, k->V.p + (long long)i * n, 1, k->w.p, k->hdev.p);
+            multidot_dev<VT>(s, k, Vb + (long long)i * n, 1, k->w.p, k->hdev.p);
             DAS_HIP(hipMemcpyAsync(hcol + i, k->hdev.p, sizeof(double), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, 1, k->V.p + (long long)i * n, n, k->hdev.p, k->w.p);
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, 1, (const VT*)(Vb + (long long)i * n), n, (const double*)k->hdev.p, k->w.p);
         }
-        multidot_dev(s, k, k->V.p, 0, k->w.p, k->hdev.p);
+        multidot_dev<VT>(s, k, Vb, 0, k->w.p, k->hdev.p);
         DAS_HIP(hipMemcpyAsync(hcol + j + 1, k->hdev.p, sizeof(double), hipMemcpyDeviceToDevice, st));
         DAS_HIP(hipMemcpyAsync(hh.data(), hcol, (j + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
         DAS_HIP(hipStreamSynchronize(st));
@@ -2362,17 +2405,17 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
         // classical Gram-Schmidt, one fused pass: h = V^T w and w.w; refinement only if needed (reference:
         // KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160): refine when the projected vector keeps less than half
         // of its squared norm, i.e. ||w - V h||^2 (= w.w - h.h) < h.h
-        multidot(s, k, j + 1, k->w.p, hh.data());
-        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
+        multidot<VT>(s, k, j + 1, k->w.p, hh.data());
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, n, (const double*)k->hdev.p, k->w.p);
         double hsq = 0.0;
         for (int i = 0; i <= j; i++) hsq += hh[i] * hh[i];
         const double ww = hh[j + 1];
         const double est = ww - hsq;
         if (alwaysRefine || !(est > hsq) || !(est > 0.0)) {
-            multidot(s, k, j + 1, k->w.p, h2.data());
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, k->V.p, n, k->hdev.p, k->w.p);
+            multidot<VT>(s, k, j + 1, k->w.p, h2.data());
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, n, (const double*)k->hdev.p, k->w.p);
             double hn2;
-            multidot(s, k, 0, k->w.p, &hn2);
+            multidot<VT>(s, k, 0, k->w.p, &hn2);
             hn = std::sqrt(std::max(hn2, 0.0));
             k->nrefine++;
         } else {
@@ -2382,7 +2425,7 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
     if (!mgs && !(hn > GMRES_BREAKDOWN_TOL * std::sqrt(std::max(hh[j + 1], 0.0)))) { hn = 0.0; G.nBreakdown++; }  // happy breakdown (hh[j+1] = |A M^-1 v_j|^2)
     for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = hh[i] + h2[i];
     H[(size_t)(j + 1) * m + j] = hn;
-    if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, k->w.p, k->V.p + (long long)(j + 1) * n);
+    if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, (const double*)k->w.p, Vb + (long long)(j + 1) * n);
     for (int i = 0; i < j; i++) {
         double a = H[(size_t)i * m + j], b2 = H[(size_t)(i + 1) * m + j];
         H[(size_t)i * m + j] = cs[i] * a + sn[i] * b2;
@@ -2403,6 +2446,7 @@ static double gmres_iter(das_solver* s, das_ksp* k) {
     if (hn == 0.0) { G.j = -G.j; G.earlyClose = true; }  // happy breakdown: close the cycle (sign marks it)
     return res;
 }
+static double gmres_iter(das_solver* s, das_ksp* k) { return k->vf32 ? gmres_iter_t<float>(s, k) : gmres_iter_t<double>(s, k); }
 // Givens update of Hessenberg column `col` (entries H[0..col+1][col] already set); returns the recurrence residual norm
 static double gmres_rotate_column(GmresRun& G, int col) {
     const int m = G.m;
@@ -2440,17 +2484,19 @@ static double gmres_rotate_column(GmresRun& G, int col) {
 //   q_j and u' come out of one more pass over the basis (k_dcgs2_update).
 // The Hessenberg column (and with it the residual norm) of a step is known one step later; a solve that stops after k
 // columns has applied the operator k + 1 times.
+template <class VT>
 static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
     const long long n = s->n;
     const int m = G.m, j = G.pend;
     hipStream_t st = s->stream;
-    double* u = k->V.p + (long long)j * n;
-    pc_apply_full(s, k, u, k->z.p);
+    VT* const Vb = basis_slot<VT>(s, k, 0);
+    VT* u = Vb + (long long)j * n;
+    pc_apply_full(s, k, basis_as_double<VT>(s, k, j), k->z.p);
     apply_operator(s, k->z.p, k->w.p);
     const int K = j + 1;
     const long long nbw = 4LL * nblk(n, MD2_CHUNK);
-    hipLaunchKernelGGL(k_multidot2<MD2_ROWS>, dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, k->V.p, n, u, k->w.p, k->partial.p, nbw);
+    hipLaunchKernelGGL((k_multidot2<MD2_ROWS, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, (const VT*)Vb, n, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
     hipLaunchKernelGGL(k_reduce, dim3(2 * K), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
     if (!(s->halo.active && s->halo.allreduce(k->hdev.p, 2 * K, st)) && s->allreduce_cb) s->allreduce_cb(k->hdev.p, 2 * K, s->comm_user);
     std::vector<double>& o = G.hh;
@@ -2471,8 +2517,8 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
         // orthogonality was lost - and uu - s.s cancels.  Rare; pay one extra pass: c = u - Q s explicitly, then c.c and c.v
         double* dsc = k->hdev.p + 2 * (m + 3);
         DAS_HIP(hipMemcpyAsync(dsc, sv, j * sizeof(double), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, k->V.p, n, dsc, u);
-        hipLaunchKernelGGL(k_multidot2<MD2_ROWS>, dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, 1, u, n, u, k->w.p, k->partial.p, nbw);
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, (const VT*)Vb, n, (const double*)dsc, u);
+        hipLaunchKernelGGL((k_multidot2<MD2_ROWS, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, 1, (const VT*)u, n, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
         hipLaunchKernelGGL(k_reduce, dim3(2), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
         if (!(s->halo.active && s->halo.allreduce(k->hdev.p, 2, st)) && s->allreduce_cb) s->allreduce_cb(k->hdev.p, 2, s->comm_user);
         double cc[2] = {0.0, 0.0};
@@ -2507,7 +2553,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
             G.j = -G.j; G.earlyClose = true;
             return res;
         }
-        const bool stop = !G.fixed && (res <= G.target || G.its >= G.maxIts);
+        const bool stop = !G.fixed && (res <= G.recTarget || G.its >= G.maxIts);
         if (stop || G.j >= m) return res;            // the cycle is closed by the caller: no further basis vector needed
     }
     const double gam = num / al2;
@@ -2516,7 +2562,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     for (int i = 0; i < j; i++) { co[i] = sv[i]; co[j + i] = tv[i] - gam * sv[i]; }
     double* dco = k->hdev.p + 2 * (m + 3);
     if (j > 0) DAS_HIP(hipMemcpyAsync(dco, co.data(), 2 * j * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, k->V.p, n, dco, gam, 1.0 / al, k->w.p);
+    hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT, VT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, Vb, n, (const double*)dco, gam, 1.0 / al, (const double*)k->w.p);
     // first-projection coefficients of the new pending vector: (t - H_jj s) / alpha, gamma - s_{j-1}
     for (int i = 0; i < j; i++) {
         double a = tv[i];
@@ -2528,7 +2574,8 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     return res;
 }
 // back substitution, x += M^{-1} (V y), true residual
-static void gmres_cycle_end(das_solver* s, das_ksp* k) {
+template <class VT>
+static void gmres_cycle_end_t(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
     const long long n = s->n;
     const int B = 256, m = G.m, j = std::abs(G.j);
@@ -2539,13 +2586,16 @@ static void gmres_cycle_end(das_solver* s, das_ksp* k) {
         G.y[i] = sacc / G.H[(size_t)i * m + i];
     }
     DAS_HIP(hipMemcpyAsync(k->hdev.p, G.y.data(), j * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, j, k->V.p, n, k->hdev.p, k->w.p);
+    hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, j, (const VT*)basis_slot<VT>(s, k, 0), n, k->hdev.p, k->w.p);
     pc_apply_full(s, k, k->w.p, k->z.p);
     hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, k->z.p, 1.0, G.d_x);
     gmres_true_residual(s, k, G, true);
     k->hist.back() = G.beta;
     k->cycleLens.push_back(j);
     G.open = false;
+}
+static void gmres_cycle_end(das_solver* s, das_ksp* k) {
+    if (k->vf32) gmres_cycle_end_t<float>(s, k); else gmres_cycle_end_t<double>(s, k);
 }
 // advance by up to `nsteps` iterations (cycles are opened / closed as needed); returns true when the solve is over
 static bool gmres_over(const GmresRun& G) { return !G.fixed && !G.open && (G.beta <= G.target || G.its >= G.maxIts || G.stalled); }
@@ -2572,13 +2622,13 @@ static bool gmres_advance(das_solver* s, das_ksp* k, long long nsteps) {
             continue;
         }
         const double res = gmres_iter(s, k);
-        const bool stop = !G.fixed && (res <= G.target || G.its >= G.maxIts);
+        const bool stop = !G.fixed && (res <= G.recTarget || G.its >= G.maxIts);
         if (G.j < 0 || G.j >= G.m || stop) {
             // a cycle that ends on a breakdown / lost orthogonality, or on a recurrence residual below the target, should
             // leave a TRUE residual below the target.  If it does not, the next cycle works on the rounding level of this
             // system; it may still gain (iterative refinement), but two such cycles in a row that do not halve the true
             // residual mean the attainable accuracy is reached: stop instead of spending gmresMaxIters on one-step cycles
-            const bool judged = G.earlyClose || (res <= G.target && G.its < G.maxIts);
+            const bool judged = G.earlyClose || (res <= G.recTarget && G.its < G.maxIts);
             gmres_cycle_end(s, k);
             if (!G.fixed && judged && G.beta > G.target) {
                 if (G.beta < 0.5 * G.betaStart) G.nonImproving = 0;
@@ -2928,6 +2978,7 @@ static int run_gmres_dr(das_solver* s, das_ksp* k, const double* d_rhs, double* 
     DAS_CHECK(s->op || s->fwd.on, DAS_ERR_STATE, "initializedRdWTMatrixFree() must be called before solveLinearEqn()");
     DAS_CHECK(!s->halo.active && !s->halo_cb, DAS_ERR_ARG, "amd.gmresDeflation is single-rank (the restart's small dense algebra is not replicated across ranks yet)");
     gmres_ws(s, k);
+    k->vf32 = false;  // the deflated solver keeps its (short) basis in fp64
     if (k->useBilu) bilu_clear_abort(k->bilu, s->stream);
     if (!k->run) k->run.reset(new GmresRun);
     GmresRun& G = *k->run;
@@ -4754,6 +4805,15 @@ int das_ksp_get_history(das_ksp_t* k, double* hist, int cap) {
     int m = std::min<int>(cap, (int)k->hist.size());
     std::copy(k->hist.begin(), k->hist.begin() + m, hist);
     return m;
+    DAS_CATCH
+}
+int das_ksp_get_basis_info(das_ksp_t* k, int* fp32, double* mappedBytes, double* bytesPerVector) {
+    DAS_TRY
+    DAS_CHECK(k, DAS_ERR_ARG, "null argument");
+    if (fp32) *fp32 = k->vf32 ? 1 : 0;
+    if (mappedBytes) *mappedBytes = (double)k->V.mappedBytes;
+    if (bytesPerVector) *bytesPerVector = (double)k->Vn * (k->vf32 ? 4.0 : 8.0);
+    return DAS_OK;
     DAS_CATCH
 }
 int das_ksp_get_cycle_lengths(das_ksp_t* k, int* lens, int cap) {

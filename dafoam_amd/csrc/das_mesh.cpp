@@ -117,6 +117,9 @@ Options::Options() {
     // > 0: GMRES with deflated restarting (GMRES-DR): gmresRestart basis vectors, this many harmonic Ritz vectors carried across restarts
     // (round 4: prototyped on the CPU, tools/gmres_dr_study.py; the device path has not been measured yet - opt-in, default off)
     i["amd.gmresDeflation"] = 0;
+    // storage type of the Krylov basis: "fp64" | "fp32" (compressed basis: vectors stored in fp32, every sum in fp64 - half the bytes of the
+    // Gram-Schmidt passes) | "auto" (default): fp32 when gmresRelTol >= 1e-7 and the basis is >= 1 GB, fp64 otherwise (gmres_ws)
+    s["amd.krylovBasisPrecision"] = "auto";
 }
 double Options::getd(const std::string& k) const {
     auto it = d.find(k);

@@ -226,6 +226,12 @@ class KSP:
         m = check(lib().das_ksp_get_history(self.handle, dptr(buf), buf.size))
         return buf[:m]
 
+    def basisInfo(self):
+        """Krylov basis of the last solve: dict(fp32 (compressed basis, amd.krylovBasisPrecision), mappedGB, bytesPerVector)."""
+        f, mb, bv = C.c_int(0), C.c_double(0), C.c_double(0)
+        check(lib().das_ksp_get_basis_info(self.handle, C.byref(f), C.byref(mb), C.byref(bv)))
+        return dict(fp32=bool(f.value), mappedGB=mb.value / 2**30, bytesPerVector=bv.value)
+
     def cycleLengths(self):
         """Columns of every closed Arnoldi cycle of the last solve (all but the last equal gmresRestart, DALinearEqn.C:155)."""
         buf = np.zeros(max(1, self.getIterationNumber() + 2), np.int32)

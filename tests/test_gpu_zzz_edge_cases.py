@@ -185,3 +185,36 @@ def test_gmres_deflated_restarting_matches_the_default_solver():
     print("iterations: full", it_full, "GMRES-DR(20, 8)", it_dr, "GMRES(20)", it_pl)
     assert f0 == 0 and f1 == 0 and relerr(psi_dr, psi_full) < 1e-7
     assert it_full <= it_dr <= 2 * it_full + 10 and (it_dr < it_pl or f2 != 0)
+
+
+def test_compressed_fp32_krylov_basis_reaches_the_same_psi():
+    """amd.krylovBasisPrecision (round 5): the basis vectors stored in fp32 (compressed-basis GMRES: half the bytes of the two Gram-Schmidt
+    passes), every inner product / update / the Hessenberg matrix in fp64.  Against the fp64 basis on the same system at gmresRelTol
+    1e-6: fail 0 on the TRUE (recomputed) residual, the iteration count within a few steps (the recurrence is driven to half the
+    target), psi equal to the accuracy both solves have; "auto" picks fp64 for this small basis and for tight tolerances."""
+    case = channel_case(24, 14, 10, perturb=0.0, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    n = case.states.size
+    rhs = np.zeros(n)
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= J.state_scales(case, g, norm_states(case))
+    out = {}
+    for prec in ("fp64", "fp32", "auto"):
+        D = make(case, adjEqnOption={"gmresRelTol": 1e-6, "gmresAbsTol": 1e-300, "gmresRestart": 400, "gmresMaxIters": 800, "printInfo": 0}, amd={"krylovBasisPrecision": prec})
+        psi, fail = D.solveAdjoint(rhs)
+        info = D.ksp.info()
+        out[prec] = (psi, fail, info["iters"], info["res"] / info["res0"], D.ksp.basisInfo())
+        print(prec, "iterations", info["iters"], "rel", info["res"] / info["res0"], D.ksp.basisInfo())
+    assert out["fp32"][4]["fp32"] and not out["fp64"][4]["fp32"] and not out["auto"][4]["fp32"]
+    for prec in ("fp64", "fp32"):
+        assert out[prec][1] == 0 and out[prec][3] <= 1e-6
+    assert abs(out["fp32"][2] - out["fp64"][2]) <= 6 + 0.05 * out["fp64"][2], (out["fp32"][2], out["fp64"][2])
+    assert relerr(out["fp32"][0], out["fp64"][0]) < 1e-4  # both are 1e-6-residual solutions of the same system
+    assert out["fp32"][4]["bytesPerVector"] * 2 == out["fp64"][4]["bytesPerVector"]
+    # a tight tolerance through the compressed basis: restarts act as iterative refinement, the true residual still gets there
+    D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "gmresAbsTol": 1e-300, "gmresRestart": 400, "gmresMaxIters": 2000, "printInfo": 0}, amd={"krylovBasisPrecision": "fp32"})
+    psi10, fail10 = D.solveAdjoint(rhs)
+    D64 = make(case, adjEqnOption={"gmresRelTol": 1e-10, "gmresAbsTol": 1e-300, "gmresRestart": 400, "gmresMaxIters": 2000, "printInfo": 0}, amd={"krylovBasisPrecision": "fp64"})
+    psi64, fail64 = D64.solveAdjoint(rhs)
+    print("1e-10: fp32 basis", D.ksp.info()["iters"], "iterations in cycles", D.ksp.cycleLengths(), "; fp64", D64.ksp.info()["iters"])
+    assert fail10 == 0 and fail64 == 0 and relerr(psi10, psi64) < 1e-7
