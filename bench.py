@@ -1,10 +1,15 @@
 #!/usr/bin/env python
 """bench.py - adjoint hot-path benchmark (BASELINE.json metric: adjoint GMRES iterations/s + dRdWTPsi GB/s).
 
-Workload at N = 1 (default `--workload naca`): BASELINE configs[2] - DASimpleFoam + SA, 2 M-cell NACA0012 wing section (O-grid of
-800 x 250 cells around the airfoil extruded to 10 spanwise layers, first cell 2e-5 chords, far field 20 chords), one GPU, full GMRES
-adjoint, linearised about a CONVERGED primal: the flow is solved first by this library's Newton-Krylov primal with grid sequencing
-(dafoam_amd/workloads.py; untimed set-up, reported).  `--workload channel` is the round-1..3 bump channel (also the N > 1 workload).
+Workload (default `--workload naca`, at EVERY N): BASELINE configs[2] - DASimpleFoam + SA on a 2.016 M-cell NACA0012 wing section: the
+O-grid section of --naca 200 x 63 cells (first cell 4e-5 chords, far field 20 chords) extruded to 160 spanwise layers of 0.025 chords
+between symmetry planes, full GMRES adjoint, linearised about a CONVERGED primal: the flow is solved first by this library's
+Newton-Krylov primal with grid sequencing on the section, extrusion and a Newton polish on the wing (dafoam_amd/workloads.py; untimed
+set-up, reported).  The 800 x 250 section BASELINE.md names converges as a primal but its adjoint needs > 1000 iterations.
+N > 1: the SAME wing about the SAME primal (converged on rank 0), cut into N spanwise slabs, ONE global solve ("scaling": "strong").
+`--workload channel` is the round-1..3 bump channel (weak scaling, or --global-cells for a fixed global size).
+No preconditioner option is passed: amd.pcUpwindBlend 0.5, the deflated coarse mode and the compressed Krylov basis are the LIBRARY's
+defaults (config.pc_options_passed_by_bench lists what the command line overrode: normally nothing).
 One "step" = one right-preconditioned GMRES iteration of the adjoint solve: node-block ILU(0) apply (two sync-free triangular
 sweeps) + coarse correction + dRdW^T.z SpMV + orthogonalisation against the j basis vectors + norm, on the device-resident system
 assembled by coloured dual-number / FD perturbation of the HIP residual.  Matrices, rhs and Krylov basis are resident in HBM.
@@ -13,15 +18,17 @@ Order of events: set-up -> the FULL solve to gmresRelTol = 1e-6 with the referen
 `config.solve`: iterations, time_to_tolerance_s, fail flag of DALinearEqn.C:422-434) -> the TIMED WINDOW of the driver contract:
 a second solve of the same system is advanced untimed to the MEAN basis depth of the full solve (at least --warmup iterations),
 then EXACTLY K (= --steps) iterations are timed.  The orthogonalisation cost grows linearly with the basis depth, so the window
-rate is the mean rate of the whole solve (config.solve.iterations_per_sec_whole_solve is printed beside it; VERDICT round 3 item 4:
-a window at j < 25 flattered the number).  `--window-at-warmup` restores the old window at j in [W, W + K).
+rate is the mean rate of the whole solve (config.solve.iterations_per_sec_whole_solve is printed beside it; rounds 1-3 timed the window
+[W, W + K) at small depths - `--window-at-warmup` restores that, config.value_is says which one a line carries).
 
   python bench.py --gpus 1 --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
 Prints ONE JSON line (rank 0) with `roofline` (dRdW^T.psi SpMV, HIP-event timed on the launch stream), `roofline_pc`,
-`roofline_iteration` and `cpu_baseline`: the oracle's all-core OpenMP C port (oracle/csrc/oracle_krylov_omp.c) on the SAME
-operator and PC matrix at the bench size (copied back from the device), plus `psi_parity`: the 200 k-cell system of the same
-family solved to 1e-10 by the GPU path and by the CPU port, |psi_gpu - psi_cpu| / |psi_cpu|.
+`roofline_iteration` and `cpu_baseline`: the oracle's OpenMP C port (oracle/csrc/oracle_krylov_omp.c; threads = the container's CPU
+quota) iterating on the SAME operator and PC matrix at the bench size (copied back from the device; the sample sits at basis depths
+j < ~35, the GPU window at the solve's mean depth), plus `psi_parity_200k`: the 198 k-cell wing of the same family solved to
+--parity-tol (1e-9) by the GPU path and by an INDEPENDENT host pipeline that assembles its own dRdW^T / dRdWTPC
+(oracle/adjoint_host.py) - |psi_gpu - psi_cpu| / |psi_cpu| and the host's Jacobian-build time beside the GPU's.
 """
 import argparse
 import ctypes as C
@@ -61,7 +68,7 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the 200 k-cell psi parity leg (GPU vs all-core CPU port)")
     ap.add_argument("--pc-blend", type=float, default=None, help="amd.pcUpwindBlend: weight of the second-order (linearUpwindV) correction in the PC residual "
                          "(the reference user's choice of div(pc) in fvSchemes); default: the library's (0.5)")
-    ap.add_argument("--deflation", type=int, default=int(os.environ.get("DAS_BENCH_DEFLATION", 0)),
+    ap.add_argument("--deflation", type=int, default=0,
                     help="amd.gmresDeflation k > 0: the full solve runs GMRES with deflated restarting (basis = --solve-restart vectors, k harmonic Ritz vectors kept); "
                          "opt-in, not yet measured on the device (DESIGN.md section 10 item 0b); the timed window stays the undeflated iteration at the solve's mean basis depth")
     ap.add_argument("--ordering", default=os.environ.get("DAS_BENCH_ORDERING", "rcm"), help="adjEqnOption.jacMatReOrdering: rcm | natural")
@@ -162,12 +169,44 @@ def main():
 
     L = _capi.lib()
     t_setup = time.time()
-    if world > 1 or a.global_cells > 0:
-        a.workload = "channel"  # the sharded path partitions the structured channel into slabs
+    if a.global_cells > 0:
+        a.workload = "channel"  # --global-cells: the structured channel cut into slabs (strong scaling of a synthetic size)
     opts = make_opts(a, dev_index, a.solve_restart, a.solve_maxit, 1e-6)
     sharded = None
     primal, case2d = None, None
-    if world > 1:
+    if world > 1 and a.workload == "naca":
+        # N > 1 keeps the N = 1 workload: the SAME wing, linearised about the SAME converged primal, cut into N
+        # spanwise slabs of whole cell layers (strong scaling).  Rank 0 converges the primal on its GPU exactly like the N = 1 run
+        # (section by grid sequencing, extrusion, Newton polish), extracts every rank's extended sub-mesh (owned cells + 3 ghost rings)
+        # and scatters them - the reference's decomposePar step done in memory (pyDAFoam.py:597-604)
+        from dafoam_amd.distributed import ShardedAdjointGeneral
+
+        gcase, part = None, None
+        if rank == 0:
+            from dafoam_amd.workloads import naca_converged_primal, naca_extruded_case
+
+            t0 = time.time()
+            if a.naca_synthetic:
+                from dafoam_amd.meshgen import naca0012_case
+
+                gcase = naca0012_case(a.naca[0], a.naca[1], a.naca[2], span=a.naca_dz * a.naca[2], first_cell=a.naca_first_cell)
+            else:
+                case2d, lv = naca_converged_primal(a.naca[0], a.naca[1], options=opts, first_cell=a.naca_first_cell, verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
+                gcase, ex = naca_extruded_case(case2d, (a.naca[0], a.naca[1]), a.naca[2], dz=a.naca_dz, first_cell=a.naca_first_cell, options=opts,
+                                               verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
+                primal = {"method": "rank 0: pseudo-transient Newton-Krylov (das_solve_primal), grid sequencing, spanwise extrusion, Newton polish; then scattered",
+                          "levels": [{k: (list(v) if isinstance(v, tuple) else v) for k, v in r.items()} for r in lv],
+                          "extruded": {k: (list(v) if isinstance(v, tuple) else v) for k, v in ex.items()}, "seconds": time.time() - t0}
+            # spanwise slabs of whole layers (the generator numbers the cells layer by layer: layer = cell // (n_around * n_normal))
+            layer = np.arange(gcase.mesh.n_cells, dtype=np.int64) // (a.naca[0] * a.naca[1])
+            part = (layer * world // a.naca[2]).astype(np.int32)
+            stage(f"rank 0: global wing ready ({gcase.mesh.n_cells} cells), scattering {world} sub-meshes")
+        sharded = ShardedAdjointGeneral.scattered(gcase, part, opts, device_index=dev_index, src=0)
+        del gcase
+        D = sharded.D
+        case = sharded.case
+        ncell = int(sharded.owned[3 * case.mesh.n_cells : 4 * case.mesh.n_cells].sum())  # owned cells of this rank (p block of the owned mask)
+    elif world > 1:
         # weak scaling: the global channel has nx*world cell columns, every rank owns nx of them (+3 ghost layers)
         from dafoam_amd.distributed import ShardedAdjoint
 
@@ -243,7 +282,8 @@ def main():
     # dF/dW scaled like the reference scales its right-hand sides
     N = case.mesh.n_cells
     rhs_h = np.zeros(n)
-    rhs_h[0 : 3 * N : 3] = 1.0 / (N * world)
+    n_global = int(L.das_get_n_global_cells(h)) if sharded is not None else N
+    rhs_h[0 : 3 * N : 3] = 1.0 / n_global
     if sharded is not None:
         rhs_h = np.where(sharded.owned, rhs_h, 0.0)
     rhs = torch.from_numpy(rhs_h).cuda()
@@ -297,6 +337,7 @@ def main():
         binfo = ksp.basisInfo()
         solve = {"converged": fail == 0, "fail": int(fail), "iterations": its, "time_to_tolerance_s": t_solve,
                  "krylov_basis": {"storage": "fp32 (compressed basis; sums, Hessenberg matrix, residuals fp64)" if binfo["fp32"] else "fp64",
+                                  "inner_products_read": "a bf16 copy of the basis (amd.krylovDotCopy; the update pass reads / writes fp64)" if binfo["dotCopy"] else "the basis itself",
                                   "mapped_GB": binfo["mappedGB"], "bytes_per_vector": binfo["bytesPerVector"]},
                  "rel_residual": inf["res"] / inf["res0"] if inf["res0"] else None, "gmresRelTol": 1e-6,
                  "gmresRestart": r_eff, "gmresMaxIters": a.solve_maxit, "mean_basis_depth": mean_depth, "gmresDeflation": int(a.deflation) if world == 1 else 0,
@@ -360,8 +401,11 @@ def main():
     iter_bytes = spmv_bytes + pc_bytes + 32.0 * jmean * n + 48.0 * n  # BASELINE.md section 3 (CGS with refinement: 4 basis reads)
     # what this implementation has to move: the delayed re-orthogonalisation reads the basis twice per iteration
     orth = a.orth
-    basis_b = 4.0 if ksp.basisInfo()["fp32"] else 8.0
-    moved_bytes = products * spmv_bytes + pc_bytes + (2.0 if orth == "dcgs2" else 4.0) * basis_b * jmean * n + 48.0 * n
+    bi = ksp.basisInfo()
+    basis_b = 4.0 if bi["fp32"] else 8.0
+    # delayed re-orthogonalisation: one inner-product pass (2 B per entry with the bf16 dot copy) + one update pass over the basis
+    orth_bytes = ((2.0 if bi["dotCopy"] else basis_b) + basis_b) * jmean * n if orth == "dcgs2" else 4.0 * basis_b * jmean * n
+    moved_bytes = products * spmv_bytes + pc_bytes + orth_bytes + 48.0 * n
     ms_step = dt / a.steps * 1e3
     stage(f"window: {a.steps} steps at depth {j0}: {ms_step:.2f} ms per step")
 
@@ -378,6 +422,12 @@ def main():
             stage(f"psi parity leg: {({k: v for k, v in parity.items() if k in ('psi_rel_diff_gpu_vs_cpu', 'error')})}")
             if cpu is not None and parity is not None:
                 cpu["psi_rel_diff_gpu_vs_cpu"] = parity.get("psi_rel_diff_gpu_vs_cpu")
+                # the reference path INCLUDING the Jacobian build (north_star): measured on the 198 k-cell system of the parity leg, where the
+                # host assembles its own matrices (at the bench size the host build would take ~10x as long: ~7 min on the container's quota)
+                if isinstance(parity.get("cpu"), dict) and "jacobian_build_seconds" in parity["cpu"]:
+                    cpu["jacobian_build_at_200k_cells"] = {"cpu_host_assembled_s": parity["cpu"]["jacobian_build_seconds"]["total"],
+                                                          "gpu_s": parity["gpu"]["jacobian_build_seconds"]["total"], "cpu_threads": parity["cpu"]["threads"],
+                                                          "cpu_solve_s": parity["cpu"]["seconds"], "gpu_solve_s": parity["gpu"]["seconds"]}
         pc_desc = ("node-block ILU(0) of FD dRdWTPC over the whole rank (8-slot cell nodes, 8x8 fp%s blocks), factorised on the device, "
                    "two sync-free sweeps per apply; + piecewise-constant pressure coarse space (%s)" % ("32" if a.fp32_factor else "64", D.getOption("amd")["pcCoarseMode"])) if a.pctype == "bilu" else \
             "RAS(overlap 1)+ILU(1) of FD dRdWTPC, RCB blocks of <= 1024 cells, one workgroup per block"
@@ -392,14 +442,15 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "strong" if a.global_cells > 0 else "weak",
+            # naca: the SAME wing at every N (total work fixed); channel: nx x ny x nz cells per GPU (weak) unless --global-cells
+            "scaling": "strong" if (a.global_cells > 0 or a.workload == "naca") else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": (f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell hex mesh per GPU ({a.nx}x{a.ny}x{a.nz} bump channel, wall-normal "
                              f"grading; state: prolonged converged coarse primal)" if a.workload != "naca" else
-                             f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell NACA0012 wing section (O-grid, {a.naca[0]} around x {a.naca[1]} normal x {a.naca[2]} "
+                             f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {n_global}-cell NACA0012 wing section (O-grid, {a.naca[0]} around x {a.naca[1]} normal x {a.naca[2]} "
                              f"spanwise hexahedra of {a.naca_dz} chords, first cell {a.naca_first_cell:g} chords, far field 20 chords, U 10 m/s, AoA 2 deg, Re 6.7e5; "
                              + ("synthetic noisy boundary-layer state)" if a.naca_synthetic else
                                 "linearised about the primal CONVERGED on the GPU: Newton-Krylov, grid sequencing, |R| = %.2e)" % primal_residual_norm))
@@ -412,9 +463,11 @@ def main():
                 "window_start_depth": j0,
                 "primal_residual_norm": primal_residual_norm,
                 "cells_per_gpu": ncell,
-                "global_cells": ncell * world,
+                "global_cells": n_global,
+                "partition": (None if world == 1 else ("spanwise slabs of whole cell layers, 3 ghost rings per cut (ShardedAdjointGeneral.scattered from rank 0)" if a.workload == "naca"
+                                                       else "slabs along x, 3 ghost layers per cut (ShardedAdjoint)")),
                 "global_solve_iterations_per_sec": a.steps * 1.0 / dt,
-                "cell_iterations_per_sec": ncell * world * a.steps * 1.0 / dt,
+                "cell_iterations_per_sec": n_global * a.steps * 1.0 / dt,
                 "aggregation": "value = iterations/s of the one global solve (weak scaling: flat = ideal); cell_iterations_per_sec = global cells x value",
                 "states_per_gpu": n,
                 "dRdWT_nnz": op_nnz,
@@ -611,7 +664,8 @@ def cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, gpu_sp
         "unit": "iter/s",
         "cores": K.threads,
         "kind": "port",
-        "sample": f"{iters} GMRES iterations (basis sizes j < {iters}) of the SAME {N}-cell system at the bench size - operator ({op_nnz} nnz) and PC matrix ({pc_nnz} nnz) "
+        "sample": f"{iters} GMRES iterations at basis sizes j < {iters} (the GPU window sits at the mean depth of its full solve, several hundred vectors: its orthogonalisation "
+                  f"works on a ~10x deeper basis - the comparison flatters the CPU) of the SAME {N}-cell system at the bench size - operator ({op_nnz} nnz) and PC matrix ({pc_nnz} nnz) "
                   f"copied back from the device - with the oracle's OpenMP C port (gcc -O3 -march=x86-64-v3 -fopenmp, {K.threads} threads = every CPU the container may use "
                   f"(affinity and CFS quota; the host shows {os.cpu_count()}), first-touch placement): CSR SpMV, "
                   f"the node-block ILU(0) of the GPU path restated for the host ({prep['nodes']} nodes, {prep['blocks']} dense 8x8 blocks, {prep['ilu_levels']} levels, "
@@ -655,12 +709,18 @@ def psi_parity_200k(a, dev_index, case2d=None):
         case, what = bench_channel_case(100, 50, 40), "bump channel 100 x 50 x 40"
     D = PYDAFOAM(options=make_opts(a, dev_index, 2000, 2000, a.parity_tol), case=case)  # restart 2000: no restart inside the plateau of the residual history
     n, N = D.getNLocalAdjointStates(), case.mesh.n_cells
+    tj = time.perf_counter()
     D.solver.runColoring()
+    t_gcol = time.perf_counter() - tj
+    tj = time.perf_counter()
     P = Mat()
     D.solver.calcdRdWT(1, P)
+    t_gpc = time.perf_counter() - tj
     ksp = KSP()
     D.solverAD.createMLRKSPMatrixFree(P, ksp)
+    tj = time.perf_counter()
     D.solverAD.initializedRdWTMatrixFree()
+    t_gop = time.perf_counter() - tj
     rhs = np.zeros(n)
     rhs[0 : 3 * N : 3] = 1.0 / N
     b, x = Vec(n), Vec(n)
@@ -683,7 +743,8 @@ def psi_parity_200k(a, dev_index, case2d=None):
     psi_cpu, cinf = host_adjoint_solve(case, NORM, rhs, ksp.pcStructure(), ksp.coarse(N), threads, rel_tol=a.parity_tol, pc_blend=blend, restart=1500, max_iters=3000,
                                        max_seconds=float(os.environ.get("DAS_BENCH_PARITY_CPU_SECONDS", 200)), stage=mark)
     return {"system": what, "cells": int(N), "states": int(n), "rel_tol_both": a.parity_tol,
-            "gpu": {"iterations": int(ginf["iters"]), "seconds": t_gpu, "fail": int(gfail), "rel_residual": ginf["res"] / ginf["res0"] if ginf["res0"] else None},
+            "gpu": {"iterations": int(ginf["iters"]), "seconds": t_gpu, "fail": int(gfail), "rel_residual": ginf["res"] / ginf["res0"] if ginf["res0"] else None,
+                    "jacobian_build_seconds": {"connectivity_and_colouring": t_gcol, "dRdWTPC_fd": t_gpc, "dRdWT_dual": t_gop, "total": t_gcol + t_gpc + t_gop}},
             "cpu": {"matrices": "host-assembled", "iterations": int(cinf["iters"]), "seconds": cinf["seconds"], "fail": int(cinf["fail"]),
                     "rel_residual": cinf["res"] / cinf["res0"] if cinf["res0"] else None, "threads": cinf["threads"], "gmresRestart": 1500,
                     "colors": cinf["colors"], "dRdWT_nnz": cinf["dRdWT_nnz"], "dRdWTPC_nnz": cinf["dRdWTPC_nnz"],

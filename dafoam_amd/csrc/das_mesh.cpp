@@ -118,8 +118,11 @@ Options::Options() {
     // (round 4: prototyped on the CPU, tools/gmres_dr_study.py; the device path has not been measured yet - opt-in, default off)
     i["amd.gmresDeflation"] = 0;
     // storage type of the Krylov basis: "fp64" | "fp32" (compressed basis: vectors stored in fp32, every sum in fp64 - half the bytes of the
-    // Gram-Schmidt passes) | "auto" (default): fp32 when gmresRelTol >= 1e-7 and the basis is >= 1 GB, fp64 otherwise (gmres_ws)
+    // Gram-Schmidt passes) | "auto" (default) = fp64: fp32 storage breaks the Arnoldi relation by eps32 |y| and cost the wing its convergence (gmres_ws)
     s["amd.krylovBasisPrecision"] = "auto";
+    // "bf16": the inner-product pass of the delayed re-orthogonalisation reads a bf16 COPY of the basis (2 instead of 8 bytes per entry), the
+    // update pass keeps fp64 - the Arnoldi relation stays exact, the basis is orthogonal to ~1e-3; "none"; "auto" (default): on for bases >= 1 GB
+    s["amd.krylovDotCopy"] = "auto";
 }
 double Options::getd(const std::string& k) const {
     auto it = d.find(k);

@@ -87,7 +87,10 @@ class Engine:
 
             self.D = PYDAFOAM(options={"solverName": case.solver_name, "normalizeStates": dict(norm_states),
                                        "adjEqnOption": {"gmresRelTol": 1e-10, "gmresMaxIters": 2000, "printInfo": 0},
-                                       "jacLowerBounds": {"dRdW": 0.0, "dRdWPC": 0.0}}, case=case)
+                                       "jacLowerBounds": {"dRdW": 0.0, "dRdWPC": 0.0},
+                                       # a DAFoam dump's dRdWTPC was assembled with the case's div(pc) = upwind: the reference PC semantics,
+                                       # not this library's default blend (amd.pcUpwindBlend 0.5)
+                                       "amd": {"pcUpwindBlend": 0.0}}, case=case)
             self.D.solver.runColoring()
             self._Mat = Mat
         else:

@@ -211,7 +211,21 @@ def test_compressed_fp32_krylov_basis_reaches_the_same_psi():
     assert abs(out["fp32"][2] - out["fp64"][2]) <= 6 + 0.05 * out["fp64"][2], (out["fp32"][2], out["fp64"][2])
     assert relerr(out["fp32"][0], out["fp64"][0]) < 1e-4  # both are 1e-6-residual solutions of the same system
     assert out["fp32"][4]["bytesPerVector"] * 2 == out["fp64"][4]["bytesPerVector"]
-    # a tight tolerance through the compressed basis: restarts act as iterative refinement, the true residual still gets there
+    # amd.krylovDotCopy "bf16" (the default for bases >= 1 GB): the inner products read a bf16 copy, the updates stay fp64 - the Arnoldi relation
+    # is exact, so the TRUE residual meets the tolerance in the first cycle, at (nearly) the iteration count of the plain solver, also at 1e-10
+    for rtol in (1e-6, 1e-10):
+        res = {}
+        for dc in ("none", "bf16"):
+            D = make(case, adjEqnOption={"gmresRelTol": rtol, "gmresAbsTol": 1e-300, "gmresRestart": 800, "gmresMaxIters": 800, "printInfo": 0}, amd={"krylovDotCopy": dc})
+            psi, fail = D.solveAdjoint(rhs)
+            info = D.ksp.info()
+            res[dc] = (psi, fail, info["iters"], info["res"] / info["res0"], D.ksp.basisInfo(), D.ksp.cycleLengths())
+            print("dot copy", dc, "rtol", rtol, "iterations", info["iters"], "rel", info["res"] / info["res0"], "cycles", D.ksp.cycleLengths())
+        assert res["bf16"][4]["dotCopy"] and not res["none"][4]["dotCopy"]
+        assert res["bf16"][1] == 0 and res["none"][1] == 0 and res["bf16"][3] <= rtol
+        assert len(res["bf16"][5]) == 1 and abs(res["bf16"][2] - res["none"][2]) <= 4 + 0.03 * res["none"][2], (res["bf16"][2], res["none"][2])
+        assert relerr(res["bf16"][0], res["none"][0]) < 100 * rtol
+    # a tight tolerance through the compressed (fp32-stored) basis: restarts act as iterative refinement, the true residual still gets there
     D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "gmresAbsTol": 1e-300, "gmresRestart": 400, "gmresMaxIters": 2000, "printInfo": 0}, amd={"krylovBasisPrecision": "fp32"})
     psi10, fail10 = D.solveAdjoint(rhs)
     D64 = make(case, adjEqnOption={"gmresRelTol": 1e-10, "gmresAbsTol": 1e-300, "gmresRestart": 400, "gmresMaxIters": 2000, "printInfo": 0}, amd={"krylovBasisPrecision": "fp64"})

@@ -46,3 +46,33 @@ def test_strong_scaling_bench_flow_one_and_two_ranks():
     # the same global problem: the 2-rank solve (block-Jacobi ILU across ranks + ONE global coarse space) needs a comparable count
     i1, i2 = d1["config"]["solve"]["iterations"], d2["config"]["solve"]["iterations"]
     assert i2 <= 1.6 * i1 + 20, (i1, i2)
+
+
+def _run_naca(nranks):
+    env = dict(os.environ, DAS_BENCH_ONE_GPU="1", DAS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["bench.py", "--gpus", str(nranks), "--naca", "100", "31", "8", "--naca-dz", "0.1", "--naca-first-cell", "8e-5", "--steps", "10", "--warmup", "5", "--no-cpu", "--no-parity",
+            "--krylov-gb", "4"]
+    if nranks == 1:
+        cmd = [sys.executable] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_default_wing_workload_keeps_its_family_with_two_ranks():
+    """`bench.py --gpus N` keeps the N = 1 workload - the NACA0012 wing about the primal converged on rank 0, cut into
+    spanwise slabs (ShardedAdjointGeneral.scattered), ONE global solve with the library's default preconditioner options.  One and two
+    ranks (both on GPU 0, gloo staging) on a small wing: the same global mesh, converged solves, a comparable iteration count."""
+    d1, d2 = _run_naca(1), _run_naca(2)
+    for d, n in ((d1, 1), (d2, 2)):
+        c = d["config"]
+        assert d["scaling"] == "strong" and d["n_gpus"] == n and "NACA0012 wing" in c["workload"]
+        assert c["global_cells"] == 100 * 31 * 8 and c["cells_per_gpu"] * n == c["global_cells"]
+        assert c["solve"]["fail"] == 0 and c["solve"]["rel_residual"] <= 2e-6
+        assert c["pc_options_passed_by_bench"] == []
+    assert d2["config"]["halo_ms"] is not None and d2["config"]["partition"].startswith("spanwise slabs")
+    i1, i2 = d1["config"]["solve"]["iterations"], d2["config"]["solve"]["iterations"]
+    assert i2 <= 1.6 * i1 + 30, (i1, i2)

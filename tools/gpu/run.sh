@@ -35,6 +35,8 @@ for st in "$@"; do
         timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --no-cpu --no-parity --no-solve --window-at-warmup $args > /dev/null 2> $O/pmc_$c.err
       done
       cd $R; python tools/pmc_summary.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $O/pmc_per_kernel.json 2> $O/pmc_summary.err; head -c 3000 $O/pmc_per_kernel.json; rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE ;;
+    hop)
+      hipcc --offload-arch=gfx950 -O3 -o /tmp/hop tools/gpu/hop_latency.hip 2>/dev/null && timeout 60 /tmp/hop | tee $O/hop_latency.log ;;
     calib)
       hipcc --offload-arch=gfx950 -O3 -o /tmp/pmc_calib tools/gpu/pmc_calib.hip && /tmp/pmc_calib 8 > $O/pmc_calib_times.log
       cd /tmp
