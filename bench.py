@@ -86,6 +86,7 @@ def parse():
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
     ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE"), help="amd.pcCoarseMode additive | deflated (default: the library's, deflated)")
     ap.add_argument("--orth", default=os.environ.get("DAS_BENCH_ORTH", "dcgs2"), help="dcgs2 (delayed re-orthogonalisation, 2 basis reads / iteration) | cgs (reference: refine if needed)")
+    ap.add_argument("--amd", action="append", default=[], metavar="KEY=VALUE", help="experiments: any amd.* option, e.g. --amd gradFaceParallel=0 (listed in config.pc_options_passed_by_bench)")
     return ap.parse_args()
 
 
@@ -122,9 +123,24 @@ def make_opts(a, dev_index, restart, maxit, rtol):
         "amd": dict({"maxKrylovBytes": int(a.krylov_gb * 2**30)},
                     **({"pcType": a.pctype} if a.pctype != "bilu" else {}), **({"pcFactorFP32": a.fp32_factor} if a.fp32_factor else {}),
                     **({"pcCoarseAggregates": a.coarse_agg} if a.coarse_agg != -1 else {}), **({"pcCoarseMode": a.coarse_mode} if a.coarse_mode else {}),
-                    **({"gmresOrthogonalization": a.orth} if a.orth != "dcgs2" else {}), **({"pcUpwindBlend": float(a.pc_blend)} if a.pc_blend is not None else {})),
+                    **({"gmresOrthogonalization": a.orth} if a.orth != "dcgs2" else {}), **({"pcUpwindBlend": float(a.pc_blend)} if a.pc_blend is not None else {}),
+                    **_amd_overrides(a)),
         "amdDevice": dev_index,
     }
+
+
+def _amd_overrides(a):
+    out = {}
+    for kv in a.amd:
+        k, v = kv.split("=", 1)
+        try:
+            out[k] = int(v)
+        except ValueError:
+            try:
+                out[k] = float(v)
+            except ValueError:
+                out[k] = v
+    return out
 
 
 def main():

@@ -43,6 +43,61 @@ __global__ __launch_bounds__(256) void k_grad(DevMeshT<G> m, ResParams prm, cons
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < m.nC) body_grad<T, RHO>(c, m, prm, W, nut, gU, gP, gN, gH, (T*)prm.wTU);
 }
+// Round 5 (north_star: "owner/neighbour gather staged through LDS, wavefront segmented reductions for cell accumulation"): the Gauss
+// gradients face-parallel.  A workgroup owns CPB consecutive cells; EIGHT lanes per cell, lane (cell, slot) evaluates face slot `slot`
+// (slot + 8, ... for polyhedra) - the dependent chain cf_face -> face record -> neighbour state of the one-thread-per-cell kernel runs
+// for all faces of a cell at once (its six-trip loop was the latency of k_grad: ~1.3 GB moved in 0.45 ms, neither bandwidth nor ALU).
+//   stage 1  the states [U | p | nuTilda] of the CPB cells are staged in LDS (coalesced); a face whose other cell lies in the tile reads it
+//            from there (the +-1 neighbours along the numbering), everyone else from global memory
+//   stage 2  every lane writes its 15 products S_f (x) {U_f, p_f, nuTilda_f} to LDS, [quantity][cell][slot]
+//   stage 3  segmented reduction: the 15 x CPB sums over the 8 slots, in slot order (deterministic), scaled by 1 / V and written to
+//            gradU / gradP / gradN with consecutive threads on consecutive addresses (the old kernel stored with a 72-byte lane stride)
+// DASimpleFoam without the T field and double metrics (the benchmark path); every other variant keeps k_grad.  amd.gradFaceParallel 0 = off.
+template <class T, int CPB>
+__global__ __launch_bounds__(CPB * 8) void k_grad_fp(DevMesh m, ResParams prm, const T* __restrict__ W, T* __restrict__ nut, T* __restrict__ gU,
+                                                     T* __restrict__ gP, T* __restrict__ gN) {
+    extern __shared__ double sh_raw[];
+    T* const tile = reinterpret_cast<T*>(sh_raw);   // [5][CPB]
+    T* const part = tile + 5 * CPB;                 // [15][CPB][8]
+    const long long N = m.nC;
+    const int c0 = blockIdx.x * CPB;
+    const int nT = min(CPB, m.nC - c0);
+    for (int i = threadIdx.x; i < 5 * CPB; i += CPB * 8) {
+        const int q = i / CPB, cl = i - q * CPB;
+        if (cl < nT) tile[i] = q < 3 ? W[3LL * (c0 + cl) + q] : W[(q == 3 ? prm.offP : prm.offN) * N + c0 + cl];
+    }
+    __syncthreads();
+    const int cl = threadIdx.x >> 3, slot = threadIdx.x & 7, c = c0 + cl;
+    T acc[15];
+#pragma unroll
+    for (int q = 0; q < 15; q++) acc[q] = T(0.0);
+    if (cl < nT) {
+        const T Uc[3] = {tile[cl], tile[CPB + cl], tile[2 * CPB + cl]};
+        const T pc = tile[3 * CPB + cl], nc = tile[4 * CPB + cl];
+        const T nut_c = nc * fv1_of<T>(nc / T(prm.nu));
+        if (slot == 0) nut[c] = nut_c;
+        T gH[3];  // (no energy-like scalar on this path)
+        for (int s = m.cf_ptr[c] + slot; s < m.cf_ptr[c + 1]; s += 8)
+            grad_face<T, false, double>(c, s, m, prm, W, Uc, pc, T(0.0), nc, nut_c, false, acc, acc + 9, acc + 12, gH, tile, c0, CPB);
+    }
+#pragma unroll
+    for (int q = 0; q < 15; q++) part[(q * CPB + cl) * 8 + slot] = acc[q];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 15 * CPB; o += CPB * 8) {
+        // output o of the tile: gradU entries first (9 per cell, cell-major like the global array), then gradP, then gradN
+        int q, oc;
+        T* dst;
+        if (o < 9 * CPB) { oc = o / 9; q = o - 9 * oc; dst = gU + 9LL * c0 + o; }
+        else if (o < 12 * CPB) { const int r = o - 9 * CPB; oc = r / 3; q = 9 + r - 3 * oc; dst = gP + 3LL * c0 + r; }
+        else { const int r = o - 12 * CPB; oc = r / 3; q = 12 + r - 3 * oc; dst = gN + 3LL * c0 + r; }
+        if (oc >= nT) continue;
+        const T* ps = part + (q * CPB + oc) * 8;
+        T sum = ps[0];
+#pragma unroll
+        for (int t = 1; t < 8; t++) sum += ps[t];
+        *dst = sum * (1.0 / m.cg[c0 + oc].V);
+    }
+}
 template <class T, bool RHO, class G = double>
 __global__ __launch_bounds__(256) void k_cell(DevMeshT<G> m, ResParams prm, const T* __restrict__ W, const T* nut, const T* gU, const T* gP,
                                               const T* gN, const T* gH, T* R, T* rAU, T* HbyA) {
@@ -174,6 +229,20 @@ struct ResWork {
 
 static inline int nblk(long long n, int b) { return (int)((n + b - 1) / b); }
 
+// the gradient launch of DASimpleFoam: face-parallel k_grad_fp where it applies (no T field, double metrics, amd.gradFaceParallel), else k_grad
+template <class T, class G>
+static void launch_grad_simple(const DevMeshT<G>& dm, const ResParams& prm, const T* W, ResWork<T>& wk, hipStream_t st) {
+    if constexpr (std::is_same<G, double>::value) {
+        if (prm.gradFaceParallel && !prm.hasT) {
+            constexpr int CPB = sizeof(T) > 8 ? 16 : 32;  // dual numbers: 16 cells per workgroup (LDS: 20 x CPB + 120 x CPB scalars)
+            const size_t shBytes = (size_t)(5 * CPB + 15 * CPB * 8) * sizeof(T);
+            hipLaunchKernelGGL((k_grad_fp<T, CPB>), dim3(nblk(dm.nC, CPB)), dim3(CPB * 8), shBytes, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((k_grad<T, false, G>), dim3(nblk(dm.nC, 256)), dim3(256), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, wk.gH.p);
+}
+
 // one residual evaluation R(W): DAResidual::masterFunction (reference DAResidual.C:100-171)
 template <class T, class G = double>
 static void eval_residual(const DevMeshT<G>& dm, const CaseParams& cp, const ResParams& prm_in, const T* W, T* R, ResWork<T>& wk,
@@ -181,7 +250,7 @@ static void eval_residual(const DevMeshT<G>& dm, const CaseParams& cp, const Res
     const ResParams prm = wk.bind(cp.solver, dm.nC, dm.nF, prm_in);
     const int B = 256;
     if (cp.solver == DAS_SOLVER_SIMPLEFOAM) {
-        hipLaunchKernelGGL((k_grad<T, false, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p, wk.gH.p);
+        launch_grad_simple<T, G>(dm, prm, W, wk, st);
         hipLaunchKernelGGL((k_cell<T, false, G>), dim3(nblk(dm.nC, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p,
                            (const T*)wk.gH.p, R, wk.rAU.p, wk.HbyA.p);
         hipLaunchKernelGGL((k_face<T, false, G>), dim3(nblk(dm.nF, B)), dim3(B), 0, st, dm, prm, W, wk.nut.p, wk.gP.p, wk.rAU.p, wk.HbyA.p, wk.q.p, R);
@@ -486,6 +555,93 @@ __global__ __launch_bounds__(256) void k_multidot2(long long n, int K, const QT*
     if ((long long)(blockIdx.x + 1) * (256 * ROWS) <= n) multidot2_body<ROWS, true, QT, VT>(n, K, V, ldv, u, v, partial, nbw);
     else multidot2_body<ROWS, false, QT, VT>(n, K, V, ldv, u, v, partial, nbw);
 }
+// The same inner products against the bf16 COPY of the basis (amd.krylovDotCopy).  Round 5, first version: the generic kernel above with
+// 2-byte elements - one 2-byte load per lane and row, 128 bytes per wave instruction: 53 ms per iteration at depth 444 instead of 35
+// (profiles/r06d_*).  Here a thread owns two OCTETS of consecutive rows (r0 .. r0+7 and r0+2048 .. r0+2055 of a 4096-row chunk): one
+// 16-byte load per octet and basis vector (a wave instruction reads 1 KB of consecutive copy entries), u and v of the same rows in
+// registers (fp64), sums in fp64, the same wave reduce-scatter.  ldh = the copy's leading dimension (a multiple of 8: aligned octets).
+#define MDH_CHUNK 4096
+__device__ __forceinline__ void bf16x8_to_double(const uint4& w, double* x) {
+    x[0] = (double)__uint_as_float(w.x << 16); x[1] = (double)__uint_as_float(w.x & 0xFFFF0000u);
+    x[2] = (double)__uint_as_float(w.y << 16); x[3] = (double)__uint_as_float(w.y & 0xFFFF0000u);
+    x[4] = (double)__uint_as_float(w.z << 16); x[5] = (double)__uint_as_float(w.z & 0xFFFF0000u);
+    x[6] = (double)__uint_as_float(w.w << 16); x[7] = (double)__uint_as_float(w.w & 0xFFFF0000u);
+}
+template <bool FULL>
+__device__ __forceinline__ void multidot2h_body(long long n, int K, const bf16s* __restrict__ Vh, long long ldh, const double* __restrict__ u,
+                                                const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
+    const int lane = threadIdx.x & 63, g = lane >> 3;
+    const long long r0 = (long long)blockIdx.x * MDH_CHUNK + (long long)threadIdx.x * 8;
+    const long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    double ur[16], vr[16];
+#pragma unroll
+    for (int o = 0; o < 2; o++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const long long row = r0 + 2048 * o + t;
+            const long long k = FULL ? row : min(row, n - 1);
+            const double m = (FULL || row < n) ? 1.0 : 0.0;
+            ur[8 * o + t] = m * u[k];
+            vr[8 * o + t] = m * v[k];
+        }
+    for (int i0 = 0; i0 < K; i0 += 4) {
+        uint4 w[4][2];
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            const bf16s* vi = Vh + (long long)min(i0 + ii, K - 1) * ldh;
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                // (the copy is allocated in whole octets per vector: an octet that starts below ldh is readable; rows >= n carry ur = vr = 0)
+                const long long row = FULL ? r0 + 2048 * o : min(r0 + 2048 * o, ldh - 8);
+                w[ii][o] = *reinterpret_cast<const uint4*>(vi + row);
+            }
+        }
+        double acc[8];
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                double x[8];
+                bf16x8_to_double(w[ii][o], x);
+                const bool live = FULL || r0 + 2048 * o <= ldh - 8;  // a clamped octet holds other rows: it must not enter the sums
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const double xv = (live && (FULL || r0 + 2048 * o + t < n)) ? x[t] : 0.0;  // (the pad rows n .. ldh-1 of the copy are never written)
+                    a += xv * ur[8 * o + t];
+                    b += xv * vr[8 * o + t];
+                }
+            }
+            acc[2 * ii] = a;
+            acc[2 * ii + 1] = b;
+        }
+        double a4[4], a2[2], a1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double snd = (g & 4) ? acc[i] : acc[i + 4], keep = (g & 4) ? acc[i + 4] : acc[i];
+            a4[i] = keep + __shfl_xor(snd, 32, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const double snd = (g & 2) ? a4[i] : a4[i + 2], keep = (g & 2) ? a4[i + 2] : a4[i];
+            a2[i] = keep + __shfl_xor(snd, 16, 64);
+        }
+        {
+            const double snd = (g & 1) ? a2[0] : a2[1], keep = (g & 1) ? a2[1] : a2[0];
+            a1 = keep + __shfl_xor(snd, 8, 64);
+        }
+        a1 += __shfl_xor(a1, 1, 64);
+        a1 += __shfl_xor(a1, 2, 64);
+        a1 += __shfl_xor(a1, 4, 64);
+        const int i = i0 + (g >> 1);
+        if ((lane & 7) == 0 && i < K) partial[((long long)(g & 1) * K + i) * nbw + slot] = a1;
+    }
+}
+__global__ __launch_bounds__(256) void k_multidot2h(long long n, int K, const bf16s* __restrict__ Vh, long long ldh, const double* __restrict__ u,
+                                                    const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
+    if ((long long)(blockIdx.x + 1) * MDH_CHUNK <= n) multidot2h_body<true>(n, K, Vh, ldh, u, v, partial, nbw);
+    else multidot2h_body<false>(n, K, Vh, ldh, u, v, partial, nbw);
+}
 // The fused update of the delayed re-orthogonalisation, one pass over the basis: with Q = the j final vectors, u = slot j
 // (projected once), v = the operator applied to u:   q_j = (u - Q s) / alpha  -> slot j,
 //                                                     u' = (v - gamma u - Q c) / alpha -> slot j + 1
@@ -497,7 +653,8 @@ __global__ __launch_bounds__(256) void k_multidot2(long long n, int K, const QT*
 #endif
 template <int UNROLL, int RPT, class VT>
 __global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, VT* __restrict__ V, long long ldv, const double* __restrict__ sc,
-                                                      double gamma, double ralpha, const double* __restrict__ v, bf16s* __restrict__ Vh = nullptr) {
+                                                      double gamma, double ralpha, const double* __restrict__ v, bf16s* __restrict__ Vh = nullptr,
+                                                      long long ldh = 0) {
     const long long k0 = ((long long)blockIdx.x * RPT) * blockDim.x + threadIdx.x;  // rows k0 + r * blockDim.x
     const double* s = sc;
     const double* c = sc + j;
@@ -528,7 +685,7 @@ __global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, VT* __
         const double qj = (u - as[r]) * ralpha, un = (v[k] - gamma * u - ac[r]) * ralpha;
         V[(long long)j * ldv + k] = (VT)qj;
         V[(long long)(j + 1) * ldv + k] = (VT)un;
-        if (Vh) { Vh[(long long)j * ldv + k] = bf16s(qj); Vh[(long long)(j + 1) * ldv + k] = bf16s(un); }
+        if (Vh) { Vh[(long long)j * ldh + k] = bf16s(qj); Vh[(long long)(j + 1) * ldh + k] = bf16s(un); }
     }
 }
 // y = sum_i c_i V_i
@@ -2149,7 +2306,8 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
         DAS_CHECK(dc == "auto" || dc == "bf16" || dc == "none", DAS_ERR_ARG, "amd.krylovDotCopy: auto | bf16 | none");
         const bool dcgs2 = s->opt.gets("amd.gmresOrthogonalization") == "dcgs2" && s->opt.geti("adjEqnOption.useMGSO") == 0;
         k->dotCopy = eligible && !k->vf32 && dcgs2 && (dc == "bf16" || (dc == "auto" && (size_t)(restart + 2) * (size_t)n * 8 >= ((size_t)1 << 30)));
-        if (k->dotCopy && (k->Vh.n < (size_t)((restart + 2) * n))) k->Vh.reserve((size_t)(wantVec * n));
+        const long long ldh = (n + 7) / 8 * 8;  // whole octets per vector: the inner-product kernel loads 16 aligned bytes per lane
+        if (k->dotCopy && (k->Vh.n < (size_t)((restart + 2) * ldh))) k->Vh.reserve((size_t)(wantVec * ldh));
     }
     if (k->restart != restart || k->w.n != (size_t)n) {
         k->restart = (int)restart;
@@ -2167,8 +2325,9 @@ static inline bool gmres_map_basis(das_solver* s, das_ksp* k, long long nvec) {
     const long long per = k->vf32 ? (s->n + 1) / 2 : s->n;  // fp64 elements of the range one basis vector occupies
     k->V.request((size_t)((nvec + 64) * per));
     if (k->dotCopy) {
-        k->Vh.request((size_t)((nvec + 64) * s->n));
-        if (!k->Vh.try_ensure((size_t)(nvec * s->n))) { if (k->V.workerError.empty()) k->V.workerError = "bf16 dot copy: " + k->Vh.workerError; return false; }
+        const long long ldh = (s->n + 7) / 8 * 8;
+        k->Vh.request((size_t)((nvec + 64) * ldh));
+        if (!k->Vh.try_ensure((size_t)(nvec * ldh))) { if (k->V.workerError.empty()) k->V.workerError = "bf16 dot copy: " + k->Vh.workerError; return false; }
     }
     return k->V.try_ensure((size_t)(nvec * per));
 }
@@ -2540,7 +2699,9 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     const int K = j + 1;
     const long long nbw = 4LL * nblk(n, MD2_CHUNK);
     bf16s* const Vh = k->dotCopy ? reinterpret_cast<bf16s*>(k->Vh.p) : nullptr;
-    if (Vh) hipLaunchKernelGGL((k_multidot2<MD2_ROWS, bf16s, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, (const bf16s*)Vh, n, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
+    const long long ldh = (n + 7) / 8 * 8;
+    static_assert(MDH_CHUNK == MD2_CHUNK, "the bf16 inner-product kernel uses the partial-sum layout of k_multidot2");
+    if (Vh) hipLaunchKernelGGL(k_multidot2h, dim3(nblk(n, MDH_CHUNK)), dim3(256), 0, st, n, K, (const bf16s*)Vh, ldh, reinterpret_cast<const double*>(u), (const double*)k->w.p, k->partial.p, nbw);
     else hipLaunchKernelGGL((k_multidot2<MD2_ROWS, VT, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, (const VT*)Vb, n, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
     hipLaunchKernelGGL(k_reduce, dim3(2 * K), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
     if (!(s->halo.active && s->halo.allreduce(k->hdev.p, 2 * K, st)) && s->allreduce_cb) s->allreduce_cb(k->hdev.p, 2 * K, s->comm_user);
@@ -2607,7 +2768,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     for (int i = 0; i < j; i++) { co[i] = sv[i]; co[j + i] = tv[i] - gam * sv[i]; }
     double* dco = k->hdev.p + 2 * (m + 3);
     if (j > 0) DAS_HIP(hipMemcpyAsync(dco, co.data(), 2 * j * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT, VT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, Vb, n, (const double*)dco, gam, 1.0 / al, (const double*)k->w.p, Vh);
+    hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT, VT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, Vb, n, (const double*)dco, gam, 1.0 / al, (const double*)k->w.p, Vh, ldh);
     // first-projection coefficients of the new pending vector: (t - H_jj s) / alpha, gamma - s_{j-1}
     for (int i = 0; i < j; i++) {
         double a = tv[i];

@@ -61,6 +61,7 @@ struct ResParams {
     // DATurboFoam switches and the MRF zone (angular velocity, origin)
     int turbo, transonic, transonicPC, mrf;
     int hasT;  // DASimpleFoam with the optional passive T field (RHO = false kernels)
+    int gradFaceParallel;  // amd.gradFaceParallel: the face-parallel LDS-staged gradient kernel k_grad_fp where it applies (host-side launch switch)
     double om[3], org[3];
     // DATurboFoam work array of the launch (typed by the kernel's scalar type): Teff.U per cell (3N)
     void* wTU;
@@ -294,6 +295,58 @@ DAS_HD void teff_dot_u(const T* g, const T& muEff, const T* U, T* q) {
 
 // ================================================================================ k_grad
 // per cell: nut = nuTilda*fv1 ; Gauss-linear gradients of U, p, nuTilda (and he = Cp (T - Tref) when RHO)
+//
+// One face slot s of cell c: S_f (x) (face values) added to the Gauss sums gU / gP / gN / gH.  `tile`: optional LDS copy of the cell
+// states [U0 U1 U2 p nuTilda][tileN] of the cells tile0 .. tile0 + tileN - 1 (k_grad_fp stages its own cells there: a neighbour inside
+// the tile is read from LDS, everyone else from W); null in the one-thread-per-cell body.
+template <class T, bool RHO, class G>
+DAS_HD void grad_face(int c, int s, const DevMeshT<G>& m, const ResParams& prm, const T* W, const T* Uc, const T& pc, const T& Tc, const T& nc,
+                      const T& nut_c, bool energy, T* gU, T* gP, T* gN, T* gH, const T* tile = nullptr, int tile0 = 0, int tileN = 0) {
+    const long long N = m.nC;
+    const CellGeomT<G>& cgc = m.cg[c];
+    int fe = m.cf_face[s];
+    int f = fe & 0x7fffffff;
+    bool nb = fe < 0;
+    const FaceGeomT<G>& g = m.fg[f];
+    T Uf[3], pf, nf, hf(0.0);
+    double sg = nb ? -1.0 : 1.0;
+    if (m.cf_other[s] >= 0) {  // internal face, or a cyclic boundary face (the paired cell acts as the neighbour)
+        int o = m.cf_other[s];
+        G wc = nb ? G(1.0 - g.w) : g.w;
+        T Uo[3], po, no;
+        const int ol = o - tile0;
+        if (tile && ol >= 0 && ol < tileN) {
+            Uo[0] = tile[ol]; Uo[1] = tile[tileN + ol]; Uo[2] = tile[2 * tileN + ol]; po = tile[3 * tileN + ol]; no = tile[4 * tileN + ol];
+        } else {
+            Uo[0] = W[3LL * o]; Uo[1] = W[3LL * o + 1]; Uo[2] = W[3LL * o + 2]; po = W[prm.offP * N + o]; no = W[prm.offN * N + o];
+        }
+        const double* Qr = cyclic_rotation(m, f);
+        if (Qr) rot_vec<T>(Qr, Uo);
+#pragma unroll
+        for (int k = 0; k < 3; k++) Uf[k] = wc * Uc[k] + (1.0 - wc) * Uo[k];
+        pf = wc * pc + (1.0 - wc) * po;
+        nf = wc * nc + (1.0 - wc) * no;
+        if (RHO) hf = prm.Cp * (wc * Tc + (1.0 - wc) * W[prm.offT * N + o] - DAS_TREF);
+        else if (energy) hf = wc * Tc + (1.0 - wc) * W[prm.offT * N + o];
+    } else {
+        BFace<T, G> b;
+        eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, cgc, prm, Uc, pc, Tc, nc, nut_c, val(W[prm.offPhi * N + f]), b);
+#pragma unroll
+        for (int k = 0; k < 3; k++) Uf[k] = b.U.xb[k];
+        pf = b.p.xb;
+        nf = b.n.xb;
+        if (energy) hf = b.he.xb;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        G S = sg * g.Sf[i];
+#pragma unroll
+        for (int j = 0; j < 3; j++) gU[3 * i + j] += S * Uf[j];
+        gP[i] += S * pf;
+        gN[i] += S * nf;
+        if (energy) gH[i] += S * hf;
+    }
+}
 template <class T, bool RHO, class G>
 DAS_HD void body_grad(int c, const DevMeshT<G>& m, const ResParams& prm, const T* W, T* nut, T* gradU, T* gradP, T* gradN, T* gradH,
                       T* TU = nullptr) {
@@ -311,44 +364,7 @@ DAS_HD void body_grad(int c, const DevMeshT<G>& m, const ResParams& prm, const T
     for (int k = 0; k < 9; k++) gU[k] = T(0.0);
 #pragma unroll
     for (int k = 0; k < 3; k++) { gP[k] = T(0.0); gN[k] = T(0.0); gH[k] = T(0.0); }
-    for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
-        int fe = m.cf_face[s];
-        int f = fe & 0x7fffffff;
-        bool nb = fe < 0;
-        const FaceGeomT<G>& g = m.fg[f];
-        T Uf[3], pf, nf, hf(0.0);
-        double sg = nb ? -1.0 : 1.0;
-        if (m.cf_other[s] >= 0) {  // internal face, or a cyclic boundary face (the paired cell acts as the neighbour)
-            int o = m.cf_other[s];
-            G wc = nb ? G(1.0 - g.w) : g.w;
-            T Uo[3] = {W[3LL * o], W[3LL * o + 1], W[3LL * o + 2]};
-            const double* Qr = cyclic_rotation(m, f);
-            if (Qr) rot_vec<T>(Qr, Uo);
-#pragma unroll
-            for (int k = 0; k < 3; k++) Uf[k] = wc * Uc[k] + (1.0 - wc) * Uo[k];
-            pf = wc * pc + (1.0 - wc) * W[prm.offP * N + o];
-            nf = wc * nc + (1.0 - wc) * W[prm.offN * N + o];
-            if (RHO) hf = prm.Cp * (wc * Tc + (1.0 - wc) * W[prm.offT * N + o] - DAS_TREF);
-            else if (energy) hf = wc * Tc + (1.0 - wc) * W[prm.offT * N + o];
-        } else {
-            BFace<T, G> b;
-            eval_bface<T, RHO>(m.bc[m.bpatch[f - m.nIF]], g, cgc, prm, Uc, pc, Tc, nc, nut_c, val(W[prm.offPhi * N + f]), b);
-#pragma unroll
-            for (int k = 0; k < 3; k++) Uf[k] = b.U.xb[k];
-            pf = b.p.xb;
-            nf = b.n.xb;
-            if (energy) hf = b.he.xb;
-        }
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            G S = sg * g.Sf[i];
-#pragma unroll
-            for (int j = 0; j < 3; j++) gU[3 * i + j] += S * Uf[j];
-            gP[i] += S * pf;
-            gN[i] += S * nf;
-            if (energy) gH[i] += S * hf;
-        }
-    }
+    for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) grad_face<T, RHO, G>(c, s, m, prm, W, Uc, pc, Tc, nc, nut_c, energy, gU, gP, gN, gH);
     G rV = 1.0 / cgc.V;
 #pragma unroll
     for (int k = 0; k < 9; k++) gradU[9LL * c + k] = gU[k] * rV;

@@ -119,6 +119,7 @@ Options::Options() {
     i["amd.gmresDeflation"] = 0;
     // storage type of the Krylov basis: "fp64" | "fp32" (compressed basis: vectors stored in fp32, every sum in fp64 - half the bytes of the
     // Gram-Schmidt passes) | "auto" (default) = fp64: fp32 storage breaks the Arnoldi relation by eps32 |y| and cost the wing its convergence (gmres_ws)
+    i["amd.gradFaceParallel"] = 1;  // DASimpleFoam gradients by the face-parallel, LDS-staged kernel k_grad_fp (0: one thread per cell, k_grad)
     s["amd.krylovBasisPrecision"] = "auto";
     // "bf16": the inner-product pass of the delayed re-orthogonalisation reads a bf16 COPY of the basis (2 instead of 8 bytes per entry), the
     // update pass keeps fp64 - the Arnoldi relation stays exact, the basis is orthogonal to ~1e-3; "none"; "auto" (default): on for bases >= 1 GB

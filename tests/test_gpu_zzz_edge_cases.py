@@ -190,8 +190,8 @@ def test_gmres_deflated_restarting_matches_the_default_solver():
 def test_compressed_fp32_krylov_basis_reaches_the_same_psi():
     """amd.krylovBasisPrecision (round 5): the basis vectors stored in fp32 (compressed-basis GMRES: half the bytes of the two Gram-Schmidt
     passes), every inner product / update / the Hessenberg matrix in fp64.  Against the fp64 basis on the same system at gmresRelTol
-    1e-6: fail 0 on the TRUE (recomputed) residual, the iteration count within a few steps (the recurrence is driven to half the
-    target), psi equal to the accuracy both solves have; "auto" picks fp64 for this small basis and for tight tolerances."""
+    1e-6: fail 0 on the TRUE (recomputed) residual, psi equal to the accuracy both solves have; "auto" means fp64.  Then the bf16 DOT
+    COPY (amd.krylovDotCopy): exact Arnoldi relation, one cycle, the iteration count of the plain solver."""
     case = channel_case(24, 14, 10, perturb=0.0, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
     g = Geometry(case.mesh)
     n = case.states.size
@@ -208,7 +208,9 @@ def test_compressed_fp32_krylov_basis_reaches_the_same_psi():
     assert out["fp32"][4]["fp32"] and not out["fp64"][4]["fp32"] and not out["auto"][4]["fp32"]
     for prec in ("fp64", "fp32"):
         assert out[prec][1] == 0 and out[prec][3] <= 1e-6
-    assert abs(out["fp32"][2] - out["fp64"][2]) <= 6 + 0.05 * out["fp64"][2], (out["fp32"][2], out["fp64"][2])
+    # fp32 STORAGE violates the Arnoldi relation by eps32 |y|: the recomputed true residual of the first cycle can miss the target and a second
+    # cycle follows (measured here: 119 iterations against 71; on the 2 M-cell wing it cost the convergence - why "auto" means fp64)
+    assert out["fp64"][2] <= out["fp32"][2] <= 3 * out["fp64"][2], (out["fp32"][2], out["fp64"][2])
     assert relerr(out["fp32"][0], out["fp64"][0]) < 1e-4  # both are 1e-6-residual solutions of the same system
     assert out["fp32"][4]["bytesPerVector"] * 2 == out["fp64"][4]["bytesPerVector"]
     # amd.krylovDotCopy "bf16" (the default for bases >= 1 GB): the inner products read a bf16 copy, the updates stay fp64 - the Arnoldi relation
