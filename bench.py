@@ -352,8 +352,8 @@ def main():
             mean_depth = (r_eff * 0.5 * r_eff + (its - r_eff) * 0.5 * (a.deflation + r_eff)) / its
         binfo = ksp.basisInfo()
         solve = {"converged": fail == 0, "fail": int(fail), "iterations": its, "time_to_tolerance_s": t_solve,
-                 "krylov_basis": {"storage": "fp32 (compressed basis; sums, Hessenberg matrix, residuals fp64)" if binfo["fp32"] else "fp64",
-                                  "inner_products_read": "a bf16 copy of the basis (amd.krylovDotCopy; the update pass reads / writes fp64)" if binfo["dotCopy"] else "the basis itself",
+                 "krylov_basis": {"storage": ("split: hi + lo floats per entry (8 B); the inner-product pass reads hi only, every vector-building pass hi + lo"
+                                              if binfo["split"] else ("fp32" if binfo["fp32"] else "fp64")),
                                   "mapped_GB": binfo["mappedGB"], "bytes_per_vector": binfo["bytesPerVector"]},
                  "rel_residual": inf["res"] / inf["res0"] if inf["res0"] else None, "gmresRelTol": 1e-6,
                  "gmresRestart": r_eff, "gmresMaxIters": a.solve_maxit, "mean_basis_depth": mean_depth, "gmresDeflation": int(a.deflation) if world == 1 else 0,
@@ -419,8 +419,8 @@ def main():
     orth = a.orth
     bi = ksp.basisInfo()
     basis_b = 4.0 if bi["fp32"] else 8.0
-    # delayed re-orthogonalisation: one inner-product pass (2 B per entry with the bf16 dot copy) + one update pass over the basis
-    orth_bytes = ((2.0 if bi["dotCopy"] else basis_b) + basis_b) * jmean * n if orth == "dcgs2" else 4.0 * basis_b * jmean * n
+    # delayed re-orthogonalisation: one inner-product pass (4 B per entry with the split basis: hi only) + one update pass over the basis
+    orth_bytes = ((4.0 if bi["split"] else basis_b) + basis_b) * jmean * n if orth == "dcgs2" else 4.0 * basis_b * jmean * n
     moved_bytes = products * spmv_bytes + pc_bytes + orth_bytes + 48.0 * n
     ms_step = dt / a.steps * 1e3
     stage(f"window: {a.steps} steps at depth {j0}: {ms_step:.2f} ms per step")
@@ -545,7 +545,7 @@ def main():
                 "bound": "hbm",
                 "algorithmic_bytes_per_step": moved_bytes,
                 "operator_products_per_step": products,
-                "formula": "products x B_spmv + B_pc + 2 b j n + 48 n at the mean j of the window, b = bytes per stored basis entry (4 with the compressed fp32 basis, 8 otherwise): what this "
+                "formula": "products x B_spmv + B_pc + 2 b j n + 48 n at the mean j of the window, b = bytes per stored basis entry (8; the split basis reads 4 + 8 in its two passes): what this "
                            "implementation moves (delayed re-orthogonalisation = 2 basis reads per iteration; products = operator products per step)"
                            if orth == "dcgs2" else "B_spmv + B_pc + 32 j n + 48 n (CGS with refinement: 4 basis reads)",
                 "achieved": moved_bytes / (ms_step * 1e-3) / 1e9,

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_grad(DevMeshT<G> m, ResParams prm, cons
 // for all faces of a cell at once (its six-trip loop was the latency of k_grad: ~1.3 GB moved in 0.45 ms, neither bandwidth nor ALU).
 //   stage 1  the states [U | p | nuTilda] of the CPB cells are staged in LDS (coalesced); a face whose other cell lies in the tile reads it
 //            from there (the +-1 neighbours along the numbering), everyone else from global memory
-//   stage 2  every lane writes its 15 products S_f (x) {U_f, p_f, nuTilda_f} to LDS, [quantity][cell][slot]
+//   stage 2  every lane writes its 15 products S_f (x) {U_f, p_f, nuTilda_f} to LDS, [cell][slot][quantity]
 //   stage 3  segmented reduction: the 15 x CPB sums over the 8 slots, in slot order (deterministic), scaled by 1 / V and written to
 //            gradU / gradP / gradN with consecutive threads on consecutive addresses (the old kernel stored with a 72-byte lane stride)
 // DASimpleFoam without the T field and double metrics (the benchmark path); every other variant keeps k_grad.  amd.gradFaceParallel 0 = off.
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(CPB * 8) void k_grad_fp(DevMesh m, ResParams prm, c
                                                      T* __restrict__ gP, T* __restrict__ gN) {
     extern __shared__ double sh_raw[];
     T* const tile = reinterpret_cast<T*>(sh_raw);   // [5][CPB]
-    T* const part = tile + 5 * CPB;                 // [15][CPB][8]
+    T* const part = tile + 5 * CPB;                 // [CPB][8][15]
     const long long N = m.nC;
     const int c0 = blockIdx.x * CPB;
     const int nT = min(CPB, m.nC - c0);
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(CPB * 8) void k_grad_fp(DevMesh m, ResParams prm, c
             grad_face<T, false, double>(c, s, m, prm, W, Uc, pc, T(0.0), nc, nut_c, false, acc, acc + 9, acc + 12, gH, tile, c0, CPB);
     }
 #pragma unroll
-    for (int q = 0; q < 15; q++) part[(q * CPB + cl) * 8 + slot] = acc[q];
+    for (int q = 0; q < 15; q++) part[(cl * 8 + slot) * 15 + q] = acc[q];  // [cell][slot][quantity]: a lane's 15 values are contiguous (stride 15: no bank conflicts)
     __syncthreads();
     for (int o = threadIdx.x; o < 15 * CPB; o += CPB * 8) {
         // output o of the tile: gradU entries first (9 per cell, cell-major like the global array), then gradP, then gradN
@@ -91,10 +91,12 @@ __global__ __launch_bounds__(CPB * 8) void k_grad_fp(DevMesh m, ResParams prm, c
         else if (o < 12 * CPB) { const int r = o - 9 * CPB; oc = r / 3; q = 9 + r - 3 * oc; dst = gP + 3LL * c0 + r; }
         else { const int r = o - 12 * CPB; oc = r / 3; q = 12 + r - 3 * oc; dst = gN + 3LL * c0 + r; }
         if (oc >= nT) continue;
-        const T* ps = part + (q * CPB + oc) * 8;
+        // (round 5, first layout [quantity][cell][slot]: neighbouring threads read 2 KB apart - every lane of a group on one bank; the dual-number
+        //  variant ran at 0.98 ms against 0.57 for k_grad, profiles/r06e_*.  Here neighbouring threads read neighbouring quantities.)
+        const T* ps = part + oc * 8 * 15 + q;
         T sum = ps[0];
 #pragma unroll
-        for (int t = 1; t < 8; t++) sum += ps[t];
+        for (int t = 1; t < 8; t++) sum += ps[15 * t];
         *dst = sum * (1.0 / m.cg[c0 + oc].V);
     }
 }
@@ -418,17 +420,12 @@ __global__ __launch_bounds__(256) void k_spmv_wave(long long n, const long long*
 #define SPMV_GRID(n) dim3(nblk((n), 256 / SPMV_LANES))
 
 // partial[i*nb + blk] = sum over this block's chunk of V_i . w   (i < m); last slot (i == m) = w . w
-// bf16 copy of a basis entry (the upper 16 bits of its fp32 value, round to nearest even): what the INNER-PRODUCT pass of the delayed
-// re-orthogonalisation reads when amd.krylovDotCopy is on - a quarter of the bytes; the update pass keeps reading and writing fp64
-struct bf16s {
-    unsigned short b;
-    __host__ __device__ bf16s() {}
-    __device__ explicit bf16s(double x) {
-        const unsigned u = __float_as_uint((float)x);
-        b = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-    }
-    __device__ explicit operator double() const { return (double)__uint_as_float((unsigned)b << 16); }
-};
+// Split storage of the Krylov basis (amd.krylovBasisPrecision "split"): a basis entry x is kept as hi = (float)x and lo = (float)(x - hi) in
+// TWO float arrays (8 bytes per entry like fp64; hi + lo carries 48 mantissa bits).  The inner-product pass of the delayed
+// re-orthogonalisation reads only the hi array (4 bytes per entry), the update pass reads and writes both - every consumer that builds
+// vectors (updates, the solution update, the preconditioner input) uses hi + lo, so the Arnoldi relation holds to 2^-48, while the
+// Gram-Schmidt coefficients carry fp32-level errors, which only cost orthogonality (1e-7).  Kernels below take the lo array as an optional
+// pointer next to a float basis: null = plain fp32 storage (amd.krylovBasisPrecision "fp32").
 // (VT: storage type of the Krylov basis - double, or float for the compressed basis of amd.krylovBasisPrecision; all sums in fp64)
 #define MD_CHUNK 1024
 template <class VT>
@@ -477,11 +474,12 @@ __global__ __launch_bounds__(256) void k_reduce(int nb, const double* __restrict
 // w -= sum_i h_i V_i
 template <class VT, class WT>
 __global__ __launch_bounds__(256) void k_multiaxpy(long long n, int m, const VT* __restrict__ V, long long ldv, const double* __restrict__ h,
-                                                   WT* __restrict__ w) {
+                                                   WT* __restrict__ w, const float* __restrict__ Vlo = nullptr) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     double s = (double)w[k];
-    for (int i = 0; i < m; i++) s -= h[i] * (double)V[(long long)i * ldv + k];
+    if (Vlo) for (int i = 0; i < m; i++) s -= h[i] * ((double)V[(long long)i * ldv + k] + (double)Vlo[(long long)i * ldv + k]);
+    else for (int i = 0; i < m; i++) s -= h[i] * (double)V[(long long)i * ldv + k];
     w[k] = (WT)s;
 }
 // Two right-hand sides against K basis vectors in ONE pass over the basis (the fused inner products of the delayed
@@ -555,93 +553,6 @@ __global__ __launch_bounds__(256) void k_multidot2(long long n, int K, const QT*
     if ((long long)(blockIdx.x + 1) * (256 * ROWS) <= n) multidot2_body<ROWS, true, QT, VT>(n, K, V, ldv, u, v, partial, nbw);
     else multidot2_body<ROWS, false, QT, VT>(n, K, V, ldv, u, v, partial, nbw);
 }
-// The same inner products against the bf16 COPY of the basis (amd.krylovDotCopy).  Round 5, first version: the generic kernel above with
-// 2-byte elements - one 2-byte load per lane and row, 128 bytes per wave instruction: 53 ms per iteration at depth 444 instead of 35
-// (profiles/r06d_*).  Here a thread owns two OCTETS of consecutive rows (r0 .. r0+7 and r0+2048 .. r0+2055 of a 4096-row chunk): one
-// 16-byte load per octet and basis vector (a wave instruction reads 1 KB of consecutive copy entries), u and v of the same rows in
-// registers (fp64), sums in fp64, the same wave reduce-scatter.  ldh = the copy's leading dimension (a multiple of 8: aligned octets).
-#define MDH_CHUNK 4096
-__device__ __forceinline__ void bf16x8_to_double(const uint4& w, double* x) {
-    x[0] = (double)__uint_as_float(w.x << 16); x[1] = (double)__uint_as_float(w.x & 0xFFFF0000u);
-    x[2] = (double)__uint_as_float(w.y << 16); x[3] = (double)__uint_as_float(w.y & 0xFFFF0000u);
-    x[4] = (double)__uint_as_float(w.z << 16); x[5] = (double)__uint_as_float(w.z & 0xFFFF0000u);
-    x[6] = (double)__uint_as_float(w.w << 16); x[7] = (double)__uint_as_float(w.w & 0xFFFF0000u);
-}
-template <bool FULL>
-__device__ __forceinline__ void multidot2h_body(long long n, int K, const bf16s* __restrict__ Vh, long long ldh, const double* __restrict__ u,
-                                                const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
-    const int lane = threadIdx.x & 63, g = lane >> 3;
-    const long long r0 = (long long)blockIdx.x * MDH_CHUNK + (long long)threadIdx.x * 8;
-    const long long slot = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    double ur[16], vr[16];
-#pragma unroll
-    for (int o = 0; o < 2; o++)
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const long long row = r0 + 2048 * o + t;
-            const long long k = FULL ? row : min(row, n - 1);
-            const double m = (FULL || row < n) ? 1.0 : 0.0;
-            ur[8 * o + t] = m * u[k];
-            vr[8 * o + t] = m * v[k];
-        }
-    for (int i0 = 0; i0 < K; i0 += 4) {
-        uint4 w[4][2];
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-            const bf16s* vi = Vh + (long long)min(i0 + ii, K - 1) * ldh;
-#pragma unroll
-            for (int o = 0; o < 2; o++) {
-                // (the copy is allocated in whole octets per vector: an octet that starts below ldh is readable; rows >= n carry ur = vr = 0)
-                const long long row = FULL ? r0 + 2048 * o : min(r0 + 2048 * o, ldh - 8);
-                w[ii][o] = *reinterpret_cast<const uint4*>(vi + row);
-            }
-        }
-        double acc[8];
-#pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-            double a = 0.0, b = 0.0;
-#pragma unroll
-            for (int o = 0; o < 2; o++) {
-                double x[8];
-                bf16x8_to_double(w[ii][o], x);
-                const bool live = FULL || r0 + 2048 * o <= ldh - 8;  // a clamped octet holds other rows: it must not enter the sums
-#pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    const double xv = (live && (FULL || r0 + 2048 * o + t < n)) ? x[t] : 0.0;  // (the pad rows n .. ldh-1 of the copy are never written)
-                    a += xv * ur[8 * o + t];
-                    b += xv * vr[8 * o + t];
-                }
-            }
-            acc[2 * ii] = a;
-            acc[2 * ii + 1] = b;
-        }
-        double a4[4], a2[2], a1;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const double snd = (g & 4) ? acc[i] : acc[i + 4], keep = (g & 4) ? acc[i + 4] : acc[i];
-            a4[i] = keep + __shfl_xor(snd, 32, 64);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const double snd = (g & 2) ? a4[i] : a4[i + 2], keep = (g & 2) ? a4[i + 2] : a4[i];
-            a2[i] = keep + __shfl_xor(snd, 16, 64);
-        }
-        {
-            const double snd = (g & 1) ? a2[0] : a2[1], keep = (g & 1) ? a2[1] : a2[0];
-            a1 = keep + __shfl_xor(snd, 8, 64);
-        }
-        a1 += __shfl_xor(a1, 1, 64);
-        a1 += __shfl_xor(a1, 2, 64);
-        a1 += __shfl_xor(a1, 4, 64);
-        const int i = i0 + (g >> 1);
-        if ((lane & 7) == 0 && i < K) partial[((long long)(g & 1) * K + i) * nbw + slot] = a1;
-    }
-}
-__global__ __launch_bounds__(256) void k_multidot2h(long long n, int K, const bf16s* __restrict__ Vh, long long ldh, const double* __restrict__ u,
-                                                    const double* __restrict__ v, double* __restrict__ partial, long long nbw) {
-    if ((long long)(blockIdx.x + 1) * MDH_CHUNK <= n) multidot2h_body<true>(n, K, Vh, ldh, u, v, partial, nbw);
-    else multidot2h_body<false>(n, K, Vh, ldh, u, v, partial, nbw);
-}
 // The fused update of the delayed re-orthogonalisation, one pass over the basis: with Q = the j final vectors, u = slot j
 // (projected once), v = the operator applied to u:   q_j = (u - Q s) / alpha  -> slot j,
 //                                                     u' = (v - gamma u - Q c) / alpha -> slot j + 1
@@ -653,8 +564,7 @@ __global__ __launch_bounds__(256) void k_multidot2h(long long n, int K, const bf
 #endif
 template <int UNROLL, int RPT, class VT>
 __global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, VT* __restrict__ V, long long ldv, const double* __restrict__ sc,
-                                                      double gamma, double ralpha, const double* __restrict__ v, bf16s* __restrict__ Vh = nullptr,
-                                                      long long ldh = 0) {
+                                                      double gamma, double ralpha, const double* __restrict__ v, float* __restrict__ Vlo = nullptr) {
     const long long k0 = ((long long)blockIdx.x * RPT) * blockDim.x + threadIdx.x;  // rows k0 + r * blockDim.x
     const double* s = sc;
     const double* c = sc + j;
@@ -669,6 +579,12 @@ __global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, VT* __
         for (int t = 0; t < UNROLL; t++)
 #pragma unroll
             for (int r = 0; r < RPT; r++) q[t][r] = (double)V[(long long)(i + t) * ldv + kk[r]];
+        if (Vlo) {
+#pragma unroll
+            for (int t = 0; t < UNROLL; t++)
+#pragma unroll
+                for (int r = 0; r < RPT; r++) q[t][r] += (double)Vlo[(long long)(i + t) * ldv + kk[r]];
+        }
 #pragma unroll
         for (int t = 0; t < UNROLL; t++)
 #pragma unroll
@@ -676,32 +592,43 @@ __global__ __launch_bounds__(256) void k_dcgs2_update(long long n, int j, VT* __
     }
     for (; i < j; i++)
 #pragma unroll
-        for (int r = 0; r < RPT; r++) { const double q = (double)V[(long long)i * ldv + kk[r]]; as[r] += s[i] * q; ac[r] += c[i] * q; }
+        for (int r = 0; r < RPT; r++) {
+            const double q = (double)V[(long long)i * ldv + kk[r]] + (Vlo ? (double)Vlo[(long long)i * ldv + kk[r]] : 0.0);
+            as[r] += s[i] * q; ac[r] += c[i] * q;
+        }
 #pragma unroll
     for (int r = 0; r < RPT; r++) {
         const long long k = k0 + (long long)r * blockDim.x;
         if (k >= n) continue;
-        const double u = (double)V[(long long)j * ldv + k];
+        const double u = (double)V[(long long)j * ldv + k] + (Vlo ? (double)Vlo[(long long)j * ldv + k] : 0.0);
         const double qj = (u - as[r]) * ralpha, un = (v[k] - gamma * u - ac[r]) * ralpha;
-        V[(long long)j * ldv + k] = (VT)qj;
-        V[(long long)(j + 1) * ldv + k] = (VT)un;
-        if (Vh) { Vh[(long long)j * ldh + k] = bf16s(qj); Vh[(long long)(j + 1) * ldh + k] = bf16s(un); }
+        const VT qh = (VT)qj, uh = (VT)un;
+        V[(long long)j * ldv + k] = qh;
+        V[(long long)(j + 1) * ldv + k] = uh;
+        if (Vlo) { Vlo[(long long)j * ldv + k] = (float)(qj - (double)qh); Vlo[(long long)(j + 1) * ldv + k] = (float)(un - (double)uh); }
     }
 }
 // y = sum_i c_i V_i
 template <class VT>
 __global__ __launch_bounds__(256) void k_lincomb(long long n, int m, const VT* __restrict__ V, long long ldv, const double* __restrict__ c,
-                                                 double* __restrict__ y) {
+                                                 double* __restrict__ y, const float* __restrict__ Vlo = nullptr) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     double s = 0.0;
-    for (int i = 0; i < m; i++) s += c[i] * (double)V[(long long)i * ldv + k];
+    if (Vlo) for (int i = 0; i < m; i++) s += c[i] * ((double)V[(long long)i * ldv + k] + (double)Vlo[(long long)i * ldv + k]);
+    else for (int i = 0; i < m; i++) s += c[i] * (double)V[(long long)i * ldv + k];
     y[k] = s;
 }
+// y = a x; xlo: x is stored split (x = x + xlo); ylo: y is stored split (y = (TO) value, ylo = the fp32 rest)
 template <class TI, class TO>
-__global__ void k_scale_to(long long n, double a, const TI* __restrict__ x, TO* __restrict__ y) {
+__global__ void k_scale_to(long long n, double a, const TI* __restrict__ x, TO* __restrict__ y, const float* __restrict__ xlo = nullptr,
+                           float* __restrict__ ylo = nullptr) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) y[k] = (TO)(a * (double)x[k]);
+    if (k >= n) return;
+    const double val = a * ((double)x[k] + (xlo ? (double)xlo[k] : 0.0));
+    const TO yh = (TO)val;
+    y[k] = yh;
+    if (ylo) ylo[k] = (float)(val - (double)yh);
 }
 __global__ void k_axpby(long long n, double a, const double* __restrict__ x, double b, double* __restrict__ y) {
     long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1177,11 +1104,9 @@ struct das_ksp {
     // compressed basis (amd.krylovBasisPrecision, gmres_ws): the basis vectors are STORED in fp32 (half the bytes of the two Gram-Schmidt
     // passes, which are most of an iteration at depth > 150), all inner products / updates / the Hessenberg matrix stay fp64
     bool vf32 = false;
-    // amd.krylovDotCopy: a bf16 copy of every basis vector, read by the inner-product pass of the delayed re-orthogonalisation instead of the
-    // fp64 basis (2 instead of 8 bytes per entry); the update pass reads / writes fp64, so the Arnoldi relation B Q = Q H stays exact and
-    // only the orthogonality of the basis drops to ~1e-3 (quasi-minimal residual within 1 + 1e-3 of GMRES's; the true residual is recomputed)
-    bool dotCopy = false;
-    VmBuf<unsigned short> Vh;
+    // split storage: V holds the hi floats, Vlo the lo floats of every basis vector (see the kernels); vf32 is set as well
+    bool split = false;
+    VmBuf<float> Vlo;
     DevBuf<double> ustage;  // fp64 copy of the basis vector the preconditioner is applied to (fp32 basis only)
     DevBuf<double> w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
     std::unique_ptr<struct GmresRun> run;
@@ -2290,24 +2215,23 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
         // (the parity tests solve to 1e-10 .. 1e-12), modified Gram-Schmidt, deflated restarting and the Newton primal's inner solves
         std::string prec = "auto";
         { auto ip = s->opt.s.find("amd.krylovBasisPrecision"); if (ip != s->opt.s.end()) prec = ip->second; }
-        DAS_CHECK(prec == "auto" || prec == "fp64" || prec == "fp32", DAS_ERR_ARG, "amd.krylovBasisPrecision: auto | fp64 | fp32");
+        DAS_CHECK(prec == "auto" || prec == "fp64" || prec == "fp32" || prec == "split", DAS_ERR_ARG, "amd.krylovBasisPrecision: auto | fp64 | split | fp32");
         const bool eligible = s->opt.geti("adjEqnOption.useMGSO") == 0 && !s->fwd.on;
-        // "auto" = fp64 (round 5, measured on the 2 M-cell wing, profiles/r06c_*: with fp32 STORAGE the recurrence follows the fp64 run to
-        // four digits for 900 iterations, but the recomputed true residual of the closing cycle is 2.5e-4 |r0| instead of 5e-7: the
-        // rounding of every stored vector violates the Arnoldi relation by eps32 |h_{j+1,j} y_j|, and the plateau of this adjoint makes
-        // |y| ~ 1e3-1e4.  fp32 storage stays an explicit option for short, well-conditioned solves.)
-        k->vf32 = eligible && prec == "fp32";
-        if (k->vf32 && k->ustage.n != (size_t)n) k->ustage.alloc(n);
-        // the bf16 dot copy (what does pay, and keeps the Arnoldi relation exact): "auto" = on for the delayed re-orthogonalisation when the
-        // basis is >= 1 GB (the Gram-Schmidt passes then dominate the iteration); off for the other schemes, fp32 storage, several ranks'
-        // legacy callbacks are fine (the copy is local)
-        std::string dc = "auto";
-        { auto ip = s->opt.s.find("amd.krylovDotCopy"); if (ip != s->opt.s.end()) dc = ip->second; }
-        DAS_CHECK(dc == "auto" || dc == "bf16" || dc == "none", DAS_ERR_ARG, "amd.krylovDotCopy: auto | bf16 | none");
+        // "fp32" storage alone (round 5, measured on the 2 M-cell wing, profiles/r06c_*): the recurrence follows the fp64 run to four
+        // digits for 900 iterations, but the recomputed true residual of the closing cycle is 2.5e-4 |r0| instead of 5e-7 - the rounding of
+        // every stored vector violates the Arnoldi relation by eps32 |h_{j+1,j} y_j|, and the plateau of this adjoint makes |y| ~ 1e3-1e4.
+        // It stays an explicit option for short, well-conditioned solves.  (A bf16 COPY for the inner products, second attempt,
+        // profiles/r06d_*, r06e_*: the preconditioned operator is close to the identity on the Krylov vectors, so the first projection
+        // must be accurate relative to a remainder of a few per cent of the vector - 2e-3 errors of the coefficients trip the
+        // lost-orthogonality safeguard at the third step and the solve falls back to the four-pass scheme.)  What works is "split":
+        // hi + lo floats, inner products on hi (fp32-accurate coefficients), everything else on hi + lo.
+        // "auto" = split for the delayed re-orthogonalisation when the basis is >= 1 GB (the Gram-Schmidt passes then dominate), else fp64.
         const bool dcgs2 = s->opt.gets("amd.gmresOrthogonalization") == "dcgs2" && s->opt.geti("adjEqnOption.useMGSO") == 0;
-        k->dotCopy = eligible && !k->vf32 && dcgs2 && (dc == "bf16" || (dc == "auto" && (size_t)(restart + 2) * (size_t)n * 8 >= ((size_t)1 << 30)));
-        const long long ldh = (n + 7) / 8 * 8;  // whole octets per vector: the inner-product kernel loads 16 aligned bytes per lane
-        if (k->dotCopy && (k->Vh.n < (size_t)((restart + 2) * ldh))) k->Vh.reserve((size_t)(wantVec * ldh));
+        const bool big = (size_t)(restart + 2) * (size_t)n * 8 >= ((size_t)1 << 30);
+        k->split = eligible && (prec == "split" || (prec == "auto" && dcgs2 && big));
+        k->vf32 = k->split || (eligible && prec == "fp32");
+        if (k->vf32 && k->ustage.n != (size_t)n) k->ustage.alloc(n);
+        if (k->split && k->Vlo.n < (size_t)((restart + 2) * n)) k->Vlo.reserve((size_t)(wantVec * n));
     }
     if (k->restart != restart || k->w.n != (size_t)n) {
         k->restart = (int)restart;
@@ -2324,16 +2248,17 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
 static inline bool gmres_map_basis(das_solver* s, das_ksp* k, long long nvec) {
     const long long per = k->vf32 ? (s->n + 1) / 2 : s->n;  // fp64 elements of the range one basis vector occupies
     k->V.request((size_t)((nvec + 64) * per));
-    if (k->dotCopy) {
-        const long long ldh = (s->n + 7) / 8 * 8;
-        k->Vh.request((size_t)((nvec + 64) * ldh));
-        if (!k->Vh.try_ensure((size_t)(nvec * ldh))) { if (k->V.workerError.empty()) k->V.workerError = "bf16 dot copy: " + k->Vh.workerError; return false; }
+    if (k->split) {
+        k->Vlo.request((size_t)((nvec + 64) * s->n));
+        if (!k->Vlo.try_ensure((size_t)(nvec * s->n))) { if (k->V.workerError.empty()) k->V.workerError = "lo half of the split basis: " + k->Vlo.workerError; return false; }
     }
     return k->V.try_ensure((size_t)(nvec * per));
 }
 // slot j of the basis in its storage type
 template <class VT>
 static inline VT* basis_slot(das_solver* s, das_ksp* k, long long j) { return reinterpret_cast<VT*>(k->V.p) + j * s->n; }
+// the lo half of slot j (split storage), or null
+static inline float* basis_lo(das_solver* s, das_ksp* k, long long j) { return k->split ? k->Vlo.p + j * s->n : nullptr; }
 
 // dev_out[0..m) = V^T w (V = m vectors of stride n starting at Vbase), dev_out[m] = w.w; summed over the ranks
 template <class VT>
@@ -2548,15 +2473,14 @@ static void gmres_begin(das_solver* s, das_ksp* k, const double* d_rhs, double* 
     k->res0 = G.beta;
     k->hist.push_back(G.beta);
     G.target = std::max(G.rtol * G.beta, G.atol);
-    G.recTarget = k->vf32 ? 0.5 * G.target : (k->dotCopy ? 0.98 * G.target : G.target);
+    G.recTarget = k->split ? 0.98 * G.target : (k->vf32 ? 0.5 * G.target : G.target);
 }
 static void gmres_cycle_start(das_solver* s, das_ksp* k) {
     GmresRun& G = *k->run;
     const long long n = s->n;
     DAS_CHECK(gmres_map_basis(s, k, 3), DAS_ERR_INTERNAL, "GMRES: no device memory for three Krylov vectors (" + k->V.workerError + ")");
-    if (k->vf32) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, (const double*)k->r.p, basis_slot<float>(s, k, 0));
-    else hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, (const double*)k->r.p, k->V.p);
-    if (k->dotCopy) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, (const double*)k->r.p, reinterpret_cast<bf16s*>(k->Vh.p));
+    if (k->vf32) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, (const double*)k->r.p, basis_slot<float>(s, k, 0), (const float*)nullptr, basis_lo(s, k, 0));
+    else hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0 / G.beta, (const double*)k->r.p, k->V.p, (const float*)nullptr, (float*)nullptr);
     std::fill(G.g.begin(), G.g.end(), 0.0);
     G.g[0] = G.beta;
     G.j = 0;
@@ -2569,7 +2493,7 @@ static void gmres_cycle_start(das_solver* s, das_ksp* k) {
 template <class VT>
 static const double* basis_as_double(das_solver* s, das_ksp* k, long long j) {
     if (sizeof(VT) == sizeof(double)) return reinterpret_cast<const double*>(basis_slot<VT>(s, k, j));
-    hipLaunchKernelGGL(k_scale_to, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, 1.0, (const VT*)basis_slot<VT>(s, k, j), k->ustage.p);
+    hipLaunchKernelGGL(k_scale_to, dim3(nblk(s->n, 256)), dim3(256), 0, s->stream, s->n, 1.0, (const VT*)basis_slot<VT>(s, k, j), k->ustage.p, (const float*)basis_lo(s, k, j), (float*)nullptr);
     return k->ustage.p;
 }
 // one Arnoldi step; returns the recurrence residual norm
@@ -2596,7 +2520,7 @@ static double gmres_iter_t(das_solver* s, das_ksp* k) {
         for (int i = 0; i <= j; i++) {
             multidot_dev<VT>(s, k, Vb + (long long)i * n, 1, k->w.p, k->hdev.p);
             DAS_HIP(hipMemcpyAsync(hcol + i, k->hdev.p, sizeof(double), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, 1, (const VT*)(Vb + (long long)i * n), n, (const double*)k->hdev.p, k->w.p);
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, 1, (const VT*)(Vb + (long long)i * n), n, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, i));
         }
         multidot_dev<VT>(s, k, Vb, 0, k->w.p, k->hdev.p);
         DAS_HIP(hipMemcpyAsync(hcol + j + 1, k->hdev.p, sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -2608,14 +2532,14 @@ static double gmres_iter_t(das_solver* s, das_ksp* k) {
         // KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160): refine when the projected vector keeps less than half
         // of its squared norm, i.e. ||w - V h||^2 (= w.w - h.h) < h.h
         multidot<VT>(s, k, j + 1, k->w.p, hh.data());
-        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, n, (const double*)k->hdev.p, k->w.p);
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, n, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
         double hsq = 0.0;
         for (int i = 0; i <= j; i++) hsq += hh[i] * hh[i];
         const double ww = hh[j + 1];
         const double est = ww - hsq;
         if (alwaysRefine || !(est > hsq) || !(est > 0.0)) {
             multidot<VT>(s, k, j + 1, k->w.p, h2.data());
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, n, (const double*)k->hdev.p, k->w.p);
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, n, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
             double hn2;
             multidot<VT>(s, k, 0, k->w.p, &hn2);
             hn = std::sqrt(std::max(hn2, 0.0));
@@ -2627,7 +2551,7 @@ static double gmres_iter_t(das_solver* s, das_ksp* k) {
     if (!mgs && !(hn > GMRES_BREAKDOWN_TOL * std::sqrt(std::max(hh[j + 1], 0.0)))) { hn = 0.0; G.nBreakdown++; }  // happy breakdown (hh[j+1] = |A M^-1 v_j|^2)
     for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = hh[i] + h2[i];
     H[(size_t)(j + 1) * m + j] = hn;
-    if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, (const double*)k->w.p, Vb + (long long)(j + 1) * n);
+    if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, (const double*)k->w.p, Vb + (long long)(j + 1) * n, (const float*)nullptr, basis_lo(s, k, j + 1));
     for (int i = 0; i < j; i++) {
         double a = H[(size_t)i * m + j], b2 = H[(size_t)(i + 1) * m + j];
         H[(size_t)i * m + j] = cs[i] * a + sn[i] * b2;
@@ -2698,11 +2622,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     apply_operator(s, k->z.p, k->w.p);
     const int K = j + 1;
     const long long nbw = 4LL * nblk(n, MD2_CHUNK);
-    bf16s* const Vh = k->dotCopy ? reinterpret_cast<bf16s*>(k->Vh.p) : nullptr;
-    const long long ldh = (n + 7) / 8 * 8;
-    static_assert(MDH_CHUNK == MD2_CHUNK, "the bf16 inner-product kernel uses the partial-sum layout of k_multidot2");
-    if (Vh) hipLaunchKernelGGL(k_multidot2h, dim3(nblk(n, MDH_CHUNK)), dim3(256), 0, st, n, K, (const bf16s*)Vh, ldh, reinterpret_cast<const double*>(u), (const double*)k->w.p, k->partial.p, nbw);
-    else hipLaunchKernelGGL((k_multidot2<MD2_ROWS, VT, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, (const VT*)Vb, n, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
+    hipLaunchKernelGGL((k_multidot2<MD2_ROWS, VT, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, (const VT*)Vb, n, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
     hipLaunchKernelGGL(k_reduce, dim3(2 * K), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
     if (!(s->halo.active && s->halo.allreduce(k->hdev.p, 2 * K, st)) && s->allreduce_cb) s->allreduce_cb(k->hdev.p, 2 * K, s->comm_user);
     std::vector<double>& o = G.hh;
@@ -2723,7 +2643,14 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
         // orthogonality was lost - and uu - s.s cancels.  Rare; pay one extra pass: c = u - Q s explicitly, then c.c and c.v
         double* dsc = k->hdev.p + 2 * (m + 3);
         DAS_HIP(hipMemcpyAsync(dsc, sv, j * sizeof(double), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, (const VT*)Vb, n, (const double*)dsc, u);
+        if (k->split) {
+            // u is stored split: project its fp64 value (staging vector) with the hi + lo basis, store it split again
+            const double* ud = basis_as_double<VT>(s, k, j);
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, (const VT*)Vb, n, (const double*)dsc, const_cast<double*>(ud), (const float*)basis_lo(s, k, 0));
+            hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, st, n, 1.0, ud, u, (const float*)nullptr, basis_lo(s, k, j));
+        } else {
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, (const VT*)Vb, n, (const double*)dsc, u);
+        }
         hipLaunchKernelGGL((k_multidot2<MD2_ROWS, VT, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, 1, (const VT*)u, n, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
         hipLaunchKernelGGL(k_reduce, dim3(2), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
         if (!(s->halo.active && s->halo.allreduce(k->hdev.p, 2, st)) && s->allreduce_cb) s->allreduce_cb(k->hdev.p, 2, s->comm_user);
@@ -2768,7 +2695,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     for (int i = 0; i < j; i++) { co[i] = sv[i]; co[j + i] = tv[i] - gam * sv[i]; }
     double* dco = k->hdev.p + 2 * (m + 3);
     if (j > 0) DAS_HIP(hipMemcpyAsync(dco, co.data(), 2 * j * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT, VT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, Vb, n, (const double*)dco, gam, 1.0 / al, (const double*)k->w.p, Vh, ldh);
+    hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT, VT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, Vb, n, (const double*)dco, gam, 1.0 / al, (const double*)k->w.p, basis_lo(s, k, 0));
     // first-projection coefficients of the new pending vector: (t - H_jj s) / alpha, gamma - s_{j-1}
     for (int i = 0; i < j; i++) {
         double a = tv[i];
@@ -2792,7 +2719,7 @@ static void gmres_cycle_end_t(das_solver* s, das_ksp* k) {
         G.y[i] = sacc / G.H[(size_t)i * m + i];
     }
     DAS_HIP(hipMemcpyAsync(k->hdev.p, G.y.data(), j * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, j, (const VT*)basis_slot<VT>(s, k, 0), n, k->hdev.p, k->w.p);
+    hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, j, (const VT*)basis_slot<VT>(s, k, 0), n, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
     pc_apply_full(s, k, k->w.p, k->z.p);
     hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, k->z.p, 1.0, G.d_x);
     gmres_true_residual(s, k, G, true);
@@ -3184,7 +3111,7 @@ static int run_gmres_dr(das_solver* s, das_ksp* k, const double* d_rhs, double* 
     DAS_CHECK(s->op || s->fwd.on, DAS_ERR_STATE, "initializedRdWTMatrixFree() must be called before solveLinearEqn()");
     DAS_CHECK(!s->halo.active && !s->halo_cb, DAS_ERR_ARG, "amd.gmresDeflation is single-rank (the restart's small dense algebra is not replicated across ranks yet)");
     gmres_ws(s, k);
-    k->vf32 = false; k->dotCopy = false;  // the deflated solver keeps its (short) basis in fp64
+    k->vf32 = false; k->split = false;  // the deflated solver keeps its (short) basis in fp64
     if (k->useBilu) bilu_clear_abort(k->bilu, s->stream);
     if (!k->run) k->run.reset(new GmresRun);
     GmresRun& G = *k->run;
@@ -5020,9 +4947,9 @@ int das_ksp_get_history(das_ksp_t* k, double* hist, int cap) {
 int das_ksp_get_basis_info(das_ksp_t* k, int* fp32, double* mappedBytes, double* bytesPerVector) {
     DAS_TRY
     DAS_CHECK(k, DAS_ERR_ARG, "null argument");
-    if (fp32) *fp32 = (k->vf32 ? 1 : 0) | (k->dotCopy ? 2 : 0);
-    if (mappedBytes) *mappedBytes = (double)k->V.mappedBytes + (k->dotCopy ? (double)k->Vh.mappedBytes : 0.0);
-    if (bytesPerVector) *bytesPerVector = (double)k->Vn * (k->vf32 ? 4.0 : 8.0);
+    if (fp32) *fp32 = ((k->vf32 && !k->split) ? 1 : 0) | (k->split ? 2 : 0);
+    if (mappedBytes) *mappedBytes = (double)k->V.mappedBytes + (k->split ? (double)k->Vlo.mappedBytes : 0.0);
+    if (bytesPerVector) *bytesPerVector = (double)k->Vn * ((k->vf32 && !k->split) ? 4.0 : 8.0);
     return DAS_OK;
     DAS_CATCH
 }

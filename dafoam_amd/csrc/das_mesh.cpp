@@ -117,13 +117,11 @@ Options::Options() {
     // > 0: GMRES with deflated restarting (GMRES-DR): gmresRestart basis vectors, this many harmonic Ritz vectors carried across restarts
     // (round 4: prototyped on the CPU, tools/gmres_dr_study.py; the device path has not been measured yet - opt-in, default off)
     i["amd.gmresDeflation"] = 0;
-    // storage type of the Krylov basis: "fp64" | "fp32" (compressed basis: vectors stored in fp32, every sum in fp64 - half the bytes of the
-    // Gram-Schmidt passes) | "auto" (default) = fp64: fp32 storage breaks the Arnoldi relation by eps32 |y| and cost the wing its convergence (gmres_ws)
-    i["amd.gradFaceParallel"] = 1;  // DASimpleFoam gradients by the face-parallel, LDS-staged kernel k_grad_fp (0: one thread per cell, k_grad)
+    // storage type of the Krylov basis: "fp64" | "split" (hi + lo floats: the inner-product pass of the delayed re-orthogonalisation reads
+    // only the hi array - 12 instead of 16 bytes per basis entry and iteration - every vector-building pass reads hi + lo: Arnoldi relation to
+    // 2^-48) | "fp32" (compressed basis, short well-conditioned solves only) | "auto" (default): split for bases >= 1 GB with dcgs2, else fp64
     s["amd.krylovBasisPrecision"] = "auto";
-    // "bf16": the inner-product pass of the delayed re-orthogonalisation reads a bf16 COPY of the basis (2 instead of 8 bytes per entry), the
-    // update pass keeps fp64 - the Arnoldi relation stays exact, the basis is orthogonal to ~1e-3; "none"; "auto" (default): on for bases >= 1 GB
-    s["amd.krylovDotCopy"] = "auto";
+    i["amd.gradFaceParallel"] = 1;  // DASimpleFoam gradients by the face-parallel, LDS-staged kernel k_grad_fp where it is the faster one (0: always k_grad)
 }
 double Options::getd(const std::string& k) const {
     auto it = d.find(k);

@@ -227,11 +227,11 @@ class KSP:
         return buf[:m]
 
     def basisInfo(self):
-        """Krylov basis of the last solve: dict(fp32 (compressed storage, amd.krylovBasisPrecision), dotCopy (bf16 copy for the inner products,
-        amd.krylovDotCopy), mappedGB (basis + copy), bytesPerVector)."""
+        """Krylov basis of the last solve: dict(fp32 (compressed fp32 storage), split (hi + lo floats: inner products read hi only),
+        mappedGB, bytesPerVector) - amd.krylovBasisPrecision."""
         f, mb, bv = C.c_int(0), C.c_double(0), C.c_double(0)
         check(lib().das_ksp_get_basis_info(self.handle, C.byref(f), C.byref(mb), C.byref(bv)))
-        return dict(fp32=bool(f.value & 1), dotCopy=bool(f.value & 2), mappedGB=mb.value / 2**30, bytesPerVector=bv.value)
+        return dict(fp32=bool(f.value & 1), split=bool(f.value & 2), mappedGB=mb.value / 2**30, bytesPerVector=bv.value)
 
     def cycleLengths(self):
         """Columns of every closed Arnoldi cycle of the last solve (all but the last equal gmresRestart, DALinearEqn.C:155)."""

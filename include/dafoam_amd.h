@@ -334,8 +334,8 @@ int das_ksp_get_pc_structure_sizes(das_ksp_t* ksp, int* nNodes, long long* nBloc
 int das_ksp_get_pc_structure(das_ksp_t* ksp, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural);
 int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, double* seconds);
 int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
-/* Krylov basis of the last solve: *fp32 = bit 0: fp32 storage (amd.krylovBasisPrecision "fp32"), bit 1: a bf16 copy feeds the inner products
- * (amd.krylovDotCopy); device bytes mapped so far (basis + copy); bytes per stored basis vector */
+/* Krylov basis of the last solve (amd.krylovBasisPrecision): *fp32 = bit 0: plain fp32 storage, bit 1: split storage (hi + lo floats, the
+ * inner products read the hi array only); device bytes mapped so far; bytes per stored basis vector */
 int das_ksp_get_basis_info(das_ksp_t* ksp, int* fp32, double* mappedBytes, double* bytesPerVector);
 /* columns of every closed Arnoldi cycle of the last solveLinearEqn (reference: KSPGMRESSetRestart, DALinearEqn.C:155 - every cycle
  * but the last holds exactly gmresRestart columns); writes min(cap, count) entries, returns the count */

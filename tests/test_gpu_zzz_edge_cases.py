@@ -187,50 +187,33 @@ def test_gmres_deflated_restarting_matches_the_default_solver():
     assert it_full <= it_dr <= 2 * it_full + 10 and (it_dr < it_pl or f2 != 0)
 
 
-def test_compressed_fp32_krylov_basis_reaches_the_same_psi():
-    """amd.krylovBasisPrecision (round 5): the basis vectors stored in fp32 (compressed-basis GMRES: half the bytes of the two Gram-Schmidt
-    passes), every inner product / update / the Hessenberg matrix in fp64.  Against the fp64 basis on the same system at gmresRelTol
-    1e-6: fail 0 on the TRUE (recomputed) residual, psi equal to the accuracy both solves have; "auto" means fp64.  Then the bf16 DOT
-    COPY (amd.krylovDotCopy): exact Arnoldi relation, one cycle, the iteration count of the plain solver."""
+def test_split_and_fp32_krylov_basis_storage():
+    """amd.krylovBasisPrecision (round 5).  "split": every basis entry as hi + lo floats - the inner-product pass of the delayed
+    re-orthogonalisation reads the hi array only (4 of 8 bytes), every pass that builds vectors reads hi + lo, so the Arnoldi relation holds
+    to 2^-48 and only the Gram-Schmidt coefficients carry fp32-level errors: ONE cycle, the iteration count of the fp64 solver, psi equal
+    to the accuracy of the solves, also at 1e-10.  "fp32" (plain compressed storage): the relation is violated by eps32 |y| - the true
+    residual of the first cycle can miss the target and a second cycle follows (fine on this channel, fatal on the wing's plateau:
+    DESIGN.md 6a).  "auto" on this small basis = fp64."""
     case = channel_case(24, 14, 10, perturb=0.0, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
     g = Geometry(case.mesh)
     n = case.states.size
     rhs = np.zeros(n)
     rhs[0 : 3 * g.nC : 3] = g.V
     rhs *= J.state_scales(case, g, norm_states(case))
-    out = {}
-    for prec in ("fp64", "fp32", "auto"):
-        D = make(case, adjEqnOption={"gmresRelTol": 1e-6, "gmresAbsTol": 1e-300, "gmresRestart": 400, "gmresMaxIters": 800, "printInfo": 0}, amd={"krylovBasisPrecision": prec})
-        psi, fail = D.solveAdjoint(rhs)
-        info = D.ksp.info()
-        out[prec] = (psi, fail, info["iters"], info["res"] / info["res0"], D.ksp.basisInfo())
-        print(prec, "iterations", info["iters"], "rel", info["res"] / info["res0"], D.ksp.basisInfo())
-    assert out["fp32"][4]["fp32"] and not out["fp64"][4]["fp32"] and not out["auto"][4]["fp32"]
-    for prec in ("fp64", "fp32"):
-        assert out[prec][1] == 0 and out[prec][3] <= 1e-6
-    # fp32 STORAGE violates the Arnoldi relation by eps32 |y|: the recomputed true residual of the first cycle can miss the target and a second
-    # cycle follows (measured here: 119 iterations against 71; on the 2 M-cell wing it cost the convergence - why "auto" means fp64)
-    assert out["fp64"][2] <= out["fp32"][2] <= 3 * out["fp64"][2], (out["fp32"][2], out["fp64"][2])
-    assert relerr(out["fp32"][0], out["fp64"][0]) < 1e-4  # both are 1e-6-residual solutions of the same system
-    assert out["fp32"][4]["bytesPerVector"] * 2 == out["fp64"][4]["bytesPerVector"]
-    # amd.krylovDotCopy "bf16" (the default for bases >= 1 GB): the inner products read a bf16 copy, the updates stay fp64 - the Arnoldi relation
-    # is exact, so the TRUE residual meets the tolerance in the first cycle, at (nearly) the iteration count of the plain solver, also at 1e-10
     for rtol in (1e-6, 1e-10):
-        res = {}
-        for dc in ("none", "bf16"):
-            D = make(case, adjEqnOption={"gmresRelTol": rtol, "gmresAbsTol": 1e-300, "gmresRestart": 800, "gmresMaxIters": 800, "printInfo": 0}, amd={"krylovDotCopy": dc})
+        out = {}
+        for prec in ("fp64", "split", "fp32", "auto"):
+            D = make(case, adjEqnOption={"gmresRelTol": rtol, "gmresAbsTol": 1e-300, "gmresRestart": 800, "gmresMaxIters": 2000, "printInfo": 0}, amd={"krylovBasisPrecision": prec})
             psi, fail = D.solveAdjoint(rhs)
             info = D.ksp.info()
-            res[dc] = (psi, fail, info["iters"], info["res"] / info["res0"], D.ksp.basisInfo(), D.ksp.cycleLengths())
-            print("dot copy", dc, "rtol", rtol, "iterations", info["iters"], "rel", info["res"] / info["res0"], "cycles", D.ksp.cycleLengths())
-        assert res["bf16"][4]["dotCopy"] and not res["none"][4]["dotCopy"]
-        assert res["bf16"][1] == 0 and res["none"][1] == 0 and res["bf16"][3] <= rtol
-        assert len(res["bf16"][5]) == 1 and abs(res["bf16"][2] - res["none"][2]) <= 4 + 0.03 * res["none"][2], (res["bf16"][2], res["none"][2])
-        assert relerr(res["bf16"][0], res["none"][0]) < 100 * rtol
-    # a tight tolerance through the compressed (fp32-stored) basis: restarts act as iterative refinement, the true residual still gets there
-    D = make(case, adjEqnOption={"gmresRelTol": 1e-10, "gmresAbsTol": 1e-300, "gmresRestart": 400, "gmresMaxIters": 2000, "printInfo": 0}, amd={"krylovBasisPrecision": "fp32"})
-    psi10, fail10 = D.solveAdjoint(rhs)
-    D64 = make(case, adjEqnOption={"gmresRelTol": 1e-10, "gmresAbsTol": 1e-300, "gmresRestart": 400, "gmresMaxIters": 2000, "printInfo": 0}, amd={"krylovBasisPrecision": "fp64"})
-    psi64, fail64 = D64.solveAdjoint(rhs)
-    print("1e-10: fp32 basis", D.ksp.info()["iters"], "iterations in cycles", D.ksp.cycleLengths(), "; fp64", D64.ksp.info()["iters"])
-    assert fail10 == 0 and fail64 == 0 and relerr(psi10, psi64) < 1e-7
+            out[prec] = dict(psi=psi, fail=fail, its=info["iters"], rel=info["res"] / info["res0"], basis=D.ksp.basisInfo(), cycles=D.ksp.cycleLengths())
+            print("rtol", rtol, prec, "iterations", info["iters"], "rel", info["res"] / info["res0"], "cycles", D.ksp.cycleLengths(), D.ksp.basisInfo())
+        assert out["split"]["basis"]["split"] and not out["split"]["basis"]["fp32"] and out["fp32"]["basis"]["fp32"]
+        assert not out["fp64"]["basis"]["split"] and not out["auto"]["basis"]["split"] and not out["auto"]["basis"]["fp32"]
+        assert out["split"]["basis"]["bytesPerVector"] == out["fp64"]["basis"]["bytesPerVector"] == 2 * out["fp32"]["basis"]["bytesPerVector"]
+        for prec in ("fp64", "split", "fp32"):
+            assert out[prec]["fail"] == 0 and out[prec]["rel"] <= rtol, (prec, out[prec]["rel"])
+        assert len(out["split"]["cycles"]) == 1 and abs(out["split"]["its"] - out["fp64"]["its"]) <= 3, (out["split"]["its"], out["fp64"]["its"])
+        assert relerr(out["split"]["psi"], out["fp64"]["psi"]) < 100 * rtol
+        assert out["fp64"]["its"] <= out["fp32"]["its"] <= 4 * out["fp64"]["its"]
+        assert relerr(out["fp32"]["psi"], out["fp64"]["psi"]) < 100 * rtol
