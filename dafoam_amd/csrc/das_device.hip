@@ -2639,6 +2639,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     for (int i = 0; i < j; i++) normBq2 += G.h1[i] * G.h1[i];
     bool explicitProj = false;
     if (j > 0 && !(ss <= 1e-2 * uu)) {
+        if (getenv("DAS_GMRES_TRACE")) fprintf(stderr, "[dafoam_amd] dcgs2 step %d: s.s / u.u = %.3e > 1e-2: explicit projection, cycle closes\n", j, ss / uu);
         // the first projection left a large component in span(Q): u is (nearly) rounding noise - the Krylov space is exhausted or
         // orthogonality was lost - and uu - s.s cancels.  Rare; pay one extra pass: c = u - Q s explicitly, then c.c and c.v
         double* dsc = k->hdev.p + 2 * (m + 3);
@@ -2722,10 +2723,18 @@ static void gmres_cycle_end_t(das_solver* s, das_ksp* k) {
     hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, j, (const VT*)basis_slot<VT>(s, k, 0), n, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
     pc_apply_full(s, k, k->w.p, k->z.p);
     hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, k->z.p, 1.0, G.d_x);
+    const double recRes = k->hist.back();
     gmres_true_residual(s, k, G, true);
     k->hist.back() = G.beta;
     k->cycleLens.push_back(j);
     G.open = false;
+    static const bool trace = getenv("DAS_GMRES_TRACE") != nullptr;
+    if (trace) {
+        double ymax = 0.0;
+        for (int i = 0; i < j; i++) ymax = std::max(ymax, std::fabs(G.y[i]));
+        fprintf(stderr, "[dafoam_amd] GMRES cycle closed after %d columns (its %lld): recurrence |r| %.6e, true |r| %.6e (|r0| %.3e), max |y| %.3e, explicit projections %d, basis %s%s\n",
+                j, G.its, recRes, G.beta, k->res0, ymax, k->nrefine, k->split ? "split" : (k->vf32 ? "fp32" : "fp64"), G.safeOrth ? ", two-pass scheme from here" : "");
+    }
 }
 static void gmres_cycle_end(das_solver* s, das_ksp* k) {
     if (k->vf32) gmres_cycle_end_t<float>(s, k); else gmres_cycle_end_t<double>(s, k);
