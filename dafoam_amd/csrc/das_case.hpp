@@ -76,7 +76,7 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.offN = rho ? 5 : 4;
     p.offPhi = rho ? 6 : 5;
     p.hasT = cp.hasT;
-    { auto it = opt.i.find("amd.gradFaceParallel"); p.gradFaceParallel = it == opt.i.end() ? 1 : (int)(it->second != 0); }
+    { auto it = opt.i.find("amd.gradFaceParallel"); p.gradFaceParallel = it == opt.i.end() ? 1 : (int)it->second; }
     p.Cp = cp.Cp;
     p.Rgas = 8314.47 / cp.molWeight;  // Foam::constant::thermodynamic::RR / molWeight
     p.mu = cp.mu;

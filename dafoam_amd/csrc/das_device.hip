@@ -235,8 +235,11 @@ static inline int nblk(long long n, int b) { return (int)((n + b - 1) / b); }
 template <class T, class G>
 static void launch_grad_simple(const DevMeshT<G>& dm, const ResParams& prm, const T* W, ResWork<T>& wk, hipStream_t st) {
     if constexpr (std::is_same<G, double>::value) {
-        if (prm.gradFaceParallel && !prm.hasT) {
-            constexpr int CPB = sizeof(T) > 8 ? 16 : 32;  // dual numbers: 16 cells per workgroup (LDS: 20 x CPB + 120 x CPB scalars)
+        // measured at 2 M cells (profiles/r06e_*, r06f_*; rocprofv3 averages over 540 launches): fp64 states 448 -> 348 us (-22 %); dual numbers
+        // 568 -> 613 us (979 with the first LDS layout): the 16-byte scalars double the LDS traffic of the transposition and halve the cells per
+        // workgroup - the dual-number passes keep k_grad (amd.gradFaceParallel 2 forces the face-parallel kernel for them as well)
+        if (prm.gradFaceParallel && !prm.hasT && (sizeof(T) == 8 || prm.gradFaceParallel >= 2)) {
+            constexpr int CPB = sizeof(T) > 8 ? 16 : 32;  // dual numbers: 16 cells per workgroup (LDS: 5 x CPB + 120 x CPB scalars)
             const size_t shBytes = (size_t)(5 * CPB + 15 * CPB * 8) * sizeof(T);
             hipLaunchKernelGGL((k_grad_fp<T, CPB>), dim3(nblk(dm.nC, CPB)), dim3(CPB * 8), shBytes, st, dm, prm, W, wk.nut.p, wk.gU.p, wk.gP.p, wk.gN.p);
             return;
@@ -2428,6 +2431,7 @@ struct GmresRun {
     int nonImproving = 0, nBreakdown = 0;
     double betaStart = 0;         // true residual norm at the start of the open cycle
 };
+static bool gmres_trace() { static const bool on = [] { const char* e = getenv("DAS_GMRES_TRACE"); return e && *e && *e != '0'; }(); return on; }
 // a new basis vector whose norm is below this fraction of the norm of the operator image it was projected from is
 // rounding noise (the rounding errors of the projection itself are ~1e-16 of that norm, at any problem size: they are
 // componentwise): the Krylov space is exhausted - happy breakdown
@@ -2639,7 +2643,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     for (int i = 0; i < j; i++) normBq2 += G.h1[i] * G.h1[i];
     bool explicitProj = false;
     if (j > 0 && !(ss <= 1e-2 * uu)) {
-        if (getenv("DAS_GMRES_TRACE")) fprintf(stderr, "[dafoam_amd] dcgs2 step %d: s.s / u.u = %.3e > 1e-2: explicit projection, cycle closes\n", j, ss / uu);
+        if (gmres_trace()) fprintf(stderr, "[dafoam_amd] dcgs2 step %d: s.s / u.u = %.3e > 1e-2: explicit projection, cycle closes\n", j, ss / uu);
         // the first projection left a large component in span(Q): u is (nearly) rounding noise - the Krylov space is exhausted or
         // orthogonality was lost - and uu - s.s cancels.  Rare; pay one extra pass: c = u - Q s explicitly, then c.c and c.v
         double* dsc = k->hdev.p + 2 * (m + 3);
@@ -2728,8 +2732,7 @@ static void gmres_cycle_end_t(das_solver* s, das_ksp* k) {
     k->hist.back() = G.beta;
     k->cycleLens.push_back(j);
     G.open = false;
-    static const bool trace = getenv("DAS_GMRES_TRACE") != nullptr;
-    if (trace) {
+    if (gmres_trace()) {
         double ymax = 0.0;
         for (int i = 0; i < j; i++) ymax = std::max(ymax, std::fabs(G.y[i]));
         fprintf(stderr, "[dafoam_amd] GMRES cycle closed after %d columns (its %lld): recurrence |r| %.6e, true |r| %.6e (|r0| %.3e), max |y| %.3e, explicit projections %d, basis %s%s\n",

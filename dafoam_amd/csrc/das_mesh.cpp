@@ -121,7 +121,7 @@ Options::Options() {
     // only the hi array - 12 instead of 16 bytes per basis entry and iteration - every vector-building pass reads hi + lo: Arnoldi relation to
     // 2^-48) | "fp32" (compressed basis, short well-conditioned solves only) | "auto" (default): split for bases >= 1 GB with dcgs2, else fp64
     s["amd.krylovBasisPrecision"] = "auto";
-    i["amd.gradFaceParallel"] = 1;  // DASimpleFoam gradients by the face-parallel, LDS-staged kernel k_grad_fp where it is the faster one (0: always k_grad)
+    i["amd.gradFaceParallel"] = 1;  // DASimpleFoam gradients by the face-parallel, LDS-staged kernel k_grad_fp: 1 = where it is the faster one (fp64 passes), 2 = dual passes too, 0 = never
 }
 double Options::getd(const std::string& k) const {
     auto it = d.find(k);

@@ -218,3 +218,27 @@ def test_split_and_fp32_krylov_basis_storage():
         assert relerr(out["split"]["psi"], out["fp64"]["psi"]) < 100 * rtol
         assert out["fp64"]["its"] <= out["fp32"]["its"] <= 4 * out["fp64"]["its"]
         assert relerr(out["fp32"]["psi"], out["fp64"]["psi"]) < 100 * rtol
+
+
+@pytest.mark.parametrize("orth", ["dcgs2", "cgs"])
+def test_split_basis_with_restarts_and_with_the_two_pass_scheme(orth):
+    """The split basis through every consumer of the basis: restarted cycles (cycle start / solution update with hi + lo) and the
+    reference's two-pass Gram-Schmidt (`cgs`: what a solve falls back to after lost orthogonality) - iteration counts, cycle lengths and
+    psi equal to the fp64 basis."""
+    case = channel_case(24, 14, 10, perturb=0.0, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    n = case.states.size
+    rhs = np.zeros(n)
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= J.state_scales(case, g, norm_states(case))
+    out = {}
+    for prec in ("fp64", "split"):
+        D = make(case, adjEqnOption={"gmresRelTol": 1e-8, "gmresAbsTol": 1e-300, "gmresRestart": 30, "gmresMaxIters": 3000, "printInfo": 0},
+                 amd={"krylovBasisPrecision": prec, "gmresOrthogonalization": orth})
+        psi, fail = D.solveAdjoint(rhs)
+        info = D.ksp.info()
+        out[prec] = (psi, fail, info["iters"], info["res"] / info["res0"], D.ksp.cycleLengths(), D.ksp.basisInfo())
+        print(orth, prec, "iterations", info["iters"], "rel", info["res"] / info["res0"], "cycles", len(D.ksp.cycleLengths()))
+    assert out["split"][5]["split"] and out["fp64"][1] == 0 and out["split"][1] == 0
+    assert abs(out["split"][2] - out["fp64"][2]) <= 3 + 0.02 * out["fp64"][2], (out["split"][2], out["fp64"][2])
+    assert relerr(out["split"][0], out["fp64"][0]) < 1e-6

@@ -25,7 +25,7 @@ for st in "$@"; do
     test)
       timeout 600 python -m pytest tests -x -q -s -m gpu -k "$args" > $O/pytest_k.log 2>&1; grep -v "^\[dafoam" $O/pytest_k.log | tail -8 | cut -c1-300 ;;
     bench)
-      DAS_BENCH_VERBOSE=1 timeout 900 python bench.py $args > $O/bench_line.json 2> $O/bench.err; grep "^\[bench" $O/bench.err | tail -40 | cut -c1-250; cut -c1-1500 $O/bench_line.json ;;
+      DAS_BENCH_VERBOSE=1 DAS_GMRES_TRACE=${DAS_GMRES_TRACE:-} timeout 900 python bench.py $args > $O/bench_line.json 2> $O/bench.err; grep "^\[bench" $O/bench.err | tail -40 | cut -c1-250; cut -c1-1500 $O/bench_line.json ;;
     stats)
       cd /tmp; timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- python $R/bench.py --no-cpu --no-parity $args > $O/stats_bench_line.json 2> $O/stats.err
       cd $R; f=$(find $O/stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv && head -25 $O/kernel_stats.csv | cut -c1-200; rm -rf $O/stats ;;
