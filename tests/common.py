@@ -1,3 +1,5 @@
+import os
+
 import numpy as np
 
 NORM_STATES = {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0}  # reference tests/runRegTests_AeroOpt.py:83
@@ -37,6 +39,11 @@ def options(case, **extra):
     o = {"solverName": case.solver_name, "normalizeStates": dict(norm_states(case)), "adjEqnOption": {"printInfo": 0}}
     amd = dict(REFERENCE_PC)
     amd.update(extra.pop("amd", {}) or {})
+    # DAS_TEST_AMD="key=value,key=value": run a tier with other amd.* switches (e.g. gradFaceParallel=2: the face-parallel gradient kernel for
+    # the dual-number passes as well) without editing the tests
+    for kv in filter(None, os.environ.get("DAS_TEST_AMD", "").split(",")):
+        k, v = kv.split("=", 1)
+        amd.setdefault(k, int(v) if v.lstrip("-").isdigit() else v)
     o.update(extra)
     o["amd"] = amd
     return o
