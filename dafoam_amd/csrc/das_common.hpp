@@ -84,6 +84,7 @@ struct VmRange {
 };
 inline std::vector<VmRange>& vm_cache() { static std::vector<VmRange> c; return c; }
 inline std::mutex& vm_cache_mutex() { static std::mutex m; return m; }
+inline std::mutex& vm_api_mutex() { static std::mutex m; return m; }
 // last resort of a failed hipMalloc: give the physical memory of the cached (idle) ranges back to the device.  The ranges are
 // dropped for good - a range that was unmapped is never handed out again (see VmBuf::release)
 inline size_t vm_cache_trim() {
@@ -276,6 +277,9 @@ struct VmBuf {
             const size_t off = mappedBytes;
             size_t sz = std::min(CHUNK, reservedBytes - off);
             lk.unlock();
+            // (one mapper at a time, process-wide: concurrent hipMemCreate / hipMemMap / hipMemSetAccess from two threads were the one thing the
+            //  two failing split-basis runs of round 5 had that the fp64 runs never had)
+            std::lock_guard<std::mutex> vmLock(vm_api_mutex());
             hipMemGenericAllocationHandle_t h;
             hipError_t e = hipMemCreate(&h, sz, &prop, 0);
             // (a 2 GB physical chunk may not exist in fragmented HBM although smaller ones do)

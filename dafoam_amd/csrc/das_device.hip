@@ -1107,9 +1107,11 @@ struct das_ksp {
     // compressed basis (amd.krylovBasisPrecision, gmres_ws): the basis vectors are STORED in fp32 (half the bytes of the two Gram-Schmidt
     // passes, which are most of an iteration at depth > 150), all inner products / updates / the Hessenberg matrix stay fp64
     bool vf32 = false;
-    // split storage: V holds the hi floats, Vlo the lo floats of every basis vector (see the kernels); vf32 is set as well
+    // split storage: slot j of V holds [hi_j (n floats) | lo_j (n floats)] - the 8 n bytes an fp64 vector takes, so the range, its on-demand
+    // mapping and its single mapper thread are exactly those of the fp64 basis (round 5: a first version kept the lo halves in a SECOND
+    // virtual range with its own mapper; two of five 2 M-cell runs lost the Arnoldi relation after ~800 vectors - recurrence 2.5e-9, true
+    // residual 5.4e-5, profiles/r06f_*, r06j_* - which the single-range layout has not shown); vf32 is set as well
     bool split = false;
-    VmBuf<float> Vlo;
     DevBuf<double> ustage;  // fp64 copy of the basis vector the preconditioner is applied to (fp32 basis only)
     DevBuf<double> w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
     std::unique_ptr<struct GmresRun> run;
@@ -2234,7 +2236,6 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
         k->split = eligible && (prec == "split" || (prec == "auto" && dcgs2 && big));
         k->vf32 = k->split || (eligible && prec == "fp32");
         if (k->vf32 && k->ustage.n != (size_t)n) k->ustage.alloc(n);
-        if (k->split && k->Vlo.n < (size_t)((restart + 2) * n)) k->Vlo.reserve((size_t)(wantVec * n));
     }
     if (k->restart != restart || k->w.n != (size_t)n) {
         k->restart = (int)restart;
@@ -2249,26 +2250,24 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
 // the helper thread of the buffer maps 64 vectors ahead of the iteration; the solver waits only if it catches up
 // false: the device cannot hold that many vectors (gmres_advance then closes the cycle: the mapped part is the restart length)
 static inline bool gmres_map_basis(das_solver* s, das_ksp* k, long long nvec) {
-    const long long per = k->vf32 ? (s->n + 1) / 2 : s->n;  // fp64 elements of the range one basis vector occupies
+    const long long per = (k->vf32 && !k->split) ? (s->n + 1) / 2 : s->n;  // fp64 elements of the range one basis vector occupies
     k->V.request((size_t)((nvec + 64) * per));
-    if (k->split) {
-        k->Vlo.request((size_t)((nvec + 64) * s->n));
-        if (!k->Vlo.try_ensure((size_t)(nvec * s->n))) { if (k->V.workerError.empty()) k->V.workerError = "lo half of the split basis: " + k->Vlo.workerError; return false; }
-    }
     return k->V.try_ensure((size_t)(nvec * per));
 }
 // slot j of the basis in its storage type
+// distance between consecutive basis vectors in elements of the storage type (split: hi and lo floats of a vector are adjacent)
+static inline long long basis_ld(das_solver* s, das_ksp* k) { return k->split ? 2 * s->n : s->n; }
 template <class VT>
-static inline VT* basis_slot(das_solver* s, das_ksp* k, long long j) { return reinterpret_cast<VT*>(k->V.p) + j * s->n; }
+static inline VT* basis_slot(das_solver* s, das_ksp* k, long long j) { return reinterpret_cast<VT*>(k->V.p) + j * basis_ld(s, k); }
 // the lo half of slot j (split storage), or null
-static inline float* basis_lo(das_solver* s, das_ksp* k, long long j) { return k->split ? k->Vlo.p + j * s->n : nullptr; }
+static inline float* basis_lo(das_solver* s, das_ksp* k, long long j) { return k->split ? reinterpret_cast<float*>(k->V.p) + j * basis_ld(s, k) + s->n : nullptr; }
 
 // dev_out[0..m) = V^T w (V = m vectors of stride n starting at Vbase), dev_out[m] = w.w; summed over the ranks
 template <class VT>
 static void multidot_dev(das_solver* s, das_ksp* k, const VT* Vbase, int m, const double* w, double* dev_out) {
     const long long n = s->n;
     int nb = nblk(n, MD_CHUNK);
-    hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, n, m, Vbase, n, w, k->partial.p, nb);
+    hipLaunchKernelGGL(k_multidot, dim3(nb), dim3(256), 0, s->stream, n, m, Vbase, basis_ld(s, k), w, k->partial.p, nb);
     hipLaunchKernelGGL(k_reduce, dim3(m + 1), dim3(256), 0, s->stream, nb, k->partial.p, dev_out);
     if (!(s->halo.active && s->halo.allreduce(dev_out, m + 1, s->stream)) && s->allreduce_cb) s->allreduce_cb(dev_out, m + 1, s->comm_user);
 }
@@ -2514,6 +2513,7 @@ static double gmres_iter_t(das_solver* s, das_ksp* k) {
     const bool mgs = s->opt.geti("adjEqnOption.useMGSO") != 0;
     std::vector<double>&H = G.H, &hh = G.hh, &h2 = G.h2, &cs = G.cs, &sn = G.sn, &g = G.g;
     VT* const Vb = basis_slot<VT>(s, k, 0);
+    const long long ld = basis_ld(s, k);
     pc_apply_full(s, k, basis_as_double<VT>(s, k, j), k->z.p);
     apply_operator(s, k->z.p, k->w.p);
     double hn;
@@ -2522,9 +2522,9 @@ static double gmres_iter_t(das_solver* s, das_ksp* k) {
         // modified Gram-Schmidt: j+1 dependent (dot, axpy) pairs, coefficients stay on the device until the end
         double* hcol = k->hdev.p + (m + 2);
         for (int i = 0; i <= j; i++) {
-            multidot_dev<VT>(s, k, Vb + (long long)i * n, 1, k->w.p, k->hdev.p);
+            multidot_dev<VT>(s, k, Vb + (long long)i * ld, 1, k->w.p, k->hdev.p);
             DAS_HIP(hipMemcpyAsync(hcol + i, k->hdev.p, sizeof(double), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, 1, (const VT*)(Vb + (long long)i * n), n, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, i));
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, 1, (const VT*)(Vb + (long long)i * ld), ld, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, i));
         }
         multidot_dev<VT>(s, k, Vb, 0, k->w.p, k->hdev.p);
         DAS_HIP(hipMemcpyAsync(hcol + j + 1, k->hdev.p, sizeof(double), hipMemcpyDeviceToDevice, st));
@@ -2536,14 +2536,14 @@ static double gmres_iter_t(das_solver* s, das_ksp* k) {
         // KSP_GMRES_CGS_REFINE_IFNEEDED, DALinearEqn.C:160): refine when the projected vector keeps less than half
         // of its squared norm, i.e. ||w - V h||^2 (= w.w - h.h) < h.h
         multidot<VT>(s, k, j + 1, k->w.p, hh.data());
-        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, n, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
+        hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, ld, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
         double hsq = 0.0;
         for (int i = 0; i <= j; i++) hsq += hh[i] * hh[i];
         const double ww = hh[j + 1];
         const double est = ww - hsq;
         if (alwaysRefine || !(est > hsq) || !(est > 0.0)) {
             multidot<VT>(s, k, j + 1, k->w.p, h2.data());
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, n, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, B)), dim3(B), 0, st, n, j + 1, (const VT*)Vb, ld, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
             double hn2;
             multidot<VT>(s, k, 0, k->w.p, &hn2);
             hn = std::sqrt(std::max(hn2, 0.0));
@@ -2555,7 +2555,7 @@ static double gmres_iter_t(das_solver* s, das_ksp* k) {
     if (!mgs && !(hn > GMRES_BREAKDOWN_TOL * std::sqrt(std::max(hh[j + 1], 0.0)))) { hn = 0.0; G.nBreakdown++; }  // happy breakdown (hh[j+1] = |A M^-1 v_j|^2)
     for (int i = 0; i <= j; i++) H[(size_t)i * m + j] = hh[i] + h2[i];
     H[(size_t)(j + 1) * m + j] = hn;
-    if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, (const double*)k->w.p, Vb + (long long)(j + 1) * n, (const float*)nullptr, basis_lo(s, k, j + 1));
+    if (hn > 0.0) hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0 / hn, (const double*)k->w.p, Vb + (long long)(j + 1) * ld, (const float*)nullptr, basis_lo(s, k, j + 1));
     for (int i = 0; i < j; i++) {
         double a = H[(size_t)i * m + j], b2 = H[(size_t)(i + 1) * m + j];
         H[(size_t)i * m + j] = cs[i] * a + sn[i] * b2;
@@ -2621,12 +2621,13 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     const int m = G.m, j = G.pend;
     hipStream_t st = s->stream;
     VT* const Vb = basis_slot<VT>(s, k, 0);
-    VT* u = Vb + (long long)j * n;
+    const long long ld = basis_ld(s, k);
+    VT* u = Vb + (long long)j * ld;
     pc_apply_full(s, k, basis_as_double<VT>(s, k, j), k->z.p);
     apply_operator(s, k->z.p, k->w.p);
     const int K = j + 1;
     const long long nbw = 4LL * nblk(n, MD2_CHUNK);
-    hipLaunchKernelGGL((k_multidot2<MD2_ROWS, VT, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, (const VT*)Vb, n, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
+    hipLaunchKernelGGL((k_multidot2<MD2_ROWS, VT, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, K, (const VT*)Vb, ld, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
     hipLaunchKernelGGL(k_reduce, dim3(2 * K), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
     if (!(s->halo.active && s->halo.allreduce(k->hdev.p, 2 * K, st)) && s->allreduce_cb) s->allreduce_cb(k->hdev.p, 2 * K, s->comm_user);
     std::vector<double>& o = G.hh;
@@ -2651,10 +2652,10 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
         if (k->split) {
             // u is stored split: project its fp64 value (staging vector) with the hi + lo basis, store it split again
             const double* ud = basis_as_double<VT>(s, k, j);
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, (const VT*)Vb, n, (const double*)dsc, const_cast<double*>(ud), (const float*)basis_lo(s, k, 0));
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, (const VT*)Vb, ld, (const double*)dsc, const_cast<double*>(ud), (const float*)basis_lo(s, k, 0));
             hipLaunchKernelGGL(k_scale_to, dim3(nblk(n, 256)), dim3(256), 0, st, n, 1.0, ud, u, (const float*)nullptr, basis_lo(s, k, j));
         } else {
-            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, (const VT*)Vb, n, (const double*)dsc, u);
+            hipLaunchKernelGGL(k_multiaxpy, dim3(nblk(n, 256)), dim3(256), 0, st, n, j, (const VT*)Vb, ld, (const double*)dsc, u);
         }
         hipLaunchKernelGGL((k_multidot2<MD2_ROWS, VT, VT>), dim3(nblk(n, MD2_CHUNK)), dim3(256), 0, st, n, 1, (const VT*)u, n, (const VT*)u, (const double*)k->w.p, k->partial.p, nbw);
         hipLaunchKernelGGL(k_reduce, dim3(2), dim3(256), 0, st, (int)nbw, k->partial.p, k->hdev.p);
@@ -2700,7 +2701,7 @@ static double gmres_iter_dcgs2(das_solver* s, das_ksp* k) {
     for (int i = 0; i < j; i++) { co[i] = sv[i]; co[j + i] = tv[i] - gam * sv[i]; }
     double* dco = k->hdev.p + 2 * (m + 3);
     if (j > 0) DAS_HIP(hipMemcpyAsync(dco, co.data(), 2 * j * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT, VT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, Vb, n, (const double*)dco, gam, 1.0 / al, (const double*)k->w.p, basis_lo(s, k, 0));
+    hipLaunchKernelGGL((k_dcgs2_update<DCGS2_UNROLL, DCGS2_RPT, VT>), dim3(nblk(n, 256 * DCGS2_RPT)), dim3(256), 0, st, n, j, Vb, ld, (const double*)dco, gam, 1.0 / al, (const double*)k->w.p, basis_lo(s, k, 0));
     // first-projection coefficients of the new pending vector: (t - H_jj s) / alpha, gamma - s_{j-1}
     for (int i = 0; i < j; i++) {
         double a = tv[i];
@@ -2724,7 +2725,7 @@ static void gmres_cycle_end_t(das_solver* s, das_ksp* k) {
         G.y[i] = sacc / G.H[(size_t)i * m + i];
     }
     DAS_HIP(hipMemcpyAsync(k->hdev.p, G.y.data(), j * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, j, (const VT*)basis_slot<VT>(s, k, 0), n, (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
+    hipLaunchKernelGGL(k_lincomb, dim3(nblk(n, B)), dim3(B), 0, st, n, j, (const VT*)basis_slot<VT>(s, k, 0), basis_ld(s, k), (const double*)k->hdev.p, k->w.p, (const float*)basis_lo(s, k, 0));
     pc_apply_full(s, k, k->w.p, k->z.p);
     hipLaunchKernelGGL(k_axpby, dim3(nblk(n, B)), dim3(B), 0, st, n, 1.0, k->z.p, 1.0, G.d_x);
     const double recRes = k->hist.back();
@@ -4960,7 +4961,7 @@ int das_ksp_get_basis_info(das_ksp_t* k, int* fp32, double* mappedBytes, double*
     DAS_TRY
     DAS_CHECK(k, DAS_ERR_ARG, "null argument");
     if (fp32) *fp32 = ((k->vf32 && !k->split) ? 1 : 0) | (k->split ? 2 : 0);
-    if (mappedBytes) *mappedBytes = (double)k->V.mappedBytes + (k->split ? (double)k->Vlo.mappedBytes : 0.0);
+    if (mappedBytes) *mappedBytes = (double)k->V.mappedBytes;
     if (bytesPerVector) *bytesPerVector = (double)k->Vn * ((k->vf32 && !k->split) ? 4.0 : 8.0);
     return DAS_OK;
     DAS_CATCH
