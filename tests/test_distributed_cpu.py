@@ -135,11 +135,20 @@ def _worker_general(rank, world, port, q, kind="simple"):
 
         if kind == "rho":  # BASELINE configs[3]: DARhoSimpleFoam, 4-way cell partition
             gcase = rho_channel_case(NX, NY, NZ + 1, lengths=(2.0, 0.2, 0.2), grading_y=2.0)  # (renumber_case knows the incompressible layout only)
+        elif kind == "wing":  # the default bench workload at N > 1: NACA0012 wing, spanwise slabs of whole cell layers (bench.py)
+            from dafoam_amd.meshgen import naca0012_case
+
+            gcase = naca0012_case(16, 5, 8, span=0.8)
         else:
             gcase = renumber_case(channel_case(NX, NY, NZ, lengths=(2.0, 0.2, 0.2), grading_y=2.0, perturb=0.0), seed=11)
         NS = norm_states(gcase)
         gg = Geometry(gcase.mesh)
-        part = rcb_partition(gg.C, world)
+        if kind == "wing":
+            layer = np.arange(gcase.mesh.n_cells, dtype=np.int64) // (16 * 5)
+            assert np.allclose(gg.C[layer == 3][:, 2], gg.C[layer == 3][0, 2])  # the generator numbers the cells layer by layer
+            part = (layer * world // 8).astype(np.int32)
+        else:
+            part = rcb_partition(gg.C, world)
         # the sub-meshes are extracted on rank 0 and scattered (what ShardedAdjointGeneral.scattered does)
         subs = [extract_submesh(gcase, part, r) for r in range(world)] if rank == 0 else None
         out = [None]
@@ -174,10 +183,11 @@ def _worker_general(rank, world, port, q, kind="simple"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(2, "simple"), (4, "simple"), (4, "rho")])
+@pytest.mark.parametrize("world,kind", [(2, "simple"), (4, "simple"), (4, "rho"), (2, "wing")])
 def test_general_partition_unstructured_mesh(world, kind):
-    """Arbitrary (RCB) partition of a randomly renumbered mesh on 2 and 4 ranks, DASimpleFoam and DARhoSimpleFoam: extract_submesh
-    (on rank 0, scattered) + halo reduction == global oracle."""
+    """Arbitrary (RCB) partition of a randomly renumbered mesh on 2 and 4 ranks, DASimpleFoam and DARhoSimpleFoam, and the NACA0012 wing cut
+    into spanwise slabs of whole layers (what `bench.py --gpus N` does with its default workload, round 5): extract_submesh (on rank 0,
+    scattered) + halo reduction == global oracle."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
