@@ -66,9 +66,10 @@ inline long long device_exclusive_scan(long long n, const int* d_cnt, long long*
 }
 
 // ---- transpose ---------------------------------------------------------------------------------------------------------
+// (grid-stride: a launch may not exceed 2^32 threads - one thread per entry failed silently beyond 4.29e9 entries, i.e. above ~4 M cells:
+//  the first thing the 5 M-cell capacity run of round 5 hit, profiles/r06m_capacity_*)
 __global__ __launch_bounds__(256) void k_tr_count(long long nnz, const int* __restrict__ col, int* __restrict__ cnt) {
-    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nnz) atomicAdd(&cnt[col[k]], 1);
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (long long)gridDim.x * blockDim.x) atomicAdd(&cnt[col[k]], 1);
 }
 // 16 lanes per row: entry (r, j) goes to the next free slot of transposed row j
 __global__ __launch_bounds__(256) void k_tr_fill(long long n, const long long* __restrict__ rp, const int* __restrict__ col,
@@ -132,7 +133,8 @@ inline void device_transpose(const DevPattern& P, DevBuf<long long>& trp, DevBuf
     const long long n = P.n, nnz = P.nnz;
     DevBuf<int> cnt((size_t)n);
     DAS_HIP(hipMemsetAsync(cnt.p, 0, n * sizeof(int), st));
-    hipLaunchKernelGGL(k_tr_count, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, nnz, P.col.p, cnt.p);
+    hipLaunchKernelGGL(k_tr_count, dim3((unsigned)std::min<long long>((nnz + 255) / 256, 1LL << 22)), dim3(256), 0, st, nnz, P.col.p, cnt.p);
+    DAS_HIP(hipGetLastError());
     trp.alloc((size_t)n + 1);
     const long long tot = device_exclusive_scan(n, cnt.p, trp.p, st);
     DAS_CHECK(tot == nnz, DAS_ERR_INTERNAL, "device transpose: entry count mismatch");
