@@ -44,6 +44,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 NORM = {"U": 10.0, "p": 50.0, "nuTilda": 1e-3, "phi": 1.0}  # reference tests/runRegTests_AeroOpt.py:83
+NORM_RHO = {"U": 50.0, "p": 1.0e5, "T": 300.0, "nuTilda": 1e-3, "phi": 1.0}  # compressible solvers (the tier's NORM_STATES_RHO)
 
 
 def parse():
@@ -86,6 +87,10 @@ def parse():
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
     ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE"), help="amd.pcCoarseMode additive | deflated (default: the library's, deflated)")
     ap.add_argument("--orth", default=os.environ.get("DAS_BENCH_ORTH", "dcgs2"), help="dcgs2 (delayed re-orthogonalisation, 2 basis reads / iteration) | cgs (reference: refine if needed)")
+    ap.add_argument("--solver", default="DASimpleFoam", choices=["DASimpleFoam", "DARhoSimpleFoam", "DATurboFoam"],
+                    help="BASELINE configs[3] / [4]: the compressible solvers run on the bump channel of --nx/--ny/--nz cells per GPU with a synthetic subsonic state "
+                         "(p 101325, T 300; DATurboFoam: one MRF zone, rotating hub) - N > 1: RCB cell partition of the global channel (ShardedAdjointGeneral.scattered); "
+                         "no converged primal and no psi parity leg for them (the host adjoint of the parity leg covers DASimpleFoam)")
     ap.add_argument("--amd", action="append", default=[], metavar="KEY=VALUE", help="experiments: any amd.* option, e.g. --amd gradFaceParallel=0 (listed in config.pc_options_passed_by_bench)")
     return ap.parse_args()
 
@@ -114,8 +119,8 @@ def stage(msg):
 
 def make_opts(a, dev_index, restart, maxit, rtol):
     return {
-        "solverName": "DASimpleFoam",
-        "normalizeStates": dict(NORM),
+        "solverName": a.solver,
+        "normalizeStates": dict(NORM if a.solver == "DASimpleFoam" else NORM_RHO),
         "adjEqnOption": {"gmresRestart": int(restart), "gmresMaxIters": int(maxit), "gmresRelTol": rtol, "gmresAbsTol": 1e-300, "printInfo": 0,
                          "jacMatReOrdering": a.ordering},
         # amd.*: ONLY what the command line / the device budget asks for explicitly - the preconditioner is the library's own default
@@ -127,6 +132,15 @@ def make_opts(a, dev_index, restart, maxit, rtol):
                     **_amd_overrides(a)),
         "amdDevice": dev_index,
     }
+
+
+def compressible_channel(a, nx):
+    """DARhoSimpleFoam / DATurboFoam on the bump channel (the generators of the GPU tier: perfect gas, p 101325, T 300, subsonic; DATurboFoam with
+    one MRF zone and a rotating hub - reference tests/runRegTests_DARhoSimpleFoam*.py, runRegTests_DATurboFoam*.py), synthetic smooth state."""
+    from dafoam_amd.meshgen import rho_channel_case, turbo_channel_case
+
+    kw = dict(lengths=(2.0, 0.2, 0.2), grading_y=2.0)
+    return rho_channel_case(nx, a.ny, a.nz, **kw) if a.solver == "DARhoSimpleFoam" else turbo_channel_case(nx, a.ny, a.nz, **kw)
 
 
 def _amd_overrides(a):
@@ -185,12 +199,29 @@ def main():
 
     L = _capi.lib()
     t_setup = time.time()
-    if a.global_cells > 0:
-        a.workload = "channel"  # --global-cells: the structured channel cut into slabs (strong scaling of a synthetic size)
+    if a.global_cells > 0 or a.solver != "DASimpleFoam":
+        a.workload = "channel"  # --global-cells: the structured channel cut into slabs; the compressible solvers: the channel generators
     opts = make_opts(a, dev_index, a.solve_restart, a.solve_maxit, 1e-6)
     sharded = None
     primal, case2d = None, None
-    if world > 1 and a.workload == "naca":
+    if world > 1 and a.solver != "DASimpleFoam":
+        # BASELINE configs[3] / [4]: compressible solver on a cell-partitioned mesh - rank 0 generates the global channel (nx x world columns),
+        # an RCB partition cuts it, the extended sub-meshes are scattered (the reference's decomposePar in memory)
+        from dafoam_amd.distributed import ShardedAdjointGeneral, rcb_partition
+
+        gcase, part = None, None
+        if rank == 0:
+            gcase = compressible_channel(a, a.nx * world)
+            from dafoam_amd.meshgen import _InputGeometry
+
+            part = rcb_partition(_InputGeometry(gcase.mesh).C, world)
+            stage(f"rank 0: global {a.solver} channel ready ({gcase.mesh.n_cells} cells), scattering {world} sub-meshes")
+        sharded = ShardedAdjointGeneral.scattered(gcase, part, opts, device_index=dev_index, src=0)
+        del gcase
+        D = sharded.D
+        case = sharded.case
+        ncell = int(sharded.owned[3 * case.mesh.n_cells : 4 * case.mesh.n_cells].sum())
+    elif world > 1 and a.workload == "naca":
         # N > 1 keeps the N = 1 workload: the SAME wing, linearised about the SAME converged primal, cut into N
         # spanwise slabs of whole cell layers (strong scaling).  Rank 0 converges the primal on its GPU exactly like the N = 1 run
         # (section by grid sequencing, extrusion, Newton polish), extracts every rank's extended sub-mesh (owned cells + 3 ghost rings)
@@ -256,6 +287,8 @@ def main():
             from dafoam_amd.meshgen import naca0012_case
 
             case = naca0012_case(a.naca[0], a.naca[1], a.naca[2], span=a.naca_dz * a.naca[2], first_cell=a.naca_first_cell)
+        elif a.solver != "DASimpleFoam":
+            case = compressible_channel(a, a.nx)
         else:
             # state = prolongation of a converged coarse primal (dafoam_amd/data/channel_primal_coarse.npz)
             case = bench_channel_case(a.nx, a.ny, a.nz)
@@ -432,7 +465,9 @@ def main():
             cpu = _with_deadline(lambda: cpu_port_at_bench_size(a, L, h, ksp, pc, n, N, op_nnz, pc_nnz, rhs_h, spmv_ms, pc_ms),
                                  float(os.environ.get("DAS_BENCH_CPU_DEADLINE", 150)), "cpu port at the bench size")
             stage(f"cpu port at the bench size: {({k: v for k, v in cpu.items() if k in ('value', 'ms_per_iteration', 'error', 'skipped')})}")
-        if not a.no_parity and not a.no_cpu and world == 1:
+        if not a.no_parity and not a.no_cpu and world == 1 and a.solver != "DASimpleFoam":
+            parity = {"skipped": "the host adjoint of the parity leg (oracle/adjoint_host.py) covers DASimpleFoam + SA; the compressible solvers' psi parity is in the GPU tier (small meshes, direct solves)"}
+        elif not a.no_parity and not a.no_cpu and world == 1:
             parity = _with_deadline(lambda: psi_parity_200k(a, dev_index, case2d), float(os.environ.get("DAS_BENCH_PARITY_DEADLINE", 330)), "psi parity leg") \
                 if not _OVERRUN else {"skipped": "the cpu port leg overran its deadline; the host is not usable for the CPU legs"}
             stage(f"psi parity leg: {({k: v for k, v in parity.items() if k in ('psi_rel_diff_gpu_vs_cpu', 'error')})}")
@@ -464,13 +499,16 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell hex mesh per GPU ({a.nx}x{a.ny}x{a.nz} bump channel, wall-normal "
+                "workload": ((f"BASELINE configs[{3 if a.solver == 'DARhoSimpleFoam' else 4}] family: {a.solver}+SA adjoint, {n_global}-cell bump channel ({ncell} cells per GPU, "
+                              f"{a.nx}x{a.ny}x{a.nz} per GPU, wall-normal grading; synthetic subsonic perfect-gas state p 101325 T 300" + (", one MRF zone with a rotating hub" if a.solver == "DATurboFoam" else "") + ")")
+                             if a.solver != "DASimpleFoam" else
+                             f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell hex mesh per GPU ({a.nx}x{a.ny}x{a.nz} bump channel, wall-normal "
                              f"grading; state: prolonged converged coarse primal)" if a.workload != "naca" else
                              f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {n_global}-cell NACA0012 wing section (O-grid, {a.naca[0]} around x {a.naca[1]} normal x {a.naca[2]} "
                              f"spanwise hexahedra of {a.naca_dz} chords, first cell {a.naca_first_cell:g} chords, far field 20 chords, U 10 m/s, AoA 2 deg, Re 6.7e5; "
                              + ("synthetic noisy boundary-layer state)" if a.naca_synthetic else
                                 "linearised about the primal CONVERGED on the GPU: Newton-Krylov, grid sequencing, |R| = %.2e)" % primal_residual_norm))
-                            + f", full GMRES adjoint, 8 states/cell, reference stencil tables; "
+                            + f", full GMRES adjoint, {8 if a.solver == 'DASimpleFoam' else 9} states/cell, reference stencil tables; "
                             f"timed iterations sit at Krylov basis sizes j in [{j0}, {j0 + a.steps})"
                             + (" = around the mean basis depth of the full solve" if (mean_depth is not None and not a.window_at_warmup) else ""),
                 "value_is": ("iterations/s of the K timed iterations placed at the mean basis depth of the full solve to 1e-6 (the orthogonalisation cost is linear in the depth, "
@@ -480,7 +518,8 @@ def main():
                 "primal_residual_norm": primal_residual_norm,
                 "cells_per_gpu": ncell,
                 "global_cells": n_global,
-                "partition": (None if world == 1 else ("spanwise slabs of whole cell layers, 3 ghost rings per cut (ShardedAdjointGeneral.scattered from rank 0)" if a.workload == "naca"
+                "partition": (None if world == 1 else ("RCB cell partition of the global channel, 3 ghost rings (ShardedAdjointGeneral.scattered from rank 0)" if a.solver != "DASimpleFoam" else
+                                                       "spanwise slabs of whole cell layers, 3 ghost rings per cut (ShardedAdjointGeneral.scattered from rank 0)" if a.workload == "naca"
                                                        else "slabs along x, 3 ghost layers per cut (ShardedAdjoint)")),
                 "global_solve_iterations_per_sec": a.steps * 1.0 / dt,
                 "cell_iterations_per_sec": n_global * a.steps * 1.0 / dt,
