@@ -87,6 +87,7 @@ def parse():
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
     ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE"), help="amd.pcCoarseMode additive | deflated (default: the library's, deflated)")
     ap.add_argument("--orth", default=os.environ.get("DAS_BENCH_ORTH", "dcgs2"), help="dcgs2 (delayed re-orthogonalisation, 2 basis reads / iteration) | cgs (reference: refine if needed)")
+    ap.add_argument("--naca-partition", default="span", choices=["span", "around"], help="naca, N > 1: spanwise slabs of whole layers (default) | sectors around the airfoil")
     ap.add_argument("--solver", default="DASimpleFoam", choices=["DASimpleFoam", "DARhoSimpleFoam", "DATurboFoam"],
                     help="BASELINE configs[3] / [4]: the compressible solvers run on the bump channel of --nx/--ny/--nz cells per GPU with a synthetic subsonic state "
                          "(p 101325, T 300; DATurboFoam: one MRF zone, rotating hub) - N > 1: RCB cell partition of the global channel (ShardedAdjointGeneral.scattered); "
@@ -245,8 +246,11 @@ def main():
                           "levels": [{k: (list(v) if isinstance(v, tuple) else v) for k, v in r.items()} for r in lv],
                           "extruded": {k: (list(v) if isinstance(v, tuple) else v) for k, v in ex.items()}, "seconds": time.time() - t0}
             # spanwise slabs of whole layers (the generator numbers the cells layer by layer: layer = cell // (n_around * n_normal))
-            layer = np.arange(gcase.mesh.n_cells, dtype=np.int64) // (a.naca[0] * a.naca[1])
-            part = (layer * world // a.naca[2]).astype(np.int32)
+            cid = np.arange(gcase.mesh.n_cells, dtype=np.int64)
+            if a.naca_partition == "around":  # sectors around the airfoil (cut lines run wall-normal; every rank keeps all spanwise layers)
+                part = ((cid % a.naca[0]) * world // a.naca[0]).astype(np.int32)
+            else:
+                part = ((cid // (a.naca[0] * a.naca[1])) * world // a.naca[2]).astype(np.int32)
             stage(f"rank 0: global wing ready ({gcase.mesh.n_cells} cells), scattering {world} sub-meshes")
         sharded = ShardedAdjointGeneral.scattered(gcase, part, opts, device_index=dev_index, src=0)
         del gcase
@@ -519,7 +523,7 @@ def main():
                 "cells_per_gpu": ncell,
                 "global_cells": n_global,
                 "partition": (None if world == 1 else ("RCB cell partition of the global channel, 3 ghost rings (ShardedAdjointGeneral.scattered from rank 0)" if a.solver != "DASimpleFoam" else
-                                                       "spanwise slabs of whole cell layers, 3 ghost rings per cut (ShardedAdjointGeneral.scattered from rank 0)" if a.workload == "naca"
+                                                       ("spanwise slabs of whole cell layers" if a.naca_partition == "span" else "sectors around the airfoil") + ", 3 ghost rings per cut (ShardedAdjointGeneral.scattered from rank 0)" if a.workload == "naca"
                                                        else "slabs along x, 3 ghost layers per cut (ShardedAdjoint)")),
                 "global_solve_iterations_per_sec": a.steps * 1.0 / dt,
                 "cell_iterations_per_sec": n_global * a.steps * 1.0 / dt,
