@@ -1397,3 +1397,31 @@ def test_bench_cpu_leg_guards():
     from oracle.linear import available_cpus
 
     assert 1 <= bench._cpu_threads() == available_cpus() <= len(os.sched_getaffinity(0))
+
+
+def test_bench_passes_no_preconditioner_option_by_default(monkeypatch):
+    """`bench.py` must pass no PC option the library would not pick itself.  With the default command line the
+    `amd` dict of the options holds the Krylov memory budget only; the library's own defaults are the ones the wing needs
+    (`amd.pcUpwindBlend 0.5`, deflated coarse mode - DAOPTION and the C++ Options agree); `--amd`, `--pc-blend`, `--coarse-mode`,
+    `--solver` reach the options; the PMC traffic of the stated workload is found for the `roofline` objects."""
+    import importlib.util
+    import sys
+
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    o = bench.make_opts(a, 0, 1000, 1000, 1e-6)
+    assert sorted(o["amd"]) == ["maxKrylovBytes"] and o["solverName"] == "DASimpleFoam" and a.workload == "naca" and a.naca == [200, 63, 160]
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--amd", "gradFaceParallel=0", "--amd", "krylovBasisPrecision=fp64", "--pc-blend", "0.2", "--coarse-mode", "additive",
+                                      "--solver", "DARhoSimpleFoam"])
+    a = bench.parse()
+    o = bench.make_opts(a, 0, 1000, 1000, 1e-6)
+    assert o["amd"]["gradFaceParallel"] == 0 and o["amd"]["krylovBasisPrecision"] == "fp64" and o["amd"]["pcUpwindBlend"] == 0.2 and o["amd"]["pcCoarseMode"] == "additive"
+    assert o["solverName"] == "DARhoSimpleFoam" and "T" in o["normalizeStates"]
+    from dafoam_amd.pyDAFoam import DAOPTION
+
+    d = DAOPTION()
+    assert d.amd["pcUpwindBlend"] == 0.5 and d.amd["pcCoarseMode"] == "deflated"
+    assert bench.pmc_traffic(2112359800, "spmv") > 2.5e10 and bench.pmc_traffic(2112359800, "k_bilu_sweep_forward") > 1.0e10 and bench.pmc_traffic(1, "spmv") is None
