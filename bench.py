@@ -87,7 +87,10 @@ def parse():
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
     ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE"), help="amd.pcCoarseMode additive | deflated (default: the library's, deflated)")
     ap.add_argument("--orth", default=os.environ.get("DAS_BENCH_ORTH", "dcgs2"), help="dcgs2 (delayed re-orthogonalisation, 2 basis reads / iteration) | cgs (reference: refine if needed)")
-    ap.add_argument("--naca-partition", default="span", choices=["span", "around"], help="naca, N > 1: spanwise slabs of whole layers (default) | sectors around the airfoil")
+    ap.add_argument("--naca-partition", default="columns", choices=["columns", "span", "around"],
+                    help="naca, N > 1: 'columns' (default) = blocks in the (around, wall-normal) index plane, every rank keeps whole spanwise columns of cells - the cut "
+                         "never crosses the strong spanwise coupling of the thin layers; 'around' = sectors around the airfoil; 'span' = spanwise slabs of whole layers")
+    ap.add_argument("--asm-overlap", type=int, default=None, help="adjEqnOption.asmOverlap (N > 1: rings of ghost cells in every rank's sub-domain solve); default: the library's (1, the reference's)")
     ap.add_argument("--solver", default="DASimpleFoam", choices=["DASimpleFoam", "DARhoSimpleFoam", "DATurboFoam"],
                     help="BASELINE configs[3] / [4]: the compressible solvers run on the bump channel of --nx/--ny/--nz cells per GPU with a synthetic subsonic state "
                          "(p 101325, T 300; DATurboFoam: one MRF zone, rotating hub) - N > 1: RCB cell partition of the global channel (ShardedAdjointGeneral.scattered); "
@@ -122,8 +125,8 @@ def make_opts(a, dev_index, restart, maxit, rtol):
     return {
         "solverName": a.solver,
         "normalizeStates": dict(NORM if a.solver == "DASimpleFoam" else NORM_RHO),
-        "adjEqnOption": {"gmresRestart": int(restart), "gmresMaxIters": int(maxit), "gmresRelTol": rtol, "gmresAbsTol": 1e-300, "printInfo": 0,
-                         "jacMatReOrdering": a.ordering},
+        "adjEqnOption": dict({"gmresRestart": int(restart), "gmresMaxIters": int(maxit), "gmresRelTol": rtol, "gmresAbsTol": 1e-300, "printInfo": 0,
+                              "jacMatReOrdering": a.ordering}, **({"asmOverlap": int(a.asm_overlap)} if a.asm_overlap is not None else {})),
         # amd.*: ONLY what the command line / the device budget asks for explicitly - the preconditioner is the library's own default
         # (round 5: amd.pcUpwindBlend 0.5 + deflated coarse mode are library defaults, no longer bench switches)
         "amd": dict({"maxKrylovBytes": int(a.krylov_gb * 2**30)},
@@ -142,6 +145,40 @@ def compressible_channel(a, nx):
 
     kw = dict(lengths=(2.0, 0.2, 0.2), grading_y=2.0)
     return rho_channel_case(nx, a.ny, a.nz, **kw) if a.solver == "DARhoSimpleFoam" else turbo_channel_case(nx, a.ny, a.nz, **kw)
+
+
+def naca_partition(cid, dims, world, kind):
+    """Cell partition of the extruded O-grid (cell id = i + n_around (j + n_normal k)).  The spanwise layers are thin (0.025 chords) against the
+    in-plane size of most cells, so the spanwise faces carry the strongest couplings of the wing's Jacobian: 'columns' and 'around' keep
+    every spanwise column of cells on one rank (the cut crosses only in-plane faces), 'span' cuts exactly those couplings (round 5:
+    1 rank 641 iterations, 2 spanwise slabs > 1000)."""
+    na, nn, nz = dims
+    i, j, k = cid % na, (cid // na) % nn, cid // (na * nn)
+    if kind == "span":
+        return (k * world // nz).astype(np.int32)
+    if kind == "around":
+        return (i * world // na).astype(np.int32)
+    # columns: recursive bisection of the (i, j) index rectangle, always across its longer side (in cells)
+    part = np.zeros(cid.size, dtype=np.int32)
+
+    def rec(sel, lo_i, hi_i, lo_j, hi_j, p0, np_):
+        if np_ == 1:
+            part[sel] = p0
+            return
+        nl = np_ // 2
+        if (hi_i - lo_i) >= (hi_j - lo_j):
+            mid = lo_i + (hi_i - lo_i) * nl // np_
+            left = i[sel] < mid
+            rec(sel[left], lo_i, mid, lo_j, hi_j, p0, nl)
+            rec(sel[~left], mid, hi_i, lo_j, hi_j, p0 + nl, np_ - nl)
+        else:
+            mid = lo_j + (hi_j - lo_j) * nl // np_
+            left = j[sel] < mid
+            rec(sel[left], lo_i, hi_i, lo_j, mid, p0, nl)
+            rec(sel[~left], lo_i, hi_i, mid, hi_j, p0 + nl, np_ - nl)
+
+    rec(np.arange(cid.size), 0, na, 0, nn, 0, world)
+    return part
 
 
 def _amd_overrides(a):
@@ -247,10 +284,7 @@ def main():
                           "extruded": {k: (list(v) if isinstance(v, tuple) else v) for k, v in ex.items()}, "seconds": time.time() - t0}
             # spanwise slabs of whole layers (the generator numbers the cells layer by layer: layer = cell // (n_around * n_normal))
             cid = np.arange(gcase.mesh.n_cells, dtype=np.int64)
-            if a.naca_partition == "around":  # sectors around the airfoil (cut lines run wall-normal; every rank keeps all spanwise layers)
-                part = ((cid % a.naca[0]) * world // a.naca[0]).astype(np.int32)
-            else:
-                part = ((cid // (a.naca[0] * a.naca[1])) * world // a.naca[2]).astype(np.int32)
+            part = naca_partition(cid, a.naca, world, a.naca_partition)
             stage(f"rank 0: global wing ready ({gcase.mesh.n_cells} cells), scattering {world} sub-meshes")
         sharded = ShardedAdjointGeneral.scattered(gcase, part, opts, device_index=dev_index, src=0)
         del gcase
@@ -310,7 +344,14 @@ def main():
     n = D.getNLocalAdjointStates()
     R0 = np.zeros(n)
     D.solver.getResiduals(R0)
-    primal_residual_norm = float(np.linalg.norm(R0))
+    if sharded is not None:
+        # the norm of the GLOBAL residual: owned rows only (the ghost rows of an extended sub-mesh end at artificial cut patches - their
+        # residuals mean nothing: rounds 5's N > 1 lines printed 3.9e4 / 9e-3 for a state whose owned rows are at 6e-7), summed over the ranks
+        r2 = torch.tensor([float(np.sum(R0[sharded.owned] ** 2))], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(r2)
+        primal_residual_norm = float(np.sqrt(r2.item()))
+    else:
+        primal_residual_norm = float(np.linalg.norm(R0))
     t0 = time.time()
     D.solver.runColoring()
     t_color = time.time() - t0
@@ -523,7 +564,8 @@ def main():
                 "cells_per_gpu": ncell,
                 "global_cells": n_global,
                 "partition": (None if world == 1 else ("RCB cell partition of the global channel, 3 ghost rings (ShardedAdjointGeneral.scattered from rank 0)" if a.solver != "DASimpleFoam" else
-                                                       ("spanwise slabs of whole cell layers" if a.naca_partition == "span" else "sectors around the airfoil") + ", 3 ghost rings per cut (ShardedAdjointGeneral.scattered from rank 0)" if a.workload == "naca"
+                                                       {"span": "spanwise slabs of whole cell layers", "around": "sectors around the airfoil (whole spanwise columns per rank)",
+                                                        "columns": "blocks of the (around, wall-normal) index plane (whole spanwise columns per rank)"}[a.naca_partition] + ", 3 ghost rings per cut (ShardedAdjointGeneral.scattered from rank 0)" if a.workload == "naca"
                                                        else "slabs along x, 3 ghost layers per cut (ShardedAdjoint)")),
                 "global_solve_iterations_per_sec": a.steps * 1.0 / dt,
                 "cell_iterations_per_sec": n_global * a.steps * 1.0 / dt,
@@ -539,6 +581,7 @@ def main():
                 "pc_coarse_aggregates": int(L.das_ksp_get_coarse(ksp.handle, None)),
                 "pc_coarse_aggregates_global": int(global_coarse) if world > 1 else None,
                 "pc_coarse_mode": D.getOption("amd")["pcCoarseMode"],
+                "asm_overlap": (int(getattr(sharded, "asm_overlap", 0)) if sharded is not None else None),
                 "pc_upwind_blend": D.getOption("amd")["pcUpwindBlend"],
                 "pc_options_passed_by_bench": sorted(k for k in make_opts(a, dev_index, 1, 1, 1e-6)["amd"] if k != "maxKrylovBytes"),
                 "coarse_ms": L.das_timer_avg_ms(h, b"coarse"),

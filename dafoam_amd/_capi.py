@@ -283,6 +283,8 @@ _SIGS = {
     "das_comm_init_rccl": (C.c_int, [_VP, C.c_int, C.c_int, C.c_char_p]),
     "das_comm_set_halo": (C.c_int, [_VP, C.c_int, c_int_p, c_ll_p, c_int_p, c_ll_p, c_int_p, C.c_longlong, c_int_p]),
     "das_set_exchange_cb": (C.c_int, [_VP, _VP, _VP]),
+    "das_set_pc_overlap": (C.c_int, [_VP, C.POINTER(C.c_ubyte), C.c_int, c_ll_p, c_int_p, c_ll_p, c_int_p]),
+    "das_set_gather_cb": (C.c_int, [_VP, _VP, _VP]),
     "das_comm_is_native": (C.c_int, [_VP]),
     "das_comm_reset": (C.c_int, [_VP]),
     "das_set_comm": (C.c_int, [_VP, _VP, _VP, _VP]),

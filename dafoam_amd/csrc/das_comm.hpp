@@ -84,6 +84,14 @@ __global__ void k_zero_idx(long long cnt, const int* __restrict__ idx, double* _
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < cnt) y[idx[k]] = 0.0;
 }
+__global__ void k_pack_idx(long long cnt, const int* __restrict__ idx, const double* __restrict__ y, double* __restrict__ buf) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) buf[k] = y[idx[k]];
+}
+__global__ void k_unpack_idx(long long cnt, const int* __restrict__ idx, const double* __restrict__ buf, double* __restrict__ y) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) y[idx[k]] = buf[k];
+}
 
 typedef void (*das_exchange_fn)(double* d_send, double* d_recv, void* user);
 
@@ -139,6 +147,54 @@ struct HaloPlan {
             if (nr > 0) hipLaunchKernelGGL(k_halo_add, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, nr, recvIdx.p + recvOff[i], recvBuf.p + recvOff[i], y);
         }
         if (nGhost > 0) hipLaunchKernelGGL(k_zero_idx, dim3((unsigned)((nGhost + 255) / 256)), dim3(256), 0, st, nGhost, ghostIdx.p, y);
+    }
+    // the halo REDUCTION of a vector that is already evaluated on all extended rows (the sparse A Z product of the deflated coarse
+    // mode): ghost-row values travel to their owners and are added there, the local ghost rows are zeroed
+    void reduce_vector(double* y, hipStream_t st) {
+        if (nSend > 0) hipLaunchKernelGGL(k_pack_idx, dim3((unsigned)((nSend + 255) / 256)), dim3(256), 0, st, nSend, sendIdx.p, (const double*)y, sendBuf.p);
+        if (comm) {
+            DAS_NCCL(rccl().GroupStart());
+            for (size_t i = 0; i < peers.size(); i++) {
+                const long long ns = sendOff[i + 1] - sendOff[i], nr = recvOff[i + 1] - recvOff[i];
+                if (ns > 0) DAS_NCCL(rccl().Send(sendBuf.p + sendOff[i], (size_t)ns, ncclDouble, peers[i], comm, st));
+                if (nr > 0) DAS_NCCL(rccl().Recv(recvBuf.p + recvOff[i], (size_t)nr, ncclDouble, peers[i], comm, st));
+            }
+            DAS_NCCL(rccl().GroupEnd());
+        } else if (exchange_cb) exchange_cb(sendBuf.p, recvBuf.p, cb_user);
+        for (size_t i = 0; i < peers.size(); i++) {
+            const long long nr = recvOff[i + 1] - recvOff[i];
+            if (nr > 0) hipLaunchKernelGGL(k_halo_add, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, st, nr, recvIdx.p + recvOff[i], recvBuf.p + recvOff[i], y);
+        }
+        if (nGhost > 0) hipLaunchKernelGGL(k_zero_idx, dim3((unsigned)((nGhost + 255) / 256)), dim3(256), 0, st, nGhost, ghostIdx.p, y);
+    }
+    // ---- overlap of the additive-Schwarz preconditioner (adjEqnOption.asmOverlap, reference DALinearEqn.C:212-216): the sub-domain
+    // solve of a rank covers its owned unknowns plus `overlap` rings of ghost cells; before every apply the input vector's entries
+    // on those ghost unknowns are GATHERED from their owners (the opposite direction of the reduction above, restricted to the overlap).
+    // ovSendIdx: my owned states in a peer's overlap (packed in the peer's order), ovRecvIdx: my overlap ghost states, per peer.
+    bool ovActive = false;
+    std::vector<long long> ovSendOff, ovRecvOff;
+    DevBuf<int> ovSendIdx, ovRecvIdx;
+    DevBuf<double> ovSendBuf, ovRecvBuf;
+    long long nOvSend = 0, nOvRecv = 0;
+    das_exchange_fn gather_cb = nullptr;
+    void* gather_user = nullptr;
+    void gather_overlap(double* v, hipStream_t st) {
+        if (!ovActive) return;
+        if (nOvSend > 0) hipLaunchKernelGGL(k_pack_idx, dim3((unsigned)((nOvSend + 255) / 256)), dim3(256), 0, st, nOvSend, ovSendIdx.p, (const double*)v, ovSendBuf.p);
+        if (comm) {
+            DAS_NCCL(rccl().GroupStart());
+            for (size_t i = 0; i < peers.size(); i++) {
+                const long long ns = ovSendOff[i + 1] - ovSendOff[i], nr = ovRecvOff[i + 1] - ovRecvOff[i];
+                if (ns > 0) DAS_NCCL(rccl().Send(ovSendBuf.p + ovSendOff[i], (size_t)ns, ncclDouble, peers[i], comm, st));
+                if (nr > 0) DAS_NCCL(rccl().Recv(ovRecvBuf.p + ovRecvOff[i], (size_t)nr, ncclDouble, peers[i], comm, st));
+            }
+            DAS_NCCL(rccl().GroupEnd());
+        } else if (gather_cb) gather_cb(ovSendBuf.p, ovRecvBuf.p, gather_user);
+        else throw das::Error(DAS_ERR_STATE, "asmOverlap > 0 on several ranks needs a transport (RCCL communicator or das_set_gather_cb)");
+        if (nOvRecv > 0) hipLaunchKernelGGL(k_unpack_idx, dim3((unsigned)((nOvRecv + 255) / 256)), dim3(256), 0, st, nOvRecv, ovRecvIdx.p, (const double*)ovRecvBuf.p, v);
+    }
+    void zero_overlap(double* z, hipStream_t st) {
+        if (ovActive && nOvRecv > 0) hipLaunchKernelGGL(k_zero_idx, dim3((unsigned)((nOvRecv + 255) / 256)), dim3(256), 0, st, nOvRecv, ovRecvIdx.p, z);
     }
     // sum of a small device buffer over the ranks, in stream order
     bool allreduce(double* d_buf, int n, hipStream_t st) {

@@ -799,14 +799,14 @@ __global__ __launch_bounds__(256) void k_az_build(long long n, const long long* 
     const long long b = ptr[i];
     for (int q = 0; q < m; q++) { oa[b + q] = la[q]; ov[b + q] = ls[q]; }
 }
-// out = v - (A Z) u
+// out = v - (A Z) u   (v == nullptr: out = (A Z) u - several ranks reduce the ghost rows before the subtraction)
 __global__ __launch_bounds__(256) void k_az_apply(long long n, const long long* __restrict__ ptr, const int* __restrict__ oa, const double* __restrict__ ov,
                                                   const double* __restrict__ u, const double* __restrict__ v, double* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double acc = 0.0;
     for (long long k = ptr[i]; k < ptr[i + 1]; k++) acc += ov[k] * u[oa[k]];
-    out[i] = v[i] - acc;
+    out[i] = v ? v[i] - acc : acc;
 }
 
 // ---- RAS/ILU(k) apply: one workgroup per (overlapping) additive-Schwarz block -------------------------------------
@@ -1097,7 +1097,7 @@ struct das_ksp {
         DevBuf<long long> azPtr;
         DevBuf<int> azAgg;
         DevBuf<double> azVal;
-        const void* azOp = nullptr;  // the operator matrix A Z was built from (rebuilt when the operator is re-assembled)
+        long long azOpId = -1;  // id of the operator A Z was built from (das_solver::opId; rebuilt when the operator is re-assembled)
         long long azEpoch = -1, azNnz = 0;
         bool azReady = false, azFailed = false;
     } coarse;
@@ -1114,6 +1114,8 @@ struct das_ksp {
     bool split = false;
     DevBuf<double> ustage;  // fp64 copy of the basis vector the preconditioner is applied to (fp32 basis only)
     DevBuf<double> w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
+    bool rasOverlap = false;  // restricted additive Schwarz across ranks: the factorisation covers owned + overlap unknowns (setup_node_ilu)
+    DevBuf<double> pcin;      // ... its input: a copy of the vector with the overlap entries gathered from their owners
     std::unique_ptr<struct GmresRun> run;
     std::unique_ptr<struct BlockWork> block;
     std::vector<double> block_res0, block_res;
@@ -1197,6 +1199,11 @@ struct das_solver {
     bool own_stream = false;
     std::vector<unsigned char> owned;  // per state; empty = single-domain
     DevBuf<unsigned char> d_owned;
+    // additive-Schwarz overlap (das_set_pc_overlap; adjEqnOption.asmOverlap, reference DALinearEqn.C:212-216): the unknowns of this rank's
+    // sub-domain solve = owned + `asmOverlap` rings of ghost cells; empty = the owned unknowns (block-Jacobi across ranks)
+    std::vector<unsigned char> pcMask;
+    DevBuf<unsigned char> d_pcMask;
+    long long opId = 0;  // bumped whenever the assembled operator is created or destroyed (caches keyed on it)
     struct FwdOp {  // Newton primal: the Krylov operator is (dR/dW S + D / tau) applied matrix-free by one dual-number residual pass
         bool on = false;
         double invTau = 0.0;
@@ -1524,6 +1531,8 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
     Mat& M = out->m;
     M.n = n;
     const bool masked = !s->owned.empty();
+    // columns kept on a sharded rank: the owned residuals; the PC matrix also keeps the residuals of the Schwarz overlap
+    const unsigned char* colMask = !masked ? (const unsigned char*)nullptr : ((isPC && !s->pcMask.empty()) ? s->d_pcMask.p : s->d_owned.p);
     const bool useBound = !(bound < 1.0e-16);
     if (!useBound && !masked) {
         M.nnz = jc.nnz;
@@ -1539,8 +1548,7 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
         M.val = std::move(vals);
     } else {
         DevBuf<int> cnt(n);
-        hipLaunchKernelGGL(k_count_keep, dim3(nblk(n, B)), dim3(B), 0, st, n, c.t_rowptr.p, c.t_col.p, vals.p, bound, useBound,
-                           masked ? s->d_owned.p : (const unsigned char*)nullptr, cnt.p);
+        hipLaunchKernelGGL(k_count_keep, dim3(nblk(n, B)), dim3(B), 0, st, n, c.t_rowptr.p, c.t_col.p, vals.p, bound, useBound, colMask, cnt.p);
         DAS_HIP(hipStreamSynchronize(st));
         std::vector<int> hc = cnt.to_host();
         std::vector<long long> nrp(n + 1, 0);
@@ -1549,8 +1557,7 @@ static das_mat* assemble(das_solver* s, int isPC, int mode) {
         M.rowptr.upload(nrp);
         M.col.alloc(M.nnz);
         M.val.alloc(M.nnz);
-        hipLaunchKernelGGL(k_compact, dim3(nblk(n, B)), dim3(B), 0, st, n, c.t_rowptr.p, c.t_col.p, vals.p, bound, useBound,
-                           masked ? s->d_owned.p : (const unsigned char*)nullptr, M.rowptr.p, M.col.p, M.val.p);
+        hipLaunchKernelGGL(k_compact, dim3(nblk(n, B)), dim3(B), 0, st, n, c.t_rowptr.p, c.t_col.p, vals.p, bound, useBound, colMask, M.rowptr.p, M.col.p, M.val.p);
     }
     DAS_HIP(hipStreamSynchronize(st));
     // the per-colour scatter lists and the transposed structure are only needed during assembly: at 2 M cells they hold
@@ -2033,9 +2040,12 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     const Mat& A = k->pcmat->m;
     const int reach = pc_stencil_reach(s);
     const int nthr = (int)std::max<long long>(1, std::min<long long>(das::host_threads(), s->opt.geti("amd.setupThreads")));
-    bilu_setup(s->mesh, s->st_full.states, s->n, s->owned, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
+    // several ranks: the sub-domain of this rank = its owned unknowns, or - asmOverlap > 0 - those plus the overlap rings (das_set_pc_overlap)
+    bilu_setup(s->mesh, s->st_full.states, s->n, (s->pcMask.empty() || k->pcTranspose) ? s->owned : s->pcMask, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
                k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s), k->pcTranspose, k->pcDiagScale, k->shiftExLo, k->shiftExHi, k->shiftEnd);
     k->useBilu = true;
+    k->rasOverlap = !s->pcMask.empty() && !k->pcTranspose && s->halo.ovActive;
+    if (k->rasOverlap && k->pcin.n != (size_t)s->n) k->pcin.alloc(s->n);
     k->pc.setup_seconds = wall_seconds() - t0;
     k->pc.nBlocks = 1;
     k->pc.fnnz = (k->bilu.nL + k->bilu.nU + k->bilu.nNodes) * (long long)BILU_NB2;
@@ -2062,7 +2072,7 @@ static void coarse_build_operator(das_solver* s, das_ksp* k, int naggG, int aggO
         for (long long c = 0; c < N; c++) if (aggRowG[c] >= 0) cellsAll[pos[aggRowG[c]]++] = (int)c;
     }
     C.naggG = naggG; C.aggOff = aggOff; C.global = naggG > C.nagg;
-    C.azOp = nullptr; C.azReady = false;  // the sparse A Z of the deflated mode belongs to the old aggregates
+    C.azOpId = -1; C.azReady = false;  // the sparse A Z of the deflated mode belongs to the old aggregates
     C.agg.upload(aggOwn); C.aggRow.upload(aggRowG); C.cellsAll.upload(cellsAll); C.aptrAll.upload(aptrAll);
     DevBuf<double> E((size_t)naggG * naggG);
     E.zero();
@@ -2176,7 +2186,16 @@ static void pc_apply(das_solver* s, das_ksp* k, const double* b, double* x) {
     hipEvent_t ev = nullptr;
     s->timer.begin("pc", s->stream, ev);
     if (k->useBilu) {
-        bilu_apply(k->bilu, b, x, s->stream);
+        if (k->rasOverlap) {
+            // restricted additive Schwarz (reference: PCASM, overlap asmOverlap, PC_ASM_RESTRICT): the sub-domain solve sees the vector on
+            // owned + overlap unknowns (overlap entries gathered from their owner ranks), only the owned part of its result is kept
+            DAS_HIP(hipMemcpyAsync(k->pcin.p, b, (size_t)s->n * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+            s->halo.gather_overlap(k->pcin.p, s->stream);
+            bilu_apply(k->bilu, k->pcin.p, x, s->stream);
+            s->halo.zero_overlap(x, s->stream);
+        } else {
+            bilu_apply(k->bilu, b, x, s->stream);
+        }
         s->timer.end("pc", s->stream, ev);
         return;
     }
@@ -2215,9 +2234,9 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
         k->V.reserve((size_t)(wantVec * n));  // (sized for fp64 vectors whatever the storage type of this solve: switching needs no new range)
         k->Vn = n;
     }
-    {   // storage type of the basis.  "auto" (default): fp32 when the tolerance is looser than what a compressed basis delivers per cycle
-        // (CB-GMRES, Aliaga et al. 2022: the recurrence tracks the true residual to ~1e-7 of |r0|); always fp64 for tight tolerances
-        // (the parity tests solve to 1e-10 .. 1e-12), modified Gram-Schmidt, deflated restarting and the Newton primal's inner solves
+    {   // storage type of the basis.  "auto" (default): split (hi + lo floats) for the delayed re-orthogonalisation when the basis is >= 1 GB,
+        // else fp64; the tolerance does not enter (split storage keeps 48 mantissa bits per entry: the parity tests solve to 1e-10 .. 1e-12
+        // with it); always fp64 for modified Gram-Schmidt, deflated restarting and the Newton primal's inner solves
         std::string prec = "auto";
         { auto ip = s->opt.s.find("amd.krylovBasisPrecision"); if (ip != s->opt.s.end()) prec = ip->second; }
         DAS_CHECK(prec == "auto" || prec == "fp64" || prec == "fp32" || prec == "split", DAS_ERR_ARG, "amd.krylovBasisPrecision: auto | fp64 | split | fp32");
@@ -2232,7 +2251,18 @@ static void gmres_ws(das_solver* s, das_ksp* k) {
         // hi + lo floats, inner products on hi (fp32-accurate coefficients), everything else on hi + lo.
         // "auto" = split for the delayed re-orthogonalisation when the basis is >= 1 GB (the Gram-Schmidt passes then dominate), else fp64.
         const bool dcgs2 = s->opt.gets("amd.gmresOrthogonalization") == "dcgs2" && s->opt.geti("adjEqnOption.useMGSO") == 0;
-        const bool big = (size_t)(restart + 2) * (size_t)n * 8 >= ((size_t)1 << 30);
+        bool big = (size_t)(restart + 2) * (size_t)n * 8 >= ((size_t)1 << 30);
+        if (s->halo.active || s->allreduce_cb) {
+            // several ranks: n (owned + ghost rows) differs from rank to rank, but the storage type fixes the recurrence target (recTarget)
+            // every rank compares the SAME all-reduced residual with - the ranks must agree on it or they disagree on closing a cycle
+            // (ADVICE round 5): split everywhere as soon as one rank's basis is that large
+            DevBuf<double> f(1);
+            const double fv = big ? 1.0 : 0.0;
+            DAS_HIP(hipMemcpyAsync(f.p, &fv, sizeof(double), hipMemcpyHostToDevice, s->stream));
+            if (!(s->halo.active && s->halo.allreduce(f.p, 1, s->stream)) && s->allreduce_cb) s->allreduce_cb(f.p, 1, s->comm_user);
+            DAS_HIP(hipStreamSynchronize(s->stream));
+            big = f.to_host()[0] > 0.5;
+        }
         k->split = eligible && (prec == "split" || (prec == "auto" && dcgs2 && big));
         k->vf32 = k->split || (eligible && prec == "fp32");
         if (k->vf32 && k->ustage.n != (size_t)n) k->ustage.alloc(n);
@@ -2287,11 +2317,13 @@ static void apply_operator(das_solver* s, const double* x, double* y);
 // primal's shifted operator keep the full product.  amd.pcCoarseSparseAZ 0 switches it off.
 static bool coarse_az_ready(das_solver* s, das_ksp* k) {
     das_ksp::CoarsePC& C = k->coarse;
-    if (!s->op || s->fwd.on || s->halo.active || s->halo_cb || C.global) return false;
+    if (!s->op || s->fwd.on) return false;
     { auto it = s->opt.i.find("amd.pcCoarseSparseAZ"); if (it != s->opt.i.end() && it->second == 0) return false; }
     const Mat& A = s->op->m;
-    if (C.azOp == (const void*)s->op.get() && C.azEpoch == s->op_epoch) return C.azReady;
-    C.azOp = (const void*)s->op.get(); C.azEpoch = s->op_epoch; C.azReady = false; C.azFailed = false;
+    // keyed on the operator's id, not its address: solveAdjoint destroys and re-creates the operator per solve and the allocator may hand
+    // back the same address
+    if (C.azOpId == s->opId && C.azEpoch == s->op_epoch) return C.azReady;
+    C.azOpId = s->opId; C.azEpoch = s->op_epoch; C.azReady = false; C.azFailed = false;
     const long long n = s->n;
     hipStream_t st = s->stream;
     DevBuf<int> cnt(n), ovf(1);
@@ -2299,7 +2331,16 @@ static bool coarse_az_ready(das_solver* s, das_ksp* k) {
     hipLaunchKernelGGL(k_az_build, dim3(nblk(n, 256)), dim3(256), 0, st, n, A.rowptr.p, A.col.p, A.val.p, C.N, C.off, C.agg.p, 0, cnt.p, (const long long*)nullptr,
                        (int*)nullptr, (double*)nullptr, ovf.p);
     DAS_HIP(hipStreamSynchronize(st));
-    if (ovf.to_host()[0]) {
+    int ovfAny = ovf.to_host()[0];
+    if (s->halo.active || s->allreduce_cb) {  // several ranks: all of them take the same path (the fallback is a collective operator product)
+        DevBuf<double> f(1);
+        const double fv = ovfAny ? 1.0 : 0.0;
+        DAS_HIP(hipMemcpyAsync(f.p, &fv, sizeof(double), hipMemcpyHostToDevice, st));
+        if (!(s->halo.active && s->halo.allreduce(f.p, 1, st)) && s->allreduce_cb) s->allreduce_cb(f.p, 1, s->comm_user);
+        DAS_HIP(hipStreamSynchronize(st));
+        ovfAny = f.to_host()[0] > 0.5 ? 1 : 0;
+    }
+    if (ovfAny) {
         C.azFailed = true;
         fprintf(stderr, "[dafoam_amd] deflated coarse mode: a row of the operator touches more than %d aggregates - keeping the full operator product per apply\n", AZ_CAP);
         return false;
@@ -2334,7 +2375,15 @@ static void pc_apply_full(das_solver* s, das_ksp* k, const double* v, double* z)
             hipLaunchKernelGGL(k_coarse_prolong, dim3(nblk(n, 256)), dim3(256), 0, s->stream, C.N, n, C.off, C.agg.p, C.u.p, C.c.p, 1);
             if (coarse_az_ready(s, k)) {
                 // A c = (A Z) u with the precomputed sparse A Z: ~1.2 entries per row instead of the whole operator
-                hipLaunchKernelGGL(k_az_apply, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, C.azPtr.p, C.azAgg.p, C.azVal.p, C.u.p, v, C.rr.p);
+                if (s->halo.active || s->halo_cb) {
+                    // several ranks: (A_ext Z) u on all extended rows, the ghost rows reduced to their owners like an operator product
+                    hipLaunchKernelGGL(k_az_apply, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, C.azPtr.p, C.azAgg.p, C.azVal.p, C.u.p, (const double*)nullptr, C.rr.p);
+                    if (s->halo.active) s->halo.reduce_vector(C.rr.p, s->stream);
+                    else s->halo_cb(C.rr.p, s->comm_user);
+                    hipLaunchKernelGGL(k_axpby, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, 1.0, v, -1.0, C.rr.p);
+                } else {
+                    hipLaunchKernelGGL(k_az_apply, dim3(nblk(n, 256)), dim3(256), 0, s->stream, n, C.azPtr.p, C.azAgg.p, C.azVal.p, C.u.p, v, C.rr.p);
+                }
                 s->timer.end("coarse", s->stream, ev);
             } else {
                 s->timer.end("coarse", s->stream, ev);
@@ -3893,6 +3942,7 @@ int das_initialize_drdwt_matrix_free(das_solver_t* s) {
     DAS_TRY
     need_init(s);
     s->op.reset(assemble(s, 0, (int)s->opt.geti("amd.jacMode")));
+    s->opId++;
     // the Krylov operator: vector-state rows repacked as group rows (das_opmat.hpp); amd.opPackVector 0 keeps the plain CSR
     {
         auto it = s->opt.i.find("amd.opPackVector");
@@ -3915,6 +3965,7 @@ int das_destroy_drdwt_matrix_free(das_solver_t* s) {
     DAS_TRY
     DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
     s->op.reset();
+    s->opId++;
     return DAS_OK;
     DAS_CATCH
 }
@@ -5087,6 +5138,45 @@ int das_comm_set_halo(das_solver_t* s, int npeers, const int* peers, const long 
     if (nGhost) H.ghostIdx.upload(ghostIdx, nGhost);
     H.ensure_streams();
     H.active = true;
+    return DAS_OK;
+    DAS_CATCH
+}
+// additive-Schwarz overlap across ranks (adjEqnOption.asmOverlap; reference DALinearEqn.C:212-216, PCASMSetOverlap): pcMask[state] != 0 for
+// the unknowns of this rank's sub-domain solve (owned + overlap rings; a superset of the owned mask), and per peer of the halo plan (same
+// peer order as das_comm_set_halo) the owned states it needs from me (ovSend) and my overlap ghost states it owns (ovRecv, in its send
+// order).  Call before calcdRdWT(1) / createMLRKSPMatrixFree: the PC matrix keeps the residual columns of the overlap, the factorisation
+// covers them, every apply gathers the overlap entries of its input first and keeps the owned part of its result (restricted variant).
+// pcMask == NULL switches the overlap off (block-Jacobi across ranks).
+int das_set_pc_overlap(das_solver_t* s, const unsigned char* pcMask, int npeers, const long long* ovSendOff, const int* ovSendIdx, const long long* ovRecvOff,
+                       const int* ovRecvIdx) {
+    DAS_TRY
+    need_init(s);
+    HaloPlan& H = s->halo;
+    if (!pcMask) { s->pcMask.clear(); H.ovActive = false; return DAS_OK; }
+    DAS_CHECK(!s->owned.empty(), DAS_ERR_STATE, "das_set_pc_overlap: das_set_owned_mask first");
+    DAS_CHECK(H.active && npeers == (int)H.peers.size() && (npeers == 0 || (ovSendOff && ovRecvOff)), DAS_ERR_ARG, "das_set_pc_overlap: the peer list is that of das_comm_set_halo");
+    s->pcMask.assign(pcMask, pcMask + s->n);
+    for (long long i = 0; i < s->n; i++) DAS_CHECK(!s->owned[i] || s->pcMask[i], DAS_ERR_ARG, "das_set_pc_overlap: the sub-domain must contain every owned unknown");
+    s->d_pcMask.upload(s->pcMask);
+    H.ovSendOff.assign(1, 0);
+    H.ovRecvOff.assign(1, 0);
+    if (npeers) { H.ovSendOff.assign(ovSendOff, ovSendOff + npeers + 1); H.ovRecvOff.assign(ovRecvOff, ovRecvOff + npeers + 1); }
+    H.nOvSend = H.ovSendOff.back(); H.nOvRecv = H.ovRecvOff.back();
+    for (long long q = 0; q < H.nOvSend; q++) DAS_CHECK(ovSendIdx[q] >= 0 && ovSendIdx[q] < s->n && s->owned[ovSendIdx[q]], DAS_ERR_ARG, "das_set_pc_overlap: send entries are owned states");
+    for (long long q = 0; q < H.nOvRecv; q++)
+        DAS_CHECK(ovRecvIdx[q] >= 0 && ovRecvIdx[q] < s->n && !s->owned[ovRecvIdx[q]] && s->pcMask[ovRecvIdx[q]], DAS_ERR_ARG, "das_set_pc_overlap: recv entries are overlap ghost states");
+    if (H.nOvSend) { H.ovSendIdx.upload(ovSendIdx, H.nOvSend); H.ovSendBuf.alloc(H.nOvSend); }
+    if (H.nOvRecv) { H.ovRecvIdx.upload(ovRecvIdx, H.nOvRecv); H.ovRecvBuf.alloc(H.nOvRecv); }
+    H.ovActive = true;
+    return DAS_OK;
+    DAS_CATCH
+}
+// host-staged transport of the overlap gather (gloo tests on single-GPU boxes): cb(d_send, d_recv) moves the packed segments
+int das_set_gather_cb(das_solver_t* s, das_exchange_cb cb, void* user) {
+    DAS_TRY
+    DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
+    s->halo.gather_cb = cb;
+    s->halo.gather_user = user;
     return DAS_OK;
     DAS_CATCH
 }

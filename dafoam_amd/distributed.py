@@ -10,7 +10,9 @@ SURVEY.md section 2.3).  MI355X design:
   * dRdW^T.x = local SpMV over the extended rows followed by ONE halo *reduction* (ghost-row contributions are
     sent to the owner rank and added there) - grouped point-to-point over xGMI (each neighbour pair has its own
     link); dots/norms = one small all-reduce per fused multi-dot;
-  * the preconditioner (RAS/ILU blocks) is built on owned cells only: no communication in the PC.
+  * the preconditioner: one node-block ILU per rank on its owned unknowns + adjEqnOption.asmOverlap rings of ghost cells (restricted
+    additive Schwarz across the ranks like the reference's ASM, DALinearEqn.C:212-216; round 6): one owner -> ghost gather of the
+    overlap entries per apply; ONE global pressure coarse space (one small all-reduce per apply).
 
 The partition implemented here is a slab decomposition along x of the structured channel generators
 (dafoam_amd.meshgen); the halo machinery itself only needs (owner rank, global key) per extended state.
@@ -241,6 +243,116 @@ def install_comm(obj, native=None):
     _capi.check(L.das_set_comm(h, None, C.cast(obj._cb[1], C.c_void_p), None))
 
 
+def cell_adjacency(mesh):
+    """Face-neighbour graph of the cells as a scipy CSR matrix: internal faces and coupled (cyclic) patch pairs."""
+    import scipy.sparse as sp
+
+    N, nIF = mesh.n_cells, mesh.n_internal_faces
+    own, nei = np.asarray(mesh.owner, dtype=np.int64), np.asarray(mesh.neighbour, dtype=np.int64)
+    rows, cols = [own[:nIF]], [nei]
+    pname = {p.name: p for p in mesh.patches}
+    for p in mesh.patches:
+        if p.type == "cyclic" and p.size:
+            q = pname[p.neighbour]
+            rows.append(own[p.start : p.start + p.size])
+            cols.append(own[q.start : q.start + q.size])
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    A = sp.coo_matrix((np.ones(r.size, np.int8), (r, c)), shape=(N, N)).tocsr()
+    return ((A + A.T) > 0).astype(np.int8).tocsr()
+
+
+def overlap_mask(mesh, owner_rank, rank, overlap):
+    """Unknowns of this rank's additive-Schwarz sub-domain (reference: PCASMSetOverlap(asmOverlap), DALinearEqn.C:212-216): the owned
+    states plus the states anchored at the cells within `overlap` face-neighbour rings of the owned cells (a cell state is anchored at
+    its cell, a face flux at the face's owner cell - the rule that assigns it to a rank); cut faces (owner_rank -1) belong to nobody.
+    Returns a bool array over the extended states."""
+    N, F = mesh.n_cells, mesh.n_faces
+    n = owner_rank.size
+    nsc = (n - 3 * N - F) // N
+    assert n == (3 + nsc) * N + F and nsc >= 1
+    inS = owner_rank[3 * N : 4 * N] == rank  # owner of the first scalar cell field = owner of the cell
+    A = cell_adjacency(mesh)
+    for _ in range(int(overlap)):
+        inS = inS | (A @ inS.astype(np.int8) > 0)
+    anchor = np.concatenate([np.repeat(np.arange(N), 3)] + [np.arange(N)] * nsc + [np.asarray(mesh.owner, dtype=np.int64)])
+    return (inS[anchor] & (owner_rank >= 0)) | (owner_rank == rank)
+
+
+def install_overlap(obj, overlap=None):
+    """Restricted additive Schwarz across the ranks (das_set_pc_overlap): adjEqnOption.asmOverlap rings (default 1, like the
+    reference; at most GHOST_LAYERS - 2 = 1 ring has the full PC stencil inside the extended sub-mesh, 2 rings are accepted) - the
+    sub-domain mask, and per peer of the halo plan the lists of the owner -> ghost gather.  Collective.  Returns the overlap used."""
+    import torch
+    import torch.distributed as dist
+
+    from . import _capi
+
+    if overlap is None:
+        adj = obj.D.getOption("adjEqnOption") if hasattr(obj.D, "getOption") else {}
+        overlap = int(adj.get("asmOverlap", 1))
+    amd = obj.D.getOption("amd") if hasattr(obj.D, "getOption") else {}
+    overlap = max(0, min(int(overlap), GHOST_LAYERS - 1))
+    L, h, halo = obj.L, obj.h, obj.halo
+    obj.asm_overlap = 0
+    if overlap == 0 or amd.get("pcType", "bilu") != "bilu":
+        _capi.check(L.das_set_pc_overlap(h, None, 0, None, None, None, None))
+        return 0
+    mask = overlap_mask(obj.case.mesh, obj.owner_rank, obj.rank, overlap)
+    peers = list(halo.peers)
+    key, orank = obj.key, obj.owner_rank
+    recv, want = [], {}
+    for q in peers:  # my overlap ghost states owned by q, in key order: q packs in that order
+        sel = np.nonzero(mask & (orank == q))[0]
+        o = np.argsort(key[sel], kind="stable")
+        recv.append(sel[o])
+        want[q] = key[sel][o]
+    gathered = [None] * obj.world
+    dist.all_gather_object(gathered, want)
+    lookup = dict(zip(key.tolist(), range(key.size)))
+    send = []
+    for q in peers:
+        ks = gathered[q].get(obj.rank, np.zeros(0, np.int64))
+        idx = np.fromiter((lookup[kk] for kk in ks.tolist()), dtype=np.int64, count=ks.size)
+        assert np.all(orank[idx] == obj.rank), "peer asks for an overlap state I do not own"
+        send.append(idx)
+    sendOff = np.concatenate([[0], np.cumsum([a.size for a in send])]).astype(np.int64)
+    recvOff = np.concatenate([[0], np.cumsum([a.size for a in recv])]).astype(np.int64)
+    sendIdx = (np.concatenate(send) if peers else np.zeros(0)).astype(np.int32)
+    recvIdx = (np.concatenate(recv) if peers else np.zeros(0)).astype(np.int32)
+    m8 = np.ascontiguousarray(mask.astype(np.uint8))
+    ip, lp = _capi.c_int_p, _capi.c_ll_p
+    _capi.check(L.das_set_pc_overlap(h, m8.ctypes.data_as(C.POINTER(C.c_ubyte)), len(peers), sendOff.ctypes.data_as(lp), sendIdx.ctypes.data_as(ip),
+                                     recvOff.ctypes.data_as(lp), recvIdx.ctypes.data_as(ip)))
+    obj.asm_overlap, obj.pc_mask = overlap, mask
+    obj.overlap_bytes_per_gather = 8 * int(sendOff[-1])
+    if getattr(obj, "_comm_native", False):
+        return overlap
+    nS, nR = int(sendOff[-1]), int(recvOff[-1])
+    stage = dist.get_backend() == "gloo"
+
+    def gather_cb(ps, pr, _user):
+        torch.cuda.current_stream(obj.dev).synchronize()
+        sb = torch.as_tensor(_DevPtr(ps, nS), device=obj.dev) if nS else torch.empty(0, dtype=torch.float64, device=obj.dev)
+        rb = torch.as_tensor(_DevPtr(pr, nR), device=obj.dev) if nR else None
+        src = sb.cpu() if stage else sb
+        dst = torch.empty(nR, dtype=torch.float64, device="cpu" if stage else obj.dev)
+        ops = []
+        for i, q in enumerate(peers):
+            if sendOff[i + 1] > sendOff[i]:
+                ops.append(dist.P2POp(dist.isend, src[sendOff[i]:sendOff[i + 1]], q))
+            if recvOff[i + 1] > recvOff[i]:
+                ops.append(dist.P2POp(dist.irecv, dst[recvOff[i]:recvOff[i + 1]], q))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        if nR:
+            rb.copy_(dst)
+
+    obj._gather_cb = _EXCH_CB(gather_cb)  # keep alive
+    _capi.check(L.das_set_gather_cb(h, C.cast(obj._gather_cb, C.c_void_p), None))
+    return overlap
+
+
 def _forward_exchange(halo, w):
     """The reverse direction of HaloExchange.reduce_: every owner sends the values of its owned states to the ranks that hold
     them as ghosts (set-up time only: aggregate ids of the global coarse space)."""
@@ -326,6 +438,7 @@ class ShardedAdjoint:
         self.n = self.key.size
         _capi.check(L.das_set_n_global_cells(h, int(NX) * int(NY) * int(NZ)))
         install_comm(self)
+        install_overlap(self)
         self.n_owned = int(self.owned.sum())
 
     # ------------------------------------------------------------------ solve_linear sequence on the shard
@@ -636,4 +749,5 @@ class ShardedAdjointGeneral(ShardedAdjoint):
         self.n = self.key.size
         _capi.check(L.das_set_n_global_cells(h, int(n_global_cells)))
         install_comm(self)
+        install_overlap(self)
         self.n_owned = int(self.owned.sum())

@@ -410,6 +410,14 @@ int das_comm_init_rccl(das_solver_t* s, int rank, int world, const char* id128);
 int das_comm_set_halo(das_solver_t* s, int npeers, const int* peers, const long long* sendOff, const int* sendIdx, const long long* recvOff,
                       const int* recvIdx, long long nGhost, const int* ghostIdx);
 int das_set_exchange_cb(das_solver_t* s, das_exchange_cb cb, void* user);
+/* Additive-Schwarz overlap of the preconditioner across ranks - adjEqnOption.asmOverlap, reference DALinearEqn.C:212-216
+ * (PCASMSetOverlap; PETSc's default restricted variant): pcMask[state] != 0 for the unknowns of this rank's sub-domain solve (owned +
+ * overlap rings of ghost cells); per peer of das_comm_set_halo (same order) the owned states it needs (ovSend) and the overlap ghost
+ * states it owns (ovRecv, in its send order).  Call before calcdRdWT(1) / createMLRKSPMatrixFree.  pcMask NULL: no overlap.
+ * das_set_gather_cb: host-staged transport of the gather (gloo tests on single-GPU boxes). */
+int das_set_pc_overlap(das_solver_t* s, const unsigned char* pcMask /* n states */, int npeers, const long long* ovSendOff, const int* ovSendIdx,
+                       const long long* ovRecvOff, const int* ovRecvIdx);
+int das_set_gather_cb(das_solver_t* s, das_exchange_cb cb, void* user);
 int das_comm_is_native(das_solver_t* s);
 /* drop the native communicator again (all ranks fall back to the callback transport together) */
 int das_comm_reset(das_solver_t* s);
