@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--fp32-factor", type=int, default=int(os.environ.get("DAS_BENCH_PCFP32", 0)))
     ap.add_argument("--krylov-gb", type=float, default=float(os.environ.get("DAS_BENCH_KRYLOV_GB", 160.0)))
     ap.add_argument("--solve-restart", type=int, default=1000)
+    ap.add_argument("--solve-rtol", type=float, default=1e-6, help="gmresRelTol of the solve to tolerance (default: the reference's 1e-6, pyDAFoam.py:526-548)")
     ap.add_argument("--solve-maxit", type=int, default=1000)
     ap.add_argument("--converge-primal", action="store_true", help="converge the flow state with the GPU Newton-Krylov primal before the adjoint (opt-in: the adjoint's conditioning does not depend on it, DESIGN.md section 6b)")
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
@@ -95,6 +96,8 @@ def parse():
                     help="BASELINE configs[3] / [4]: the compressible solvers run on the bump channel of --nx/--ny/--nz cells per GPU with a synthetic subsonic state "
                          "(p 101325, T 300; DATurboFoam: one MRF zone, rotating hub) - N > 1: RCB cell partition of the global channel (ShardedAdjointGeneral.scattered); "
                          "no converged primal and no psi parity leg for them (the host adjoint of the parity leg covers DASimpleFoam)")
+    ap.add_argument("--dump-psi", default=None, metavar="FILE.npy", help="after the solve to tolerance: rank 0 writes psi in the GLOBAL state ordering (owned entries of every rank gathered, "
+                    "face states back in the global face orientation) - psi of an N-rank run against psi of the 1-rank run")
     ap.add_argument("--amd", action="append", default=[], metavar="KEY=VALUE", help="experiments: any amd.* option, e.g. --amd gradFaceParallel=0 (listed in config.pc_options_passed_by_bench)")
     return ap.parse_args()
 
@@ -383,6 +386,9 @@ def main():
     rhs = torch.from_numpy(rhs_h).cuda()
     sol = torch.zeros(n, dtype=torch.float64, device="cuda")
     setup_s = time.time() - t_setup
+    _est, _ord = C.c_double(-1.0), C.c_int(-1)
+    L.das_ksp_get_pc_stability(ksp.handle, C.byref(_est), C.byref(_ord))
+    pc_stab = {"estimate_max_abs_LUinv_P_e_minus_e": _est.value, "elimination_order": _ord.value}
     stage(f"adjoint set-up done: colouring {t_color:.1f} s, dRdWTPC {t_pcmat:.1f} s, factorisation {t_pc:.1f} s, dRdWT {t_op:.1f} s")
 
     def check(rc):
@@ -402,7 +408,7 @@ def main():
     r_eff = int(max(1, min(a.solve_restart, a.krylov_gb * 2**30 // (8 * n) - 2)))
     mean_depth = None
     if not a.no_solve:
-        D.solver.updateDAOption({"adjEqnOption": {"gmresRestart": a.solve_restart, "gmresMaxIters": a.solve_maxit, "gmresRelTol": 1e-6, "gmresAbsTol": 1e-14}})
+        D.solver.updateDAOption({"adjEqnOption": {"gmresRestart": a.solve_restart, "gmresMaxIters": a.solve_maxit, "gmresRelTol": a.solve_rtol, "gmresAbsTol": 1e-14}})
         sol.zero_()
         barrier()
         t0 = time.perf_counter()
@@ -433,12 +439,26 @@ def main():
                  "krylov_basis": {"storage": ("split: hi + lo floats per entry (8 B); the inner-product pass reads hi only, every vector-building pass hi + lo"
                                               if binfo["split"] else ("fp32" if binfo["fp32"] else "fp64")),
                                   "mapped_GB": binfo["mappedGB"], "bytes_per_vector": binfo["bytesPerVector"]},
-                 "rel_residual": inf["res"] / inf["res0"] if inf["res0"] else None, "gmresRelTol": 1e-6,
+                 "rel_residual": inf["res"] / inf["res0"] if inf["res0"] else None, "gmresRelTol": a.solve_rtol,
                  "gmresRestart": r_eff, "gmresMaxIters": a.solve_maxit, "mean_basis_depth": mean_depth, "gmresDeflation": int(a.deflation) if world == 1 else 0,
                  "rel_residual_at_1000_iterations": float(hist[1000] / hist[0]) if len(hist) > 1000 else None,
                  "rel_residual_every_100": [float(v / hist[0]) for v in hist[::100]],
                  "iterations_per_sec_whole_solve": its / t_solve}
         stage(f"solve: {its} iterations, {t_solve:.1f} s, fail {fail}")
+        if a.dump_psi:
+            x_h = sol.cpu().numpy()
+            if sharded is not None and hasattr(sharded, "info"):
+                own_m = sharded.owned
+                mine = (sharded.key[own_m], x_h[own_m] * sharded.info["state_sign"][own_m])
+                parts = [None] * world if rank == 0 else None
+                dist.gather_object(mine, parts, dst=0)
+                if rank == 0:
+                    psi_g = np.full(sum(p_[0].size for p_ in parts), np.nan)
+                    for kk, vv in parts:
+                        psi_g[kk] = vv
+                    np.save(a.dump_psi, psi_g)
+            elif rank == 0:
+                np.save(a.dump_psi, x_h)
 
     # ---- timed window (driver contract): W' untimed iterations, then EXACTLY K timed, inside ONE Arnoldi cycle.  W' = the mean basis
     # depth of the full solve minus K/2 (>= --warmup): the window rate is then the mean per-iteration rate of the whole solve ----------
@@ -582,6 +602,7 @@ def main():
                 "pc_coarse_aggregates_global": int(global_coarse) if world > 1 else None,
                 "pc_coarse_mode": D.getOption("amd")["pcCoarseMode"],
                 "asm_overlap": (int(getattr(sharded, "asm_overlap", 0)) if sharded is not None else None),
+                "pc_stability": pc_stab,
                 "pc_upwind_blend": D.getOption("amd")["pcUpwindBlend"],
                 "pc_options_passed_by_bench": sorted(k for k in make_opts(a, dev_index, 1, 1, 1e-6)["amd"] if k != "maxKrylovBytes"),
                 "coarse_ms": L.das_timer_avg_ms(h, b"coarse"),

@@ -586,7 +586,7 @@ inline std::vector<int> bilu_rcm_cells(const Mesh& m, const std::vector<char>& c
 inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned,
                                  const std::vector<char>& cellOwned, int reach, NodeILU& P, std::vector<int>& unkNode,
                                  std::vector<unsigned char>& unkSlot, std::vector<long long>& bptr, std::vector<long long>& bdiag,
-                                 std::vector<int>& bcol, int nthr, bool rcm = false) {
+                                 std::vector<int>& bcol, int nthr, int order = 0, const double* dir = nullptr) {
     const int nC = m.nC;
     // ---- unknowns cell by cell, packed into nodes of 8 slots
     std::vector<std::vector<int>> ownedFaces;
@@ -609,8 +609,16 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
     auto is_owned = [&](long long g) { return owned.empty() || owned[g]; };
     // cell order of the elimination: the mesh's own numbering, or RCM of the cell graph
     std::vector<int> cellOrder;
-    if (rcm) cellOrder = bilu_rcm_cells(m, cellOwned);
+    // order: 0 the mesh's numbering, 1 reverse Cuthill-McKee, 2 Cuthill-McKee (1 backwards), 3 the mesh's numbering backwards, 4 / 5 below
+    if (order == 1 || order == 2) cellOrder = bilu_rcm_cells(m, cellOwned);
     else { cellOrder.reserve(nC); for (int c = 0; c < nC; c++) if (cellOwned[c]) cellOrder.push_back(c); }
+    if (order == 2 || order == 3) std::reverse(cellOrder.begin(), cellOrder.end());
+    if (order == 4 || order == 5) {  // 4 / 5: along / against the direction `dir` (the mean flow; default x), cell centres projected on it
+        const double d0 = dir ? dir[0] : 1.0, d1 = dir ? dir[1] : 0.0, d2 = dir ? dir[2] : 0.0, sgn = order == 4 ? 1.0 : -1.0;
+        std::vector<double> key(nC);
+        for (int c = 0; c < nC; c++) key[c] = sgn * (m.cg[c].C[0] * d0 + m.cg[c].C[1] * d1 + m.cg[c].C[2] * d2);
+        std::sort(cellOrder.begin(), cellOrder.end(), [&](int a, int b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
+    }
     std::vector<std::pair<int, int>> cellNodePairs;  // (cell, node), cells in visiting order
     std::vector<int> lateUnk, lateCell;
     for (int c : cellOrder) {
@@ -749,8 +757,8 @@ inline void bilu_launch_shape(NodeILU& P, hipStream_t st);
 // Numeric setup on the device from the assembled PC matrix (device CSR, rows = states).
 inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned, int reach,
                        bool fp32, long long An, const long long* d_rp, const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P,
-                       bool debug, int nthr, bool rcm, bool transpose = false, double diagScale = 1.0, long long shiftExLo = 0,
-                       long long shiftExHi = 0, long long shiftEnd = (long long)1 << 62) {
+                       bool debug, int nthr, int order, bool transpose = false, double diagScale = 1.0, long long shiftExLo = 0,
+                       long long shiftExHi = 0, long long shiftEnd = (long long)1 << 62, const double* dir = nullptr) {
     const double t0 = wall_seconds();
     std::vector<char> cellOwned(m.nC, 1);
     if (!owned.empty()) {
@@ -761,7 +769,7 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     std::vector<int> unkNode, bcol;
     std::vector<unsigned char> unkSlot;
     std::vector<long long> bptr, bdiag;
-    bilu_build_structure(m, states, n, owned, cellOwned, reach, P, unkNode, unkSlot, bptr, bdiag, bcol, std::max(1, nthr), rcm);
+    bilu_build_structure(m, states, n, owned, cellOwned, reach, P, unkNode, unkSlot, bptr, bdiag, bcol, std::max(1, nthr), order, dir);
     const int nN = P.nNodes;
     P.fp32 = fp32;
     P.nodeUnk.upload(P.h_nodeUnk);

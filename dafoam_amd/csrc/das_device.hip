@@ -1114,6 +1114,9 @@ struct das_ksp {
     bool split = false;
     DevBuf<double> ustage;  // fp64 copy of the basis vector the preconditioner is applied to (fp32 basis only)
     DevBuf<double> w, z, r, xdev, bdev, partial, hdev, rich_r, rich_d;
+    int pcOrder = -1;  // elimination order of the node-block ILU (bilu_build_structure); -1: adjEqnOption.jacMatReOrdering
+    int pcOrderUsed = -1;  // ... the order the stability check settled on
+    double pcStability = -1.0;  // stability estimate of the factorisation (-1: not computed)
     bool rasOverlap = false;  // restricted additive Schwarz across ranks: the factorisation covers owned + overlap unknowns (setup_node_ilu)
     DevBuf<double> pcin;      // ... its input: a copy of the vector with the overlap entries gathered from their owners
     std::unique_ptr<struct GmresRun> run;
@@ -2041,8 +2044,17 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     const int reach = pc_stencil_reach(s);
     const int nthr = (int)std::max<long long>(1, std::min<long long>(das::host_threads(), s->opt.geti("amd.setupThreads")));
     // several ranks: the sub-domain of this rank = its owned unknowns, or - asmOverlap > 0 - those plus the overlap rings (das_set_pc_overlap)
+    // mean velocity direction (elimination orders 4 / 5: along / against the flow)
+    double dir[3] = {1.0, 0.0, 0.0};
+    if (!s->st_full.states.empty() && s->st_full.states[0].kind == KIND_VEC && s->h_W.size() == (size_t)s->n) {
+        const StateDef& u = s->st_full.states[0];
+        double m[3] = {0, 0, 0};
+        for (long long c = 0; c < u.size / 3; c++) for (int q = 0; q < 3; q++) m[q] += s->h_W[u.offset + 3 * c + q];
+        const double nm = std::sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+        if (nm > 0.0) for (int q = 0; q < 3; q++) dir[q] = m[q] / nm;
+    }
     bilu_setup(s->mesh, s->st_full.states, s->n, (s->pcMask.empty() || k->pcTranspose) ? s->owned : s->pcMask, reach, s->opt.geti("amd.pcFactorFP32") != 0, A.n, A.rowptr.p, A.col.p, A.val.p, s->stream,
-               k->bilu, s->opt.geti("debug") != 0, nthr, pc_ordering_rcm(s), k->pcTranspose, k->pcDiagScale, k->shiftExLo, k->shiftExHi, k->shiftEnd);
+               k->bilu, s->opt.geti("debug") != 0, nthr, k->pcOrder >= 0 ? k->pcOrder : (pc_ordering_rcm(s) ? 1 : 0), k->pcTranspose, k->pcDiagScale, k->shiftExLo, k->shiftExHi, k->shiftEnd, dir);
     k->useBilu = true;
     k->rasOverlap = !s->pcMask.empty() && !k->pcTranspose && s->halo.ovActive;
     if (k->rasOverlap && k->pcin.n != (size_t)s->n) k->pcin.alloc(s->n);
@@ -2050,6 +2062,53 @@ static void setup_node_ilu(das_solver* s, das_ksp* k) {
     k->pc.nBlocks = 1;
     k->pc.fnnz = (k->bilu.nL + k->bilu.nU + k->bilu.nNodes) * (long long)BILU_NB2;
     k->pc.next = (long long)k->bilu.nNodes * BILU_NB;
+}
+
+// Stability estimate of the incomplete factorisation: max |(LU)^-1 P e - e| over the sub-domain's unknowns for e = ones and for a +-1
+// pattern.  O(1) for a usable factorisation (it is ||I - M^-1 P|| on two vectors), 1e10 and more when the triangular recurrences of an
+// ILU of a not diagonally dominant matrix grow exponentially (Chow & Saad 1997, "Experimental study of ILU preconditioners for
+// indefinite matrices": the ||(LU)^-1 e|| test) - which the blended second-order PC matrix (amd.pcUpwindBlend) does for some elimination
+// orders: round 6, 403 k-cell wing, sectors without overlap and 8 index blocks: M^-1 amplifies by 1e16, GMRES makes no progress.
+static double pc_stability_estimate(das_solver* s, das_ksp* k) {
+    const long long n = s->n;
+    const Mat& P = k->pcmat->m;
+    const std::vector<unsigned char>& mask = (s->pcMask.empty() || k->pcTranspose) ? s->owned : s->pcMask;
+    std::vector<double> e(n), z(n);
+    DevBuf<double> de(n), dw(n), dz(n);
+    double est = 0.0;
+    long long worst = -1;
+    for (int trial = 0; trial < 2; trial++) {
+        for (long long i = 0; i < n; i++) {
+            const bool in = mask.empty() || mask[i];
+            unsigned long long hsh = (unsigned long long)i * 0x9E3779B97F4A7C15ull;
+            hsh ^= hsh >> 29;
+            e[i] = !in ? 0.0 : (trial == 0 ? 1.0 : ((hsh & 1ull) ? 1.0 : -1.0));
+        }
+        de.upload(e);
+        hipLaunchKernelGGL(k_spmv_wave, SPMV_GRID(P.n), dim3(256), 0, s->stream, P.n, P.rowptr.p, P.col.p, P.val.p, (const double*)de.p, dw.p);
+        dz.zero();
+        bilu_apply(k->bilu, dw.p, dz.p, s->stream);
+        DAS_HIP(hipStreamSynchronize(s->stream));
+        z = dz.to_host();
+        const int* nu = k->bilu.h_nodeUnk.data();
+        for (size_t q = 0; q < k->bilu.h_nodeUnk.size(); q++) {
+            const int gi = nu[q];
+            if (gi < 0) continue;
+            const double d = std::fabs(z[gi] - e[gi]);
+            if (d > est || d != d) worst = gi;
+            est = (d > est || d != d) ? (d != d ? 1e300 : d) : est;
+        }
+    }
+    if (worst >= 0 && getenv("DAS_PC_STAB")) {  // where the worst entry sits (state, cell / face centre, frozen wall distance)
+        for (const StateDef& sd : s->st_full.states) {
+            if (worst < sd.offset || worst >= sd.offset + sd.size) continue;
+            const long long ent = (worst - sd.offset) / (sd.kind == KIND_VEC ? 3 : 1);
+            const double* C = sd.kind == KIND_FACE ? s->mesh.fg[ent].Cf : s->mesh.cg[ent].C;
+            fprintf(stderr, "[dafoam_amd] rank %s: worst entry of the stability test: state %s entity %lld at (%.4g %.4g %.4g)%s\n", getenv("RANK") ? getenv("RANK") : "0",
+                    sd.name.c_str(), ent, C[0], C[1], C[2], (!s->owned.empty() && !s->owned[worst]) ? " (overlap ring)" : "");
+        }
+    }
+    return est;
 }
 
 // E = Z^T P Z and its dense inverse for a coarse space of naggG aggregates of which [aggOff, aggOff + C.nagg) are this rank's;
@@ -4797,8 +4856,39 @@ int das_create_ml_rksp_matrix_free(das_solver_t* s, das_mat_t* pc, das_ksp_t** k
     k->pcmat = pc;
     const std::string pcType = s->opt.gets("amd.pcType");
     DAS_CHECK(pcType == "bilu" || pcType == "ras", DAS_ERR_ARG, "amd.pcType must be \"bilu\" or \"ras\"");
-    if (pcType == "bilu") setup_node_ilu(s, k.get());
-    else setup_block_ilu(s, k.get());
+    if (pcType == "bilu") {
+        if (getenv("DAS_BILU_ORDER")) k->pcOrder = atoi(getenv("DAS_BILU_ORDER"));
+        setup_node_ilu(s, k.get());
+        // amd.pcStabilityLimit > 0: an incomplete factorisation whose stability estimate exceeds the limit is rebuilt with another elimination
+        // order of the cells (reverse Cuthill-McKee / Cuthill-McKee / the mesh's numbering / that backwards; the configured one first) until one
+        // passes; none does: the order with the smallest estimate.  The choice is local to the rank (no collective in here): the triangular
+        // recurrences of a sub-domain blow up or not depending on the direction the elimination crosses it (round 6, 403 k-cell wing on 8
+        // ranks: the outer blocks next to the wake grow by 1e8 ... 1e27 along the 32 spanwise layers in one order and by 1e2 in another)
+        const double limit = s->opt.getd("amd.pcStabilityLimit");
+        if (limit > 0.0) {
+            const int first = k->pcOrder >= 0 ? k->pcOrder : (pc_ordering_rcm(s) ? 1 : 0);
+            int tried[6], nTried = 0, best = first;
+            double bestEst = 0.0;
+            for (int attempt = 0; attempt < 6; attempt++) {
+                int o = first;
+                if (attempt > 0) { o = -1; for (int c : {1, 2, 4, 5, 3, 0}) { bool seen = false; for (int q = 0; q < nTried; q++) seen = seen || tried[q] == c; if (!seen) { o = c; break; } } }
+                if (attempt > 0) { k->pcOrder = o; k->bilu = NodeILU(); setup_node_ilu(s, k.get()); }
+                tried[nTried++] = o;
+                k->pcStability = pc_stability_estimate(s, k.get());
+                k->pcOrderUsed = o;
+                if (s->opt.geti("debug") || getenv("DAS_PC_STAB") || k->pcStability > limit)
+                    fprintf(stderr, "[dafoam_amd] rank %s: preconditioner stability estimate max|(LU)^-1 P e - e| = %.3e with elimination order %d (limit %.1e)%s\n",
+                            getenv("RANK") ? getenv("RANK") : "0", k->pcStability, o, limit, k->pcStability > limit ? ": unstable, trying another order" : "");
+                if (attempt == 0 || k->pcStability < bestEst) { best = o; bestEst = k->pcStability; }
+                if (k->pcStability <= limit) break;
+            }
+            if (k->pcOrderUsed != best) {
+                k->pcOrder = best; k->bilu = NodeILU(); setup_node_ilu(s, k.get());
+                k->pcOrderUsed = best; k->pcStability = bestEst;
+                fprintf(stderr, "[dafoam_amd] rank %s: no elimination order passes the stability limit; keeping order %d (estimate %.3e)\n", getenv("RANK") ? getenv("RANK") : "0", best, bestEst);
+            }
+        }
+    } else setup_block_ilu(s, k.get());
     setup_coarse(s, k.get());
     *ksp = k.release();
     return DAS_OK;
@@ -4966,6 +5056,16 @@ int das_ksp_get_status(das_ksp_t* k, int* reason, int* nBreakdown, int* nSweepGr
     if (nBreakdown) *nBreakdown = k->nBreakdown;
     if (nSweepGrid) *nSweepGrid = k->useBilu ? k->bilu.launchGrid : 0;
     if (sweepPerXcd) *sweepPerXcd = k->useBilu ? k->bilu.launchPerXcd : 0;
+    return DAS_OK;
+    DAS_CATCH
+}
+// stability estimate of the factorisation (max |(LU)^-1 P e - e|; -1: not computed - amd.pcStabilityLimit 0) and the elimination order the
+// check settled on (0 mesh numbering, 1 reverse Cuthill-McKee, 2 Cuthill-McKee, 3 mesh numbering backwards; -1: no check)
+int das_ksp_get_pc_stability(das_ksp_t* k, double* estimate, int* orderUsed) {
+    DAS_TRY
+    DAS_CHECK(k, DAS_ERR_ARG, "null ksp handle");
+    if (estimate) *estimate = k->pcStability;
+    if (orderUsed) *orderUsed = k->pcOrderUsed;
     return DAS_OK;
     DAS_CATCH
 }

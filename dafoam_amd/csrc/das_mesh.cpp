@@ -77,6 +77,9 @@ Options::Options() {
     // 1000 / 1000 budget; its extra operator product per apply is replaced by the sparse A Z of the coarse space (coarse_az_ready:
     // ~1.2 entries per row) wherever the operator is the assembled single-rank matrix
     s["amd.pcCoarseMode"] = "deflated";
+    // stability check of the incomplete factorisation (das_create_ml_rksp_matrix_free): estimate = max |(LU)^-1 P e - e| on two vectors; above
+    // the limit the factorisation is rebuilt with another elimination order of the cells (0: no check)
+    d["amd.pcStabilityLimit"] = 1.0e8;
     i["amd.pcCoarseSparseAZ"] = 1;   // deflated mode: A (Z u) through the precomputed sparse A Z (0: one full operator product per apply)
     i["amd.coloringOnDevice"] = 1;   // serial first-fit colouring as a data-flow kernel (das_color.hpp); 0: host variants
     d["amd.primalTau0"] = 1.0;          // Newton primal: initial pseudo-time factor (diagonal scaled by 1 + 1/tau), SER growth

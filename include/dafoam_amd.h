@@ -359,6 +359,12 @@ int das_debug_gmres_dr_host(long long n, void* A, void* M, void* user, const dou
  * KSP_DIVERGED_BREAKDOWN; the reference's failure flag is still the tolerance rule of DALinearEqn.C:422-434);
  * nBreakdown = happy breakdowns detected, nSweepGrid / sweepPerXcd = launch shape of the preconditioner sweeps */
 int das_ksp_get_status(das_ksp_t* ksp, int* reason, int* nBreakdown, int* nSweepGrid, int* sweepPerXcd);
+/* Stability estimate of the incomplete factorisation, max |(LU)^-1 P e - e| on two test vectors (amd.pcStabilityLimit; -1: not computed),
+ * and the elimination order of the cells the check settled on (0 mesh numbering, 1 reverse Cuthill-McKee = jacMatReOrdering "rcm",
+ * 2 Cuthill-McKee, 3 mesh numbering backwards, 4 / 5 along / against the mean flow; -1: no check).  A factorisation above the limit is
+ * rebuilt with the next order, rank by rank.  The reference's PETSc ILU has no such check; its MatFactorInfo shift (DALinearEqn.C:270-272)
+ * only replaces zero pivots. */
+int das_ksp_get_pc_stability(das_ksp_t* ksp, double* estimate, int* orderUsed);
 /* two-level preconditioner (amd.pcCoarseAggregates / pcCoarseField / pcCoarseMode): number of aggregates of the
  * piecewise-constant pressure coarse space (0 = none) and, optionally, the aggregate of every cell (-1 = not owned) */
 int das_ksp_get_coarse(das_ksp_t* ksp, int* aggOfCell);
