@@ -389,6 +389,12 @@ def main():
     _est, _ord = C.c_double(-1.0), C.c_int(-1)
     L.das_ksp_get_pc_stability(ksp.handle, C.byref(_est), C.byref(_ord))
     pc_stab = {"estimate_max_abs_LUinv_P_e_minus_e": _est.value, "elimination_order": _ord.value}
+    _so, _se = (C.c_int * 16)(), (C.c_double * 16)()
+    _K = int(L.das_ksp_get_pc_subdomains(ksp.handle, _so, _se))
+    pc_stab["subdomains_in_rank"] = _K
+    if _K > 1:
+        pc_stab["subdomain_elimination_orders"] = [int(_so[i]) for i in range(_K)]
+        pc_stab["subdomain_estimates"] = [float(_se[i]) for i in range(_K)]
     stage(f"adjoint set-up done: colouring {t_color:.1f} s, dRdWTPC {t_pcmat:.1f} s, factorisation {t_pc:.1f} s, dRdWT {t_op:.1f} s")
 
     def check(rc):
@@ -467,8 +473,9 @@ def main():
     else:
         j0 = int(max(a.warmup, min(round(mean_depth - 0.5 * a.steps), r_eff - a.steps - 1)))
     window_restart = max(j0 + a.steps, 1)
-    # (the window keeps the solve's gmresRelTol: "fixed" runs ignore the tolerance, but amd.krylovBasisPrecision "auto" reads it - the timed
-    #  iterations must use the same basis storage type as the solve they stand for)
+    # (amd.krylovBasisPrecision "auto" picks the basis storage from the orthogonalisation scheme and the basis SIZE, (restart + 2) n 8 B >= 1 GB ->
+    #  split, not from the tolerance: the window's restart is >= the solve's mean depth, so at bench sizes the timed iterations run on the same
+    #  storage type as the solve they stand for - config.solve.krylov_basis says which)
     D.solver.updateDAOption({"adjEqnOption": {"gmresRestart": window_restart, "gmresMaxIters": 10**9, "gmresRelTol": 1e-6, "gmresAbsTol": 1e-300}})
     sol.zero_()
     check(L.das_ksp_begin_device(h, ksp.handle, C.c_void_p(rhs.data_ptr()), C.c_void_p(sol.data_ptr()), 1))

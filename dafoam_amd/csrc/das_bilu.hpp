@@ -59,6 +59,7 @@ constexpr int BILU_CTRL_SIZE = 17 * BILU_CTRL_STRIDE;
 struct BiluView {
     int nNodes;
     const int* nodeUnk;          // nNodes*8: global state index of a slot or -1 (processing order)
+    const int* nodeOut;          // nNodes*8: where the slot's solution is written (= nodeUnk; -1 for the overlap copies of a multi-block factorisation)
     const long long* ptr[2];     // [0] L rows by p, [1] U rows by q = nNodes-1-p
     const int* col[2];           // node positions p of the dependencies
     const double* val[2];
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep(BiluView P, co
                 gi = P.nodeUnk[p * BILU_NB + g];
                 rhs = gi >= 0 ? b[gi] : 0.0;
             } else {
-                gi = P.nodeUnk[p * BILU_NB + k];
+                gi = P.nodeOut[p * BILU_NB + k];
                 rhs = P.y[p * BILU_NB + g];
                 dinv = P.invD[p * BILU_NB2 + k * 8 + g];
             }
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(BILU_WG, BILU_OCC) void k_bilu_sweep_m(BiluView P, 
 #pragma unroll
             for (int r = 0; r < S; r++) rhs[r] = gi >= 0 ? b[gi + r * ld] : 0.0;
         } else {
-            gi = P.nodeUnk[p * BILU_NB + k];
+            gi = P.nodeOut[p * BILU_NB + k];
 #pragma unroll
             for (int r = 0; r < S; r++) rhs[r] = ym[(p * BILU_NB + g) * S + r];
             dinv = P.invD[p * BILU_NB2 + k * 8 + g];
@@ -530,7 +531,8 @@ struct NodeILU {
     // host copies (tests / introspection)
     std::vector<int> h_nodeUnk, h_bcol, h_lvlPtr, h_natural;  // h_natural[p] = natural (cell-order) index of the node at position p
     std::vector<long long> h_bptr;
-    DevBuf<int> nodeUnk, Lcol, Ucol;
+    DevBuf<int> nodeUnk, nodeOut, Lcol, Ucol;  // nodeOut: allocated only by bilu_setup_multi (else the view points at nodeUnk)
+    std::vector<int> h_nodeOut;
     DevBuf<long long> Lptr, Uptr;
     DevBuf<double> Lval, Uval, invD, y, z;
     DevBuf<float> Lvalf, Uvalf;
@@ -544,7 +546,7 @@ struct NodeILU {
 
 // reverse Cuthill-McKee ordering of the owned cells on the face-neighbour graph (jacMatReOrdering "rcm": the reference
 // hands MATORDERINGRCM to the sub-domain ILU, DALinearEqn.C:238-290); start cells are pseudo-peripheral (two BFS sweeps)
-inline std::vector<int> bilu_rcm_cells(const Mesh& m, const std::vector<char>& cellOwned) {
+inline std::vector<int> bilu_rcm_cells(const Mesh& m, const std::vector<char>& cellOwned, const double* startDir = nullptr) {
     const int nC = m.nC;
     std::vector<int> order, deg(nC, 0), queue;
     std::vector<char> seen(nC, 0);
@@ -567,13 +569,25 @@ inline std::vector<int> bilu_rcm_cells(const Mesh& m, const std::vector<char>& c
     std::vector<int> tmp;
     for (int c0 = 0; c0 < nC; c0++) {
         if (!cellOwned[c0] || seen[c0]) continue;
-        // pseudo-peripheral start: the last cell of a BFS from c0, then the last cell of a BFS from there
+        // pseudo-peripheral start: the last cell of a BFS from c0, then the last cell of a BFS from there; with a direction: the cell of
+        // the component that lies furthest AGAINST it (the most upstream one)
         int start = c0;
-        for (int sweep = 0; sweep < 2; sweep++) {
+        if (startDir) {
             tmp.clear();
-            bfs(start, tmp, tmpMark);
-            start = tmp.back();
-            for (int c : tmp) tmpMark[c] = 0;
+            bfs(c0, tmp, tmpMark);
+            double best = 1e300;
+            for (int c : tmp) {
+                tmpMark[c] = 0;
+                const double key = m.cg[c].C[0] * startDir[0] + m.cg[c].C[1] * startDir[1] + m.cg[c].C[2] * startDir[2];
+                if (key < best) { best = key; start = c; }
+            }
+        } else {
+            for (int sweep = 0; sweep < 2; sweep++) {
+                tmp.clear();
+                bfs(start, tmp, tmpMark);
+                start = tmp.back();
+                for (int c : tmp) tmpMark[c] = 0;
+            }
         }
         bfs(start, order, seen);
     }
@@ -613,6 +627,11 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
     if (order == 1 || order == 2) cellOrder = bilu_rcm_cells(m, cellOwned);
     else { cellOrder.reserve(nC); for (int c = 0; c < nC; c++) if (cellOwned[c]) cellOrder.push_back(c); }
     if (order == 2 || order == 3) std::reverse(cellOrder.begin(), cellOrder.end());
+    if (order == 6 || order == 7) {  // Cuthill-McKee levels grown from the most upstream cell: 6 downstream-wards, 7 upstream-wards
+        const double xdir[3] = {1.0, 0.0, 0.0};
+        cellOrder = bilu_rcm_cells(m, cellOwned, dir ? dir : xdir);
+        if (order == 6) std::reverse(cellOrder.begin(), cellOrder.end());
+    }
     if (order == 4 || order == 5) {  // 4 / 5: along / against the direction `dir` (the mean flow; default x), cell centres projected on it
         const double d0 = dir ? dir[0] : 1.0, d1 = dir ? dir[1] : 0.0, d2 = dir ? dir[2] : 0.0, sgn = order == 4 ? 1.0 : -1.0;
         std::vector<double> key(nC);
@@ -754,6 +773,17 @@ inline void bilu_build_structure(const Mesh& m, const std::vector<StateDef>& sta
 struct NodeILU;
 inline void bilu_launch_shape(NodeILU& P, hipStream_t st);
 
+// host structure of a factorisation handed to the numeric part: permuted block CSR + one (unknown -> node, slot) map per block of unknowns
+struct BiluStructRef {
+    const std::vector<long long>* bptr;
+    const std::vector<long long>* bdiag;
+    const std::vector<int>* bcol;
+    std::vector<const std::vector<int>*> unkNode;
+    std::vector<const std::vector<unsigned char>*> unkSlot;
+};
+inline void bilu_numeric(long long n, const BiluStructRef& S, bool fp32, long long An, const long long* d_rp, const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P,
+                         bool debug, bool transpose, double diagScale, long long shiftExLo, long long shiftExHi, long long shiftEnd, double t0);
+
 // Numeric setup on the device from the assembled PC matrix (device CSR, rows = states).
 inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<unsigned char>& owned, int reach,
                        bool fp32, long long An, const long long* d_rp, const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P,
@@ -770,15 +800,23 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     std::vector<unsigned char> unkSlot;
     std::vector<long long> bptr, bdiag;
     bilu_build_structure(m, states, n, owned, cellOwned, reach, P, unkNode, unkSlot, bptr, bdiag, bcol, std::max(1, nthr), order, dir);
+    BiluStructRef S{&bptr, &bdiag, &bcol, {&unkNode}, {&unkSlot}};
+    bilu_numeric(n, S, fp32, An, d_rp, d_ci, d_av, st, P, debug, transpose, diagScale, shiftExLo, shiftExHi, shiftEnd, t0);
+}
+
+inline void bilu_numeric(long long n, const BiluStructRef& S, bool fp32, long long An, const long long* d_rp, const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P,
+                         bool debug, bool transpose, double diagScale, long long shiftExLo, long long shiftExHi, long long shiftEnd, double t0) {
     const int nN = P.nNodes;
     P.fp32 = fp32;
     P.nodeUnk.upload(P.h_nodeUnk);
     DevBuf<int> d_unkNode, d_bcol;
     DevBuf<unsigned char> d_unkSlot;
     DevBuf<long long> d_bptr, d_bdiag;
+    const std::vector<int>& bcol = *S.bcol;
+    const std::vector<long long>&bptr = *S.bptr, &bdiag = *S.bdiag;
     DevBuf<unsigned char> d_late;
     d_late.upload(P.h_late);
-    d_unkNode.upload(unkNode); d_unkSlot.upload(unkSlot); d_bptr.upload(bptr); d_bdiag.upload(bdiag); d_bcol.upload(bcol);
+    d_bptr.upload(bptr); d_bdiag.upload(bdiag); d_bcol.upload(bcol);
     DevBuf<double> bval((size_t)P.nnzB * BILU_NB2);
     DevBuf<unsigned long long> d_dropped(1);
     DevBuf<int> d_nshift(1);
@@ -787,8 +825,12 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     DAS_HIP(hipMemsetAsync(d_nshift.p, 0, sizeof(int), st));
     P.t_struct = wall_seconds() - t0;
     double t1 = wall_seconds();
-    hipLaunchKernelGGL(k_bilu_scatter, dim3((unsigned)((An + 15) / 16)), dim3(256), 0, st, An, d_rp, d_ci, d_av, d_unkNode.p, d_unkSlot.p, d_bptr.p,
-                       d_bcol.p, d_late.p, bval.p, d_dropped.p, transpose ? 1 : 0, diagScale, shiftExLo, shiftExHi, shiftEnd);
+    for (size_t q = 0; q < S.unkNode.size(); q++) {  // one scatter per block of unknowns (one; K for a multi-block factorisation)
+        d_unkNode.upload(*S.unkNode[q]); d_unkSlot.upload(*S.unkSlot[q]);
+        hipLaunchKernelGGL(k_bilu_scatter, dim3((unsigned)((An + 15) / 16)), dim3(256), 0, st, An, d_rp, d_ci, d_av, d_unkNode.p, d_unkSlot.p, d_bptr.p,
+                           d_bcol.p, d_late.p, bval.p, d_dropped.p, transpose ? 1 : 0, diagScale, shiftExLo, shiftExHi, shiftEnd);
+        DAS_HIP(hipStreamSynchronize(st));
+    }
     hipLaunchKernelGGL(k_bilu_pad_diag, dim3((unsigned)(((long long)nN * BILU_NB + 255) / 256)), dim3(256), 0, st, nN, P.nodeUnk.p, d_bdiag.p, bval.p);
     DAS_HIP(hipGetLastError());
     unsigned long long dropped = 0;
@@ -835,6 +877,8 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
     DAS_HIP(hipStreamSynchronize(st));
     P.t_pack = wall_seconds() - t1;
     P.view.nNodes = nN; P.view.nodeUnk = P.nodeUnk.p;
+    if (!P.h_nodeOut.empty()) P.nodeOut.upload(P.h_nodeOut);
+    P.view.nodeOut = P.h_nodeOut.empty() ? P.nodeUnk.p : P.nodeOut.p;
     P.view.ptr[0] = P.Lptr.p; P.view.ptr[1] = P.Uptr.p; P.view.col[0] = P.Lcol.p; P.view.col[1] = P.Ucol.p;
     P.view.val[0] = P.Lval.p; P.view.val[1] = P.Uval.p; P.view.valf[0] = P.Lvalf.p; P.view.valf[1] = P.Uvalf.p;
     P.view.invD = P.invD.p; P.view.y = P.y.p; P.view.z = P.z.p; P.view.ctrl = P.ctrl.p;
@@ -845,6 +889,87 @@ inline void bilu_setup(const Mesh& m, const std::vector<StateDef>& states, long 
                         "factor %.2f GB%s; structure %.2f s, scatter %.3f s, factorise %.3f s, pack %.3f s\n", nN, (double)nN * BILU_NB / (double)n, P.nnzB,
                 (double)P.nnzB / nN, P.maxRow, P.nLevels, P.nshift, P.factor_bytes() / 1e9, fp32 ? " (fp32)" : "", P.t_struct, P.t_scatter, P.t_factor,
                 P.t_pack);
+}
+
+// K sub-domain factorisations (restricted additive Schwarz inside one GPU) as ONE structure: the node graphs of the blocks are disjoint, so
+// their level sets interleave - level l of the merged structure holds level l of every block - and ONE pair of sweeps runs all blocks at
+// once: max(levels) dependent hops instead of their sum, sum(nodes) / max(levels) nodes per level to fill the device.  An unknown of an
+// overlap ring sits in a node of every block that reaches it; all copies read the right-hand side, only the owner block's copy writes the
+// solution (nodeOut).  masks[b]: unknowns of block b (owned + overlap), orders[b]: its elimination order, subOf[unknown]: the owner block.
+inline void bilu_setup_multi(const Mesh& m, const std::vector<StateDef>& states, long long n, const std::vector<const std::vector<unsigned char>*>& masks,
+                             const std::vector<int>& orders, const std::vector<unsigned char>& subOf, int reach, bool fp32, long long An, const long long* d_rp,
+                             const int* d_ci, const double* d_av, hipStream_t st, NodeILU& P, bool debug, int nthr, const double* dir) {
+    const double t0 = wall_seconds();
+    const int K = (int)masks.size();
+    struct Blk { NodeILU S; std::vector<int> unkNode, bcol, newPos; std::vector<unsigned char> unkSlot; std::vector<long long> bptr, bdiag; };
+    std::vector<Blk> B(K);
+    int nLv = 0;
+    long long nN = 0, nnzB = 0;
+    for (int b = 0; b < K; b++) {
+        const std::vector<unsigned char>& mask = *masks[b];
+        std::vector<char> cellOwned(m.nC, 1);
+        const StateDef& s0 = states[0];
+        const int stride = s0.kind == KIND_VEC ? 3 : 1;
+        for (int c = 0; c < m.nC; c++) cellOwned[c] = mask[s0.offset + (long long)stride * c] ? 1 : 0;
+        bilu_build_structure(m, states, n, mask, cellOwned, reach, B[b].S, B[b].unkNode, B[b].unkSlot, B[b].bptr, B[b].bdiag, B[b].bcol, std::max(1, nthr), orders[b], dir);
+        nLv = std::max(nLv, B[b].S.nLevels);
+        nN += B[b].S.nNodes;
+        nnzB += B[b].S.nnzB;
+    }
+    DAS_CHECK(nN < (1LL << 31) && nnzB < (1LL << 40), DAS_ERR_INTERNAL, "multi-block preconditioner too large");
+    // ---- merged processing order: level-major, block after block inside a level
+    std::vector<int> lvlPtr(nLv + 1, 0);
+    for (int b = 0; b < K; b++) for (int l = 0; l < B[b].S.nLevels; l++) lvlPtr[l + 1] += B[b].S.h_lvlPtr[l + 1] - B[b].S.h_lvlPtr[l];
+    for (int l = 0; l < nLv; l++) lvlPtr[l + 1] += lvlPtr[l];
+    {
+        std::vector<int> cursor(lvlPtr.begin(), lvlPtr.end() - 1);
+        for (int b = 0; b < K; b++) {
+            B[b].newPos.resize(B[b].S.nNodes);
+            for (int l = 0; l < B[b].S.nLevels; l++) for (int p = B[b].S.h_lvlPtr[l]; p < B[b].S.h_lvlPtr[l + 1]; p++) B[b].newPos[p] = cursor[l]++;
+        }
+    }
+    std::vector<long long> bptr(nN + 1, 0), bdiag(nN, -1);
+    for (int b = 0; b < K; b++) for (int p = 0; p < B[b].S.nNodes; p++) bptr[B[b].newPos[p] + 1] = B[b].bptr[p + 1] - B[b].bptr[p];
+    for (long long p = 0; p < nN; p++) bptr[p + 1] += bptr[p];
+    std::vector<int> bcol((size_t)bptr[nN]);
+    P = NodeILU();
+    P.h_nodeUnk.assign((size_t)nN * BILU_NB, -1);
+    P.h_nodeOut.assign((size_t)nN * BILU_NB, -1);
+    P.h_late.assign(nN, 0);
+    P.h_natural.assign(nN, 0);
+    int maxRow = 0, nPrimary = 0;
+    long long natOff = 0;
+    for (int b = 0; b < K; b++) {
+        Blk& Q = B[b];
+#pragma omp parallel for schedule(static) num_threads(std::max(1, nthr))
+        for (int p = 0; p < Q.S.nNodes; p++) {
+            const long long np = Q.newPos[p];
+            int* dst = bcol.data() + bptr[np];
+            const long long r0 = Q.bptr[p], len = Q.bptr[p + 1] - r0;
+            for (long long q = 0; q < len; q++) dst[q] = Q.newPos[Q.bcol[r0 + q]];  // stays ascending: positions of one block keep their order
+            bdiag[np] = bptr[np] + (Q.bdiag[p] - r0);
+            for (int k = 0; k < BILU_NB; k++) {
+                const int gi = Q.S.h_nodeUnk[(size_t)p * BILU_NB + k];
+                P.h_nodeUnk[(size_t)np * BILU_NB + k] = gi;
+                P.h_nodeOut[(size_t)np * BILU_NB + k] = (gi >= 0 && subOf[gi] == (unsigned char)b) ? gi : -1;
+            }
+            P.h_late[np] = Q.S.h_late[p];
+            P.h_natural[np] = (int)(natOff + Q.S.h_natural[p]);
+        }
+        for (long long g = 0; g < n; g++) if (Q.unkNode[g] >= 0) Q.unkNode[g] = Q.newPos[Q.unkNode[g]];
+        maxRow = std::max(maxRow, Q.S.maxRow);
+        nPrimary += Q.S.nPrimary;
+        natOff += Q.S.nNodes;
+        Q.S = NodeILU();
+        std::vector<int>().swap(Q.bcol);
+        std::vector<long long>().swap(Q.bptr);
+        std::vector<long long>().swap(Q.bdiag);
+    }
+    P.n = n; P.nNodes = (int)nN; P.nLevels = nLv; P.nnzB = bptr[nN]; P.maxRow = maxRow; P.nPrimary = nPrimary;
+    P.h_bptr = bptr; P.h_bcol = bcol; P.h_lvlPtr = lvlPtr;
+    BiluStructRef S{&bptr, &bdiag, &bcol, {}, {}};
+    for (int b = 0; b < K; b++) { S.unkNode.push_back(&B[b].unkNode); S.unkSlot.push_back(&B[b].unkSlot); }
+    bilu_numeric(n, S, fp32, An, d_rp, d_ci, d_av, st, P, debug, false, 1.0, 0, 0, (long long)1 << 62, t0);
 }
 
 // Which XCC ids do the workgroups of a launch on this device see?  One tiny launch per process (cached): 256 workgroups OR

@@ -9,6 +9,7 @@ struct CaseParams {
     double nu = 1.5e-5, relax_U = 0.7, relax_nuTilda = 0.7, relax_T = 1.0, DT = 0.01, deltaT = 1.0;
     double Cp = 1005.0, molWeight = 28.96, mu = 1.8e-5, Pr = 0.7, Prt = 1.0;
     int mrf = 0, transonic = 0, transonicPC = 1, hasT = 0, sutherland = 0;
+    int hasCyclic = 0;  // the mesh has coupled (cyclic) patch pairs
     double As = 1.4792e-06, Ts = 116.0;
     double om[3] = {0, 0, 0}, org[3] = {0, 0, 0};
     std::vector<double> phi_frozen, T_old;
@@ -30,6 +31,7 @@ struct CaseParams {
             for (int k = 0; k < 3; k++) { om[k] = c->mrf_omega[k]; org[k] = c->mrf_origin[k]; }
             DAS_CHECK(!mrf || c->patch_mrf_rotating, DAS_ERR_ARG, "MRF needs the per-patch rotating flags");
         }
+        for (int p = 0; p < c->n_patches; p++) hasCyclic = hasCyclic || c->patch_type[p] == DAS_PATCH_CYCLIC;
         hasT = (solver == DAS_SOLVER_SIMPLEFOAM) && c->simple_has_T != 0;
         if (hasT) {
             Pr = c->Pr; Prt = c->Prt;
@@ -77,6 +79,8 @@ inline ResParams make_params(const CaseParams& cp, const Options& opt, int isPC)
     p.offPhi = rho ? 6 : 5;
     p.hasT = cp.hasT;
     { auto it = opt.i.find("amd.gradFaceParallel"); p.gradFaceParallel = it == opt.i.end() ? 1 : (int)it->second; }
+    // the face / cell split of the cell pass (body_fcoef + body_bcoef + body_cell2) serves DASimpleFoam + SA without T field, MRF and cyclic pairs
+    { auto it = opt.i.find("amd.cellFaceSplit"); p.cellFaceSplit = (it == opt.i.end() ? 0 : (int)it->second) && cp.solver == DAS_SOLVER_SIMPLEFOAM && !cp.hasT && !cp.mrf && !cp.hasCyclic; }
     p.Cp = cp.Cp;
     p.Rgas = 8314.47 / cp.molWeight;  // Foam::constant::thermodynamic::RR / molWeight
     p.mu = cp.mu;

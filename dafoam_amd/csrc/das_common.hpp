@@ -84,13 +84,18 @@ struct VmRange {
 };
 inline std::vector<VmRange>& vm_cache() { static std::vector<VmRange> c; return c; }
 inline std::mutex& vm_cache_mutex() { static std::mutex m; return m; }
-inline std::mutex& vm_api_mutex() { static std::mutex m; return m; }
+inline std::recursive_mutex& vm_api_mutex() { static std::recursive_mutex m; return m; }  // recursive: vm_cache_trim is also called by the mapper, which holds it
 // last resort of a failed hipMalloc: give the physical memory of the cached (idle) ranges back to the device.  The ranges are
 // dropped for good - a range that was unmapped is never handed out again (see VmBuf::release)
-inline size_t vm_cache_trim() {
+// (only the ranges of `device` - the other GPUs' solvers keep theirs; the VM API calls are serialised with the mappers)
+inline size_t vm_cache_trim(int device = -1) {
+    std::lock_guard<std::recursive_mutex> api(vm_api_mutex());
     std::lock_guard<std::mutex> lk(vm_cache_mutex());
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = -1;
     size_t freed = 0;
+    std::vector<VmRange> keep;
     for (VmRange& r : vm_cache()) {
+        if (device >= 0 && r.device != device) { keep.push_back(std::move(r)); continue; }
         size_t off = 0;
         for (size_t i = 0; i < r.handles.size(); i++) {
             (void)hipMemUnmap((char*)r.p + off, r.sizes[i]);
@@ -100,7 +105,7 @@ inline size_t vm_cache_trim() {
         }
         // the address range itself stays reserved (never freed: a later reservation must not land on it)
     }
-    vm_cache().clear();
+    vm_cache().swap(keep);
     return freed;
 }
 
@@ -252,7 +257,7 @@ struct VmBuf {
                 }
                 // nothing cached fits: the idle ranges hold physical memory this (larger) basis will need - give it back to the device
                 // (a later, larger solver otherwise runs out of memory next to tens of idle GB)
-                if (vm_cache_trim() > 0) (void)hipDeviceSynchronize();
+                if (vm_cache_trim(device) > 0) (void)hipDeviceSynchronize();
                 void* base = nullptr;
                 if (hipMemAddressReserve(&base, total, align, nullptr, 0) == hipSuccess && base) {
                     p = (T*)base; reservedBytes = total; vmm = true; n = n_;
@@ -279,7 +284,7 @@ struct VmBuf {
             lk.unlock();
             // (one mapper at a time, process-wide: concurrent hipMemCreate / hipMemMap / hipMemSetAccess from two threads were the one thing the
             //  two failing split-basis runs of round 5 had that the fp64 runs never had)
-            std::lock_guard<std::mutex> vmLock(vm_api_mutex());
+            std::lock_guard<std::recursive_mutex> vmLock(vm_api_mutex());
             hipMemGenericAllocationHandle_t h;
             hipError_t e = hipMemCreate(&h, sz, &prop, 0);
             // (a 2 GB physical chunk may not exist in fragmented HBM although smaller ones do)
@@ -291,7 +296,7 @@ struct VmBuf {
             if (e != hipSuccess) {
                 // idle cached ranges of destroyed solvers may hold the memory this chunk needs (the range in use is not in the cache)
                 (void)hipGetLastError();
-                if (vm_cache_trim() > 0) {
+                if (vm_cache_trim(device) > 0) {
                     (void)hipDeviceSynchronize();
                     sz = std::min(CHUNK, reservedBytes - off);
                     e = hipMemCreate(&h, sz, &prop, 0);

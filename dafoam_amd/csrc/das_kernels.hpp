@@ -61,6 +61,7 @@ struct ResParams {
     // DATurboFoam switches and the MRF zone (angular velocity, origin)
     int turbo, transonic, transonicPC, mrf;
     int hasT;  // DASimpleFoam with the optional passive T field (RHO = false kernels)
+    int cellFaceSplit;     // amd.cellFaceSplit and the case allows it: k_fcoef + k_bcoef + k_cell2 instead of k_cell (host-side launch switch)
     int gradFaceParallel;  // amd.gradFaceParallel: the face-parallel LDS-staged gradient kernel k_grad_fp where it applies (host-side launch switch)
     double om[3], org[3];
     // DATurboFoam work array of the launch (typed by the kernel's scalar type): Teff.U per cell (3N)
@@ -695,6 +696,226 @@ DAS_HD void body_cell(int c, const DevMeshT<G>& m, const ResParams& prm, const T
     const T betaFI = prm.betaFI ? MkSeed<T>::make(prm.betaFI[c], prm.dBetaFI ? prm.dBetaFI[c] : 0.0) : T(1.0);
     T nres = convdiff - rho_c * ((SA_CB2 / SA_SIGMA) * (gNc[0] * gNc[0] + gNc[1] * gNc[1] + gNc[2] * gNc[2]) + SA_CB1 * Stilda * nc * betaFI)
              + SA_CW1 * rho_c * fw * nc / (y * y) * nc;
+    if (!prm.normN) nres = nres * cgc.V;
+    R[prm.offN * N + c] = nres;
+}
+
+// ================================================================================ k_fcoef / k_bcoef / k_cell2
+// Round 6: body_cell split the classical finite-volume way for the benchmark path (DASimpleFoam + SA without the T field, MRF and cyclic
+// pairs; double metrics).  body_cell evaluates every internal face TWICE (once from each side) inside a serial six-trip loop whose
+// dependent loads (face slot -> face record -> neighbour gradients) nothing hides at one wave per SIMD.  Here:
+//   body_fcoef  one thread per INTERNAL face: everything that is symmetric in the two cells, once - the diffusion coefficients of the U
+//               and nuTilda equations and the explicit face fluxes (non-orthogonal correction, dev2 stress, linearUpwindV correction);
+//               SIX scalars per face, stored quantity-major (fc[q nIF + f]);
+//   body_bcoef  one thread per BOUNDARY face: the patch coefficients of its cell (13 scalars, brec[13 b + q]);
+//   body_cell2  one thread per cell: gathers the records of its faces (the upwind coefficients come from phi), then relax, URes, rAU,
+//               HbyA and the SA residual exactly as body_cell.
+// Same arithmetic as body_cell up to the association of the face-interpolation weights (1 - (1 - w) vs w); reference arithmetic:
+// DAResidualSimpleFoam.C:106-237, DASpalartAllmaras.C:407-488.
+#define DAS_FC_N 6    // cd, cdn, F[3], FN
+#define DAS_BREC_N 13  // iC[3], bsrc[3], vmx, vmn, srcb[3], bdN, bsN
+template <class T>
+DAS_HD void body_fcoef(int f, const DevMeshT<double>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const T* gradN, T* fc) {
+    const long long N = m.nC, nIF = m.nIF;
+    const int o = m.owner[f], n = m.neigh[f];
+    const FaceGeomT<double>& g = m.fg[f];
+    const T phi = W[prm.offPhi * N + f];
+    const double wl = g.w, wn = 1.0 - g.w;
+    const T nuT_o = W[prm.offN * N + o], nuT_n = W[prm.offN * N + n];
+    const T muEff_o = prm.nu + nut[o], muEff_n = prm.nu + nut[n];
+    const T gam = (wl * muEff_o + wn * muEff_n) * g.magSf;
+    fc[0 * nIF + f] = gam * g.nod;
+    const T gn = (wl * ((nuT_o + prm.nu) * (1.0 / SA_SIGMA)) + wn * ((nuT_n + prm.nu) * (1.0 / SA_SIGMA))) * g.magSf;
+    fc[1 * nIF + f] = gn * g.nod;
+    T F[3] = {T(0.0), T(0.0), T(0.0)};
+    // owner side, then neighbour side: one gradient tensor live at a time
+    T cvg[3] = {T(0.0), T(0.0), T(0.0)};
+    T corrv[3] = {T(0.0), T(0.0), T(0.0)};
+    const double pv = val(phi);
+    const bool pos = pv > 0.0;  // the upwind cell is the owner when the flux is positive
+    T cvn(0.0);
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const int c = side == 0 ? o : n;
+        const double wc = side == 0 ? wl : wn;
+        T gU[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) gU[k] = gradU[9LL * c + k];
+        T tau[9];
+        dev2T_scaled<T>(gU, side == 0 ? muEff_o : muEff_n, tau);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            cvg[j] += wc * (g.corr[0] * gU[j] + g.corr[1] * gU[3 + j] + g.corr[2] * gU[6 + j]);
+            F[j] += wc * (g.Sf[0] * tau[j] + g.Sf[1] * tau[3 + j] + g.Sf[2] * tau[6 + j]);
+        }
+        if (prm.convBlend > 0.0 && (pos == (side == 0))) {
+            const CellGeomT<double>& cgu = m.cg[c];
+            const double d[3] = {g.Cf[0] - cgu.C[0], g.Cf[1] - cgu.C[1], g.Cf[2] - cgu.C[2]};
+#pragma unroll
+            for (int j = 0; j < 3; j++) corrv[j] = d[0] * gU[j] + d[1] * gU[3 + j] + d[2] * gU[6 + j];
+        }
+        cvn += wc * (g.corr[0] * gradN[3LL * c] + g.corr[1] * gradN[3LL * c + 1] + g.corr[2] * gradN[3LL * c + 2]);
+    }
+    if (prm.convBlend > 0.0) {
+        T mx[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const T UO = W[3LL * o + j], UN = W[3LL * n + j];
+            mx[j] = pos ? wn * (UN - UO) : wl * (UO - UN);
+        }
+        T sfc = corrv[0] * corrv[0] + corrv[1] * corrv[1] + corrv[2] * corrv[2];
+        T mxc = corrv[0] * mx[0] + corrv[1] * mx[1] + corrv[2] * mx[2];
+        if (val(sfc) > 0.0) {
+            if (val(mxc) < 0.0) { corrv[0] = T(0.0); corrv[1] = T(0.0); corrv[2] = T(0.0); }
+            else if (val(sfc) > val(mxc)) {
+                T sc = mxc / (sfc + DAS_VSMALL);
+                corrv[0] = corrv[0] * sc; corrv[1] = corrv[1] * sc; corrv[2] = corrv[2] * sc;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) F[j] -= prm.convBlend * (phi * corrv[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) fc[(2 + j) * nIF + f] = F[j] + gam * cvg[j];
+    fc[5 * nIF + f] = gn * cvn;
+}
+
+template <class T>
+DAS_HD void body_bcoef(int b, const DevMeshT<double>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, T* brec) {
+    const long long N = m.nC;
+    const int f = m.nIF + b, c = m.owner[f];
+    const FaceGeomT<double>& g = m.fg[f];
+    const CellGeomT<double>& cgc = m.cg[c];
+    const T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
+    const T pc = W[prm.offP * N + c], nc = W[prm.offN * N + c], nut_c = nut[c];
+    const T phi = W[prm.offPhi * N + f];
+    T gUc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) gUc[k] = gradU[9LL * c + k];
+    BFace<T, double> bf;
+    eval_bface<T, false>(m.bc[m.bpatch[b]], g, cgc, prm, Uc, pc, T(0.0), nc, nut_c, val(phi), bf);
+    T* r = brec + (long long)DAS_BREC_N * b;
+    const T muEff_b = bf.rho_b * (bf.nu_b + bf.nut_b);
+    const T gam_b = muEff_b * g.magSf;
+    T iC[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        iC[k] = phi * bf.U.vic[k] - gam_b * bf.U.gic[k];
+        r[k] = iC[k];
+        r[3 + k] = gam_b * bf.U.gbc[k] - phi * bf.U.vbc[k];
+    }
+    T a0 = dabs(iC[0]), a1 = dabs(iC[1]), a2 = dabs(iC[2]);
+    T vmx = a0;
+    if (val(a1) > val(vmx)) vmx = a1;
+    if (val(a2) > val(vmx)) vmx = a2;
+    T vmn = iC[0];
+    if (val(iC[1]) < val(vmn)) vmn = iC[1];
+    if (val(iC[2]) < val(vmn)) vmn = iC[2];
+    r[6] = vmx;
+    r[7] = vmn;
+    T gUb[9], dsn[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        T snG = bf.U.gic[j] * Uc[j] + bf.U.gbc[j];
+        T ngU = bf.nrm[0] * gUc[j] + bf.nrm[1] * gUc[3 + j] + bf.nrm[2] * gUc[6 + j];
+        dsn[j] = snG - ngU;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) gUb[3 * i + j] = gUc[3 * i + j] + bf.nrm[i] * dsn[j];
+    T tau_b[9];
+    dev2T_scaled<T>(gUb, muEff_b, tau_b);
+#pragma unroll
+    for (int j = 0; j < 3; j++) r[8 + j] = g.Sf[0] * tau_b[j] + g.Sf[1] * tau_b[3 + j] + g.Sf[2] * tau_b[6 + j];
+    const T gn_b = bf.rho_b * (bf.n.xb + bf.nu_b) * (g.magSf / SA_SIGMA);
+    r[11] = phi * bf.n.vic - gn_b * bf.n.gic;
+    r[12] = gn_b * bf.n.gbc - phi * bf.n.vbc;
+}
+
+template <class T>
+DAS_HD void body_cell2(int c, const DevMeshT<double>& m, const ResParams& prm, const T* W, const T* nut, const T* gradU, const T* gradP, const T* gradN,
+                       const T* fc, const T* brec, T* R, T* rAU, T* HbyA) {
+    const long long N = m.nC, nIF = m.nIF;
+    const CellGeomT<double>& cgc = m.cg[c];
+    const T Uc[3] = {W[3LL * c], W[3LL * c + 1], W[3LL * c + 2]};
+    const T nc = W[prm.offN * N + c];
+    T D0(0.0), sumOff(0.0), sumPhi(0.0), vmaxs(0.0), vmins(0.0);
+    T offU[3], src[3], bdiag[3], bsrc[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { offU[k] = T(0.0); src[k] = T(0.0); bdiag[k] = T(0.0); bsrc[k] = T(0.0); }
+    T dN(0.0), offN(0.0), sN(0.0), bdN(0.0), bsN(0.0);
+    for (int s = m.cf_ptr[c]; s < m.cf_ptr[c + 1]; s++) {
+        const int fe = m.cf_face[s];
+        const int f = fe & 0x7fffffff;
+        const bool nb = fe < 0;
+        const T phi = W[prm.offPhi * N + f];
+        if (f < nIF) {
+            const int o = m.cf_other[s];
+            const double sg = nb ? -1.0 : 1.0;
+            const double wu = val(phi) >= 0.0 ? 1.0 : 0.0;  // upwind weight of the owner value = pos0(flux)
+            T dcoef, off;
+            if (!nb) { dcoef = wu * phi; off = (1.0 - wu) * phi; }
+            else { dcoef = -((1.0 - wu) * phi); off = -(wu * phi); }
+            sumPhi += sg * phi;
+            const T cd = fc[f], cdn = fc[nIF + f];
+            const T offTot = off - cd;
+            D0 += dcoef + cd;
+            sumOff += dabs(offTot);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { offU[k] += offTot * W[3LL * o + k]; src[k] += sg * fc[(2 + k) * nIF + f]; }
+            dN += dcoef + cdn;
+            offN += (off - cdn) * W[prm.offN * N + o];
+            sN += sg * fc[5 * nIF + f];
+        } else {
+            const T* r = brec + (long long)DAS_BREC_N * (f - nIF);
+            sumPhi += phi;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { bdiag[k] += r[k]; bsrc[k] += r[3 + k]; src[k] += r[8 + k]; }
+            vmaxs += r[6];
+            vmins += r[7];
+            bdN += r[11];
+            bsN += r[12];
+        }
+    }
+    D0 -= sumPhi;
+    dN -= sumPhi;
+    T D = dmax(dabs(D0 + vmaxs), sumOff) * (1.0 / prm.alphaU) - vmins;
+    T dD = D - D0;
+    const double rV = 1.0 / cgc.V;
+    T avgb = (bdiag[0] + bdiag[1] + bdiag[2]) * (1.0 / 3.0);
+    T A = (D + avgb) * rV;
+    T rA = 1.0 / A;
+    rAU[c] = rA;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        T sk = src[k] + dD * Uc[k];
+        T ures = ((D + bdiag[k]) * Uc[k] + offU[k] - sk - bsrc[k]) * rV + gradP[3LL * c + k];
+        if (!prm.normU) ures = ures * cgc.V;
+        R[3LL * c + k] = ures;
+        T H = ((avgb - bdiag[k]) * Uc[k] - offU[k] + sk + bsrc[k]) * rV;
+        HbyA[3LL * c + k] = rA * H;
+    }
+    // ---- SA source terms (as body_cell)
+    const T gNc[3] = {gradN[3LL * c], gradN[3LL * c + 1], gradN[3LL * c + 2]};
+    const double y = cgc.y;
+    const double k2y2 = (SA_KAPPA * y) * (SA_KAPPA * y);
+    T chi = nc / T(prm.nu);
+    T fv1 = fv1_of<T>(chi);
+    T fv2 = 1.0 - chi / (1.0 + chi * fv1);
+    T w01 = 0.5 * (gradU[9LL * c + 1] - gradU[9LL * c + 3]), w02 = 0.5 * (gradU[9LL * c + 2] - gradU[9LL * c + 6]), w12 = 0.5 * (gradU[9LL * c + 5] - gradU[9LL * c + 7]);
+    T Omega = 1.4142135623730951 * dsqrt(2.0 * (w01 * w01 + w02 * w02 + w12 * w12));
+    T Stilda = dmax(Omega + fv2 * nc / k2y2, SA_CS * Omega);
+    T r = dmin(nc / (dmax(Stilda, DAS_SMALL) * k2y2), 10.0);
+    T r2 = r * r, r6 = r2 * r2 * r2;
+    T gg = r + SA_CW2 * (r6 - r);
+    T g2 = gg * gg, g6 = g2 * g2 * g2;
+    const double cw36 = SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3 * SA_CW3;
+    T fw = gg * dpow((1.0 + cw36) / (g6 + cw36), 1.0 / 6.0);
+    T convdiff = ((dN + bdN) * nc + offN - sN - bsN) * rV;
+    const T betaFI = prm.betaFI ? MkSeed<T>::make(prm.betaFI[c], prm.dBetaFI ? prm.dBetaFI[c] : 0.0) : T(1.0);
+    T nres = convdiff - ((SA_CB2 / SA_SIGMA) * (gNc[0] * gNc[0] + gNc[1] * gNc[1] + gNc[2] * gNc[2]) + SA_CB1 * Stilda * nc * betaFI)
+             + SA_CW1 * fw * nc / (y * y) * nc;
     if (!prm.normN) nres = nres * cgc.V;
     R[prm.offN * N + c] = nres;
 }

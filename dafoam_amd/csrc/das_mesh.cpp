@@ -80,6 +80,9 @@ Options::Options() {
     // stability check of the incomplete factorisation (das_create_ml_rksp_matrix_free): estimate = max |(LU)^-1 P e - e| on two vectors; above
     // the limit the factorisation is rebuilt with another elimination order of the cells (0: no check)
     d["amd.pcStabilityLimit"] = 1.0e8;
+    s["amd.pcOrderCandidates"] = "1245";  // elimination orders tried after the configured one (das_ksp_get_pc_stability lists them)
+    d["amd.pcStabilityGood"] = 1.0e4;  // where the smallest estimate of all candidates is wanted (sub-domains): an estimate below this ends the search
+    i["amd.pcSubdomains"] = -1;  // K > 1: restricted additive Schwarz inside the GPU (K node-block ILUs on RCB blocks + asmOverlap rings, own elimination orders, one merged level structure); -1 (default): 4 from 1 M cells on, else 1
     i["amd.pcCoarseSparseAZ"] = 1;   // deflated mode: A (Z u) through the precomputed sparse A Z (0: one full operator product per apply)
     i["amd.coloringOnDevice"] = 1;   // serial first-fit colouring as a data-flow kernel (das_color.hpp); 0: host variants
     d["amd.primalTau0"] = 1.0;          // Newton primal: initial pseudo-time factor (diagonal scaled by 1 + 1/tau), SER growth
@@ -124,6 +127,11 @@ Options::Options() {
     // only the hi array - 12 instead of 16 bytes per basis entry and iteration - every vector-building pass reads hi + lo: Arnoldi relation to
     // 2^-48) | "fp32" (compressed basis, short well-conditioned solves only) | "auto" (default): split for bases >= 1 GB with dcgs2, else fp64
     s["amd.krylovBasisPrecision"] = "auto";
+    // DASimpleFoam cell pass as per-face coefficient passes + a per-cell gather pass (k_fcoef, k_bcoef, k_cell2: every internal face evaluated once
+    // instead of twice).  Measured at 2 M cells (profiles/r07n_*): dual numbers 489 + 21 + 938 us against 1100 us for the monolithic k_cell, fp64
+    // 317 + 30 + 484 against ~700: the gather pass alone costs what the monolith costs - the time is in the per-cell gathers, not in the face
+    // arithmetic the split removes.  Off by default (1: on).
+    i["amd.cellFaceSplit"] = 0;
     i["amd.gradFaceParallel"] = 1;  // DASimpleFoam gradients by the face-parallel, LDS-staged kernel k_grad_fp: 1 = where it is the faster one (fp64 passes), 2 = dual passes too, 0 = never
 }
 double Options::getd(const std::string& k) const {

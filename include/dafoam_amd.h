@@ -365,6 +365,11 @@ int das_ksp_get_status(das_ksp_t* ksp, int* reason, int* nBreakdown, int* nSweep
  * rebuilt with the next order, rank by rank.  The reference's PETSc ILU has no such check; its MatFactorInfo shift (DALinearEqn.C:270-272)
  * only replaces zero pivots. */
 int das_ksp_get_pc_stability(das_ksp_t* ksp, double* estimate, int* orderUsed);
+/* amd.pcSubdomains K (default -1: 4 from 1 M cells on): restricted additive Schwarz INSIDE the rank - K node-block ILUs on recursive-coordinate-
+ * bisection blocks of the cells plus adjEqnOption.asmOverlap rings, each with its own elimination order, merged into one level structure so
+ * that one pair of sweeps runs them together (the reference reaches several sub-domains per device only through more MPI ranks,
+ * DALinearEqn.C:212-216).  Returns K (1: one factorisation, -1: null handle); orders[K] / estimates[K] are optional. */
+int das_ksp_get_pc_subdomains(das_ksp_t* ksp, int* orders, double* estimates);
 /* two-level preconditioner (amd.pcCoarseAggregates / pcCoarseField / pcCoarseMode): number of aggregates of the
  * piecewise-constant pressure coarse space (0 = none) and, optionally, the aggregate of every cell (-1 = not owned) */
 int das_ksp_get_coarse(das_ksp_t* ksp, int* aggOfCell);

@@ -5,6 +5,8 @@
 
 using namespace das;
 
+static int g_split = 0;  // 1: DASimpleFoam cell pass through the face / cell split (emu_set_cell_split)
+extern "C" void emu_set_cell_split(int on) { g_split = on; }
 template <class T, class MV>
 static void eval_on(const MV& m, const CaseParams& cp, const ResParams& prm, const std::vector<T>& W, std::vector<T>& R);
 template <class T>
@@ -17,7 +19,21 @@ static void eval_on(const MV& m, const CaseParams& cp, const ResParams& prm, con
     if (cp.solver == DAS_SOLVER_SIMPLEFOAM) {
         std::vector<T> nut(N), gU(9 * N), gP(3 * N), gN(3 * N), gH(3 * N), rAU(N), HbyA(3 * N), q(m.nF);
         for (int c = 0; c < m.nC; c++) body_grad<T, false>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), gH.data());
-        for (int c = 0; c < m.nC; c++)
+        bool split = false;
+        if constexpr (std::is_same<MV, DevMeshT<double>>::value) {
+            // the face / cell split of body_cell (body_fcoef + body_bcoef + body_cell2) where the product path launches it
+            bool cyc = false;
+            for (int b = 0; b < m.nF - m.nIF; b++) cyc = cyc || m.cyc[b] >= 0;
+            if (g_split && !prm.hasT && !prm.mrf && !cyc) {
+                split = true;
+                std::vector<T> fc((size_t)DAS_FC_N * m.nIF), brec((size_t)DAS_BREC_N * (m.nF - m.nIF));
+                for (int f = 0; f < m.nIF; f++) body_fcoef<T>(f, m, prm, W.data(), nut.data(), gU.data(), gN.data(), fc.data());
+                for (int b = 0; b < m.nF - m.nIF; b++) body_bcoef<T>(b, m, prm, W.data(), nut.data(), gU.data(), brec.data());
+                for (int c = 0; c < m.nC; c++)
+                    body_cell2<T>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), fc.data(), brec.data(), R.data(), rAU.data(), HbyA.data());
+            }
+        }
+        for (int c = 0; c < m.nC && !split; c++)
             body_cell<T, false>(c, m, prm, W.data(), nut.data(), gU.data(), gP.data(), gN.data(), gH.data(), R.data(), rAU.data(), HbyA.data());
         for (int f = 0; f < m.nF; f++) body_face<T, false>(f, m, prm, W.data(), nut.data(), gP.data(), rAU.data(), HbyA.data(), q.data(), R.data());
         for (int c = 0; c < m.nC; c++) body_pres<T, false>(c, m, prm, q.data(), R.data());

@@ -1,6 +1,7 @@
 """GPU tier (-m gpu): the HIP path, called through the C-ABI / pyDASolvers mirror, against the oracle on the
 same seeded inputs.  Tolerances: residuals 1e-12 (fp64, different summation order), dual-number Jacobian
 entries 1e-10, adjoint vector psi <= 1e-6 relative (BASELINE.json north_star)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -63,6 +64,29 @@ def test_residual_parity_simplefoam(wall_function, isPC):
     Ro = residual(case, g, case.states, isPC=bool(isPC))
     for nm, sl in blocks(case, g):
         assert relerr(R[sl], Ro[sl]) < 1e-12, nm
+
+
+def test_cell_face_split_kernels_equal_the_monolithic_cell_kernel():
+    """Round 6 (amd.cellFaceSplit, off by default): k_fcoef + k_bcoef + k_cell2 against k_cell on the device - residual values, a dual-number
+    Jacobian-transpose product and the FD PC matrix - on the bump channel with a wall function and on the NACA0012 O-grid."""
+    from dafoam_amd.meshgen import naca0012_case
+    from dafoam_amd.pyDASolvers import Mat
+
+    for case in (channel_case(9, 8, 7, wall_function=True), naca0012_case(32, 10, 4, span=0.4, first_cell=1e-3)):
+        out = []
+        for split in (0, 1):
+            D = make(case, amd={"cellFaceSplit": split, "pcUpwindBlend": 0.5})
+            R = np.zeros(case.states.size)
+            D.solver.getResiduals(R)
+            psi = np.random.default_rng(2).standard_normal(R.size)
+            prod = np.zeros(R.size)
+            D.solverAD.calcJacTVecProduct("states", "stateVar", case.states, "residuals", "residual", psi, prod)
+            D.solver.runColoring()
+            pc = Mat()
+            D.solver.calcdRdWT(1, pc)
+            out.append((R, prod, pc.to_scipy().tocsr()))
+        assert relerr(out[1][0], out[0][0]) < 1e-13 and relerr(out[1][1], out[0][1]) < 1e-12
+        assert abs(out[1][2] - out[0][2]).max() <= 1e-6 * abs(out[0][2]).max()  # finite differences of two summation orders
 
 
 def test_residual_parity_scalar_transport_config0():
@@ -557,6 +581,68 @@ def test_node_block_ilu_apply_matches_oracle(dims, fp32, solver):
         assert np.all(S["natural"][Bo.dropped_pairs.ravel()] >= nPrimary)
     # applying it twice gives the same answer (the sweeps re-arm their sentinels / tickets every call)
     assert np.array_equal(y, ksp.applyPC(D.solver, x))
+
+
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_node_block_ilu_elimination_orders_match_oracle(order, monkeypatch):
+    """Round 6: the elimination order of the cells is a choice of the factorisation (mesh numbering, reverse Cuthill-McKee = jacMatReOrdering
+    "rcm", Cuthill-McKee, mesh numbering backwards, along / against the mean flow, Cuthill-McKee grown from the most upstream cell in both
+    directions) - the stability check of das_create_ml_rksp_matrix_free switches between them.  Every order: a valid level structure, and
+    the device apply equals the oracle's scalar ILU(0) on the filled node pattern eliminated in THAT order."""
+    from dafoam_amd import _capi
+    from dafoam_amd.pyDASolvers import KSP, Mat
+
+    monkeypatch.setenv("DAS_BILU_ORDER", str(order))
+    case = channel_case(9, 8, 7, grading_y=2.0)
+    D = make(case, amd={"pcCoarseAggregates": 0, "pcStabilityLimit": 1e300}, adjEqnOption={"printInfo": 0})
+    D.solver.runColoring()
+    pc = Mat()
+    D.solver.calcdRdWT(1, pc)
+    ksp = KSP()
+    D.solverAD.createMLRKSPMatrixFree(pc, ksp)
+    est, used = C.c_double(-1.0), C.c_int(-1)
+    _capi.check(_capi.lib().das_ksp_get_pc_stability(ksp.handle, C.byref(est), C.byref(used)))
+    assert used.value == order and 0.0 <= est.value < 1e12
+    S = ksp.pcStructure()
+    nu = S["nodeUnk"]
+    P = pc.to_scipy().tocsr()
+    n = P.shape[0]
+    assert np.array_equal(np.sort(nu[nu >= 0]), np.arange(n))
+    lev = np.repeat(np.arange(S["lvlPtr"].size - 1), np.diff(S["lvlPtr"]))
+    for p in range(0, nu.shape[0], max(1, nu.shape[0] // 200)):
+        cols = S["bcol"][S["bptr"][p]:S["bptr"][p + 1]]
+        assert np.all(lev[cols[cols < p]] < lev[p]) and np.all(lev[cols[cols > p]] > lev[p])
+    x = np.random.default_rng(order).standard_normal(n)
+    y = ksp.applyPC(D.solver, x)
+    B = OL.NodeBlockILU.__new__(OL.NodeBlockILU)
+    B.n, B.nu, B.bptr, B.bcol = n, nu, S["bptr"].astype(np.int64), S["bcol"].astype(np.int64)
+    assert relerr(y, B.scalar_twin(P, node_order=np.argsort(S["natural"]))(x)) < 1e-9
+
+
+@pytest.mark.parametrize("variant", ["subdomains", "pick_min_of_all_orders"])
+def test_adjoint_with_subdomain_ilus_and_order_fallback_reaches_the_same_psi(variant):
+    """Round 6: (a) amd.pcSubdomains K - restricted additive Schwarz inside the GPU: K node-block ILUs on RCB blocks of the cells + asmOverlap
+    rings, each with its own elimination order, sweeps on K streams; (b) a stability limit no factorisation passes - every candidate order is
+    factorised and the one with the smallest estimate kept.  psi is preconditioner-independent: both reach the direct solve's."""
+    from dafoam_amd import _capi
+
+    case = converged_case((10, 8, 6), lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(case.mesh)
+    sc, con, col, A = oracle_mats(case, g)
+    rhs = np.zeros(A.shape[0])
+    rhs[0 : 3 * g.nC : 3] = g.V
+    rhs *= sc
+    psi_o = spla.spsolve(A.tocsc(), rhs)
+    amd = {"pcSubdomains": 3} if variant == "subdomains" else {"pcStabilityLimit": 1e-30, "pcOrderCandidates": "124567"}
+    D = make(case, amd=amd, adjEqnOption={"gmresRelTol": 1e-10, "printInfo": 0, "gmresMaxIters": 800})
+    psi, fail = D.solveAdjoint(rhs)
+    assert fail == 0 and relerr(psi, psi_o) <= 1e-6
+    est, used = C.c_double(-1.0), C.c_int(-1)
+    _capi.check(_capi.lib().das_ksp_get_pc_stability(D.ksp.handle, C.byref(est), C.byref(used)))
+    assert est.value > 0.0 and 0 <= used.value <= 7
+    # twice: the sub-domain streams / tickets re-arm
+    psi2, fail2 = D.solveAdjoint(rhs)
+    assert fail2 == 0 and relerr(psi2, psi_o) <= 1e-6
 
 
 @pytest.mark.parametrize("nrhs", [2, 3, 8])
