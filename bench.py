@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
     ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE"), help="amd.pcCoarseMode additive | deflated (default: the library's, deflated)")
     ap.add_argument("--orth", default=os.environ.get("DAS_BENCH_ORTH", "dcgs2"), help="dcgs2 (delayed re-orthogonalisation, 2 basis reads / iteration) | cgs (reference: refine if needed)")
+    ap.add_argument("--naca-sweep", type=float, default=0.0, help="naca: sweep angle in degrees (round 6: a genuinely 3-D wing segment - every layer its own section; with --naca-taper)")
+    ap.add_argument("--naca-taper", type=float, default=0.0, help="naca: fraction of the chord lost from the first to the last layer (0.3: tip chord 0.7)")
+    ap.add_argument("--naca-polish-steps", type=int, default=None, help="naca: Newton steps on the 3-D mesh (default 3 for the extruded section, 40 for a swept / tapered segment)")
     ap.add_argument("--naca-partition", default="columns", choices=["columns", "span", "around"],
                     help="naca, N > 1: 'columns' (default) = blocks in the (around, wall-normal) index plane, every rank keeps whole spanwise columns of cells - the cut "
                          "never crosses the strong spanwise coupling of the thin layers; 'around' = sectors around the airfoil; 'span' = spanwise slabs of whole layers")
@@ -182,6 +185,20 @@ def naca_partition(cid, dims, world, kind):
 
     rec(np.arange(cid.size), 0, na, 0, nn, 0, world)
     return part
+
+
+def _wing3d_kwargs(a):
+    """naca_extruded_case arguments of a swept / tapered wing segment (--naca-sweep / --naca-taper): the mesh transformation and enough
+    Newton steps to converge the primal on it (the extruded section's state is only a starting guess there)."""
+    swept = bool(a.naca_sweep or a.naca_taper)
+    kw = {}
+    if swept:
+        kw["case_kwargs"] = {"sweep_deg": float(a.naca_sweep), "taper": float(a.naca_taper)}
+    steps = a.naca_polish_steps if a.naca_polish_steps is not None else (40 if swept else 3)
+    kw["polish_steps"] = int(steps)
+    if swept:
+        kw["polish_tol"] = 1e-5
+    return kw
 
 
 def _amd_overrides(a):
@@ -281,7 +298,7 @@ def main():
             else:
                 case2d, lv = naca_converged_primal(a.naca[0], a.naca[1], options=opts, first_cell=a.naca_first_cell, verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
                 gcase, ex = naca_extruded_case(case2d, (a.naca[0], a.naca[1]), a.naca[2], dz=a.naca_dz, first_cell=a.naca_first_cell, options=opts,
-                                               verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
+                                               verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")), **_wing3d_kwargs(a))
                 primal = {"method": "rank 0: pseudo-transient Newton-Krylov (das_solve_primal), grid sequencing, spanwise extrusion, Newton polish; then scattered",
                           "levels": [{k: (list(v) if isinstance(v, tuple) else v) for k, v in r.items()} for r in lv],
                           "extruded": {k: (list(v) if isinstance(v, tuple) else v) for k, v in ex.items()}, "seconds": time.time() - t0}
@@ -317,7 +334,7 @@ def main():
             t2d = time.time() - t0
             if a.naca[2] > 1:
                 case, ex = naca_extruded_case(case2d, (a.naca[0], a.naca[1]), a.naca[2], dz=a.naca_dz, first_cell=a.naca_first_cell, options=opts,
-                                              verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
+                                              verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")), **_wing3d_kwargs(a))
             else:
                 case, ex = case2d, None
             primal = {"method": "pseudo-transient Newton-Krylov (das_solve_primal), grid sequencing on the one-layer O-grid, spanwise extrusion, Newton polish",
@@ -576,7 +593,8 @@ def main():
                              if a.solver != "DASimpleFoam" else
                              f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell hex mesh per GPU ({a.nx}x{a.ny}x{a.nz} bump channel, wall-normal "
                              f"grading; state: prolonged converged coarse primal)" if a.workload != "naca" else
-                             f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {n_global}-cell NACA0012 wing section (O-grid, {a.naca[0]} around x {a.naca[1]} normal x {a.naca[2]} "
+                             f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {n_global}-cell NACA0012 " + (f"SWEPT wing segment (sweep {a.naca_sweep:g} deg, taper {a.naca_taper:g}: every layer its own section; " if (a.naca_sweep or a.naca_taper) else "wing section (")
+                             + f"O-grid, {a.naca[0]} around x {a.naca[1]} normal x {a.naca[2]} "
                              f"spanwise hexahedra of {a.naca_dz} chords, first cell {a.naca_first_cell:g} chords, far field 20 chords, U 10 m/s, AoA 2 deg, Re 6.7e5; "
                              + ("synthetic noisy boundary-layer state)" if a.naca_synthetic else
                                 "linearised about the primal CONVERGED on the GPU: Newton-Krylov, grid sequencing, |R| = %.2e)" % primal_residual_norm))

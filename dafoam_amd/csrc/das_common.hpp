@@ -427,6 +427,8 @@ void point_steps(const Mesh& m, double relStep, std::vector<double>& h);
 // aggregates along the strongest pressure-Laplacian couplings (at most maxAgg of them); ownedCell: optional mask; returns the count
 int strength_aggregates(const Mesh& m, const std::vector<unsigned char>* ownedCell, int maxAgg, std::vector<int>& agg);
 
+void mesh_metrics_only(int nP, const double* pts, int nF, int nIF, int nC, const int* fptr, const int* fpts, const int* own, const int* nei,
+                       double* Sf, double* Cf, double* C, double* V, double* w);
 double wall_seconds();
 
 }  // namespace das

@@ -2192,20 +2192,35 @@ static void choose_order_and_factorise(das_solver* s, das_ksp* k, NodeILU& F, co
     }
     if (getenv("DAS_BILU_PICK_MIN")) pickMin = atoi(getenv("DAS_BILU_PICK_MIN")) != 0;
     const double good = s->opt.getd("amd.pcStabilityGood");  // pickMin: an estimate this small ends the search
-    int best = cand[0], last = -1;
-    double bestEst = 0.0, est = 0.0;
+    // every evaluated candidate: (order, estimate, dependency levels).  The levels matter for sub-domains: the merged structure of
+    // amd.pcSubdomains runs max(levels over the blocks) dependent hops - one block in a deep order (round 6, 2 M cells, K = 6 / 8: a
+    // Cuthill-McKee order of a thin block) leaves thousands of levels with a handful of nodes each: 108 - 151 ms per apply instead of 6.
+    // Among the candidates below the limit only those within 1.5 x the shallowest compete for the smallest estimate.
+    struct Cand { int o; double est; int levels; };
+    std::vector<Cand> seen;
+    int last = -1;
     for (size_t attempt = 0; attempt < cand.size(); attempt++) {
         const int o = cand[attempt];
         F = NodeILU();
         setup_node_ilu_into(s, k, F, mask, o);
-        est = pc_stability_estimate(s, k, F, mask);
+        const double est = pc_stability_estimate(s, k, F, mask);
         last = o;
+        seen.push_back({o, est, F.nLevels});
         if (s->opt.geti("debug") || getenv("DAS_PC_STAB") || (est > limit && !pickMin))
-            fprintf(stderr, "[dafoam_amd] rank %s: preconditioner stability estimate max|(LU)^-1 P e - e| = %.3e with elimination order %d (limit %.1e)%s\n",
-                    getenv("RANK") ? getenv("RANK") : "0", est, o, limit, (est > limit && !pickMin) ? ": unstable, trying another order" : "");
-        if (attempt == 0 || est < bestEst) { best = o; bestEst = est; }
+            fprintf(stderr, "[dafoam_amd] rank %s: preconditioner stability estimate max|(LU)^-1 P e - e| = %.3e with elimination order %d, %d levels (limit %.1e)%s\n",
+                    getenv("RANK") ? getenv("RANK") : "0", est, o, F.nLevels, limit, (est > limit && !pickMin) ? ": unstable, trying another order" : "");
         if (est <= limit && (!pickMin || est <= good)) break;
     }
+    bool anyOk = false;
+    for (const Cand& c : seen) anyOk = anyOk || c.est <= limit;
+    int minLv = 1 << 30;
+    for (const Cand& c : seen) if (!anyOk || c.est <= limit) minLv = std::min(minLv, c.levels);
+    int best = seen.back().o;
+    double bestEst = 1e300;
+    if (!pickMin && seen.back().est <= limit) bestEst = seen.back().est;  // first stable candidate (the loop stopped there)
+    else
+        for (const Cand& c : seen)
+            if ((!anyOk || c.est <= limit) && (double)c.levels <= 1.5 * minLv && c.est < bestEst) { best = c.o; bestEst = c.est; }
     if (last != best) {
         F = NodeILU();
         setup_node_ilu_into(s, k, F, mask, best);
@@ -4032,6 +4047,15 @@ int das_get_of_mesh_points(das_solver_t* s, double* points) {
     return DAS_OK;
     DAS_CATCH
 }
+// metrics of a bare mesh, no solver handle (input generators: dafoam_amd/meshgen.py at bench sizes)
+int das_mesh_metrics(int nPoints, const double* points, int nFaces, int nInternalFaces, int nCells, const int* facePtr, const int* facePts, const int* owner,
+                     const int* neighbour, double* Sf, double* Cf, double* C, double* V, double* weights) {
+    DAS_TRY
+    DAS_CHECK(points && facePtr && facePts && owner && neighbour && Sf && Cf && C && V, DAS_ERR_ARG, "null argument");
+    mesh_metrics_only(nPoints, points, nFaces, nInternalFaces, nCells, facePtr, facePts, owner, neighbour, Sf, Cf, C, V, weights);
+    return DAS_OK;
+    DAS_CATCH
+}
 int das_get_geometry(das_solver_t* s, double* Sf, double* Cf, double* C, double* V, double* w, double* nod, double* corr, double* bdc) {
     DAS_TRY
     DAS_CHECK(s, DAS_ERR_ARG, "null solver handle");
@@ -5182,6 +5206,15 @@ int das_ksp_get_pc_structure(das_ksp_t* ksp, int* nodeUnk, long long* bptr, int*
     DAS_TRY
     DAS_CHECK(ksp && ksp->useBilu, DAS_ERR_STATE, "the KSP does not hold a node-block ILU preconditioner (amd.pcType \"bilu\")");
     copy_pc_structure(ksp->bilu, nodeUnk, bptr, bcol, lvlPtr, natural);
+    return DAS_OK;
+    DAS_CATCH
+}
+// nodeOut[nNodes * 8]: the unknown a slot WRITES (= nodeUnk, or -1 for the overlap copies of a multi-block factorisation, amd.pcSubdomains)
+int das_ksp_get_pc_node_out(das_ksp_t* ksp, int* nodeOut) {
+    DAS_TRY
+    DAS_CHECK(ksp && ksp->useBilu && nodeOut, DAS_ERR_STATE, "the KSP does not hold a node-block ILU preconditioner (amd.pcType \"bilu\")");
+    const std::vector<int>& src = ksp->bilu.h_nodeOut.empty() ? ksp->bilu.h_nodeUnk : ksp->bilu.h_nodeOut;
+    std::copy(src.begin(), src.end(), nodeOut);
     return DAS_OK;
     DAS_CATCH
 }

@@ -243,13 +243,45 @@ void Mesh::compute_geometry(const double* y_wall) {
     cg.assign(nC, CellGeom{});
     const GeomTopo t = geom_topo();
     const double* P = points.data();
+    const int nthr = host_threads();
+#pragma omp parallel for schedule(static) num_threads(nthr)
     for (int f = 0; f < nF; f++) geom_face(f, t, P, fg[f]);
+    long long bad = 0;
+#pragma omp parallel for schedule(static) num_threads(nthr) reduction(+ : bad)
     for (int c = 0; c < nC; c++) {
         const bool ok = geom_cell(c, t, fg.data(), cg[c]);
         cg[c].y = y_wall ? y_wall[c] : 1.0;
-        DAS_CHECK(ok, DAS_ERR_ARG, "non-positive cell volume");
+        if (!ok) bad++;
     }
+    DAS_CHECK(bad == 0, DAS_ERR_ARG, "non-positive cell volume");
+#pragma omp parallel for schedule(static) num_threads(nthr)
     for (int f = 0; f < nF; f++) geom_weights(f, t, cg.data(), fg.data(), fg[f]);
+}
+
+// fvMesh metrics of a bare polyhedral mesh (no case, no solver handle): what the synthetic-input generators need (face area vectors and
+// centres, cell centres and volumes, interpolation weights) - the per-entity bodies of das_geom.hpp over all host threads
+void mesh_metrics_only(int nP, const double* pts, int nF, int nIF, int nC, const int* fptr, const int* fpts, const int* own, const int* nei,
+                       double* Sf, double* Cf, double* C, double* V, double* w) {
+    Mesh m;
+    m.nP = nP; m.nF = nF; m.nIF = nIF; m.nC = nC; m.nPatch = 0;
+    m.points.assign(pts, pts + 3LL * nP);
+    m.face_ptr.assign(fptr, fptr + nF + 1);
+    m.face_pts.assign(fpts, fpts + fptr[nF]);
+    m.owner.assign(own, own + nF);
+    m.neighbour.assign(nei, nei + nIF);
+    m.bface_patch.assign(nF - nIF, 0);
+    m.cyc_face.assign(nF - nIF, -1);
+    m.bc.assign(1, PatchBC{});
+    m.build_addressing();
+    m.compute_geometry(nullptr);
+    const int nthr = host_threads();
+#pragma omp parallel for schedule(static) num_threads(nthr)
+    for (int f = 0; f < nF; f++) {
+        for (int k = 0; k < 3; k++) { Sf[3LL * f + k] = m.fg[f].Sf[k]; Cf[3LL * f + k] = m.fg[f].Cf[k]; }
+        if (f < nIF && w) w[f] = m.fg[f].w;
+    }
+#pragma omp parallel for schedule(static) num_threads(nthr)
+    for (int c = 0; c < nC; c++) { for (int k = 0; k < 3; k++) C[3LL * c + k] = m.cg[c].C[k]; V[c] = m.cg[c].V; }
 }
 
 void Mesh::build_addressing() {

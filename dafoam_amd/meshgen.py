@@ -17,6 +17,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional
 
+import os
+
 import numpy as np
 
 # boundary-condition type codes shared with the C-ABI (include/dafoam_amd.h)
@@ -249,6 +251,8 @@ class _InputGeometry:
     in oracle/foam_mesh.py - neither is imported here."""
 
     def __init__(self, mesh: PolyMesh):
+        if mesh.n_faces >= 1_000_000 and not os.environ.get("DAS_MESHGEN_NUMPY") and self._native(mesh):
+            return
         F = mesh.n_faces
         nv = np.diff(mesh.face_ptr)
         assert np.all(nv == nv[0]), "input generator handles uniform polygons"
@@ -292,6 +296,33 @@ class _InputGeometry:
         so = np.abs(np.einsum("ij,ij->i", self.Sf[:nIF], self.Cf[:nIF] - self.C[own[:nIF]]))
         sn = np.abs(np.einsum("ij,ij->i", self.Sf[:nIF], self.C[nei] - self.Cf[:nIF]))
         self.w = sn / (so + sn)
+
+
+def _native_metrics(self, mesh: PolyMesh) -> bool:
+    """Bench sizes (>= 1 M faces): the library's host geometry bodies over all threads (das_mesh_metrics) instead of the numpy fan sums
+    below - 30 s -> ~2 s at 2 M cells (bench hygiene).  Same formulas (fvMesh metrics), different summation order; the
+    small meshes of the tests always take the numpy path.  False if the library is not built."""
+    try:
+        import ctypes as C
+
+        from . import _capi
+
+        L = _capi.lib()
+    except Exception:
+        return False
+    F, N, nIF = mesh.n_faces, mesh.n_cells, mesh.n_internal_faces
+    pts = np.ascontiguousarray(mesh.points, dtype=np.float64)
+    fptr, fpts = np.ascontiguousarray(mesh.face_ptr, dtype=np.int32), np.ascontiguousarray(mesh.face_pts, dtype=np.int32)
+    own, nei = np.ascontiguousarray(mesh.owner, dtype=np.int32), np.ascontiguousarray(mesh.neighbour, dtype=np.int32)
+    self.Sf, self.Cf, self.C, self.V, self.w = np.empty((F, 3)), np.empty((F, 3)), np.empty((N, 3)), np.empty(N), np.empty(nIF)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    rc = L.das_mesh_metrics(pts.shape[0], pts.ctypes.data_as(dp), F, nIF, N, fptr.ctypes.data_as(ip), fpts.ctypes.data_as(ip), own.ctypes.data_as(ip),
+                            nei.ctypes.data_as(ip), self.Sf.ctypes.data_as(dp), self.Cf.ctypes.data_as(dp), self.C.ctypes.data_as(dp), self.V.ctypes.data_as(dp),
+                            self.w.ctypes.data_as(dp))
+    return rc == 0
+
+
+_InputGeometry._native = _native_metrics
 
 
 def wall_distance(mesh: PolyMesh, cell_centres, face_centres, face_areas) -> np.ndarray:
@@ -876,14 +907,18 @@ def naca_normal_distribution(ny, first_cell=2.0e-5, radius=20.0):
 
 
 def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first_cell=2.0e-5, U0=10.0, aoa_deg=2.0, nu=1.5e-5, nuTilda0=4.5e-5,
-                  wall_function=False, seed=0, perturb=0.02, y_wall_section=None) -> FoamCase:
+                  wall_function=False, seed=0, perturb=0.02, y_wall_section=None, sweep_deg=0.0, taper=0.0) -> FoamCase:
     """DASimpleFoam + SA around a NACA0012 (chord 1) on a single-block O-grid of n_around x n_normal x nz hexahedra, extruded
     `span` in z with symmetry front/back (the reference's 2-D airfoil cases use one cell and `empty`/symmetry sides,
     tests/runRegTests_AeroOpt.py).  Wall-normal geometric stretching from `first_cell` (y+ ~ 1 at Re 6.7e5) to the far
     field at `radius` chords.  The branch cut behind the trailing edge is an ORDINARY set of internal faces (points merged),
     so the mesh needs no coupled patches.  Patches: airfoil (wall), farfield (patch: U / nuTilda inletOutlet about the
     free stream at `aoa_deg`, p fixedValue), front / back (symmetry).  States: a smooth synthetic boundary-layer-like flow
-    (seeded perturbation) - the adjoint operator's conditioning does not depend on primal convergence."""
+    (seeded perturbation) - the adjoint operator's conditioning does not depend on primal convergence.
+    `sweep_deg` / `taper` (round 6; BASELINE.md config 3 names a swept-wing O-grid): a genuinely three-dimensional wing segment - layer k
+    is the section scaled about the quarter chord to the chord 1 - taper z_k / span and shifted downstream by z_k tan(sweep); the
+    transformation fades out with the distance from the wall (half at 3 chords), the far field and the two end planes stay where they
+    are.  The spanwise copies of the section are then no longer identical: no degenerate spanwise modes."""
     nx, ny = int(n_around), int(n_normal)
     d = naca_normal_distribution(ny, first_cell, radius)             # distance from the wall, d[0] = 0, d[ny] = radius
     sblend = d / d[-1]
@@ -914,10 +949,20 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
         return (np.asarray(i) % nx) + nx * (np.asarray(j) + ny * np.asarray(k))
 
     points = np.zeros((nx * (ny + 1) * (nz + 1), 3))
+    swept = (sweep_deg != 0.0) or (taper != 0.0)
+    wfade = 1.0 / (1.0 + (sblend * radius / 3.0) ** 2)                # per ring of points: 1 at the wall, 1/2 at ~3 chords ...
+    wfade = (wfade - wfade[-1]) / (1.0 - wfade[-1])                   # ... exactly 0 on the far-field ring
+    tan_sw = np.tan(np.deg2rad(sweep_deg))
     for k in range(nz + 1):
         base = nx * (ny + 1) * k
-        points[base : base + nx * (ny + 1), 0] = pts2[:, :, 0].ravel()
-        points[base : base + nx * (ny + 1), 1] = pts2[:, :, 1].ravel()
+        px, py = pts2[:, :, 0], pts2[:, :, 1]
+        if swept:
+            cr = 1.0 - taper * zs[k] / max(span, 1e-300)
+            sc = 1.0 + (cr - 1.0) * wfade[:, None]
+            px = 0.25 + (px - 0.25) * sc + zs[k] * tan_sw * wfade[:, None]
+            py = py * sc
+        points[base : base + nx * (ny + 1), 0] = px.ravel()
+        points[base : base + nx * (ny + 1), 1] = py.ravel()
         points[base : base + nx * (ny + 1), 2] = zs[k]
     I, Jc, K = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
     I, Jc, K = I.ravel(), Jc.ravel(), K.ravel()
@@ -974,6 +1019,10 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
     if y_wall_section is not None:
         assert len(y_wall_section) == nx * ny
         y = np.tile(np.asarray(y_wall_section, dtype=float), nz)
+        if swept:  # the near field of layer k is the section scaled by its chord: so is the distance to the wall (frozen input of the SA model)
+            zc = 0.5 * (zs[:-1] + zs[1:])
+            wc = 0.5 * (wfade[:-1] + wfade[1:])
+            y = (y.reshape(nz, ny, nx) * (1.0 + (-taper * zc / max(span, 1e-300))[:, None, None] * wc[None, :, None])).ravel()
     else:
         y = wall_distance_exact(mesh, g.C, g.Cf, g.Sf)
     a = np.deg2rad(aoa_deg)

@@ -208,7 +208,9 @@ class KSP:
         ip = _capi.c_int_p
         check(L.das_ksp_get_pc_structure(self.handle, nu.ctypes.data_as(ip), bptr.ctypes.data_as(_capi.c_ll_p), bcol.ctypes.data_as(ip),
                                          lvl.ctypes.data_as(ip), nat.ctypes.data_as(ip)))
-        return dict(nodeUnk=nu.reshape(-1, 8), bptr=bptr, bcol=bcol, lvlPtr=lvl, natural=nat)
+        out = np.empty(nN.value * 8, np.int32)
+        check(L.das_ksp_get_pc_node_out(self.handle, out.ctypes.data_as(ip)))
+        return dict(nodeUnk=nu.reshape(-1, 8), bptr=bptr, bcol=bcol, lvlPtr=lvl, natural=nat, nodeOut=out.reshape(-1, 8))
 
     def coarse(self, n_cells):
         """(nAgg, aggOfCell) of the two-level preconditioner's pressure coarse space (nAgg = 0: none)."""

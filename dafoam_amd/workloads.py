@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-from .meshgen import extrude_naca_state, naca0012_case, prolong_naca_state
+from .meshgen import extrude_naca_state, naca0012_case, naca_fluxes_from_velocity, prolong_naca_state
 
 # COLD start (coarsest level, free stream + boundary-layer guess): CFL ramp, pseudo-time term on the transport rows only - with the term on
 # the pressure rows the pseudo-time evolution itself is unstable there (round 4, CPU twin with exact Jacobians: blow-up beyond tau ~ 3)
@@ -77,6 +77,13 @@ def naca_extruded_case(case2d, dims2d, nz, dz=0.1, first_cell=2.0e-5, options=No
     t0 = time.time()
     case3 = naca0012_case(nx, ny, nz, span=dz * nz, first_cell=first_cell, y_wall_section=case2d.y_wall, **ckw)
     case3.states = extrude_naca_state(case2d, case2d.states, case3, (nx, ny, nz))
+    if ckw.get("sweep_deg", 0.0) or ckw.get("taper", 0.0):
+        # swept / tapered segment: the layers are no longer copies of the section - cell fields start from the section's, the face fluxes
+        # from the interpolated velocities on the real faces; the Newton steps below then have real work to do
+        N3 = case3.mesh.n_cells
+        W3 = np.asarray(case3.states).copy()
+        W3[5 * N3 :] = naca_fluxes_from_velocity(case3, W3[: 3 * N3].reshape(N3, 3))
+        case3.states = W3
     info = dict(dims=(nx, ny, nz), steps=0, seconds=0.0)
     if polish_steps > 0:
         opts = dict(options or {})

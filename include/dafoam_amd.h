@@ -175,6 +175,11 @@ int das_get_geometry(das_solver_t* s, double* Sf /*3F*/, double* Cf /*3F*/, doub
                      double* weights /*Fi*/, double* nonOrthDeltaCoeffs /*Fi*/, double* nonOrthCorr /*3Fi*/,
                      double* bDeltaCoeffs /*Fb*/);
 
+/* fvMesh metrics of a bare polyhedral mesh (no case, no solver handle, no GPU): Sf / Cf per face, C / V per cell, linear interpolation
+ * weights per internal face (may be NULL) - the synthetic-input generators of the bench use it at 2 M cells (numpy: 30 s) */
+int das_mesh_metrics(int nPoints, const double* points, int nFaces, int nInternalFaces, int nCells, const int* facePtr, const int* facePts, const int* owner,
+                     const int* neighbour, double* Sf /*3F*/, double* Cf /*3F*/, double* C /*3N*/, double* V /*N*/, double* weights /*Fi*/);
+
 /* ---- state / residual access -------------------------------------------------------------
  * das_update_of_fields <- updateOFFields(states)   pyDASolvers.pyx:268   (DAField::stateVec2OFField)
  * das_get_of_fields    <- getOFFields(states)      pyDASolvers.pyx:273
@@ -332,6 +337,8 @@ int das_pc_structure_build(das_solver_t* s, int* nNodes, long long* nBlocks, int
 int das_pc_structure_get(das_solver_t* s, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural);
 int das_ksp_get_pc_structure_sizes(das_ksp_t* ksp, int* nNodes, long long* nBlocks, int* nLevels);
 int das_ksp_get_pc_structure(das_ksp_t* ksp, int* nodeUnk, long long* bptr, int* bcol, int* lvlPtr, int* natural);
+/* nodeOut[nNodes * 8]: the unknown every slot WRITES: nodeUnk, or -1 for the overlap copies of a multi-block factorisation (amd.pcSubdomains) */
+int das_ksp_get_pc_node_out(das_ksp_t* ksp, int* nodeOut);
 int das_ksp_get_info(das_ksp_t* ksp, int* iters, double* res0, double* res, double* seconds);
 int das_ksp_get_history(das_ksp_t* ksp, double* hist, int cap);
 /* Krylov basis of the last solve (amd.krylovBasisPrecision): *fp32 = bit 0: plain fp32 storage, bit 1: split storage (hi + lo floats, the

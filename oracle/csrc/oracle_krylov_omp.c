@@ -39,6 +39,7 @@ typedef struct {
     /* alternative preconditioner: node-block ILU(0) (dense 8x8 blocks on a node pattern, level order = node order) */
     int has_bilu, nNodes, nLv;
     int* nodeUnk;   /* nNodes x 8, -1 = empty slot */
+    int* nodeOut;   /* nNodes x 8: the unknown a slot writes (multi-block structures: -1 for overlap copies); NULL = nodeUnk */
     ll* bptr; int* bcol; ll* bdiag;
     double* bval;   /* 64 per block: L blocks (row-scaled by the pivot inverse), U blocks */
     double* invD;   /* 64 per node */
@@ -81,8 +82,8 @@ static void free_pc(okry* k) {
     k->has_pc = 0;
 }
 static void free_bilu(okry* k) {
-    free(k->nodeUnk); free(k->bptr); free(k->bcol); free(k->bdiag); free(k->bval); free(k->invD); free(k->lvlPtr); free(k->by); free(k->bx);
-    k->nodeUnk = NULL; k->bptr = NULL; k->bcol = NULL; k->bdiag = NULL; k->bval = NULL; k->invD = NULL; k->lvlPtr = NULL; k->by = k->bx = NULL;
+    free(k->nodeUnk); free(k->nodeOut); free(k->bptr); free(k->bcol); free(k->bdiag); free(k->bval); free(k->invD); free(k->lvlPtr); free(k->by); free(k->bx);
+    k->nodeUnk = NULL; k->nodeOut = NULL; k->bptr = NULL; k->bcol = NULL; k->bdiag = NULL; k->bval = NULL; k->invD = NULL; k->lvlPtr = NULL; k->by = k->bx = NULL;
     k->has_bilu = 0;
 }
 static void free_coarse(okry* k) { free(k->agg); free(k->Einv); free(k->cr); free(k->cz); k->agg = NULL; k->Einv = k->cr = k->cz = NULL; k->has_coarse = 0; }
@@ -315,8 +316,17 @@ static inline void mm8(const double* a, const double* b, double* c) { /* c = a b
             c[i * 8 + j] = s;
         }
 }
+int okry_set_pc_bilu2(okry* k, ll n, const ll* rp, const int* ci, const double* v, int nNodes, const int* nodeUnk, const int* nodeOut, const ll* bptr,
+                      const int* bcol, int nLv, const int* lvlPtr, double shift);
 int okry_set_pc_bilu(okry* k, ll n, const ll* rp, const int* ci, const double* v, int nNodes, const int* nodeUnk, const ll* bptr, const int* bcol,
                      int nLv, const int* lvlPtr, double shift) {
+    return okry_set_pc_bilu2(k, n, rp, ci, v, nNodes, nodeUnk, NULL, bptr, bcol, nLv, lvlPtr, shift);
+}
+/* nodeOut != NULL: a multi-block structure (amd.pcSubdomains of the product): an unknown of an overlap ring sits in one node per block that
+ * reaches it, the node patterns of the blocks are disjoint; a matrix entry (u, v) goes to the block (I, J) of every node I holding u and the
+ * node J holding v INSIDE I's pattern; only the slot with nodeOut == u writes the solution */
+int okry_set_pc_bilu2(okry* k, ll n, const ll* rp, const int* ci, const double* v, int nNodes, const int* nodeUnk, const int* nodeOut, const ll* bptr,
+                      const int* bcol, int nLv, const int* lvlPtr, double shift) {
     free_bilu(k);
     if (k->n && k->n != n) return -2;
     k->n = n;
@@ -331,21 +341,28 @@ int okry_set_pc_bilu(okry* k, ll n, const ll* rp, const int* ci, const double* v
     k->invD = (double*)xmalloc((size_t)nNodes * 64 * 8);
     k->lvlPtr = (int*)malloc((nLv + 1) * sizeof(int));
     k->by = (double*)xmalloc((size_t)nNodes * 8 * 8); k->bx = (double*)xmalloc((size_t)nNodes * 8 * 8);
-    int* unkNode = (int*)xmalloc(n * sizeof(int));
-    unsigned char* unkSlot = (unsigned char*)xmalloc(n);
-    if (!k->nodeUnk || !k->bptr || !k->bcol || !k->bdiag || !k->bval || !k->invD || !k->lvlPtr || !k->by || !k->bx || !unkNode || !unkSlot) return -1;
+    /* slots holding an unknown: chained lists (head per unknown, next per slot) - one entry per unknown, or one per block for overlap unknowns */
+    ll* unkHead = (ll*)xmalloc(n * sizeof(ll));
+    ll* slotNext = (ll*)xmalloc((size_t)nNodes * 8 * sizeof(ll));
+    if (nodeOut) { k->nodeOut = (int*)xmalloc((size_t)nNodes * 8 * sizeof(int)); if (!k->nodeOut) return -1; memcpy(k->nodeOut, nodeOut, (size_t)nNodes * 8 * sizeof(int)); }
+    if (!k->nodeUnk || !k->bptr || !k->bcol || !k->bdiag || !k->bval || !k->invD || !k->lvlPtr || !k->by || !k->bx || !unkHead || !slotNext) return -1;
     memcpy(k->lvlPtr, lvlPtr, (nLv + 1) * sizeof(int));
 #pragma omp parallel for schedule(static) num_threads(nt)
-    for (ll u = 0; u < n; u++) unkNode[u] = -1;
+    for (ll u = 0; u < n; u++) unkHead[u] = -1;
+    for (ll sl = 0; sl < (ll)nNodes * 8; sl++) {
+        const int u = nodeUnk[sl];
+        slotNext[sl] = -1;
+        if (u >= 0) { slotNext[sl] = unkHead[u]; unkHead[u] = sl; }
+    }
 #pragma omp parallel for schedule(static) num_threads(nt)
     for (int I = 0; I < nNodes; I++) {
         k->bptr[I] = bptr[I];
         if (I == nNodes - 1) k->bptr[nNodes] = bptr[nNodes];
-        for (int r = 0; r < 8; r++) { const int u = nodeUnk[(size_t)I * 8 + r]; k->nodeUnk[(size_t)I * 8 + r] = u; if (u >= 0) { unkNode[u] = I; unkSlot[u] = (unsigned char)r; } }
+        for (int r = 0; r < 8; r++) k->nodeUnk[(size_t)I * 8 + r] = nodeUnk[(size_t)I * 8 + r];
         k->bdiag[I] = -1;
         for (ll e = bptr[I]; e < bptr[I + 1]; e++) { k->bcol[e] = bcol[e]; if (bcol[e] == I) k->bdiag[I] = e; memset(k->bval + (size_t)e * 64, 0, 64 * 8); }
     }
-    for (int I = 0; I < nNodes; I++) if (k->bdiag[I] < 0) { free(unkNode); free(unkSlot); return -3; }
+    for (int I = 0; I < nNodes; I++) if (k->bdiag[I] < 0) { free(unkHead); free(slotNext); return -3; }
     /* scatter the scalar entries into the dense blocks (entries outside the node pattern are dropped by construction) */
 #pragma omp parallel for schedule(dynamic, 256) num_threads(nt)
     for (int I = 0; I < nNodes; I++) {
@@ -353,15 +370,16 @@ int okry_set_pc_bilu(okry* k, ll n, const ll* rp, const int* ci, const double* v
             const int u = k->nodeUnk[(size_t)I * 8 + r];
             if (u < 0) { k->bval[(size_t)k->bdiag[I] * 64 + r * 8 + r] = 1.0; continue; }  /* empty slot: identity row */
             for (ll q = rp[u]; q < rp[u + 1]; q++) {
-                const int J = unkNode[ci[q]];
-                if (J < 0) continue;
-                ll lo = k->bptr[I], hi = k->bptr[I + 1] - 1, e = -1;
-                while (lo <= hi) { const ll mid = (lo + hi) >> 1; const int cm = k->bcol[mid]; if (cm == J) { e = mid; break; } if (cm < J) lo = mid + 1; else hi = mid - 1; }
-                if (e >= 0) k->bval[(size_t)e * 64 + r * 8 + unkSlot[ci[q]]] = v[q];
+                for (ll sl = unkHead[ci[q]]; sl >= 0; sl = slotNext[sl]) {  /* the node holding the column unknown inside I's pattern (at most one) */
+                    const int J = (int)(sl >> 3);
+                    ll lo = k->bptr[I], hi = k->bptr[I + 1] - 1, e = -1;
+                    while (lo <= hi) { const ll mid = (lo + hi) >> 1; const int cm = k->bcol[mid]; if (cm == J) { e = mid; break; } if (cm < J) lo = mid + 1; else hi = mid - 1; }
+                    if (e >= 0) { k->bval[(size_t)e * 64 + r * 8 + (int)(sl & 7)] = v[q]; break; }
+                }
             }
         }
     }
-    free(unkNode); free(unkSlot);
+    free(unkHead); free(slotNext);
     /* block IKJ, the nodes of one level in parallel */
     int nshift = 0;
 #pragma omp parallel num_threads(nt) reduction(+ : nshift)
@@ -429,7 +447,7 @@ static void bilu_apply(okry* k, const double* b, double* x) {
         }
 #pragma omp for schedule(static)
         for (int I = 0; I < nN; I++)
-            for (int r = 0; r < 8; r++) { const int u = k->nodeUnk[(size_t)I * 8 + r]; if (u >= 0) x[u] = z[(size_t)I * 8 + r]; }
+            for (int r = 0; r < 8; r++) { const int u = (k->nodeOut ? k->nodeOut : k->nodeUnk)[(size_t)I * 8 + r]; if (u >= 0) x[u] = z[(size_t)I * 8 + r]; }
     }
 }
 ll okry_bilu_blocks(const okry* k) { return k->has_bilu ? k->bptr[k->nNodes] : 0; }

@@ -61,6 +61,7 @@ def lib_omp():
         L.okry_spmv.argtypes = [vp, _dp, _dp]
         L.okry_set_pc_ilu0.argtypes = [vp, C.c_longlong, _lp, _ip, _dp, _ip, C.c_double]
         L.okry_set_pc_bilu.argtypes = [vp, C.c_longlong, _lp, _ip, _dp, C.c_int, _ip, _lp, _ip, C.c_int, _ip, C.c_double]
+        L.okry_set_pc_bilu2.argtypes = [vp, C.c_longlong, _lp, _ip, _dp, C.c_int, _ip, _ip, _lp, _ip, C.c_int, _ip, C.c_double]
         L.okry_bilu_blocks.restype = C.c_longlong
         L.okry_bilu_blocks.argtypes = [vp]
         L.okry_pc_levels.argtypes = [vp, _ip, _ip]
@@ -160,8 +161,15 @@ class OmpKrylov:
         bptr = np.ascontiguousarray(structure["bptr"], dtype=np.int64)
         bcol = np.ascontiguousarray(structure["bcol"], dtype=np.int32)
         lvl = np.ascontiguousarray(structure["lvlPtr"], dtype=np.int32)
-        rc = self.L.okry_set_pc_bilu(self.h, self.n, _p(rp, _lp), _p(ci, _ip), _p(v, _dp), nu.shape[0], _p(nu, _ip), _p(bptr, _lp), _p(bcol, _ip),
-                                     lvl.size - 1, _p(lvl, _ip), float(shift))
+        nout = structure.get("nodeOut") if hasattr(structure, "get") else None
+        if nout is not None and not np.array_equal(np.asarray(nout).reshape(-1, 8), nu):
+            # multi-block structure (amd.pcSubdomains of the product): overlap unknowns sit in one node per block, only the owner's copy writes
+            nout = np.ascontiguousarray(nout, dtype=np.int32).reshape(-1, 8)
+            rc = self.L.okry_set_pc_bilu2(self.h, self.n, _p(rp, _lp), _p(ci, _ip), _p(v, _dp), nu.shape[0], _p(nu, _ip), _p(nout, _ip), _p(bptr, _lp), _p(bcol, _ip),
+                                          lvl.size - 1, _p(lvl, _ip), float(shift))
+        else:
+            rc = self.L.okry_set_pc_bilu(self.h, self.n, _p(rp, _lp), _p(ci, _ip), _p(v, _dp), nu.shape[0], _p(nu, _ip), _p(bptr, _lp), _p(bcol, _ip),
+                                         lvl.size - 1, _p(lvl, _ip), float(shift))
         assert rc >= 0, rc
         self.levels = (lvl.size - 1, lvl.size - 1)
         self.nshift = rc

@@ -640,9 +640,34 @@ def test_adjoint_with_subdomain_ilus_and_order_fallback_reaches_the_same_psi(var
     est, used = C.c_double(-1.0), C.c_int(-1)
     _capi.check(_capi.lib().das_ksp_get_pc_stability(D.ksp.handle, C.byref(est), C.byref(used)))
     assert est.value > 0.0 and 0 <= used.value <= 7
-    # twice: the sub-domain streams / tickets re-arm
+    # twice: the tickets re-arm
     psi2, fail2 = D.solveAdjoint(rhs)
     assert fail2 == 0 and relerr(psi2, psi_o) <= 1e-6
+    if variant == "subdomains":
+        # the merged multi-block factorisation against the oracle's host restatement of the same structure: an overlap unknown sits in one
+        # node per block (all read the right-hand side), only the owner block's copy (nodeOut) writes
+        K, ests = (C.c_int * 16)(), (C.c_double * 16)()
+        assert _capi.lib().das_ksp_get_pc_subdomains(D.ksp.handle, K, ests) == 3
+        S = D.ksp.pcStructure()
+        nu, nout = S["nodeUnk"], S["nodeOut"]
+        n = psi_o.size
+        cnt = np.bincount(nu[nu >= 0], minlength=n)
+        assert cnt.min() == 1 and cnt.max() >= 2                          # overlap rings: some unknowns in several nodes ...
+        assert np.array_equal(np.sort(nout[nout >= 0]), np.arange(n))     # ... every unknown written exactly once
+        assert np.all((nout == nu) | (nout == -1))
+        Kh = OL.OmpKrylov(4)
+        x = np.random.default_rng(1).standard_normal(n)
+        D2 = make(case, amd=dict(amd, pcCoarseAggregates=0), adjEqnOption={"printInfo": 0})
+        D2.solver.runColoring()
+        from dafoam_amd.pyDASolvers import KSP, Mat
+        pc2 = Mat()
+        D2.solver.calcdRdWT(1, pc2)
+        k2 = KSP()
+        D2.solverAD.createMLRKSPMatrixFree(pc2, k2)
+        S2 = k2.pcStructure()
+        P2 = pc2.to_scipy().tocsr()
+        Kh.set_pc_bilu((P2.indptr.astype(np.int64), P2.indices.astype(np.int32), P2.data), S2)
+        assert relerr(k2.applyPC(D2.solver, x), Kh.pc_solve(x)) < 1e-9
 
 
 @pytest.mark.parametrize("nrhs", [2, 3, 8])

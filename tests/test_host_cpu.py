@@ -200,6 +200,35 @@ def test_face_cell_split_of_the_cell_pass_equals_the_monolith_and_the_oracle():
         E.emu_set_cell_split(0)
 
 
+def test_native_mesh_metrics_equal_the_numpy_input_geometry_and_the_swept_wing_is_a_valid_mesh():
+    """Round 6: (a) das_mesh_metrics - the library's host geometry bodies for a bare mesh, what the input generators use from 1 M faces on -
+    against the generators' numpy fan sums; (b) the swept / tapered wing segment of bench.py --naca-sweep / --naca-taper: positive volumes,
+    owner -> neighbour face normals, the far field and the end planes where the unswept mesh has them, every layer its own chord."""
+    from dafoam_amd.meshgen import _InputGeometry, naca0012_case
+
+    for case in (channel_case(6, 5, 4), naca0012_case(24, 8, 3, span=0.3, first_cell=1e-3)):
+        g = _InputGeometry(case.mesh)
+        h = _InputGeometry.__new__(_InputGeometry)
+        assert h._native(case.mesh)
+        for nm, tol in (("Sf", 1e-13), ("Cf", 1e-13), ("C", 1e-12), ("V", 1e-12), ("w", 1e-9)):
+            a, b = getattr(h, nm), getattr(g, nm)
+            assert np.abs(a - b).max() <= tol * np.abs(b).max(), nm
+    c0 = naca0012_case(40, 12, 6, span=1.2, first_cell=1e-3, perturb=0.0)
+    c1 = naca0012_case(40, 12, 6, span=1.2, first_cell=1e-3, perturb=0.0, sweep_deg=25.0, taper=0.3)
+    g1 = _InputGeometry(c1.mesh)
+    nIF = c1.mesh.n_internal_faces
+    assert np.all(g1.V > 0) and np.all(np.einsum("ij,ij->i", g1.Sf[:nIF], g1.C[c1.mesh.neighbour] - g1.C[c1.mesh.owner[:nIF]]) > 0)
+    p0, p1 = c0.mesh.points, c1.mesh.points
+    assert np.array_equal(p0[:, 2], p1[:, 2])                                         # the layers stay planes of constant z
+    first = p0[:, 2] == 0.0
+    assert np.allclose(p0[first], p1[first])                                           # the root section is the unswept one
+    far = np.hypot(p0[:, 0] - 0.5, p0[:, 1]) > 19.0
+    assert np.abs(p1[far] - p0[far]).max() < 0.05                                       # the far field (20 chords) hardly moves
+    tip = slice(40 * 13 * 6, 40 * 13 * 6 + 40)                                          # the wall ring of the last layer of points
+    chord_tip = p1[tip, 0].max() - p1[tip, 0].min()
+    assert abs(chord_tip - 0.7) < 0.01 and abs(p1[tip, 0].min() - (0.25 - 0.25 * 0.7 + 1.2 * np.tan(np.deg2rad(25.0)))) < 0.01  # chord 0.7 about the swept quarter-chord line
+
+
 def test_kernel_bodies_match_oracle_scalar_transport():
     case = scalar_transport_case(8, 7, 6)
     g = Geometry(case.mesh)
