@@ -90,7 +90,7 @@ def parse():
     ap.add_argument("--orth", default=os.environ.get("DAS_BENCH_ORTH", "dcgs2"), help="dcgs2 (delayed re-orthogonalisation, 2 basis reads / iteration) | cgs (reference: refine if needed)")
     ap.add_argument("--naca-sweep", type=float, default=0.0, help="naca: sweep angle in degrees (round 6: a genuinely 3-D wing segment - every layer its own section; with --naca-taper)")
     ap.add_argument("--naca-taper", type=float, default=0.0, help="naca: fraction of the chord lost from the first to the last layer (0.3: tip chord 0.7)")
-    ap.add_argument("--naca-polish-steps", type=int, default=None, help="naca: Newton steps on the 3-D mesh (default 3 for the extruded section, 40 for a swept / tapered segment)")
+    ap.add_argument("--naca-polish-steps", type=int, default=None, help="naca: Newton steps on the 3-D mesh (default 3 for the extruded section, at most 60 for a swept / tapered segment)")
     ap.add_argument("--naca-partition", default="columns", choices=["columns", "span", "around"],
                     help="naca, N > 1: 'columns' (default) = blocks in the (around, wall-normal) index plane, every rank keeps whole spanwise columns of cells - the cut "
                          "never crosses the strong spanwise coupling of the thin layers; 'around' = sectors around the airfoil; 'span' = spanwise slabs of whole layers")
@@ -150,6 +150,8 @@ def compressible_channel(a, nx):
     from dafoam_amd.meshgen import rho_channel_case, turbo_channel_case
 
     kw = dict(lengths=(2.0, 0.2, 0.2), grading_y=2.0)
+    if getattr(a, "converge_primal", False):
+        kw["perturb"] = 0.0  # a primal solve starts from the smooth guess, not from the seeded noise of the rate-only runs
     return rho_channel_case(nx, a.ny, a.nz, **kw) if a.solver == "DARhoSimpleFoam" else turbo_channel_case(nx, a.ny, a.nz, **kw)
 
 
@@ -194,10 +196,10 @@ def _wing3d_kwargs(a):
     kw = {}
     if swept:
         kw["case_kwargs"] = {"sweep_deg": float(a.naca_sweep), "taper": float(a.naca_taper)}
-    steps = a.naca_polish_steps if a.naca_polish_steps is not None else (40 if swept else 3)
+    steps = a.naca_polish_steps if a.naca_polish_steps is not None else (60 if swept else 3)
     kw["polish_steps"] = int(steps)
     if swept:
-        kw["polish_tol"] = 1e-5
+        kw["polish_tol"] = 1e-10  # relative to the residual of the section's state on the deformed mesh (1e5): the extruded wing's level, 1e-5
     return kw
 
 

@@ -2209,7 +2209,10 @@ static void choose_order_and_factorise(das_solver* s, das_ksp* k, NodeILU& F, co
         if (s->opt.geti("debug") || getenv("DAS_PC_STAB") || (est > limit && !pickMin))
             fprintf(stderr, "[dafoam_amd] rank %s: preconditioner stability estimate max|(LU)^-1 P e - e| = %.3e with elimination order %d, %d levels (limit %.1e)%s\n",
                     getenv("RANK") ? getenv("RANK") : "0", est, o, F.nLevels, limit, (est > limit && !pickMin) ? ": unstable, trying another order" : "");
-        if (est <= limit && (!pickMin || est <= good)) break;
+        // (a DEEP order is never accepted early: levels >> nodes^(1/3) - e.g. reverse Cuthill-McKee of a thin far-field block, 23755 levels
+        //  for 270 k nodes where ~500 are normal)
+        const bool deep = (double)F.nLevels > 30.0 * std::cbrt((double)std::max(1, F.nNodes));
+        if (est <= limit && (!pickMin || (est <= good && !deep))) break;
     }
     bool anyOk = false;
     for (const Cand& c : seen) anyOk = anyOk || c.est <= limit;
