@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--naca-sweep", type=float, default=0.0, help="naca: sweep angle in degrees (round 6: a genuinely 3-D wing segment - every layer its own section; with --naca-taper)")
     ap.add_argument("--naca-taper", type=float, default=0.0, help="naca: fraction of the chord lost from the first to the last layer (0.3: tip chord 0.7)")
     ap.add_argument("--naca-polish-steps", type=int, default=None, help="naca: Newton steps on the 3-D mesh (default 3 for the extruded section, at most 60 for a swept / tapered segment)")
+    ap.add_argument("--naca-state-cache", default=None, metavar="FILE.npy", help="naca: load the converged 3-D state from this file if it exists (same mesh arguments!), else converge and save it - "
+                    "repeated experiments on one box skip the primal")
     ap.add_argument("--naca-partition", default="columns", choices=["columns", "span", "around"],
                     help="naca, N > 1: 'columns' (default) = blocks in the (around, wall-normal) index plane, every rank keeps whole spanwise columns of cells - the cut "
                          "never crosses the strong spanwise coupling of the thin layers; 'around' = sectors around the airfoil; 'span' = spanwise slabs of whole layers")
@@ -334,9 +336,17 @@ def main():
             t0 = time.time()
             case2d, lv = naca_converged_primal(a.naca[0], a.naca[1], options=opts, first_cell=a.naca_first_cell, verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")))
             t2d = time.time() - t0
-            if a.naca[2] > 1:
+            if a.naca[2] > 1 and a.naca_state_cache and os.path.exists(a.naca_state_cache):
+                kw3 = _wing3d_kwargs(a)
+                kw3["polish_steps"] = 0
+                case, ex = naca_extruded_case(case2d, (a.naca[0], a.naca[1]), a.naca[2], dz=a.naca_dz, first_cell=a.naca_first_cell, options=opts, **kw3)
+                case.states = np.load(a.naca_state_cache)
+                ex["loaded_from"] = a.naca_state_cache
+            elif a.naca[2] > 1:
                 case, ex = naca_extruded_case(case2d, (a.naca[0], a.naca[1]), a.naca[2], dz=a.naca_dz, first_cell=a.naca_first_cell, options=opts,
                                               verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")), **_wing3d_kwargs(a))
+                if a.naca_state_cache:
+                    np.save(a.naca_state_cache, np.asarray(case.states))
             else:
                 case, ex = case2d, None
             primal = {"method": "pseudo-transient Newton-Krylov (das_solve_primal), grid sequencing on the one-layer O-grid, spanwise extrusion, Newton polish",

@@ -203,6 +203,7 @@ _SIGS = {
     "das_get_residuals": (C.c_int, [_VP, c_double_p]),
     "das_calc_residuals": (C.c_int, [_VP, C.c_int, c_double_p]),
     "das_solve_primal": (C.c_int, [_VP, C.c_int, C.c_double, C.c_double, c_double_p, c_double_p, C.c_int]),
+    "das_simple_iteration": (C.c_int, [_VP, C.c_int, C.c_double, C.c_double, C.c_int, c_double_p]),
     "das_run_coloring": (C.c_int, [_VP]),
     "das_update_of_mesh": (C.c_int, [_VP, c_double_p]),
     "das_get_of_mesh_points": (C.c_int, [_VP, c_double_p]),

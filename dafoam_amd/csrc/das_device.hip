@@ -25,6 +25,7 @@
 #include "das_opmat.hpp"
 #include "das_graph.hpp"
 #include "das_volcoord.hpp"
+#include "das_simple.hpp"
 
 #include <omp.h>
 
@@ -2247,7 +2248,7 @@ static long long pc_subdomain_count(das_solver* s) {
 // of sweeps runs the K blocks together - max(levels) dependent hops, every level K times as wide - and only the owner block's copy of an
 // overlap unknown writes the result.  (First version, K sweep pairs on K streams + a combine pass: 8.3 ms per apply at 2 M cells against
 // 6.4 ms for the single factorisation - profiles/r07m_*, r07n_*.)
-static void setup_subdomain_ilus(das_solver* s, das_ksp* k, int K) {
+static bool setup_subdomain_ilus(das_solver* s, das_ksp* k, int K) {
     const double t0 = wall_seconds();
     const Mesh& m = s->mesh;
     const long long N = m.nC, n = s->n;
@@ -2308,6 +2309,15 @@ static void setup_subdomain_ilus(das_solver* s, das_ksp* k, int K) {
         if (k->subOrder[b] < 0) k->subOrder[b] = k->pcOrder >= 0 ? k->pcOrder : (pc_ordering_rcm(s) ? 1 : 0);
         if (s->opt.geti("debug") || getenv("DAS_PC_STAB"))
             fprintf(stderr, "[dafoam_amd] sub-domain %d of %d: %d nodes, %d levels, elimination order %d, stability estimate %.3e\n", b, K, F.nNodes, F.nLevels, k->subOrder[b], k->subEst[b]);
+        // a block whose best order is still DEEP (levels >> nodes^(1/3): coordinate-bisection blocks that cut the grid lines of a swept wing
+        // diagonally - round 6: 2489 ... 16618 levels for 540 k nodes, 13.9 ms per apply and more iterations than the single factorisation)
+        // makes the merged structure slow: the caller falls back to ONE factorisation
+        if ((double)F.nLevels > 30.0 * std::cbrt((double)std::max(1, F.nNodes)) && s->opt.geti("amd.pcSubdomains") < 0) {
+            fprintf(stderr, "[dafoam_amd] sub-domain %d of %d needs %d dependency levels for %d nodes: the blocks do not suit this mesh, one factorisation instead "
+                            "(amd.pcSubdomains K > 1 forces the blocks)\n", b, K, F.nLevels, F.nNodes);
+            k->subOrder.clear(); k->subEst.clear();
+            return false;
+        }
     }
     // ---- ONE merged level structure for the K blocks
     {
@@ -2334,6 +2344,7 @@ static void setup_subdomain_ilus(das_solver* s, das_ksp* k, int K) {
     k->pc.next = (long long)k->bilu.nNodes * BILU_NB;
     if (s->opt.geti("debug") || getenv("DAS_PC_STAB"))
         fprintf(stderr, "[dafoam_amd] %d sub-domains merged: %d nodes, %d levels (%.0f nodes per level)\n", K, k->bilu.nNodes, k->bilu.nLevels, (double)k->bilu.nNodes / std::max(1, k->bilu.nLevels));
+    return true;
 }
 
 // E = Z^T P Z and its dense inverse for a coarse space of naggG aggregates of which [aggOff, aggOff + C.nagg) are this rank's;
@@ -4111,6 +4122,261 @@ int das_calc_residuals(das_solver_t* s, int isPC, double* residuals) {
 }
 int das_get_residuals(das_solver_t* s, double* residuals) { return das_calc_residuals(s, 0, residuals); }
 
+// =====================================================================================================
+// SIMPLE sweeps on the device (das_simple.hpp; reference DASimpleFoam.C:123-185, UEqnSimple.H, pEqnSimple.H, DASpalartAllmaras.C:386-405)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_simple_ueqn(DevMesh m, ResParams prm, const double* __restrict__ W, const double* gP, const double* fc, const double* brec, double* D,
+                                                     double* bd, double* sb, double* rhs) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m.nC) body_simple_ueqn(c, m, prm, W, gP, fc, brec, D, bd, sb, rhs);
+}
+__global__ __launch_bounds__(256) void k_simple_offdiag(DevMesh m, ResParams prm, const double* __restrict__ W, const double* fc, int cdIdx, double* up, double* lo) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < m.nIF) body_simple_offdiag(f, m, prm, W, fc, cdIdx, up, lo);
+}
+__global__ __launch_bounds__(256) void k_ldu_mv(DevMesh m, const double* __restrict__ diag, const double* __restrict__ up, const double* __restrict__ lo,
+                                                const double* __restrict__ x, double* __restrict__ y, double sign) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m.nC) y[c] = sign * body_ldu_row(c, m, diag, up, lo, x);
+}
+__global__ __launch_bounds__(256) void k_simple_hbya(DevMesh m, const double* __restrict__ Us, const double* D, const double* bd, const double* sb, const double* up,
+                                                     const double* lo, double* rAU, double* HbyA) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m.nC) body_simple_hbya(c, m, Us, D, bd, sb, up, lo, rAU, HbyA);
+}
+__global__ __launch_bounds__(256) void k_simple_pface(DevMesh m, ResParams prm, const double* __restrict__ Wn, const double* nut, const double* rAU, const double* HbyA,
+                                                      double* phiH, double* gpf, double* cp, double* pbc) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < m.nF) body_simple_pface(f, m, prm, Wn, nut, rAU, HbyA, phiH, gpf, cp, pbc);
+}
+__global__ __launch_bounds__(256) void k_simple_peqn(DevMesh m, const double* phiH, const double* gpf, const double* cp, const double* pbc, const double* gradP, double* dp,
+                                                     double* rhs) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m.nC) body_simple_peqn(c, m, phiH, gpf, cp, pbc, gradP, dp, rhs);
+}
+__global__ __launch_bounds__(256) void k_simple_gradp(DevMesh m, const double* __restrict__ pcell, const double* pbc, double* gradP) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m.nC) body_simple_gradp(c, m, pcell, pbc, gradP);
+}
+__global__ __launch_bounds__(256) void k_simple_flux(DevMesh m, const double* __restrict__ pn, const double* gradP, const double* phiH, const double* gpf, const double* cp,
+                                                     const double* pbc, double* phiOut) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < m.nF) body_simple_flux(f, m, pn, gradP, phiH, gpf, cp, pbc, phiOut);
+}
+__global__ __launch_bounds__(256) void k_simple_saeqn(DevMesh m, ResParams prm, const double* __restrict__ W, const double* gU, const double* gN, const double* fc,
+                                                      const double* brec, double* diag, double* rhs) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < m.nC) body_simple_saeqn(c, m, prm, W, gU, gN, fc, brec, diag, rhs);
+}
+// U = HbyA - rAU grad(p), p <- relaxed pressure, both written into the state vector Wn
+__global__ __launch_bounds__(256) void k_simple_correct(long long N, int offP, const double* __restrict__ HbyA, const double* rAU, const double* gradP, const double* pRel,
+                                                        double* Wn) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    for (int k = 0; k < 3; k++) Wn[3 * c + k] = HbyA[3 * c + k] - rAU[c] * gradP[3 * c + k];
+    Wn[offP * N + c] = pRel[c];
+}
+// small vector kernels of the inner Krylov solvers (host scalars; the sweeps are the reference's primal, not the fast path)
+__global__ __launch_bounds__(256) void k_sv_dot(long long n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ part) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += a[i] * b[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(256) void k_sv_lin(long long n, double* y, double a, const double* x, double b, const double* z) {  // y = a x + b z
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a * x[i] + b * z[i];
+}
+__global__ __launch_bounds__(256) void k_sv_bicg_p(long long n, double* p, const double* r, double beta, double om, const double* v) {  // p = r + beta (p - om v)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = r[i] + beta * (p[i] - om * v[i]);
+}
+__global__ __launch_bounds__(256) void k_sv_divdiag(long long n, double* out, const double* in, const double* diag, double sign) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] / (sign * diag[i]);
+}
+__global__ __launch_bounds__(256) void k_sv_bicg_x(long long n, double* x, double alpha, const double* ph, double om, const double* sh, double* r, const double* s, const double* t) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { x[i] += alpha * ph[i] + om * sh[i]; r[i] = s[i] - om * t[i]; }
+}
+__global__ __launch_bounds__(256) void k_sv_gather3(long long n, const double* W, int k, const double* D, const double* bd, const double* rhs3, double* x, double* dg, double* b) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) { x[c] = W[3 * c + k]; dg[c] = D[c] + bd[3 * c + k]; b[c] = rhs3[3 * c + k]; }
+}
+__global__ __launch_bounds__(256) void k_sv_scatter3(long long n, const double* x, int k, double* W) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) W[3 * c + k] = x[c];
+}
+__global__ __launch_bounds__(256) void k_sv_relax(long long n, double* pn, const double* pold, double alpha) {  // pn = pold + alpha (pn - pold)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pn[i] = pold[i] + alpha * (pn[i] - pold[i]);
+}
+__global__ __launch_bounds__(256) void k_sv_bound(long long n, const double* x, double lo, double* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = x[i] > lo ? x[i] : lo;
+}
+
+struct SimpleWork {
+    DevBuf<double> Wn, D, bd, sb, rhsU, up, lo, rAU, HbyA, phiH, gpf, cp, pbc, dp, rp, x, b, dg, pn, phiN, gPn;
+    DevBuf<double> r, r0, p, v, sv, t, ph, sh, part, red;
+};
+struct LduDev { const double* diag; const double* up; const double* lo; };
+
+static double sv_dot(das_solver* s, SimpleWork& w, long long n, const double* a, const double* b) {
+    const int nb = (int)std::min<long long>(512, (n + 255) / 256);
+    hipLaunchKernelGGL(k_sv_dot, dim3(nb), dim3(256), 0, s->stream, n, a, b, w.part.p);
+    hipLaunchKernelGGL(k_group_sum, dim3(1), dim3(256), 0, s->stream, (long long)nb, (const unsigned char*)nullptr, (const double*)w.part.p, w.red.p);
+    double h[2];
+    DAS_HIP(hipMemcpyAsync(h, w.red.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    DAS_HIP(hipStreamSynchronize(s->stream));
+    return h[0];
+}
+// Jacobi-preconditioned BiCGStab (convection-diffusion systems) on the LDU matrix; x holds the start vector; returns the iterations
+static int sv_bicgstab(das_solver* s, SimpleWork& w, const LduDev& A, const double* b, double* x, double tol, int maxit) {
+    const long long n = s->dm.nC;
+    const int G = nblk(n, 256);
+    hipStream_t st = s->stream;
+    hipLaunchKernelGGL(k_ldu_mv, dim3(G), dim3(256), 0, st, s->dm, A.diag, A.up, A.lo, (const double*)x, w.r.p, 1.0);
+    hipLaunchKernelGGL(k_sv_lin, dim3(G), dim3(256), 0, st, n, w.r.p, 1.0, b, -1.0, (const double*)w.r.p);
+    DAS_HIP(hipMemcpyAsync(w.r0.p, w.r.p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    w.p.zero(); w.v.zero();
+    const double bn = std::sqrt(sv_dot(s, w, n, b, b)) + 1e-300;
+    double rho = 1.0, alpha = 1.0, om = 1.0;
+    for (int it = 1; it <= maxit; it++) {
+        if (std::sqrt(sv_dot(s, w, n, w.r.p, w.r.p)) <= tol * bn) return it - 1;
+        const double rho1 = sv_dot(s, w, n, w.r0.p, w.r.p);
+        if (rho1 == 0.0 || !std::isfinite(rho1)) return it - 1;  // breakdown: keep the iterate (right-hand sides that vanish to rounding end here)
+        const double beta = (rho1 / rho) * (alpha / om);
+        hipLaunchKernelGGL(k_sv_bicg_p, dim3(G), dim3(256), 0, st, n, w.p.p, (const double*)w.r.p, beta, om, (const double*)w.v.p);
+        hipLaunchKernelGGL(k_sv_divdiag, dim3(G), dim3(256), 0, st, n, w.ph.p, (const double*)w.p.p, A.diag, 1.0);
+        hipLaunchKernelGGL(k_ldu_mv, dim3(G), dim3(256), 0, st, s->dm, A.diag, A.up, A.lo, (const double*)w.ph.p, w.v.p, 1.0);
+        alpha = rho1 / sv_dot(s, w, n, w.r0.p, w.v.p);
+        hipLaunchKernelGGL(k_sv_lin, dim3(G), dim3(256), 0, st, n, w.sv.p, 1.0, (const double*)w.r.p, -alpha, (const double*)w.v.p);
+        if (std::sqrt(sv_dot(s, w, n, w.sv.p, w.sv.p)) <= tol * bn) {
+            hipLaunchKernelGGL(k_sv_lin, dim3(G), dim3(256), 0, st, n, x, 1.0, (const double*)x, alpha, (const double*)w.ph.p);
+            return it;
+        }
+        hipLaunchKernelGGL(k_sv_divdiag, dim3(G), dim3(256), 0, st, n, w.sh.p, (const double*)w.sv.p, A.diag, 1.0);
+        hipLaunchKernelGGL(k_ldu_mv, dim3(G), dim3(256), 0, st, s->dm, A.diag, A.up, A.lo, (const double*)w.sh.p, w.t.p, 1.0);
+        om = sv_dot(s, w, n, w.t.p, w.sv.p) / sv_dot(s, w, n, w.t.p, w.t.p);
+        hipLaunchKernelGGL(k_sv_bicg_x, dim3(G), dim3(256), 0, st, n, x, alpha, (const double*)w.ph.p, om, (const double*)w.sh.p, w.r.p, (const double*)w.sv.p, (const double*)w.t.p);
+        rho = rho1;
+    }
+    return maxit;
+}
+// Jacobi-preconditioned conjugate gradients on sign * A (the pressure equation: A symmetric negative definite, sign = -1)
+static int sv_pcg(das_solver* s, SimpleWork& w, const LduDev& A, double sign, const double* b, double* x, double tol, int maxit) {
+    const long long n = s->dm.nC;
+    const int G = nblk(n, 256);
+    hipStream_t st = s->stream;
+    hipLaunchKernelGGL(k_ldu_mv, dim3(G), dim3(256), 0, st, s->dm, A.diag, A.up, A.lo, (const double*)x, w.r.p, 1.0);
+    hipLaunchKernelGGL(k_sv_lin, dim3(G), dim3(256), 0, st, n, w.r.p, sign, b, -sign, (const double*)w.r.p);
+    const double bn = std::sqrt(sv_dot(s, w, n, b, b)) + 1e-300;
+    double rz = 0.0;
+    for (int it = 1; it <= maxit; it++) {
+        if (std::sqrt(sv_dot(s, w, n, w.r.p, w.r.p)) <= tol * bn) return it - 1;
+        hipLaunchKernelGGL(k_sv_divdiag, dim3(G), dim3(256), 0, st, n, w.ph.p, (const double*)w.r.p, A.diag, sign);  // z
+        const double rz1 = sv_dot(s, w, n, w.r.p, w.ph.p);
+        if (it == 1) DAS_HIP(hipMemcpyAsync(w.p.p, w.ph.p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        else hipLaunchKernelGGL(k_sv_lin, dim3(G), dim3(256), 0, st, n, w.p.p, 1.0, (const double*)w.ph.p, rz1 / rz, (const double*)w.p.p);
+        rz = rz1;
+        hipLaunchKernelGGL(k_ldu_mv, dim3(G), dim3(256), 0, st, s->dm, A.diag, A.up, A.lo, (const double*)w.p.p, w.v.p, sign);  // q = sign A p
+        const double alpha = rz / sv_dot(s, w, n, w.p.p, w.v.p);
+        hipLaunchKernelGGL(k_sv_lin, dim3(G), dim3(256), 0, st, n, x, 1.0, (const double*)x, alpha, (const double*)w.p.p);
+        hipLaunchKernelGGL(k_sv_lin, dim3(G), dim3(256), 0, st, n, w.r.p, 1.0, (const double*)w.r.p, -alpha, (const double*)w.v.p);
+    }
+    return maxit;
+}
+
+// nSweeps SIMPLE iterations on the solver's states (DASimpleFoam + SA without T field, MRF, cyclic pairs; single rank).  alphaP: explicit
+// pressure relaxation (fvSolution relaxationFactors.fields.p), linTol / maxLin: relative tolerance and iteration cap of the inner solves
+// (the reference's fvSolution solvers; tight values reproduce the oracle's direct solves).  info[3] = inner iterations (U, p, nuTilda)
+// of the last sweep.
+static void run_simple_sweeps(das_solver* s, int nSweeps, double alphaP, double linTol, int maxLin, double* info) {
+    need_init(s);
+    DAS_CHECK(s->cp.solver == DAS_SOLVER_SIMPLEFOAM && !s->cp.hasT && !s->cp.mrf && !s->cp.hasCyclic, DAS_ERR_ARG,
+              "SIMPLE sweeps serve DASimpleFoam + SA without T field, MRF and cyclic pairs");
+    DAS_CHECK(!s->halo.active && !s->halo_cb && s->owned.empty(), DAS_ERR_ARG, "the SIMPLE sweeps are single-rank");
+    const DevMesh& dm = s->dm;
+    const long long N = dm.nC, F = dm.nF, nIF = dm.nIF, nBF = F - nIF, n = s->n;
+    const int B = 256;
+    hipStream_t st = s->stream;
+    ResParams prm = s->wk.bind(s->cp.solver, N, F, make_params(s->cp, s->opt, 0));
+    ResWork<double>& wk = s->wk;
+    if (wk.fc.n != (size_t)DAS_FC_N * nIF) wk.fc.alloc((size_t)DAS_FC_N * nIF);
+    if (wk.brec.n != (size_t)DAS_BREC_N * nBF) wk.brec.alloc((size_t)DAS_BREC_N * nBF);
+    SimpleWork w;
+    w.Wn.alloc(n); w.D.alloc(N); w.bd.alloc(3 * N); w.sb.alloc(3 * N); w.rhsU.alloc(3 * N); w.up.alloc(nIF); w.lo.alloc(nIF); w.rAU.alloc(N); w.HbyA.alloc(3 * N);
+    w.phiH.alloc(F); w.gpf.alloc(F); w.cp.alloc(nIF); w.pbc.alloc(4 * std::max<long long>(1, nBF)); w.dp.alloc(N); w.rp.alloc(N); w.x.alloc(N); w.b.alloc(N); w.dg.alloc(N);
+    w.pn.alloc(N); w.phiN.alloc(F); w.gPn.alloc(3 * N);
+    w.r.alloc(N); w.r0.alloc(N); w.p.alloc(N); w.v.alloc(N); w.sv.alloc(N); w.t.alloc(N); w.ph.alloc(N); w.sh.alloc(N); w.part.alloc(512); w.red.alloc(2);
+    double* W = s->d_W.p;
+    int itU = 0, itP = 0, itN = 0;
+    auto grads_and_records = [&](const double* Wc) {
+        launch_grad_simple<double, double>(dm, prm, Wc, wk, st);
+        if (nIF > 0) hipLaunchKernelGGL((k_fcoef<double>), dim3(nblk(nIF, B)), dim3(B), 0, st, dm, prm, Wc, (const double*)wk.nut.p, (const double*)wk.gU.p, (const double*)wk.gN.p, wk.fc.p);
+        if (nBF > 0) hipLaunchKernelGGL((k_bcoef<double>), dim3(nblk(nBF, B)), dim3(B), 0, st, dm, prm, Wc, (const double*)wk.nut.p, (const double*)wk.gU.p, wk.brec.p);
+    };
+    for (int sw = 0; sw < nSweeps; sw++) {
+        itU = itP = itN = 0;
+        // ---- momentum predictor (UEqnSimple.H)
+        grads_and_records(W);
+        hipLaunchKernelGGL(k_simple_ueqn, dim3(nblk(N, B)), dim3(B), 0, st, dm, prm, (const double*)W, (const double*)wk.gP.p, (const double*)wk.fc.p, (const double*)wk.brec.p, w.D.p,
+                           w.bd.p, w.sb.p, w.rhsU.p);
+        if (nIF > 0) hipLaunchKernelGGL(k_simple_offdiag, dim3(nblk(nIF, B)), dim3(B), 0, st, dm, prm, (const double*)W, (const double*)wk.fc.p, 0, w.up.p, w.lo.p);
+        DAS_HIP(hipMemcpyAsync(w.Wn.p, W, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        for (int k = 0; k < 3; k++) {
+            hipLaunchKernelGGL(k_sv_gather3, dim3(nblk(N, B)), dim3(B), 0, st, N, (const double*)W, k, (const double*)w.D.p, (const double*)w.bd.p, (const double*)w.rhsU.p, w.x.p, w.dg.p, w.b.p);
+            itU += sv_bicgstab(s, w, LduDev{w.dg.p, w.up.p, w.lo.p}, w.b.p, w.x.p, linTol, maxLin);
+            hipLaunchKernelGGL(k_sv_scatter3, dim3(nblk(N, B)), dim3(B), 0, st, N, (const double*)w.x.p, k, w.Wn.p);
+        }
+        // ---- pressure corrector (pEqnSimple.H)
+        hipLaunchKernelGGL(k_simple_hbya, dim3(nblk(N, B)), dim3(B), 0, st, dm, (const double*)w.Wn.p, (const double*)w.D.p, (const double*)w.bd.p, (const double*)w.sb.p,
+                           (const double*)w.up.p, (const double*)w.lo.p, w.rAU.p, w.HbyA.p);
+        hipLaunchKernelGGL(k_simple_pface, dim3(nblk(F, B)), dim3(B), 0, st, dm, prm, (const double*)w.Wn.p, (const double*)wk.nut.p, (const double*)w.rAU.p, (const double*)w.HbyA.p,
+                           w.phiH.p, w.gpf.p, w.cp.p, w.pbc.p);
+        DAS_HIP(hipMemcpyAsync(w.gPn.p, wk.gP.p, 3 * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+        DAS_HIP(hipMemcpyAsync(w.pn.p, W + prm.offP * N, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+        for (int corr = 0; corr < 2; corr++) {  // nNonOrthogonalCorrectors 1
+            hipLaunchKernelGGL(k_simple_peqn, dim3(nblk(N, B)), dim3(B), 0, st, dm, (const double*)w.phiH.p, (const double*)w.gpf.p, (const double*)w.cp.p, (const double*)w.pbc.p,
+                               (const double*)w.gPn.p, w.dp.p, w.rp.p);
+            itP += sv_pcg(s, w, LduDev{w.dp.p, w.cp.p, w.cp.p}, -1.0, w.rp.p, w.pn.p, linTol, maxLin);
+            hipLaunchKernelGGL(k_simple_gradp, dim3(nblk(N, B)), dim3(B), 0, st, dm, (const double*)w.pn.p, (const double*)w.pbc.p, w.gPn.p);
+        }
+        hipLaunchKernelGGL(k_simple_flux, dim3(nblk(F, B)), dim3(B), 0, st, dm, (const double*)w.pn.p, (const double*)w.gPn.p, (const double*)w.phiH.p, (const double*)w.gpf.p,
+                           (const double*)w.cp.p, (const double*)w.pbc.p, w.phiN.p);
+        hipLaunchKernelGGL(k_sv_relax, dim3(nblk(N, B)), dim3(B), 0, st, N, w.pn.p, (const double*)(W + prm.offP * N), alphaP);
+        hipLaunchKernelGGL(k_simple_gradp, dim3(nblk(N, B)), dim3(B), 0, st, dm, (const double*)w.pn.p, (const double*)w.pbc.p, w.gPn.p);
+        hipLaunchKernelGGL(k_simple_correct, dim3(nblk(N, B)), dim3(B), 0, st, N, prm.offP, (const double*)w.HbyA.p, (const double*)w.rAU.p, (const double*)w.gPn.p,
+                           (const double*)w.pn.p, w.Wn.p);
+        DAS_HIP(hipMemcpyAsync(w.Wn.p + prm.offPhi * N, w.phiN.p, F * sizeof(double), hipMemcpyDeviceToDevice, st));
+        // ---- SA transport at the updated U / phi (DASpalartAllmaras::correct)
+        grads_and_records(w.Wn.p);
+        hipLaunchKernelGGL(k_simple_saeqn, dim3(nblk(N, B)), dim3(B), 0, st, dm, prm, (const double*)w.Wn.p, (const double*)wk.gU.p, (const double*)wk.gN.p, (const double*)wk.fc.p,
+                           (const double*)wk.brec.p, w.dg.p, w.b.p);
+        if (nIF > 0) hipLaunchKernelGGL(k_simple_offdiag, dim3(nblk(nIF, B)), dim3(B), 0, st, dm, prm, (const double*)w.Wn.p, (const double*)wk.fc.p, 1, w.up.p, w.lo.p);
+        DAS_HIP(hipMemcpyAsync(w.x.p, w.Wn.p + prm.offN * N, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+        itN += sv_bicgstab(s, w, LduDev{w.dg.p, w.up.p, w.lo.p}, w.b.p, w.x.p, linTol, maxLin);
+        hipLaunchKernelGGL(k_sv_bound, dim3(nblk(N, B)), dim3(B), 0, st, N, (const double*)w.x.p, 1e-16, w.Wn.p + prm.offN * N);  // DAUtility::boundVar
+        DAS_HIP(hipMemcpyAsync(W, w.Wn.p, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    DAS_HIP(hipGetLastError());
+    DAS_HIP(hipStreamSynchronize(st));
+    s->h_W = s->d_W.to_host();
+    if (info) { info[0] = itU; info[1] = itP; info[2] = itN; }
+}
+
+int das_simple_iteration(das_solver_t* s, int nSweeps, double alphaP, double linTol, int maxLinIters, double* info3) {
+    DAS_TRY
+    DAS_CHECK(s && nSweeps >= 0 && alphaP > 0.0 && linTol > 0.0 && maxLinIters > 0, DAS_ERR_ARG, "das_simple_iteration: bad argument");
+    run_simple_sweeps(s, nSweeps, alphaP, linTol, maxLinIters, info3);
+    return DAS_OK;
+    DAS_CATCH
+}
+
 // solvePrimal (reference pyDASolvers.pyx solvePrimal -> DASimpleFoam::solvePrimal, DASimpleFoam.C:123-185): converge
 // R(W) = 0 from the current states; returns 0 converged / 1 not converged; info4 = {steps, GMRES iterations, |R0|, |R|}
 int das_solve_primal(das_solver_t* s, int maxSteps, double relTol, double absTol, double* info4, double* hist, int histCap) {
@@ -5094,8 +5360,7 @@ int das_create_ml_rksp_matrix_free(das_solver_t* s, das_mat_t* pc, das_ksp_t** k
     if (pcType == "bilu") {
         if (getenv("DAS_BILU_ORDER")) k->pcOrder = atoi(getenv("DAS_BILU_ORDER"));
         const long long K = pc_subdomain_count(s);
-        if (K > 1) setup_subdomain_ilus(s, k.get(), (int)K);
-        else {
+        if (!(K > 1 && setup_subdomain_ilus(s, k.get(), (int)K))) {
             const double t0 = wall_seconds();
             // a sub-domain of a multi-rank solve takes the elimination order with the smallest estimate, one rank alone the first stable one
             choose_order_and_factorise(s, k.get(), k->bilu, (s->pcMask.empty() || k->pcTranspose) ? s->owned : s->pcMask, !s->owned.empty(), k->pcOrderUsed, k->pcStability);

@@ -85,6 +85,13 @@ Options::Options() {
     i["amd.pcSubdomains"] = -1;  // K > 1: restricted additive Schwarz inside the GPU (K node-block ILUs on RCB blocks + asmOverlap rings, own elimination orders, one merged level structure); -1 (default): 4 from 1 M cells on, else 1
     i["amd.pcCoarseSparseAZ"] = 1;   // deflated mode: A (Z u) through the precomputed sparse A Z (0: one full operator product per apply)
     i["amd.coloringOnDevice"] = 1;   // serial first-fit colouring as a data-flow kernel (das_color.hpp); 0: host variants
+    // PYDAFOAM.solvePrimal: "newton" (default: pseudo-transient Newton-Krylov, das_solve_primal) | "simple" (the reference's own loop: SIMPLE sweeps on
+    // the device, das_simple_iteration, in blocks of simpleSweepsPerCheck sweeps between residual checks; inner solvers to simpleLinearTol)
+    s["amd.primalMethod"] = "newton";
+    i["amd.simpleSweepsPerCheck"] = 10;
+    d["amd.simpleAlphaP"] = 0.3;
+    d["amd.simpleLinearTol"] = 1.0e-6;
+    i["amd.simpleLinearIters"] = 2000;
     d["amd.primalTau0"] = 1.0;          // Newton primal: initial pseudo-time factor (diagonal scaled by 1 + 1/tau), SER growth
     d["amd.primalSERExponent"] = 1.5;   // tau = tau0 (|R0| / |R|)^exponent (measured: 1.0 -> 52+ steps, 1.5 -> 20-29, 2.0 -> 17-21 on the bench channels)
     // pseudo-time control: "ser" (tau = tau0 (|R0|/|R|)^p: starts close to the solution) | "ramp" (CFL ramp: tau grows by >= primalTauGrowth

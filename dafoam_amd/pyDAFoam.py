@@ -536,7 +536,25 @@ class PYDAFOAM(object):
             ref = float(np.linalg.norm(R))
             self._primalResRef = ref if ref > 0.0 else 1.0
             ref = self._primalResRef
-        _, self.primalInfo = self.solver.solvePrimal(maxSteps=maxSteps, relTol=0.0, absTol=tol * ref)
+        amd = self.getOption("amd") or {}
+        if str(amd.get("primalMethod", "newton")) == "simple":
+            # the reference's own loop, SIMPLE sweeps on the device (das_simple_iteration): blocks of sweeps until the residual norm meets the
+            # tolerance or `maxSteps` blocks of amd.simpleSweepsPerCheck sweeps are done
+            per = int(amd.get("simpleSweepsPerCheck", 10))
+            R = np.zeros(self.getNLocalAdjointStates())
+            self.solver.getResiduals(R)
+            hist, inner = [float(np.linalg.norm(R))], 0
+            for _ in range(int(maxSteps)):
+                if hist[-1] <= tol * ref:
+                    break
+                it = self.solver.simpleIteration(per, alphaP=float(amd.get("simpleAlphaP", 0.3)), linTol=float(amd.get("simpleLinearTol", 1e-6)),
+                                                 maxLinIters=int(amd.get("simpleLinearIters", 2000)))
+                inner += per * (it["U"] + it["p"] + it["nuTilda"])
+                self.solver.getResiduals(R)
+                hist.append(float(np.linalg.norm(R)))
+            self.primalInfo = dict(steps=(len(hist) - 1) * per, linearIterations=inner, res0=hist[0], res=hist[-1], history=np.asarray(hist), method="simple")
+        else:
+            _, self.primalInfo = self.solver.solvePrimal(maxSteps=maxSteps, relTol=0.0, absTol=tol * ref)
         self.primalMaxRes = self.primalInfo["res"] / ref
         self.primalInfo["primalMaxRes"] = self.primalMaxRes
         self.primalFail = int(self.primalMaxRes / tol > float(self.getOption("primalMinResTolDiff")))

@@ -836,6 +836,15 @@ class pyDASolvers:
         nst = int(info4[0])
         return rc, dict(steps=nst, linearIterations=int(info4[1]), res0=float(info4[2]), res=float(info4[3]), history=hist[: nst + 1].copy())
 
+    def simpleIteration(self, nSweeps=1, alphaP=0.3, linTol=1e-12, maxLinIters=20000):
+        """nSweeps iterations of the reference's own primal loop, SIMPLE (DASimpleFoam::solvePrimal, DASimpleFoam.C:123-185: UEqnSimple.H,
+        pEqnSimple.H, DASpalartAllmaras::correct), on the device from the current states (das_simple_iteration); alphaP = the explicit
+        pressure relaxation of fvSolution, linTol / maxLinIters = the inner solvers' settings.  Returns the inner iteration counts of the
+        last sweep; the new states are read with getOFFields / getStates."""
+        info = np.zeros(3)
+        check(lib().das_simple_iteration(self._h, int(nSweeps), float(alphaP), float(linTol), int(maxLinIters), dptr(info)))
+        return dict(U=int(info[0]), p=int(info[1]), nuTilda=int(info[2]))
+
     def solveLinearEqnBlock(self, myKSP: KSP, rhs, sol):
         """Several adjoint systems with the same operator through ONE block GMRES (the reference loops solveLinearEqn over
         the objective functions, mphys_dafoam.py:478-481).  rhs, sol: (n, s) arrays, s <= 8; returns (fail, res0[s], res[s])."""

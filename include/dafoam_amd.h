@@ -202,6 +202,14 @@ int das_calc_residuals(das_solver_t* s, int isPC, double* residuals);
  * amd.primalPseudoTimeFields "all" | "momentum" (cold starts: the term on the transport rows only)).  Returns 0 converged
  * (|R| <= max(relTol |R0|, absTol)) / 1 not converged; info4 = {Newton steps, GMRES iterations, |R0|, |R|}. */
 int das_solve_primal(das_solver_t* s, int maxSteps, double relTol, double absTol, double* info4, double* hist, int histCap);
+/* das_simple_iteration: nSweeps iterations of the reference's OWN primal loop - SIMPLE (DASimpleFoam::solvePrimal, DASimpleFoam.C:123-185:
+ * UEqnSimple.H, pEqnSimple.H with nNonOrthogonalCorrectors 1, DASpalartAllmaras::correct) - on the device, from the current states:
+ * relaxed momentum predictor, rAU / HbyA / constrainHbyA, pressure equation, phi = phiHbyA - flux, explicit p relaxation (alphaP =
+ * fvSolution relaxationFactors.fields.p), U correction, SA transport + bound.  Inner solves: Jacobi-preconditioned BiCGStab (U, nuTilda) /
+ * CG (p) to the relative tolerance linTol, at most maxLinIters iterations.  DASimpleFoam + SA without T field, MRF and cyclic pairs, one
+ * rank.  info3 (optional) = inner iterations of the last sweep (U, p, nuTilda).  The Newton-Krylov das_solve_primal reaches the same
+ * fixed point in far fewer steps; the sweeps reproduce the reference's iteration (and the oracle's, oracle/primal.py) sweep by sweep. */
+int das_simple_iteration(das_solver_t* s, int nSweeps, double alphaP, double linTol, int maxLinIters, double* info3);
 int das_run_coloring(das_solver_t* s);
 /* das_set_coloring <- DAJacCon::readJacConColoring (DAJacCon.C:1980-2019): colours read back from a dRdWColoring_n.bin
  *                      cache; validated against the freshly built connectivity ("Conflicting Colors Found!" otherwise). */

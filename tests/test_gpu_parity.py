@@ -1265,6 +1265,45 @@ def test_newton_krylov_primal_reaches_the_simple_fixed_point():
     assert afail == 0 and relerr(psi, spla.spsolve(A.tocsc(), rhs)) <= 1e-5
 
 
+def test_simple_sweeps_on_the_device_equal_the_oracle_and_reach_the_newton_fixed_point():
+    """Round 6: das_simple_iteration - the reference's own primal loop (SIMPLE: DASimpleFoam.C:123-185, UEqnSimple.H,
+    pEqnSimple.H, DASpalartAllmaras::correct) on the device.  (a) 1 and 3 sweeps from the synthetic state equal the oracle's sweeps
+    (direct inner solves) to the inner solvers' tolerance, with and without the wall function and on the NACA0012 O-grid; (b) run to
+    convergence, the sweeps reach the fixed point of the oracle's SIMPLE loop - the same one the Newton-Krylov primal reaches."""
+    from dafoam_amd.meshgen import naca0012_case
+    from oracle.primal import simple_iteration
+
+    for case in (channel_case(7, 6, 5, perturb=0.0), channel_case(7, 6, 5, wall_function=True, perturb=0.0), naca0012_case(24, 8, 3, span=0.3, first_cell=1e-3, perturb=0.0)):
+        g = Geometry(case.mesh)
+        W0 = case.states.copy()
+        Wo = [W0]
+        for _ in range(3):
+            Wo.append(simple_iteration(case, g, Wo[-1]))
+        for ns in (1, 3):
+            D = make(case)
+            info = D.solver.simpleIteration(ns, alphaP=0.3, linTol=1e-13)
+            assert info["U"] > 0 and info["p"] > 0
+            W = np.zeros(W0.size)
+            D.solver.getOFFields(W)
+            for nm, sl in blocks(case, g):
+                assert relerr(W[sl], Wo[ns][sl]) < 1e-9, (nm, ns)
+    # (b) to convergence: the fixed point of the SIMPLE loop = the converged case of the adjoint tests (oracle SIMPLE, 1e-11)
+    conv = converged_case((10, 8, 6), lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    start = channel_case(10, 8, 6, perturb=0.0, lengths=(1.0, 0.2, 0.2), grading_y=2.0)
+    g = Geometry(start.mesh)
+    sc = J.state_scales(start, g, norm_states(start))
+    D = make(start)
+    R = np.zeros(start.states.size)
+    D.solver.getResiduals(R)
+    r0 = np.linalg.norm(R)
+    D.solver.simpleIteration(400, alphaP=0.3, linTol=1e-10)
+    D.solver.getResiduals(R)
+    assert np.linalg.norm(R) < 1e-6 * r0
+    W = np.zeros(R.size)
+    D.solver.getOFFields(W)
+    assert relerr(W / sc, conv.states / sc) < 1e-5
+
+
 def test_newton_krylov_primal_compressible():
     """The same Newton-Krylov primal on DARhoSimpleFoam + SA: the fixed point of the oracle's compressible SIMPLE loop."""
     from oracle.primal import solve_primal

@@ -229,6 +229,31 @@ def test_native_mesh_metrics_equal_the_numpy_input_geometry_and_the_swept_wing_i
     assert abs(chord_tip - 0.7) < 0.01 and abs(p1[tip, 0].min() - (0.25 - 0.25 * 0.7 + 1.2 * np.tan(np.deg2rad(25.0)))) < 0.01  # chord 0.7 about the swept quarter-chord line
 
 
+def test_simple_sweep_bodies_equal_the_oracle_simple_iteration():
+    """Round 6 (SURVEY 8 row f4): the SIMPLE sweep of DASimpleFoam + SA (csrc/das_simple.hpp: momentum predictor with fvMatrix::relax, rAU /
+    HbyA / constrainHbyA, pressure equation with one non-orthogonal corrector, phi = phiHbyA - flux, explicit p relaxation, U correction,
+    SA transport + bound; reference DASimpleFoam.C:123-185, UEqnSimple.H, pEqnSimple.H, DASpalartAllmaras.C:386-405) - the per-entity
+    bodies in host loops with serial Krylov solvers against the oracle's restatement with direct solves (oracle/primal.py), 1 and 3
+    sweeps, on the bump channel (with and without the wall function) and on the NACA0012 O-grid."""
+    from dafoam_amd.meshgen import naca0012_case
+    from oracle.primal import simple_iteration
+
+    E = _emu()
+    E.emu_simple_iteration.argtypes = [C.POINTER(das_case_t), _capi.c_double_p, C.c_longlong, C.c_int, C.c_double, C.c_double, _capi.c_double_p]
+    for case in (channel_case(7, 6, 5, perturb=0.0), channel_case(7, 6, 5, wall_function=True, perturb=0.0), naca0012_case(24, 8, 3, span=0.3, first_cell=1e-3, perturb=0.0)):
+        g = Geometry(case.mesh)
+        W = case.states.copy()
+        oracle_states = [W]
+        for _ in range(3):
+            oracle_states.append(simple_iteration(case, g, oracle_states[-1]))
+        cs = CaseStruct(case)
+        for ns in (1, 3):
+            out = np.zeros_like(W)
+            assert E.emu_simple_iteration(cs.byref(), dptr(W), W.size, ns, 0.3, 1e-13, dptr(out)) == 0
+            for nm, sl in blocks(case, g):
+                assert relerr(out[sl], oracle_states[ns][sl]) < 1e-10, (nm, ns)
+
+
 def test_kernel_bodies_match_oracle_scalar_transport():
     case = scalar_transport_case(8, 7, 6)
     g = Geometry(case.mesh)
