@@ -276,6 +276,7 @@ _SIGS = {
     "das_ksp_get_pc_node_out": (C.c_int, [_VP, c_int_p]),
     "das_mesh_metrics": (C.c_int, [C.c_int, c_double_p, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     "das_ksp_get_coarse": (C.c_int, [_VP, c_int_p]),
+    "das_ksp_coarse_sparse_az_active": (C.c_int, [_VP]),
     "das_ksp_set_global_coarse": (C.c_int, [_VP, _VP, C.c_int, C.c_int, c_int_p]),
     "das_ksp_run_fixed_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),
     "das_ksp_begin_device": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int]),

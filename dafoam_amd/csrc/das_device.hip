@@ -5572,6 +5572,9 @@ int das_ksp_get_pc_subdomains(das_ksp_t* k, int* orders, double* estimates) {
     }
     return k->nSub;
 }
+// 1 if the last preconditioner applies of this KSP took the A-DEF1 term A (Z u) from the precomputed sparse A Z (k_az_build / k_az_apply), 0 if
+// they ran a full operator product (amd.pcCoarseSparseAZ 0, no assembled operator, build failed), -1: null handle
+int das_ksp_coarse_sparse_az_active(das_ksp_t* k) { return k ? (k->coarse.active && k->coarse.deflated && k->coarse.azReady ? 1 : 0) : -1; }
 // coarse space of the two-level preconditioner: number of aggregates (0 = none); aggOfCell[nCells] (optional) = aggregate or -1
 int das_ksp_get_coarse(das_ksp_t* k, int* aggOfCell) {
     if (!k || !k->coarse.active) return 0;

@@ -388,6 +388,9 @@ int das_ksp_get_pc_subdomains(das_ksp_t* ksp, int* orders, double* estimates);
 /* two-level preconditioner (amd.pcCoarseAggregates / pcCoarseField / pcCoarseMode): number of aggregates of the
  * piecewise-constant pressure coarse space (0 = none) and, optionally, the aggregate of every cell (-1 = not owned) */
 int das_ksp_get_coarse(das_ksp_t* ksp, int* aggOfCell);
+/* 1 if the deflated coarse correction of this KSP takes A (Z u) from the precomputed sparse A Z (amd.pcCoarseSparseAZ, round 5), 0 if it runs
+ * a full operator product per apply - test aid */
+int das_ksp_coarse_sparse_az_active(das_ksp_t* ksp);
 /* multi-GPU: ONE coarse space over all ranks instead of one per rank (the reference's ASM level couples the sub-domains through
  * its overlap, DALinearEqn.C:199-216; a per-rank coarse space lets the iteration count grow with the number of GPUs).
  * Collective over the installed communication.  naggGlobal <= 2048: size of the global coarse operator; aggOffset: position of

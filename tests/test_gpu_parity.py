@@ -772,7 +772,22 @@ def test_two_level_pc_apply_and_iteration_gain(mode):
         Mop = Mat()
         D.solver.calcdRdWT(0, Mop, mode=1)
         y_o = B.solve(x - Mop.to_scipy() @ cvec) + cvec
-    assert relerr(ksp.applyPC(D.solver, x), y_o) < 1e-9
+    y = ksp.applyPC(D.solver, x)
+    assert relerr(y, y_o) < 1e-9
+    if mode == "deflated":
+        # the A-DEF1 term A (Z u) came from the precomputed sparse A Z (k_az_build / k_az_apply) - the numpy line above used the whole
+        # operator: this IS the direct comparison of the sparse A Z; the same apply with amd.pcCoarseSparseAZ 0 runs the full product
+        from dafoam_amd import _capi
+        assert _capi.lib().das_ksp_coarse_sparse_az_active(ksp.handle) == 1
+        D0 = make(case, amd={"pcCoarseAggregates": 24, "pcCoarseMode": mode, "pcCoarseSparseAZ": 0}, **opts)
+        D0.solver.runColoring()
+        pc0 = Mat()
+        D0.solver.calcdRdWT(1, pc0)
+        k0 = KSP()
+        D0.solverAD.createMLRKSPMatrixFree(pc0, k0)
+        D0.solverAD.initializedRdWTMatrixFree()
+        y0 = k0.applyPC(D0.solver, x)
+        assert _capi.lib().das_ksp_coarse_sparse_az_active(k0.handle) == 0 and relerr(y, y0) < 1e-11
     sc = J.state_scales(case, g, norm_states(case))
     rhs = np.zeros(n)
     rhs[0 : 3 * N : 3] = g.V

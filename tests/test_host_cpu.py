@@ -254,6 +254,35 @@ def test_simple_sweep_bodies_equal_the_oracle_simple_iteration():
                 assert relerr(out[sl], oracle_states[ns][sl]) < 1e-10, (nm, ns)
 
 
+def test_additive_schwarz_overlap_mask_of_a_rank():
+    """Round 6: the sub-domain of a rank under adjEqnOption.asmOverlap (dafoam_amd.distributed.overlap_mask; reference PCASMSetOverlap,
+    DALinearEqn.C:212-216) on the slab partition of the channel: overlap 0 = the owned unknowns; overlap k = owned + the states anchored at
+    the cells within k face-neighbour rings (cell states at the cell, face fluxes at the face's owner cell), never a cut face; nested in k."""
+    from dafoam_amd.distributed import SlabPartition, overlap_mask, state_table
+
+    NX, NY, NZ = 8, 4, 3
+    for rank in (0, 1):
+        part = SlabPartition(NX, NY, NZ, rank, 2)
+        case = channel_case(part.nxl, NY, NZ, x_range=(part.e0, part.e1, NX), lengths=(2.0, 0.2, 0.2), perturb=0.0)
+        key, orank, owned = state_table(part, case.mesh)
+        m = case.mesh
+        N, F = m.n_cells, m.n_faces
+        m0, m1, m2 = (overlap_mask(m, orank, rank, k) for k in (0, 1, 2))
+        assert np.array_equal(m0, owned)
+        assert np.all(m1[owned]) and np.all(m2[m1]) and m1.sum() > owned.sum() and m2.sum() > m1.sum()
+        assert not np.any(m2[orank < 0])                                      # cut faces belong to nobody
+        cell_owned = orank[3 * N : 4 * N] == rank
+        own_f, nei = np.asarray(m.owner), np.asarray(m.neighbour)
+        nIF = m.n_internal_faces
+        ring1 = cell_owned.copy()
+        ring1[own_f[:nIF][cell_owned[nei]]] = True
+        ring1[nei[cell_owned[own_f[:nIF]]]] = True
+        assert np.array_equal(m1[3 * N : 4 * N], ring1)                       # p block: exactly the owned cells + one ring
+        assert np.array_equal(m1[: 3 * N].reshape(N, 3).all(axis=1), ring1)   # U block alike
+        phi = m1[5 * N :]
+        assert np.array_equal(phi[orank[5 * N :] >= 0], ring1[own_f][orank[5 * N :] >= 0])  # fluxes follow their owner cell
+
+
 def test_kernel_bodies_match_oracle_scalar_transport():
     case = scalar_transport_case(8, 7, 6)
     g = Geometry(case.mesh)
