@@ -907,7 +907,7 @@ def naca_normal_distribution(ny, first_cell=2.0e-5, radius=20.0):
 
 
 def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first_cell=2.0e-5, U0=10.0, aoa_deg=2.0, nu=1.5e-5, nuTilda0=4.5e-5,
-                  wall_function=False, seed=0, perturb=0.02, y_wall_section=None, sweep_deg=0.0, taper=0.0) -> FoamCase:
+                  wall_function=False, seed=0, perturb=0.02, y_wall_section=None, sweep_deg=0.0, taper=0.0, fold_seam=False) -> FoamCase:
     """DASimpleFoam + SA around a NACA0012 (chord 1) on a single-block O-grid of n_around x n_normal x nz hexahedra, extruded
     `span` in z with symmetry front/back (the reference's 2-D airfoil cases use one cell and `empty`/symmetry sides,
     tests/runRegTests_AeroOpt.py).  Wall-normal geometric stretching from `first_cell` (y+ ~ 1 at Re 6.7e5) to the far
@@ -918,7 +918,12 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
     `sweep_deg` / `taper` (round 6; BASELINE.md config 3 names a swept-wing O-grid): a genuinely three-dimensional wing segment - layer k
     is the section scaled about the quarter chord to the chord 1 - taper z_k / span and shifted downstream by z_k tan(sweep); the
     transformation fades out with the distance from the wall (half at 3 chords), the far field and the two end planes stay where they
-    are.  The spanwise copies of the section are then no longer identical: no degenerate spanwise modes."""
+    are.  The spanwise copies of the section are then no longer identical: no degenerate spanwise modes.
+    `fold_seam` (round 6): CELL NUMBERING only - the position around the section runs 0, n-1, 1, n-2, ... instead of 0, 1, ..., n-1, so that
+    the two cells either side of the O-grid's seam are neighbours in the numbering too (what OpenFOAM's renumberMesh does for a user's mesh).
+    In the plain numbering the last cells of a ring depend on the first cells of the same ring and the first cells of the NEXT ring on the
+    last ones of this ring: every index-ordered data-flow computation (the first-fit colouring, das_color.hpp) is serialised ring after
+    ring.  Geometry, patches and the state are the same mesh; `naca_ring_position` decodes the position from a cell id."""
     nx, ny = int(n_around), int(n_normal)
     d = naca_normal_distribution(ny, first_cell, radius)             # distance from the wall, d[0] = 0, d[ny] = radius
     sblend = d / d[-1]
@@ -945,8 +950,10 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
     def pid(i, j, k):
         return (np.asarray(i) % nx) + nx * (np.asarray(j) + (ny + 1) * np.asarray(k))
 
+    fold = naca_fold_table(nx) if fold_seam else np.arange(nx)
+
     def cid(i, j, k):
-        return (np.asarray(i) % nx) + nx * (np.asarray(j) + ny * np.asarray(k))
+        return fold[np.asarray(i) % nx] + nx * (np.asarray(j) + ny * np.asarray(k))
 
     points = np.zeros((nx * (ny + 1) * (nz + 1), 3))
     swept = (sweep_deg != 0.0) or (taper != 0.0)
@@ -1017,7 +1024,7 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
     # frozen wall distance: of an extrusion it is the section's, layer by layer (the symmetry planes are no walls) - `y_wall_section`
     # (n_around * n_normal values of the one-layer case) saves the nearest-wall search over all cells of the extruded mesh
     if y_wall_section is not None:
-        assert len(y_wall_section) == nx * ny
+        assert len(y_wall_section) == nx * ny  # (a section generated with the same fold_seam: the tile keeps the numbering)
         y = np.tile(np.asarray(y_wall_section, dtype=float), nz)
         if swept:  # the near field of layer k is the section scaled by its chord: so is the distance to the wall (frozen input of the SA model)
             zc = 0.5 * (zs[:-1] + zs[1:])
@@ -1057,6 +1064,22 @@ def naca0012_case(n_around=800, n_normal=250, nz=1, radius=20.0, span=0.1, first
     return case
 
 
+def naca_fold_table(nx):
+    """fold[i] = number of ring position i in the seam-folded numbering 0, n-1, 1, n-2, ... (naca0012_case(fold_seam=True))."""
+    i = np.arange(nx)
+    return np.where(i < (nx + 1) // 2, 2 * i, 2 * (nx - 1 - i) + 1)
+
+
+def naca_ring_position(cell_ids, nx, fold_seam=False):
+    """Position around the section (0 ... nx-1, lower side first) of the cells with the given ids."""
+    r = np.asarray(cell_ids) % nx
+    if not fold_seam:
+        return r
+    inv = np.empty(nx, dtype=np.int64)
+    inv[naca_fold_table(nx)] = np.arange(nx)
+    return inv[r]
+
+
 def naca_fluxes_from_velocity(case: FoamCase, U):
     """phi of every face from cell velocities: linear interpolation on internal faces, the boundary value of the patch
     condition on the rest (wall 0, far field: the owner cell / free stream by flow direction, symmetry 0)."""
@@ -1075,7 +1098,7 @@ def naca_fluxes_from_velocity(case: FoamCase, U):
     return phi
 
 
-def prolong_naca_state(coarse_dims, coarse_states, fine_case: FoamCase, fine_dims, first_cell=2.0e-5, radius=20.0, coarse_first_cell=None):
+def prolong_naca_state(coarse_dims, coarse_states, fine_case: FoamCase, fine_dims, first_cell=2.0e-5, radius=20.0, coarse_first_cell=None, fold_seam=False):
     """Cell fields of a 2-D (one spanwise layer) NACA0012 O-grid solution interpolated to a finer O-grid of the same family
     (grid sequencing of the primal: the reference users start a fine case from `mapFields` of a coarse one).  Bilinear in
     (contour parameter, wall distance along the ray); phi is rebuilt from the interpolated velocity."""
@@ -1096,10 +1119,16 @@ def prolong_naca_state(coarse_dims, coarse_states, fine_case: FoamCase, fine_dim
     i0m, i1m = i0 % nxc, (i0 + 1) % nxc
     j1 = np.minimum(j0 + 1, nyc - 1)
 
-    def interp(fc):                                                     # fc[(nyc, nxc)] -> (nyf, nxf)
+    foldc = naca_fold_table(nxc) if fold_seam else np.arange(nxc)      # ring position -> column of the coarse arrays
+    foldf = naca_fold_table(nxf) if fold_seam else np.arange(nxf)
+
+    def interp(fc):                                                     # fc[(nyc, nxc)] -> (nyf, nxf), both in their cell numbering
+        fc = fc[:, foldc]                                               # columns in ring order
         a = fc[j0][:, i0m] * (1 - wi)[None, :] + fc[j0][:, i1m] * wi[None, :]
         b = fc[j1][:, i0m] * (1 - wi)[None, :] + fc[j1][:, i1m] * wi[None, :]
-        return a * (1 - wj)[:, None] + b * wj[:, None]
+        out = np.empty((nyf, nxf))
+        out[:, foldf] = a * (1 - wj)[:, None] + b * wj[:, None]
+        return out
 
     Wc = np.asarray(coarse_states)
     Uc = Wc[: 3 * Nc].reshape(nyc, nxc, 3)

@@ -49,7 +49,7 @@ def naca_converged_primal(n_around=800, n_normal=250, options=None, first_cell=2
         t0 = time.time()
         case = naca0012_case(nx, ny, 1, first_cell=fc, **ckw)
         if W_prev is not None:
-            case.states = prolong_naca_state(levels[li - 1], W_prev, case, (nx, ny), first_cell=fc, coarse_first_cell=fcs[li - 1])
+            case.states = prolong_naca_state(levels[li - 1], W_prev, case, (nx, ny), first_cell=fc, coarse_first_cell=fcs[li - 1], fold_seam=bool(ckw.get("fold_seam", False)))
         opts = dict(options or {})
         opts["amd"] = dict(opts.get("amd", {}), **(NACA_PRIMAL_AMD if W_prev is None else NACA_PRIMAL_AMD_FINE))
         D = PYDAFOAM(options=opts, case=case)

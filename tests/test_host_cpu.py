@@ -254,6 +254,46 @@ def test_simple_sweep_bodies_equal_the_oracle_simple_iteration():
                 assert relerr(out[sl], oracle_states[ns][sl]) < 1e-10, (nm, ns)
 
 
+def test_seam_folded_cell_numbering_is_the_same_mesh_and_keeps_the_grid_sequencing_helpers_consistent():
+    """Round 6 (naca0012_case(fold_seam=True), bench.py --naca-fold): the O-grid with the ring positions numbered 0, n-1, 1, n-2, ... - the
+    same cells, geometry and state as the plain numbering under the permutation naca_ring_position decodes; ring neighbours are at most
+    two ids apart (plain numbering: n - 1 across the seam); prolongation and extrusion commute with the permutation; the residual of the
+    oracle is the same numbers."""
+    from dafoam_amd.meshgen import _InputGeometry, extrude_naca_state, naca0012_case, naca_ring_position, prolong_naca_state
+
+    nx, ny = 24, 8
+    c0 = naca0012_case(nx, ny, 1, first_cell=1e-3, perturb=0.0)
+    c1 = naca0012_case(nx, ny, 1, first_cell=1e-3, perturb=0.0, fold_seam=True)
+    N = c0.mesh.n_cells
+    ids = np.arange(N)
+    old = naca_ring_position(ids, nx, True) + nx * (ids // nx)             # cell of c0 that cell `ids` of c1 is
+    g0, g1 = _InputGeometry(c0.mesh), _InputGeometry(c1.mesh)
+    assert np.abs(g1.C - g0.C[old]).max() < 1e-13 and np.abs(g1.V - g0.V[old]).max() < 1e-14
+    assert np.allclose(c1.states[3 * N : 4 * N], c0.states[3 * N : 4 * N][old], rtol=0, atol=1e-13)
+    nIF = c1.mesh.n_internal_faces
+    ring = (c1.mesh.owner[:nIF] // nx) == (c1.mesh.neighbour // nx)
+    assert np.abs(c1.mesh.owner[:nIF][ring].astype(int) - c1.mesh.neighbour[ring].astype(int)).max() <= 2
+    ring0 = (c0.mesh.owner[:nIF] // nx) == (c0.mesh.neighbour // nx)
+    assert np.abs(c0.mesh.owner[:nIF][ring0].astype(int) - c0.mesh.neighbour[ring0].astype(int)).max() == nx - 1
+    R0 = residual(c0, Geometry(c0.mesh), c0.states)
+    R1 = residual(c1, Geometry(c1.mesh), c1.states)
+    assert relerr(R1[3 * N : 4 * N], R0[3 * N : 4 * N][old]) < 1e-11 and relerr(R1[: 3 * N].reshape(N, 3), R0[: 3 * N].reshape(N, 3)[old]) < 1e-11
+    # grid sequencing: coarse folded -> fine folded equals the plain prolongation, permuted
+    f0 = naca0012_case(2 * nx, 2 * ny, 1, first_cell=5e-4, perturb=0.0)
+    f1 = naca0012_case(2 * nx, 2 * ny, 1, first_cell=5e-4, perturb=0.0, fold_seam=True)
+    P0 = prolong_naca_state((nx, ny), c0.states, f0, (2 * nx, 2 * ny), first_cell=5e-4, coarse_first_cell=1e-3)
+    P1 = prolong_naca_state((nx, ny), c1.states, f1, (2 * nx, 2 * ny), first_cell=5e-4, coarse_first_cell=1e-3, fold_seam=True)
+    Nf = f0.mesh.n_cells
+    idf = np.arange(Nf)
+    oldf = naca_ring_position(idf, 2 * nx, True) + 2 * nx * (idf // (2 * nx))
+    assert np.allclose(P1[3 * Nf : 4 * Nf], P0[3 * Nf : 4 * Nf][oldf], rtol=0, atol=1e-12)
+    assert np.allclose(P1[: 3 * Nf].reshape(Nf, 3), P0[: 3 * Nf].reshape(Nf, 3)[oldf], rtol=0, atol=1e-12)
+    # extrusion keeps the numbering layer by layer
+    e1 = naca0012_case(nx, ny, 3, span=0.3, first_cell=1e-3, perturb=0.0, fold_seam=True, y_wall_section=c1.y_wall)
+    W3 = extrude_naca_state(c1, c1.states, e1, (nx, ny, 3))
+    assert np.array_equal(W3[3 * 3 * N : 4 * 3 * N], np.tile(c1.states[3 * N : 4 * N], 3))
+
+
 def test_additive_schwarz_overlap_mask_of_a_rank():
     """Round 6: the sub-domain of a rank under adjEqnOption.asmOverlap (dafoam_amd.distributed.overlap_mask; reference PCASMSetOverlap,
     DALinearEqn.C:212-216) on the slab partition of the channel: overlap 0 = the owned unknowns; overlap k = owned + the states anchored at
