@@ -870,9 +870,11 @@ def psi_parity_200k(a, dev_index, case2d=None):
 
         o10 = make_opts(a, dev_index, 1000, 1000, a.parity_tol)
         if case2d is None:
-            case2d, _ = naca_converged_primal(a.naca[0], a.naca[1], options=o10, first_cell=a.naca_first_cell)
+            case2d, _ = naca_converged_primal(a.naca[0], a.naca[1], options=o10, first_cell=a.naca_first_cell, case_kwargs=({"fold_seam": True} if a.naca_fold else None))
         nzp = max(1, int(round(200000.0 / (a.naca[0] * a.naca[1]))))
-        case, _ = naca_extruded_case(case2d, (a.naca[0], a.naca[1]), nzp, dz=0.1, first_cell=a.naca_first_cell, options=o10) if nzp > 1 else (case2d, None)
+        # (the section arrives in the bench's cell numbering: the extrusion must use the same one)
+        case, _ = (naca_extruded_case(case2d, (a.naca[0], a.naca[1]), nzp, dz=0.1, first_cell=a.naca_first_cell, options=o10,
+                                      case_kwargs=({"fold_seam": True} if a.naca_fold else None)) if nzp > 1 else (case2d, None))
         what = f"NACA0012 wing section {a.naca[0]} x {a.naca[1]} x {nzp} (the bench's converged section, {nzp} spanwise layers of 0.1 chords: BASELINE configs[1] size)"
     else:
         case, what = bench_channel_case(100, 50, 40), "bump channel 100 x 50 x 40"
