@@ -139,6 +139,10 @@ def _worker_general(rank, world, port, q, kind="simple"):
             from dafoam_amd.meshgen import naca0012_case
 
             gcase = naca0012_case(16, 5, 8, span=0.8)
+        elif kind == "wing_columns":
+            from dafoam_amd.meshgen import naca0012_case
+
+            gcase = naca0012_case(16, 6, 4, span=0.4, fold_seam=True)
         else:
             gcase = renumber_case(channel_case(NX, NY, NZ, lengths=(2.0, 0.2, 0.2), grading_y=2.0, perturb=0.0), seed=11)
         NS = norm_states(gcase)
@@ -147,6 +151,24 @@ def _worker_general(rank, world, port, q, kind="simple"):
             layer = np.arange(gcase.mesh.n_cells, dtype=np.int64) // (16 * 5)
             assert np.allclose(gg.C[layer == 3][:, 2], gg.C[layer == 3][0, 2])  # the generator numbers the cells layer by layer
             part = (layer * world // 8).astype(np.int32)
+        elif kind == "wing_columns":
+            # round 6: what `bench.py --gpus N` does by default - the O-grid numbered across its seam (fold_seam), cut into blocks of the
+            # (around, wall-normal) index plane that keep whole spanwise columns of cells (bench.naca_partition decodes the ring position)
+            import sys
+
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bench import naca_partition
+            from dafoam_amd.meshgen import naca_ring_position
+
+            cid = np.arange(gcase.mesh.n_cells, dtype=np.int64)
+            part = naca_partition(cid, (16, 6, 4), world, "columns", fold=True)
+            assert np.unique(part).size == world
+            i, j = naca_ring_position(cid, 16, True), (cid // 16) % 6
+            for r in range(world):  # every rank: a rectangle of the index plane, all 4 layers of each of its columns
+                sel = part == r
+                cols = np.unique(i[sel] * 100 + j[sel])
+                assert sel.sum() == cols.size * 4
+                assert (i[sel].max() - i[sel].min() + 1) * (j[sel].max() - j[sel].min() + 1) == cols.size
         else:
             part = rcb_partition(gg.C, world)
         # the sub-meshes are extracted on rank 0 and scattered (what ShardedAdjointGeneral.scattered does)
@@ -183,7 +205,7 @@ def _worker_general(rank, world, port, q, kind="simple"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(2, "simple"), (4, "simple"), (4, "rho"), (2, "wing")])
+@pytest.mark.parametrize("world,kind", [(2, "simple"), (4, "simple"), (4, "rho"), (2, "wing"), (4, "wing_columns")])
 def test_general_partition_unstructured_mesh(world, kind):
     """Arbitrary (RCB) partition of a randomly renumbered mesh on 2 and 4 ranks, DASimpleFoam and DARhoSimpleFoam, and the NACA0012 wing cut
     into spanwise slabs of whole layers (what `bench.py --gpus N` does with its default workload, round 5): extract_submesh (on rank 0,
