@@ -84,6 +84,7 @@ def parse():
     ap.add_argument("--solve-restart", type=int, default=1000)
     ap.add_argument("--solve-rtol", type=float, default=1e-6, help="gmresRelTol of the solve to tolerance (default: the reference's 1e-6, pyDAFoam.py:526-548)")
     ap.add_argument("--solve-maxit", type=int, default=1000)
+    ap.add_argument("--rho-levels", type=int, default=1, help="DARhoSimpleFoam with --converge-primal: grid-sequencing levels of the primal (2: converge nx/2 x ny/2 x nz/2 first, prolong)")
     ap.add_argument("--converge-primal", action="store_true", help="converge the flow state with the GPU Newton-Krylov primal before the adjoint (opt-in: the adjoint's conditioning does not depend on it, DESIGN.md section 6b)")
     ap.add_argument("--coarse-agg", type=int, default=int(os.environ.get("DAS_BENCH_COARSE", -1)), help="two-level PC: aggregates (-1 auto, 0 off)")
     ap.add_argument("--coarse-mode", default=os.environ.get("DAS_BENCH_COARSE_MODE"), help="amd.pcCoarseMode additive | deflated (default: the library's, deflated)")
@@ -146,6 +147,10 @@ def make_opts(a, dev_index, restart, maxit, rtol):
                     **({"pcType": a.pctype} if a.pctype != "bilu" else {}), **({"pcFactorFP32": a.fp32_factor} if a.fp32_factor else {}),
                     **({"pcCoarseAggregates": a.coarse_agg} if a.coarse_agg != -1 else {}), **({"pcCoarseMode": a.coarse_mode} if a.coarse_mode else {}),
                     **({"gmresOrthogonalization": a.orth} if a.orth != "dcgs2" else {}), **({"pcUpwindBlend": float(a.pc_blend)} if a.pc_blend is not None else {}),
+                    # compressible solvers with --converge-primal: the cold-start settings that converge the bump channel from its smooth synthetic state
+                    # (round 6, profiles/r08d_*: CFL ramp from tau 0.1, growth 1.3, PC rebuilt every step, pseudo-time term on all rows: 6.6e7 -> 5e-2 in
+                    # 35 Newton steps at 100 k cells; switched evolution relaxation diverges there, the NACA cold-start settings stall)
+                    **({"primalTauMode": "ramp", "primalTau0": 0.1, "primalTauGrowth": 1.3, "primalPCLag": 1} if (a.solver != "DASimpleFoam" and getattr(a, "converge_primal", False)) else {}),
                     **_amd_overrides(a)),
         "amdDevice": dev_index,
     }
@@ -366,6 +371,16 @@ def main():
             from dafoam_amd.meshgen import naca0012_case
 
             case = naca0012_case(a.naca[0], a.naca[1], a.naca[2], span=a.naca_dz * a.naca[2], first_cell=a.naca_first_cell, fold_seam=a.naca_fold)
+        elif a.solver == "DARhoSimpleFoam" and a.converge_primal and a.rho_levels > 1:
+            # BASELINE configs[3] about a CONVERGED compressible primal: grid sequencing on the device (round 6)
+            from dafoam_amd.workloads import rho_channel_converged_primal
+
+            t0 = time.time()
+            case, lv = rho_channel_converged_primal(a.nx, a.ny, a.nz, options=opts, levels=a.rho_levels, verbose=bool(os.environ.get("DAS_BENCH_VERBOSE")),
+                                                    case_kwargs=dict(lengths=(2.0, 0.2, 0.2), grading_y=2.0))
+            primal = {"method": "pseudo-transient Newton-Krylov (das_solve_primal), grid sequencing on the bump channel: cold start by a CFL ramp on the coarsest level, "
+                                "prolonged starts with switched evolution relaxation", "levels": [{k: (list(v) if isinstance(v, tuple) else v) for k, v in r.items()} for r in lv],
+                      "seconds": time.time() - t0, "fail": int(lv[-1]["fail"]), "res0": lv[-1]["res0"], "res": lv[-1]["res"], "steps": lv[-1]["steps"]}
         elif a.solver != "DASimpleFoam":
             case = compressible_channel(a, a.nx)
         else:
@@ -610,7 +625,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ((f"BASELINE configs[{3 if a.solver == 'DARhoSimpleFoam' else 4}] family: {a.solver}+SA adjoint, {n_global}-cell bump channel ({ncell} cells per GPU, "
-                              f"{a.nx}x{a.ny}x{a.nz} per GPU, wall-normal grading; synthetic subsonic perfect-gas state p 101325 T 300" + (", one MRF zone with a rotating hub" if a.solver == "DATurboFoam" else "") + ")")
+                              f"{a.nx}x{a.ny}x{a.nz} per GPU, wall-normal grading; " + ("linearised about the compressible primal CONVERGED on the GPU (Newton-Krylov, grid sequencing; subsonic perfect gas, p 101325 T 300 at the boundaries; |R| = %.2e)" % primal_residual_norm if (a.converge_primal and a.solver == "DARhoSimpleFoam") else "synthetic subsonic perfect-gas state p 101325 T 300") + (", one MRF zone with a rotating hub" if a.solver == "DATurboFoam" else "") + ")")
                              if a.solver != "DASimpleFoam" else
                              f"BASELINE configs[2]: DASimpleFoam+SA adjoint, {ncell}-cell hex mesh per GPU ({a.nx}x{a.ny}x{a.nz} bump channel, wall-normal "
                              f"grading; state: prolonged converged coarse primal)" if a.workload != "naca" else
@@ -650,7 +665,7 @@ def main():
                 "asm_overlap": (int(getattr(sharded, "asm_overlap", 0)) if sharded is not None else None),
                 "pc_stability": pc_stab,
                 "pc_upwind_blend": D.getOption("amd")["pcUpwindBlend"],
-                "pc_options_passed_by_bench": sorted(k for k in make_opts(a, dev_index, 1, 1, 1e-6)["amd"] if k != "maxKrylovBytes"),
+                "pc_options_passed_by_bench": sorted(k for k in make_opts(a, dev_index, 1, 1, 1e-6)["amd"] if k != "maxKrylovBytes" and not k.startswith("primal")),
                 "coarse_ms": L.das_timer_avg_ms(h, b"coarse"),
                 "halo_ms": L.das_timer_avg_ms(h, b"halo") if world > 1 else None,
                 # adjoint setup (what the reference does between the primal and the Krylov solve) vs. building the synthetic input

@@ -807,6 +807,54 @@ def rho_channel_case(nx=7, ny=7, nz=7, lengths=(1.0, 0.2, 0.1), U0=50.0, p0=1013
     return case
 
 
+def prolong_rho_channel_state(case: FoamCase, dims, coarse):
+    """Compressible twin of prolong_channel_state: the cell fields [U | p | T | nuTilda] of a converged coarse DARhoSimpleFoam channel
+    solution `coarse` = dict(dims, W) of the SAME geometry interpolated tri-linearly in logical block coordinates; the mass flux is rebuilt
+    as interpolate(rho) interpolate(U).Sf with rho = p / (R T) (grid sequencing of the compressible primal, round 6)."""
+    from scipy.interpolate import RegularGridInterpolator
+
+    nx, ny, nz = dims
+    cx, cy, cz = [int(v) for v in coarse["dims"]]
+    Wc = np.asarray(coarse["W"])
+    Nc = cx * cy * cz
+    xs, ys, zs = _logical_centres(cx, cy, cz)
+    xf, yf, zf = _logical_centres(nx, ny, nz)
+    X, Y, Z = np.meshgrid(xf, yf, zf, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+
+    def field(v):
+        a = v.reshape(cz, cy, cx).transpose(2, 1, 0)
+        f = RegularGridInterpolator((xs, ys, zs), a, bounds_error=False, fill_value=None)
+        return f(pts).reshape(nx, ny, nz).transpose(2, 1, 0).ravel()
+
+    U = np.stack([field(Wc[k : 3 * Nc : 3]) for k in range(3)], 1)
+    p = field(Wc[3 * Nc : 4 * Nc])
+    T = field(Wc[4 * Nc : 5 * Nc])
+    nt = np.maximum(field(Wc[5 * Nc : 6 * Nc]), 1e-12)
+    mesh = case.mesh
+    g = _InputGeometry(mesh)
+    R = 8314.47 / case.thermo["molWeight"]
+    rho = p / (R * T)
+    nIF = mesh.n_internal_faces
+    own, nei = mesh.owner, mesh.neighbour
+    w = g.w[:, None]
+    Uf = w * U[own[:nIF]] + (1 - w) * U[nei]
+    rhof = g.w * rho[own[:nIF]] + (1 - g.w) * rho[nei]
+    phi = np.zeros(mesh.n_faces)
+    phi[:nIF] = rhof * np.einsum("ij,ij->i", Uf, g.Sf[:nIF])
+    for pt in mesh.patches:
+        sl = slice(pt.start, pt.start + pt.size)
+        code, val = case.bcs[pt.name]["U"]
+        if code == BC_FIXED_VALUE:
+            phi[sl] = rho[own[sl]] * (g.Sf[sl] @ np.asarray(val, dtype=float))
+        elif code == BC_SYMMETRY:
+            phi[sl] = 0.0
+        else:
+            phi[sl] = rho[own[sl]] * np.einsum("ij,ij->i", U[own[sl]], g.Sf[sl])
+    case.states = np.concatenate([U.ravel(), p, T, nt, phi])
+    return case
+
+
 def simple_T_channel_case(nx=7, ny=7, nz=7, T0=300.0, **kw) -> FoamCase:
     """DASimpleFoam + SA with the optional passive T field (reference DAResidualSimpleFoam.C:215-235): the incompressible
     channel plus a smooth temperature field; fixedValue T at the inlet, inletOutlet at the outlet, hot bottom wall."""

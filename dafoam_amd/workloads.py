@@ -99,3 +99,41 @@ def naca_extruded_case(case2d, dims2d, nz, dz=0.1, first_cell=2.0e-5, options=No
     if verbose:
         print(f"[naca primal] extruded {nx} x {ny} x {nz}: {info}", flush=True)
     return case3, info
+
+
+# compressible bump channel (BASELINE configs[3] family), round 6: cold start by a CFL ramp from a small pseudo-time step with the
+# preconditioner rebuilt every step (switched evolution relaxation diverges from the smooth synthetic state, the NACA cold-start settings
+# stall: profiles/r07s_*, r07t_*, r08d_*), finer levels from the prolonged coarse solution with switched evolution relaxation
+RHO_PRIMAL_AMD_COLD = {"primalTauMode": "ramp", "primalTau0": 0.1, "primalTauGrowth": 1.3, "primalPCLag": 1, "primalPseudoTimeFields": "all"}
+RHO_PRIMAL_AMD_FINE = {"primalTauMode": "ser", "primalTau0": 1.0, "primalSERExponent": 1.5, "primalPCLag": 1, "primalPseudoTimeFields": "all"}
+
+
+def rho_channel_converged_primal(nx, ny, nz, options=None, levels=2, rel_tol=1e-8, max_steps=100, verbose=False, case_kwargs=None):
+    """Converged DARhoSimpleFoam + SA state on the nx x ny x nz bump channel by grid sequencing: the coarsest level (every dimension halved
+    `levels - 1` times) from the smooth synthetic state with the cold-start settings, every finer level from the prolonged solution.
+    Returns (case, info) like naca_converged_primal."""
+    from .meshgen import prolong_rho_channel_state, rho_channel_case
+    from .pyDAFoam import PYDAFOAM
+
+    ckw = dict(case_kwargs or {})
+    dims = [(max(4, nx >> (levels - 1 - l)), max(4, ny >> (levels - 1 - l)), max(4, nz >> (levels - 1 - l))) for l in range(levels)]
+    prev, info, case = None, [], None
+    for li, d in enumerate(dims):
+        t0 = time.time()
+        case = rho_channel_case(*d, **ckw)
+        if prev is not None:
+            prolong_rho_channel_state(case, d, prev)
+        opts = dict(options or {})
+        opts["amd"] = dict(opts.get("amd", {}), **(RHO_PRIMAL_AMD_COLD if prev is None else RHO_PRIMAL_AMD_FINE))
+        D = PYDAFOAM(options=opts, case=case)
+        fail, inf = D.solver.solvePrimal(maxSteps=max_steps, relTol=rel_tol, absTol=0.0)
+        W = D.getStates().copy()
+        case.states = W
+        prev = {"dims": d, "W": W}
+        rec = dict(dims=d, steps=inf["steps"], linearIterations=inf["linearIterations"], res0=inf["res0"], res=inf["res"], fail=int(fail), seconds=time.time() - t0)
+        info.append(rec)
+        if verbose:
+            print(f"[rho primal] level {d}: {rec['steps']} Newton steps, {rec['linearIterations']} GMRES iterations, |R| {rec['res0']:.3e} -> {rec['res']:.3e}, "
+                  f"{rec['seconds']:.1f} s, fail {rec['fail']}", flush=True)
+        del D
+    return case, info

@@ -107,3 +107,21 @@ def test_compressible_solvers_are_launchable_through_the_bench(solver):
         assert solver in c["workload"] and d["n_gpus"] == nranks and d["value"] > 0 and d["roofline"]["frac"] > 0
         assert c["global_cells"] == 20 * nranks * 12 * 8 and c["states_per_gpu"] >= 9 * c["cells_per_gpu"]
         assert c["psi_parity_200k"] is None or "skipped" in c["psi_parity_200k"]
+
+
+def test_compressible_bench_about_a_primal_converged_by_grid_sequencing():
+    """Round 6: BASELINE configs[3] about a CONVERGED compressible primal - `bench.py --solver DARhoSimpleFoam
+    --converge-primal --rho-levels 2`: the coarse bump channel from its smooth synthetic state with the cold-start settings (CFL ramp, PC
+    rebuilt every step), the fine level from the prolonged solution; then the adjoint converges inside the reference's budget."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    args = ["bench.py", "--solver", "DARhoSimpleFoam", "--converge-primal", "--rho-levels", "2", "--nx", "32", "--ny", "16", "--nz", "12", "--steps", "5", "--warmup", "3",
+            "--no-cpu", "--no-parity", "--krylov-gb", "2"]
+    out = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    c = d["config"]
+    pk = c["primal_newton_krylov"]
+    assert [lv["dims"] for lv in pk["levels"]] == [[16, 8, 6], [32, 16, 12]] and all(lv["fail"] == 0 for lv in pk["levels"])
+    assert pk["levels"][-1]["res"] <= 1e-7 * pk["levels"][0]["res0"]
+    assert "CONVERGED" in c["workload"] and c["solve"]["fail"] == 0 and c["solve"]["rel_residual"] <= 2e-6 and c["solve"]["iterations"] < 1000
+
