@@ -2174,7 +2174,8 @@ static double pc_stability_estimate(das_solver* s, das_ksp* k, NodeILU& F, const
 // transport information well or badly, depending on the direction the elimination crosses them - round 6: 403 k-cell wing on 8 ranks, outer
 // blocks next to the wake: 1e8 ... 1e27 in one order, 1e2 in another; 2 M cells on 4 ranks: 691 iterations with the smallest-estimate
 // orders, > 1000 with reverse Cuthill-McKee everywhere); otherwise the first candidate below the limit.  Local to the rank: no collective.
-static void choose_order_and_factorise(das_solver* s, das_ksp* k, NodeILU& F, const std::vector<unsigned char>& mask, bool pickMin, int& orderUsed, double& estimate) {
+static void choose_order_and_factorise(das_solver* s, das_ksp* k, NodeILU& F, const std::vector<unsigned char>& mask, bool pickMin, int& orderUsed, double& estimate,
+                                       bool earlyAccept = true) {
     const int configured = k->pcOrder >= 0 ? k->pcOrder : (pc_ordering_rcm(s) ? 1 : 0);
     const double limit = s->opt.getd("amd.pcStabilityLimit");
     if (!(limit > 0.0)) {
@@ -2213,7 +2214,9 @@ static void choose_order_and_factorise(das_solver* s, das_ksp* k, NodeILU& F, co
         // (a DEEP order is never accepted early: levels >> nodes^(1/3) - e.g. reverse Cuthill-McKee of a thin far-field block, 23755 levels
         //  for 270 k nodes where ~500 are normal)
         const bool deep = (double)F.nLevels > 30.0 * std::cbrt((double)std::max(1, F.nNodes));
-        if (est <= limit && (!pickMin || (est <= good && !deep))) break;
+        // (earlyAccept false - the sub-domains of a multi-rank solve: every candidate is evaluated; 403 k cells on 8 ranks: 722 iterations, with the
+        //  early accept 867)
+        if (est <= limit && (!pickMin || (earlyAccept && est <= good && !deep))) break;
     }
     bool anyOk = false;
     for (const Cand& c : seen) anyOk = anyOk || c.est <= limit;
@@ -5363,7 +5366,7 @@ int das_create_ml_rksp_matrix_free(das_solver_t* s, das_mat_t* pc, das_ksp_t** k
         if (!(K > 1 && setup_subdomain_ilus(s, k.get(), (int)K))) {
             const double t0 = wall_seconds();
             // a sub-domain of a multi-rank solve takes the elimination order with the smallest estimate, one rank alone the first stable one
-            choose_order_and_factorise(s, k.get(), k->bilu, (s->pcMask.empty() || k->pcTranspose) ? s->owned : s->pcMask, !s->owned.empty(), k->pcOrderUsed, k->pcStability);
+            choose_order_and_factorise(s, k.get(), k->bilu, (s->pcMask.empty() || k->pcTranspose) ? s->owned : s->pcMask, !s->owned.empty(), k->pcOrderUsed, k->pcStability, /*earlyAccept*/ s->owned.empty());
             if (k->pcOrderUsed >= 0) k->pcOrder = k->pcOrderUsed;
             k->useBilu = true;
             k->rasOverlap = !s->pcMask.empty() && !k->pcTranspose && s->halo.ovActive;
