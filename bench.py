@@ -233,6 +233,11 @@ def _amd_overrides(a):
 
 def main():
     a = parse()
+    if os.environ.get("DAS_BENCH_FAULT_DUMP"):
+        # diagnosis of a stalled multi-rank run: every rank dumps its Python stacks to stderr after this many seconds (and keeps running)
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["DAS_BENCH_FAULT_DUMP"]), repeat=False, exit=False)
     import torch
     import torch.distributed as dist
 
