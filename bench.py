@@ -248,6 +248,11 @@ def main():
     # debugging aids for boxes with a single GPU (never set by the driver): all ranks on device 0, host-staged gloo
     backend = os.environ.get("DAS_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("DAS_BENCH_ONE_GPU") == "1" else local_rank
+    if os.environ.get("DAS_BENCH_ONE_GPU") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # several ranks share ONE device (the 1-GPU test box): the per-XCD ticket counters of the preconditioner sweeps assume that a launch has
+        # workgroups resident on every XCD - true for one process per GPU, not when eight processes compete for the compute units (round 6: an 8-rank
+        # run at 2 M cells stalled with one rank's stream never finishing).  The device-wide counter needs no residency assumption.
+        os.environ.setdefault("DAS_BILU_XCD", "0")
     torch.cuda.set_device(dev_index)
     if world > 1:
         import datetime

@@ -210,6 +210,11 @@ def install_comm(obj, native=None):
         return
     nS, nR = int(sendOff[-1]), int(recvOff[-1])
     stage = dist.get_backend() == "gloo"
+    if stage:
+        # gloo with device tensors = several ranks sharing ONE GPU (the 1-GPU test box): the per-XCD ticket counters of the preconditioner
+        # sweeps assume workgroups of a launch resident on every XCD - not guaranteed when several processes compete for the compute units
+        # (round 6: 8 ranks at 2 M cells stalled in 3 of 5 runs, 0 of 3 with the device-wide counter); read at the next factorisation
+        os.environ.setdefault("DAS_BILU_XCD", "0")
 
     def exch_cb(ps, pr, _user):
         torch.cuda.current_stream(obj.dev).synchronize()
