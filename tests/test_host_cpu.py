@@ -294,6 +294,39 @@ def test_seam_folded_cell_numbering_is_the_same_mesh_and_keeps_the_grid_sequenci
     assert np.array_equal(W3[3 * 3 * N : 4 * 3 * N], np.tile(c1.states[3 * N : 4 * N], 3))
 
 
+def test_compressible_channel_prolongation_is_consistent():
+    """Round 6 (grid sequencing of the DARhoSimpleFoam primal, dafoam_amd.meshgen.prolong_rho_channel_state): a coarse state prolonged to a
+    mesh of the SAME size reproduces the cell fields; to a finer mesh it keeps their ranges, and the rebuilt mass flux is
+    interpolate(rho) interpolate(U).Sf - on a uniform state exactly rho U.Sf on the internal faces."""
+    from dafoam_amd.meshgen import _InputGeometry, prolong_rho_channel_state, rho_channel_case
+
+    kw = dict(lengths=(2.0, 0.2, 0.2), grading_y=2.0)
+    c = rho_channel_case(6, 4, 4, **kw)
+    same = rho_channel_case(6, 4, 4, **kw)
+    prolong_rho_channel_state(same, (6, 4, 4), {"dims": (6, 4, 4), "W": c.states})
+    N = c.mesh.n_cells
+    assert np.allclose(same.states[: 6 * N], c.states[: 6 * N], rtol=1e-12, atol=1e-12)
+    f = rho_channel_case(12, 8, 8, **kw)
+    prolong_rho_channel_state(f, (12, 8, 8), {"dims": (6, 4, 4), "W": c.states})
+    Nf = f.mesh.n_cells
+    for b in (3, 4, 5):  # p, T, nuTilda: finite, positive, within one coarse range of the coarse extremes (the outermost half cells extrapolate linearly)
+        lo, hi = c.states[b * N : (b + 1) * N].min(), c.states[b * N : (b + 1) * N].max()
+        v = f.states[b * Nf : (b + 1) * Nf]
+        assert np.all(np.isfinite(v)) and v.min() > 0.0 and v.min() >= lo - (hi - lo) - 1e-9 * abs(lo) and v.max() <= hi + (hi - lo) + 1e-9 * abs(hi)
+    u = rho_channel_case(5, 4, 3, **kw)
+    Nu = u.mesh.n_cells
+    W = u.states.copy()
+    W[: 3 * Nu] = np.tile([30.0, 0.0, 0.0], Nu)
+    W[3 * Nu : 4 * Nu], W[4 * Nu : 5 * Nu] = 101325.0, 300.0
+    fu = rho_channel_case(10, 8, 6, **kw)
+    prolong_rho_channel_state(fu, (10, 8, 6), {"dims": (5, 4, 3), "W": W})
+    g = _InputGeometry(fu.mesh)
+    rho = 101325.0 / (8314.47 / fu.thermo["molWeight"] * 300.0)
+    nIF = fu.mesh.n_internal_faces
+    phi = fu.states[6 * fu.mesh.n_cells :]
+    assert np.allclose(phi[:nIF], rho * 30.0 * g.Sf[:nIF, 0], rtol=1e-12, atol=1e-12 * rho * 30.0 * np.abs(g.Sf[:, 0]).max())
+
+
 def test_additive_schwarz_overlap_mask_of_a_rank():
     """Round 6: the sub-domain of a rank under adjEqnOption.asmOverlap (dafoam_amd.distributed.overlap_mask; reference PCASMSetOverlap,
     DALinearEqn.C:212-216) on the slab partition of the channel: overlap 0 = the owned unknowns; overlap k = owned + the states anchored at
